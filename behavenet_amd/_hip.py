@@ -1,0 +1,304 @@
+"""ctypes binding of libbehavenet_hip.so (include/behavenet_hip.h).
+
+This module is the only place where Python touches the C ABI.  It hands over raw device
+pointers (``tensor.data_ptr()``) and the current HIP stream; PyTorch is used for device memory
+and streams only.  There is NO fallback: if the library is missing, or a tensor is not a
+contiguous fp32 device tensor, the call raises.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_LIB_NAME = 'libbehavenet_hip.so'
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+_lib = None
+
+ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
+
+PROF_NONE, PROF_CONV_FWD, PROF_CONV_BWD_D, PROF_CONV_BWD_W = 0, 1, 2, 3
+PROF_CONVT_FWD, PROF_CONVT_BWD_D, PROF_CONVT_BWD_W, PROF_ADAM = 4, 5, 6, 7
+
+_c_int, _c_float, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+_CONV_GEOM = [_c_int] * 12
+
+# name -> (restype, argtypes); mirrors include/behavenet_hip.h one to one
+SIGNATURES = {
+    'bn_version': (_c_int, []),
+    'bn_build_arch': (ctypes.c_char_p, []),
+    'bn_error_string': (ctypes.c_char_p, [_c_int]),
+    'bn_conv2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
+    'bn_conv2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
+    'bn_conv2d_bwd_weight_ws_bytes': (_c_size_t, _CONV_GEOM),
+    'bn_conv2d_bwd_weight': (
+        _c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_void_p, _c_size_t, _c_void_p]),
+    'bn_convT2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
+    'bn_convT2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
+    'bn_convT2d_bwd_weight_ws_bytes': (_c_size_t, _CONV_GEOM),
+    'bn_convT2d_bwd_weight': (
+        _c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_void_p, _c_size_t, _c_void_p]),
+    'bn_act_bwd': (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_int, _c_float, _c_void_p]),
+    'bn_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p]),
+    'bn_linear_bwd': (
+        _c_int, [_c_void_p] * 5 + [_c_int, _c_float, _c_void_p, _c_void_p, _c_int] +
+        [_c_int] * 3 + [_c_void_p]),
+    'bn_sqerr_frame_sums': (_c_int, [_c_void_p] * 4 + [_c_int, _c_size_t, _c_void_p]),
+    'bn_sqerr_bwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_float, _c_void_p, _c_void_p]),
+    'bn_reduce_sum': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_float, _c_void_p]),
+    'bn_reparam_fwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
+    'bn_kl_rows': (_c_int, [_c_void_p] * 3 + [_c_int, _c_int, _c_void_p]),
+    'bn_reparam_bwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
+    'bn_kl_bwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_float, _c_void_p, _c_void_p]),
+    'bn_adam_amsgrad_step': (
+        _c_int, [_c_void_p] * 5 + [_c_size_t] + [_c_float] * 5 + [_c_int, _c_void_p]),
+    'bn_u8_to_unit_float': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_void_p]),
+    'bn_prof_select': (_c_int, [_c_int] * 3),
+    'bn_prof_read': (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
+    'bn_prof_kernel_name': (ctypes.c_char_p, []),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load(required=True):
+    """Load the shared library (once).  Raises if it is missing and ``required``."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        if required:
+            raise HipLibraryError(
+                '%s not found next to the package (%s). Build it with '
+                '`python -c "import __graft_entry__ as g; g.build()"` or '
+                '`make -C behavenet_amd/csrc`. There is no CPU fallback.' % (_LIB_NAME, _LIB_PATH))
+        return None
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().bn_error_string(int(rc))
+        raise HipLibraryError('%s failed: %s (code %d)' % (what, msg.decode() if msg else '?', rc))
+
+
+def _ptr(t, name, dtype=torch.float32, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise HipLibraryError('%s: tensor is None' % name)
+    if not t.is_cuda:
+        raise HipLibraryError(
+            '%s: expected a tensor on the GPU, got device %s (the HIP path has no CPU fallback)'
+            % (name, t.device))
+    if t.dtype != dtype:
+        raise HipLibraryError('%s: expected dtype %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise HipLibraryError('%s: tensor must be contiguous' % name)
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------
+# convolution roles.  geom = (N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q) for conv and
+# (N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo) for convT -- the header's order.
+# ------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only scratch arena per device (never shrinks, reused across calls on one stream)."""
+    if nbytes == 0:
+        return None
+    buf = _ws_cache.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[device] = buf
+    return buf
+
+
+def conv2d_fwd(x, w, b, geom, act, slope):
+    N, C, H, W, K, R, S, st, pt, pl, P, Q = geom
+    y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
+    _check(load().bn_conv2d_fwd(
+        _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), *geom,
+        act, slope, _stream()), 'bn_conv2d_fwd')
+    return y
+
+
+def conv2d_bwd_data(dy, w, geom, dact_src, dact, slope):
+    N, C, H, W = geom[:4]
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    _check(load().bn_conv2d_bwd_data(
+        _ptr(dy, 'dy'), _ptr(w, 'w'), _ptr(dx, 'dx'), _ptr(dact_src, 'dact_src', allow_none=True),
+        *geom, dact, slope, _stream()), 'bn_conv2d_bwd_data')
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, dw, db, geom, accumulate):
+    lib = load()
+    nbytes = lib.bn_conv2d_bwd_weight_ws_bytes(*geom)
+    ws = _workspace(nbytes, x.device)
+    _check(lib.bn_conv2d_bwd_weight(
+        _ptr(x, 'x'), _ptr(dy, 'dy'), _ptr(dw, 'dw'), _ptr(db, 'db', allow_none=True), *geom,
+        int(accumulate), ws.data_ptr() if ws is not None else None, nbytes, _stream()),
+        'bn_conv2d_bwd_weight')
+
+
+def convT2d_fwd(x, w, b, geom, act, slope):
+    N, Ci, Hi, Wi, Co, R, S, st, ct, cl, Ho, Wo = geom
+    y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+    _check(load().bn_convT2d_fwd(
+        _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), *geom,
+        act, slope, _stream()), 'bn_convT2d_fwd')
+    return y
+
+
+def convT2d_bwd_data(dy, w, geom, dact_src, dact, slope):
+    N, Ci, Hi, Wi = geom[:4]
+    dx = torch.empty((N, Ci, Hi, Wi), dtype=torch.float32, device=dy.device)
+    _check(load().bn_convT2d_bwd_data(
+        _ptr(dy, 'dy'), _ptr(w, 'w'), _ptr(dx, 'dx'), _ptr(dact_src, 'dact_src', allow_none=True),
+        *geom, dact, slope, _stream()), 'bn_convT2d_bwd_data')
+    return dx
+
+
+def convT2d_bwd_weight(x, dy, dw, db, geom, accumulate):
+    lib = load()
+    nbytes = lib.bn_convT2d_bwd_weight_ws_bytes(*geom)
+    ws = _workspace(nbytes, x.device)
+    _check(lib.bn_convT2d_bwd_weight(
+        _ptr(x, 'x'), _ptr(dy, 'dy'), _ptr(dw, 'dw'), _ptr(db, 'db', allow_none=True), *geom,
+        int(accumulate), ws.data_ptr() if ws is not None else None, nbytes, _stream()),
+        'bn_convT2d_bwd_weight')
+
+
+def act_bwd(dy, y, act, slope, out=None):
+    if out is None:
+        out = torch.empty_like(dy)
+    _check(load().bn_act_bwd(
+        _ptr(dy, 'dy'), _ptr(y, 'y'), _ptr(out, 'dpre'), dy.numel(), act, slope, _stream()),
+        'bn_act_bwd')
+    return out
+
+
+def linear_fwd(x, w, b):
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _check(load().bn_linear_fwd(
+        _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), M, K, N,
+        _stream()), 'bn_linear_fwd')
+    return y
+
+
+def linear_bwd(x, w, dy, need_dx, dact_src, dact, slope, dw, db, accumulate):
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), dtype=torch.float32, device=dy.device) if need_dx else None
+    _check(load().bn_linear_bwd(
+        _ptr(x, 'x', allow_none=True), _ptr(w, 'w'), _ptr(dy, 'dy'),
+        _ptr(dx, 'dx', allow_none=True), _ptr(dact_src, 'dact_src', allow_none=True), dact, slope,
+        _ptr(dw, 'dw', allow_none=True), _ptr(db, 'db', allow_none=True), int(accumulate),
+        M, K, N, _stream()), 'bn_linear_bwd')
+    return dx
+
+
+def sqerr_frame_sums(pred, target, mask):
+    N = pred.shape[0]
+    D = pred.numel() // N
+    out = torch.empty((N,), dtype=torch.float32, device=pred.device)
+    _check(load().bn_sqerr_frame_sums(
+        _ptr(pred, 'pred'), _ptr(target, 'target'), _ptr(mask, 'mask', allow_none=True),
+        _ptr(out, 'frame_sums'), N, D, _stream()), 'bn_sqerr_frame_sums')
+    return out
+
+
+def sqerr_bwd(pred, target, mask, scale, gscale):
+    dpred = torch.empty_like(pred)
+    _check(load().bn_sqerr_bwd(
+        _ptr(pred, 'pred'), _ptr(target, 'target'), _ptr(mask, 'mask', allow_none=True),
+        _ptr(dpred, 'dpred'), pred.numel(), float(scale), _ptr(gscale, 'gscale', allow_none=True),
+        _stream()), 'bn_sqerr_bwd')
+    return dpred
+
+
+def reduce_sum(t, scale=1.0):
+    out = torch.empty((), dtype=torch.float32, device=t.device)
+    _check(load().bn_reduce_sum(_ptr(t, 'in'), _ptr(out, 'out'), t.numel(), float(scale),
+                                _stream()), 'bn_reduce_sum')
+    return out
+
+
+def reparam_fwd(mu, logvar, eps):
+    z = torch.empty_like(mu)
+    _check(load().bn_reparam_fwd(
+        _ptr(mu, 'mu'), _ptr(logvar, 'logvar'), _ptr(eps, 'eps'), _ptr(z, 'z'), mu.numel(),
+        _stream()), 'bn_reparam_fwd')
+    return z
+
+
+def kl_rows(mu, logvar):
+    N, D = mu.shape
+    out = torch.empty((N,), dtype=torch.float32, device=mu.device)
+    _check(load().bn_kl_rows(_ptr(mu, 'mu'), _ptr(logvar, 'logvar'), _ptr(out, 'kl_rows'), N, D,
+                             _stream()), 'bn_kl_rows')
+    return out
+
+
+def reparam_bwd(dz, z, mu):
+    dlogvar = torch.empty_like(mu)
+    _check(load().bn_reparam_bwd(
+        _ptr(dz, 'dz'), _ptr(z, 'z'), _ptr(mu, 'mu'), _ptr(dlogvar, 'dlogvar'), mu.numel(),
+        _stream()), 'bn_reparam_bwd')
+    return dlogvar
+
+
+def kl_bwd(mu, logvar, scale, gscale):
+    dmu, dlogvar = torch.empty_like(mu), torch.empty_like(mu)
+    _check(load().bn_kl_bwd(
+        _ptr(mu, 'mu'), _ptr(logvar, 'logvar'), _ptr(dmu, 'dmu'), _ptr(dlogvar, 'dlogvar'),
+        mu.numel(), float(scale), _ptr(gscale, 'gscale', allow_none=True), _stream()),
+        'bn_kl_bwd')
+    return dmu, dlogvar
+
+
+def adam_amsgrad_step(p, g, m, v, vmax, lr, beta1, beta2, eps, weight_decay, step):
+    _check(load().bn_adam_amsgrad_step(
+        _ptr(p, 'p'), _ptr(g, 'g'), _ptr(m, 'm'), _ptr(v, 'v'), _ptr(vmax, 'vmax'), p.numel(),
+        lr, beta1, beta2, eps, weight_decay, int(step), _stream()), 'bn_adam_amsgrad_step')
+
+
+def u8_to_unit_float(u8):
+    out = torch.empty(u8.shape, dtype=torch.float32, device=u8.device)
+    _check(load().bn_u8_to_unit_float(
+        _ptr(u8, 'in', dtype=torch.uint8), _ptr(out, 'out'), u8.numel(), _stream()),
+        'bn_u8_to_unit_float')
+    return out
+
+
+def prof_select(family, C=0, K=0):
+    _check(load().bn_prof_select(family, C, K), 'bn_prof_select')
+
+
+def prof_read():
+    ms, n = ctypes.c_double(0.0), ctypes.c_long(0)
+    _check(load().bn_prof_read(ctypes.byref(ms), ctypes.byref(n)), 'bn_prof_read')
+    name = load().bn_prof_kernel_name()
+    return ms.value, n.value, (name.decode() if name else '')

@@ -1,0 +1,51 @@
+// Internal launcher prototypes (one per kernel family); implemented in the .hip files,
+// dispatched from capi.hip.
+#pragma once
+#include "bn_common.h"
+
+struct GemmArgs {
+    const float* A; long sai, sak;
+    const float* B; long sbk, sbj;
+    float* C; long sci, scj;
+    int M, N, K;               // C is M x N, reduction length K
+    const float* bias_j;       // nullable, added per column j
+    const float* dact_src;     // nullable, same layout as C
+    int dact; float slope;
+    int accumulate;
+};
+
+// conv_generic.hip
+int bn_launch_down_generic(const float* big, const float* w, const float* bias, float* out,
+                           const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                           hipStream_t st);
+int bn_launch_up_generic(const float* small, const float* w, const float* bias, float* out,
+                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                         hipStream_t st);
+int bn_launch_wgrad_generic(const float* small, const float* big, float* dw, const BnGeom& g,
+                            int accumulate, hipStream_t st);
+int bn_launch_channel_sum(const float* t, float* db, int N, int C, int npix, int accumulate,
+                          hipStream_t st);
+
+// gemm.hip
+int bn_launch_gemm(const GemmArgs& a, hipStream_t st);
+int bn_launch_col_sum(const float* dy, float* db, int M, int N, int accumulate, hipStream_t st);
+
+// elementwise.hip
+int bn_launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, float slope,
+                      hipStream_t st);
+int bn_launch_sqerr_frame_sums(const float* pred, const float* target, const float* mask,
+                               float* frame_sums, int N, size_t D, hipStream_t st);
+int bn_launch_sqerr_bwd(const float* pred, const float* target, const float* mask, float* dpred,
+                        size_t n, float scale, const float* gscale, hipStream_t st);
+int bn_launch_reduce_sum(const float* in, float* out, size_t n, float scale, hipStream_t st);
+int bn_launch_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z,
+                          size_t n, hipStream_t st);
+int bn_launch_kl_rows(const float* mu, const float* logvar, float* kl_rows, int N, int D,
+                      hipStream_t st);
+int bn_launch_reparam_bwd(const float* dz, const float* z, const float* mu, float* dlogvar,
+                          size_t n, hipStream_t st);
+int bn_launch_kl_bwd(const float* mu, const float* logvar, float* dmu, float* dlogvar, size_t n,
+                     float scale, const float* gscale, hipStream_t st);
+int bn_launch_adam(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
+                   float b1, float b2, float eps, float wd, int step, hipStream_t st);
+int bn_launch_u8_to_unit_float(const unsigned char* in, float* out, size_t n, hipStream_t st);

@@ -1,0 +1,365 @@
+// extern "C" surface of libbehavenet_hip.so (include/behavenet_hip.h): argument checks, the
+// mapping of the six convolution roles onto the three kernel families, fast-path dispatch and
+// the hipEvent profiling hook.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include "bn_common.h"
+#include "bn_launch.h"
+#include "bn_fast.h"
+
+// ------------------------------------------------------------------------------------------
+// profiling hook
+// ------------------------------------------------------------------------------------------
+namespace {
+struct ProfState {
+    int family = BN_PROF_NONE;
+    int C = 0, K = 0;
+    static const int kMaxPairs = 4096;
+    hipEvent_t ev[2 * kMaxPairs];
+    int created = 0;
+    int used = 0;          // pairs recorded since the last read/reset
+    double total_ms = 0.0;
+    long launches = 0;
+    char kernel_name[96] = "";
+} g_prof;
+
+void prof_drain() {
+    for (int i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) == hipSuccess) {
+            g_prof.total_ms += ms;
+            g_prof.launches += 1;
+        }
+    }
+    g_prof.used = 0;
+}
+}  // namespace
+
+BnProfScope::BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s)
+    : active(false), stream(s), e0(nullptr), e1(nullptr) {
+    if (g_prof.family == BN_PROF_NONE || g_prof.family != family) return;
+    if (g_prof.C > 0 && g_prof.C != C) return;
+    if (g_prof.K > 0 && g_prof.K != K) return;
+    if (g_prof.used >= ProfState::kMaxPairs) prof_drain();
+    const int i = g_prof.used;
+    while (g_prof.created <= 2 * i + 1) {
+        if (hipEventCreate(&g_prof.ev[g_prof.created]) != hipSuccess) return;
+        g_prof.created++;
+    }
+    e0 = g_prof.ev[2 * i];
+    e1 = g_prof.ev[2 * i + 1];
+    if (kernel_name) {
+        strncpy(g_prof.kernel_name, kernel_name, sizeof(g_prof.kernel_name) - 1);
+        g_prof.kernel_name[sizeof(g_prof.kernel_name) - 1] = 0;
+    }
+    if (hipEventRecord(e0, stream) != hipSuccess) return;
+    active = true;
+}
+
+BnProfScope::~BnProfScope() {
+    if (!active) return;
+    if (hipEventRecord(e1, stream) == hipSuccess) g_prof.used++;
+}
+
+extern "C" int bn_prof_select(int family, int C, int K) {
+    if (family < BN_PROF_NONE || family > BN_PROF_ADAM) return BN_E_BADARG;
+    g_prof.family = family;
+    g_prof.C = C;
+    g_prof.K = K;
+    g_prof.used = 0;
+    g_prof.total_ms = 0.0;
+    g_prof.launches = 0;
+    g_prof.kernel_name[0] = 0;
+    return 0;
+}
+
+extern "C" int bn_prof_read(double* total_ms, long* launches) {
+    if (!total_ms || !launches) return BN_E_BADARG;
+    prof_drain();
+    *total_ms = g_prof.total_ms;
+    *launches = g_prof.launches;
+    return 0;
+}
+
+extern "C" const char* bn_prof_kernel_name(void) { return g_prof.kernel_name; }
+
+// ------------------------------------------------------------------------------------------
+// info
+// ------------------------------------------------------------------------------------------
+extern "C" int bn_version(void) { return 1; }
+extern "C" const char* bn_build_arch(void) { return "gfx950"; }
+extern "C" const char* bn_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case BN_E_BADARG: return "BN_E_BADARG: null pointer or non-positive size";
+        case BN_E_SHAPE: return "BN_E_SHAPE: geometry not supported";
+        case BN_E_WORKSPACE: return "BN_E_WORKSPACE: workspace too small";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown error";
+}
+
+// ------------------------------------------------------------------------------------------
+// convolution roles -> kernel families
+// ------------------------------------------------------------------------------------------
+static inline BnGeom conv_geom(int N, int C, int H, int W, int K, int R, int S, int stride,
+                               int pad_t, int pad_l, int P, int Q) {
+    BnGeom g;
+    g.N = N; g.Cs = K; g.Hs = P; g.Ws = Q; g.Cb = C; g.Hb = H; g.Wb = W;
+    g.R = R; g.S = S; g.stride = stride; g.pt = pad_t; g.pl = pad_l;
+    return g;
+}
+static inline BnGeom convT_geom(int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
+                                int crop_t, int crop_l, int Ho, int Wo) {
+    BnGeom g;
+    g.N = N; g.Cs = Ci; g.Hs = Hi; g.Ws = Wi; g.Cb = Co; g.Hb = Ho; g.Wb = Wo;
+    g.R = R; g.S = S; g.stride = stride; g.pt = crop_t; g.pl = crop_l;
+    return g;
+}
+
+static int run_down(int family, const float* big, const float* w, const float* bias, float* out,
+                    const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                    hipStream_t st) {
+    const char* name = "k_down_generic";
+    const bool fast = bn_fast_down_supported(g, &name);
+    BnProfScope prof(family, g.Cb, g.Cs, name, st);
+    if (fast) return bn_launch_down_fast(big, w, bias, out, dact_src, g, act, dact, slope, st);
+    return bn_launch_down_generic(big, w, bias, out, dact_src, g, act, dact, slope, st);
+}
+
+static int run_up(int family, const float* small, const float* w, const float* bias, float* out,
+                  const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                  hipStream_t st) {
+    const char* name = "k_up_generic";
+    const bool fast = bn_fast_up_supported(g, &name);
+    BnProfScope prof(family, g.Cs, g.Cb, name, st);
+    if (fast) return bn_launch_up_fast(small, w, bias, out, dact_src, g, act, dact, slope, st);
+    return bn_launch_up_generic(small, w, bias, out, dact_src, g, act, dact, slope, st);
+}
+
+static int run_wgrad(int family, const float* small, const float* big, float* dw,
+                     const BnGeom& g, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    const char* name = "k_wgrad_generic";
+    const bool fast = bn_fast_wgrad_supported(g, &name);
+    BnProfScope prof(family, g.Cb, g.Cs, name, st);
+    if (fast) {
+        if (ws_bytes < bn_fast_wgrad_ws_bytes(g) || (!ws && bn_fast_wgrad_ws_bytes(g) > 0))
+            return BN_E_WORKSPACE;
+        return bn_launch_wgrad_fast(small, big, dw, g, accumulate, ws, st);
+    }
+    return bn_launch_wgrad_generic(small, big, dw, g, accumulate, st);
+}
+
+extern "C" int bn_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int N,
+                             int C, int H, int W, int K, int R, int S, int stride, int pad_t,
+                             int pad_l, int P, int Q, int act, float slope, bn_stream_t stream) {
+    if (!x || !w || !y) return BN_E_BADARG;
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    return run_down(BN_PROF_CONV_FWD, x, w, b, y, nullptr, g, act, BN_ACT_NONE, slope,
+                    (hipStream_t)stream);
+}
+
+extern "C" int bn_conv2d_bwd_data(const float* dy, const float* w, float* dx,
+                                  const float* dact_src, int N, int C, int H, int W, int K, int R,
+                                  int S, int stride, int pad_t, int pad_l, int P, int Q, int dact,
+                                  float slope, bn_stream_t stream) {
+    if (!dy || !w || !dx) return BN_E_BADARG;
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    return run_up(BN_PROF_CONV_BWD_D, dy, w, nullptr, dx, dact_src, g, BN_ACT_NONE, dact, slope,
+                  (hipStream_t)stream);
+}
+
+extern "C" size_t bn_conv2d_bwd_weight_ws_bytes(int N, int C, int H, int W, int K, int R, int S,
+                                                int stride, int pad_t, int pad_l, int P, int Q) {
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g)) return 0;
+    const char* name = nullptr;
+    return bn_fast_wgrad_supported(g, &name) ? bn_fast_wgrad_ws_bytes(g) : 0;
+}
+
+extern "C" int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N,
+                                    int C, int H, int W, int K, int R, int S, int stride,
+                                    int pad_t, int pad_l, int P, int Q, int accumulate, void* ws,
+                                    size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !dy || !dw) return BN_E_BADARG;
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = run_wgrad(BN_PROF_CONV_BWD_W, dy, x, dw, g, accumulate, ws, ws_bytes, st);
+    if (rc) return rc;
+    if (db) rc = bn_launch_channel_sum(dy, db, N, K, P * Q, accumulate, st);
+    return rc;
+}
+
+extern "C" int bn_convT2d_fwd(const float* x, const float* w, const float* b, float* y, int N,
+                              int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
+                              int crop_t, int crop_l, int Ho, int Wo, int act, float slope,
+                              bn_stream_t stream) {
+    if (!x || !w || !y) return BN_E_BADARG;
+    const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    return run_up(BN_PROF_CONVT_FWD, x, w, b, y, nullptr, g, act, BN_ACT_NONE, slope,
+                  (hipStream_t)stream);
+}
+
+extern "C" int bn_convT2d_bwd_data(const float* dy, const float* w, float* dx,
+                                   const float* dact_src, int N, int Ci, int Hi, int Wi, int Co,
+                                   int R, int S, int stride, int crop_t, int crop_l, int Ho,
+                                   int Wo, int dact, float slope, bn_stream_t stream) {
+    if (!dy || !w || !dx) return BN_E_BADARG;
+    const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    return run_down(BN_PROF_CONVT_BWD_D, dy, w, nullptr, dx, dact_src, g, BN_ACT_NONE, dact, slope,
+                    (hipStream_t)stream);
+}
+
+extern "C" size_t bn_convT2d_bwd_weight_ws_bytes(int N, int Ci, int Hi, int Wi, int Co, int R,
+                                                 int S, int stride, int crop_t, int crop_l,
+                                                 int Ho, int Wo) {
+    const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
+    if (!bn_geom_ok(g)) return 0;
+    const char* name = nullptr;
+    return bn_fast_wgrad_supported(g, &name) ? bn_fast_wgrad_ws_bytes(g) : 0;
+}
+
+extern "C" int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N,
+                                     int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
+                                     int crop_t, int crop_l, int Ho, int Wo, int accumulate,
+                                     void* ws, size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !dy || !dw) return BN_E_BADARG;
+    const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = run_wgrad(BN_PROF_CONVT_BWD_W, x, dy, dw, g, accumulate, ws, ws_bytes, st);
+    if (rc) return rc;
+    if (db) rc = bn_launch_channel_sum(dy, db, N, Co, Ho * Wo, accumulate, st);
+    return rc;
+}
+
+extern "C" int bn_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act,
+                          float slope, bn_stream_t stream) {
+    if (!dy || !y || !dpre) return BN_E_BADARG;
+    if (n == 0) return 0;
+    return bn_launch_act_bwd(dy, y, dpre, n, act, slope, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// linear
+// ------------------------------------------------------------------------------------------
+extern "C" int bn_linear_fwd(const float* x, const float* w, const float* b, float* y, int M,
+                             int K, int N, bn_stream_t stream) {
+    if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return BN_E_BADARG;
+    GemmArgs a;
+    a.A = x; a.sai = K; a.sak = 1;
+    a.B = w; a.sbk = 1; a.sbj = K;
+    a.C = y; a.sci = N; a.scj = 1;
+    a.M = M; a.N = N; a.K = K;
+    a.bias_j = b; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f; a.accumulate = 0;
+    return bn_launch_gemm(a, (hipStream_t)stream);
+}
+
+extern "C" int bn_linear_bwd(const float* x, const float* w, const float* dy, float* dx,
+                             const float* dact_src, int dact, float slope, float* dw, float* db,
+                             int accumulate, int M, int K, int N, bn_stream_t stream) {
+    if (!dy || M <= 0 || K <= 0 || N <= 0) return BN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 0;
+    if (dx) {
+        if (!w) return BN_E_BADARG;
+        GemmArgs a;                       // dx[m,k] = sum_n dy[m,n] w[n,k]
+        a.A = dy; a.sai = N; a.sak = 1;
+        a.B = w; a.sbk = K; a.sbj = 1;
+        a.C = dx; a.sci = K; a.scj = 1;
+        a.M = M; a.N = K; a.K = N;
+        a.bias_j = nullptr; a.dact_src = dact_src; a.dact = dact; a.slope = slope;
+        a.accumulate = 0;
+        rc = bn_launch_gemm(a, st);
+        if (rc) return rc;
+    }
+    if (dw) {
+        if (!x) return BN_E_BADARG;
+        GemmArgs a;                       // dw[n,k] = sum_m dy[m,n] x[m,k]
+        a.A = dy; a.sai = 1; a.sak = N;
+        a.B = x; a.sbk = K; a.sbj = 1;
+        a.C = dw; a.sci = K; a.scj = 1;
+        a.M = N; a.N = K; a.K = M;
+        a.bias_j = nullptr; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f;
+        a.accumulate = accumulate;
+        rc = bn_launch_gemm(a, st);
+        if (rc) return rc;
+    }
+    if (db) rc = bn_launch_col_sum(dy, db, M, N, accumulate, st);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// losses / variational tail / optimiser / input conversion
+// ------------------------------------------------------------------------------------------
+extern "C" int bn_sqerr_frame_sums(const float* pred, const float* target, const float* mask,
+                                   float* frame_sums, int N, size_t D, bn_stream_t stream) {
+    if (!pred || !target || !frame_sums || N <= 0 || D == 0) return BN_E_BADARG;
+    return bn_launch_sqerr_frame_sums(pred, target, mask, frame_sums, N, D, (hipStream_t)stream);
+}
+
+extern "C" int bn_sqerr_bwd(const float* pred, const float* target, const float* mask,
+                            float* dpred, size_t n, float scale, const float* gscale,
+                            bn_stream_t stream) {
+    if (!pred || !target || !dpred) return BN_E_BADARG;
+    if (n == 0) return 0;
+    return bn_launch_sqerr_bwd(pred, target, mask, dpred, n, scale, gscale, (hipStream_t)stream);
+}
+
+extern "C" int bn_reduce_sum(const float* in, float* out, size_t n, float scale,
+                             bn_stream_t stream) {
+    if (!in || !out) return BN_E_BADARG;
+    return bn_launch_reduce_sum(in, out, n, scale, (hipStream_t)stream);
+}
+
+extern "C" int bn_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z,
+                              size_t n, bn_stream_t stream) {
+    if (!mu || !logvar || !eps || !z) return BN_E_BADARG;
+    if (n == 0) return 0;
+    return bn_launch_reparam_fwd(mu, logvar, eps, z, n, (hipStream_t)stream);
+}
+
+extern "C" int bn_kl_rows(const float* mu, const float* logvar, float* kl_rows, int N, int D,
+                          bn_stream_t stream) {
+    if (!mu || !logvar || !kl_rows || N <= 0 || D <= 0) return BN_E_BADARG;
+    return bn_launch_kl_rows(mu, logvar, kl_rows, N, D, (hipStream_t)stream);
+}
+
+extern "C" int bn_reparam_bwd(const float* dz, const float* z, const float* mu, float* dlogvar,
+                              size_t n, bn_stream_t stream) {
+    if (!dz || !z || !mu || !dlogvar) return BN_E_BADARG;
+    if (n == 0) return 0;
+    return bn_launch_reparam_bwd(dz, z, mu, dlogvar, n, (hipStream_t)stream);
+}
+
+extern "C" int bn_kl_bwd(const float* mu, const float* logvar, float* dmu, float* dlogvar,
+                         size_t n, float scale, const float* gscale, bn_stream_t stream) {
+    if (!mu || !logvar || !dmu || !dlogvar) return BN_E_BADARG;
+    if (n == 0) return 0;
+    return bn_launch_kl_bwd(mu, logvar, dmu, dlogvar, n, scale, gscale, (hipStream_t)stream);
+}
+
+extern "C" int bn_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
+                                    size_t n, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, int step, bn_stream_t stream) {
+    if (!p || !g || !m || !v || !vmax || step < 1) return BN_E_BADARG;
+    if (n == 0) return 0;
+    BnProfScope prof(BN_PROF_ADAM, 0, 0, "k_adam_amsgrad", (hipStream_t)stream);
+    return bn_launch_adam(p, g, m, v, vmax, n, lr, beta1, beta2, eps, weight_decay, step,
+                          (hipStream_t)stream);
+}
+
+extern "C" int bn_u8_to_unit_float(const unsigned char* in, float* out, size_t n,
+                                   bn_stream_t stream) {
+    if (!in || !out) return BN_E_BADARG;
+    if (n == 0) return 0;
+    return bn_launch_u8_to_unit_float(in, out, n, (hipStream_t)stream);
+}

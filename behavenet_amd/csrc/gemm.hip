@@ -1,0 +1,99 @@
+// Dense latent projections on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate,
+// bit-identical to an fmaf chain).  One strided kernel serves nn.Linear forward, its data
+// gradient and its weight gradient:   C[i,j] (+)= epi( sum_k A(i,k) * B(k,j) ).
+//
+// Lane mapping (cdna_hip_programming.md section 3): lane l feeds A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; accumulator register t of lane l is C[(t&3)+8*(t>>2)+4*(l>>5)][l&31].
+// The latent GEMMs are skinny (N=12..64 or K=12..64), so a workgroup owns one 32x32 output tile
+// and its SPLITK waves split the reduction dimension, combined in fixed order through LDS.
+#include "bn_common.h"
+#include "bn_launch.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+
+template <int SPLITK>
+__global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
+    __shared__ float red[SPLITK > 1 ? SPLITK * 16 * 64 : 1];
+    const int lane = threadIdx.x & 63;
+    const int ws = threadIdx.x >> 6;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int li = lane & 31, lk = lane >> 5;
+
+    // this wave's slice of the reduction dimension (even length so k pairs stay aligned)
+    int kper = (a.K + SPLITK - 1) / SPLITK;
+    kper = (kper + 1) & ~1;
+    const int kbeg = ws * kper;
+    const int kend = min(a.K, kbeg + kper);
+
+    const int ia = i0 + li, jb = j0 + li;
+    const bool a_ok = ia < a.M, b_ok = jb < a.N;
+    const float* ap = a.A + (long)(a_ok ? ia : 0) * a.sai;
+    const float* bp = a.B + (long)(b_ok ? jb : 0) * a.sbj;
+
+    floatx16 acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+
+    for (int k = kbeg + lk; k < kend + lk; k += 2) {
+        const bool k_ok = k < kend;
+        const float av = (a_ok && k_ok) ? ap[(long)k * a.sak] : 0.f;
+        const float bv = (b_ok && k_ok) ? bp[(long)k * a.sbk] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+
+    if (SPLITK > 1) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) red[(ws * 16 + t) * 64 + lane] = acc[t];
+        __syncthreads();
+        if (ws != 0) return;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            float s = red[t * 64 + lane];
+            for (int w2 = 1; w2 < SPLITK; ++w2) s += red[(w2 * 16 + t) * 64 + lane];
+            acc[t] = s;
+        }
+    }
+
+    const int j = j0 + (lane & 31);
+    if (j >= a.N) return;
+    const float bj = a.bias_j ? a.bias_j[j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int i = i0 + (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5);
+        if (i >= a.M) continue;
+        const long off = (long)i * a.sci + (long)j * a.scj;
+        float v = acc[t] + bj;
+        if (a.dact_src) v *= bn_act_grad_from_output(a.dact_src[off], a.dact, a.slope);
+        a.C[off] = a.accumulate ? a.C[off] + v : v;
+    }
+}
+
+// db[n] (+)= sum_m dy[m,n]   (dy row-major M x N); one wave per column
+__global__ __launch_bounds__(64) void k_col_sum(const float* __restrict__ dy,
+                                                float* __restrict__ db, int M, int N,
+                                                int accumulate) {
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int m = threadIdx.x; m < M; m += 64) acc += dy[(size_t)m * N + n];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (threadIdx.x == 0) db[n] = accumulate ? db[n] + acc : acc;
+}
+
+int bn_launch_gemm(const GemmArgs& a, hipStream_t st) {
+    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
+    if (a.K >= 512) {
+        hipLaunchKernelGGL(k_gemm_mfma<8>, grid, dim3(512), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(k_gemm_mfma<1>, grid, dim3(64), 0, st, a);
+    }
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_launch_col_sum(const float* dy, float* db, int M, int N, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(k_col_sum, dim3(N), dim3(64), 0, st, dy, db, M, N, accumulate);
+    BN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,136 @@
+"""In-memory trial generator with the duck type ``fit()`` / ``export_latents`` consume.
+
+The reference's HDF5-backed ``ConcatSessionsGenerator`` (behavenet/data/data_generator.py:432-633)
+is I/O and out of scope for the kernels; what the hot path needs is its
+*interface*: ``n_datasets``, ``n_tot_batches[dtype]``, ``reset_iterators(dtype)``,
+``next_batch(dtype) -> (dict, int)`` with ``data[key]`` shaped ``(1, B, ...)`` and
+``datasets[i].{n_trials, batch_idxs, lab, expt, animal, session}``.  One batch = one trial.
+
+Frames are synthesised like the reference's integration test (tests/integration.py:105-109):
+``uint8`` noise, consumed as ``float32 / 255``.  Where the trial lives is a choice:
+
+* ``placement='host'``      -- float32 on the host, copied per batch (what the reference does,
+                              data_generator.py:251-263,630-631)
+* ``placement='device_u8'`` -- uint8 resident in HBM, converted per batch by a HIP kernel
+* ``placement='device'``    -- float32 resident in HBM (bench default: inputs already resident)
+"""
+
+import numpy as np
+import torch
+
+from behavenet_amd import _hip
+
+__all__ = ['split_trials', 'SyntheticSession', 'SyntheticSessionsGenerator']
+
+
+def split_trials(n_trials, rng_seed=0, train_tr=8, val_tr=1, test_tr=1, gap_tr=0):
+    """Blocks of ``train | gap | val | gap | test | gap`` trials (ref data_generator.py:42-134)."""
+    np.random.seed(rng_seed)
+    per_block = train_tr + val_tr + test_tr + 3 * gap_tr
+    n_blocks = n_trials // per_block
+    if n_blocks == 0:
+        raise ValueError(
+            'Not enough trials (n=%i) for the train/test/val/gap values %i/%i/%i/%i' %
+            (n_trials, train_tr, val_tr, test_tr, gap_tr))
+    leftover = n_trials - per_block * n_blocks
+    offset = np.random.randint(0, high=leftover) if leftover > 0 else 0
+    out = {'train': [], 'test': [], 'val': []}
+    for block in np.random.permutation(n_blocks):
+        cur = block * per_block + offset
+        out['train'].append(np.arange(cur, cur + train_tr))
+        cur += train_tr + gap_tr
+        out['val'].append(np.arange(cur, cur + val_tr))
+        cur += val_tr + gap_tr
+        out['test'].append(np.arange(cur, cur + test_tr))
+    return {k: np.concatenate(v, axis=0) for k, v in out.items()}
+
+
+class SyntheticSession(object):
+    """One session of synthetic trials (stands in for ``SingleSessionDatasetBatchedLoad``)."""
+
+    def __init__(self, n_trials, frames_per_trial, img_shape, seed=0, n_labels=0,
+                 trial_splits='8;1;1;0', rng_seed_data=0, name=('lab', 'expt', 'animal', 'sess')):
+        self.lab, self.expt, self.animal, self.session = name
+        self.n_trials = n_trials
+        rng = np.random.default_rng(seed)
+        if np.isscalar(frames_per_trial):
+            frames_per_trial = [int(frames_per_trial)] * n_trials
+        self.images_u8 = [
+            rng.integers(0, 255, size=(int(t),) + tuple(img_shape), dtype=np.uint8)
+            for t in frames_per_trial]
+        self.labels = None
+        if n_labels > 0:
+            self.labels = [rng.standard_normal((int(t), n_labels)).astype(np.float32)
+                           for t in frames_per_trial]
+        tr, va, te, gap = [int(v) for v in trial_splits.split(';')]
+        self.batch_idxs = split_trials(n_trials, rng_seed_data, tr, va, te, gap)
+        self.n_batches = {k: len(v) for k, v in self.batch_idxs.items()}
+
+
+class SyntheticSessionsGenerator(object):
+    """Serves one trial per ``next_batch`` call; sessions are drawn with ``np.random.choice``
+    and trials in ``torch.randperm`` order, so ``fit``'s per-epoch reseeding controls both."""
+
+    _dtypes = ['train', 'val', 'test']
+
+    def __init__(self, sessions, device='cuda', placement='device'):
+        if placement not in ('host', 'device_u8', 'device'):
+            raise ValueError('unknown placement "%s"' % placement)
+        self.datasets = list(sessions)
+        self.n_datasets = len(self.datasets)
+        self.device = device
+        self.placement = placement
+        self.n_tot_batches = {
+            k: sum(ds.n_batches[k] for ds in self.datasets) for k in self._dtypes}
+        tot = float(sum(ds.n_batches['train'] for ds in self.datasets))
+        self.batch_ratios = [ds.n_batches['train'] / tot for ds in self.datasets]
+        self._store = []
+        for ds in self.datasets:
+            trials = []
+            for u8 in ds.images_u8:
+                if placement == 'host':
+                    t = torch.from_numpy(u8.astype(np.float32) / 255)
+                    if device == 'cuda':
+                        t = t.pin_memory()
+                elif placement == 'device_u8':
+                    t = torch.from_numpy(u8).to(device)
+                else:
+                    t = torch.from_numpy(u8.astype(np.float32) / 255).to(device)
+                trials.append(t)
+            labels = None
+            if ds.labels is not None:
+                labels = [torch.from_numpy(l).to(device) for l in ds.labels]
+            self._store.append((trials, labels))
+        self._queues = [{k: [] for k in self._dtypes} for _ in self.datasets]
+        for k in self._dtypes:
+            self.reset_iterators(k)
+
+    def __len__(self):
+        return self.n_datasets
+
+    def reset_iterators(self, dtype):
+        kinds = self._dtypes if dtype == 'all' else [dtype]
+        for i, ds in enumerate(self.datasets):
+            for k in kinds:
+                idxs = ds.batch_idxs[k]
+                order = torch.randperm(len(idxs)).tolist()
+                self._queues[i][k] = [int(idxs[j]) for j in order]
+
+    def next_batch(self, dtype):
+        if all(len(q[dtype]) == 0 for q in self._queues):
+            return None, None
+        while True:
+            sess = int(np.random.choice(np.arange(self.n_datasets), p=self.batch_ratios))
+            if self._queues[sess][dtype]:
+                trial = self._queues[sess][dtype].pop(0)
+                break
+        trials, labels = self._store[sess]
+        img = trials[trial]
+        if self.placement == 'host':
+            img = img.to(self.device, non_blocking=True)
+        elif self.placement == 'device_u8':
+            img = _hip.u8_to_unit_float(img)
+        sample = {'images': img[None], 'batch_idx': torch.tensor([trial])}
+        if labels is not None:
+            sample['labels'] = labels[trial][None]
+        return sample, sess

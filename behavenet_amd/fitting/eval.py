@@ -1,0 +1,95 @@
+"""Inference-only encode of every trial -> ``*_latents.pkl`` (BASELINE config 5).
+
+Mirror of ``export_latents`` in the reference ``behavenet/fitting/eval.py:6-118``: same pickle
+schema ``{'latents': [per-trial (T x D) arrays, empty for gap trials], 'trials': batch_idxs}``
+and file name ``<lab>_<expt>_<animal>_<session>_latents.pkl`` so the ARHMM stage can read it.
+Differences below the surface: runs under ``torch.no_grad()`` (the reference builds an unused
+graph), accepts device-resident ``uint8`` frames (converted by ``bn_u8_to_unit_float``), and
+under ``torch.distributed`` shards trials round-robin over ranks and gathers on rank 0.
+"""
+
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from behavenet_amd import _hip
+from behavenet_amd.fitting import distributed as bdist
+
+__all__ = ['export_latents', 'encode_trial']
+
+
+def encode_trial(model, y, sess=None, labels_2d=None, chunk_size=200):
+    """Latents (T x D numpy) of one trial, encoded in 200-frame chunks (ref eval.py:51-97)."""
+    mc = model.hparams['model_class']
+    if y.dtype == torch.uint8:
+        y = _hip.u8_to_unit_float(y.contiguous())
+    n = y.shape[0]
+    parts = []
+    with torch.no_grad():
+        for beg in range(0, n, chunk_size):
+            end = min(beg + chunk_size, n)
+            y_in = y[beg:end]
+            if labels_2d is not None:
+                y_in = torch.cat((y_in, labels_2d[beg:end]), dim=1)
+            out = model.encoding(y_in, dataset=sess)
+            if mc == 'ps-vae':
+                cur = torch.cat([out[0], out[1]], dim=1)
+            else:
+                cur = out[0]
+            if mc == 'cond-ae-msp':
+                cur = model.U(cur)
+            parts.append(cur)
+    return torch.cat(parts, dim=0).cpu().numpy()
+
+
+def export_latents(data_generator, model, filename=None):
+    """Encode train/val/test trials of every session and pickle them (ref eval.py:6-118)."""
+    if model.hparams['model_class'] == 'msps-vae':
+        return model.export_latents(data_generator, filename=filename)
+    model.eval()
+    rank, world = bdist.rank(), bdist.world_size()
+
+    latents = [[np.array([]) for _ in range(ds.n_trials)] for ds in data_generator.datasets]
+    cond_enc = model.hparams['model_class'] == 'cond-ae' and \
+        model.hparams.get('conditional_encoder', False)
+    counter = 0
+    for dtype in ['train', 'val', 'test']:
+        data_generator.reset_iterators(dtype)
+        for _ in range(data_generator.n_tot_batches[dtype]):
+            data, sess = data_generator.next_batch(dtype)
+            mine = (counter % world) == rank
+            counter += 1
+            if not mine:
+                continue
+            idx = data['batch_idx']
+            idx = idx.item() if hasattr(idx, 'item') else int(idx)
+            labels_2d = data['labels_sc'][0] if cond_enc else None
+            latents[sess][idx] = encode_trial(model, data['images'][0], sess, labels_2d)
+
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(latents, gathered, dst=0)
+        if rank != 0:
+            return []
+        for other in gathered[1:]:
+            for s, per_sess in enumerate(other):
+                for i, arr in enumerate(per_sess):
+                    if arr.size:
+                        latents[s][i] = arr
+
+    filenames = []
+    for sess, dataset in enumerate(data_generator.datasets):
+        if filename is None:
+            sess_id = '%s_%s_%s_%s_latents.pkl' % (
+                dataset.lab, dataset.expt, dataset.animal, dataset.session)
+            out = os.path.join(model.hparams['expt_dir'], 'version_%i' % model.version, sess_id)
+        else:
+            out = filename
+        print('saving latents %i of %i:\n%s' % (sess + 1, data_generator.n_datasets, out))
+        with open(out, 'wb') as f:
+            pickle.dump({'latents': latents[sess], 'trials': dataset.batch_idxs}, f)
+        filenames.append(out)
+    return filenames

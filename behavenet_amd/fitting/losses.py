@@ -1,0 +1,109 @@
+"""Loss terms of the autoencoder hot path, on the HIP kernels.
+
+Host-side mirror of the reference ``behavenet/fitting/losses.py`` (same function names,
+argument order and return conventions).  Inputs must be fp32 tensors on the GPU; there is no
+CPU implementation here (the CPU restatement used for checking lives in ``oracle/``).
+"""
+
+import numpy as np
+import torch
+
+from behavenet_amd import hip_functions as hf
+
+__all__ = [
+    'mse', 'gaussian_ll', 'gaussian_ll_to_mse', 'kl_div_to_std_normal', 'index_code_mi',
+    'total_correlation', 'dimension_wise_kl_to_std_normal', 'decomposed_kl', 'subspace_overlap']
+
+LN2PI = np.log(2 * np.pi)
+
+
+def mse(y_pred, y_true, masks=None):
+    """mean((y_pred - y_true)^2 [* masks]) over ALL elements (ref losses.py:36-59).
+
+    With a mask the divisor is still the element count, not the mask sum.
+    """
+    return hf.sq_err(y_pred, y_true, masks, 1.0 / y_pred.numel())
+
+
+def gaussian_ll(y_pred, y_mean, masks=None, std=1):
+    """Diagonal-Gaussian log-likelihood, summed over dims, averaged over frames (ref :62-96)."""
+    n_frames = y_pred.shape[0]
+    n_dims = int(np.prod(y_pred.shape[1:]))
+    log_var = np.log(std ** 2)
+    const = -(0.5 * LN2PI + 0.5 * log_var) * n_dims
+    return hf.sq_err(y_pred, y_mean, masks, -(0.5 / (std ** 2)) / n_frames) + float(const)
+
+
+def gaussian_ll_to_mse(ll, n_dims, gaussian_std=1, mse_std=1):
+    """Strip the Gaussian constants from a log-likelihood value (ref :99-127); host floats."""
+    llc = np.copy(ll)
+    llc += (0.5 * LN2PI + 0.5 * np.log(gaussian_std ** 2)) * n_dims
+    llc *= -(gaussian_std ** 2) / 0.5
+    llc /= n_dims
+    llc *= 1.0 / (mse_std ** 2)
+    return llc
+
+
+def kl_div_to_std_normal(mu, logvar):
+    """KL(N(mu, exp(logvar)) || N(0, 1)) summed over dims, averaged over frames (ref :130-147)."""
+    return hf.kl_to_std_normal(mu, logvar)
+
+
+# ------------------------------------------------------------------------------------------
+# beta-TC decomposition (ref :150-372).  N <= 200 frames x D <= 64 dims: the (N, N, D) pairwise
+# tensor is < 10 MB, launch-latency bound; expressed with device tensor ops (torch glue) until
+# the dedicated single-workgroup kernel lands (SURVEY.md section 2.1 "decomposed_kl").
+# ------------------------------------------------------------------------------------------
+def _gaussian_log_density_unsummed(z, mu, logvar):
+    return -0.5 * (torch.exp(-logvar) * (z - mu) ** 2 + logvar + LN2PI)
+
+
+def _gaussian_log_density_unsummed_std_normal(z):
+    return -0.5 * (z ** 2 + LN2PI)
+
+
+def _pairwise_log_q(z, mu, logvar):
+    # [j, i, l] = log q(z(x_j)_l | x_i)
+    return _gaussian_log_density_unsummed(z[:, None], mu[None, :], logvar[None, :])
+
+
+def index_code_mi(z, mu, logvar):
+    lq = _pairwise_log_q(z, mu, logvar)
+    joint = lq.sum(dim=2)
+    log_qz = torch.logsumexp(joint, dim=1)
+    log_qz_cond = torch.diag(joint)
+    return torch.mean(log_qz_cond - log_qz)
+
+
+def total_correlation(z, mu, logvar):
+    lq = _pairwise_log_q(z, mu, logvar)
+    log_qz_product = torch.logsumexp(lq, dim=1).sum(dim=1)
+    log_qz = torch.logsumexp(lq.sum(dim=2), dim=1)
+    return torch.mean(log_qz - log_qz_product)
+
+
+def dimension_wise_kl_to_std_normal(z, mu, logvar):
+    lq = _pairwise_log_q(z, mu, logvar)
+    log_qz_product = torch.logsumexp(lq, dim=1).sum(dim=1)
+    log_pz_product = _gaussian_log_density_unsummed_std_normal(z).sum(dim=1)
+    return torch.mean(log_qz_product - log_pz_product)
+
+
+def decomposed_kl(z, mu, logvar):
+    """(index-code MI, total correlation, dimension-wise KL) batch estimates (ref :284-351)."""
+    lq = _pairwise_log_q(z, mu, logvar)
+    joint = lq.sum(dim=2)
+    log_qz = torch.logsumexp(joint, dim=1)
+    log_qz_cond = torch.diag(joint)
+    log_qz_product = torch.logsumexp(lq, dim=1).sum(dim=1)
+    log_pz_product = _gaussian_log_density_unsummed_std_normal(z).sum(dim=1)
+    return (torch.mean(log_qz_cond - log_qz),
+            torch.mean(log_qz - log_qz_product),
+            torch.mean(log_qz_product - log_pz_product))
+
+
+def subspace_overlap(A, B, C=None):
+    """mean((U U^T - I)^2) for the stacked subspace bases (ref :375-399)."""
+    U = torch.cat([A, B] if C is None else [A, B, C], dim=0)
+    eye = torch.eye(U.shape[0], device=U.device)
+    return torch.mean((torch.matmul(U, U.t()) - eye).pow(2))

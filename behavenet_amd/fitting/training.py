@@ -1,0 +1,277 @@
+"""Training loop for the autoencoder hot path.
+
+Host-side mirror of the reference ``behavenet/fitting/training.py``: ``fit(hparams, model,
+data_generator, exp, method='ae')`` with the same duck-typed generator / experiment protocol,
+the same metric rows, early stopping and checkpoint files.  Differences, all below the
+reference's Python surface:
+
+* the optimizer is :class:`behavenet_amd.fitting.optim.FlatAdamAMSGrad` (one HIP launch);
+* with ``torch.distributed`` initialised, gradients are all-reduced over RCCL before each step;
+* ``model.loss`` synchronises with the host once per call instead of once per chunk.
+"""
+
+import copy
+import os
+
+import numpy as np
+import torch
+
+from behavenet_amd.fitting import distributed as bdist
+
+__all__ = ['Logger', 'EarlyStopping', 'fit']
+
+_PREFIX = {'train': 'tr', 'val': 'val', 'test': 'test'}
+
+
+class Logger(object):
+    """Accumulates every key of the loss dicts, in aggregate and per dataset (ref :16-170)."""
+
+    def __init__(self, n_datasets=1):
+        self.n_datasets = n_datasets
+        kinds = ['train', 'val', 'test', 'curr']
+        self.metrics = {k: {} for k in kinds}
+        self.metrics_by_dataset = []
+        if n_datasets > 1:
+            self.metrics_by_dataset = [{k: {} for k in kinds} for _ in range(n_datasets)]
+
+    def reset_metrics(self, dtype):
+        for key in self.metrics[dtype]:
+            self.metrics[dtype][key] = 0
+        for per in self.metrics_by_dataset:
+            for key in per[dtype]:
+                per[dtype][key] = 0
+
+    def update_metrics(self, dtype, loss_dict, dataset=None):
+        for key, val in {**loss_dict, 'batches': 1}.items():
+            self.metrics[dtype][key] = self.metrics[dtype].get(key, 0) + val
+            if isinstance(dataset, int) and self.n_datasets > 1:
+                per = self.metrics_by_dataset[dataset][dtype]
+                per[key] = per.get(key, 0) + val
+
+    def create_metric_row(
+            self, dtype, epoch, batch, dataset, trial, best_epoch=None, by_dataset=False):
+        if dtype not in _PREFIX:
+            raise ValueError("%s is an invalid data type" % dtype)
+        prefix = _PREFIX[dtype]
+        row = {'epoch': epoch, 'batch': batch, 'trial': trial}
+        if dtype == 'val':
+            row['best_val_epoch'] = best_epoch
+        if by_dataset and self.n_datasets > 1:
+            source = self.metrics_by_dataset[dataset][dtype]
+        else:
+            dataset = -1
+            source = self.metrics[dtype]
+        norm = source['batches']
+        for key, val in source.items():
+            if key != 'batches':
+                row['%s_%s' % (prefix, key)] = val / norm
+        row['dataset'] = dataset
+        return row
+
+    def get_loss(self, dtype):
+        return self.metrics[dtype]['loss'] / self.metrics[dtype]['batches']
+
+
+class EarlyStopping(object):
+    """Stop when the validation loss has not improved for `patience` checks (ref :173-241)."""
+
+    def __init__(self, patience=10, min_epochs=10, delta=0):
+        self.patience = patience
+        self.min_epochs = min_epochs
+        self.delta = delta
+        self.counter = 0
+        self.best_epoch = 0
+        self.best_loss = np.inf
+        self.stopped_epoch = 0
+        self.should_stop = False
+
+    def on_val_check(self, epoch, curr_loss):
+        if curr_loss < self.best_loss - self.delta:
+            self.best_loss = curr_loss
+            self.best_epoch = epoch
+            self.counter = 0
+        else:
+            self.counter += 1
+        if epoch > self.min_epochs and self.counter >= self.patience:
+            print('\n== early stopping criteria met; exiting train loop ==')
+            print('training epochs: %d' % epoch)
+            print('end cost: %04f' % curr_loss)
+            print('best epoch: %i' % self.best_epoch)
+            print('best cost: %04f\n' % self.best_loss)
+            self.stopped_epoch = epoch
+            self.should_stop = True
+
+
+def _snapshot(model, hparams):
+    """deepcopy with ``hparams`` detached, as the reference does (training.py:393-396)."""
+    model.hparams = None
+    snap = copy.deepcopy(model)
+    model.hparams = hparams
+    snap.hparams = hparams
+    return snap
+
+
+def _progress(iterable, enabled):
+    if not enabled:
+        return iterable
+    try:
+        from tqdm import tqdm
+        return tqdm(iterable)
+    except ImportError:
+        return iterable
+
+
+def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
+    """Fit a model with Adam(amsgrad) SGD and early stopping (ref training.py:244-461).
+
+    ``optimizer`` (optional) injects an object with ``zero_grad()``/``step()``; by default a
+    :class:`FlatAdamAMSGrad` over ``model.get_parameters()`` is built.
+    """
+    if optimizer is None:
+        from behavenet_amd.fitting.optim import FlatAdamAMSGrad
+        optimizer = FlatAdamAMSGrad(
+            model.get_parameters(), lr=hparams['learning_rate'],
+            weight_decay=hparams.get('l2_reg', 0))
+    flat_g = getattr(optimizer, 'flat_g', None)
+    if bdist.is_active() and getattr(optimizer, 'flat_p', None) is not None:
+        bdist.broadcast_parameters_(optimizer.flat_p)
+
+    logger = Logger(n_datasets=data_generator.n_datasets)
+    early_stop = None
+    if hparams['enable_early_stop']:
+        early_stop = EarlyStopping(
+            patience=hparams['early_stop_history'], min_epochs=hparams['min_n_epochs'])
+
+    n_train = data_generator.n_tot_batches['train']
+    max_epochs = hparams['max_n_epochs']
+    interval = hparams['val_check_interval']
+    val_check_batch = np.append(
+        interval * n_train * np.arange(1, int((max_epochs + 1) / interval)),
+        [n_train * max_epochs, n_train * (max_epochs + 1)]).astype('int')
+
+    best_val_loss = np.inf
+    best_val_epoch = None
+    best_val_model = None
+    best_model_saved = False
+
+    if hparams.get('rng_seed_train', None) is None:
+        rng_train = np.random.randint(0, 10000)
+    else:
+        rng_train = int(hparams['rng_seed_train'])
+    torch.manual_seed(rng_train)
+    np.random.seed(rng_train)
+
+    expt_dir = os.path.join(hparams['expt_dir'], 'version_%i' % exp.version)
+    is_main = bdist.rank() == 0
+    show_bar = hparams.get('progress_bar', True) and is_main
+
+    i_epoch = 0
+    for i_epoch in range(max_epochs + 1):
+        # epoch 0 evaluates the randomly initialised model: forward/backward, no step (:320-322)
+        if is_main:
+            print_epoch(i_epoch, max_epochs)
+        torch.manual_seed(rng_train + i_epoch)
+        np.random.seed(rng_train + i_epoch)
+        logger.reset_metrics('train')
+        data_generator.reset_iterators('train')
+        model.curr_epoch = i_epoch
+
+        for i_train in _progress(range(n_train), show_bar):
+            model.train()
+            optimizer.zero_grad()
+            data, dataset = data_generator.next_batch('train')
+            if data is not None:
+                loss_dict = model.loss(data, dataset=dataset, accumulate_grad=True)
+                logger.update_metrics('train', loss_dict, dataset=dataset)
+                if i_epoch > 0:
+                    if flat_g is not None:
+                        bdist.all_reduce_flat_(flat_g)
+                    optimizer.step()
+
+            if (i_train + 1) % n_train == 0:
+                exp.log(logger.create_metric_row(
+                    'train', i_epoch, i_train, -1, trial=-1,
+                    by_dataset=False, best_epoch=best_val_epoch))
+                if data_generator.n_datasets > 1 and dataset is not None and \
+                        (isinstance(dataset, int) or len(dataset) == 1):
+                    for dataset in range(data_generator.n_datasets):
+                        exp.log(logger.create_metric_row(
+                            'train', i_epoch, i_train, dataset, trial=-1,
+                            by_dataset=True, best_epoch=best_val_epoch))
+                exp.save()
+
+            curr_batch = (i_train + 1) + i_epoch * n_train
+            if np.any(curr_batch == val_check_batch):
+                logger.reset_metrics('val')
+                data_generator.reset_iterators('val')
+                model.eval()
+                for _ in range(data_generator.n_tot_batches['val']):
+                    data, dataset = data_generator.next_batch('val')
+                    loss_dict = model.loss(data, dataset=dataset, accumulate_grad=False)
+                    logger.update_metrics('val', loss_dict, dataset=dataset)
+
+                if logger.get_loss('val') < best_val_loss:
+                    best_val_loss = logger.get_loss('val')
+                    if is_main:
+                        model.save(os.path.join(expt_dir, 'best_val_model.pt'))
+                    best_model_saved = True
+                    best_val_model = _snapshot(model, hparams)
+                    best_val_epoch = i_epoch
+
+                exp.log(logger.create_metric_row(
+                    'val', i_epoch, i_train, -1, trial=-1,
+                    by_dataset=False, best_epoch=best_val_epoch))
+                if data_generator.n_datasets > 1 and \
+                        (isinstance(dataset, int) or len(dataset) == 1):
+                    for dataset in range(data_generator.n_datasets):
+                        exp.log(logger.create_metric_row(
+                            'val', i_epoch, i_train, dataset, trial=-1,
+                            by_dataset=True, best_epoch=best_val_epoch))
+                exp.save()
+
+        if hparams['enable_early_stop']:
+            early_stop.on_val_check(i_epoch, logger.get_loss('val'))
+            if early_stop.should_stop:
+                break
+
+    if not best_model_saved:
+        if is_main:
+            model.save(os.path.join(expt_dir, 'best_val_model.pt'))
+        best_val_model = _snapshot(model, hparams)
+
+    if hparams.get('save_last_model', False) and is_main:
+        model.save(os.path.join(expt_dir, 'last_model.pt'))
+
+    # test loss, one row per test trial.  NB the reference evaluates `model`, not
+    # `best_val_model`, here (training.py:433,442) -- kept.
+    logger.reset_metrics('test')
+    data_generator.reset_iterators('test')
+    best_val_model.eval()
+    for i_test in range(data_generator.n_tot_batches['test']):
+        data, dataset = data_generator.next_batch('test')
+        logger.reset_metrics('test')
+        loss_dict = model.loss(data, dataset=dataset, accumulate_grad=False)
+        logger.update_metrics('test', loss_dict, dataset=dataset)
+        trial = data['batch_idx']
+        trial = trial.item() if hasattr(trial, 'item') else int(trial)
+        exp.log(logger.create_metric_row(
+            'test', i_epoch, i_test, dataset, trial=trial, by_dataset=True))
+    exp.save()
+
+    if method == 'ae' and hparams['export_latents']:
+        if is_main:
+            print('exporting latents')
+        from behavenet_amd.fitting.eval import export_latents
+        export_latents(data_generator, best_val_model)
+    elif method == 'nll' and hparams.get('export_predictions', False):
+        raise NotImplementedError('neural decoders are outside the MI355X hot path')
+    return best_val_model
+
+
+def print_epoch(curr, total):
+    """Zero-padded epoch counter."""
+    width = 1 if total < 10 else min(len(str(total)), 5) if total < 100000 else 0
+    if width:
+        print('epoch %0*i/%0*i' % (width, curr, width, total))
+    else:
+        print('epoch %i/%i' % (curr, total))

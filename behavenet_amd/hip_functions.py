@@ -1,0 +1,223 @@
+"""autograd glue between the model classes and the HIP kernels.
+
+Each ``torch.autograd.Function`` here stands for one fused block of the reference network and
+calls the C ABI (behavenet_amd/_hip.py) for both directions; torch autograd only chains them.
+
+* :class:`ConvStackFn` -- a whole encoder or decoder convolution stack
+  (ZeroPad2d/Conv2d/LeakyReLU x L, or ConvTranspose2d/crop/LeakyReLU|Sigmoid x L;
+  reference aes.py:203-211 and aes.py:460-476).  The backward pass is orchestrated by hand so
+  that the activation derivative of layer l-1 is applied in the epilogue of layer l's data
+  gradient kernel instead of in a separate pass.
+* :class:`LinearFn` -- nn.Linear on the matrix cores (aes.py:121,125,266).
+* :class:`SqErrFn` -- masked sum of squared differences (losses.py:56-59,84-96).
+* :class:`ReparamFn`, :class:`KLFn` -- the variational tail (vaes.py:33-35, losses.py:146-147).
+"""
+
+import torch
+
+from behavenet_amd import _hip
+
+LRELU_SLOPE = 0.05  # aes.py:114,341
+
+
+class ConvLayerPlan(object):
+    """Geometry of one fused layer, independent of the batch size.
+
+    kind 'conv':  (C, H, W) -> (K, P, Q), zero padding (pad_t, pad_l) folded into the kernel
+    kind 'convT': (Ci, Hi, Wi) -> (Co, Ho, Wo), crop (crop_t, crop_l) folded into the kernel
+    """
+
+    __slots__ = ('kind', 'cin', 'hin', 'win', 'cout', 'hout', 'wout', 'R', 'S', 'stride',
+                 'off_t', 'off_l', 'act')
+
+    def __init__(self, kind, cin, hin, win, cout, hout, wout, R, S, stride, off_t, off_l, act):
+        self.kind = kind
+        self.cin, self.hin, self.win = int(cin), int(hin), int(win)
+        self.cout, self.hout, self.wout = int(cout), int(hout), int(wout)
+        self.R, self.S, self.stride = int(R), int(S), int(stride)
+        self.off_t, self.off_l = int(off_t), int(off_l)
+        self.act = act
+
+    def geom(self, n):
+        """Argument tuple in the order of include/behavenet_hip.h."""
+        return (int(n), self.cin, self.hin, self.win, self.cout, self.R, self.S, self.stride,
+                self.off_t, self.off_l, self.hout, self.wout)
+
+    def __repr__(self):
+        return '%s(%dx%dx%d->%dx%dx%d k%dx%d s%d off(%d,%d) act%d)' % (
+            self.kind, self.cin, self.hin, self.win, self.cout, self.hout, self.wout, self.R,
+            self.S, self.stride, self.off_t, self.off_l, self.act)
+
+
+def _fwd(layer, x, w, b):
+    g = layer.geom(x.shape[0])
+    if layer.kind == 'conv':
+        return _hip.conv2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE)
+    return _hip.convT2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE)
+
+
+class ConvStackFn(torch.autograd.Function):
+    """y = layer_L(...layer_1(x)); params = (w_1, b_1, ..., w_L, b_L)."""
+
+    @staticmethod
+    def forward(ctx, plan, x, *params):
+        if x.shape[1:] != (plan[0].cin, plan[0].hin, plan[0].win):
+            raise ValueError('conv stack expects input (N,%d,%d,%d), got %s' % (
+                plan[0].cin, plan[0].hin, plan[0].win, tuple(x.shape)))
+        x = x.contiguous()
+        acts = [x]
+        h = x
+        for i, layer in enumerate(plan):
+            h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach())
+            acts.append(h)
+        ctx.plan = plan
+        ctx.need_dx = x.requires_grad
+        ctx.save_for_backward(*acts, *params[0::2])
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan = ctx.plan
+        n_layers = len(plan)
+        saved = ctx.saved_tensors
+        acts, weights = saved[:n_layers + 1], saved[n_layers + 1:]
+        dout = dout.contiguous()
+        n = dout.shape[0]
+
+        top = plan[-1]
+        if top.act != _hip.ACT_NONE:
+            dpre = _hip.act_bwd(dout, acts[-1], top.act, LRELU_SLOPE)
+        else:
+            dpre = dout
+
+        grads = [None] * (2 * n_layers)
+        for i in range(n_layers - 1, -1, -1):
+            layer = plan[i]
+            g = layer.geom(n)
+            w = weights[i]
+            x_in = acts[i]
+            need_w = ctx.needs_input_grad[2 + 2 * i]
+            need_b = ctx.needs_input_grad[3 + 2 * i]
+            if need_w:
+                dw = torch.empty_like(w)
+                db = torch.empty((layer.cout,), dtype=w.dtype, device=w.device) if need_b \
+                    else None
+                if layer.kind == 'conv':
+                    _hip.conv2d_bwd_weight(x_in, dpre, dw, db, g, False)
+                else:
+                    _hip.convT2d_bwd_weight(x_in, dpre, dw, db, g, False)
+                grads[2 * i], grads[2 * i + 1] = dw, db
+            if i > 0 or ctx.need_dx:
+                # fuse the derivative of the layer below into this kernel's epilogue
+                dact_src = acts[i] if i > 0 else None
+                dact = plan[i - 1].act if i > 0 else _hip.ACT_NONE
+                if layer.kind == 'conv':
+                    dpre = _hip.conv2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
+                else:
+                    dpre = _hip.convT2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
+        dx = dpre if ctx.need_dx else None
+        return (None, dx) + tuple(grads)
+
+
+def conv_stack(plan, x, params):
+    return ConvStackFn.apply(plan, x, *params)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x w^T + b on v_mfma_f32_32x32x2_f32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return _hip.linear_fwd(x, w.detach().contiguous(),
+                               b.detach() if b is not None else None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dw = torch.empty_like(w) if need_dw else None
+        db = torch.empty((w.shape[0],), dtype=w.dtype, device=w.device) if need_db else None
+        dx = _hip.linear_bwd(x, w.contiguous(), dy, need_dx, None, _hip.ACT_NONE, 0.0, dw, db,
+                             False)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    return LinearFn.apply(x, w, b)
+
+
+class SqErrFn(torch.autograd.Function):
+    """scale * sum_i (a_i - b_i)^2 * mask_i, returned as a 0-dim device tensor."""
+
+    @staticmethod
+    def forward(ctx, a, b, mask, scale):
+        a, b = a.contiguous(), b.contiguous()
+        mask = mask.contiguous() if mask is not None else None
+        ctx.save_for_backward(a, b, mask)
+        ctx.scale = float(scale)
+        sums = _hip.sqerr_frame_sums(a, b, mask)
+        return _hip.reduce_sum(sums, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, mask = ctx.saved_tensors
+        g = g.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _hip.sqerr_bwd(a, b, mask, ctx.scale, g)
+        if ctx.needs_input_grad[1]:
+            db = _hip.sqerr_bwd(b, a, mask, ctx.scale, g)
+        return da, db, None, None
+
+
+def sq_err(a, b, mask, scale):
+    return SqErrFn.apply(a, b, mask, scale)
+
+
+class ReparamFn(torch.autograd.Function):
+    """z = mu + eps * exp(logvar)  (std = exp(logvar) as in the reference, vaes.py:33)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        mu, logvar, eps = mu.contiguous(), logvar.contiguous(), eps.contiguous()
+        z = _hip.reparam_fwd(mu, logvar, eps)
+        ctx.save_for_backward(mu, z)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        mu, z = ctx.saved_tensors
+        # dz/dmu = 1, dz/dlogvar = eps*exp(logvar) = z - mu
+        dz = dz.contiguous()
+        dlogvar = _hip.reparam_bwd(dz, z, mu) if ctx.needs_input_grad[1] else None
+        return (dz if ctx.needs_input_grad[0] else None), dlogvar, None
+
+
+def reparameterize_with_eps(mu, logvar, eps):
+    return ReparamFn.apply(mu, logvar, eps)
+
+
+class KLFn(torch.autograd.Function):
+    """mean_n 0.5 * sum_d (exp(logvar) - logvar + mu^2 - 1)  (losses.py:146-147)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        ctx.save_for_backward(mu, logvar)
+        rows = _hip.kl_rows(mu, logvar)
+        return _hip.reduce_sum(rows, 1.0 / mu.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        dmu, dlogvar = _hip.kl_bwd(mu, logvar, 1.0 / mu.shape[0], g.contiguous())
+        return dmu, dlogvar
+
+
+def kl_to_std_normal(mu, logvar):
+    return KLFn.apply(mu, logvar)

@@ -1,0 +1,523 @@
+"""Autoencoder models on the MI355X HIP kernels.
+
+Host-side mirror of the reference ``behavenet/models/aes.py``: same class names, constructor
+hparams, ``forward/encoding/decoding/loss`` signatures and ``state_dict`` keys, so a reference
+checkpoint loads here and vice versa.  The ``nn.Conv2d`` / ``nn.ConvTranspose2d`` /
+``nn.Linear`` children are kept as *parameter containers only* (identical registration order
+=> identical initialisation from ``torch.manual_seed``); their own ``forward`` is never used.
+The arithmetic runs through :mod:`behavenet_amd.hip_functions`.
+"""
+
+import numpy as np
+import torch
+from torch import nn
+
+import behavenet_amd.fitting.losses as losses
+from behavenet_amd import _hip
+from behavenet_amd.models.base import BaseModule, BaseModel
+from behavenet_amd.hip_functions import ConvLayerPlan, conv_stack, linear
+
+__all__ = [
+    'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
+    'load_pretrained_ae']
+
+
+def _mark_footprint(module):
+    module._bn_counts_for_footprint = True
+    return module
+
+
+def _unsupported_on_hip(what):
+    raise NotImplementedError(
+        '%s is not implemented by the MI355X kernels yet (SURVEY.md section 8(f), rank 3)' % what)
+
+
+class ConvAEEncoder(BaseModule):
+    """Convolutional encoder (ref aes.py:17-218)."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = hparams
+        self.encoder = None
+        self.build_model()
+
+    def __str__(self):
+        out = 'Encoder architecture:\n'
+        i = 0
+        for i, module in enumerate(self.encoder):
+            out += '    {:02d}: {}\n'.format(i, module)
+        out += '    {:02d}: {}\n'.format(i + 1 if len(self.encoder) else 0, self.FF)
+        return out
+
+    def build_model(self):
+        hp = self.hparams
+        self.encoder = nn.ModuleList()
+        self._layer_names = []   # conv module name per fused layer
+        self._plan = []
+        n_layers = len(hp['ae_encoding_n_channels'])
+        gnum = 0
+        for i in range(n_layers):
+            if hp['ae_encoding_layer_type'][i] != 'conv':
+                continue
+            args, pads = self._get_conv2d_args(i, gnum)
+            if hp.get('fit_sess_io_layers', False) and i == 0:
+                name = 'conv%i_sess_io_layers' % gnum
+                self.encoder.add_module(name, nn.ModuleList([
+                    _mark_footprint(nn.Conv2d(**args)) for _ in range(hp['n_datasets'])]))
+            else:
+                name = 'conv%i' % gnum
+                self.encoder.add_module(name, _mark_footprint(nn.Conv2d(**args)))
+            if hp['ae_batch_norm']:
+                self.encoder.add_module('batchnorm%i' % gnum, nn.BatchNorm2d(
+                    hp['ae_encoding_n_channels'][i],
+                    momentum=hp.get('ae_batch_norm_momentum', 0.1),
+                    track_running_stats=hp.get('track_running_stats', True)))
+            if i < n_layers - 1 and hp['ae_encoding_layer_type'][i + 1] == 'maxpool':
+                self.encoder.add_module('maxpool%i' % gnum, _mark_footprint(nn.MaxPool2d(
+                    **self._get_maxpool2d_args(i))))
+            self.encoder.add_module('relu%i' % gnum, nn.LeakyReLU(0.05))
+
+            if i == 0:
+                hin, win = hp['ae_input_dim'][1], hp['ae_input_dim'][2]
+            else:
+                hin, win = hp['ae_encoding_y_dim'][i - 1], hp['ae_encoding_x_dim'][i - 1]
+            k = args['kernel_size']
+            self._plan.append(ConvLayerPlan(
+                'conv', args['in_channels'], hin, win, args['out_channels'],
+                hp['ae_encoding_y_dim'][i], hp['ae_encoding_x_dim'][i], k, k, args['stride'],
+                pads[0], pads[1], _hip.ACT_LRELU))
+            self._layer_names.append(name)
+            gnum += 1
+
+        last = hp['ae_encoding_n_channels'][-1] * hp['ae_encoding_y_dim'][-1] * \
+            hp['ae_encoding_x_dim'][-1]
+        self.FF = _mark_footprint(nn.Linear(last, hp['n_ae_latents']))
+        if hp.get('variational', False):
+            self.logvar = _mark_footprint(nn.Linear(last, hp['n_ae_latents']))
+
+    def _get_conv2d_args(self, layer, global_layer):
+        """nn.Conv2d kwargs + the (top, left) zero padding folded into the kernel (ref :127-163)."""
+        hp = self.hparams
+        if layer == 0:
+            extra = 0
+            if hp['model_class'] == 'cond-ae' and hp.get('conditional_encoder', False):
+                extra = int(hp['n_labels'] / 2)  # x/y label coordinates share one 2d map
+            in_channels = hp['ae_input_dim'][0] + extra
+        else:
+            in_channels = hp['ae_encoding_n_channels'][layer - 1]
+        x0, x1 = hp['ae_encoding_x_padding'][layer]
+        y0, y1 = hp['ae_encoding_y_padding'][layer]
+        if x0 == x1 and y0 == y1:
+            padding = (y0, x0)
+        else:
+            # asymmetric TF-"same" padding: the reference inserts a ZeroPad2d; the module is kept
+            # (names / printing) but the padding is folded into the conv kernel's tile load
+            self.encoder.add_module('zero_pad%i' % global_layer, nn.ZeroPad2d((x0, x1, y0, y1)))
+            padding = 0
+        args = {
+            'in_channels': in_channels,
+            'out_channels': hp['ae_encoding_n_channels'][layer],
+            'kernel_size': hp['ae_encoding_kernel_size'][layer],
+            'stride': hp['ae_encoding_stride_size'][layer],
+            'padding': padding}
+        return args, (y0, x0)
+
+    def _get_maxpool2d_args(self, layer):
+        hp = self.hparams
+        return {
+            'kernel_size': int(hp['ae_encoding_kernel_size'][layer + 1]),
+            'stride': int(hp['ae_encoding_stride_size'][layer + 1]),
+            'padding': (hp['ae_encoding_y_padding'][layer + 1][0],
+                        hp['ae_encoding_x_padding'][layer + 1][0]),
+            'return_indices': True,
+            'ceil_mode': hp['ae_padding_type'] != 'valid'}
+
+    def _stack_params(self, dataset):
+        params = []
+        for name in self._layer_names:
+            mod = getattr(self.encoder, name)
+            if isinstance(mod, nn.ModuleList):
+                mod = mod[dataset]
+            params += [mod.weight, mod.bias]
+        return params
+
+    def _features(self, x, dataset=None):
+        """Run the conv stack -> (N, C*H*W) post-LeakyReLU features."""
+        hp = self.hparams
+        if hp['ae_batch_norm']:
+            _unsupported_on_hip('ae_batch_norm=1')
+        if hp.get('ae_network_type', 'strides_only') == 'max_pooling' or \
+                any(t == 'maxpool' for t in hp['ae_encoding_layer_type']):
+            _unsupported_on_hip('max-pooling architectures')
+        h = conv_stack(self._plan, x, self._stack_params(dataset))
+        return h.view(h.size(0), -1)
+
+    def forward(self, x, dataset=None):
+        """-> (latents, pool_idx, output_sizes) or (mu, logvar, pool_idx, output_sizes)."""
+        x1 = self._features(x, dataset)
+        if self.hparams.get('variational', False):
+            return (linear(x1, self.FF.weight, self.FF.bias),
+                    linear(x1, self.logvar.weight, self.logvar.bias), [], [])
+        return linear(x1, self.FF.weight, self.FF.bias), [], []
+
+
+class ConvAEDecoder(BaseModule):
+    """Convolutional decoder (ref aes.py:221-488)."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = hparams
+        self.decoder = None
+        self.build_model()
+
+    def __str__(self):
+        out = 'Decoder architecture:\n'
+        out += '    {:02d}: {}\n'.format(0, self.FF)
+        for i, module in enumerate(self.decoder):
+            out += '    {:02d}: {}\n'.format(i + 1, module)
+        return out
+
+    def build_model(self):
+        hp = self.hparams
+        start = hp['ae_decoding_starting_dim']
+        self.FF = _mark_footprint(nn.Linear(hp['hidden_layer_size'], start[0] * start[1] * start[2]))
+        self.decoder = nn.ModuleList()
+        self.conv_t_pads = {}
+        self._layer_names = []
+        self._plan = []
+        n_layers = len(hp['ae_decoding_n_channels'])
+        gnum = 0
+        for i in range(n_layers):
+            if hp['ae_decoding_layer_type'][i] != 'convtranspose':
+                continue
+            if i > 0 and hp['ae_decoding_layer_type'][i - 1] == 'unpool':
+                k = int(hp['ae_decoding_kernel_size'][i - 1])
+                s = int(hp['ae_decoding_stride_size'][i - 1])
+                self.decoder.add_module('maxunpool%i' % gnum, _mark_footprint(nn.MaxUnpool2d(
+                    kernel_size=(k, k), stride=(s, s),
+                    padding=(hp['ae_decoding_y_padding'][i - 1][0],
+                             hp['ae_decoding_x_padding'][i - 1][0]))))
+            args, crop, out_hw = self._get_convtranspose2d_args(i, gnum)
+            is_last = i == n_layers - 1 and not hp['ae_decoding_last_FF_layer']
+            if hp.get('fit_sess_io_layers', False) and is_last:
+                name = 'convtranspose%i_sess_io_layers' % gnum
+                self.decoder.add_module(name, nn.ModuleList([
+                    _mark_footprint(nn.ConvTranspose2d(**args))
+                    for _ in range(hp['n_datasets'])]))
+                self.conv_t_pads[name] = self.conv_t_pads['convtranspose%i' % gnum]
+            else:
+                name = 'convtranspose%i' % gnum
+                self.decoder.add_module(name, _mark_footprint(nn.ConvTranspose2d(**args)))
+            if is_last:
+                self.decoder.add_module('sigmoid%i' % gnum, nn.Sigmoid())
+                act = _hip.ACT_SIGMOID
+            else:
+                if hp['ae_batch_norm']:
+                    self.decoder.add_module('batchnorm%i' % gnum, nn.BatchNorm2d(
+                        hp['ae_decoding_n_channels'][i],
+                        momentum=hp.get('ae_batch_norm_momentum', 0.1),
+                        track_running_stats=hp.get('track_running_stats', True)))
+                self.decoder.add_module('relu%i' % gnum, nn.LeakyReLU(0.05))
+                act = _hip.ACT_LRELU
+
+            if i == 0:
+                hin, win = start[1], start[2]
+            else:
+                hin, win = hp['ae_decoding_y_dim'][i - 1], hp['ae_decoding_x_dim'][i - 1]
+            k = args['kernel_size'][0]
+            self._plan.append(ConvLayerPlan(
+                'convT', args['in_channels'], hin, win, args['out_channels'], out_hw[0], out_hw[1],
+                k, k, args['stride'][0], crop[0], crop[1], act))
+            self._layer_names.append(name)
+            gnum += 1
+
+        if hp['ae_decoding_last_FF_layer']:
+            if hp.get('fit_sess_io_layers', False):
+                raise NotImplementedError
+            self.decoder.add_module('last_ff%i' % gnum, _mark_footprint(nn.Linear(
+                hp['ae_decoding_x_dim'][-1] * hp['ae_decoding_y_dim'][-1] *
+                hp['ae_decoding_n_channels'][-1],
+                hp['ae_input_dim'][0] * hp['ae_input_dim'][1] * hp['ae_input_dim'][2])))
+            self.decoder.add_module('sigmoid%i' % gnum, nn.Sigmoid())
+            self._last_ff_name = 'last_ff%i' % gnum
+
+    def _get_convtranspose2d_args(self, layer, global_layer):
+        """nn.ConvTranspose2d kwargs, the (top, left) crop and the output size (ref :361-430).
+
+        Full transposed-conv size is ``(in-1)*stride + k``; the reference either passes
+        ``padding`` (symmetric), crops afterwards with ``F.pad(x, [-l,-r,-t,-b])`` (asymmetric),
+        or extends with ``output_padding`` ('valid').  All three reduce to "output pixel (h, w)
+        is full-size pixel (h+crop_t, w+crop_l), for h < Ho, w < Wo".
+        """
+        hp = self.hparams
+        start = hp['ae_decoding_starting_dim']
+        in_channels = start[0] if layer == 0 else hp['ae_decoding_n_channels'][layer - 1]
+        k = hp['ae_decoding_kernel_size'][layer]
+        s = hp['ae_decoding_stride_size'][layer]
+        x0, x1 = hp['ae_decoding_x_padding'][layer]
+        y0, y1 = hp['ae_decoding_y_padding'][layer]
+        in_y = start[1] if layer == 0 else hp['ae_decoding_y_dim'][layer - 1]
+        in_x = start[2] if layer == 0 else hp['ae_decoding_x_dim'][layer - 1]
+        name = 'convtranspose%i' % global_layer
+        if hp['ae_padding_type'] == 'valid':
+            out_pad = (hp['ae_decoding_y_dim'][layer] - ((in_y - 1) * s + k),
+                       hp['ae_decoding_x_dim'][layer] - ((in_x - 1) * s + k))
+            in_pad = (y0, x0)
+            self.conv_t_pads[name] = None
+            crop = (y0, x0)
+            out_hw = ((in_y - 1) * s + k - 2 * y0 + out_pad[0],
+                      (in_x - 1) * s + k - 2 * x0 + out_pad[1])
+        elif hp['ae_padding_type'] == 'same':
+            out_pad = 0
+            if x0 == x1 and y0 == y1:
+                in_pad = (y0, x0)
+                self.conv_t_pads[name] = None
+            else:
+                in_pad = 0
+                self.conv_t_pads[name] = [x0, x1, y0, y1]
+            crop = (y0, x0)
+            out_hw = ((in_y - 1) * s + k - y0 - y1, (in_x - 1) * s + k - x0 - x1)
+        else:
+            raise ValueError('"%s" is not a valid padding type' % hp['ae_padding_type'])
+        args = {
+            'in_channels': in_channels,
+            'out_channels': hp['ae_decoding_n_channels'][layer],
+            'kernel_size': (k, k),
+            'stride': (s, s),
+            'padding': in_pad,
+            'output_padding': out_pad}
+        return args, crop, out_hw
+
+    def _stack_params(self, dataset):
+        params = []
+        for name in self._layer_names:
+            mod = getattr(self.decoder, name)
+            if isinstance(mod, nn.ModuleList):
+                mod = mod[dataset]
+            params += [mod.weight, mod.bias]
+        return params
+
+    def forward(self, x, pool_idx=None, target_output_size=None, dataset=None):
+        hp = self.hparams
+        if hp['ae_batch_norm']:
+            _unsupported_on_hip('ae_batch_norm=1')
+        if any(t == 'unpool' for t in hp['ae_decoding_layer_type']):
+            _unsupported_on_hip('max-pooling architectures')
+        if hp['ae_decoding_last_FF_layer']:
+            _unsupported_on_hip('ae_decoding_last_FF_layer=1')
+        start = hp['ae_decoding_starting_dim']
+        h = linear(x, self.FF.weight, self.FF.bias)
+        h = h.view(h.size(0), start[0], start[1], start[2])
+        return conv_stack(self._plan, h, self._stack_params(dataset))
+
+
+class LinearAEEncoder(BaseModule):
+    """Single dense layer encoder (ref aes.py:491-544)."""
+
+    def __init__(self, n_latents, input_size):
+        super().__init__()
+        self.n_latents = n_latents
+        self.input_size = input_size
+        self.encoder = None
+        self.decoder = None
+        self.build_model()
+
+    def __str__(self):
+        return 'Encoder architecture:\n    {}\n'.format(self.encoder)
+
+    def build_model(self):
+        self.encoder = nn.Linear(
+            out_features=self.n_latents, in_features=int(np.prod(self.input_size)), bias=True)
+
+    def forward(self, x, dataset=None):
+        x = x.reshape(x.size(0), -1)
+        return linear(x, self.encoder.weight, self.encoder.bias), None, None
+
+
+class LinearAEDecoder(BaseModule):
+    """Dense decoder, optionally tied to the encoder weights (ref aes.py:547-613)."""
+
+    def __init__(self, n_latents, output_size, encoder=None):
+        super().__init__()
+        self.n_latents = n_latents
+        self.output_size = output_size
+        self.encoder = encoder
+        self.decoder = None
+        self.build_model()
+
+    def __str__(self):
+        out = 'Decoder architecture:\n'
+        if self.bias is not None:
+            out += '    Encoder weights transposed (plus independent bias)\n'
+        else:
+            out += '    {}\n'.format(self.decoder)
+        return out
+
+    def build_model(self):
+        if self.encoder is None:
+            self.decoder = nn.Linear(
+                out_features=int(np.prod(self.output_size)), in_features=self.n_latents, bias=True)
+        else:
+            self.bias = nn.Parameter(
+                torch.zeros(int(np.prod(self.output_size))), requires_grad=True)
+
+    def forward(self, x, dataset=None):
+        if self.encoder is None:
+            x = linear(x, self.decoder.weight, self.decoder.bias)
+        else:
+            # tied weights: y = x W_enc + b   (W_enc is (n_latents, n_pixels))
+            x = linear(x, self.encoder.encoder.weight.t().contiguous(), self.bias)
+        return x.view(x.size(0), *self.output_size)
+
+
+class AE(BaseModel):
+    """Base autoencoder class (ref aes.py:616-773)."""
+
+    def __init__(self, hparams):
+        super().__init__()
+        self.hparams = hparams
+        self.model_type = self.hparams['model_type']
+        self.img_size = (
+            self.hparams['n_input_channels'],
+            self.hparams['y_pixels'],
+            self.hparams['x_pixels'])
+        self.encoding = None
+        self.decoding = None
+        self.build_model()
+
+    def __str__(self):
+        out = '\nAutoencoder architecture\n'
+        out += '------------------------\n'
+        out += self.encoding.__str__()
+        out += self.decoding.__str__()
+        out += '\n'
+        return out
+
+    def build_model(self):
+        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
+        if self.model_type == 'conv':
+            self.encoding = ConvAEEncoder(self.hparams)
+            self.decoding = ConvAEDecoder(self.hparams)
+        elif self.model_type == 'linear':
+            if self.hparams.get('fit_sess_io_layers', False):
+                raise NotImplementedError
+            n_latents = self.hparams['n_ae_latents']
+            self.encoding = LinearAEEncoder(n_latents, self.img_size)
+            self.decoding = LinearAEDecoder(n_latents, self.img_size, self.encoding)
+        else:
+            raise ValueError('"%s" is an invalid model_type' % self.model_type)
+
+    def forward(self, x, dataset=None, **kwargs):
+        """-> (x_hat (N,C,H,W), latents (N,n_latents))."""
+        if self.model_type == 'conv':
+            z, pool_idx, outsize = self.encoding(x, dataset=dataset)
+            y = self.decoding(z, pool_idx, outsize, dataset=dataset)
+        elif self.model_type == 'linear':
+            z, _, _ = self.encoding(x)
+            y = self.decoding(z)
+        else:
+            raise ValueError('"%s" is an invalid model_type' % self.model_type)
+        return y, z
+
+    def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
+        """Pixel MSE over 200-frame chunks with one backward per chunk (ref aes.py:722-773).
+
+        Each chunk's loss is the mean over *that chunk*, so the accumulated gradient is
+        sum_chunks grad(mean_chunk) exactly as in the reference; the returned
+        value is the frame-weighted mean (G3).  Losses stay on the device until the end of the
+        call: one host synchronisation per ``loss()`` instead of one per chunk.
+        """
+        x = data['images'][0]
+        m = data['masks'][0] if 'masks' in data else None
+        batch_size = x.shape[0]
+        n_chunks = int(np.ceil(batch_size / chunk_size))
+
+        vals, sizes = [], []
+        for chunk in range(n_chunks):
+            beg = chunk * chunk_size
+            end = min((chunk + 1) * chunk_size, batch_size)
+            x_in = x[beg:end]
+            m_in = m[beg:end] if m is not None else None
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                x_hat, _ = self.forward(x_in, dataset=dataset)
+                loss = losses.mse(x_in, x_hat, m_in)
+            if accumulate_grad:
+                loss.backward()
+            vals.append(loss.detach())
+            sizes.append(end - beg)
+
+        vals = torch.stack(vals).cpu().numpy().astype(np.float64)
+        loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
+        return {'loss': loss_val}
+
+
+class ConditionalAE(AE):
+    """Conditional autoencoder: labels are appended to the latents (ref aes.py:776-898)."""
+
+    def __init__(self, hparams):
+        if hparams['model_type'] == 'linear':
+            raise NotImplementedError
+        super().__init__(hparams)
+
+    def build_model(self):
+        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents'] + self.hparams['n_labels']
+        self.encoding = ConvAEEncoder(self.hparams)
+        self.decoding = ConvAEDecoder(self.hparams)
+
+    def forward(self, x, dataset=None, labels=None, labels_2d=None, **kwargs):
+        if self.hparams.get('conditional_encoder', False):
+            x = torch.cat((x, labels_2d), dim=1)
+        z, pool_idx, outsize = self.encoding(x, dataset=dataset)
+        z_aug = torch.cat((z, labels), dim=1)
+        y = self.decoding(z_aug, pool_idx, outsize, dataset=dataset)
+        return y, z
+
+    def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
+        x = data['images'][0]
+        y = data['labels'][0]
+        m = data['masks'][0] if 'masks' in data else None
+        labels_2d = data['labels_sc'][0] if self.hparams.get('conditional_encoder', False) \
+            else None
+        batch_size = x.shape[0]
+        n_chunks = int(np.ceil(batch_size / chunk_size))
+        vals, sizes = [], []
+        for chunk in range(n_chunks):
+            beg = chunk * chunk_size
+            end = min((chunk + 1) * chunk_size, batch_size)
+            x_in, y_in = x[beg:end], y[beg:end]
+            m_in = m[beg:end] if m is not None else None
+            l2d = labels_2d[beg:end] if labels_2d is not None else None
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                x_hat, _ = self.forward(x_in, dataset=dataset, labels=y_in, labels_2d=l2d)
+                loss = losses.mse(x_in, x_hat, m_in)
+            if accumulate_grad:
+                loss.backward()
+            vals.append(loss.detach())
+            sizes.append(end - beg)
+        vals = torch.stack(vals).cpu().numpy().astype(np.float64)
+        loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
+        return {'loss': loss_val}
+
+
+def load_pretrained_ae(model, hparams):
+    """Initialise ``model`` from ``hparams['pretrained_weights_path']`` (ref aes.py:1220-1274).
+
+    Tensors whose shapes differ (typically the FF layers when the latent count changed) are
+    dropped and keep their fresh initialisation.
+    """
+    path = hparams.get('pretrained_weights_path', None)
+    if path is None or path is False or path == '':
+        print('Initializing with random weights')
+        return model
+    if hparams['model_type'] == 'linear':
+        raise NotImplementedError('Loading pretrained weights with linear AE')
+    print('Loading pretrained weights')
+    loaded = torch.load(path, map_location=lambda storage, loc: storage)
+    if loaded['encoding.FF.weight'].shape != model.encoding.FF.weight.shape:
+        print('PRETRAINED MODEL HAS DIFFERENT SPATIAL DIMENSIONS OR N LATENTS: '
+              'NOT LOADING FF PARAMETERS')
+        for key in ('encoding.FF.weight', 'encoding.FF.bias',
+                    'decoding.FF.weight', 'decoding.FF.bias'):
+            loaded.pop(key, None)
+    model.load_state_dict(loaded, strict=False)
+    return model

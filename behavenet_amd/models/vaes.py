@@ -1,0 +1,394 @@
+"""Variational autoencoder models on the MI355X HIP kernels.
+
+Host-side mirror of the reference ``behavenet/models/vaes.py`` for the classes on the hot path:
+``VAE``, ``ConditionalVAE``, ``BetaTCVAE``, ``PSVAE`` (+ ``ConvAEPSEncoder``).  Quirks of the
+reference that are reproduced on purpose:
+
+* ``reparameterize`` uses ``std = exp(logvar)`` while the KL terms treat ``logvar`` as a
+  log-variance;
+* with ``vae.beta_anneal_epochs > 0`` the beta table continues with ones, not with beta;
+* ``loss_data_mse`` / ``loss_mse`` of PS-VAE / beta-TC-VAE divide the *accumulated*
+  log-likelihood by the current chunk size.
+"""
+
+import numpy as np
+import torch
+from torch import nn
+
+import behavenet_amd.fitting.losses as losses
+from behavenet_amd import hip_functions as hf
+from behavenet_amd.hip_functions import linear
+from behavenet_amd.models.aes import AE, ConvAEDecoder, ConvAEEncoder
+from behavenet_amd.models.base import DiagLinear
+
+__all__ = [
+    'reparameterize', 'VAE', 'ConditionalVAE', 'BetaTCVAE', 'PSVAE', 'ConvAEPSEncoder',
+    'set_eps_provider']
+
+_eps_provider = None
+
+
+def set_eps_provider(fn):
+    """Install ``fn(like_tensor) -> eps`` used instead of ``torch.randn_like``.
+
+    The reference draws eps from torch's CPU generator; the device generator produces a
+    different stream, so parity tests inject the oracle's eps here.  ``None`` restores the
+    default (device RNG).
+    """
+    global _eps_provider
+    _eps_provider = fn
+
+
+def reparameterize(mu, logvar, eps=None):
+    """Sample ``mu + eps * exp(logvar)`` (ref vaes.py:17-35; std = exp(logvar), sic)."""
+    if eps is None:
+        eps = _eps_provider(logvar) if _eps_provider is not None else torch.randn_like(logvar)
+    return hf.reparameterize_with_eps(mu, logvar, eps)
+
+
+def _r2_variance_weighted(y_true, y_pred):
+    """sklearn.metrics.r2_score(..., multioutput='variance_weighted') in numpy."""
+    y_true = np.asarray(y_true, dtype=np.float64)
+    y_pred = np.asarray(y_pred, dtype=np.float64)
+    if y_true.ndim == 1:
+        y_true, y_pred = y_true[:, None], y_pred[:, None]
+    num = ((y_true - y_pred) ** 2).sum(axis=0)
+    den = ((y_true - y_true.mean(axis=0)) ** 2).sum(axis=0)
+    nonzero = den != 0
+    scores = np.ones(y_true.shape[1])
+    scores[nonzero] = 1 - num[nonzero] / den[nonzero]
+    scores[(num != 0) & ~nonzero] = 0.0
+    if not np.any(nonzero):
+        return float(np.mean(scores))
+    return float(np.average(scores, weights=den))
+
+
+def _anneal_tables(beta, anneal_epochs, max_n_epochs, tail_is_beta):
+    tail = (beta if tail_is_beta else 1.0) * np.ones(max_n_epochs + 1)
+    if anneal_epochs > 0:
+        beta_vals = np.append(np.linspace(0, beta, anneal_epochs), tail)
+        kl_vals = np.append(np.linspace(0, 1, anneal_epochs), np.ones(max_n_epochs + 1))
+    else:
+        beta_vals = beta * np.ones(max_n_epochs + 1)
+        kl_vals = np.ones(max_n_epochs + 1)
+    return beta_vals, kl_vals
+
+
+def _collect(pairs, batch_size):
+    """One device->host transfer for all per-chunk scalars: [(dict of 0-dim tensors, bs), ...]."""
+    keys = list(pairs[0][0].keys())
+    flat = torch.stack([torch.stack([d[k].detach().float() for k in keys]) for d, _ in pairs])
+    vals = flat.cpu().numpy().astype(np.float64)
+    return keys, vals, [bs for _, bs in pairs]
+
+
+class VAE(AE):
+    """Variational autoencoder / beta-VAE (ref vaes.py:38-208)."""
+
+    def __init__(self, hparams):
+        if hparams['model_type'] == 'linear':
+            raise NotImplementedError
+        hparams['variational'] = True
+        super().__init__(hparams)
+        self.curr_epoch = 0  # set by fit()
+        anneal = self.hparams.get('vae.beta_anneal_epochs', 0)
+        # NB: after annealing the reference continues with ones, not with beta (vaes.py:93-100)
+        self.beta_vals, _ = _anneal_tables(
+            hparams['vae.beta'], anneal, hparams['max_n_epochs'], tail_is_beta=anneal <= 0)
+
+    def forward(self, x, dataset=None, use_mean=False, **kwargs):
+        """-> (x_hat, z, mu, logvar)."""
+        mu, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
+        z = mu if use_mean else reparameterize(mu, logvar)
+        x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+        return x_hat, z, mu, logvar
+
+    def _elbo_loss(self, data, dataset, accumulate_grad, chunk_size, fwd_kwargs_fn):
+        x = data['images'][0]
+        m = data['masks'][0] if 'masks' in data else None
+        beta = self.beta_vals[self.curr_epoch]
+        batch_size = x.shape[0]
+        n_chunks = int(np.ceil(batch_size / chunk_size))
+        pairs = []
+        for chunk in range(n_chunks):
+            beg = chunk * chunk_size
+            end = min((chunk + 1) * chunk_size, batch_size)
+            x_in = x[beg:end]
+            m_in = m[beg:end] if m is not None else None
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                x_hat, _, mu, logvar = self.forward(
+                    x_in, dataset=dataset, use_mean=False, **fwd_kwargs_fn(beg, end))
+                loss_ll = losses.gaussian_ll(x_in, x_hat, m_in)
+                loss_kl = losses.kl_div_to_std_normal(mu, logvar)
+                loss = -loss_ll + float(beta) * loss_kl
+            if accumulate_grad:
+                loss.backward()
+            pairs.append(({'loss': loss, 'loss_ll': loss_ll, 'loss_kl': loss_kl}, end - beg))
+        keys, vals, sizes = _collect(pairs, batch_size)
+        out = {k: 0.0 for k in keys}
+        out['loss_mse'] = 0.0
+        n_dims = np.prod(x.shape[1:])
+        for row, bs in zip(vals, sizes):
+            for k, v in zip(keys, row):
+                out[k] += v * bs
+            out['loss_mse'] += losses.gaussian_ll_to_mse(row[keys.index('loss_ll')], n_dims) * bs
+        for k in out:
+            out[k] = float(out[k] / batch_size)
+        out['beta'] = beta
+        return out
+
+    def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
+        """-> {'loss','loss_ll','loss_kl','loss_mse','beta'} (ref vaes.py:131-208)."""
+        return self._elbo_loss(data, dataset, accumulate_grad, chunk_size, lambda b, e: {})
+
+
+class ConditionalVAE(VAE):
+    """Conditional VAE: labels appended to the sampled latents (ref vaes.py:211-364)."""
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+
+    def build_model(self):
+        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents'] + self.hparams['n_labels']
+        self.encoding = ConvAEEncoder(self.hparams)
+        self.decoding = ConvAEDecoder(self.hparams)
+
+    def forward(self, x, dataset=None, labels=None, labels_2d=None, use_mean=False, **kwargs):
+        if self.hparams['conditional_encoder']:
+            x = torch.cat((x, labels_2d), dim=1)
+        mu, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
+        z = mu if use_mean else reparameterize(mu, logvar)
+        z_aug = torch.cat((z, labels), dim=1)
+        x_hat = self.decoding(z_aug, pool_idx, outsize, dataset=dataset)
+        return x_hat, z, mu, logvar
+
+    def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
+        y = data['labels'][0]
+        y_2d = data['labels_sc'][0] if self.hparams['conditional_encoder'] else None
+
+        def kwargs(beg, end):
+            return {'labels': y[beg:end],
+                    'labels_2d': y_2d[beg:end] if y_2d is not None else None}
+        return self._elbo_loss(data, dataset, accumulate_grad, chunk_size, kwargs)
+
+
+class BetaTCVAE(VAE):
+    """beta-TC-VAE: KL term decomposed into MI + beta*TC + dim-wise KL (ref vaes.py:367-503)."""
+
+    def __init__(self, hparams):
+        if hparams['model_type'] == 'linear':
+            raise NotImplementedError
+        super().__init__(hparams)
+        self.curr_epoch = 0
+        self.beta_vals, self.kl_anneal_vals = _anneal_tables(
+            hparams['beta_tcvae.beta'], self.hparams.get('beta_tcvae.beta_anneal_epochs', 0),
+            hparams['max_n_epochs'], tail_is_beta=True)
+
+    def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
+        x = data['images'][0]
+        m = data['masks'][0] if 'masks' in data else None
+        beta = self.beta_vals[self.curr_epoch]
+        kl = self.kl_anneal_vals[self.curr_epoch]
+        batch_size = x.shape[0]
+        n_chunks = int(np.ceil(batch_size / chunk_size))
+        pairs = []
+        for chunk in range(n_chunks):
+            beg = chunk * chunk_size
+            end = min((chunk + 1) * chunk_size, batch_size)
+            x_in = x[beg:end]
+            m_in = m[beg:end] if m is not None else None
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                x_hat, sample, mu, logvar = self.forward(x_in, dataset=dataset, use_mean=False)
+                ll = losses.gaussian_ll(x_in, x_hat, m_in)
+                mi, tc, dwkl = losses.decomposed_kl(sample, mu, logvar)
+                loss = -ll + float(kl) * mi + float(beta) * tc + float(kl) * dwkl
+            if accumulate_grad:
+                loss.backward()
+            pairs.append(({'loss': loss, 'loss_ll': ll, 'loss_mi': mi, 'loss_tc': tc,
+                           'loss_dwkl': dwkl}, end - beg))
+        keys, vals, sizes = _collect(pairs, batch_size)
+        out = {k: 0.0 for k in keys}
+        out['loss_mse'] = 0.0
+        n_dims = np.prod(x.shape[1:])
+        for row, bs in zip(vals, sizes):
+            for k, v in zip(keys, row):
+                out[k] += v * bs
+            # reference bookkeeping (vaes.py:494-495): accumulated ll / current chunk size
+            out['loss_mse'] += losses.gaussian_ll_to_mse(out['loss_ll'] / bs, n_dims) * bs
+        for k in out:
+            out[k] = float(out[k] / batch_size)
+        out['beta'] = beta
+        return out
+
+
+class ConvAEPSEncoder(ConvAEEncoder):
+    """Encoder with fixed orthogonal projections A (labels) / B (rest) and the diagonal label
+    map D (ref vaes.py:1276-1363)."""
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        n_latents = self.hparams['n_ae_latents']
+        n_labels = self.hparams['n_labels']
+        self.A = nn.Linear(n_latents, n_labels, bias=False)
+        self.B = nn.Linear(n_latents, n_latents - n_labels, bias=False)
+        self.D = DiagLinear(n_labels, bias=True)
+        # rows of one random orthogonal matrix, frozen; seeded by numpy's global RNG like the
+        # reference (scipy.stats.ortho_group.rvs, vaes.py:1296-1302)
+        from scipy.stats import ortho_group
+        m = ortho_group.rvs(dim=n_latents).astype('float32')
+        with torch.no_grad():
+            self.A.weight = nn.Parameter(torch.from_numpy(m[:n_labels, :]), requires_grad=False)
+            self.B.weight = nn.Parameter(torch.from_numpy(m[n_labels:, :]), requires_grad=False)
+
+    def __str__(self):
+        out = 'Encoder architecture:\n'
+        i = 0
+        for i, module in enumerate(self.encoder):
+            out += '    {:02d}: {}\n'.format(i, module)
+        i += 1
+        out += '    {:02d}: {}\n'.format(i, self.FF)
+        out += '    {:02d}: {} (to constrained latents)\n'.format(i, self.A)
+        out += '    {:02d}: {} (to unconstrained latents)\n'.format(i, self.B)
+        out += '    {:02d}: {} (constrained latents to labels)\n'.format(i, self.D)
+        return out
+
+    def forward(self, x, dataset=None):
+        """-> (y, w, logvar, pool_idx, output_sizes)."""
+        x1 = self._features(x, dataset)
+        h = linear(x1, self.FF.weight, self.FF.bias)
+        y = linear(h, self.A.weight, None)
+        w = linear(h, self.B.weight, None)
+        return y, w, linear(x1, self.logvar.weight, self.logvar.bias), [], []
+
+
+class PSVAE(AE):
+    """Partitioned-subspace VAE (ref vaes.py:506-846)."""
+
+    def __init__(self, hparams):
+        if hparams['model_type'] == 'linear':
+            raise NotImplementedError
+        if hparams['n_ae_latents'] < hparams['n_labels']:
+            raise ValueError('PS-VAE model must contain at least as many latents as labels')
+        self.n_latents = hparams['n_ae_latents']
+        self.n_labels = hparams['n_labels']
+        hparams['variational'] = True
+        super().__init__(hparams)
+        self.curr_epoch = 0
+        self.beta_vals, self.kl_anneal_vals = _anneal_tables(
+            hparams['ps_vae.beta'], self.hparams.get('ps_vae.anneal_epochs', 0),
+            hparams['max_n_epochs'], tail_is_beta=True)
+
+    def build_model(self):
+        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
+        if self.model_type == 'conv':
+            self.encoding = ConvAEPSEncoder(self.hparams)
+            self.decoding = ConvAEDecoder(self.hparams)
+        elif self.model_type == 'linear':
+            raise NotImplementedError
+        else:
+            raise ValueError('"%s" is an invalid model_type' % self.model_type)
+
+    def forward(self, x, dataset=None, use_mean=False, **kwargs):
+        """-> (x_hat, z, mu, logvar, y_hat)."""
+        y, w, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
+        mu = torch.cat([y, w], dim=1)
+        z = mu if use_mean else reparameterize(mu, logvar)
+        x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+        y_hat = self.encoding.D(y)
+        return x_hat, z, mu, logvar, y_hat
+
+    def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
+        """Modified ELBO of the PS-VAE (ref vaes.py:603-729); returns the same 11 keys."""
+        x = data['images'][0]
+        y = data['labels'][0]
+        m = data['masks'][0] if 'masks' in data else None
+        n = data['labels_masks'][0] if 'labels_masks' in data else None
+        batch_size = x.shape[0]
+        n_chunks = int(np.ceil(batch_size / chunk_size))
+        n_labels = self.hparams['n_labels']
+        alpha = self.hparams['ps_vae.alpha']
+        beta = self.beta_vals[self.curr_epoch]
+        kl = self.kl_anneal_vals[self.curr_epoch]
+
+        pairs, y_hat_all = [], []
+        for chunk in range(n_chunks):
+            beg = chunk * chunk_size
+            end = min((chunk + 1) * chunk_size, batch_size)
+            x_in, y_in = x[beg:end], y[beg:end]
+            m_in = m[beg:end] if m is not None else None
+            n_in = n[beg:end] if n is not None else None
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                x_hat, sample, mu, logvar, y_hat = self.forward(
+                    x_in, dataset=dataset, use_mean=False)
+                t = {}
+                t['loss_data_ll'] = losses.gaussian_ll(x_in, x_hat, m_in)
+                t['loss_label_ll'] = losses.gaussian_ll(y_in, y_hat, n_in)
+                t['loss_zs_kl'] = losses.kl_div_to_std_normal(
+                    mu[:, :n_labels].contiguous(), logvar[:, :n_labels].contiguous())
+                mi, tc, dwkl = losses.decomposed_kl(
+                    sample[:, n_labels:], mu[:, n_labels:], logvar[:, n_labels:])
+                t['loss_zu_mi'], t['loss_zu_tc'], t['loss_zu_dwkl'] = mi, tc, dwkl
+                t['loss'] = -t['loss_data_ll'] - float(alpha) * t['loss_label_ll'] \
+                    + t['loss_zs_kl'] + float(kl) * mi + float(beta) * tc + float(kl) * dwkl
+            if accumulate_grad:
+                t['loss'].backward()
+            pairs.append((t, end - beg))
+            y_hat_all.append(y_hat.detach())
+
+        keys, vals, sizes = _collect(pairs, batch_size)
+        order = ['loss', 'loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi',
+                 'loss_zu_tc', 'loss_zu_dwkl']
+        out = {k: 0.0 for k in order}
+        out['loss_data_mse'] = 0.0
+        n_dims = np.prod(x.shape[1:])
+        for row, bs in zip(vals, sizes):
+            for k, v in zip(keys, row):
+                out[k] += v * bs
+            # reference bookkeeping (vaes.py:705-706): accumulated ll / current chunk size
+            out['loss_data_mse'] += losses.gaussian_ll_to_mse(
+                out['loss_data_ll'] / bs, n_dims) * bs
+
+        y_hat_np = torch.cat(y_hat_all, dim=0).cpu().numpy()
+        y_np = y.detach().cpu().numpy()
+        if n is not None:
+            n_np = n.detach().cpu().numpy()
+            r2 = _r2_variance_weighted(y_np[n_np == 1], y_hat_np[n_np == 1])
+        else:
+            r2 = _r2_variance_weighted(y_np, y_hat_np)
+
+        for k in out:
+            out[k] = float(out[k] / batch_size)
+        out['alpha'] = alpha
+        out['beta'] = beta
+        out['label_r2'] = r2
+        return out
+
+    def get_predicted_labels(self, x, dataset=None, use_mean=True):
+        y, w, logvar, _, _ = self.encoding(x, dataset=dataset)
+        if not use_mean:
+            y = reparameterize(y, logvar[:, :self.n_labels].contiguous())
+        return self.encoding.D(y)
+
+    def get_transformed_latents(self, inputs, dataset=None, as_numpy=True):
+        """Latents with the supervised block mapped to label space by D (ref vaes.py:755-800)."""
+        if not isinstance(inputs, torch.Tensor):
+            inputs = torch.Tensor(inputs)
+        if len(inputs.shape) == 2:
+            y_og = inputs[:, :self.hparams['n_labels']]
+            w_og = inputs[:, self.hparams['n_labels']:]
+        else:
+            y_og, w_og, _, _, _ = self.encoding(inputs, dataset=dataset)
+        out = torch.cat([self.encoding.D(y_og), w_og], dim=1)
+        return out.cpu().detach().numpy() if as_numpy else out
+
+    def get_inverse_transformed_latents(self, inputs, dataset=None, as_numpy=True):
+        """Inverse of :meth:`get_transformed_latents` for latent inputs (ref vaes.py:802-846)."""
+        if not isinstance(inputs, torch.Tensor):
+            inputs = torch.Tensor(inputs)
+        if len(inputs.shape) != 2:
+            raise NotImplementedError
+        y_og = inputs[:, :self.hparams['n_labels']]
+        w_og = inputs[:, self.hparams['n_labels']:]
+        y_new = torch.div(torch.sub(y_og, self.encoding.D.bias), self.encoding.D.weight)
+        out = torch.cat([y_new, w_og], dim=1)
+        return out.cpu().detach().numpy() if as_numpy else out

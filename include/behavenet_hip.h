@@ -1,0 +1,188 @@
+/*
+ * behavenet_hip.h -- C ABI of libbehavenet_hip.so: the MI355X (gfx950) kernels underneath the
+ * BehaveNet conv-autoencoder hot path.
+ *
+ * The reference (themattinthehatt/behavenet) is pure Python and has no FFI of its own: its hot
+ * path bottoms out in third-party ATen operators called from `torch.nn` modules.  Each entry
+ * point below replaces one such operator call site (cited as reference file:line) with a
+ * hand-written HIP kernel.  Everything above this boundary is Python glue.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - tensors are fp32, contiguous, NCHW (images) or row-major (matrices);
+ *   - the caller owns every buffer; the library never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *   - return value: 0 on success, a positive hipError_t if a launch failed, a negative
+ *     BN_E_* code for an argument/shape error.  No entry point throws or exits.
+ *   - "accumulate != 0" means the gradient outputs are added to (+=) instead of overwritten,
+ *     which is how the reference accumulates over its 200-frame chunks (aes.py:751-771).
+ */
+#ifndef BEHAVENET_HIP_H
+#define BEHAVENET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BN_E_BADARG   (-1)  /* null pointer / non-positive size */
+#define BN_E_SHAPE    (-2)  /* geometry not representable (e.g. kernel larger than supported) */
+#define BN_E_WORKSPACE (-3) /* caller-provided workspace too small */
+
+/* activation codes for fused epilogues */
+#define BN_ACT_NONE    0
+#define BN_ACT_LRELU   1    /* LeakyReLU(slope)  -- aes.py:114,341 */
+#define BN_ACT_SIGMOID 2    /* Sigmoid           -- aes.py:330 */
+
+typedef void* bn_stream_t;
+
+/* library / build info */
+int         bn_version(void);                 /* ABI version, currently 1 */
+const char* bn_build_arch(void);              /* "gfx950" */
+const char* bn_error_string(int code);        /* static string for a BN_E_* / hip code */
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution (replaces ZeroPad2d + nn.Conv2d + LeakyReLU, aes.py:81-86,113-114,145-155).
+ *   y[n,k,p,q] = act( b[k] + sum_{c,r,s} x[n,c,p*stride+r-pad_t,q*stride+s-pad_l] * w[k,c,r,s] )
+ * reads outside [0,H)x[0,W) are zero, so TF-"same" asymmetric padding needs no padded copy.
+ * x:(N,C,H,W) w:(K,C,R,S) b:(K) or NULL  y:(N,K,P,Q)
+ * ------------------------------------------------------------------------------------------ */
+int bn_conv2d_fwd(const float* x, const float* w, const float* b, float* y,
+                  int N, int C, int H, int W, int K, int R, int S, int stride,
+                  int pad_t, int pad_l, int P, int Q,
+                  int act, float slope, bn_stream_t stream);
+
+/* dx[n,c,h,w] = act'(dact_src[n,c,h,w]) * sum_{k,r,s} dy[n,k,p,q] * w[k,c,r,s],
+ * p*stride+r-pad_t == h.  `dy` is the gradient w.r.t. the PRE-activation of this layer.
+ * `dact_src` (nullable) is the saved post-activation input of this layer (= output of the layer
+ * below); when given, the derivative of the lower layer's activation `dact` is applied in the
+ * epilogue so dx is the lower layer's pre-activation gradient (autograd of aes.py:203-211). */
+int bn_conv2d_bwd_data(const float* dy, const float* w, float* dx, const float* dact_src,
+                       int N, int C, int H, int W, int K, int R, int S, int stride,
+                       int pad_t, int pad_l, int P, int Q,
+                       int dact, float slope, bn_stream_t stream);
+
+/* dw[k,c,r,s] (+)= sum_{n,p,q} dy[n,k,p,q] * x[n,c,p*stride+r-pad_t,q*stride+s-pad_l]
+ * db[k]       (+)= sum_{n,p,q} dy[n,k,p,q]                      (db nullable)
+ * `ws` is scratch of at least bn_conv2d_bwd_weight_ws_bytes(...) bytes (deterministic two-pass
+ * reduction; no atomics). */
+size_t bn_conv2d_bwd_weight_ws_bytes(int N, int C, int H, int W, int K, int R, int S, int stride,
+                                     int pad_t, int pad_l, int P, int Q);
+int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                         int N, int C, int H, int W, int K, int R, int S, int stride,
+                         int pad_t, int pad_l, int P, int Q,
+                         int accumulate, void* ws, size_t ws_bytes, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Transposed convolution (replaces nn.ConvTranspose2d + crop F.pad(x,[-l,-r,-t,-b]) +
+ * LeakyReLU/Sigmoid, aes.py:315-321,326-341,466-470).  The crop (or torch `padding`) is folded
+ * into the output index range; the un-cropped tensor is never materialised:
+ *   y[n,co,h,w] = act( b[co] + sum_{ci,r,s} x[n,ci,p,q] * w[ci,co,r,s] ),
+ *   p*stride + r == h + crop_t,  q*stride + s == w + crop_l,  0<=h<Ho, 0<=w<Wo.
+ * x:(N,Ci,Hi,Wi) w:(Ci,Co,R,S) b:(Co) or NULL  y:(N,Co,Ho,Wo)
+ * ------------------------------------------------------------------------------------------ */
+int bn_convT2d_fwd(const float* x, const float* w, const float* b, float* y,
+                   int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
+                   int crop_t, int crop_l, int Ho, int Wo,
+                   int act, float slope, bn_stream_t stream);
+
+/* dx[n,ci,p,q] = act'(dact_src[n,ci,p,q]) * sum_{co,r,s} dy[n,co,p*stride+r-crop_t,...] * w[ci,co,r,s] */
+int bn_convT2d_bwd_data(const float* dy, const float* w, float* dx, const float* dact_src,
+                        int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
+                        int crop_t, int crop_l, int Ho, int Wo,
+                        int dact, float slope, bn_stream_t stream);
+
+/* dw[ci,co,r,s] (+)= sum_{n,p,q} x[n,ci,p,q] * dy[n,co,p*stride+r-crop_t,q*stride+s-crop_l]
+ * db[co]        (+)= sum_{n,h,w} dy[n,co,h,w] */
+size_t bn_convT2d_bwd_weight_ws_bytes(int N, int Ci, int Hi, int Wi, int Co, int R, int S,
+                                      int stride, int crop_t, int crop_l, int Ho, int Wo);
+int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw, float* db,
+                          int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
+                          int crop_t, int crop_l, int Ho, int Wo,
+                          int accumulate, void* ws, size_t ws_bytes, bn_stream_t stream);
+
+/* dpre[i] = dy[i] * act'(y[i]) where y is the saved POST-activation output
+ * (autograd of LeakyReLU / Sigmoid at the top of a conv stack).  In-place (dpre == dy) allowed. */
+int bn_act_bwd(const float* dy, const float* y, float* dpre, size_t n,
+               int act, float slope, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense latent projections (replaces nn.Linear, aes.py:121,125,266 and the PS-VAE heads
+ * vaes.py:1288-1302).  MFMA (v_mfma_f32_32x32x2_f32: exact fp32).
+ *   y[m,n] = b[n] + sum_k x[m,k] * w[n,k]        x:(M,K) w:(N,K) b:(N) or NULL  y:(M,N)
+ * ------------------------------------------------------------------------------------------ */
+int bn_linear_fwd(const float* x, const float* w, const float* b, float* y,
+                  int M, int K, int N, bn_stream_t stream);
+/* dx[m,k] = act'(dact_src[m,k]) * sum_n dy[m,n] w[n,k]   (dx, dact_src nullable)
+ * dw[n,k] (+)= sum_m dy[m,n] x[m,k]   db[n] (+)= sum_m dy[m,n]   (dw, db nullable) */
+int bn_linear_bwd(const float* x, const float* w, const float* dy,
+                  float* dx, const float* dact_src, int dact, float slope,
+                  float* dw, float* db, int accumulate,
+                  int M, int K, int N, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pixel losses (replaces losses.mse / losses.gaussian_ll, losses.py:56-59,84-96).
+ * frame_sums[n] = sum_d (pred[n,d]-target[n,d])^2 * mask[n,d]   (mask nullable), d < D.
+ * The caller turns frame sums into mse (sum/(N*D)) or gaussian ll; see fitting/losses.py.
+ * ------------------------------------------------------------------------------------------ */
+int bn_sqerr_frame_sums(const float* pred, const float* target, const float* mask,
+                        float* frame_sums, int N, size_t D, bn_stream_t stream);
+/* dpred[i] = (*gscale) * scale * 2 * (pred[i]-target[i]) * mask[i];  gscale: device scalar or NULL */
+int bn_sqerr_bwd(const float* pred, const float* target, const float* mask, float* dpred,
+                 size_t n, float scale, const float* gscale, bn_stream_t stream);
+/* out[0] = sum_i in[i] * scale  (deterministic single-workgroup tree; n small) */
+int bn_reduce_sum(const float* in, float* out, size_t n, float scale, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Variational tail (replaces vaes.reparameterize + losses.kl_div_to_std_normal,
+ * vaes.py:33-35, losses.py:146-147).  NOTE std = exp(logvar), as in the reference.
+ *   z = mu + eps*exp(logvar);  kl_rows[n] = 0.5*sum_d(exp(lv) - lv + mu^2 - 1)
+ * ------------------------------------------------------------------------------------------ */
+int bn_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z,
+                   size_t n, bn_stream_t stream);
+int bn_kl_rows(const float* mu, const float* logvar, float* kl_rows, int N, int D,
+               bn_stream_t stream);
+/* autograd of the two ops above:
+ *   dlogvar[i] = dz[i] * (z[i] - mu[i])                       (dmu = dz needs no kernel)
+ *   dmu[i] = s*mu[i], dlogvar[i] = s*0.5*(exp(logvar[i])-1),  s = scale * (*gscale) */
+int bn_reparam_bwd(const float* dz, const float* z, const float* mu, float* dlogvar, size_t n,
+                   bn_stream_t stream);
+int bn_kl_bwd(const float* mu, const float* logvar, float* dmu, float* dlogvar, size_t n,
+              float scale, const float* gscale, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser (replaces torch.optim.Adam(amsgrad=True).step, training.py:284-286,352), over one
+ * flat fp32 parameter arena.  `step` is 1-based.  weight_decay adds wd*p to the gradient.
+ * ------------------------------------------------------------------------------------------ */
+int bn_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax, size_t n,
+                         float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int step, bn_stream_t stream);
+
+/* uint8 frames -> float32/255 (replaces the host-side astype(float32)/255 of
+ * data_generator.py:251-263 for device-resident uint8 trials) */
+int bn_u8_to_unit_float(const unsigned char* in, float* out, size_t n, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * In-library kernel timing used by bench.py's roofline line: when enabled, every launch of the
+ * selected kernel family is bracketed by hipEvents on its own stream.
+ * ------------------------------------------------------------------------------------------ */
+#define BN_PROF_NONE        0
+#define BN_PROF_CONV_FWD    1
+#define BN_PROF_CONV_BWD_D  2
+#define BN_PROF_CONV_BWD_W  3
+#define BN_PROF_CONVT_FWD   4
+#define BN_PROF_CONVT_BWD_D 5
+#define BN_PROF_CONVT_BWD_W 6
+#define BN_PROF_ADAM        7
+/* select family + optional geometry filter (C<=0 / K<=0 = any).  Resets the accumulators. */
+int bn_prof_select(int family, int C, int K);
+/* host-synchronising: total milliseconds and launch count since bn_prof_select */
+int bn_prof_read(double* total_ms, long* launches);
+/* name of the device kernel that served the most recent launch of the selected family */
+const char* bn_prof_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEHAVENET_HIP_H */

@@ -1,0 +1,64 @@
+"""Build (hparams, inputs) for the golden cases without touching the reference."""
+
+import json
+import os
+
+import numpy as np
+import torch
+
+from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+from tests.golden_utils import base_hparams, make_frames, make_labels
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    return z, meta
+
+
+def case_hparams(meta):
+    arch = load_handcrafted_arch(list(meta['dim']), meta['n_lat'], None, check_memory=False)
+    hp = base_hparams(arch, meta['model_class'], meta['extra_hp'])
+    if meta['n_labels']:
+        hp['n_labels'] = meta['n_labels']
+    return hp
+
+
+def case_data(meta, device='cpu'):
+    x = torch.from_numpy(make_frames(meta['n_frames'], meta['dim'], seed=1)).to(device)
+    data = {'images': x[None]}
+    if meta['n_labels']:
+        y = torch.from_numpy(make_labels(meta['n_frames'], meta['n_labels'], seed=2)).to(device)
+        data['labels'] = y[None]
+    return data
+
+
+def seeded_build(builder, hp):
+    """Construct a model exactly as make_golden.py constructed the reference one."""
+    np.random.seed(0)
+    torch.manual_seed(0)
+    return builder(hp)
+
+
+class EpsReplay(object):
+    """Feeds recorded eps tensors (in order) to reparameterize."""
+
+    def __init__(self, tensors, device='cpu'):
+        self.tensors = [torch.from_numpy(np.asarray(t)).to(device) for t in tensors]
+        self.i = 0
+
+    def __call__(self, like):
+        t = self.tensors[self.i]
+        self.i += 1
+        assert t.shape == like.shape
+        return t
+
+
+def eps_list(z, prefix):
+    out, i = [], 0
+    while prefix + str(i) in z.files:
+        out.append(z[prefix + str(i)])
+        i += 1
+    return out

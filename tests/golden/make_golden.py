@@ -1,0 +1,286 @@
+"""Generate golden vectors by importing the REAL reference (themattinthehatt/behavenet).
+
+Run in the build container only (the reference is mounted read-only at /root/reference and
+never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Outputs small fixtures next to this file:
+  planner.json          layer-planner outputs for several input shapes / arch jsons
+  ae_<case>.npz         AE forward/backward/Adam(amsgrad) trajectories
+  vae_cfg1.npz, psvae_cfg4.npz, condvae_cfg1.npz, betatc_cfg1.npz   variational variants
+  fit_cfg1.json         metric rows of the reference fit() driven by the repo's synthetic
+                        generator stub (behavenet_amd.data.data_generator)
+
+Large tensors (weights: 8.7 M floats) are NOT stored; they are pinned through float64
+checksums and strided samples -- the same torch version + seed regenerates them bit-exactly
+(checked by tests/test_oracle_golden.py).  Inputs are regenerated from numpy seeds.
+"""
+
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)   # repo first: both trees have a `tests` package
+sys.dont_write_bytecode = True
+
+# --- commentjson shim (absent in this image; the reference only needs .load) ---------------
+_shim = types.ModuleType('commentjson')
+
+
+def _cj_load(f):
+    txt = '\n'.join(line.split('#')[0] for line in f.read().splitlines())
+    return json.loads(txt)
+
+
+_shim.load = _cj_load
+sys.modules['commentjson'] = _shim
+
+from behavenet.models import ae_model_architecture_generator as ref_arch  # noqa: E402
+from behavenet.models.aes import AE as RefAE  # noqa: E402
+from behavenet.models.vaes import (  # noqa: E402
+    VAE as RefVAE, PSVAE as RefPSVAE, ConditionalVAE as RefCondVAE, BetaTCVAE as RefBetaTC)
+from behavenet.fitting.training import fit as ref_fit  # noqa: E402
+
+from tests.golden_utils import (  # noqa: E402
+    checksum, strided_sample, make_frames, make_labels, base_hparams)
+
+torch.set_num_threads(8)
+
+
+def jsonable(o):
+    if isinstance(o, dict):
+        return {k: jsonable(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [jsonable(v) for v in o]
+    if isinstance(o, (np.integer,)):
+        return int(o)
+    if isinstance(o, (np.floating,)):
+        return float(o)
+    return o
+
+
+def planner_fixture():
+    out = {}
+    cases = {
+        'default_1x32x32': ([1, 32, 32], 8, None),
+        'default_1x128x128': ([1, 128, 128], 12, None),
+        'default_2x128x128': ([2, 128, 128], 16, None),
+        'default_1x64x48': ([1, 64, 48], 8, None),
+        'arch2_2x128x128': ([2, 128, 128], 12, 'ae_arch_2.json'),
+        'archdefault_1x128x128': ([1, 128, 128], 12, 'ae_arch_default.json'),
+    }
+    for name, (dim, n_lat, js) in cases.items():
+        path = None if js is None else os.path.join(REF, 'configs', 'ae_jsons', js)
+        arch = ref_arch.load_handcrafted_arch(list(dim), n_lat, path, check_memory=False)
+        out[name] = {'input_dim': dim, 'n_ae_latents': n_lat, 'arch_json': js,
+                     'arch': jsonable(arch)}
+    # calculate_output_dim grid
+    grid = []
+    for layer_type in ['conv', 'maxpool']:
+        for pad in ['same', 'valid']:
+            for inp in [15, 16, 17, 31, 32, 64, 128]:
+                for k in ([2] if layer_type == 'maxpool' else [3, 4, 5, 7]):
+                    for s in [1, 2, 3, 5]:
+                        if pad == 'valid' and inp < k:
+                            continue
+                        r = ref_arch.calculate_output_dim(inp, k, s, pad, layer_type)
+                        grid.append([inp, k, s, pad, layer_type] + [int(v) for v in r])
+    out['calculate_output_dim'] = grid
+    with open(os.path.join(HERE, 'planner.json'), 'w') as f:
+        json.dump(out, f)
+    print('planner.json written')
+
+
+def tensor_record(store, prefix, t, full_limit=4096):
+    a = t.detach().cpu().numpy()
+    store[prefix + '/checksum'] = checksum(a)
+    if a.size <= full_limit:
+        store[prefix + '/full'] = a.astype(np.float32)
+    else:
+        store[prefix + '/sample'] = strided_sample(a)
+
+
+def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None, n_labels=0,
+               chunked=False, store_xhat=True):
+    arch = ref_arch.load_handcrafted_arch(list(dim), n_lat, None, check_memory=False)
+    hp = base_hparams(arch, model_class, extra_hp)
+    if n_labels:
+        hp['n_labels'] = n_labels
+    np.random.seed(0)            # PS-VAE draws its orthogonal A/B from numpy's global RNG
+    torch.manual_seed(0)
+    model = RefModel(hp)
+    model.train()
+    store = {}
+    for k, v in model.state_dict().items():
+        tensor_record(store, 'param0/' + k, v, full_limit=1024)
+
+    x = torch.from_numpy(make_frames(n_frames, dim, seed=1))
+    data = {'images': x[None]}
+    if n_labels:
+        y = torch.from_numpy(make_labels(n_frames, n_labels, seed=2))
+        data['labels'] = y[None]
+
+    # eps: record what torch's CPU generator hands to reparameterize so that the oracle and the
+    # device run can be fed the same noise
+    variational = model_class in ('vae', 'ps-vae', 'cond-vae', 'beta-tcvae')
+    eps_log = []
+    if variational:
+        import behavenet.models.vaes as ref_vaes
+        orig = ref_vaes.reparameterize
+
+        def recording(mu, logvar):
+            std = torch.exp(logvar)
+            eps = torch.randn_like(std)
+            eps_log.append(eps.clone())
+            return eps.mul(std).add_(mu)
+        ref_vaes.reparameterize = recording
+
+    # forward taps
+    acts = []
+    hooks = []
+    for mod_name, mod in model.named_modules():
+        if isinstance(mod, (torch.nn.LeakyReLU, torch.nn.Sigmoid)):
+            hooks.append(mod.register_forward_hook(
+                lambda m, i, o, nm=mod_name: acts.append((nm, o.detach().clone()))))
+    torch.manual_seed(123)
+    with torch.no_grad():
+        kw = {}
+        if model_class == 'cond-vae':
+            kw = {'labels': data['labels'][0], 'labels_2d': None}
+        n_fwd = min(n_frames, 8)
+        if model_class == 'cond-vae':
+            kw['labels'] = kw['labels'][:n_fwd]
+        out = model(x[:n_fwd], dataset=0, **kw)
+    for h in hooks:
+        h.remove()
+    for nm, a in acts:
+        store['act/' + nm + '/checksum'] = checksum(a.numpy())
+    x_hat = out[0]
+    if store_xhat:
+        store['fwd/x_hat'] = x_hat.numpy().astype(np.float32)
+    else:
+        store['fwd/x_hat_first'] = x_hat[:1].numpy().astype(np.float32)
+    store['fwd/x_hat/checksum'] = checksum(x_hat.numpy())
+    names = {2: ['z'], 4: ['z', 'mu', 'logvar'], 5: ['z', 'mu', 'logvar', 'y_hat']}[len(out)]
+    for nm, t in zip(names, out[1:]):
+        store['fwd/' + nm] = t.numpy().astype(np.float32)
+    if variational:
+        store['fwd/eps'] = eps_log[0].numpy()
+        eps_log.clear()
+
+    # loss + grads (fresh eps stream for the loss call)
+    torch.manual_seed(124)
+    model.zero_grad()
+    model.curr_epoch = 3 if variational else 0
+    loss_dict = model.loss(data, dataset=0, accumulate_grad=True)
+    store['loss/keys'] = np.array(sorted(loss_dict.keys()))
+    store['loss/vals'] = np.array([float(loss_dict[k]) for k in sorted(loss_dict.keys())],
+                                  dtype=np.float64)
+    if variational:
+        for i, e in enumerate(eps_log):
+            store['loss/eps%d' % i] = e.numpy()
+        eps_log.clear()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            tensor_record(store, 'grad/' + k, p.grad, full_limit=4096)
+
+    # 3 Adam(amsgrad) steps, as training.py:284-286,336-352 (epoch > 0)
+    opt = torch.optim.Adam(model.get_parameters(), lr=hp['learning_rate'],
+                           weight_decay=hp.get('l2_reg', 0), amsgrad=True)
+    traj = []
+    for step in range(3):
+        torch.manual_seed(200 + step)
+        opt.zero_grad()
+        ld = model.loss(data, dataset=0, accumulate_grad=True)
+        opt.step()
+        traj.append(float(ld['loss']))
+        if variational:
+            for i, e in enumerate(eps_log):
+                store['adam/eps_step%d_%d' % (step, i)] = e.numpy()
+            eps_log.clear()
+    store['adam/losses'] = np.array(traj, dtype=np.float64)
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        tensor_record(store, 'adam/param/' + k, p, full_limit=1024)
+        st = opt.state[p]
+        for sk in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
+            store['adam/%s/%s/checksum' % (sk, k)] = checksum(st[sk].numpy())
+
+    if variational:
+        ref_vaes.reparameterize = orig
+
+    meta = {'dim': list(dim), 'n_lat': n_lat, 'n_frames': n_frames, 'model_class': model_class,
+            'n_labels': n_labels, 'extra_hp': extra_hp or {}, 'n_fwd': n_fwd,
+            'curr_epoch': model.curr_epoch if variational else 0}
+    store['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **store)
+    print('%s written (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+
+
+class ListExp(object):
+    """Stand-in for test_tube.Experiment: collects rows."""
+    version = 0
+
+    def __init__(self):
+        self.rows = []
+
+    def log(self, row):
+        self.rows.append(dict(row))
+
+    def save(self):
+        pass
+
+
+def fit_fixture():
+    from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSessionsGenerator
+    dim = [1, 32, 32]
+    arch = ref_arch.load_handcrafted_arch(list(dim), 8, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    with tempfile.TemporaryDirectory() as tmp:
+        hp.update({'expt_dir': tmp, 'max_n_epochs': 2, 'min_n_epochs': 0,
+                   'val_check_interval': 1, 'enable_early_stop': False,
+                   'early_stop_history': 10, 'rng_seed_train': 0, 'export_latents': False})
+        os.makedirs(os.path.join(tmp, 'version_0'))
+        sess = SyntheticSession(10, 32, dim, seed=0, trial_splits='8;1;1;0')
+        gen = SyntheticSessionsGenerator([sess], device='cpu', placement='host')
+        torch.manual_seed(0)
+        model = RefAE(hp)
+        model.version = 0
+        exp = ListExp()
+        ref_fit(hp, model, gen, exp, method='ae')
+        final = {k: checksum(v.numpy()).tolist() for k, v in model.state_dict().items()}
+    with open(os.path.join(HERE, 'fit_cfg1.json'), 'w') as f:
+        json.dump({'rows': jsonable(exp.rows), 'final_param_checksums': final}, f)
+    print('fit_cfg1.json written:', len(exp.rows), 'rows')
+
+
+if __name__ == '__main__':
+    planner_fixture()
+    model_case('ae_cfg1', RefAE, [1, 32, 32], 8, 8, 'ae')
+    model_case('ae_cfg1_b210', RefAE, [1, 32, 32], 8, 210, 'ae', store_xhat=True)
+    model_case('ae_cfg2', RefAE, [1, 128, 128], 12, 4, 'ae')
+    model_case('ae_1x64x48', RefAE, [1, 64, 48], 8, 6, 'ae')
+    model_case('vae_cfg1', RefVAE, [1, 32, 32], 8, 8, 'vae',
+               extra_hp={'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0, 'max_n_epochs': 10})
+    model_case('betatc_cfg1', RefBetaTC, [1, 32, 32], 8, 8, 'beta-tcvae',
+               extra_hp={'vae.beta': 1.0, 'vae.beta_anneal_epochs': 0, 'beta_tcvae.beta': 3.0,
+                         'beta_tcvae.beta_anneal_epochs': 5, 'max_n_epochs': 10})
+    model_case('condvae_cfg1', RefCondVAE, [1, 32, 32], 8, 8, 'cond-vae', n_labels=4,
+               extra_hp={'vae.beta': 1.0, 'vae.beta_anneal_epochs': 0, 'max_n_epochs': 10,
+                         'conditional_encoder': False})
+    model_case('psvae_cfg4', RefPSVAE, [2, 128, 128], 16, 6, 'ps-vae', n_labels=4,
+               extra_hp={'ps_vae.alpha': 1000, 'ps_vae.beta': 5, 'ps_vae.anneal_epochs': 100,
+                         'max_n_epochs': 10}, store_xhat=False)
+    fit_fixture()

@@ -1,0 +1,48 @@
+"""Helpers shared by the golden-vector generator and the tests that consume the fixtures."""
+
+import numpy as np
+
+
+def checksum(a):
+    """[sum, sum|.|, sum(.^2), size] in float64 -- pins a large tensor without storing it."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    return np.array([a.sum(), np.abs(a).sum(), (a * a).sum(), a.size], dtype=np.float64)
+
+
+def strided_sample(a, n=64):
+    a = np.asarray(a).ravel()
+    idx = np.linspace(0, a.size - 1, n).astype(np.int64)
+    return a[idx].astype(np.float32)
+
+
+def checksum_close(got, want, rtol):
+    """Compare two checksum vectors; the abs-sum sets the scale for the signed sum."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    if got[3] != want[3]:
+        return False
+    scale = max(want[1], 1e-30)
+    return (abs(got[0] - want[0]) <= rtol * scale and
+            abs(got[1] - want[1]) <= rtol * scale and
+            abs(got[2] - want[2]) <= 2 * rtol * max(want[2], 1e-30))
+
+
+def make_frames(n_frames, dim, seed):
+    """uint8 noise frames consumed as float32/255 (reference tests/integration.py:105-109)."""
+    rng = np.random.default_rng(seed)
+    u8 = rng.integers(0, 255, size=(n_frames,) + tuple(dim), dtype=np.uint8)
+    return u8.astype(np.float32) / 255
+
+
+def make_labels(n_frames, n_labels, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n_frames, n_labels)).astype(np.float32)
+
+
+def base_hparams(arch, model_class, extra=None):
+    hp = dict(arch)
+    hp.update({
+        'model_class': model_class, 'device': 'cpu', 'learning_rate': 1e-4, 'l2_reg': 0.0,
+        'fit_sess_io_layers': False, 'n_datasets': 1, 'rng_seed_model': 0})
+    if extra:
+        hp.update(extra)
+    return hp

@@ -1,0 +1,134 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) against golden vectors captured from the reference.
+
+The reference's own tests do not pin forward/backward numerics of the models
+(reference tests/README.md:13), so the golden vectors come from running the imported reference
+in the build container (tests/golden/make_golden.py).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from tests.cases import load_case, case_hparams, case_data, seeded_build, EpsReplay, eps_list
+from tests.golden_utils import checksum, checksum_close, strided_sample
+
+CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
+         'condvae_cfg1', 'psvae_cfg4']
+
+
+def _check_tensor(z, prefix, t, rtol, atol=1e-7):
+    a = t.detach().cpu().numpy()
+    assert checksum_close(checksum(a), z[prefix + '/checksum'], rtol), prefix
+    want = z[prefix + '/full'] if prefix + '/full' in z.files else z[prefix + '/sample']
+    got = a if prefix + '/full' in z.files else strided_sample(a)
+    # element tolerance relative to the tensor's own scale (tiny entries carry rounding noise)
+    atol = max(atol, rtol * float(np.abs(want).max())) if rtol > 0 else atol
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=prefix)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_oracle_matches_reference(name):
+    torch.set_num_threads(8)
+    z, meta = load_case(name)
+    hp = case_hparams(meta)
+    model = seeded_build(ref_cpu.build_model, hp)
+    variational = meta['model_class'] in ('vae', 'ps-vae', 'cond-vae', 'beta-tcvae')
+
+    # (i) identical initial parameters from the same seed (bit-exact)
+    sd = model.state_dict()
+    want_keys = sorted(k[len('param0/'):-len('/checksum')] for k in z.files
+                       if k.startswith('param0/') and k.endswith('/checksum'))
+    assert sorted(sd.keys()) == want_keys
+    for k, v in sd.items():
+        _check_tensor(z, 'param0/' + k, v, rtol=0.0, atol=0.0)
+
+    data = case_data(meta)
+    x = data['images'][0]
+    n_fwd = meta['n_fwd']
+
+    # (ii) forward: per-layer activation checksums, x_hat, latents
+    model.train()
+    taps_e, taps_d = [], []
+    with torch.no_grad():
+        if variational:
+            model.eps_fn = EpsReplay([z['fwd/eps']])
+        enc_out = model.encoding(x[:n_fwd], dataset=0, taps=taps_e)
+        kw = {}
+        if meta['model_class'] == 'cond-vae':
+            kw = {'labels': data['labels'][0][:n_fwd], 'labels_2d': None}
+        out = model(x[:n_fwd], dataset=0, **kw)
+    act_keys = [k for k in z.files if k.startswith('act/encoding')]
+    assert len(act_keys) == len(taps_e)
+    for i, t in enumerate(taps_e):
+        assert checksum_close(checksum(t.numpy()),
+                              z['act/encoding.encoder.relu%d/checksum' % i], 1e-6)
+    if 'fwd/x_hat' in z.files:
+        np.testing.assert_allclose(out[0].numpy(), z['fwd/x_hat'], rtol=1e-5, atol=1e-6)
+    else:
+        np.testing.assert_allclose(out[0][:1].numpy(), z['fwd/x_hat_first'], rtol=1e-5, atol=1e-6)
+    assert checksum_close(checksum(out[0].numpy()), z['fwd/x_hat/checksum'], 1e-6)
+    names = {2: ['z'], 4: ['z', 'mu', 'logvar'], 5: ['z', 'mu', 'logvar', 'y_hat']}[len(out)]
+    for nm, t in zip(names, out[1:]):
+        np.testing.assert_allclose(t.numpy(), z['fwd/' + nm], rtol=1e-5, atol=1e-6, err_msg=nm)
+
+    # (iii) loss dict + accumulated gradients (two chunks for the b210 case: SURVEY G2)
+    model.zero_grad()
+    if variational:
+        model.curr_epoch = meta['curr_epoch']
+        model.eps_fn = EpsReplay(eps_list(z, 'loss/eps'))
+    loss = model.loss(data, dataset=0, accumulate_grad=True)
+    keys = [str(k) for k in z['loss/keys']]
+    assert sorted(loss.keys()) == keys
+    got = np.array([float(loss[k]) for k in keys])
+    np.testing.assert_allclose(got, z['loss/vals'], rtol=1e-6, atol=1e-9)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            _check_tensor(z, 'grad/' + k, p.grad, rtol=2e-5, atol=1e-9)
+
+    # (iv) three Adam(amsgrad) steps
+    opt = ref_cpu.make_optimizer(model, hp)
+    losses = []
+    for step in range(3):
+        if variational:
+            model.eps_fn = EpsReplay(eps_list(z, 'adam/eps_step%d_' % step))
+        losses.append(ref_cpu.train_step(model, opt, data)['loss'])
+    np.testing.assert_allclose(losses, z['adam/losses'], rtol=1e-6)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            _check_tensor(z, 'adam/param/' + k, p, rtol=1e-6, atol=1e-8)
+            st = opt.state[p]
+            for sk in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
+                assert checksum_close(checksum(st[sk].numpy()),
+                                      z['adam/%s/%s/checksum' % (sk, k)], 1e-4), (sk, k)
+
+
+def test_oracle_loss_known_answers():
+    """The closed-form answers of the reference's tests/test_fitting/test_losses.py:8-94."""
+    LN2PI = np.log(2 * np.pi)
+    x = torch.rand((5, 3))
+    assert ref_cpu.mse(x, x) == 0
+    a = torch.tensor([1, 2, 3, 4, 5, 6], dtype=torch.float)
+    b = torch.tensor([2, 3, 4, 5, 6, 7], dtype=torch.float)
+    m = torch.tensor([1, 0, 1, 0, 1, 0], dtype=torch.float)
+    assert ref_cpu.mse(a, b, m) == 0.5
+
+    n_batch, n_dims = 5, 3
+    x = torch.rand((n_batch, n_dims))
+    assert ref_cpu.gaussian_ll(x, x) == -(0.5 * LN2PI) * n_dims
+    ones, zeros = torch.ones(n_batch, n_dims), torch.zeros(n_batch, n_dims)
+    mask = torch.zeros(n_batch, n_dims)
+    mask[:, 0] = 1
+    assert ref_cpu.gaussian_ll(ones, zeros, masks=mask) == -(0.5 * LN2PI) * n_dims - 0.5
+
+    ll = ref_cpu.gaussian_ll(ones, zeros)
+    mse_ = 2 * (-ll - 0.5 * LN2PI * n_dims) / n_dims
+    assert np.allclose(ref_cpu.gaussian_ll_to_mse(ll.numpy(), n_dims), mse_.numpy())
+
+    assert ref_cpu.kl_div_to_std_normal(torch.zeros(1, 1), torch.zeros(1, 1)) == 0
+
+    zz, mu, lv = torch.rand(5, 3), torch.rand(5, 3), torch.rand(5, 3)
+    mi, tc, dw = ref_cpu.decomposed_kl(zz, mu, lv)
+    assert ref_cpu.index_code_mi(zz, mu, lv).item() == mi.item()
+    assert ref_cpu.total_correlation(zz, mu, lv).item() == tc.item()
+    assert ref_cpu.dimension_wise_kl_to_std_normal(zz, mu, lv).item() == dw.item()
