@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Headline benchmark: conv-AE training frames/s, 128x128x1 frames, batch (= trial) 256.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" is one pass of the reference's hot loop over one 256-frame trial
+(training.py:336-352 with i_epoch > 0): zero_grad -> next_batch -> AE.loss(accumulate_grad=True)
+(chunks of 200 + 56 frames, forward + backward per chunk) -> [RCCL all-reduce of the flat
+gradient] -> Adam(amsgrad) step.  Trials are synthetic uint8-noise frames (float32/255) already
+resident in HBM.  With N > 1 every rank consumes its own trial per step (weak scaling) and the
+gradients are summed over ranks before the identical optimizer step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline:     enc.conv0 (the HBM-bound encoder conv BASELINE.json targets): algorithmic bytes
+                (589,824 B/frame = 65,536 in + 524,288 out) / HIP-event time of its launches
+                inside the timed region, vs 8 TB/s.
+  cpu_baseline: the CPU oracle (oracle/ref_cpu.py, the pinned restatement of the reference)
+                running the same step on this host's cores.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from behavenet_amd import _hip  # noqa: E402
+from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSessionsGenerator  # noqa: E402
+from behavenet_amd.fitting import distributed as bdist  # noqa: E402
+from behavenet_amd.fitting.optim import FlatAdamAMSGrad  # noqa: E402
+from behavenet_amd.models import AE  # noqa: E402
+from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+DIM = [1, 128, 128]
+N_LATENTS = 12
+BATCH = 256
+CONV0_BYTES_PER_FRAME = 65536 + 524288            # enc.conv0 in + out
+TRAIN_FLOP_PER_FRAME = 2.0843e9                   # fwd+bwd, 2*MAC
+
+
+def build_hparams():
+    arch = load_handcrafted_arch(list(DIM), N_LATENTS, None, check_memory=False)
+    hp = dict(arch)
+    hp.update({'model_class': 'ae', 'device': 'cuda', 'learning_rate': 1e-4, 'l2_reg': 0.0,
+               'fit_sess_io_layers': False, 'n_datasets': 1, 'rng_seed_model': 0})
+    return hp
+
+
+def one_step(model, opt, gen):
+    model.train()
+    opt.zero_grad()
+    data, dataset = gen.next_batch('train')
+    if data is None:
+        gen.reset_iterators('train')
+        data, dataset = gen.next_batch('train')
+    loss = model.loss(data, dataset=dataset, accumulate_grad=True)
+    bdist.all_reduce_flat_(opt.flat_g)
+    opt.step()
+    return loss
+
+
+def cpu_baseline(hp_template, budget_s=20.0):
+    """Time the CPU oracle on the same workload (bounded sample) on this host's cores."""
+    from oracle import ref_cpu
+    from tests.golden_utils import make_frames
+    hp = dict(hp_template)
+    hp['device'] = 'cpu'
+    torch.manual_seed(0)
+    model = ref_cpu.AE(hp)
+    opt = ref_cpu.make_optimizer(model, hp)
+    warm = {'images': torch.from_numpy(make_frames(16, DIM, seed=5))[None]}
+    ref_cpu.train_step(model, opt, warm)
+    data = {'images': torch.from_numpy(make_frames(BATCH, DIM, seed=6))[None]}
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        ref_cpu.train_step(model, opt, data)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or steps >= 5 or (steps >= 1 and el + el / steps > 1.5 * budget_s):
+            break
+    return {'value': BATCH * steps / el, 'unit': 'frames/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': '%d full training step(s) of the same workload (batch %d, chunks 200+56, '
+                      'fwd+bwd+Adam) in %.1f s, torch %s CPU' % (steps, BATCH, el,
+                                                                torch.__version__)}
+
+
+def profile_kernel(model, opt, gen, family, C, K, steps=2):
+    """HIP-event time per launch of one kernel family/geometry over a few extra steps."""
+    _hip.prof_select(family, C, K)
+    for _ in range(steps):
+        one_step(model, opt, gen)
+    torch.cuda.synchronize()
+    ms, n, name = _hip.prof_read()
+    _hip.prof_select(_hip.PROF_NONE)
+    return ms, n, name
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=20.0)
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False')
+    rank, world = bdist.init_from_env()
+    if world != max(1, args.gpus):
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    _hip.load()
+
+    hp = build_hparams()
+    torch.manual_seed(hp['rng_seed_model'])
+    model = AE(hp).to('cuda')
+    opt = FlatAdamAMSGrad(model.get_parameters(), lr=hp['learning_rate'],
+                          weight_decay=hp['l2_reg'])
+    bdist.broadcast_parameters_(opt.flat_p)
+
+    # 20 trials x 256 frames per rank, trial_splits 8;1;1;0 -> 16 train trials
+    sess = SyntheticSession(20, BATCH, DIM, seed=100 + rank, trial_splits='8;1;1;0')
+    gen = SyntheticSessionsGenerator([sess], device='cuda', placement='device')
+    torch.manual_seed(1 + rank)
+    np.random.seed(1 + rank)
+    gen.reset_iterators('train')
+
+    for _ in range(args.warmup):
+        one_step(model, opt, gen)
+
+    def barrier():
+        if bdist.is_active():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    _hip.prof_select(_hip.PROF_CONV_FWD, 1, 32)     # enc.conv0 launches inside the timed region
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = one_step(model, opt, gen)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    conv0_ms, conv0_n, conv0_name = _hip.prof_read()
+    _hip.prof_select(_hip.PROF_NONE)
+
+    if bdist.is_active():
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = BATCH * world * args.steps
+    value = frames / elapsed
+
+    # enc.conv0 roofline: every step launches it once per chunk (200 + 56 frames)
+    conv0_bytes = CONV0_BYTES_PER_FRAME * BATCH * args.steps
+    achieved = conv0_bytes / (conv0_ms * 1e-3) / 1e9 if conv0_ms > 0 else 0.0
+    traffic = None
+    tr_path = os.path.join(REPO, 'profiles', 'conv0_hbm_traffic.json')
+    if os.path.exists(tr_path):
+        with open(tr_path) as f:
+            traffic = json.load(f).get('hbm_bytes_per_launch_avg')
+    roofline = {
+        'bound': 'hbm', 'kernel': conv0_name, 'layer': 'enc.conv0 fwd (1->32, k5 s2, +bias+lrelu)',
+        'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 4),
+        'launches': conv0_n, 'avg_launch_us': round(conv0_ms * 1e3 / max(conv0_n, 1), 2),
+        'algorithmic_bytes_per_launch_avg': CONV0_BYTES_PER_FRAME * BATCH // 2,
+        'traffic': traffic}
+
+    out = {
+        'metric': 'AE training frames/sec (128x128x1, batch 256)',
+        'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'configs[1]: conv AE (default arch 32-64-128-256-512, k5, strides '
+                               '2,2,2,2,5), 1x128x128 uint8-noise frames as float32/255, 12 '
+                               'latents, one 256-frame trial per step per GPU (chunks 200+56), '
+                               'Adam(amsgrad) lr 1e-4',
+                   'frames_per_step_per_gpu': BATCH, 'global_frames_per_step': BATCH * world,
+                   'sharding': 'one trial per rank per step, RCCL all-reduce(sum) of the flat '
+                               '35 MB gradient' if world > 1 else 'single GPU',
+                   'inputs': 'resident in HBM'},
+        'final_loss': last['loss'] if last else None,
+        'whole_step_fp32_tflops': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12, 2),
+        'whole_step_fp32_frac': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12 /
+                                      FP32_PEAK_TFLOPS, 4),
+        'roofline': roofline,
+    }
+
+    if rank == 0 and world == 1:
+        # FLOP-bound middle layers, profiled over two extra (untimed) steps each
+        extra = []
+        for label, fam, C, K, flop_per_frame in [
+                ('enc.conv1 fwd', _hip.PROF_CONV_FWD, 32, 64, 104857600.0),
+                ('enc.conv2 fwd', _hip.PROF_CONV_FWD, 64, 128, 104857600.0),
+                ('enc.conv3 fwd', _hip.PROF_CONV_FWD, 128, 256, 104857600.0),
+                ('enc.conv1 bwd-weight', _hip.PROF_CONV_BWD_W, 32, 64, 104857600.0),
+                ('enc.conv1 bwd-data', _hip.PROF_CONV_BWD_D, 32, 64, 104857600.0)]:
+            ms, n, name = profile_kernel(model, opt, gen, fam, C, K)
+            if n:
+                tf = flop_per_frame * BATCH * 2 / (ms * 1e-3) / 1e12
+                extra.append({'layer': label, 'kernel': name, 'bound': 'mfma',
+                              'achieved': round(tf, 2), 'peak': FP32_PEAK_TFLOPS,
+                              'unit': 'TFLOP/s', 'frac': round(tf / FP32_PEAK_TFLOPS, 4),
+                              'avg_launch_us': round(ms * 1e3 / n, 1)})
+        out['roofline_other_kernels'] = extra
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(hp, args.cpu_budget)
+            out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if bdist.is_active():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

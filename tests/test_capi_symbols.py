@@ -1,0 +1,43 @@
+"""The C-ABI library loads and exports every symbol include/behavenet_hip.h declares
+(no compute calls: this runs without a GPU)."""
+
+import ctypes
+import os
+import re
+
+from behavenet_amd import _hip
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    with open(os.path.join(REPO, 'include', 'behavenet_hip.h')) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    names = re.findall(r'\b(bn_[a-zA-Z0-9_]+)\s*\(', text)
+    return sorted(set(names))
+
+
+def test_library_is_built():
+    assert os.path.exists(_hip.lib_path()), \
+        'libbehavenet_hip.so missing: run `python -c "import __graft_entry__ as g; g.build()"`'
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared_symbols()
+    assert len(names) >= 26
+    lib = ctypes.CDLL(_hip.lib_path())
+    for n in names:
+        assert hasattr(lib, n), 'header declares %s but the .so does not export it' % n
+    # the ctypes table covers the header one to one
+    assert sorted(_hip.SIGNATURES.keys()) == names
+
+
+def test_info_calls():
+    lib = _hip.load()
+    assert lib.bn_version() == 1
+    assert lib.bn_build_arch() == b'gfx950'
+    assert b'BN_E_SHAPE' in lib.bn_error_string(-2)
+    # argument errors are reported, not thrown
+    assert lib.bn_conv2d_fwd(None, None, None, None, *([1] * 12), 0, 0.0, None) == -1
+    assert lib.bn_prof_select(99, 0, 0) == -1

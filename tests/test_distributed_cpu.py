@@ -1,0 +1,96 @@
+"""world_size-2 gloo checks of the data-parallel host logic (runs on CPU).
+
+With the CPU oracle model standing in for the HIP model: frame-sharded chunks whose local loss
+is scaled to the global chunk mean, followed by ONE all-reduce (sum) of the flat gradient,
+must reproduce the single-process gradient of AE.loss."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from behavenet_amd.fitting import distributed as bdist
+from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+from oracle import ref_cpu
+from tests.golden_utils import base_hparams, make_frames
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _sharded_grad(model, x, chunk_size):
+    """'frames' mode: local slice of every chunk, loss scaled to the global chunk mean."""
+    B = x.shape[0]
+    per_elem = int(np.prod(x.shape[1:]))
+    for beg in range(0, B, chunk_size):
+        end = min(beg + chunk_size, B)
+        lb, le = bdist.shard_bounds(beg, end)
+        if le <= lb:
+            continue
+        x_in = x[lb:le]
+        x_hat, _ = model(x_in, dataset=0)
+        loss = ((x_in - x_hat) ** 2).sum() / ((end - beg) * per_elem)
+        loss.backward()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+                       'RANK': str(rank), 'WORLD_SIZE': str(world)})
+    torch.set_num_threads(2)
+    r, w = bdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world) and bdist.is_active()
+    arch = load_handcrafted_arch([1, 32, 32], 8, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    torch.manual_seed(0)
+    model = ref_cpu.AE(hp)
+    x = torch.from_numpy(make_frames(50, [1, 32, 32], seed=3))
+    _sharded_grad(model, x, chunk_size=30)
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    bdist.all_reduce_flat_(flat)
+    tot = bdist.all_reduce_scalars([1.0, float(rank)])
+    if rank == 0:
+        out.put((flat.numpy(), tot))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_sharded_gradient_matches_single_process():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat, tot = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert tot == [2.0, 1.0]
+
+    arch = load_handcrafted_arch([1, 32, 32], 8, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    torch.manual_seed(0)
+    model = ref_cpu.AE(hp)
+    x = torch.from_numpy(make_frames(50, [1, 32, 32], seed=3))
+    model.loss({'images': x[None]}, dataset=0, accumulate_grad=True, chunk_size=30)
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
+    scale = np.abs(want).max()
+    np.testing.assert_allclose(flat, want, rtol=1e-4, atol=1e-6 * scale)
+
+
+def test_shard_bounds_partition():
+    for n in [1, 7, 56, 200]:
+        for R in [1, 2, 3, 8]:
+            edges = [bdist.shard_bounds(10, 10 + n, r, R) for r in range(R)]
+            assert edges[0][0] == 10 and edges[-1][1] == 10 + n
+            for a, b in zip(edges[:-1], edges[1:]):
+                assert a[1] == b[0]

@@ -1,0 +1,315 @@
+"""Kernel-level parity on the MI355X: every C-ABI entry point (called through ctypes) against the
+CPU oracle's operators on the same seeded inputs.
+
+Tolerance (fp32 path, BASELINE.json north_star: 1e-4 relative): every element must satisfy
+|got - want| <= 1e-4 * |want| + 1e-5 * max|want|, and the scale-normalised max error must be
+below 2e-5 (accumulation order differs from mkldnn; the MFMA path is an exact fp32 fmaf chain).
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from behavenet_amd import _hip
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+SLOPE = 0.05
+
+
+def close(got, want, rtol=1e-4, norm_tol=2e-5, name=''):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want)
+    assert err.max() / scale <= norm_tol, '%s: normalised max err %.3e' % (name, err.max() / scale)
+    assert np.all(err <= rtol * np.abs(want) + 1e-5 * scale), name
+
+
+def act_ref(t, act):
+    if act == _hip.ACT_LRELU:
+        return F.leaky_relu(t, SLOPE)
+    if act == _hip.ACT_SIGMOID:
+        return torch.sigmoid(t)
+    return t
+
+
+# (name, N, C, H, W, K, R, stride, (pad_t, pad_b), (pad_l, pad_r))
+CONV_CASES = [
+    ('E0', 3, 1, 128, 128, 32, 5, 2, (1, 2), (1, 2)),
+    ('E1', 2, 32, 64, 64, 64, 5, 2, (1, 2), (1, 2)),
+    ('E2', 2, 64, 32, 32, 128, 5, 2, (1, 2), (1, 2)),
+    ('E3', 3, 128, 16, 16, 256, 5, 2, (1, 2), (1, 2)),
+    ('E4', 5, 256, 8, 8, 512, 5, 5, (1, 1), (1, 1)),
+    ('E4_cfg1', 4, 256, 2, 2, 512, 5, 5, (1, 2), (1, 2)),
+    ('E0_2ch', 2, 2, 128, 128, 32, 5, 2, (1, 2), (1, 2)),
+    ('k4s2', 2, 5, 17, 19, 7, 4, 2, (1, 2), (1, 1)),
+    ('k3s1', 2, 4, 9, 11, 6, 3, 1, (1, 1), (1, 1)),
+    ('k7s2_valid', 2, 3, 21, 18, 9, 7, 2, (0, 0), (0, 0)),
+    ('nonsquare_last', 3, 256, 4, 3, 512, 5, 5, (0, 1), (1, 1)),
+    ('odd_channels', 2, 33, 20, 20, 65, 5, 2, (1, 2), (1, 2)),
+]
+
+
+def _conv_setup(case, seed=0):
+    name, N, C, H, W, K, R, st, (pt, pb), (pl, pr) = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((N, C, H, W), generator=g) - 0.3
+    w = (torch.rand((K, C, R, R), generator=g) - 0.5) * (2.0 / np.sqrt(C * R * R))
+    b = torch.rand((K,), generator=g) - 0.5
+    P = (H + pt + pb - R) // st + 1
+    Q = (W + pl + pr - R) // st + 1
+    geom = (N, C, H, W, K, R, R, st, pt, pl, P, Q)
+    return x, w, b, geom, (pl, pr, pt, pb)
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_NONE])
+def test_conv2d_fwd(case, act):
+    x, w, b, geom, pad = _conv_setup(case)
+    want = act_ref(F.conv2d(F.pad(x, pad), w, b, stride=geom[7]), act)
+    got = _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, act, SLOPE)
+    close(got, want, name=case[0])
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_bwd(case):
+    x, w, b, geom, pad = _conv_setup(case, seed=1)
+    N, C, H, W, K, R, S, st, pt, pl, P, Q = geom
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    b.requires_grad_(True)
+    # x plays the role of a post-LeakyReLU activation of the layer below
+    xin = F.leaky_relu(x, SLOPE)
+    xin.retain_grad()
+    y = F.conv2d(F.pad(xin, pad), w, b, stride=st)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.rand(y.shape, generator=g) - 0.5
+    y.backward(dy)
+
+    dyd, wd = dy.to(DEV), w.detach().to(DEV)
+    xind = xin.detach().to(DEV).contiguous()
+    # plain data gradient, and the fused form that applies lrelu'(input) in the epilogue
+    close(_hip.conv2d_bwd_data(dyd, wd, geom, None, _hip.ACT_NONE, SLOPE), xin.grad,
+          name=case[0] + ' dx')
+    close(_hip.conv2d_bwd_data(dyd, wd, geom, xind, _hip.ACT_LRELU, SLOPE), x.grad,
+          name=case[0] + ' dx*lrelu')
+    dw = torch.full_like(wd, 7.0)
+    db = torch.full((K,), 7.0, device=DEV)
+    _hip.conv2d_bwd_weight(xind, dyd, dw, db, geom, False)
+    close(dw, w.grad, name=case[0] + ' dw')
+    close(db, b.grad, name=case[0] + ' db')
+    # accumulate: a second call adds on top (cross-chunk accumulation)
+    _hip.conv2d_bwd_weight(xind, dyd, dw, db, geom, True)
+    close(dw, 2 * w.grad, name=case[0] + ' dw acc')
+    close(db, 2 * b.grad, name=case[0] + ' db acc')
+
+
+# (name, N, Ci, Hi, Wi, Co, R, stride, torch_padding, crop(l,r,t,b) or None, output_padding)
+CONVT_CASES = [
+    ('D0', 5, 512, 2, 2, 256, 5, 5, (1, 1), None, 0),
+    ('D0_cfg1', 4, 512, 1, 1, 256, 5, 5, 0, (1, 2, 1, 2), 0),
+    ('D1', 3, 256, 8, 8, 128, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('D2', 2, 128, 16, 16, 64, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('D3', 2, 64, 32, 32, 32, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('D4', 3, 32, 64, 64, 1, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('D4_2ch', 2, 32, 64, 64, 2, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('k4s2', 2, 7, 9, 10, 5, 4, 2, (1, 1), None, 0),
+    ('k3s1', 2, 6, 9, 11, 4, 3, 1, (1, 1), None, 0),
+    ('valid_outpad', 2, 9, 8, 6, 3, 7, 2, 0, None, (1, 0)),
+    ('nonsquare_first', 3, 512, 1, 1, 256, 5, 5, 0, (1, 1, 0, 1), 0),
+    ('odd_channels', 2, 65, 10, 10, 33, 5, 2, 0, (1, 2, 1, 2), 0),
+]
+
+
+def _convT_setup(case, seed=0):
+    name, N, Ci, Hi, Wi, Co, R, st, tpad, crop, opad = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((N, Ci, Hi, Wi), generator=g) - 0.3
+    w = (torch.rand((Ci, Co, R, R), generator=g) - 0.5) * (2.0 / np.sqrt(Ci * R * R / st / st))
+    b = torch.rand((Co,), generator=g) - 0.5
+    tp = (tpad, tpad) if isinstance(tpad, int) else tpad
+    op = (opad, opad) if isinstance(opad, int) else opad
+    if crop is not None:
+        crop_t, crop_l = crop[2], crop[0]
+        Ho = (Hi - 1) * st + R - crop[2] - crop[3]
+        Wo = (Wi - 1) * st + R - crop[0] - crop[1]
+    else:
+        crop_t, crop_l = tp
+        Ho = (Hi - 1) * st + R - 2 * tp[0] + op[0]
+        Wo = (Wi - 1) * st + R - 2 * tp[1] + op[1]
+    geom = (N, Ci, Hi, Wi, Co, R, R, st, crop_t, crop_l, Ho, Wo)
+
+    def ref(xx, ww, bb):
+        y = F.conv_transpose2d(xx, ww, bb, stride=st, padding=tp, output_padding=op)
+        if crop is not None:
+            y = F.pad(y, [-c for c in crop])
+        return y
+    return x, w, b, geom, ref
+
+
+@pytest.mark.parametrize('case', CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
+@pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_SIGMOID])
+def test_convT2d_fwd(case, act):
+    x, w, b, geom, ref = _convT_setup(case)
+    want = act_ref(ref(x, w, b), act)
+    assert tuple(want.shape[2:]) == (geom[10], geom[11])
+    got = _hip.convT2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, act, SLOPE)
+    close(got, want, name=case[0])
+
+
+@pytest.mark.parametrize('case', CONVT_CASES, ids=[c[0] for c in CONVT_CASES])
+def test_convT2d_bwd(case):
+    x, w, b, geom, ref = _convT_setup(case, seed=1)
+    Co = geom[4]
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    b.requires_grad_(True)
+    xin = F.leaky_relu(x, SLOPE)
+    xin.retain_grad()
+    y = ref(xin, w, b)
+    g = torch.Generator().manual_seed(5)
+    dy = torch.rand(y.shape, generator=g) - 0.5
+    y.backward(dy)
+    dyd, wd = dy.to(DEV), w.detach().to(DEV)
+    xind = xin.detach().to(DEV).contiguous()
+    close(_hip.convT2d_bwd_data(dyd, wd, geom, None, _hip.ACT_NONE, SLOPE), xin.grad,
+          name=case[0] + ' dx')
+    close(_hip.convT2d_bwd_data(dyd, wd, geom, xind, _hip.ACT_LRELU, SLOPE), x.grad,
+          name=case[0] + ' dx*lrelu')
+    dw = torch.full_like(wd, -3.0)
+    db = torch.full((Co,), -3.0, device=DEV)
+    _hip.convT2d_bwd_weight(xind, dyd, dw, db, geom, False)
+    close(dw, w.grad, name=case[0] + ' dw')
+    close(db, b.grad, name=case[0] + ' db')
+    _hip.convT2d_bwd_weight(xind, dyd, dw, db, geom, True)
+    close(dw, 2 * w.grad, name=case[0] + ' dw acc')
+
+
+@pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_SIGMOID, _hip.ACT_NONE])
+def test_act_bwd(act):
+    g = torch.Generator().manual_seed(0)
+    pre = (torch.rand((7, 33, 5), generator=g) - 0.5).requires_grad_(True)
+    y = act_ref(pre, act)
+    dy = torch.rand(y.shape, generator=g)
+    y.backward(dy)
+    got = _hip.act_bwd(dy.to(DEV), y.detach().to(DEV), act, SLOPE)
+    close(got, pre.grad, name='act_bwd')
+
+
+@pytest.mark.parametrize('M,K,N', [(200, 2048, 12), (56, 2048, 12), (200, 12, 2048), (7, 512, 8),
+                                   (33, 16, 4), (5, 37, 65), (200, 2048, 16)])
+def test_linear(M, K, N):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.rand((M, K), generator=g) - 0.4).requires_grad_(True)
+    w = ((torch.rand((N, K), generator=g) - 0.5) / np.sqrt(K)).requires_grad_(True)
+    b = (torch.rand((N,), generator=g) - 0.5).requires_grad_(True)
+    y = F.linear(x, w, b)
+    dy = torch.rand(y.shape, generator=g) - 0.5
+    y.backward(dy)
+    xd, wd, bd, dyd = x.detach().to(DEV), w.detach().to(DEV), b.detach().to(DEV), dy.to(DEV)
+    close(_hip.linear_fwd(xd, wd, bd), y, name='linear fwd')
+    close(_hip.linear_fwd(xd, wd, None), F.linear(x, w), name='linear fwd nobias')
+    dw = torch.empty_like(wd)
+    db = torch.empty((N,), device=DEV)
+    dx = _hip.linear_bwd(xd, wd, dyd, True, None, _hip.ACT_NONE, 0.0, dw, db, False)
+    close(dx, x.grad, name='linear dx')
+    close(dw, w.grad, name='linear dw')
+    close(db, b.grad, name='linear db')
+    _hip.linear_bwd(xd, wd, dyd, False, None, _hip.ACT_NONE, 0.0, dw, db, True)
+    close(dw, 2 * w.grad, name='linear dw acc')
+
+
+@pytest.mark.parametrize('shape,masked', [((5, 1, 32, 32), False), ((3, 2, 128, 128), True),
+                                          ((6, 4), True), ((7, 3), False), ((200, 1, 128, 128), False)])
+def test_sqerr(shape, masked):
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(shape, generator=g)
+    b = torch.rand(shape, generator=g)
+    m = (torch.rand(shape, generator=g) > 0.3).float() if masked else None
+    d = (a - b) ** 2
+    if m is not None:
+        d = d * m
+    want = d.reshape(shape[0], -1).sum(dim=1)
+    md = m.to(DEV) if m is not None else None
+    got = _hip.sqerr_frame_sums(a.to(DEV), b.to(DEV), md)
+    close(got, want, name='frame sums')
+    close(_hip.reduce_sum(got, 0.25), 0.25 * want.sum(), name='reduce')
+    gs = torch.tensor(0.7, device=DEV)
+    dpred = _hip.sqerr_bwd(a.to(DEV), b.to(DEV), md, 0.1, gs)
+    want_d = 0.7 * 0.1 * 2 * (a - b)
+    if m is not None:
+        want_d = want_d * m
+    close(dpred, want_d, name='sqerr bwd')
+
+
+def test_reparam_and_kl():
+    g = torch.Generator().manual_seed(4)
+    mu = (torch.rand((37, 12), generator=g) - 0.5).requires_grad_(True)
+    lv = (torch.rand((37, 12), generator=g) - 0.5).requires_grad_(True)
+    eps = torch.randn((37, 12), generator=g)
+    z = eps * torch.exp(lv) + mu
+    dz = torch.rand(z.shape, generator=g)
+    z.backward(dz)
+    mud, lvd = mu.detach().to(DEV), lv.detach().to(DEV)
+    zd = _hip.reparam_fwd(mud, lvd, eps.to(DEV))
+    close(zd, z, name='reparam')
+    close(_hip.reparam_bwd(dz.to(DEV), zd, mud), lv.grad, name='reparam dlogvar')
+
+    mu.grad = None
+    lv.grad = None
+    kl = torch.mean(0.5 * torch.sum(lv.exp() - lv + mu.pow(2) - 1, dim=1))
+    kl.backward()
+    rows = _hip.kl_rows(mud, lvd)
+    close(_hip.reduce_sum(rows, 1.0 / 37), kl, name='kl')
+    dmu, dlv = _hip.kl_bwd(mud, lvd, 1.0 / 37, None)
+    close(dmu, mu.grad, name='kl dmu')
+    close(dlv, lv.grad, name='kl dlogvar')
+
+
+@pytest.mark.parametrize('wd', [0.0, 0.01])
+def test_adam_amsgrad_trajectory(wd):
+    g = torch.Generator().manual_seed(6)
+    n = 100003
+    p0 = torch.rand(n, generator=g) - 0.5
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=wd, amsgrad=True)
+    pd = p0.to(DEV)
+    m, v, vmax = (torch.zeros(n, device=DEV) for _ in range(3))
+    for step in range(1, 6):
+        grad = torch.rand(n, generator=g) - 0.5
+        if step == 3:
+            grad = grad * 0.01   # makes max_exp_avg_sq matter
+        ref.grad = grad.clone()
+        opt.step()
+        _hip.adam_amsgrad_step(pd, grad.to(DEV), m, v, vmax, 1e-3, 0.9, 0.999, 1e-8, wd, step)
+    close(pd, ref.detach(), rtol=1e-5, norm_tol=1e-6, name='adam p')
+    st = opt.state[ref]
+    close(m, st['exp_avg'], name='adam m')
+    close(v, st['exp_avg_sq'], name='adam v')
+    close(vmax, st['max_exp_avg_sq'], name='adam vmax')
+
+
+def test_u8_to_unit_float_bit_exact():
+    rng = np.random.default_rng(0)
+    u8 = rng.integers(0, 256, size=(3, 1, 37, 41), dtype=np.uint8)
+    want = u8.astype(np.float32) / 255
+    got = _hip.u8_to_unit_float(torch.from_numpy(u8).to(DEV)).cpu().numpy()
+    assert np.array_equal(got, want)
+    allv = np.arange(256, dtype=np.uint8)
+    got = _hip.u8_to_unit_float(torch.from_numpy(allv).to(DEV)).cpu().numpy()
+    assert np.array_equal(got, allv.astype(np.float32) / 255)
+
+
+def test_errors_are_loud():
+    x = torch.zeros((1, 1, 8, 8))
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.conv2d_fwd(x, x, None, (1, 1, 8, 8, 1, 3, 3, 1, 1, 1, 8, 8), 0, 0.0)   # CPU tensor
+    xd = torch.zeros((1, 1, 8, 8), device=DEV)
+    wd = torch.zeros((1, 1, 11, 11), device=DEV)
+    with pytest.raises(_hip.HipLibraryError):   # kernel larger than supported -> BN_E_SHAPE
+        _hip.conv2d_fwd(xd, wd, None, (1, 1, 8, 8, 1, 11, 11, 1, 5, 5, 8, 8), 0, 0.0)
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.conv2d_fwd(xd.double(), wd, None, (1, 1, 8, 8, 1, 11, 11, 1, 5, 5, 8, 8), 0, 0.0)

@@ -1,0 +1,301 @@
+"""Model-level parity on the MI355X: the HIP-backed models (behavenet_amd.models) against
+
+  (a) the CPU oracle (oracle/ref_cpu.py) on the same seeded inputs -- full tensors;
+  (b) the committed golden vectors captured from the imported reference (tests/golden/*.npz);
+  (c) size-independent properties at BASELINE's full size (batch 256, two chunks).
+
+Tolerance: 1e-4 relative (BASELINE.json north_star), applied as in tests/test_gpu_kernels.py.
+"""
+
+import copy
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from behavenet_amd import _hip
+from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSessionsGenerator
+from behavenet_amd.fitting.optim import FlatAdamAMSGrad
+from behavenet_amd.fitting.training import fit
+from behavenet_amd.fitting import losses
+from behavenet_amd.models import AE, VAE, ConditionalVAE, BetaTCVAE, PSVAE
+from behavenet_amd.models import vaes as hip_vaes
+from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+from oracle import ref_cpu
+from tests.cases import load_case, case_hparams, case_data, seeded_build, EpsReplay, eps_list
+from tests.golden_utils import base_hparams, checksum, checksum_close, make_frames
+from tests.test_gpu_kernels import close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+BUILDERS = {'ae': AE, 'vae': VAE, 'cond-vae': ConditionalVAE, 'beta-tcvae': BetaTCVAE,
+            'ps-vae': PSVAE}
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _pair(meta):
+    """(hip model on the GPU, oracle on the CPU) with identical parameters."""
+    hp_h, hp_o = case_hparams(meta), case_hparams(meta)
+    hip = seeded_build(BUILDERS[meta['model_class']], hp_h).to(DEV)
+    ora = seeded_build(ref_cpu.build_model, hp_o)
+    for (k1, v1), (k2, v2) in zip(hip.state_dict().items(), ora.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2)
+    return hip, ora, hp_h
+
+
+CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
+         'condvae_cfg1', 'psvae_cfg4']
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_forward_loss_grads_vs_oracle_and_golden(name):
+    z, meta = load_case(name)
+    hip, ora, hp = _pair(meta)
+    variational = meta['model_class'] in ('vae', 'ps-vae', 'cond-vae', 'beta-tcvae')
+    data_c = case_data(meta)
+    data_g = {k: v.to(DEV) for k, v in data_c.items()}
+    n_fwd = meta['n_fwd']
+    kw_c, kw_g = {}, {}
+    if meta['model_class'] == 'cond-vae':
+        kw_c = {'labels': data_c['labels'][0][:n_fwd], 'labels_2d': None}
+        kw_g = {'labels': data_g['labels'][0][:n_fwd], 'labels_2d': None}
+
+    # forward (same eps on both sides, the one the reference drew)
+    hip.train()
+    ora.train()
+    if variational:
+        ora.eps_fn = EpsReplay([z['fwd/eps']])
+        hip_vaes.set_eps_provider(EpsReplay([z['fwd/eps']], DEV))
+    try:
+        with torch.no_grad():
+            out_o = ora(data_c['images'][0][:n_fwd], dataset=0, **kw_c)
+            out_h = hip(data_g['images'][0][:n_fwd], dataset=0, **kw_g)
+        for i, (a, b) in enumerate(zip(out_h, out_o)):
+            close(a, b, name='%s fwd out%d' % (name, i))
+        # against the reference itself
+        if 'fwd/x_hat' in z.files:
+            close(out_h[0], torch.from_numpy(z['fwd/x_hat']), name=name + ' x_hat golden')
+        assert checksum_close(checksum(out_h[0].cpu().numpy()), z['fwd/x_hat/checksum'], 2e-5)
+        close(out_h[1], torch.from_numpy(z['fwd/z']), name=name + ' z golden')
+
+        # loss dict and accumulated gradients
+        hip.zero_grad()
+        ora.zero_grad()
+        if variational:
+            hip.curr_epoch = ora.curr_epoch = meta['curr_epoch']
+            ora.eps_fn = EpsReplay(eps_list(z, 'loss/eps'))
+            hip_vaes.set_eps_provider(EpsReplay(eps_list(z, 'loss/eps'), DEV))
+        loss_o = ora.loss(data_c, dataset=0, accumulate_grad=True)
+        loss_h = hip.loss(data_g, dataset=0, accumulate_grad=True)
+    finally:
+        hip_vaes.set_eps_provider(None)
+    assert sorted(loss_h.keys()) == sorted(loss_o.keys()) == [str(k) for k in z['loss/keys']]
+    for k, want in zip([str(k) for k in z['loss/keys']], z['loss/vals']):
+        assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-7), k
+        assert loss_h[k] == pytest.approx(float(want), rel=1e-4, abs=1e-7), k
+    for (k, ph), (_, po) in zip(hip.named_parameters(), ora.named_parameters()):
+        if po.grad is None:
+            assert ph.grad is None or not ph.requires_grad
+            continue
+        close(ph.grad, po.grad, name='%s grad %s' % (name, k))
+        assert checksum_close(checksum(ph.grad.cpu().numpy()), z['grad/' + k + '/checksum'],
+                              1e-4), k
+
+
+@pytest.mark.parametrize('name', ['ae_cfg1', 'ae_cfg2', 'vae_cfg1'])
+def test_adam_trajectory_vs_oracle_and_golden(name):
+    z, meta = load_case(name)
+    hip, ora, hp = _pair(meta)
+    variational = meta['model_class'] != 'ae'
+    data_c = case_data(meta)
+    data_g = {k: v.to(DEV) for k, v in data_c.items()}
+    opt_o = ref_cpu.make_optimizer(ora, hp)
+    opt_h = FlatAdamAMSGrad(hip.get_parameters(), lr=hp['learning_rate'],
+                            weight_decay=hp.get('l2_reg', 0))
+    if variational:
+        hip.curr_epoch = ora.curr_epoch = meta['curr_epoch']
+    losses_h = []
+    try:
+        for step in range(3):
+            if variational:
+                ora.eps_fn = EpsReplay(eps_list(z, 'adam/eps_step%d_' % step))
+                hip_vaes.set_eps_provider(EpsReplay(eps_list(z, 'adam/eps_step%d_' % step), DEV))
+            ref_cpu.train_step(ora, opt_o, data_c)
+            hip.train()
+            opt_h.zero_grad()
+            losses_h.append(hip.loss(data_g, dataset=0, accumulate_grad=True)['loss'])
+            opt_h.step()
+    finally:
+        hip_vaes.set_eps_provider(None)
+    np.testing.assert_allclose(losses_h, z['adam/losses'], rtol=1e-4)
+    for i, ((k, ph), (_, po)) in enumerate(zip(hip.named_parameters(), ora.named_parameters())):
+        close(ph, po, rtol=1e-4, norm_tol=1e-5, name='%s adam %s' % (name, k))
+        assert checksum_close(checksum(ph.detach().cpu().numpy()),
+                              z['adam/param/' + k + '/checksum'], 1e-5), k
+    # optimizer state of the first and the largest tensor
+    for i in (0, 8):
+        m, v, vmax = opt_h.state_tensors(i)
+        st = opt_o.state[list(ora.get_parameters())[i]]
+        close(m, st['exp_avg'], name='exp_avg')
+        close(v, st['exp_avg_sq'], name='exp_avg_sq')
+        close(vmax, st['max_exp_avg_sq'], name='max_exp_avg_sq')
+
+
+def test_fit_on_gpu_reproduces_reference_rows(tmp_path):
+    with open(os.path.join(GOLDEN, 'fit_cfg1.json')) as f:
+        want = json.load(f)
+    dim = [1, 32, 32]
+    arch = load_handcrafted_arch(list(dim), 8, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    hp.update({'expt_dir': str(tmp_path), 'max_n_epochs': 2, 'min_n_epochs': 0,
+               'val_check_interval': 1, 'enable_early_stop': False, 'early_stop_history': 10,
+               'rng_seed_train': 0, 'export_latents': True, 'progress_bar': False,
+               'device': 'cuda'})
+    os.makedirs(os.path.join(str(tmp_path), 'version_0'))
+    sess = SyntheticSession(10, 32, dim, seed=0, trial_splits='8;1;1;0')
+    gen = SyntheticSessionsGenerator([sess], device=DEV, placement='device_u8')
+    torch.manual_seed(0)
+    model = AE(hp).to(DEV)
+    model.version = 0
+
+    class Exp(object):
+        version = 0
+        rows = []
+
+        def log(self, row):
+            self.rows.append(dict(row))
+
+        def save(self):
+            pass
+    exp = Exp()
+    best = fit(hp, model, gen, exp, method='ae')
+    assert len(exp.rows) == len(want['rows'])
+    for got, ref in zip(exp.rows, want['rows']):
+        assert set(got.keys()) == set(ref.keys())
+        for k, v in ref.items():
+            if isinstance(v, float):
+                assert got[k] == pytest.approx(v, rel=1e-4), k
+            else:
+                assert got[k] == v, k
+    for k, v in model.state_dict().items():
+        assert checksum_close(checksum(v.cpu().numpy()), want['final_param_checksums'][k], 1e-5)
+
+    # checkpoint is key-compatible with the reference / the oracle
+    sd = torch.load(os.path.join(str(tmp_path), 'version_0', 'best_val_model.pt'),
+                    map_location='cpu')
+    ora = ref_cpu.AE(case_hparams({'dim': dim, 'n_lat': 8, 'model_class': 'ae',
+                                   'extra_hp': {}, 'n_labels': 0}))
+    ora.load_state_dict(sd)
+
+    # export_latents: pickle schema + values against the oracle encoder
+    pkl = os.path.join(str(tmp_path), 'version_0', 'lab_expt_animal_sess_latents.pkl')
+    with open(pkl, 'rb') as f:
+        lat = pickle.load(f)
+    assert set(lat.keys()) == {'latents', 'trials'}
+    assert len(lat['latents']) == 10 and set(lat['trials'].keys()) == {'train', 'val', 'test'}
+    ora.load_state_dict({k: v.cpu() for k, v in best.state_dict().items()})
+    x0 = torch.from_numpy(sess.images_u8[0].astype(np.float32) / 255)
+    with torch.no_grad():
+        z0 = ora.encoding(x0)[0]
+    assert lat['latents'][0].shape == (32, 8)
+    close(torch.from_numpy(lat['latents'][0]), z0, name='exported latents')
+
+
+def test_full_size_batch256_properties():
+    """BASELINE config 2 at full size (1x128x128, 12 latents, batch 256 = chunks 200+56)."""
+    arch = load_handcrafted_arch([1, 128, 128], 12, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    torch.manual_seed(0)
+    model = AE(hp).to(DEV)
+    x = torch.from_numpy(make_frames(256, [1, 128, 128], seed=11)).to(DEV)
+    data = {'images': x[None]}
+
+    # (1) determinism: two runs give bit-identical loss and gradients
+    def run():
+        model.zero_grad(set_to_none=True)
+        out = model.loss(data, dataset=0, accumulate_grad=True)
+        return out['loss'], [p.grad.clone() for p in model.parameters()]
+    l1, g1 = run()
+    l2, g2 = run()
+    assert l1 == l2
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+
+    # (2) chunk additivity: grad(batch) = grad(first 200) + grad(last 56), and the
+    #     reported loss is the frame-weighted mean of the chunk losses (G3)
+    model.zero_grad(set_to_none=True)
+    la = model.loss({'images': x[None, :200]}, dataset=0, accumulate_grad=True)['loss']
+    ga = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad(set_to_none=True)
+    lb = model.loss({'images': x[None, 200:]}, dataset=0, accumulate_grad=True)['loss']
+    gb = [p.grad.clone() for p in model.parameters()]
+    assert l1 == pytest.approx((la * 200 + lb * 56) / 256, rel=1e-6)
+    for g, a, b in zip(g1, ga, gb):
+        close(g, a + b, rtol=1e-5, norm_tol=1e-6, name='chunk additivity')
+
+    # (3) frame independence: reconstructing a sub-batch gives the same frames
+    with torch.no_grad():
+        full, _ = model(x[:64])
+        part, _ = model(x[32:40])
+    close(part, full[32:40], rtol=1e-6, norm_tol=1e-6, name='frame independence')
+
+    # (4) the loss value equals the oracle's on a 16-frame sample of the same batch
+    ora = ref_cpu.AE(case_hparams({'dim': [1, 128, 128], 'n_lat': 12, 'model_class': 'ae',
+                                   'extra_hp': {}, 'n_labels': 0}))
+    ora.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    lo = ora.loss({'images': x[None, :16].cpu()}, accumulate_grad=False)['loss']
+    lh = model.loss({'images': x[None, :16]}, accumulate_grad=False)['loss']
+    assert lh == pytest.approx(lo, rel=1e-5)
+
+
+def test_losses_known_answers_on_device():
+    """Closed-form answers of the reference's tests/test_fitting/test_losses.py:8-94."""
+    LN2PI = np.log(2 * np.pi)
+    x = torch.rand((5, 3), device=DEV)
+    assert losses.mse(x, x).item() == 0
+    a = torch.tensor([1, 2, 3, 4, 5, 6], dtype=torch.float, device=DEV)
+    b = torch.tensor([2, 3, 4, 5, 6, 7], dtype=torch.float, device=DEV)
+    m = torch.tensor([1, 0, 1, 0, 1, 0], dtype=torch.float, device=DEV)
+    assert losses.mse(a, b, m).item() == 0.5
+    n_batch, n_dims = 5, 3
+    assert losses.gaussian_ll(x, x).item() == pytest.approx(-(0.5 * LN2PI) * n_dims, rel=1e-6)
+    ones = torch.ones(n_batch, n_dims, device=DEV)
+    zeros = torch.zeros(n_batch, n_dims, device=DEV)
+    mask = torch.zeros(n_batch, n_dims, device=DEV)
+    mask[:, 0] = 1
+    assert losses.gaussian_ll(ones, zeros, masks=mask).item() == pytest.approx(
+        -(0.5 * LN2PI) * n_dims - 0.5, rel=1e-6)
+    ll = losses.gaussian_ll(ones, zeros)
+    mse_ = 2 * (-ll.item() - 0.5 * LN2PI * n_dims) / n_dims
+    assert np.allclose(losses.gaussian_ll_to_mse(ll.cpu().numpy(), n_dims), mse_)
+    assert losses.kl_div_to_std_normal(torch.zeros(1, 1, device=DEV),
+                                       torch.zeros(1, 1, device=DEV)).item() == 0
+    zz, mu, lv = (torch.rand(5, 3, device=DEV) for _ in range(3))
+    mi, tc, dw = losses.decomposed_kl(zz, mu, lv)
+    assert losses.index_code_mi(zz, mu, lv).item() == mi.item()
+    assert losses.total_correlation(zz, mu, lv).item() == tc.item()
+    assert losses.dimension_wise_kl_to_std_normal(zz, mu, lv).item() == dw.item()
+
+
+def test_deepcopy_after_arena_and_eval_no_grad_side_effects():
+    z, meta = load_case('ae_cfg1')
+    hip, ora, hp = _pair(meta)
+    data = {k: v.to(DEV) for k, v in case_data(meta).items()}
+    opt = FlatAdamAMSGrad(hip.get_parameters(), lr=1e-4)
+    opt.zero_grad()
+    hip.loss(data, accumulate_grad=True)
+    g = [p.grad.clone() for p in hip.parameters()]
+    hip.eval()
+    hip.loss(data, accumulate_grad=False)   # validation pass: gradients untouched
+    for a, p in zip(g, hip.parameters()):
+        assert torch.equal(a, p.grad)
+    hip.hparams = None
+    snap = copy.deepcopy(hip)
+    hip.hparams = snap.hparams = hp
+    opt.step()
+    changed = sum(int(not torch.equal(a, b)) for a, b in zip(
+        snap.state_dict().values(), hip.state_dict().values()))
+    assert changed == len(hip.state_dict())   # the snapshot does not alias the live arena
