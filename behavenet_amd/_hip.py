@@ -23,20 +23,24 @@ PROF_CONVT_FWD, PROF_CONVT_BWD_D, PROF_CONVT_BWD_W, PROF_ADAM = 4, 5, 6, 7
 _c_int, _c_float, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 
 _CONV_GEOM = [_c_int] * 12
+_ACT_WS = [_c_int, _c_float, _c_void_p, _c_size_t, _c_void_p]   # act, slope, ws, ws_bytes, stream
+
+OP_CONV_FWD, OP_CONV_BWD_D, OP_CONV_BWD_W = 1, 2, 3
+OP_CONVT_FWD, OP_CONVT_BWD_D, OP_CONVT_BWD_W = 4, 5, 6
 
 # name -> (restype, argtypes); mirrors include/behavenet_hip.h one to one
 SIGNATURES = {
     'bn_version': (_c_int, []),
     'bn_build_arch': (ctypes.c_char_p, []),
     'bn_error_string': (ctypes.c_char_p, [_c_int]),
-    'bn_conv2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
-    'bn_conv2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
-    'bn_conv2d_bwd_weight_ws_bytes': (_c_size_t, _CONV_GEOM),
+    'bn_set_force_generic': (_c_int, [_c_int]),
+    'bn_conv_ws_bytes': (_c_size_t, [_c_int] + _CONV_GEOM),
+    'bn_conv2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
+    'bn_conv2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_conv2d_bwd_weight': (
         _c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_void_p, _c_size_t, _c_void_p]),
-    'bn_convT2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
-    'bn_convT2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
-    'bn_convT2d_bwd_weight_ws_bytes': (_c_size_t, _CONV_GEOM),
+    'bn_convT2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
+    'bn_convT2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_convT2d_bwd_weight': (
         _c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_void_p, _c_size_t, _c_void_p]),
     'bn_act_bwd': (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_int, _c_float, _c_void_p]),
@@ -122,71 +126,79 @@ def _stream():
 _ws_cache = {}
 
 
-def _workspace(nbytes, device):
-    """Grow-only scratch arena per device (never shrinks, reused across calls on one stream)."""
+def _workspace(op, geom, device):
+    """(pointer, nbytes) of the grow-only scratch arena of `device` sized for this call."""
+    nbytes = load().bn_conv_ws_bytes(op, *geom)
     if nbytes == 0:
-        return None
+        return None, 0
     buf = _ws_cache.get(device)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[device] = buf
-    return buf
+    return buf.data_ptr(), nbytes
 
 
 def conv2d_fwd(x, w, b, geom, act, slope):
     N, C, H, W, K, R, S, st, pt, pl, P, Q = geom
     y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
+    ws, nb = _workspace(OP_CONV_FWD, geom, x.device)
     _check(load().bn_conv2d_fwd(
         _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), *geom,
-        act, slope, _stream()), 'bn_conv2d_fwd')
+        act, slope, ws, nb, _stream()), 'bn_conv2d_fwd')
     return y
 
 
 def conv2d_bwd_data(dy, w, geom, dact_src, dact, slope):
     N, C, H, W = geom[:4]
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    ws, nb = _workspace(OP_CONV_BWD_D, geom, dy.device)
     _check(load().bn_conv2d_bwd_data(
         _ptr(dy, 'dy'), _ptr(w, 'w'), _ptr(dx, 'dx'), _ptr(dact_src, 'dact_src', allow_none=True),
-        *geom, dact, slope, _stream()), 'bn_conv2d_bwd_data')
+        *geom, dact, slope, ws, nb, _stream()), 'bn_conv2d_bwd_data')
     return dx
 
 
 def conv2d_bwd_weight(x, dy, dw, db, geom, accumulate):
-    lib = load()
-    nbytes = lib.bn_conv2d_bwd_weight_ws_bytes(*geom)
-    ws = _workspace(nbytes, x.device)
-    _check(lib.bn_conv2d_bwd_weight(
+    ws, nb = _workspace(OP_CONV_BWD_W, geom, x.device)
+    _check(load().bn_conv2d_bwd_weight(
         _ptr(x, 'x'), _ptr(dy, 'dy'), _ptr(dw, 'dw'), _ptr(db, 'db', allow_none=True), *geom,
-        int(accumulate), ws.data_ptr() if ws is not None else None, nbytes, _stream()),
-        'bn_conv2d_bwd_weight')
+        int(accumulate), ws, nb, _stream()), 'bn_conv2d_bwd_weight')
 
 
 def convT2d_fwd(x, w, b, geom, act, slope):
     N, Ci, Hi, Wi, Co, R, S, st, ct, cl, Ho, Wo = geom
     y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+    ws, nb = _workspace(OP_CONVT_FWD, geom, x.device)
     _check(load().bn_convT2d_fwd(
         _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), *geom,
-        act, slope, _stream()), 'bn_convT2d_fwd')
+        act, slope, ws, nb, _stream()), 'bn_convT2d_fwd')
     return y
 
 
 def convT2d_bwd_data(dy, w, geom, dact_src, dact, slope):
     N, Ci, Hi, Wi = geom[:4]
     dx = torch.empty((N, Ci, Hi, Wi), dtype=torch.float32, device=dy.device)
+    ws, nb = _workspace(OP_CONVT_BWD_D, geom, dy.device)
     _check(load().bn_convT2d_bwd_data(
         _ptr(dy, 'dy'), _ptr(w, 'w'), _ptr(dx, 'dx'), _ptr(dact_src, 'dact_src', allow_none=True),
-        *geom, dact, slope, _stream()), 'bn_convT2d_bwd_data')
+        *geom, dact, slope, ws, nb, _stream()), 'bn_convT2d_bwd_data')
     return dx
 
 
 def convT2d_bwd_weight(x, dy, dw, db, geom, accumulate):
-    lib = load()
-    nbytes = lib.bn_convT2d_bwd_weight_ws_bytes(*geom)
-    ws = _workspace(nbytes, x.device)
-    _check(lib.bn_convT2d_bwd_weight(
+    ws, nb = _workspace(OP_CONVT_BWD_W, geom, x.device)
+    _check(lib_call('bn_convT2d_bwd_weight')(
         _ptr(x, 'x'), _ptr(dy, 'dy'), _ptr(dw, 'dw'), _ptr(db, 'db', allow_none=True), *geom,
-        int(accumulate), ws.data_ptr() if ws is not None else None, nbytes, _stream()),
-        'bn_convT2d_bwd_weight')
+        int(accumulate), ws, nb, _stream()), 'bn_convT2d_bwd_weight')
+
+
+def set_force_generic(on):
+    """Route convolutions through the shape-agnostic kernels (test hook); returns previous."""
+    return bool(load().bn_set_force_generic(1 if on else 0))
+
+
+def lib_call(name):
+    return getattr(load(), name)
 
 
 def act_bwd(dy, y, act, slope, out=None):

@@ -3,6 +3,7 @@
 // the hipEvent profiling hook.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "bn_common.h"
 #include "bn_launch.h"
@@ -120,66 +121,105 @@ static inline BnGeom convT_geom(int N, int Ci, int Hi, int Wi, int Co, int R, in
     return g;
 }
 
+// BN_FORCE_GENERIC=1 in the environment disables every fast path (used by tests to cross-check
+// the specialised kernels against the shape-agnostic ones on the device).
+static int g_force_generic = -1;
+static bool force_generic() {
+    if (g_force_generic < 0) {
+        const char* e = getenv("BN_FORCE_GENERIC");
+        g_force_generic = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_force_generic == 1;
+}
+extern "C" int bn_set_force_generic(int on) {
+    const int prev = force_generic() ? 1 : 0;
+    g_force_generic = on ? 1 : 0;
+    return prev;
+}
+
+static inline bool ws_ok(const BnFastPlan& p, void* ws, size_t ws_bytes) {
+    return p.ws_bytes == 0 || (ws != nullptr && ws_bytes >= p.ws_bytes);
+}
+
 static int run_down(int family, const float* big, const float* w, const float* bias, float* out,
                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
-                    hipStream_t st) {
-    const char* name = "k_down_generic";
-    const bool fast = bn_fast_down_supported(g, &name);
-    BnProfScope prof(family, g.Cb, g.Cs, name, st);
-    if (fast) return bn_launch_down_fast(big, w, bias, out, dact_src, g, act, dact, slope, st);
+                    void* ws, size_t ws_bytes, hipStream_t st) {
+    BnFastPlan plan = bn_fast_down_plan(g);
+    if (force_generic()) plan.supported = false;
+    BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_down_generic", st);
+    if (plan.supported) {
+        if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
+        return bn_launch_down_fast(plan, big, w, bias, out, dact_src, g, act, dact, slope, ws, st);
+    }
     return bn_launch_down_generic(big, w, bias, out, dact_src, g, act, dact, slope, st);
 }
 
 static int run_up(int family, const float* small, const float* w, const float* bias, float* out,
                   const float* dact_src, const BnGeom& g, int act, int dact, float slope,
-                  hipStream_t st) {
-    const char* name = "k_up_generic";
-    const bool fast = bn_fast_up_supported(g, &name);
-    BnProfScope prof(family, g.Cs, g.Cb, name, st);
-    if (fast) return bn_launch_up_fast(small, w, bias, out, dact_src, g, act, dact, slope, st);
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+    BnFastPlan plan = bn_fast_up_plan(g);
+    if (force_generic()) plan.supported = false;
+    BnProfScope prof(family, g.Cs, g.Cb, plan.supported ? plan.kernel_name : "k_up_generic", st);
+    if (plan.supported) {
+        if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
+        return bn_launch_up_fast(plan, small, w, bias, out, dact_src, g, act, dact, slope, ws, st);
+    }
     return bn_launch_up_generic(small, w, bias, out, dact_src, g, act, dact, slope, st);
 }
 
 static int run_wgrad(int family, const float* small, const float* big, float* dw,
                      const BnGeom& g, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
-    const char* name = "k_wgrad_generic";
-    const bool fast = bn_fast_wgrad_supported(g, &name);
-    BnProfScope prof(family, g.Cb, g.Cs, name, st);
-    if (fast) {
-        if (ws_bytes < bn_fast_wgrad_ws_bytes(g) || (!ws && bn_fast_wgrad_ws_bytes(g) > 0))
-            return BN_E_WORKSPACE;
-        return bn_launch_wgrad_fast(small, big, dw, g, accumulate, ws, st);
+    BnFastPlan plan = bn_fast_wgrad_plan(g);
+    if (force_generic()) plan.supported = false;
+    BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_wgrad_generic",
+                     st);
+    if (plan.supported) {
+        if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
+        return bn_launch_wgrad_fast(plan, small, big, dw, g, accumulate, ws, st);
     }
     return bn_launch_wgrad_generic(small, big, dw, g, accumulate, st);
 }
 
+extern "C" size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, int R, int S,
+                                   int stride, int off_t, int off_l, int P, int Q) {
+    BnGeom g;
+    switch (op) {
+        case BN_OP_CONV_FWD: case BN_OP_CONV_BWD_D: case BN_OP_CONV_BWD_W:
+            g = conv_geom(N, C, H, W, K, R, S, stride, off_t, off_l, P, Q); break;
+        case BN_OP_CONVT_FWD: case BN_OP_CONVT_BWD_D: case BN_OP_CONVT_BWD_W:
+            g = convT_geom(N, C, H, W, K, R, S, stride, off_t, off_l, P, Q); break;
+        default: return 0;
+    }
+    if (!bn_geom_ok(g) || force_generic()) return 0;
+    BnFastPlan plan;
+    switch (op) {
+        case BN_OP_CONV_FWD: case BN_OP_CONVT_BWD_D: plan = bn_fast_down_plan(g); break;
+        case BN_OP_CONV_BWD_D: case BN_OP_CONVT_FWD: plan = bn_fast_up_plan(g); break;
+        default: plan = bn_fast_wgrad_plan(g); break;
+    }
+    return plan.supported ? plan.ws_bytes : 0;
+}
+
 extern "C" int bn_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int N,
                              int C, int H, int W, int K, int R, int S, int stride, int pad_t,
-                             int pad_l, int P, int Q, int act, float slope, bn_stream_t stream) {
+                             int pad_l, int P, int Q, int act, float slope, void* ws,
+                             size_t ws_bytes, bn_stream_t stream) {
     if (!x || !w || !y) return BN_E_BADARG;
     const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
-    return run_down(BN_PROF_CONV_FWD, x, w, b, y, nullptr, g, act, BN_ACT_NONE, slope,
-                    (hipStream_t)stream);
+    return run_down(BN_PROF_CONV_FWD, x, w, b, y, nullptr, g, act, BN_ACT_NONE, slope, ws,
+                    ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int bn_conv2d_bwd_data(const float* dy, const float* w, float* dx,
                                   const float* dact_src, int N, int C, int H, int W, int K, int R,
                                   int S, int stride, int pad_t, int pad_l, int P, int Q, int dact,
-                                  float slope, bn_stream_t stream) {
+                                  float slope, void* ws, size_t ws_bytes, bn_stream_t stream) {
     if (!dy || !w || !dx) return BN_E_BADARG;
     const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
     return run_up(BN_PROF_CONV_BWD_D, dy, w, nullptr, dx, dact_src, g, BN_ACT_NONE, dact, slope,
-                  (hipStream_t)stream);
-}
-
-extern "C" size_t bn_conv2d_bwd_weight_ws_bytes(int N, int C, int H, int W, int K, int R, int S,
-                                                int stride, int pad_t, int pad_l, int P, int Q) {
-    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
-    if (!bn_geom_ok(g)) return 0;
-    const char* name = nullptr;
-    return bn_fast_wgrad_supported(g, &name) ? bn_fast_wgrad_ws_bytes(g) : 0;
+                  ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N,
@@ -199,32 +239,24 @@ extern "C" int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
 extern "C" int bn_convT2d_fwd(const float* x, const float* w, const float* b, float* y, int N,
                               int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                               int crop_t, int crop_l, int Ho, int Wo, int act, float slope,
-                              bn_stream_t stream) {
+                              void* ws, size_t ws_bytes, bn_stream_t stream) {
     if (!x || !w || !y) return BN_E_BADARG;
     const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
-    return run_up(BN_PROF_CONVT_FWD, x, w, b, y, nullptr, g, act, BN_ACT_NONE, slope,
-                  (hipStream_t)stream);
+    return run_up(BN_PROF_CONVT_FWD, x, w, b, y, nullptr, g, act, BN_ACT_NONE, slope, ws,
+                  ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int bn_convT2d_bwd_data(const float* dy, const float* w, float* dx,
                                    const float* dact_src, int N, int Ci, int Hi, int Wi, int Co,
                                    int R, int S, int stride, int crop_t, int crop_l, int Ho,
-                                   int Wo, int dact, float slope, bn_stream_t stream) {
+                                   int Wo, int dact, float slope, void* ws, size_t ws_bytes,
+                                   bn_stream_t stream) {
     if (!dy || !w || !dx) return BN_E_BADARG;
     const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
     return run_down(BN_PROF_CONVT_BWD_D, dy, w, nullptr, dx, dact_src, g, BN_ACT_NONE, dact, slope,
-                    (hipStream_t)stream);
-}
-
-extern "C" size_t bn_convT2d_bwd_weight_ws_bytes(int N, int Ci, int Hi, int Wi, int Co, int R,
-                                                 int S, int stride, int crop_t, int crop_l,
-                                                 int Ho, int Wo) {
-    const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
-    if (!bn_geom_ok(g)) return 0;
-    const char* name = nullptr;
-    return bn_fast_wgrad_supported(g, &name) ? bn_fast_wgrad_ws_bytes(g) : 0;
+                    ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw, float* db, int N,

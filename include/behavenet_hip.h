@@ -43,6 +43,26 @@ const char* bn_build_arch(void);              /* "gfx950" */
 const char* bn_error_string(int code);        /* static string for a BN_E_* / hip code */
 
 /* ------------------------------------------------------------------------------------------
+ * Scratch memory.  Some kernels split their reduction dimension over workgroups and combine
+ * the partial results in a second, fixed-order pass (deterministic; no atomics).  The caller
+ * owns the scratch: ask how much a call needs (0 is common) and pass at least that much.
+ * `op` is one of BN_OP_*; the twelve ints are the same geometry arguments, in the same order,
+ * as the entry point's.
+ * ------------------------------------------------------------------------------------------ */
+#define BN_OP_CONV_FWD    1
+#define BN_OP_CONV_BWD_D  2
+#define BN_OP_CONV_BWD_W  3
+#define BN_OP_CONVT_FWD   4
+#define BN_OP_CONVT_BWD_D 5
+#define BN_OP_CONVT_BWD_W 6
+/* Test hook: on != 0 routes every convolution through the shape-agnostic kernels (so the
+ * specialised ones can be cross-checked on the device).  Returns the previous setting.  The
+ * environment variable BN_FORCE_GENERIC=1 sets the initial value. */
+int bn_set_force_generic(int on);
+size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, int R, int S, int stride,
+                        int off_t, int off_l, int P, int Q);
+
+/* ------------------------------------------------------------------------------------------
  * Convolution (replaces ZeroPad2d + nn.Conv2d + LeakyReLU, aes.py:81-86,113-114,145-155).
  *   y[n,k,p,q] = act( b[k] + sum_{c,r,s} x[n,c,p*stride+r-pad_t,q*stride+s-pad_l] * w[k,c,r,s] )
  * reads outside [0,H)x[0,W) are zero, so TF-"same" asymmetric padding needs no padded copy.
@@ -51,7 +71,7 @@ const char* bn_error_string(int code);        /* static string for a BN_E_* / hi
 int bn_conv2d_fwd(const float* x, const float* w, const float* b, float* y,
                   int N, int C, int H, int W, int K, int R, int S, int stride,
                   int pad_t, int pad_l, int P, int Q,
-                  int act, float slope, bn_stream_t stream);
+                  int act, float slope, void* ws, size_t ws_bytes, bn_stream_t stream);
 
 /* dx[n,c,h,w] = act'(dact_src[n,c,h,w]) * sum_{k,r,s} dy[n,k,p,q] * w[k,c,r,s],
  * p*stride+r-pad_t == h.  `dy` is the gradient w.r.t. the PRE-activation of this layer.
@@ -61,14 +81,10 @@ int bn_conv2d_fwd(const float* x, const float* w, const float* b, float* y,
 int bn_conv2d_bwd_data(const float* dy, const float* w, float* dx, const float* dact_src,
                        int N, int C, int H, int W, int K, int R, int S, int stride,
                        int pad_t, int pad_l, int P, int Q,
-                       int dact, float slope, bn_stream_t stream);
+                       int dact, float slope, void* ws, size_t ws_bytes, bn_stream_t stream);
 
 /* dw[k,c,r,s] (+)= sum_{n,p,q} dy[n,k,p,q] * x[n,c,p*stride+r-pad_t,q*stride+s-pad_l]
- * db[k]       (+)= sum_{n,p,q} dy[n,k,p,q]                      (db nullable)
- * `ws` is scratch of at least bn_conv2d_bwd_weight_ws_bytes(...) bytes (deterministic two-pass
- * reduction; no atomics). */
-size_t bn_conv2d_bwd_weight_ws_bytes(int N, int C, int H, int W, int K, int R, int S, int stride,
-                                     int pad_t, int pad_l, int P, int Q);
+ * db[k]       (+)= sum_{n,p,q} dy[n,k,p,q]                      (db nullable) */
 int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                          int N, int C, int H, int W, int K, int R, int S, int stride,
                          int pad_t, int pad_l, int P, int Q,
@@ -85,18 +101,16 @@ int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, float* db,
 int bn_convT2d_fwd(const float* x, const float* w, const float* b, float* y,
                    int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                    int crop_t, int crop_l, int Ho, int Wo,
-                   int act, float slope, bn_stream_t stream);
+                   int act, float slope, void* ws, size_t ws_bytes, bn_stream_t stream);
 
 /* dx[n,ci,p,q] = act'(dact_src[n,ci,p,q]) * sum_{co,r,s} dy[n,co,p*stride+r-crop_t,...] * w[ci,co,r,s] */
 int bn_convT2d_bwd_data(const float* dy, const float* w, float* dx, const float* dact_src,
                         int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                         int crop_t, int crop_l, int Ho, int Wo,
-                        int dact, float slope, bn_stream_t stream);
+                        int dact, float slope, void* ws, size_t ws_bytes, bn_stream_t stream);
 
 /* dw[ci,co,r,s] (+)= sum_{n,p,q} x[n,ci,p,q] * dy[n,co,p*stride+r-crop_t,q*stride+s-crop_l]
  * db[co]        (+)= sum_{n,h,w} dy[n,co,h,w] */
-size_t bn_convT2d_bwd_weight_ws_bytes(int N, int Ci, int Hi, int Wi, int Co, int R, int S,
-                                      int stride, int crop_t, int crop_l, int Ho, int Wo);
 int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw, float* db,
                           int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                           int crop_t, int crop_l, int Ho, int Wo,

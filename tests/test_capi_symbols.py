@@ -39,5 +39,6 @@ def test_info_calls():
     assert lib.bn_build_arch() == b'gfx950'
     assert b'BN_E_SHAPE' in lib.bn_error_string(-2)
     # argument errors are reported, not thrown
-    assert lib.bn_conv2d_fwd(None, None, None, None, *([1] * 12), 0, 0.0, None) == -1
+    assert lib.bn_conv2d_fwd(None, None, None, None, *([1] * 12), 0, 0.0, None, 0, None) == -1
+    assert lib.bn_conv_ws_bytes(99, *([1] * 12)) == 0
     assert lib.bn_prof_select(99, 0, 0) == -1

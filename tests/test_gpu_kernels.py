@@ -97,7 +97,7 @@ def test_conv2d_bwd(case):
     dy = torch.rand((N, K, P, Q), generator=g) - 0.5
 
     def grads(dt):
-        x, w, b = (t.to(dt).requires_grad_(True) for t in (x0, w0, b0))
+        x, w, b = (t.detach().clone().to(dt).requires_grad_(True) for t in (x0, w0, b0))
         # x plays the role of a post-LeakyReLU activation of the layer below
         xin = F.leaky_relu(x, SLOPE)
         xin.retain_grad()
@@ -187,7 +187,7 @@ def test_convT2d_bwd(case):
     dy = torch.rand((N, Co, Ho, Wo), generator=g) - 0.5
 
     def grads(dt):
-        x, w, b = (t.to(dt).requires_grad_(True) for t in (x0, w0, b0))
+        x, w, b = (t.detach().clone().to(dt).requires_grad_(True) for t in (x0, w0, b0))
         xin = F.leaky_relu(x, SLOPE)
         xin.retain_grad()
         ref(xin, w, b).backward(dy.to(dt))
