@@ -361,17 +361,9 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
 // =============================================================================================
 // placeholders until the next kernels land
 // =============================================================================================
-BnFastPlan bn_fast_up_plan(const BnGeom&) {
-    BnFastPlan p = {false, "k_up_generic", 0, 0, 0, 0, 0, 0};
-    return p;
-}
 BnFastPlan bn_fast_wgrad_plan(const BnGeom&) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
     return p;
-}
-int bn_launch_up_fast(const BnFastPlan&, const float*, const float*, const float*, float*,
-                      const float*, const BnGeom&, int, int, float, void*, hipStream_t) {
-    return BN_E_SHAPE;
 }
 int bn_launch_wgrad_fast(const BnFastPlan&, const float*, const float*, float*, const BnGeom&, int,
                          void*, hipStream_t) {
