@@ -24,3 +24,17 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
                       int act, int dact, float slope, void* ws, hipStream_t st);
 int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float* big, float* dw,
                          const BnGeom& g, int accumulate, void* ws, hipStream_t st);
+
+// conv_s5.hip: stride == kernel size (non-overlapping windows), direct-from-global MFMA GEMMs
+BnFastPlan bn_s5_up_plan(const BnGeom& g);
+BnFastPlan bn_s5_wgrad_plan(const BnGeom& g);
+int bn_launch_up_s5(const float* small, const float* w, const float* bias, float* out,
+                    const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                    hipStream_t st);
+int bn_launch_wgrad_s5(const float* small, const float* big, float* dw, const BnGeom& g,
+                       int accumulate, hipStream_t st);
+
+// conv_edge.hip: HBM-bound single-channel-side layers (enc.conv0 / dec.convT4)
+BnFastPlan bn_edge_wgrad_plan(const BnGeom& g);
+int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float* big, float* dw,
+                         const BnGeom& g, int accumulate, void* ws, hipStream_t st);

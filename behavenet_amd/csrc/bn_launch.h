@@ -23,8 +23,9 @@ int bn_launch_up_generic(const float* small, const float* w, const float* bias, 
                          hipStream_t st);
 int bn_launch_wgrad_generic(const float* small, const float* big, float* dw, const BnGeom& g,
                             int accumulate, hipStream_t st);
+size_t bn_channel_sum_ws_bytes(int N, int C, int npix);
 int bn_launch_channel_sum(const float* t, float* db, int N, int C, int npix, int accumulate,
-                          hipStream_t st);
+                          void* ws, size_t ws_bytes, hipStream_t st);
 
 // gemm.hip
 int bn_launch_gemm(const GemmArgs& a, hipStream_t st);

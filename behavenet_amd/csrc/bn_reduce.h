@@ -1,0 +1,19 @@
+// Deterministic second pass of the split reductions: out[i] (+)= sum_z part[z][i].
+// 64 outputs x 4 z-lanes per workgroup: each thread sums every 4th split with 4 independent
+// running sums (loads stay in flight), the z-lanes are combined through LDS in fixed order.
+#pragma once
+#include "bn_common.h"
+
+// ab_elems > 0: part is laid out [z][tap][ab] and out is [ab][ntap] (weight-gradient layout)
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part,
+                                                      float* __restrict__ out, int total,
+                                                      int splits, int accumulate, int ab_elems,
+                                                      int ntap);
+
+static inline int bn_launch_sum_partials(const float* part, float* out, int total, int splits,
+                                         int accumulate, int ab_elems, int ntap, hipStream_t st) {
+    hipLaunchKernelGGL(k_sum_partials, dim3((total + 63) / 64), dim3(256), 0, st, part, out, total,
+                       splits, accumulate, ab_elems, ntap);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

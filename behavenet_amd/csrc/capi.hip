@@ -157,6 +157,13 @@ static int run_down(int family, const float* big, const float* w, const float* b
 static int run_up(int family, const float* small, const float* w, const float* bias, float* out,
                   const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                   void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!force_generic()) {
+        const BnFastPlan s5 = bn_s5_up_plan(g);
+        if (s5.supported) {
+            BnProfScope prof(family, g.Cs, g.Cb, s5.kernel_name, st);
+            return bn_launch_up_s5(small, w, bias, out, dact_src, g, act, dact, slope, st);
+        }
+    }
     BnFastPlan plan = bn_fast_up_plan(g);
     if (force_generic()) plan.supported = false;
     BnProfScope prof(family, g.Cs, g.Cb, plan.supported ? plan.kernel_name : "k_up_generic", st);
@@ -169,6 +176,21 @@ static int run_up(int family, const float* small, const float* w, const float* b
 
 static int run_wgrad(int family, const float* small, const float* big, float* dw,
                      const BnGeom& g, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!force_generic()) {
+        const BnFastPlan s5 = bn_s5_wgrad_plan(g);
+        if (s5.supported) {
+            BnProfScope prof(family, g.Cb, g.Cs, s5.kernel_name, st);
+            return bn_launch_wgrad_s5(small, big, dw, g, accumulate, st);
+        }
+    }
+    if (!force_generic()) {
+        const BnFastPlan ed = bn_edge_wgrad_plan(g);
+        if (ed.supported) {
+            if (!ws_ok(ed, ws, ws_bytes)) return BN_E_WORKSPACE;
+            BnProfScope prof(family, g.Cb, g.Cs, ed.kernel_name, st);
+            return bn_launch_edge_wgrad(ed, small, big, dw, g, accumulate, ws, st);
+        }
+    }
     BnFastPlan plan = bn_fast_wgrad_plan(g);
     if (force_generic()) plan.supported = false;
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_wgrad_generic",
@@ -190,14 +212,23 @@ extern "C" size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, in
             g = convT_geom(N, C, H, W, K, R, S, stride, off_t, off_l, P, Q); break;
         default: return 0;
     }
-    if (!bn_geom_ok(g) || force_generic()) return 0;
+    if (!bn_geom_ok(g)) return 0;
+    // the bias gradient (channel sums of dy) reuses the scratch after the weight gradient
+    size_t bias_ws = 0;
+    if (op == BN_OP_CONV_BWD_W) bias_ws = bn_channel_sum_ws_bytes(N, K, P * Q);
+    if (op == BN_OP_CONVT_BWD_W) bias_ws = bn_channel_sum_ws_bytes(N, K, P * Q);
+    if (force_generic()) return bias_ws;
     BnFastPlan plan;
     switch (op) {
         case BN_OP_CONV_FWD: case BN_OP_CONVT_BWD_D: plan = bn_fast_down_plan(g); break;
         case BN_OP_CONV_BWD_D: case BN_OP_CONVT_FWD: plan = bn_fast_up_plan(g); break;
-        default: plan = bn_fast_wgrad_plan(g); break;
+        default:
+            plan = bn_edge_wgrad_plan(g);
+            if (!plan.supported) plan = bn_fast_wgrad_plan(g);
+            break;
     }
-    return plan.supported ? plan.ws_bytes : 0;
+    const size_t need = plan.supported ? plan.ws_bytes : 0;
+    return need > bias_ws ? need : bias_ws;
 }
 
 extern "C" int bn_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int N,
@@ -232,7 +263,7 @@ extern "C" int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
     hipStream_t st = (hipStream_t)stream;
     int rc = run_wgrad(BN_PROF_CONV_BWD_W, dy, x, dw, g, accumulate, ws, ws_bytes, st);
     if (rc) return rc;
-    if (db) rc = bn_launch_channel_sum(dy, db, N, K, P * Q, accumulate, st);
+    if (db) rc = bn_launch_channel_sum(dy, db, N, K, P * Q, accumulate, ws, ws_bytes, st);
     return rc;
 }
 
@@ -269,7 +300,7 @@ extern "C" int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw,
     hipStream_t st = (hipStream_t)stream;
     int rc = run_wgrad(BN_PROF_CONVT_BWD_W, x, dy, dw, g, accumulate, ws, ws_bytes, st);
     if (rc) return rc;
-    if (db) rc = bn_launch_channel_sum(dy, db, N, Co, Ho * Wo, accumulate, st);
+    if (db) rc = bn_launch_channel_sum(dy, db, N, Co, Ho * Wo, accumulate, ws, ws_bytes, st);
     return rc;
 }
 

@@ -207,10 +207,103 @@ int bn_launch_wgrad_generic(const float* small, const float* big, float* dw, con
     return 0;
 }
 
+// two-pass variant for large tensors: (channel, frame-slice) partial sums, then a fixed-order
+// combine -- one block per channel cannot pull a 100 MB gradient tensor through 32..64 CUs
+__global__ __launch_bounds__(GEN_THREADS) void k_channel_sum_part(
+    const float* __restrict__ t, float* __restrict__ part, int N, int C, int npix, int S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, sp = blockIdx.y;
+    const int n_beg = (int)((long)sp * N / S), n_end = (int)((long)(sp + 1) * N / S);
+    float acc = 0.f;
+    const bool vec = (npix & 3) == 0 && ((((uintptr_t)t) & 15u) == 0);
+    for (int n = n_beg; n < n_end; ++n) {
+        const float* tp = t + ((size_t)n * C + c) * npix;
+        if (vec) {
+            const float4* t4 = reinterpret_cast<const float4*>(tp);
+            for (int i = threadIdx.x; i < (npix >> 2); i += GEN_THREADS) {
+                const float4 v = t4[i];
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            for (int i = threadIdx.x; i < npix; i += GEN_THREADS) acc += tp[i];
+        }
+    }
+    const float s = bn_block_reduce_256(acc, red);
+    if (threadIdx.x == 0) part[(size_t)c * S + sp] = s;
+}
+
+__global__ void k_channel_sum_final(const float* __restrict__ part, float* __restrict__ db, int C,
+                                    int S, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float v = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) v += part[(size_t)c * S + s];
+    db[c] = accumulate ? db[c] + v : v;
+}
+
+static int channel_sum_splits(int N, int C, int npix) {
+    if ((long)N * npix < 32768) return 1;
+    int s = 1024 / C;
+    if (s > 64) s = 64;
+    if (s > N) s = N;
+    return s < 1 ? 1 : s;
+}
+
+size_t bn_channel_sum_ws_bytes(int N, int C, int npix) {
+    const int s = channel_sum_splits(N, C, npix);
+    return s > 1 ? (size_t)C * s * sizeof(float) : 0;
+}
+
 int bn_launch_channel_sum(const float* t, float* db, int N, int C, int npix, int accumulate,
-                          hipStream_t st) {
+                          void* ws, size_t ws_bytes, hipStream_t st) {
+    const int S = channel_sum_splits(N, C, npix);
+    if (S > 1 && ws && ws_bytes >= (size_t)C * S * sizeof(float)) {
+        hipLaunchKernelGGL(k_channel_sum_part, dim3(C, S), dim3(GEN_THREADS), 0, st, t, (float*)ws,
+                           N, C, npix, S);
+        BN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_channel_sum_final, dim3((C + 63) / 64), dim3(64), 0, st,
+                           (const float*)ws, db, C, S, accumulate);
+        BN_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_channel_sum, dim3(C), dim3(GEN_THREADS), 0, st, t, db, N, C, npix,
                        accumulate);
     BN_LAUNCH_CHECK();
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// second pass of split reductions (declared in bn_reduce.h)
+// ---------------------------------------------------------------------------------------------
+#include "bn_reduce.h"
+__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part,
+                                                      float* __restrict__ out, int total,
+                                                      int splits, int accumulate, int ab_elems,
+                                                      int ntap) {
+    __shared__ float red[4][64];
+    const int il = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+        int z = zl;
+        for (; z + 12 < splits; z += 16) {
+            s0 += part[(size_t)z * total + i];
+            s1 += part[(size_t)(z + 4) * total + i];
+            s2 += part[(size_t)(z + 8) * total + i];
+            s3 += part[(size_t)(z + 12) * total + i];
+        }
+        for (; z < splits; z += 4) s0 += part[(size_t)z * total + i];
+    }
+    red[zl][il] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zl == 0 && i < total) {
+        const float v = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+        size_t o = i;
+        if (ab_elems > 0) {
+            const int tap = i / ab_elems;
+            o = (size_t)(i - tap * ab_elems) * ntap + tap;
+        }
+        out[o] = accumulate ? out[o] + v : v;
+    }
 }

@@ -358,14 +358,3 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
     return 0;
 }
 
-// =============================================================================================
-// placeholders until the next kernels land
-// =============================================================================================
-BnFastPlan bn_fast_wgrad_plan(const BnGeom&) {
-    BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
-    return p;
-}
-int bn_launch_wgrad_fast(const BnFastPlan&, const float*, const float*, float*, const BnGeom&, int,
-                         void*, hipStream_t) {
-    return BN_E_SHAPE;
-}

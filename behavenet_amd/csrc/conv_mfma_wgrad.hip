@@ -1,0 +1,276 @@
+// family 3: weight gradients on the matrix cores (kernel 5x5, stride 2):
+//   dW[a][b][r][s] = sum_{n,p,q} small[n,a,p,q] * big[n,b,2p+r-pt,2q+s-pl]
+//
+// GEMM view per tap: D[a][b] += A[a][pixel] * B[pixel][b], reduction over the N*P*Q pixels.
+// v_mfma_f32_16x16x4_f32 (4 accumulator registers) lets one wave keep all 25 taps of a 16x16
+// (a,b) block resident: 100 accumulator registers, one A read + 25 B reads per 25 MFMAs.
+// A workgroup is 8 waves = 4(a) x 2(b) blocks -> a 64 x 32 tile of dW, and walks a strided set
+// of 64-pixel "stages" (software-pipelined global->register->LDS staging).  The big-side tile
+// is stored column-parity-split in LDS (x -> (x&1)*HALF + x/2) so that the stride-2 gather of
+// four consecutive pixels is bank-conflict free.  The reduction over stages is split over
+// workgroups; partial tiles go to scratch as [split][tap][a][b] and k_wgrad_reduce sums them
+// in fixed order (deterministic, no atomics) into dW[a][b][tap] (+= when accumulating).
+#include "bn_common.h"
+#include "bn_fast.h"
+#include "bn_reduce.h"
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define WG_THREADS 512
+#define WG_TA 64            // a-channels per workgroup tile
+#define WG_TB 32            // b-channels per workgroup tile
+#define WG_TPX 64           // small-image pixels per stage
+#define WG_KB 31            // max big-tile elements per thread per stage
+#define WG_KS ((WG_TA * WG_TPX) / WG_THREADS)   // small-tile elements per thread per stage (8)
+#define WG_MAX_LDS (96 * 1024)
+
+static inline int ilog2_exact_wg(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return ((1 << l) == v) ? l : -1;
+}
+
+struct WgradTile {
+    int F, PT_H, lgQ, lgPTQ;       // pixel stage = F frames x PT_H rows x Q columns (64 pixels)
+    int tiles_per_frame;           // P / PT_H (1 when F > 1)
+    int n_stages;                  // total stages = ceil(N/F) * tiles_per_frame
+    int IH, HALF, RW;              // big tile rows per frame, parity-half length, row stride
+    int FSb;                       // per-frame stride inside a channel (IH * RW)
+    int BCH;                       // per-channel stride (== 2 mod 32: conflict-free B reads)
+    int big_elems;                 // WG_TB * F * IH * RW
+    float inv_rw, inv_bch, inv_ih; // reciprocals for the staging index decode
+    int rows_per_b;                // F * IH
+    int splits;                    // reduction splits (gridDim.y)
+    int sl_floats;
+};
+
+__global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
+    const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
+    BnGeom g, WgradTile t) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SP = WG_TPX + 2;          // small tile row stride (== 2 mod 32)
+    float* sl = smem;                        // [WG_TA][SP]
+    float* bl = smem + t.sl_floats;          // [WG_TB][BCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ablk = wv >> 1, bblk = wv & 1;
+    const int lj = lane & 15, kk = lane >> 4;
+
+    const int n_btiles = (g.Cb + WG_TB - 1) / WG_TB;
+    const int atile = blockIdx.x / n_btiles, btile = blockIdx.x - atile * n_btiles;
+    const int a0 = atile * WG_TA, b0 = btile * WG_TB;
+    const int Q = g.Ws, PQ = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
+
+    floatx4 acc[25];
+#pragma unroll
+    for (int tp = 0; tp < 25; ++tp) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+    float sr[WG_KS];
+    float br[WG_KB];
+
+    // raw buffer descriptors: an out-of-range byte offset reads as 0.0f, which gives the zero
+    // padding, the halo, channel tails and frame tails without any select on the loaded value
+    const __amdgpu_buffer_rsrc_t rs_small = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)big, 0, (int)((size_t)g.N * g.Cb * HWb * 4), 0x00020000);
+    constexpr int OOB = 0x7fffffff;
+
+    // stage -> (first frame, first small-image row)
+    auto stage_origin = [&](int st, int& n0, int& p0) {
+        const int grp = st / t.tiles_per_frame;
+        n0 = grp * t.F;
+        p0 = (st - grp * t.tiles_per_frame) * t.PT_H;
+    };
+
+    // The thread's k-th big-tile element IS LDS word e = tid + 512*k of the padded image
+    // bl[b][BCH] (publishing is a plain store); its source is decoded per stage:
+    //   b = e / BCH, within = e % BCH -> (row rr = f*IH + y, parity-split column xx)
+    auto issue_loads = [&](int st) {
+        int n0, p0;
+        stage_origin(st, n0, p0);
+#pragma unroll
+        for (int k = 0; k < WG_KS; ++k) {
+            const int e = tid + WG_THREADS * k;
+            const int a = e >> 6, pix = e & (WG_TPX - 1);
+            const int f = pix >> t.lgPTQ;
+            const int rem = pix & ((1 << t.lgPTQ) - 1);
+            const bool ok = (a0 + a < g.Cs) && (n0 + f < g.N);
+            const int off = (((n0 + f) * g.Cs + a0 + a) * PQ + p0 * Q + rem) * 4;
+            sr[k] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs_small, ok ? off : OOB, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < WG_KB; ++k) {
+            int e = tid + WG_THREADS * k;
+            asm volatile("" : "+v"(e));   // keep the decode inside the stage loop (no hoisting)
+            const int b = (int)(((float)e + 0.5f) * t.inv_bch);
+            const int within = e - b * t.BCH;
+            const int rr = (int)(((float)within + 0.5f) * t.inv_rw);
+            const int xx = within - rr * t.RW;
+            const int f = (t.F == 1) ? 0 : (int)(((float)rr + 0.5f) * t.inv_ih);
+            const int y = rr - f * t.IH;
+            const int par = xx >= t.HALF ? 1 : 0;
+            const int x = 2 * (xx - par * t.HALF) + par;
+            const int hb = 2 * p0 - g.pt + y, wb = x - g.pl;
+            const bool ok = (b < WG_TB) && (rr < t.rows_per_b) && (b0 + b < g.Cb) &&
+                            (n0 + f < g.N) && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+            const int off = ((((n0 + f) * g.Cb + b0 + b) * g.Hb + hb) * g.Wb + wb) * 4;
+            br[k] = __builtin_bit_cast(
+                float, __builtin_amdgcn_raw_buffer_load_b32(rs_big, ok ? off : OOB, 0, 0));
+        }
+    };
+
+    auto publish = [&]() {
+#pragma unroll
+        for (int k = 0; k < WG_KS; ++k) {
+            const int e = tid + WG_THREADS * k;
+            sl[(e >> 6) * SP + (e & (WG_TPX - 1))] = sr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < WG_KB; ++k) {
+            const int e = tid + WG_THREADS * k;
+            if (e < WG_TB * t.BCH) bl[e] = br[k];
+        }
+    };
+
+    const float* ap = sl + (ablk * 16 + lj) * SP + kk;
+    const float* bp = bl + (bblk * 16 + lj) * t.BCH;
+
+    int st = blockIdx.y;
+    if (st < t.n_stages) issue_loads(st);
+    for (; st < t.n_stages; st += t.splits) {
+        __syncthreads();
+        publish();
+        __syncthreads();
+        if (st + t.splits < t.n_stages) issue_loads(st + t.splits);
+
+#pragma unroll 2
+        for (int ks = 0; ks < WG_TPX / 4; ++ks) {
+            const int pix = 4 * ks + kk;
+            const int f = pix >> t.lgPTQ;
+            const int rem = pix & ((1 << t.lgPTQ) - 1);
+            const int pj = rem >> t.lgQ, qj = rem & (Q - 1);
+            const float av = ap[4 * ks];
+            const float* bq = bp + f * t.FSb + (2 * pj) * t.RW + qj;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                    const float bv = bq[r * t.RW + (s & 1) * t.HALF + (s >> 1)];
+                    acc[r * 5 + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r * 5 + s],
+                                                                          0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // partial tile -> scratch [split][tap][a][b]; lane holds D[i = 4*kk + e][j = lj]
+    float* dst = part + (size_t)blockIdx.y * 25 * g.Cs * g.Cb;
+    const int b = b0 + bblk * 16 + lj;
+    if (b < g.Cb) {
+#pragma unroll
+        for (int tp = 0; tp < 25; ++tp) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = a0 + ablk * 16 + 4 * kk + e;
+                if (a < g.Cs) dst[((size_t)tp * g.Cs + a) * g.Cb + b] = acc[tp][e];
+            }
+        }
+    }
+}
+
+// dW[a][b][tap] (+)= sum_z part[z][tap][a][b]; coalesced reads along b, fixed order over z
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part,
+                                                      float* __restrict__ dw, int Cs, int Cb,
+                                                      int splits, int accumulate) {
+    const int total = 25 * Cs * Cb;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float v = part[i];
+    for (int z = 1; z < splits; ++z) v += part[(size_t)z * total + i];
+    const int tap = i / (Cs * Cb);
+    const int ab = i - tap * (Cs * Cb);
+    float* o = dw + (size_t)ab * 25 + tap;
+    *o = accumulate ? *o + v : v;
+}
+
+static bool wgrad_tile(const BnGeom& g, WgradTile* t, size_t* lds_bytes) {
+    const int lgQ = ilog2_exact_wg(g.Ws), lgP = ilog2_exact_wg(g.Hs);
+    if (lgQ < 0 || lgP < 0 || g.Ws < 4) return false;
+    const int PQ = g.Hs * g.Ws;
+    if (g.Ws > WG_TPX) return false;
+    if (PQ >= WG_TPX) {
+        t->F = 1;
+        t->PT_H = WG_TPX / g.Ws;
+    } else {
+        t->F = WG_TPX / PQ;
+        t->PT_H = g.Hs;
+    }
+    t->lgQ = lgQ;
+    t->lgPTQ = ilog2_exact_wg(t->PT_H * g.Ws);
+    t->tiles_per_frame = (t->F == 1) ? g.Hs / t->PT_H : 1;
+    t->n_stages = ((g.N + t->F - 1) / t->F) * t->tiles_per_frame;
+    t->IH = 2 * (t->PT_H - 1) + 5;
+    const int IW = 2 * (g.Ws - 1) + 5;
+    t->HALF = (IW + 1) / 2;
+    t->RW = 2 * t->HALF;
+    t->FSb = t->IH * t->RW;
+    t->rows_per_b = t->F * t->IH;
+    int bch = t->F * t->FSb;
+    while ((bch & 31) != 2) ++bch;
+    t->BCH = bch;
+    t->big_elems = WG_TB * t->BCH;
+    if (t->big_elems > WG_THREADS * WG_KB) return false;
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;   // 32-bit offsets
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    t->inv_rw = 1.0f / (float)t->RW;
+    t->inv_bch = 1.0f / (float)t->BCH;
+    t->inv_ih = 1.0f / (float)t->IH;
+    t->sl_floats = WG_TA * (WG_TPX + 2);
+    *lds_bytes = ((size_t)t->sl_floats + (size_t)WG_TB * t->BCH) * 4;
+    return *lds_bytes <= WG_MAX_LDS;
+}
+
+static int wgrad_splits(const BnGeom& g, const WgradTile& t) {
+    const int tiles = ((g.Cs + WG_TA - 1) / WG_TA) * ((g.Cb + WG_TB - 1) / WG_TB);
+    int splits = (256 + tiles - 1) / tiles;         // one workgroup per CU
+    if (splits > t.n_stages) splits = t.n_stages;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+BnFastPlan bn_fast_wgrad_plan(const BnGeom& g) {
+    BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
+    if (g.R != 5 || g.S != 5 || g.stride != 2) return p;
+    if (g.Cs < 16 || g.Cb < 16) return p;
+    WgradTile t;
+    size_t lds = 0;
+    if (!wgrad_tile(g, &t, &lds)) return p;
+    p.supported = true;
+    p.d = wgrad_splits(g, t);
+    p.ws_bytes = (size_t)p.d * 25 * g.Cs * g.Cb * sizeof(float);
+    p.kernel_name = "k_wgrad_mfma<s2>";
+    return p;
+}
+
+int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float* big, float* dw,
+                         const BnGeom& g, int accumulate, void* ws, hipStream_t st) {
+    WgradTile t;
+    size_t lds = 0;
+    if (!wgrad_tile(g, &t, &lds)) return BN_E_SHAPE;
+    t.splits = plan.d;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_mfma,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WG_MAX_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int tiles = ((g.Cs + WG_TA - 1) / WG_TA) * ((g.Cb + WG_TB - 1) / WG_TB);
+    dim3 grid(tiles, t.splits);
+    hipLaunchKernelGGL(k_wgrad_mfma, grid, dim3(WG_THREADS), lds, st, small, big, (float*)ws, g, t);
+    BN_LAUNCH_CHECK();
+    return bn_launch_sum_partials((const float*)ws, dw, 25 * g.Cs * g.Cb, t.splits, accumulate,
+                                  g.Cs * g.Cb, 25, st);
+}

@@ -1,0 +1,201 @@
+// Layers whose stride equals the kernel size (the default arch's last encoder / first decoder
+// layer: k5 s5).  The 5x5 windows do not overlap, so every input element is used by exactly one
+// (output pixel, tap): the "gather" is a pure permutation and the op is a plain GEMM.  Operands
+// are short (K = 512 channels or N*4 pixels) and L2-resident, so these kernels feed
+// v_mfma_f32_32x32x2_f32 straight from global memory (per-lane gathers, no LDS staging):
+//
+//   up    (convT fwd / conv bwd-data):  D[(c,tap)][pixel] = sum_k W[k][c][tap] * small[n][k][p][q]
+//                                       scattered to out[n][c][5p+r-pt][5q+s-pl]
+//   wgrad (both weight gradients):      D[a][(b,tap)] = sum_pixel small[n][a][p][q] *
+//                                                       big[n][b][5p+r-pt][5q+s-pl]
+//
+// Out-of-range reads (padding, tails) go through raw buffer descriptors and return 0.
+#include "bn_common.h"
+#include "bn_fast.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define S5_THREADS 256
+#define S5_OOB 0x7fffffff
+
+__device__ __forceinline__ float ldbuf(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
+// ---------------------------------------------------------------------------------------------
+// up: rows = (c, tap) in [0, Cb*25), columns = small pixels in [0, N*Hs*Ws), K = Cs
+// workgroup: 4 waves, each 64 rows x 32 columns; grid (row tiles of 64, column tiles of 128)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(S5_THREADS) void k_up_s5(
+    const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, int act, int dact,
+    float slope) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, kk = lane >> 5;
+    const int rows = g.Cb * 25, HWs = g.Hs * g.Ws, npix = g.N * HWs;
+    const int row0 = blockIdx.x * 64;
+    const int col = (blockIdx.y * 4 + wv) * 32 + li;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)w, 0, (int)((size_t)g.Cs * rows * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)npix * g.Cs * 4), 0x00020000);
+
+    // A(i, k) = w[k*rows + row];  B(k, j) = small[(n*Cs + k)*HWs + pq]
+    int aoff[2];
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr) {
+        const int r = row0 + mr * 32 + li;
+        aoff[mr] = r < rows ? (kk * rows + r) * 4 : S5_OOB;
+    }
+    const int n = col / HWs, pq = col - n * HWs;
+    int boff = col < npix ? ((n * g.Cs + kk) * HWs + pq) * 4 : S5_OOB;
+    const int astep = 2 * rows * 4, bstep = 2 * HWs * 4;
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mr][e] = 0.f;
+
+    const int ksteps = (g.Cs + 1) / 2;
+#pragma unroll 4
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const bool kok = 2 * ks + kk < g.Cs;
+        const float b = ldbuf(rx, (kok && boff != S5_OOB) ? boff + ks * bstep : S5_OOB);
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+            const float a = ldbuf(rw, (kok && aoff[mr] != S5_OOB) ? aoff[mr] + ks * astep : S5_OOB);
+            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mr], 0, 0, 0);
+        }
+    }
+
+    // scatter: row -> (c, r, s), column -> (n, p, q) -> out[n][c][5p+r-pt][5q+s-pl]
+    if (col >= npix) return;
+    const int p = pq / g.Ws, q = pq - p * g.Ws;
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = row0 + mr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (r >= rows) continue;
+            const int c = r / 25, tap = r - c * 25;
+            const int tr = tap / 5, ts = tap - tr * 5;
+            const int h = 5 * p + tr - g.pt, x = 5 * q + ts - g.pl;
+            if (h < 0 || h >= g.Hb || x < 0 || x >= g.Wb) continue;
+            const size_t idx = (((size_t)n * g.Cb + c) * g.Hb + h) * g.Wb + x;
+            float v = acc[mr][e] + (bias ? bias[c] : 0.f);
+            v = bn_apply_act(v, act, slope);
+            if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
+            out[idx] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad: rows = a in [0, Cs), columns = (b, tap) in [0, Cb*25), K = N*Hs*Ws pixels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(S5_THREADS) void k_wgrad_s5(
+    const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ dw,
+    BnGeom g, int accumulate) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, kk = lane >> 5;
+    const int cols = g.Cb * 25, HWs = g.Hs * g.Ws, npix = g.N * HWs, HWb = g.Hb * g.Wb;
+    const int row0 = blockIdx.x * 64;
+    const int col = (blockIdx.y * 4 + wv) * 32 + li;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)npix * g.Cs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)big, 0, (int)((size_t)g.N * g.Cb * HWb * 4), 0x00020000);
+
+    // column -> (b, r, s): lane-constant part of the big-side address
+    const bool cok = col < cols;
+    const int b = cok ? col / 25 : 0;
+    const int tap = col - b * 25;
+    const int tr = tap / 5, ts = tap - tr * 5;
+    const int a_lane[2] = {row0 + li, row0 + 32 + li};
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mr][e] = 0.f;
+
+    const int ksteps = (npix + 1) / 2;
+#pragma unroll 4
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int pix = 2 * ks + kk;
+        const int n = pix / HWs, pq = pix - n * HWs;
+        const int p = pq / g.Ws, q = pq - p * g.Ws;
+        const int h = 5 * p + tr - g.pt, x = 5 * q + ts - g.pl;
+        const bool bok = cok && pix < npix && h >= 0 && h < g.Hb && x >= 0 && x < g.Wb;
+        const float bv = ldbuf(rb, bok ? (((n * g.Cb + b) * g.Hb + h) * g.Wb + x) * 4 : S5_OOB);
+#pragma unroll
+        for (int mr = 0; mr < 2; ++mr) {
+            const bool aok = pix < npix && a_lane[mr] < g.Cs;
+            const float av = ldbuf(rs, aok ? ((n * g.Cs + a_lane[mr]) * HWs + pq) * 4 : S5_OOB);
+            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mr], 0, 0, 0);
+        }
+    }
+
+    if (!cok) return;
+#pragma unroll
+    for (int mr = 0; mr < 2; ++mr) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int a = row0 + mr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (a >= g.Cs) continue;
+            float* o = dw + (size_t)a * cols + col;
+            *o = accumulate ? *o + acc[mr][e] : acc[mr][e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static bool s5_geom(const BnGeom& g) {
+    if (g.R != 5 || g.S != 5 || g.stride != 5) return false;
+    // every big-side pixel must map to a window inside the small image
+    if (g.Hb + g.pt > 5 * g.Hs || g.Wb + g.pl > 5 * g.Ws) return false;
+    if (g.pt > 4 || g.pl > 4) return false;
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    if ((size_t)g.Cs * g.Cb * 25 * 4 >= 0x7fffffffull) return false;
+    return g.Cs >= 32 && g.Cb >= 16;
+}
+
+BnFastPlan bn_s5_up_plan(const BnGeom& g) {
+    BnFastPlan p = {false, "k_up_generic", 0, 0, 0, 0, 0, 0};
+    if (!s5_geom(g)) return p;
+    p.supported = true;
+    p.kernel_name = "k_up_s5";
+    return p;
+}
+
+BnFastPlan bn_s5_wgrad_plan(const BnGeom& g) {
+    BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
+    if (!s5_geom(g)) return p;
+    p.supported = true;
+    p.kernel_name = "k_wgrad_s5";
+    return p;
+}
+
+int bn_launch_up_s5(const float* small, const float* w, const float* bias, float* out,
+                    const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                    hipStream_t st) {
+    const int rows = g.Cb * 25, npix = g.N * g.Hs * g.Ws;
+    dim3 grid((rows + 63) / 64, (npix + 127) / 128);
+    hipLaunchKernelGGL(k_up_s5, grid, dim3(S5_THREADS), 0, st, small, w, bias, out, dact_src, g,
+                       act, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_launch_wgrad_s5(const float* small, const float* big, float* dw, const BnGeom& g,
+                       int accumulate, hipStream_t st) {
+    const int cols = g.Cb * 25;
+    dim3 grid((g.Cs + 63) / 64, (cols + 127) / 128);
+    hipLaunchKernelGGL(k_wgrad_s5, grid, dim3(S5_THREADS), 0, st, small, big, dw, g, accumulate);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
