@@ -144,6 +144,13 @@ static inline bool ws_ok(const BnFastPlan& p, void* ws, size_t ws_bytes) {
 static int run_down(int family, const float* big, const float* w, const float* bias, float* out,
                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                     void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!force_generic()) {
+        const BnFastPlan ed = bn_edge_down_plan(g);
+        if (ed.supported) {
+            BnProfScope prof(family, g.Cb, g.Cs, ed.kernel_name, st);
+            return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
+        }
+    }
     BnFastPlan plan = bn_fast_down_plan(g);
     if (force_generic()) plan.supported = false;
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_down_generic", st);
@@ -162,6 +169,13 @@ static int run_up(int family, const float* small, const float* w, const float* b
         if (s5.supported) {
             BnProfScope prof(family, g.Cs, g.Cb, s5.kernel_name, st);
             return bn_launch_up_s5(small, w, bias, out, dact_src, g, act, dact, slope, st);
+        }
+    }
+    if (!force_generic() && !dact_src) {
+        const BnFastPlan ed = bn_edge_up_plan(g);
+        if (ed.supported) {
+            BnProfScope prof(family, g.Cs, g.Cb, ed.kernel_name, st);
+            return bn_launch_edge_up(small, w, bias, out, g, act, slope, st);
         }
     }
     BnFastPlan plan = bn_fast_up_plan(g);

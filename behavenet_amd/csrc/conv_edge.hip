@@ -150,3 +150,216 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
     BN_LAUNCH_CHECK();
     return bn_launch_sum_partials((const float*)ws, dw, g.Cs * 25, plan.d, accumulate, 0, 0, st);
 }
+
+// =============================================================================================
+// gather-down with one big-side channel (enc.conv0 forward, dec.convT4 data gradient):
+//   out[n,m,p,q] = epi( sum_{r,s} big[n,0,2p+r-pt,2q+s-pl] * W[m][0][r][s] ),   m < 32
+// MFMA roles: rows = m, columns = 32 output pixels of one row, reduction = 25 taps (13 steps,
+// the 26th tap is a zero weight).  Workgroup tile: 8 output rows x 64 columns (16 blocks, 4 per
+// wave) from a 19 x 131 input patch; output 64 KB per workgroup in 128-byte wavefront rows.
+// =============================================================================================
+#define DC_TH 8
+#define DC_W 64
+#define DC_IH (2 * DC_TH + 3)
+#define DC_RW (2 * DC_W + 4)
+#define DC_KB ((DC_IH * DC_RW + ED_THREADS - 1) / ED_THREADS)
+
+__global__ __launch_bounds__(ED_THREADS) void k_down_c1(
+    const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, int act, int dact,
+    float slope) {
+    __shared__ float bl[DC_IH * DC_RW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int tiles_per_frame = g.Hs / DC_TH;
+    const int n = blockIdx.x / tiles_per_frame;
+    const int p0 = (blockIdx.x - n * tiles_per_frame) * DC_TH;
+    const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
+
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)big, 0, (int)((size_t)g.N * HWb * 4), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < DC_KB; ++k) {
+        const int e = tid + ED_THREADS * k;
+        const int y = e / DC_RW, x = e - y * DC_RW;
+        const int hb = 2 * p0 - g.pt + y, wb = x - g.pl;
+        const bool ok = y < DC_IH && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+        const float v = ed_ld(rb, ok ? ((n * g.Hb + hb) * g.Wb + wb) * 4 : ED_OOB);
+        if (e < DC_IH * DC_RW) bl[e] = v;
+    }
+
+    // A operand: weights of output channel li, taps (2t + kk); lane-constant tap offsets
+    float av[13];
+    int toff[13];
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+        const int tap = 2 * t + kk;
+        av[t] = (tap < 25 && li < g.Cs) ? w[li * 25 + tap] : 0.f;
+        const int tc = tap < 25 ? tap : 0;
+        toff[t] = (tc / 5) * DC_RW + (tc % 5);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int bk = 0; bk < 4; ++bk) {
+        const int blk = wv * 4 + bk;
+        const int pr = blk >> 1, q = (blk & 1) * 32 + li;
+        const float* bq = bl + (2 * pr) * DC_RW + 2 * q;
+        floatx16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 13; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bq[toff[t]], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (m >= g.Cs) continue;
+            const size_t idx = ((size_t)n * g.Cs + m) * PQ + (size_t)(p0 + pr) * g.Ws + q;
+            float v = acc[e] + (bias ? bias[m] : 0.f);
+            v = bn_apply_act(v, act, slope);
+            if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
+            out[idx] = v;
+        }
+    }
+}
+
+BnFastPlan bn_edge_down_plan(const BnGeom& g) {
+    BnFastPlan p = {false, "k_down_generic", 0, 0, 0, 0, 0, 0};
+    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb != 1) return p;
+    if (g.Cs > 32 || g.Ws != DC_W || (g.Hs % DC_TH) != 0) return p;
+    if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
+    if ((size_t)g.N * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
+    p.supported = true;
+    p.kernel_name = "k_down_c1";
+    return p;
+}
+
+int bn_launch_edge_down(const float* big, const float* w, const float* bias, float* out,
+                        const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_down_c1, dim3(g.N * (g.Hs / DC_TH)), dim3(ED_THREADS), 0, st, big, w, bias,
+                       out, dact_src, g, act, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// =============================================================================================
+// gather-up with one big-side channel (dec.convT4 forward):
+//   out[n,0,h,w] = act( b + sum_{c,r,s} small[n,c,p,q] * W[c][0][r][s] ),  2p+r = h+1, 2q+s = w+1
+// Two phases per workgroup (8 small-image rows -> 16 x 128 output pixels):
+//  1. a skinny GEMM on the matrix cores  T[tap][pos] = sum_c W[c][tap] * small[c][pos]
+//     (rows = 25 taps, K = Cs channels, columns = positions incl. a one-pixel halo), small read
+//     straight from HBM in wavefront rows, T kept in LDS;
+//  2. every output pixel gathers its <= 9 contributions T[(r,s)][(p,q)] from LDS, adds the
+//     bias, applies the activation and is stored as float2 (both column parities per lane).
+// =============================================================================================
+#define UC_TH 8
+#define UC_W 64
+#define UC_PW (UC_W + 2)                      // positions per row incl. halo
+#define UC_NPOS ((UC_TH + 2) * UC_PW)         // 660
+#define UC_NBLK ((UC_NPOS + 31) / 32)         // 21
+#define UC_DP (UC_NBLK * 32)                  // 672: row stride of T in LDS
+#define UC_LDS (25 * UC_DP * 4)
+
+__global__ __launch_bounds__(ED_THREADS) void k_up_c1(
+    const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, BnGeom g, int act, float slope) {
+    extern __shared__ __attribute__((aligned(16))) float dl[];     // T[25][UC_DP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int tiles_per_frame = g.Hs / UC_TH;
+    const int n = blockIdx.x / tiles_per_frame;
+    const int a0 = (blockIdx.x - n * tiles_per_frame) * UC_TH;
+    const int HWs = g.Hs * g.Ws;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)g.N * g.Cs * HWs * 4), 0x00020000);
+
+    // A operand: W[c = 2t+kk][tap = li]   (Cs <= 32 -> 16 steps)
+    float av[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int c = 2 * t + kk;
+        av[t] = (li < 25 && c < g.Cs) ? w[c * 25 + li] : 0.f;
+    }
+
+    for (int blk = wv; blk < UC_NBLK; blk += 4) {
+        const int f = blk * 32 + li;
+        const int py = f / UC_PW, px = f - py * UC_PW;
+        const int p = a0 - 1 + py, q = px - 1;
+        const bool ok = f < UC_NPOS && p >= 0 && p < g.Hs && q >= 0 && q < g.Ws;
+        const int boff = ok ? ((n * g.Cs + kk) * HWs + p * g.Ws + q) * 4 : ED_OOB;
+        float bv[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            bv[t] = ed_ld(rs, (ok && 2 * t + kk < g.Cs) ? boff + t * (2 * HWs * 4) : ED_OOB);
+        floatx16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int tap = (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (tap < 25) dl[tap * UC_DP + f] = acc[e];
+        }
+    }
+    __syncthreads();
+
+    // phase 2: thread -> column pair b (w = 2b, 2b+1), wave -> row h_l = 4k + wv
+    const int b = lane;
+    const float bs = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int hl = 4 * k + wv;                 // 0..15
+        const int h = 2 * a0 + hl;
+        const int hh = hl + 1;                     // (h + pt) relative to row 2*a0, pt = 1
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int r = (hh & 1) + 2 * u;
+            if (r >= 5) continue;
+            const int py = ((hh - r) >> 1) + 1;     // position row inside the tile (halo = 1)
+            const float* row = dl + py * UC_PW;
+            // w = 2b   -> ww = 2b+1: s in {1,3}, q = b - {0,1}   -> px = q + 1
+            o0 += row[(r * 5 + 1) * UC_DP + b + 1] + row[(r * 5 + 3) * UC_DP + b];
+            // w = 2b+1 -> ww = 2b+2: s in {0,2,4}, q = b + 1 - {0,1,2}
+            o1 += (row[(r * 5 + 0) * UC_DP + b + 2] + row[(r * 5 + 2) * UC_DP + b + 1]) +
+                  row[(r * 5 + 4) * UC_DP + b];
+        }
+        float2 v;
+        v.x = bn_apply_act(o0 + bs, act, slope);
+        v.y = bn_apply_act(o1 + bs, act, slope);
+        *reinterpret_cast<float2*>(out + ((size_t)n * g.Hb + h) * g.Wb + 2 * b) = v;
+    }
+}
+
+BnFastPlan bn_edge_up_plan(const BnGeom& g) {
+    BnFastPlan p = {false, "k_up_generic", 0, 0, 0, 0, 0, 0};
+    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb != 1 || g.pt != 1 || g.pl != 1) return p;
+    if (g.Cs > 32 || g.Ws != UC_W || (g.Hs % UC_TH) != 0) return p;
+    if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
+    p.supported = true;
+    p.kernel_name = "k_up_c1";
+    return p;
+}
+
+int bn_launch_edge_up(const float* small, const float* w, const float* bias, float* out,
+                      const BnGeom& g, int act, float slope, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_up_c1,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, UC_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_up_c1, dim3(g.N * (g.Hs / UC_TH)), dim3(ED_THREADS), UC_LDS, st, small, w,
+                       bias, out, g, act, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
