@@ -131,10 +131,13 @@ def _workspace(op, geom, device):
     nbytes = load().bn_conv_ws_bytes(op, *geom)
     if nbytes == 0:
         return None, 0
-    buf = _ws_cache.get(device)
+    # one arena per (device, stream): kernels on different streams may run concurrently
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[device] = buf
+        with torch.cuda.stream(torch.cuda.current_stream(device)):
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
     return buf.data_ptr(), nbytes
 
 

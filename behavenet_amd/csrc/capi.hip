@@ -146,7 +146,11 @@ static int run_down(int family, const float* big, const float* w, const float* b
                     void* ws, size_t ws_bytes, hipStream_t st) {
     if (!force_generic()) {
         const BnFastPlan ed = bn_edge_down_plan(g);
-        if (ed.supported) {
+        // epilogues the edge kernel is instantiated for: plain / LeakyReLU forward, or a data
+        // gradient carrying the LeakyReLU' mask of the layer below
+        const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
+                                     : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
+        if (ed.supported && epi_ok) {
             BnProfScope prof(family, g.Cb, g.Cs, ed.kernel_name, st);
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }

@@ -164,10 +164,14 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
 #define DC_RW (2 * DC_W + 4)
 #define DC_KB ((DC_IH * DC_RW + ED_THREADS - 1) / ED_THREADS)
 
+// MFMA roles: rows = 32 output pixels of one image row (A = gathered input), columns = output
+// channels (B = weights), so that after the 13 steps a lane holds, for ITS channel, four groups
+// of 4 consecutive pixels -> the epilogue is four 16-byte stores (and four 16-byte mask loads)
+// per 32-pixel block instead of sixteen 4-byte ones.
+template <int ACT, bool MASK>
 __global__ __launch_bounds__(ED_THREADS) void k_down_c1(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, int act, int dact,
-    float slope) {
+    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope) {
     __shared__ float bl[DC_IH * DC_RW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,48 +183,64 @@ __global__ __launch_bounds__(ED_THREADS) void k_down_c1(
 
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)big, 0, (int)((size_t)g.N * HWb * 4), 0x00020000);
+    float stage[DC_KB];
 #pragma unroll
     for (int k = 0; k < DC_KB; ++k) {
         const int e = tid + ED_THREADS * k;
         const int y = e / DC_RW, x = e - y * DC_RW;
         const int hb = 2 * p0 - g.pt + y, wb = x - g.pl;
         const bool ok = y < DC_IH && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
-        const float v = ed_ld(rb, ok ? ((n * g.Hb + hb) * g.Wb + wb) * 4 : ED_OOB);
-        if (e < DC_IH * DC_RW) bl[e] = v;
+        stage[k] = ed_ld(rb, ok ? ((n * g.Hb + hb) * g.Wb + wb) * 4 : ED_OOB);
     }
 
-    // A operand: weights of output channel li, taps (2t + kk); lane-constant tap offsets
-    float av[13];
+    // B operand: weights of output channel li for taps (2t + kk); lane-constant tap offsets of
+    // the A gather (pixel li of the block, tap 2t + kk)
+    float wv_[13];
     int toff[13];
 #pragma unroll
     for (int t = 0; t < 13; ++t) {
         const int tap = 2 * t + kk;
-        av[t] = (tap < 25 && li < g.Cs) ? w[li * 25 + tap] : 0.f;
+        wv_[t] = (tap < 25 && li < g.Cs) ? w[li * 25 + tap] : 0.f;
         const int tc = tap < 25 ? tap : 0;
         toff[t] = (tc / 5) * DC_RW + (tc % 5);
     }
+    const float bz = (bias && li < g.Cs) ? bias[li] : 0.f;
+#pragma unroll
+    for (int k = 0; k < DC_KB; ++k) {
+        const int e = tid + ED_THREADS * k;
+        if (e < DC_IH * DC_RW) bl[e] = stage[k];
+    }
     __syncthreads();
 
-#pragma unroll 1
+    // lane -> (channel li, pixel quad 4*kk + 8*grp) of every block
+    const size_t chan = ((size_t)n * g.Cs + li) * PQ;
+#pragma unroll 2
     for (int bk = 0; bk < 4; ++bk) {
         const int blk = wv * 4 + bk;
-        const int pr = blk >> 1, q = (blk & 1) * 32 + li;
-        const float* bq = bl + (2 * pr) * DC_RW + 2 * q;
+        const int pr = blk >> 1, q0 = (blk & 1) * 32;
+        const float* aq = bl + (2 * pr) * DC_RW + 2 * (q0 + li);
         floatx16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int t = 0; t < 13; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bq[toff[t]], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[toff[t]], wv_[t], acc, 0, 0, 0);
+        if (li >= g.Cs) continue;
+        const size_t row = chan + (size_t)(p0 + pr) * g.Ws + q0 + 4 * kk;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = (e & 3) + 8 * (e >> 2) + 4 * kk;
-            if (m >= g.Cs) continue;
-            const size_t idx = ((size_t)n * g.Cs + m) * PQ + (size_t)(p0 + pr) * g.Ws + q;
-            float v = acc[e] + (bias ? bias[m] : 0.f);
-            v = bn_apply_act(v, act, slope);
-            if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
-            out[idx] = v;
+        for (int grp = 0; grp < 4; ++grp) {
+            float4 v = make_float4(acc[4 * grp] + bz, acc[4 * grp + 1] + bz, acc[4 * grp + 2] + bz,
+                                   acc[4 * grp + 3] + bz);
+            if (ACT == BN_ACT_LRELU) {
+                v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+                v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+            }
+            if (MASK) {
+                const float4 d = *reinterpret_cast<const float4*>(dact_src + row + 8 * grp);
+                v.x *= d.x > 0.f ? 1.f : slope; v.y *= d.y > 0.f ? 1.f : slope;
+                v.z *= d.z > 0.f ? 1.f : slope; v.w *= d.w > 0.f ? 1.f : slope;
+            }
+            *reinterpret_cast<float4*>(out + row + 8 * grp) = v;
         }
     }
 }
@@ -239,8 +259,17 @@ BnFastPlan bn_edge_down_plan(const BnGeom& g) {
 int bn_launch_edge_down(const float* big, const float* w, const float* bias, float* out,
                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                         hipStream_t st) {
-    hipLaunchKernelGGL(k_down_c1, dim3(g.N * (g.Hs / DC_TH)), dim3(ED_THREADS), 0, st, big, w, bias,
-                       out, dact_src, g, act, dact, slope);
+    const dim3 grid(g.N * (g.Hs / DC_TH));
+    if (act == BN_ACT_LRELU && !dact_src) {
+        hipLaunchKernelGGL((k_down_c1<BN_ACT_LRELU, false>), grid, dim3(ED_THREADS), 0, st, big, w,
+                           bias, out, dact_src, g, slope);
+    } else if (act == BN_ACT_NONE && !dact_src) {
+        hipLaunchKernelGGL((k_down_c1<BN_ACT_NONE, false>), grid, dim3(ED_THREADS), 0, st, big, w,
+                           bias, out, dact_src, g, slope);
+    } else {   // data gradient: no activation of its own, LeakyReLU' mask of the layer below
+        hipLaunchKernelGGL((k_down_c1<BN_ACT_NONE, true>), grid, dim3(ED_THREADS), 0, st, big, w,
+                           bias, out, dact_src, g, slope);
+    }
     BN_LAUNCH_CHECK();
     return 0;
 }

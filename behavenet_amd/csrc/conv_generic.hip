@@ -164,9 +164,18 @@ __global__ __launch_bounds__(GEN_THREADS) void k_channel_sum(
     __shared__ float red[4];
     const int c = blockIdx.x;
     float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float* tp = t + ((size_t)n * C + c) * npix;
-        for (int i = threadIdx.x; i < npix; i += GEN_THREADS) acc += tp[i];
+    if (npix >= GEN_THREADS) {
+        for (int n = 0; n < N; ++n) {
+            const float* tp = t + ((size_t)n * C + c) * npix;
+            for (int i = threadIdx.x; i < npix; i += GEN_THREADS) acc += tp[i];
+        }
+    } else {
+        // few pixels per frame (e.g. 2x2 maps): spread (frame, pixel) pairs over the threads
+        const int total = N * npix;
+        for (int i = threadIdx.x; i < total; i += GEN_THREADS) {
+            const int n = i / npix, px = i - n * npix;
+            acc += t[((size_t)n * C + c) * npix + px];
+        }
     }
     const float s = bn_block_reduce_256(acc, red);
     if (threadIdx.x == 0) db[c] = accumulate ? db[c] + s : s;

@@ -6,6 +6,7 @@
 // No im2col matrix is ever materialised: a workgroup stages an input tile (with its halo and
 // the zero padding) and a slice of the weights in LDS, and every lane gathers its MFMA operand
 // straight from that tile.  See DESIGN.md "Kernel families" for the tilings.
+#include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"
 
@@ -166,29 +167,44 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_down_mfma(
         __syncthreads();
         if (c0 + CC < c_end) issue_loads(c0 + CC);   // in flight behind the MFMAs below
 
-        // one (channel pair, kernel row) per trip: S taps unrolled keeps ~S*(MR+NR) operand
-        // registers live instead of letting the scheduler hoist all R*S*CC/2 LDS reads
-#pragma unroll 1
-        for (int it = 0; it < (CC / 2) * R; ++it) {
+        // MFMA loop, one (channel pair, kernel row) = S taps per "row".  Operands are double
+        // buffered by hand: the LDS reads of row i+1 are issued BEFORE the MFMAs of row i (the
+        // sched_barriers pin that order), so an MFMA never waits on an LDS round trip.
+        constexpr int NIT = (CC / 2) * R;
+        float a0[S][MR], b0[S][NR], a1[S][MR], b1[S][NR];
+        auto load_row = [&](int it, float (&av)[S][MR], float (&bv)[S][NR]) {
             const int cp = it / R, r = it - cp * R;
             const float* wa = wl + ((2 * cp + kk) * RS + r * S) * TMP + li;
             const float* xb = xl + (2 * cp) * t.CHS + r * t.IWp;
-            {
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    float av[MR], bv[NR];
+            for (int s = 0; s < S; ++s) {
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) av[mr] = wa[s * TMP + mr * 32];
+                for (int mr = 0; mr < MR; ++mr) av[s][mr] = wa[s * TMP + mr * 32];
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) bv[nr] = xb[base[nr] + s];
-#pragma unroll
-                    for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                        for (int nr = 0; nr < NR; ++nr)
-                            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                av[mr], bv[nr], acc[mr][nr], 0, 0, 0);
-                }
+                for (int nr = 0; nr < NR; ++nr) bv[s][nr] = xb[base[nr] + s];
             }
+        };
+        auto mfma_row = [&](float (&av)[S][MR], float (&bv)[S][NR]) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            av[s][mr], bv[s][nr], acc[mr][nr], 0, 0, 0);
+        };
+        load_row(0, a0, b0);
+#pragma unroll 1
+        for (int it = 0; it < NIT; it += 2) {
+            if (it + 1 < NIT) load_row(it + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 2 < NIT) load_row(it + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + 1 < NIT) mfma_row(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -284,11 +300,21 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
         if (cand[i][0] == 2 && g.Cs < 64) continue;
         int nwg = 0;
         if (!down_tile(g, cand[i][0], cand[i][1], CC, &t, &nwg)) continue;
-        if (best < 0 || (best_wg < 768 && nwg > best_wg)) {
+        if (best < 0 || (best_wg < 384 && nwg > best_wg)) {
             best = i;
             best_wg = nwg;
         }
-        if (best_wg >= 768) break;
+        if (best_wg >= 384) break;
+    }
+    // tuning hook (tools/kbench.py): BN_DOWN_TILE=<candidate index 0..2> pins the tile shape
+    if (const char* e = getenv("BN_DOWN_TILE")) {
+        const int i = e[0] - '0';
+        int nwg = 0;
+        if (i >= 0 && i < 3 && !(cand[i][0] == 2 && g.Cs < 64) &&
+            down_tile(g, cand[i][0], cand[i][1], CC, &t, &nwg)) {
+            best = i;
+            best_wg = nwg;
+        }
     }
     if (best < 0) return p;
     p.supported = true;

@@ -35,11 +35,23 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = 0.f;
 
-    for (int k = kbeg + lk; k < kend + lk; k += 2) {
-        const bool k_ok = k < kend;
-        const float av = (a_ok && k_ok) ? ap[(long)k * a.sak] : 0.f;
-        const float bv = (b_ok && k_ok) ? bp[(long)k * a.sbk] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    // 8 reduction steps per trip: 16 independent (clamped, unconditional) loads are in flight
+    // before the first MFMA needs one -- these skinny GEMMs are latency-, not bandwidth-bound
+    const int klast = max(kend - 1, kbeg);
+    for (int k0 = kbeg + lk; k0 < kend + lk; k0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + 2 * u, klast);
+            av[u] = ap[(long)k * a.sak];
+            bv[u] = bp[(long)k * a.sbk];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = (k0 + 2 * u) < kend;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_ok && ok) ? av[u] : 0.f,
+                                                       (b_ok && ok) ? bv[u] : 0.f, acc, 0, 0, 0);
+        }
     }
 
     if (SPLITK > 1) {

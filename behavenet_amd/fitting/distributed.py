@@ -63,6 +63,9 @@ def all_reduce_flat_(flat, average=False):
     """In-place sum (or mean) of one flat buffer over all ranks; no-op for world_size 1."""
     if not is_active():
         return flat
+    if flat.is_cuda:
+        from behavenet_amd.hip_functions import join_side_streams
+        join_side_streams()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat.div_(world_size())

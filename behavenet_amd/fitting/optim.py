@@ -16,6 +16,7 @@ views into the arena).
 import torch
 
 from behavenet_amd import _hip
+from behavenet_amd.hip_functions import join_side_streams
 
 _ALIGN = 4  # floats (16 bytes)
 
@@ -62,10 +63,12 @@ class FlatAdamAMSGrad(object):
                 p.grad = view
 
     def zero_grad(self):
+        join_side_streams()   # pending side-stream accumulations must not race the memset
         self._grads_in_arena()
         self.flat_g.zero_()
 
     def step(self):
+        join_side_streams()   # weight gradients queued on the side stream are complete
         self._grads_in_arena()
         self.step_count += 1
         if self.flat_p.is_cuda:

@@ -19,6 +19,58 @@ from behavenet_amd import _hip
 
 LRELU_SLOPE = 0.05  # aes.py:114,341
 
+# When set (by the models' loss() around loss.backward()), weight/bias gradients are accumulated
+# by the kernels straight into existing `param.grad` buffers (accumulate=1 of the C ABI) and the
+# autograd node returns None for them: this is the reference's cross-chunk `+=` without the
+# temporary + add-kernel per parameter.  Off by default so torch.autograd.grad() keeps working.
+_direct_grads = False
+
+
+class accumulate_into_param_grads(object):
+    """Context manager: let backward kernels add into `param.grad` in place."""
+
+    def __enter__(self):
+        global _direct_grads
+        self._prev = _direct_grads
+        _direct_grads = True
+
+    def __exit__(self, *exc):
+        global _direct_grads
+        _direct_grads = self._prev
+        return False
+
+
+_use_side_stream = True
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    s = _side_streams.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _side_streams[key] = s
+    return s
+
+
+def join_side_streams():
+    """Make the current stream wait for all weight-gradient work queued on the side streams.
+
+    Called by the models at the end of ``loss()`` and by the optimizer before ``step()``.
+    """
+    for key, s in _side_streams.items():
+        torch.cuda.current_stream(s.device).wait_stream(s)
+
+
+def _grad_buffer(p):
+    """`p.grad` if the kernels may accumulate into it directly, else None."""
+    if not _direct_grads or not isinstance(p, torch.nn.Parameter):
+        return None
+    g = p.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32 or not g.is_cuda:
+        return None
+    return g
+
 
 class ConvLayerPlan(object):
     """Geometry of one fused layer, independent of the batch size.
@@ -72,6 +124,7 @@ class ConvStackFn(torch.autograd.Function):
             acts.append(h)
         ctx.plan = plan
         ctx.need_dx = x.requires_grad
+        ctx.param_refs = params
         ctx.save_for_backward(*acts, *params[0::2])
         return h
 
@@ -99,14 +152,34 @@ class ConvStackFn(torch.autograd.Function):
             need_w = ctx.needs_input_grad[2 + 2 * i]
             need_b = ctx.needs_input_grad[3 + 2 * i]
             if need_w:
-                dw = torch.empty_like(w)
-                db = torch.empty((layer.cout,), dtype=w.dtype, device=w.device) if need_b \
-                    else None
-                if layer.kind == 'conv':
-                    _hip.conv2d_bwd_weight(x_in, dpre, dw, db, g, False)
+                gw = _grad_buffer(ctx.param_refs[2 * i])
+                gb = _grad_buffer(ctx.param_refs[2 * i + 1]) if need_b else None
+                direct = gw is not None and (gb is not None or not need_b)
+                if direct:
+                    dw, db = gw, gb
                 else:
-                    _hip.convT2d_bwd_weight(x_in, dpre, dw, db, g, False)
-                grads[2 * i], grads[2 * i + 1] = dw, db
+                    dw = torch.empty_like(w)
+                    db = torch.empty((layer.cout,), dtype=w.dtype, device=w.device) if need_b \
+                        else None
+                wgrad = _hip.conv2d_bwd_weight if layer.kind == 'conv' else _hip.convT2d_bwd_weight
+                side = _side_stream(w.device) if (direct and _use_side_stream) else None
+                if side is not None:
+                    # weight gradients go to a second HIP stream: they only depend on dpre and the
+                    # saved input, while the main stream continues down the data-gradient chain;
+                    # the tail of one kernel is filled by workgroups of the other.  Gradients
+                    # land in param.grad in stream order; join_side_streams() publishes them.
+                    main = torch.cuda.current_stream(w.device)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        wgrad(x_in, dpre, dw, db, g, True)
+                    dpre.record_stream(side)
+                    x_in.record_stream(side)
+                else:
+                    wgrad(x_in, dpre, dw, db, g, direct)
+                if not direct:
+                    grads[2 * i], grads[2 * i + 1] = dw, db
             if i > 0 or ctx.need_dx:
                 # fuse the derivative of the layer below into this kernel's epilogue
                 dact_src = acts[i] if i > 0 else None
@@ -131,6 +204,7 @@ class LinearFn(torch.autograd.Function):
         x = x.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.param_refs = (w, b)
         return _hip.linear_fwd(x, w.detach().contiguous(),
                                b.detach() if b is not None else None)
 
@@ -140,10 +214,18 @@ class LinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_db = ctx.has_bias and ctx.needs_input_grad[2]
-        dw = torch.empty_like(w) if need_dw else None
-        db = torch.empty((w.shape[0],), dtype=w.dtype, device=w.device) if need_db else None
+        gw = _grad_buffer(ctx.param_refs[0]) if need_dw else None
+        gb = _grad_buffer(ctx.param_refs[1]) if need_db else None
+        direct = need_dw and gw is not None and (gb is not None or not need_db)
+        if direct:
+            dw, db = gw, gb
+        else:
+            dw = torch.empty_like(w) if need_dw else None
+            db = torch.empty((w.shape[0],), dtype=w.dtype, device=w.device) if need_db else None
         dx = _hip.linear_bwd(x, w.contiguous(), dy, need_dx, None, _hip.ACT_NONE, 0.0, dw, db,
-                             False)
+                             direct)
+        if direct:
+            return dx, None, None
         return dx, dw, db
 
 

@@ -15,7 +15,8 @@ from torch import nn
 import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
 from behavenet_amd.models.base import BaseModule, BaseModel
-from behavenet_amd.hip_functions import ConvLayerPlan, conv_stack, linear
+from behavenet_amd.hip_functions import (
+    ConvLayerPlan, conv_stack, linear, accumulate_into_param_grads, join_side_streams)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
@@ -442,10 +443,12 @@ class AE(BaseModel):
                 x_hat, _ = self.forward(x_in, dataset=dataset)
                 loss = losses.mse(x_in, x_hat, m_in)
             if accumulate_grad:
-                loss.backward()
+                with accumulate_into_param_grads():
+                    loss.backward()
             vals.append(loss.detach())
             sizes.append(end - beg)
 
+        join_side_streams()
         vals = torch.stack(vals).cpu().numpy().astype(np.float64)
         loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
         return {'loss': loss_val}
@@ -491,9 +494,11 @@ class ConditionalAE(AE):
                 x_hat, _ = self.forward(x_in, dataset=dataset, labels=y_in, labels_2d=l2d)
                 loss = losses.mse(x_in, x_hat, m_in)
             if accumulate_grad:
-                loss.backward()
+                with accumulate_into_param_grads():
+                    loss.backward()
             vals.append(loss.detach())
             sizes.append(end - beg)
+        join_side_streams()
         vals = torch.stack(vals).cpu().numpy().astype(np.float64)
         loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
         return {'loss': loss_val}
