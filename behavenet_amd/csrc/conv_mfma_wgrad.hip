@@ -5,11 +5,17 @@
 // v_mfma_f32_16x16x4_f32 (4 accumulator registers) lets one wave keep all 25 taps of a 16x16
 // (a,b) block resident: 100 accumulator registers, one A read + 25 B reads per 25 MFMAs.
 // A workgroup is 8 waves = 4(a) x 2(b) blocks -> a 64 x 32 tile of dW, and walks a strided set
-// of 64-pixel "stages" (software-pipelined global->register->LDS staging).  The big-side tile
-// is stored column-parity-split in LDS (x -> (x&1)*HALF + x/2) so that the stride-2 gather of
-// four consecutive pixels is bank-conflict free.  The reduction over stages is split over
-// workgroups; partial tiles go to scratch as [split][tap][a][b] and k_wgrad_reduce sums them
-// in fixed order (deterministic, no atomics) into dW[a][b][tap] (+= when accumulating).
+// of 64-pixel "stages".
+//
+// Staging is pure LDS-DMA (buffer_load ... lds): every thread's k-th element IS LDS word
+// tid + 512*k of the stage image, so a wave's 64 lanes land contiguously and only the per-lane
+// SOURCE offset is computed; out-of-range offsets (zero padding, halo, channel / frame tails)
+// arrive as 0.0f.  No staging registers, no ds_write pass; the image is double buffered
+// (2 x 78 KB of the 160 KB LDS) so the DMA of stage i+1 runs behind the MFMAs of stage i with
+// one barrier per stage.  The big-side tile is stored column-parity-split
+// (x -> (x&1)*HALF + x/2) so the stride-2 gather of four consecutive pixels is bank-conflict
+// free.  Partial tiles go to scratch as [split][tap][a][b]; k_sum_partials combines them in
+// fixed order (deterministic, no atomics) into dW[a][b][tap] (+= when accumulating).
 #include "bn_common.h"
 #include "bn_fast.h"
 #include "bn_reduce.h"
@@ -20,9 +26,11 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define WG_TA 64            // a-channels per workgroup tile
 #define WG_TB 32            // b-channels per workgroup tile
 #define WG_TPX 64           // small-image pixels per stage
-#define WG_KB 31            // max big-tile elements per thread per stage
-#define WG_KS ((WG_TA * WG_TPX) / WG_THREADS)   // small-tile elements per thread per stage (8)
-#define WG_MAX_LDS (96 * 1024)
+#define WG_SP (WG_TPX + 2)  // small tile row stride (== 2 mod 32: conflict-free A reads)
+#define WG_KB 31            // max big-tile words per thread per stage
+#define WG_KS ((WG_TA * WG_TPX) / WG_THREADS)   // small-tile words per thread per stage (8)
+#define WG_MAX_LDS (160 * 1024)
+#define WG_OOB 0x7fffffff
 
 static inline int ilog2_exact_wg(int v) {
     int l = 0;
@@ -37,20 +45,17 @@ struct WgradTile {
     int IH, HALF, RW;              // big tile rows per frame, parity-half length, row stride
     int FSb;                       // per-frame stride inside a channel (IH * RW)
     int BCH;                       // per-channel stride (== 2 mod 32: conflict-free B reads)
-    int big_elems;                 // WG_TB * F * IH * RW
-    float inv_rw, inv_bch, inv_ih; // reciprocals for the staging index decode
+    int big_words;                 // WG_TB * BCH
+    float inv_rw, inv_bch, inv_ih; // reciprocals for the source-offset decode
     int rows_per_b;                // F * IH
     int splits;                    // reduction splits (gridDim.y)
-    int sl_floats;
+    int buf_floats;                // one LDS stage image: WG_TA*WG_SP + WG_TB*BCH (16-B multiple)
 };
 
 __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
     BnGeom g, WgradTile t) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int SP = WG_TPX + 2;          // small tile row stride (== 2 mod 32)
-    float* sl = smem;                        // [WG_TA][SP]
-    float* bl = smem + t.sl_floats;          // [WG_TB][BCH]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ablk = wv >> 1, bblk = wv & 1;
@@ -65,43 +70,34 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
 #pragma unroll
     for (int tp = 0; tp < 25; ++tp) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
 
-    float sr[WG_KS];
-    float br[WG_KB];
-
-    // raw buffer descriptors: an out-of-range byte offset reads as 0.0f, which gives the zero
-    // padding, the halo, channel tails and frame tails without any select on the loaded value
     const __amdgpu_buffer_rsrc_t rs_small = __builtin_amdgcn_make_buffer_rsrc(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(
         (void*)big, 0, (int)((size_t)g.N * g.Cb * HWb * 4), 0x00020000);
-    constexpr int OOB = 0x7fffffff;
 
-    // stage -> (first frame, first small-image row)
-    auto stage_origin = [&](int st, int& n0, int& p0) {
+    // queue the LDS-DMA of one stage into image `buf`
+    auto issue_dma = [&](int st, int buf) {
         const int grp = st / t.tiles_per_frame;
-        n0 = grp * t.F;
-        p0 = (st - grp * t.tiles_per_frame) * t.PT_H;
-    };
-
-    // The thread's k-th big-tile element IS LDS word e = tid + 512*k of the padded image
-    // bl[b][BCH] (publishing is a plain store); its source is decoded per stage:
-    //   b = e / BCH, within = e % BCH -> (row rr = f*IH + y, parity-split column xx)
-    auto issue_loads = [&](int st) {
-        int n0, p0;
-        stage_origin(st, n0, p0);
+        const int n0 = grp * t.F;
+        const int p0 = (st - grp * t.tiles_per_frame) * t.PT_H;
+        float* sl = smem + buf * t.buf_floats;
+        float* bl = sl + WG_TA * WG_SP;
+        // small tile: word (a = 8k + wv, pix = lane); a stage's pixels are contiguous per frame
 #pragma unroll
         for (int k = 0; k < WG_KS; ++k) {
-            const int e = tid + WG_THREADS * k;
-            const int a = e >> 6, pix = e & (WG_TPX - 1);
-            const int f = pix >> t.lgPTQ;
-            const int rem = pix & ((1 << t.lgPTQ) - 1);
+            const int a = 8 * k + wv;
+            const int f = lane >> t.lgPTQ;
+            const int rem = lane & ((1 << t.lgPTQ) - 1);
             const bool ok = (a0 + a < g.Cs) && (n0 + f < g.N);
             const int off = (((n0 + f) * g.Cs + a0 + a) * PQ + p0 * Q + rem) * 4;
-            sr[k] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rs_small, ok ? off : OOB, 0, 0));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_small, sl + a * WG_SP, 4,
+                                                     ok ? off : WG_OOB, 0, 0, 0);
         }
+        // big tile: word e = tid + 512k of bl[b][BCH]:  b = e / BCH, within = e % BCH ->
+        // (row rr = f*IH + y, parity-split column xx) -> source pixel (hb, wb)
 #pragma unroll
         for (int k = 0; k < WG_KB; ++k) {
+            if (WG_THREADS * k + 64 * wv >= t.big_words) break;      // wave-uniform
             int e = tid + WG_THREADS * k;
             asm volatile("" : "+v"(e));   // keep the decode inside the stage loop (no hoisting)
             const int b = (int)(((float)e + 0.5f) * t.inv_bch);
@@ -116,35 +112,26 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
             const bool ok = (b < WG_TB) && (rr < t.rows_per_b) && (b0 + b < g.Cb) &&
                             (n0 + f < g.N) && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
             const int off = ((((n0 + f) * g.Cb + b0 + b) * g.Hb + hb) * g.Wb + wb) * 4;
-            br[k] = __builtin_bit_cast(
-                float, __builtin_amdgcn_raw_buffer_load_b32(rs_big, ok ? off : OOB, 0, 0));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_big, bl + WG_THREADS * k + 64 * wv, 4,
+                                                     ok ? off : WG_OOB, 0, 0, 0);
         }
     };
 
-    auto publish = [&]() {
-#pragma unroll
-        for (int k = 0; k < WG_KS; ++k) {
-            const int e = tid + WG_THREADS * k;
-            sl[(e >> 6) * SP + (e & (WG_TPX - 1))] = sr[k];
-        }
-#pragma unroll
-        for (int k = 0; k < WG_KB; ++k) {
-            const int e = tid + WG_THREADS * k;
-            if (e < WG_TB * t.BCH) bl[e] = br[k];
-        }
-    };
-
-    const float* ap = sl + (ablk * 16 + lj) * SP + kk;
-    const float* bp = bl + (bblk * 16 + lj) * t.BCH;
+    const int a_off = (ablk * 16 + lj) * WG_SP + kk;
+    const int b_off = WG_TA * WG_SP + (bblk * 16 + lj) * t.BCH;
 
     int st = blockIdx.y;
-    if (st < t.n_stages) issue_loads(st);
+    int cur = 0;
+    if (st < t.n_stages) issue_dma(st, 0);
     for (; st < t.n_stages; st += t.splits) {
+        // own DMAs of this stage have landed; after the barrier everyone's have, and every wave
+        // is done reading the other image (it was computed from in the previous trip)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        publish();
-        __syncthreads();
-        if (st + t.splits < t.n_stages) issue_loads(st + t.splits);
+        if (st + t.splits < t.n_stages) issue_dma(st + t.splits, cur ^ 1);
 
+        const float* ap = smem + cur * t.buf_floats + a_off;
+        const float* bp = smem + cur * t.buf_floats + b_off;
 #pragma unroll 2
         for (int ks = 0; ks < WG_TPX / 4; ++ks) {
             const int pix = 4 * ks + kk;
@@ -163,6 +150,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
                 }
             }
         }
+        cur ^= 1;
     }
 
     // partial tile -> scratch [split][tap][a][b]; lane holds D[i = 4*kk + e][j = lj]
@@ -178,21 +166,6 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
             }
         }
     }
-}
-
-// dW[a][b][tap] (+)= sum_z part[z][tap][a][b]; coalesced reads along b, fixed order over z
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part,
-                                                      float* __restrict__ dw, int Cs, int Cb,
-                                                      int splits, int accumulate) {
-    const int total = 25 * Cs * Cb;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    float v = part[i];
-    for (int z = 1; z < splits; ++z) v += part[(size_t)z * total + i];
-    const int tap = i / (Cs * Cb);
-    const int ab = i - tap * (Cs * Cb);
-    float* o = dw + (size_t)ab * 25 + tap;
-    *o = accumulate ? *o + v : v;
 }
 
 static bool wgrad_tile(const BnGeom& g, WgradTile* t, size_t* lds_bytes) {
@@ -220,15 +193,17 @@ static bool wgrad_tile(const BnGeom& g, WgradTile* t, size_t* lds_bytes) {
     int bch = t->F * t->FSb;
     while ((bch & 31) != 2) ++bch;
     t->BCH = bch;
-    t->big_elems = WG_TB * t->BCH;
-    if (t->big_elems > WG_THREADS * WG_KB) return false;
+    t->big_words = WG_TB * t->BCH;
+    if (t->big_words > WG_THREADS * WG_KB) return false;
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;   // 32-bit offsets
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
     t->inv_rw = 1.0f / (float)t->RW;
     t->inv_bch = 1.0f / (float)t->BCH;
     t->inv_ih = 1.0f / (float)t->IH;
-    t->sl_floats = WG_TA * (WG_TPX + 2);
-    *lds_bytes = ((size_t)t->sl_floats + (size_t)WG_TB * t->BCH) * 4;
+    // the DMA writes whole 64-word wave rows: round the image up so the last row stays inside
+    int words = WG_TA * WG_SP + ((t->big_words + 63) & ~63);
+    t->buf_floats = (words + 3) & ~3;
+    *lds_bytes = (size_t)2 * t->buf_floats * 4;
     return *lds_bytes <= WG_MAX_LDS;
 }
 

@@ -17,6 +17,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 #define S5_THREADS 256
 #define S5_OOB 0x7fffffff
+#define S5_U 8                 // reduction steps (MFMA pairs) per load batch
 
 __device__ __forceinline__ float ldbuf(__amdgpu_buffer_rsrc_t r, int byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
@@ -58,16 +59,26 @@ __global__ __launch_bounds__(S5_THREADS) void k_up_s5(
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mr][e] = 0.f;
 
+    // batches of S5_U reduction steps: all 3*S5_U loads are issued (L2 round trip ~600-900
+    // cycles) before the first MFMA of the batch consumes one
     const int ksteps = (g.Cs + 1) / 2;
-#pragma unroll 4
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const bool kok = 2 * ks + kk < g.Cs;
-        const float b = ldbuf(rx, (kok && boff != S5_OOB) ? boff + ks * bstep : S5_OOB);
+    for (int k0 = 0; k0 < ksteps; k0 += S5_U) {
+        float bq[S5_U], aq[S5_U][2];
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr) {
-            const float a = ldbuf(rw, (kok && aoff[mr] != S5_OOB) ? aoff[mr] + ks * astep : S5_OOB);
-            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mr], 0, 0, 0);
+        for (int u = 0; u < S5_U; ++u) {
+            const int ks = k0 + u;
+            const bool kok = ks < ksteps && 2 * ks + kk < g.Cs;
+            bq[u] = ldbuf(rx, (kok && boff != S5_OOB) ? boff + ks * bstep : S5_OOB);
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+                aq[u][mr] =
+                    ldbuf(rw, (kok && aoff[mr] != S5_OOB) ? aoff[mr] + ks * astep : S5_OOB);
         }
+#pragma unroll
+        for (int u = 0; u < S5_U; ++u)
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+                acc[mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u][mr], bq[u], acc[mr], 0, 0, 0);
     }
 
     // scatter: row -> (c, r, s), column -> (n, p, q) -> out[n][c][5p+r-pt][5q+s-pl]
@@ -123,20 +134,31 @@ __global__ __launch_bounds__(S5_THREADS) void k_wgrad_s5(
         for (int e = 0; e < 16; ++e) acc[mr][e] = 0.f;
 
     const int ksteps = (npix + 1) / 2;
-#pragma unroll 4
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int pix = 2 * ks + kk;
-        const int n = pix / HWs, pq = pix - n * HWs;
-        const int p = pq / g.Ws, q = pq - p * g.Ws;
-        const int h = 5 * p + tr - g.pt, x = 5 * q + ts - g.pl;
-        const bool bok = cok && pix < npix && h >= 0 && h < g.Hb && x >= 0 && x < g.Wb;
-        const float bv = ldbuf(rb, bok ? (((n * g.Cb + b) * g.Hb + h) * g.Wb + x) * 4 : S5_OOB);
+    // pixel (n, p, q) of this lane's k index, advanced by 2 pixels per step without divisions
+    int n = kk / HWs, p = (kk - n * HWs) / g.Ws, q = kk - n * HWs - p * g.Ws;
+    for (int k0 = 0; k0 < ksteps; k0 += S5_U) {
+        float bq[S5_U], aq[S5_U][2];
 #pragma unroll
-        for (int mr = 0; mr < 2; ++mr) {
-            const bool aok = pix < npix && a_lane[mr] < g.Cs;
-            const float av = ldbuf(rs, aok ? ((n * g.Cs + a_lane[mr]) * HWs + pq) * 4 : S5_OOB);
-            acc[mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mr], 0, 0, 0);
+        for (int u = 0; u < S5_U; ++u) {
+            const int pix = 2 * (k0 + u) + kk;
+            const int pq = p * g.Ws + q;
+            const int h = 5 * p + tr - g.pt, x = 5 * q + ts - g.pl;
+            const bool bok = cok && pix < npix && h >= 0 && h < g.Hb && x >= 0 && x < g.Wb;
+            bq[u] = ldbuf(rb, bok ? (((n * g.Cb + b) * g.Hb + h) * g.Wb + x) * 4 : S5_OOB);
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr) {
+                const bool aok = pix < npix && a_lane[mr] < g.Cs;
+                aq[u][mr] = ldbuf(rs, aok ? ((n * g.Cs + a_lane[mr]) * HWs + pq) * 4 : S5_OOB);
+            }
+            q += 2;
+            while (q >= g.Ws) { q -= g.Ws; ++p; }
+            while (p >= g.Hs) { p -= g.Hs; ++n; }
         }
+#pragma unroll
+        for (int u = 0; u < S5_U; ++u)
+#pragma unroll
+            for (int mr = 0; mr < 2; ++mr)
+                acc[mr] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u][mr], bq[u], acc[mr], 0, 0, 0);
     }
 
     if (!cok) return;

@@ -95,3 +95,22 @@ extern "C" int bn_debug_probe_fill3(float* out, int n_frames, void* stream) {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+
+// LDS-DMA semantics probe: odd lanes use an out-of-range offset; LDS is pre-filled with 7.0
+__global__ void k_probe_lds_dma(const float* p, float* o, int n) {
+    __shared__ float lds[256];
+    lds[threadIdx.x] = 7.0f;
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, n * 4, 0x00020000);
+    int off = threadIdx.x * 4;
+    if (threadIdx.x & 1) off = 0x7fffffff;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds + (threadIdx.x >> 6) * 64, 4, off, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    o[threadIdx.x] = lds[threadIdx.x];
+}
+extern "C" int bn_debug_probe_lds_dma(const float* p, float* o, int n, void* stream) {
+    hipLaunchKernelGGL(k_probe_lds_dma, dim3(1), dim3(256), 0, (hipStream_t)stream, p, o, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

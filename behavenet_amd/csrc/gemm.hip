@@ -35,10 +35,39 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = 0.f;
 
+    // Unit-stride operands: each lane loads 16 bytes (4 consecutive k of ITS row / column) per
+    // operand and feeds 4 MFMA steps from them -- step u pairs k = base+u (lane half 0) with
+    // k = base+4+u (lane half 1).  A per-lane 4-byte gather would touch 64 cache lines per
+    // instruction for 2 useful floats each; this touches them once per 8 k.
+    const bool vec = (a.sak == 1) && (a.sbk == 1) && ((kbeg & 7) == 0) && ((kend & 7) == 0) &&
+                     ((a.sai & 3) == 0) && ((a.sbj & 3) == 0) &&
+                     ((((uintptr_t)a.A) | ((uintptr_t)a.B)) & 15u) == 0;
+    if (vec) {
+        for (int k0 = kbeg; k0 < kend; k0 += 16) {      // 2 float4 per operand per trip
+            float4 av4[2], bv4[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = min(k0 + 8 * h + 4 * lk, kend - 4);
+                av4[h] = *reinterpret_cast<const float4*>(ap + k);
+                bv4[h] = *reinterpret_cast<const float4*>(bp + k);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = (k0 + 8 * h) < kend;
+                const float ax[4] = {av4[h].x, av4[h].y, av4[h].z, av4[h].w};
+                const float bx[4] = {bv4[h].x, bv4[h].y, bv4[h].z, bv4[h].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_ok && ok) ? ax[u] : 0.f,
+                                                               (b_ok && ok) ? bx[u] : 0.f, acc, 0,
+                                                               0, 0);
+            }
+        }
+    }
     // 8 reduction steps per trip: 16 independent (clamped, unconditional) loads are in flight
     // before the first MFMA needs one -- these skinny GEMMs are latency-, not bandwidth-bound
     const int klast = max(kend - 1, kbeg);
-    for (int k0 = kbeg + lk; k0 < kend + lk; k0 += 16) {
+    for (int k0 = kbeg + lk; k0 < (vec ? 0 : kend + lk); k0 += 16) {
         float av[8], bv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
