@@ -43,6 +43,12 @@ SIGNATURES = {
     'bn_convT2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_convT2d_bwd_weight': (
         _c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_void_p, _c_size_t, _c_void_p]),
+    'bn_batchnorm_ws_bytes': (_c_size_t, [_c_int, _c_int]),
+    'bn_batchnorm_stats': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
+    'bn_batchnorm_finalize': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_float] * 3 + [_c_void_p]),
+    'bn_batchnorm_act_fwd': (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_float, _c_void_p]),
+    'bn_batchnorm_act_bwd': (
+        _c_int, [_c_void_p] * 9 + [_c_int] * 6 + [_c_float, _c_void_p, _c_size_t, _c_void_p]),
     'bn_act_bwd': (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_int, _c_float, _c_void_p]),
     'bn_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p]),
     'bn_linear_bwd': (
@@ -202,6 +208,71 @@ def set_force_generic(on):
 
 def lib_call(name):
     return getattr(load(), name)
+
+
+def _bn_ws(n, c, device):
+    nbytes = load().bn_batchnorm_ws_bytes(n, c)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, 'bn')
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf.data_ptr(), nbytes
+
+
+def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope):
+    """-> (y, mean, invstd); updates the running statistics in place (train mode)."""
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    invstd = torch.empty_like(mean)
+    ws, nb = _bn_ws(n, c, x.device)
+    _check(load().bn_batchnorm_stats(_ptr(x, 'x'), _ptr(mean, 'mean'), _ptr(var, 'var'), n, c, hw,
+                                     ws, nb, _stream()), 'bn_batchnorm_stats')
+    cnt = n * hw
+    unbias = cnt / (cnt - 1.0) if cnt > 1 else 1.0
+    _check(load().bn_batchnorm_finalize(
+        _ptr(mean, 'mean'), _ptr(var, 'var'), _ptr(invstd, 'invstd'),
+        _ptr(running_mean, 'running_mean', allow_none=True),
+        _ptr(running_var, 'running_var', allow_none=True), c, eps, momentum, unbias, _stream()),
+        'bn_batchnorm_finalize')
+    y = torch.empty_like(x)
+    _check(load().bn_batchnorm_act_fwd(
+        _ptr(x, 'x'), _ptr(mean, 'mean'), _ptr(invstd, 'invstd'),
+        _ptr(gamma, 'gamma', allow_none=True), _ptr(beta, 'beta', allow_none=True), _ptr(y, 'y'),
+        n, c, hw, act, slope, _stream()), 'bn_batchnorm_act_fwd')
+    return y, mean, invstd
+
+
+def batchnorm_eval_fwd(x, gamma, beta, running_mean, running_var, eps, act, slope):
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    invstd = torch.empty((c,), dtype=torch.float32, device=x.device)
+    _check(load().bn_batchnorm_finalize(
+        _ptr(running_mean, 'running_mean'), _ptr(running_var, 'running_var'),
+        _ptr(invstd, 'invstd'), None, None, c, eps, 0.0, 1.0, _stream()), 'bn_batchnorm_finalize')
+    y = torch.empty_like(x)
+    _check(load().bn_batchnorm_act_fwd(
+        _ptr(x, 'x'), _ptr(running_mean, 'mean'), _ptr(invstd, 'invstd'),
+        _ptr(gamma, 'gamma', allow_none=True), _ptr(beta, 'beta', allow_none=True), _ptr(y, 'y'),
+        n, c, hw, act, slope, _stream()), 'bn_batchnorm_act_fwd')
+    return y, invstd
+
+
+def batchnorm_bwd(x, y, dy, mean, invstd, gamma, dgamma, dbeta, accumulate, batch_stats, act,
+                  slope):
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    dx = torch.empty_like(x)
+    ws, nb = _bn_ws(n, c, x.device)
+    _check(load().bn_batchnorm_act_bwd(
+        _ptr(x, 'x'), _ptr(y, 'y'), _ptr(dy, 'dy'), _ptr(mean, 'mean'), _ptr(invstd, 'invstd'),
+        _ptr(gamma, 'gamma', allow_none=True), _ptr(dx, 'dx'),
+        _ptr(dgamma, 'dgamma', allow_none=True), _ptr(dbeta, 'dbeta', allow_none=True),
+        int(accumulate), int(batch_stats), n, c, hw, act, slope, ws, nb, _stream()),
+        'bn_batchnorm_act_bwd')
+    return dx
 
 
 def act_bwd(dy, y, act, slope, out=None):

@@ -50,3 +50,18 @@ int bn_launch_kl_bwd(const float* mu, const float* logvar, float* dmu, float* dl
 int bn_launch_adam(float* p, const float* g, float* m, float* v, float* vmax, size_t n, float lr,
                    float b1, float b2, float eps, float wd, int step, hipStream_t st);
 int bn_launch_u8_to_unit_float(const unsigned char* in, float* out, size_t n, hipStream_t st);
+
+// batchnorm.hip
+size_t bn_batchnorm_ws_bytes_impl(int N, int C);
+int bn_launch_bn_stats(const float* x, float* mean, float* var, int N, int C, int HW, void* ws,
+                       hipStream_t st);
+int bn_launch_bn_finalize(const float* mean, const float* var, float* invstd, float* running_mean,
+                          float* running_var, int C, float eps, float momentum, float unbias,
+                          hipStream_t st);
+int bn_launch_bn_act_fwd(const float* x, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, float* y, int N, int C, int HW,
+                         int act, float slope, hipStream_t st);
+int bn_launch_bn_act_bwd(const float* x, const float* y, const float* dy, const float* mean,
+                         const float* invstd, const float* gamma, float* dx, float* dgamma,
+                         float* dbeta, int accumulate, int batch_stats, int N, int C, int HW,
+                         int act, float slope, void* ws, hipStream_t st);

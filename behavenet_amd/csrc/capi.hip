@@ -330,6 +330,48 @@ extern "C" int bn_act_bwd(const float* dy, const float* y, float* dpre, size_t n
 }
 
 // ------------------------------------------------------------------------------------------
+// batch norm
+// ------------------------------------------------------------------------------------------
+extern "C" size_t bn_batchnorm_ws_bytes(int N, int C) {
+    return (N > 0 && C > 0) ? bn_batchnorm_ws_bytes_impl(N, C) : 0;
+}
+
+extern "C" int bn_batchnorm_stats(const float* x, float* mean, float* var, int N, int C, int HW,
+                                  void* ws, size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !mean || !var || N <= 0 || C <= 0 || HW <= 0) return BN_E_BADARG;
+    if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(N, C)) return BN_E_WORKSPACE;
+    return bn_launch_bn_stats(x, mean, var, N, C, HW, ws, (hipStream_t)stream);
+}
+
+extern "C" int bn_batchnorm_finalize(const float* mean, const float* var, float* invstd,
+                                     float* running_mean, float* running_var, int C, float eps,
+                                     float momentum, float unbias, bn_stream_t stream) {
+    if (!mean || !var || !invstd || C <= 0) return BN_E_BADARG;
+    return bn_launch_bn_finalize(mean, var, invstd, running_mean, running_var, C, eps, momentum,
+                                 unbias, (hipStream_t)stream);
+}
+
+extern "C" int bn_batchnorm_act_fwd(const float* x, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, float* y, int N, int C,
+                                    int HW, int act, float slope, bn_stream_t stream) {
+    if (!x || !mean || !invstd || !y || N <= 0 || C <= 0 || HW <= 0) return BN_E_BADARG;
+    return bn_launch_bn_act_fwd(x, mean, invstd, gamma, beta, y, N, C, HW, act, slope,
+                                (hipStream_t)stream);
+}
+
+extern "C" int bn_batchnorm_act_bwd(const float* x, const float* y, const float* dy,
+                                    const float* mean, const float* invstd, const float* gamma,
+                                    float* dx, float* dgamma, float* dbeta, int accumulate,
+                                    int batch_stats, int N, int C, int HW, int act, float slope,
+                                    void* ws, size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !y || !dy || !mean || !invstd || !dx || N <= 0 || C <= 0 || HW <= 0)
+        return BN_E_BADARG;
+    if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(N, C)) return BN_E_WORKSPACE;
+    return bn_launch_bn_act_bwd(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, accumulate,
+                                batch_stats, N, C, HW, act, slope, ws, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
 // linear
 // ------------------------------------------------------------------------------------------
 extern "C" int bn_linear_fwd(const float* x, const float* w, const float* b, float* y, int M,

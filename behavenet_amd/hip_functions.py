@@ -95,6 +95,10 @@ class ConvLayerPlan(object):
         return (int(n), self.cin, self.hin, self.win, self.cout, self.R, self.S, self.stride,
                 self.off_t, self.off_l, self.hout, self.wout)
 
+    def with_act(self, act):
+        return ConvLayerPlan(self.kind, self.cin, self.hin, self.win, self.cout, self.hout,
+                             self.wout, self.R, self.S, self.stride, self.off_t, self.off_l, act)
+
     def __repr__(self):
         return '%s(%dx%dx%d->%dx%dx%d k%dx%d s%d off(%d,%d) act%d)' % (
             self.kind, self.cin, self.hin, self.win, self.cout, self.hout, self.wout, self.R,
@@ -194,6 +198,89 @@ class ConvStackFn(torch.autograd.Function):
 
 def conv_stack(plan, x, params):
     return ConvStackFn.apply(plan, x, *params)
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """y = act(BatchNorm2d(x)) with nn.BatchNorm2d's train / eval semantics (aes.py:90-97,113).
+
+    Train mode (or no running statistics): normalise with the batch's own biased variance and
+    fold the batch statistics into ``running_mean`` / ``running_var`` (unbiased variance,
+    ``momentum=None`` -> cumulative average).  Eval mode: normalise with the running statistics.
+    """
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, module, act):
+        x = x.contiguous()
+        g = gamma.detach() if gamma is not None else None
+        b = beta.detach() if beta is not None else None
+        rm, rv = module.running_mean, module.running_var
+        batch_stats = module.training or rm is None
+        if batch_stats:
+            factor = 0.0
+            if module.training and module.track_running_stats and rm is not None:
+                module.num_batches_tracked.add_(1)
+                if module.momentum is None:
+                    factor = 1.0 / float(module.num_batches_tracked.item())
+                else:
+                    factor = float(module.momentum)
+            else:
+                rm = rv = None
+            y, mean, invstd = _hip.batchnorm_train_fwd(
+                x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE)
+        else:
+            mean = rm
+            y, invstd = _hip.batchnorm_eval_fwd(x, g, b, rm, rv, float(module.eps), act,
+                                                LRELU_SLOPE)
+            mean = mean.clone()  # the running buffers may move before backward
+        ctx.batch_stats = bool(batch_stats)
+        ctx.act = act
+        ctx.param_refs = (gamma, beta)
+        ctx.save_for_backward(x, y, mean, invstd, g)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, invstd, g = ctx.saved_tensors
+        gamma, beta = ctx.param_refs
+        need_g = gamma is not None and ctx.needs_input_grad[1]
+        need_b = beta is not None and ctx.needs_input_grad[2]
+        gg = _grad_buffer(gamma) if need_g else None
+        gb = _grad_buffer(beta) if need_b else None
+        direct = (need_g or need_b) and (gg is not None or not need_g) and \
+            (gb is not None or not need_b)
+        if direct:
+            dgamma, dbeta = gg, gb
+        else:
+            dgamma = torch.empty_like(mean) if need_g else None
+            dbeta = torch.empty_like(mean) if need_b else None
+        dx = _hip.batchnorm_bwd(x, y, dy.contiguous(), mean, invstd, g, dgamma, dbeta, direct,
+                                ctx.batch_stats, ctx.act, LRELU_SLOPE)
+        if direct:
+            dgamma = dbeta = None
+        return (dx if ctx.needs_input_grad[0] else None), dgamma, dbeta, None, None
+
+
+def conv_stack_bn(plan, x, params, bn_modules):
+    """Conv stack whose layer i is followed by ``bn_modules[i]`` (or None) before its activation.
+
+    Runs of layers without batch norm stay one fused :class:`ConvStackFn`; a batch-normed layer
+    is convolution (no activation) -> :class:`BatchNormActFn` (normalisation + activation fused).
+    """
+    h = x
+    run_plan, run_params = [], []
+    for i, layer in enumerate(plan):
+        run_params += [params[2 * i], params[2 * i + 1]]
+        if bn_modules[i] is None:
+            run_plan.append(layer)
+            continue
+        run_plan.append(layer.with_act(_hip.ACT_NONE))
+        h = ConvStackFn.apply(run_plan, h, *run_params)
+        bn = bn_modules[i]
+        h = BatchNormActFn.apply(h, bn.weight, bn.bias, bn, layer.act)
+        run_plan, run_params = [], []
+    if run_plan:
+        h = ConvStackFn.apply(run_plan, h, *run_params)
+    return h
 
 
 class LinearFn(torch.autograd.Function):

@@ -16,7 +16,8 @@ import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ConvLayerPlan, conv_stack, linear, accumulate_into_param_grads, join_side_streams)
+    ConvLayerPlan, conv_stack, conv_stack_bn, linear, accumulate_into_param_grads,
+    join_side_streams)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
@@ -31,6 +32,15 @@ def _mark_footprint(module):
 def _unsupported_on_hip(what):
     raise NotImplementedError(
         '%s is not implemented by the MI355X kernels yet (SURVEY.md section 8(f), rank 3)' % what)
+
+
+def _bn_modules(container, layer_names):
+    """nn.BatchNorm2d following each (transposed) convolution of the stack, or None."""
+    out = []
+    for name in layer_names:
+        num = ''.join(ch for ch in name.split('_')[0] if ch.isdigit())
+        out.append(getattr(container, 'batchnorm%s' % num, None))
+    return out
 
 
 class ConvAEEncoder(BaseModule):
@@ -145,12 +155,14 @@ class ConvAEEncoder(BaseModule):
     def _features(self, x, dataset=None):
         """Run the conv stack -> (N, C*H*W) post-LeakyReLU features."""
         hp = self.hparams
-        if hp['ae_batch_norm']:
-            _unsupported_on_hip('ae_batch_norm=1')
         if hp.get('ae_network_type', 'strides_only') == 'max_pooling' or \
                 any(t == 'maxpool' for t in hp['ae_encoding_layer_type']):
             _unsupported_on_hip('max-pooling architectures')
-        h = conv_stack(self._plan, x, self._stack_params(dataset))
+        if hp['ae_batch_norm']:
+            h = conv_stack_bn(self._plan, x, self._stack_params(dataset),
+                              _bn_modules(self.encoder, self._layer_names))
+        else:
+            h = conv_stack(self._plan, x, self._stack_params(dataset))
         return h.view(h.size(0), -1)
 
     def forward(self, x, dataset=None):
@@ -300,8 +312,6 @@ class ConvAEDecoder(BaseModule):
 
     def forward(self, x, pool_idx=None, target_output_size=None, dataset=None):
         hp = self.hparams
-        if hp['ae_batch_norm']:
-            _unsupported_on_hip('ae_batch_norm=1')
         if any(t == 'unpool' for t in hp['ae_decoding_layer_type']):
             _unsupported_on_hip('max-pooling architectures')
         if hp['ae_decoding_last_FF_layer']:
@@ -309,6 +319,9 @@ class ConvAEDecoder(BaseModule):
         start = hp['ae_decoding_starting_dim']
         h = linear(x, self.FF.weight, self.FF.bias)
         h = h.view(h.size(0), start[0], start[1], start[2])
+        if hp['ae_batch_norm']:
+            return conv_stack_bn(self._plan, h, self._stack_params(dataset),
+                                 _bn_modules(self.decoder, self._layer_names))
         return conv_stack(self._plan, h, self._stack_params(dataset))
 
 

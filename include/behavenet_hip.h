@@ -122,6 +122,32 @@ int bn_act_bwd(const float* dy, const float* y, float* dpre, size_t n,
                int act, float slope, bn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * BatchNorm2d + activation for `ae_batch_norm = 1` architectures (replaces nn.BatchNorm2d +
+ * LeakyReLU, aes.py:90-97,113-114,332-341).  x,y,dy,dx: (N,C,HW) fp32; per-channel vectors: (C).
+ *   stats:    mean[c], var[c] (biased) over (N, HW) -- two-pass, deterministic
+ *   finalize: invstd = 1/sqrt(var+eps); running = (1-momentum)*running + momentum*{mean,
+ *             var*unbias}  (running_* nullable; pass momentum = 1/num_batches_tracked for
+ *             nn.BatchNorm2d(momentum=None))
+ *   act_fwd:  y = act((x-mean)*invstd*gamma + beta)      (eval mode: pass the running stats)
+ *   act_bwd:  dy is the gradient w.r.t. y; dx w.r.t. x; dgamma/dbeta (+)= their sums;
+ *             batch_stats=1 when mean/invstd are the batch's own (train mode), 0 when they are
+ *             the running statistics (constants w.r.t. x)
+ * ------------------------------------------------------------------------------------------ */
+size_t bn_batchnorm_ws_bytes(int N, int C);
+int bn_batchnorm_stats(const float* x, float* mean, float* var, int N, int C, int HW,
+                       void* ws, size_t ws_bytes, bn_stream_t stream);
+int bn_batchnorm_finalize(const float* mean, const float* var, float* invstd,
+                          float* running_mean, float* running_var, int C, float eps,
+                          float momentum, float unbias, bn_stream_t stream);
+int bn_batchnorm_act_fwd(const float* x, const float* mean, const float* invstd,
+                         const float* gamma, const float* beta, float* y, int N, int C, int HW,
+                         int act, float slope, bn_stream_t stream);
+int bn_batchnorm_act_bwd(const float* x, const float* y, const float* dy, const float* mean,
+                         const float* invstd, const float* gamma, float* dx, float* dgamma,
+                         float* dbeta, int accumulate, int batch_stats, int N, int C, int HW,
+                         int act, float slope, void* ws, size_t ws_bytes, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Dense latent projections (replaces nn.Linear, aes.py:121,125,266 and the PS-VAE heads
  * vaes.py:1288-1302).  MFMA (v_mfma_f32_32x32x2_f32: exact fp32).
  *   y[m,n] = b[n] + sum_k x[m,k] * w[n,k]        x:(M,K) w:(N,K) b:(N) or NULL  y:(M,N)

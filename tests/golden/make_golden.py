@@ -217,6 +217,12 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
         for sk in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
             store['adam/%s/%s/checksum' % (sk, k)] = checksum(st[sk].numpy())
 
+    # batch-norm running statistics after: 1 no-grad train-mode forward, the loss call and the
+    # three steps (one update per 200-frame chunk each time)
+    for k, v in model.named_buffers():
+        if 'running_' in k or 'num_batches_tracked' in k:
+            store['adam/buffer/' + k] = v.detach().numpy().astype(np.float64)
+
     if variational:
         ref_vaes.reparameterize = orig
 
@@ -267,6 +273,17 @@ def fit_fixture():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'bn':
+        # batch-norm cases only (added later; the other fixtures are left untouched)
+        model_case('ae_cfg1_bn', RefAE, [1, 32, 32], 8, 8, 'ae',
+                   extra_hp={'ae_batch_norm': True})
+        model_case('ae_cfg1_bn_b210', RefAE, [1, 32, 32], 8, 210, 'ae',
+                   extra_hp={'ae_batch_norm': True, 'ae_batch_norm_momentum': None},
+                   store_xhat=True)
+        model_case('vae_1x64x48_bn', RefVAE, [1, 64, 48], 8, 6, 'vae',
+                   extra_hp={'ae_batch_norm': True, 'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0,
+                             'max_n_epochs': 10})
+        sys.exit(0)
     planner_fixture()
     model_case('ae_cfg1', RefAE, [1, 32, 32], 8, 8, 'ae')
     model_case('ae_cfg1_b210', RefAE, [1, 32, 32], 8, 210, 'ae', store_xhat=True)

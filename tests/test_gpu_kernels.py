@@ -23,7 +23,7 @@ DEV = 'cuda'
 SLOPE = 0.05
 
 
-def close(got, want, want64=None, rtol=1e-4, norm_tol=1e-4, name=''):
+def close(got, want, want64=None, rtol=1e-4, norm_tol=1e-4, name='', cond=False):
     got = got.detach().cpu().double().numpy()
     want = want.detach().cpu().double().numpy()
     assert got.shape == want.shape, (name, got.shape, want.shape)
@@ -37,6 +37,11 @@ def close(got, want, want64=None, rtol=1e-4, norm_tol=1e-4, name=''):
     scale = max(np.abs(w64).max(), 1e-30)
     e_hip = np.abs(got - w64).max() / scale
     e_cpu = np.abs(want - w64).max() / scale
+    if cond:
+        # ill-conditioned operator (a batch norm over a handful of values): the fp32 reference
+        # itself misses the exact answer by more than the stated tolerance; the bar becomes "at
+        # least as close to the float64 evaluation as the reference's own arithmetic"
+        norm_tol = max(norm_tol, 2 * e_cpu)
     assert e_hip <= norm_tol, '%s: err vs f64 %.3e' % (name, e_hip)
     assert e_hip <= max(8 * e_cpu, 3e-6), \
         '%s: hip err %.3e vs f64, cpu fp32 oracle err %.3e' % (name, e_hip, e_cpu)
@@ -207,6 +212,62 @@ def test_convT2d_bwd(case):
     close(db, dbr, db64, name=case[0] + ' db')
     _hip.convT2d_bwd_weight(xind, dyd, dw, db, geom, True)
     close(dw, 2 * dwr, 2 * dw64, name=case[0] + ' dw acc')
+
+
+BN_CASES = [  # (N, C, H, W, momentum, training, affine)
+    (200, 32, 16, 16, 0.1, True, True),
+    (7, 64, 9, 5, 0.1, True, True),
+    (3, 512, 2, 2, None, True, True),
+    (2, 33, 7, 3, 0.3, True, False),
+    (5, 16, 8, 8, 0.1, False, True),
+    (1, 1200, 1, 3, 0.1, True, True),
+]
+
+
+@pytest.mark.parametrize('case', BN_CASES)
+@pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_NONE])
+def test_batchnorm_act(case, act):
+    """nn.BatchNorm2d (+LeakyReLU) forward, running statistics and backward (aes.py:90-97)."""
+    from behavenet_amd.hip_functions import BatchNormActFn
+    N, C, H, W, mom, training, affine = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, C, H, W), generator=g) * 1.7 + 0.4
+    gy = torch.randn((N, C, H, W), generator=g)
+    mods = {}
+    for key, dt in (('f32', torch.float32), ('f64', torch.float64), ('hip', torch.float32)):
+        m = torch.nn.BatchNorm2d(C, momentum=mom, affine=affine)
+        with torch.no_grad():
+            if affine:
+                m.weight.copy_(torch.rand((C,), generator=torch.Generator().manual_seed(5)) + 0.5)
+                m.bias.copy_(torch.rand((C,), generator=torch.Generator().manual_seed(6)) - 0.5)
+            m.running_mean.copy_(torch.rand((C,), generator=torch.Generator().manual_seed(7)))
+            m.running_var.copy_(torch.rand((C,), generator=torch.Generator().manual_seed(8)) + 0.5)
+        m = m.to(dt)
+        m.train(training)
+        mods[key] = m
+    mods['hip'] = mods['hip'].to(DEV)
+
+    outs = {}
+    for key, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        xi = x.detach().clone().to(dt).requires_grad_(True)
+        for rep in range(2):   # two calls: running statistics move twice (momentum=None path)
+            y = act_ref(mods[key](xi), act)
+        y.backward(gy.to(dt))
+        outs[key] = (y, xi.grad)
+    xh = x.detach().clone().to(DEV).requires_grad_(True)
+    mh = mods['hip']
+    for rep in range(2):
+        yh = BatchNormActFn.apply(xh, mh.weight, mh.bias, mh, act)
+    yh.backward(gy.to(DEV))
+
+    close(yh, outs['f32'][0], outs['f64'][0], name='bn y')
+    close(xh.grad, outs['f32'][1], outs['f64'][1], name='bn dx')
+    if affine:
+        close(mh.weight.grad, mods['f32'].weight.grad, mods['f64'].weight.grad, name='bn dgamma')
+        close(mh.bias.grad, mods['f32'].bias.grad, mods['f64'].bias.grad, name='bn dbeta')
+    close(mh.running_mean, mods['f32'].running_mean, mods['f64'].running_mean, name='bn rmean')
+    close(mh.running_var, mods['f32'].running_var, mods['f64'].running_var, name='bn rvar')
+    assert int(mh.num_batches_tracked) == int(mods['f32'].num_batches_tracked)
 
 
 @pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_SIGMOID, _hip.ACT_NONE])

@@ -46,8 +46,19 @@ def _pair(meta):
     return hip, ora, hp_h
 
 
+def _bias_before_batchnorm(key, names):
+    """A conv bias that feeds a batch norm: its gradient is analytically zero (the layer subtracts
+    the channel mean again), so what any implementation computes for it is rounding noise."""
+    if not key.endswith('.bias') or 'conv' not in key:
+        return False
+    parts = key.split('.')
+    head = '.'.join(parts[:-2])
+    num = ''.join(ch for ch in parts[-2].split('_')[0] if ch.isdigit())
+    return '%s.batchnorm%s.weight' % (head, num) in names
+
+
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
-         'condvae_cfg1', 'psvae_cfg4']
+         'condvae_cfg1', 'psvae_cfg4', 'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -96,16 +107,46 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
     for k, want in zip([str(k) for k in z['loss/keys']], z['loss/vals']):
         assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-7), k
         assert loss_h[k] == pytest.approx(float(want), rel=1e-4, abs=1e-7), k
+    # batch-norm cases: a float64 run of the oracle measures how well-conditioned the gradients
+    # are (ae_cfg1_bn_b210 normalises 10 values per channel in its second chunk: the fp32
+    # reference is ~1e-3 from the exact answer there)
+    g64 = None
+    if meta['extra_hp'].get('ae_batch_norm') and not variational:
+        ora64 = seeded_build(ref_cpu.build_model, case_hparams(meta)).double()
+        ora64.train()
+        data64 = {k: v.double() for k, v in data_c.items()}
+        with torch.no_grad():
+            ora64(data64['images'][0][:n_fwd], dataset=0)
+        ora64.zero_grad()
+        ora64.loss(data64, dataset=0, accumulate_grad=True)
+        g64 = {k: p.grad for k, p in ora64.named_parameters()}
+    names = set(k for k, _ in ora.named_parameters())
     for (k, ph), (_, po) in zip(hip.named_parameters(), ora.named_parameters()):
         if po.grad is None:
             assert ph.grad is None or not ph.requires_grad
             continue
-        close(ph.grad, po.grad, name='%s grad %s' % (name, k))
+        if _bias_before_batchnorm(k, names):
+            wscale = float(dict(ora.named_parameters())[k[:-4] + 'weight'].grad.abs().max())
+            assert float(ph.grad.abs().max()) <= 1e-4 * wscale, k
+            assert float(po.grad.abs().max()) <= 1e-4 * wscale, k
+            continue
+        if g64 is not None:
+            close(ph.grad, po.grad, g64[k], name='%s grad %s' % (name, k), cond=True)
+            w64 = g64[k].numpy()
+            e_ref = np.abs(po.grad.double().numpy() - w64).max() / max(np.abs(w64).max(), 1e-30)
+            ctol = max(1e-4, 4 * e_ref)
+        else:
+            close(ph.grad, po.grad, name='%s grad %s' % (name, k))
+            ctol = 1e-4
         assert checksum_close(checksum(ph.grad.cpu().numpy()), z['grad/' + k + '/checksum'],
-                              1e-4), k
+                              ctol), k
+    # batch-norm running statistics after the same call sequence (one forward, one loss call)
+    for (k, bh), (_, bo) in zip(hip.named_buffers(), ora.named_buffers()):
+        if 'running_' in k or 'num_batches' in k:
+            close(bh.float(), bo.float(), name='%s buffer %s' % (name, k))
 
 
-@pytest.mark.parametrize('name', ['ae_cfg1', 'ae_cfg2', 'vae_cfg1'])
+@pytest.mark.parametrize('name', ['ae_cfg1', 'ae_cfg2', 'vae_cfg1', 'ae_cfg1_bn'])
 def test_adam_trajectory_vs_oracle_and_golden(name):
     z, meta = load_case(name)
     hip, ora, hp = _pair(meta)
@@ -135,11 +176,28 @@ def test_adam_trajectory_vs_oracle_and_golden(name):
     # gradient moves a weight by a fraction of lr per step: allow 2 % of the maximal travel
     # (n_steps * lr) per element, on top of the 1e-4 relative tolerance.
     travel = 0.02 * 3 * hp['learning_rate']
+    names = set(k for k, _ in ora.named_parameters())
+    bn_case = bool(meta['extra_hp'].get('ae_batch_norm'))
     for i, ((k, ph), (_, po)) in enumerate(zip(hip.named_parameters(), ora.named_parameters())):
         if not po.requires_grad:
             assert torch.equal(ph.cpu(), po)
             continue
         got, want = ph.detach().cpu().numpy(), po.detach().numpy()
+        if _bias_before_batchnorm(k, names):
+            # zero-gradient parameter: Adam normalises rounding noise into +-lr steps, in the
+            # reference as much as here; it can only be bounded by the full travel
+            np.testing.assert_allclose(got, want, rtol=0, atol=3.03 * hp['learning_rate'],
+                                       err_msg=k)
+            continue
+        if bn_case:
+            # batch norm over 8 values per channel: gradient noise ~1e-4 of the tensor's scale in
+            # either implementation, which Adam turns into sign flips for the elements below
+            # it.  Bound every element by the full travel and the outliers to a small fraction.
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=3.03 * hp['learning_rate'],
+                                       err_msg=k)
+            frac = np.mean(np.abs(got - want) > travel + 1e-4 * np.abs(want))
+            assert frac <= 0.05, (k, frac)
+            continue
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=travel, err_msg=k)
         ref = z['adam/param/' + k + '/checksum']
         assert abs(checksum(got)[0] - ref[0]) <= 1e-4 * ref[1] + travel * got.size, k
@@ -147,9 +205,16 @@ def test_adam_trajectory_vs_oracle_and_golden(name):
     for i in (0, 8):
         m, v, vmax = opt_h.state_tensors(i)
         st = opt_o.state[list(ora.get_parameters())[i]]
-        close(m, st['exp_avg'], name='exp_avg')
-        close(v, st['exp_avg_sq'], name='exp_avg_sq')
-        close(vmax, st['max_exp_avg_sq'], name='max_exp_avg_sq')
+        tol = 2e-3 if bn_case else 1e-4
+        close(m, st['exp_avg'], name='exp_avg', norm_tol=tol)
+        close(v, st['exp_avg_sq'], name='exp_avg_sq', norm_tol=tol)
+        close(vmax, st['max_exp_avg_sq'], name='max_exp_avg_sq', norm_tol=tol)
+    # running statistics: the conv biases under a batch norm random-walk by up to 3*lr (above)
+    # and shift the channel means with them
+    for (k, bh), (_, bo) in zip(hip.named_buffers(), ora.named_buffers()):
+        if 'running_' in k or 'num_batches' in k:
+            np.testing.assert_allclose(bh.float().cpu().numpy(), bo.float().numpy(), rtol=1e-3,
+                                       atol=3.03 * hp['learning_rate'], err_msg=k)
 
 
 def test_fit_on_gpu_reproduces_reference_rows(tmp_path):

@@ -14,7 +14,8 @@ from tests.cases import load_case, case_hparams, case_data, seeded_build, EpsRep
 from tests.golden_utils import checksum, checksum_close, strided_sample
 
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
-         'condvae_cfg1', 'psvae_cfg4']
+         'condvae_cfg1', 'psvae_cfg4',
+         'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn']
 
 
 def _check_tensor(z, prefix, t, rtol, atol=1e-7):
@@ -53,7 +54,11 @@ def test_oracle_matches_reference(name):
     with torch.no_grad():
         if variational:
             model.eps_fn = EpsReplay([z['fwd/eps']])
+        # the extra encoder pass (for the per-layer taps) must not count as a batch-norm update
+        bufs = {k: v.clone() for k, v in model.named_buffers()}
         enc_out = model.encoding(x[:n_fwd], dataset=0, taps=taps_e)
+        for k, v in model.named_buffers():
+            v.copy_(bufs[k])
         kw = {}
         if meta['model_class'] == 'cond-vae':
             kw = {'labels': data['labels'][0][:n_fwd], 'labels_2d': None}
@@ -101,6 +106,14 @@ def test_oracle_matches_reference(name):
             for sk in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
                 assert checksum_close(checksum(st[sk].numpy()),
                                       z['adam/%s/%s/checksum' % (sk, k)], 1e-4), (sk, k)
+    # batch-norm running statistics (train-mode forward + loss call + 3 steps)
+    n_buf = 0
+    for k, v in model.named_buffers():
+        if 'adam/buffer/' + k in z.files:
+            np.testing.assert_allclose(v.numpy().astype(np.float64), z['adam/buffer/' + k],
+                                       rtol=1e-5, atol=1e-8, err_msg=k)
+            n_buf += 1
+    assert n_buf == len([k for k in z.files if k.startswith('adam/buffer/')])
 
 
 def test_oracle_loss_known_answers():
