@@ -49,12 +49,18 @@ __device__ __forceinline__ float bn_act_grad_from_output(float y, int act, float
 // profiling hook (bn_prof_*): brackets launches of one kernel family with hipEvents
 // ---------------------------------------------------------------------------------------------
 struct BnProfScope {
-    bool active;
+    bool active, on_dispatch;
     hipStream_t stream;
     hipEvent_t e0, e1;
-    BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s);
+    // on_dispatch: the op is ONE kernel whose launcher attaches the events to the dispatch
+    // itself (hipExtLaunchKernelGGL start/stop events = the kernel's own begin/end timestamps,
+    // what rocprofv3 reports) instead of bracketing it with two event records on the stream
+    BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s,
+                bool on_dispatch = false);
     ~BnProfScope();
 };
+// launcher side of on_dispatch: true (and the pair) if a profiling scope is waiting for it
+bool bn_prof_take_dispatch_events(hipEvent_t* e0, hipEvent_t* e1);
 
 #define BN_LAUNCH_CHECK()                                   \
     do {                                                    \

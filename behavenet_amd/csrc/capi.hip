@@ -38,8 +38,21 @@ void prof_drain() {
 }
 }  // namespace
 
-BnProfScope::BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s)
-    : active(false), stream(s), e0(nullptr), e1(nullptr) {
+static hipEvent_t g_dispatch_e0 = nullptr, g_dispatch_e1 = nullptr;
+static bool g_dispatch_pending = false, g_dispatch_taken = false;
+
+bool bn_prof_take_dispatch_events(hipEvent_t* e0, hipEvent_t* e1) {
+    if (!g_dispatch_pending) return false;
+    *e0 = g_dispatch_e0;
+    *e1 = g_dispatch_e1;
+    g_dispatch_pending = false;
+    g_dispatch_taken = true;
+    return true;
+}
+
+BnProfScope::BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s,
+                         bool on_dispatch_)
+    : active(false), on_dispatch(on_dispatch_), stream(s), e0(nullptr), e1(nullptr) {
     if (g_prof.family == BN_PROF_NONE || g_prof.family != family) return;
     if (g_prof.C > 0 && g_prof.C != C) return;
     if (g_prof.K > 0 && g_prof.K != K) return;
@@ -55,12 +68,25 @@ BnProfScope::BnProfScope(int family, int C, int K, const char* kernel_name, hipS
         strncpy(g_prof.kernel_name, kernel_name, sizeof(g_prof.kernel_name) - 1);
         g_prof.kernel_name[sizeof(g_prof.kernel_name) - 1] = 0;
     }
+    if (on_dispatch) {
+        g_dispatch_e0 = e0;
+        g_dispatch_e1 = e1;
+        g_dispatch_pending = true;
+        g_dispatch_taken = false;
+        active = true;
+        return;
+    }
     if (hipEventRecord(e0, stream) != hipSuccess) return;
     active = true;
 }
 
 BnProfScope::~BnProfScope() {
     if (!active) return;
+    if (on_dispatch) {
+        if (g_dispatch_taken) g_prof.used++;
+        g_dispatch_pending = g_dispatch_taken = false;
+        return;
+    }
     if (hipEventRecord(e1, stream) == hipSuccess) g_prof.used++;
 }
 
@@ -151,7 +177,7 @@ static int run_down(int family, const float* big, const float* w, const float* b
         const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
                                      : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
         if (ed.supported && epi_ok) {
-            BnProfScope prof(family, g.Cb, g.Cs, ed.kernel_name, st);
+            BnProfScope prof(family, g.Cb, g.Cs, ed.kernel_name, st, /*on_dispatch=*/true);
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }
     }

@@ -10,6 +10,7 @@
 // are used as the FMA engine (v_mfma_f32_32x32x2_f32, exact fp32) only because that keeps the
 // VALU and LDS out of the way of the stream.  Every global access is a full 128/256-byte
 // wavefront row; padding, halos and tails come from raw-buffer out-of-range zeros.
+#include <hip/hip_ext.h>
 #include "bn_common.h"
 #include "bn_fast.h"
 #include "bn_reduce.h"
@@ -154,44 +155,72 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
 // =============================================================================================
 // gather-down with one big-side channel (enc.conv0 forward, dec.convT4 data gradient):
 //   out[n,m,p,q] = epi( sum_{r,s} big[n,0,2p+r-pt,2q+s-pl] * W[m][0][r][s] ),   m < 32
-// MFMA roles: rows = m, columns = 32 output pixels of one row, reduction = 25 taps (13 steps,
-// the 26th tap is a zero weight).  Workgroup tile: 8 output rows x 64 columns (16 blocks, 4 per
-// wave) from a 19 x 131 input patch; output 64 KB per workgroup in 128-byte wavefront rows.
+// Persistent, wave-autonomous kernel: a workgroup is ONE wave and owns a private LDS arena, so
+// there is no barrier anywhere.  The work unit is a pair of output rows of one frame
+// (2 x 64 pixels x 32 channels = 16 KB of output, from a 7 x 128 input patch); wave g handles
+// units g, g + G, g + 2G, ...  and the grid size G is chosen by the host so that every CU gets
+// the same number of units (N = 200: 25 units per CU = 9 waves x <= 3 units).
+// Per unit:
+//  * the patch of the NEXT unit is already in flight (float4 buffer loads into registers issued
+//    one unit ahead); the current one goes to LDS with ds_write_b128, zero borders included
+//    (out-of-range loads return 0);
+//  * MFMA roles: rows = 32 output pixels of one image row (A = gathered input), columns =
+//    output channels (B = weights, lane-resident), reduction = 25 taps (13 steps, the 26th tap
+//    is a zero weight);
+//  * the accumulators of one output row (64 pixels x 32 channels) are transposed through the
+//    wave's LDS slab so that 16 consecutive lanes store one 256-byte image row of one channel:
+//    every store instruction writes four full rows (8 HBM lines).
 // =============================================================================================
-#define DC_TH 8
 #define DC_W 64
-#define DC_IH (2 * DC_TH + 3)
-#define DC_RW (2 * DC_W + 4)
-#define DC_KB ((DC_IH * DC_RW + ED_THREADS - 1) / ED_THREADS)
+#define DC_ROWS 2                        // output rows per unit
+#define DC_IH (2 * DC_ROWS + 3)          // patch rows (7)
+#define DC_X0 4                          // LDS column of image column 0
+#define DC_RW (2 * DC_W + 8)             // 4 zero columns | 128 image columns | 4 zero columns
+#define DC_C4 (DC_RW / 4)                // float4 slots per patch row (34)
+#define DC_NLD ((DC_IH * DC_C4 + 63) / 64)   // float4 loads per lane per unit (4)
+#define DC_TS (DC_W + 4)                 // transpose slab row stride (68: b128-conflict-free)
+#define DC_SLAB (32 * DC_TS)
+#define DC_MAX_WAVES_PER_CU 12           // 12.5 KB of LDS per wave, <= 168 VGPRs
 
-// MFMA roles: rows = 32 output pixels of one image row (A = gathered input), columns = output
-// channels (B = weights), so that after the 13 steps a lane holds, for ITS channel, four groups
-// of 4 consecutive pixels -> the epilogue is four 16-byte stores (and four 16-byte mask loads)
-// per 32-pixel block instead of sixteen 4-byte ones.
+typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef float floatx4e __attribute__((ext_vector_type(4)));
+
 template <int ACT, bool MASK>
-__global__ __launch_bounds__(ED_THREADS) void k_down_c1(
+__global__ __launch_bounds__(64) void k_down_c1(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope) {
-    __shared__ float bl[DC_IH * DC_RW];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope,
+    int units) {
+    __shared__ __attribute__((aligned(16))) float bl[DC_IH * DC_RW];
+    __shared__ __attribute__((aligned(16))) float tw[DC_SLAB];
+    const int lane = threadIdx.x;
     const int li = lane & 31, kk = lane >> 5;
-    const int tiles_per_frame = g.Hs / DC_TH;
-    const int n = blockIdx.x / tiles_per_frame;
-    const int p0 = (blockIdx.x - n * tiles_per_frame) * DC_TH;
+    const int upf = g.Hs / DC_ROWS;                  // units per frame
     const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
 
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)big, 0, (int)((size_t)g.N * HWb * 4), 0x00020000);
-    float stage[DC_KB];
+
+    // lane-constant part of the patch decode: slot e = lane + 64k -> (row y, float4 column c4)
+    int ld_y[DC_NLD], ld_off[DC_NLD];
 #pragma unroll
-    for (int k = 0; k < DC_KB; ++k) {
-        const int e = tid + ED_THREADS * k;
-        const int y = e / DC_RW, x = e - y * DC_RW;
-        const int hb = 2 * p0 - g.pt + y, wb = x - g.pl;
-        const bool ok = y < DC_IH && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
-        stage[k] = ed_ld(rb, ok ? ((n * g.Hb + hb) * g.Wb + wb) * 4 : ED_OOB);
+    for (int k = 0; k < DC_NLD; ++k) {
+        const int e = lane + 64 * k;
+        const int y = e / DC_C4, c4 = e - y * DC_C4;
+        const bool col_ok = e < DC_IH * DC_C4 && c4 >= 1 && c4 <= DC_W / 2;
+        ld_y[k] = col_ok ? y : -0x10000;            // fails the row test below
+        ld_off[k] = (y * g.Wb + 4 * (c4 - 1)) * 4;
     }
+    auto issue = [&](int u, intx4 (&st)[DC_NLD]) {
+        const int n = u / upf;
+        const int hb0 = 2 * DC_ROWS * (u - n * upf) - g.pt;       // image row of patch row 0
+        const int base = (n * g.Hb + hb0) * g.Wb * 4;
+#pragma unroll
+        for (int k = 0; k < DC_NLD; ++k) {
+            const int hb = hb0 + ld_y[k];
+            const bool ok = hb >= 0 && hb < g.Hb;
+            st[k] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? base + ld_off[k] : ED_OOB, 0, 0);
+        }
+    };
 
     // B operand: weights of output channel li for taps (2t + kk); lane-constant tap offsets of
     // the A gather (pixel li of the block, tap 2t + kk)
@@ -205,42 +234,75 @@ __global__ __launch_bounds__(ED_THREADS) void k_down_c1(
         toff[t] = (tc / 5) * DC_RW + (tc % 5);
     }
     const float bz = (bias && li < g.Cs) ? bias[li] : 0.f;
-#pragma unroll
-    for (int k = 0; k < DC_KB; ++k) {
-        const int e = tid + ED_THREADS * k;
-        if (e < DC_IH * DC_RW) bl[e] = stage[k];
-    }
-    __syncthreads();
+    const int a_col = DC_X0 - g.pl + 2 * li;
 
-    // lane -> (channel li, pixel quad 4*kk + 8*grp) of every block
-    const size_t chan = ((size_t)n * g.Cs + li) * PQ;
-#pragma unroll 2
-    for (int bk = 0; bk < 4; ++bk) {
-        const int blk = wv * 4 + bk;
-        const int pr = blk >> 1, q0 = (blk & 1) * 32;
-        const float* aq = bl + (2 * pr) * DC_RW + 2 * (q0 + li);
-        floatx16 acc;
+    intx4 stage[DC_NLD];
+    int u = blockIdx.x;
+    if (u < units) issue(u, stage);
+#pragma unroll 1
+    for (; u < units; u += gridDim.x) {
+        // LDS operations of one wave execute in order: the previous unit's reads are done
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int k = 0; k < DC_NLD; ++k) {
+            const int e = lane + 64 * k;
+            if (e < DC_IH * DC_C4) *reinterpret_cast<intx4*>(bl + 4 * e) = stage[k];
+        }
+        if (u + (int)gridDim.x < units) issue(u + gridDim.x, stage);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        const int n = u / upf;
+        const int p0 = DC_ROWS * (u - n * upf);
+        const float* aq = bl + a_col;
+#pragma unroll 1
+        for (int pr = 0; pr < DC_ROWS; ++pr) {
+            // two independent accumulators (the half-rows), interleaved step by step: a 13-long
+            // dependent chain would stall the issue after every MFMA.  The stores of this row
+            // drain while the next row's (and the other waves') MFMAs run.
+            floatx16 acc[2];
 #pragma unroll
-        for (int t = 0; t < 13; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[toff[t]], wv_[t], acc, 0, 0, 0);
-        if (li >= g.Cs) continue;
-        const size_t row = chan + (size_t)(p0 + pr) * g.Ws + q0 + 4 * kk;
+            for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            float4 v = make_float4(acc[4 * grp] + bz, acc[4 * grp + 1] + bz, acc[4 * grp + 2] + bz,
-                                   acc[4 * grp + 3] + bz);
-            if (ACT == BN_ACT_LRELU) {
-                v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
-                v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                for (int e = 0; e < 16; ++e) acc[qh][e] = 0.f;
+            const float* ar = aq + (2 * pr) * DC_RW;
+#pragma unroll
+            for (int t = 0; t < 13; ++t) {
+#pragma unroll
+                for (int qh = 0; qh < 2; ++qh)
+                    acc[qh] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[toff[t] + 64 * qh], wv_[t],
+                                                                   acc[qh], 0, 0, 0);
             }
-            if (MASK) {
-                const float4 d = *reinterpret_cast<const float4*>(dact_src + row + 8 * grp);
-                v.x *= d.x > 0.f ? 1.f : slope; v.y *= d.y > 0.f ? 1.f : slope;
-                v.z *= d.z > 0.f ? 1.f : slope; v.w *= d.w > 0.f ? 1.f : slope;
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                // lane holds, for channel li, pixels 32*qh + 8*grp + 4*kk + {0..3}
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    floatx4e v = {acc[qh][4 * grp] + bz, acc[qh][4 * grp + 1] + bz,
+                                  acc[qh][4 * grp + 2] + bz, acc[qh][4 * grp + 3] + bz};
+                    if (ACT == BN_ACT_LRELU) {
+                        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+                        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                    }
+                    *reinterpret_cast<floatx4e*>(tw + li * DC_TS + 32 * qh + 8 * grp + 4 * kk) = v;
+                }
             }
-            *reinterpret_cast<float4*>(out + row + 8 * grp) = v;
+            // the asm only keeps the compiler from moving the slab reads above the writes
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const size_t row0 = ((size_t)n * g.Cs * g.Hs + (p0 + pr)) * DC_W + 4 * (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ch = 4 * i + (lane >> 4);
+                floatx4e v = *reinterpret_cast<const floatx4e*>(tw + ch * DC_TS + 4 * (lane & 15));
+                if (ch < g.Cs) {
+                    const size_t o = row0 + (size_t)ch * PQ;
+                    if (MASK) {
+                        const floatx4e d = *reinterpret_cast<const floatx4e*>(dact_src + o);
+                        v.x *= d.x > 0.f ? 1.f : slope; v.y *= d.y > 0.f ? 1.f : slope;
+                        v.z *= d.z > 0.f ? 1.f : slope; v.w *= d.w > 0.f ? 1.f : slope;
+                    }
+                    *reinterpret_cast<floatx4e*>(out + o) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
 }
@@ -248,27 +310,41 @@ __global__ __launch_bounds__(ED_THREADS) void k_down_c1(
 BnFastPlan bn_edge_down_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_down_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb != 1) return p;
-    if (g.Cs > 32 || g.Ws != DC_W || (g.Hs % DC_TH) != 0) return p;
+    if (g.Cs > 32 || g.Ws != DC_W || (g.Hs % DC_ROWS) != 0) return p;
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
+    if (g.pl < 0 || g.pl > DC_X0 || g.pt < 0) return p;
     if ((size_t)g.N * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
     p.supported = true;
     p.kernel_name = "k_down_c1";
     return p;
 }
 
+// grid = waves; every CU should get the same number of units in the fewest rounds
+static int down_c1_grid(int units) {
+    const int n_cu = 256;
+    const int per_cu = (units + n_cu - 1) / n_cu;
+    const int rounds = (per_cu + DC_MAX_WAVES_PER_CU - 1) / DC_MAX_WAVES_PER_CU;
+    const int waves = (per_cu + rounds - 1) / rounds;
+    const int grid = n_cu * waves;
+    return grid < units ? grid : units;
+}
+
 int bn_launch_edge_down(const float* big, const float* w, const float* bias, float* out,
                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                         hipStream_t st) {
-    const dim3 grid(g.N * (g.Hs / DC_TH));
+    const int units = g.N * (g.Hs / DC_ROWS);
+    const dim3 grid(down_c1_grid(units));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bn_prof_take_dispatch_events(&e0, &e1);   // stay null unless bench.py's hook is armed
     if (act == BN_ACT_LRELU && !dact_src) {
-        hipLaunchKernelGGL((k_down_c1<BN_ACT_LRELU, false>), grid, dim3(ED_THREADS), 0, st, big, w,
-                           bias, out, dact_src, g, slope);
+        hipExtLaunchKernelGGL((k_down_c1<BN_ACT_LRELU, false>), grid, dim3(64), 0, st, e0, e1, 0,
+                              big, w, bias, out, dact_src, g, slope, units);
     } else if (act == BN_ACT_NONE && !dact_src) {
-        hipLaunchKernelGGL((k_down_c1<BN_ACT_NONE, false>), grid, dim3(ED_THREADS), 0, st, big, w,
-                           bias, out, dact_src, g, slope);
+        hipExtLaunchKernelGGL((k_down_c1<BN_ACT_NONE, false>), grid, dim3(64), 0, st, e0, e1, 0,
+                              big, w, bias, out, dact_src, g, slope, units);
     } else {   // data gradient: no activation of its own, LeakyReLU' mask of the layer below
-        hipLaunchKernelGGL((k_down_c1<BN_ACT_NONE, true>), grid, dim3(ED_THREADS), 0, st, big, w,
-                           bias, out, dact_src, g, slope);
+        hipExtLaunchKernelGGL((k_down_c1<BN_ACT_NONE, true>), grid, dim3(64), 0, st, e0, e1, 0,
+                              big, w, bias, out, dact_src, g, slope, units);
     }
     BN_LAUNCH_CHECK();
     return 0;

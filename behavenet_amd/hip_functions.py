@@ -40,6 +40,20 @@ class accumulate_into_param_grads(object):
         return False
 
 
+def backward_chunks(chunk_losses):
+    """Run the per-chunk backward passes, in chunk order, after ALL chunk forwards.
+
+    The reference interleaves forward and backward per chunk (aes.py:748-769); the parameters do
+    not change in between, so running the forwards first gives bit-identical gradients (same
+    kernels, same accumulation order) while the forwards run with the weight-gradient side
+    stream idle and the tail of chunk c's weight gradients overlaps the head of chunk c+1's data
+    gradients.
+    """
+    with accumulate_into_param_grads():
+        for loss in chunk_losses:
+            loss.backward()
+
+
 _use_side_stream = True
 _side_streams = {}
 

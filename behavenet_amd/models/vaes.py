@@ -17,7 +17,7 @@ from torch import nn
 
 import behavenet_amd.fitting.losses as losses
 from behavenet_amd import hip_functions as hf
-from behavenet_amd.hip_functions import linear, accumulate_into_param_grads
+from behavenet_amd.hip_functions import linear
 from behavenet_amd.models.aes import AE, ConvAEDecoder, ConvAEEncoder
 from behavenet_amd.models.base import DiagLinear
 
@@ -109,7 +109,7 @@ class VAE(AE):
         beta = self.beta_vals[self.curr_epoch]
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
-        pairs = []
+        pairs, deferred = [], []
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
@@ -122,9 +122,9 @@ class VAE(AE):
                 loss_kl = losses.kl_div_to_std_normal(mu, logvar)
                 loss = -loss_ll + float(beta) * loss_kl
             if accumulate_grad:
-                with accumulate_into_param_grads():
-                    loss.backward()
+                deferred.append(loss)
             pairs.append(({'loss': loss, 'loss_ll': loss_ll, 'loss_kl': loss_kl}, end - beg))
+        hf.backward_chunks(deferred)
         hf.join_side_streams()
         keys, vals, sizes = _collect(pairs, batch_size)
         out = {k: 0.0 for k in keys}
@@ -193,7 +193,7 @@ class BetaTCVAE(VAE):
         kl = self.kl_anneal_vals[self.curr_epoch]
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
-        pairs = []
+        pairs, deferred = [], []
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
@@ -205,10 +205,10 @@ class BetaTCVAE(VAE):
                 mi, tc, dwkl = losses.decomposed_kl(sample, mu, logvar)
                 loss = -ll + float(kl) * mi + float(beta) * tc + float(kl) * dwkl
             if accumulate_grad:
-                with accumulate_into_param_grads():
-                    loss.backward()
+                deferred.append(loss)
             pairs.append(({'loss': loss, 'loss_ll': ll, 'loss_mi': mi, 'loss_tc': tc,
                            'loss_dwkl': dwkl}, end - beg))
+        hf.backward_chunks(deferred)
         hf.join_side_streams()
         keys, vals, sizes = _collect(pairs, batch_size)
         out = {k: 0.0 for k in keys}
@@ -314,7 +314,7 @@ class PSVAE(AE):
         beta = self.beta_vals[self.curr_epoch]
         kl = self.kl_anneal_vals[self.curr_epoch]
 
-        pairs, y_hat_all = [], []
+        pairs, y_hat_all, deferred = [], [], []
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
@@ -335,11 +335,11 @@ class PSVAE(AE):
                 t['loss'] = -t['loss_data_ll'] - float(alpha) * t['loss_label_ll'] \
                     + t['loss_zs_kl'] + float(kl) * mi + float(beta) * tc + float(kl) * dwkl
             if accumulate_grad:
-                with accumulate_into_param_grads():
-                    t['loss'].backward()
+                deferred.append(t['loss'])
             pairs.append((t, end - beg))
             y_hat_all.append(y_hat.detach())
 
+        hf.backward_chunks(deferred)
         hf.join_side_streams()
         keys, vals, sizes = _collect(pairs, batch_size)
         order = ['loss', 'loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi',

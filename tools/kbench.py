@@ -32,13 +32,21 @@ LAYERS = {
 }
 
 
+RING = 0   # keep this many previous outputs alive so that results rotate through > 256 MB (MALL)
+
+
 def timeit(fn, iters):
-    fn()
+    keep = []
+    keep.append(fn())
+    for _ in range(RING):
+        keep.append(fn())
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        fn()
+        keep.append(fn())
+        if len(keep) > RING + 1:
+            keep.pop(0)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
@@ -55,7 +63,11 @@ def main():
     ap.add_argument('--layers', default=','.join(LAYERS))
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--no-check', action='store_true')
+    ap.add_argument('--ring', type=int, default=0,
+                    help='outputs kept alive (defeats the 256 MB Infinity Cache for small layers)')
     args = ap.parse_args()
+    global RING
+    RING = args.ring
     N = args.n
     dev = 'cuda'
     rows = []
