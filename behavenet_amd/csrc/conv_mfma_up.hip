@@ -9,6 +9,7 @@
 // small[c][a+dy][b+dx] (dy,dx in -1..1) are read from LDS once and shared by the classes:
 // per channel pair 9 B-reads + 25*MR A-reads feed 25*MR MFMAs (v_mfma_f32_32x32x2_f32).
 // The two column classes of a lane are adjacent in memory, so the epilogue stores float2.
+#include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"
 
@@ -223,12 +224,18 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
     if (g.Cb < 16 || g.Cs < 2) return p;
     UpTile t;
     int nwg2 = 0, nwg1 = 0;
-    const bool ok2 = g.Cb >= 64 && up_tile(g, 2, 4, &t, &nwg2);
-    const bool ok1 = up_tile(g, 1, 4, &t, &nwg1);
+    static int env_mr = -1, env_cc = -1;          // tuning hooks: BN_UP_MR=1|2, BN_UP_CC=4|8
+    if (env_mr < 0) { const char* e = getenv("BN_UP_MR"); env_mr = e ? atoi(e) : 0; }
+    if (env_cc < 0) { const char* e = getenv("BN_UP_CC"); env_cc = e ? atoi(e) : 0; }
+    const int cc = (env_cc == 8 && (g.Cs % 8) == 0) ? 8 : 4;
+    const bool ok2 = g.Cb >= 64 && up_tile(g, 2, cc, &t, &nwg2);
+    const bool ok1 = up_tile(g, 1, cc, &t, &nwg1);
     if (!ok1 && !ok2) return p;
     p.supported = true;
     p.a = (ok2 && (nwg2 >= 768 || !ok1)) ? 2 : 1;
-    p.c = 4;
+    if (env_mr == 2 && ok2) p.a = 2;
+    if (env_mr == 1 && ok1) p.a = 1;
+    p.c = cc;
     p.kernel_name = "k_up_mfma<s2>";
     return p;
 }
@@ -244,8 +251,14 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
     const int groups = (g.N + t.F - 1) / t.F;
     dim3 grid(groups * t.tiles_per_frame, (g.Cb + 32 * MR - 1) / (32 * MR));
     const size_t lds = ((size_t)t.xl_floats + (size_t)CC * 25 * (32 * MR + 1)) * 4;
-    if (MR == 2) {
+    if (MR == 2 && CC == 8) {
+        hipLaunchKernelGGL((k_up_mfma<2, 8>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+                           dact_src, g, t, act, dact, slope);
+    } else if (MR == 2) {
         hipLaunchKernelGGL((k_up_mfma<2, 4>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+                           dact_src, g, t, act, dact, slope);
+    } else if (CC == 8) {
+        hipLaunchKernelGGL((k_up_mfma<1, 8>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                            dact_src, g, t, act, dact, slope);
     } else {
         hipLaunchKernelGGL((k_up_mfma<1, 4>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,

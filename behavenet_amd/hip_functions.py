@@ -54,6 +54,34 @@ def backward_chunks(chunk_losses):
             loss.backward()
 
 
+class Readback(object):
+    """Asynchronous device -> host copy of a small tensor through a pooled pinned buffer.
+
+    ``Readback(t)`` enqueues the copy on the current stream; ``.numpy()`` waits for THAT copy only
+    (an event), not for work enqueued afterwards.  The models start the read-back of the chunk
+    losses after the forwards, enqueue every backward launch, and only then wait: the value is
+    long there, and the host returns with the backward kernels still queued, so the optimizer
+    step and the next batch's forward follow them without a bubble.
+    """
+    _pool = {}
+
+    def __init__(self, t):
+        t = t.detach()
+        self._key = (t.dtype, tuple(t.shape))
+        free = Readback._pool.setdefault(self._key, [])
+        self._buf = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self._buf.copy_(t, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+    def numpy(self):
+        self._event.synchronize()
+        out = self._buf.numpy().copy()
+        Readback._pool[self._key].append(self._buf)
+        self._buf = None
+        return out
+
+
 _use_side_stream = True
 _side_streams = {}
 

@@ -16,7 +16,8 @@ import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ConvLayerPlan, conv_stack, conv_stack_bn, linear, backward_chunks, join_side_streams)
+    ConvLayerPlan, Readback, conv_stack, conv_stack_bn, linear, backward_chunks,
+    join_side_streams)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
@@ -459,9 +460,12 @@ class AE(BaseModel):
             vals.append(loss.detach())
             sizes.append(end - beg)
 
+        # the loss values only need the forwards: their read-back is enqueued before the
+        # (deferred) backwards and waited for after every backward launch is queued
+        vals = Readback(torch.stack(vals))
         backward_chunks(deferred)
         join_side_streams()
-        vals = torch.stack(vals).cpu().numpy().astype(np.float64)
+        vals = vals.numpy().astype(np.float64)
         loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
         return {'loss': loss_val}
 
@@ -509,9 +513,12 @@ class ConditionalAE(AE):
                 deferred.append(loss)
             vals.append(loss.detach())
             sizes.append(end - beg)
+        # the loss values only need the forwards: their read-back is enqueued before the
+        # (deferred) backwards and waited for after every backward launch is queued
+        vals = Readback(torch.stack(vals))
         backward_chunks(deferred)
         join_side_streams()
-        vals = torch.stack(vals).cpu().numpy().astype(np.float64)
+        vals = vals.numpy().astype(np.float64)
         loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
         return {'loss': loss_val}
 

@@ -75,11 +75,14 @@ def _anneal_tables(beta, anneal_epochs, max_n_epochs, tail_is_beta):
 
 
 def _collect(pairs, batch_size):
-    """One device->host transfer for all per-chunk scalars: [(dict of 0-dim tensors, bs), ...]."""
+    """One device->host transfer for all per-chunk scalars: [(dict of 0-dim tensors, bs), ...].
+
+    Returns (keys, Readback of the (n_chunks, n_keys) table, chunk sizes); the caller enqueues
+    the backwards and then takes ``.numpy()`` (see hip_functions.Readback).
+    """
     keys = list(pairs[0][0].keys())
     flat = torch.stack([torch.stack([d[k].detach().float() for k in keys]) for d, _ in pairs])
-    vals = flat.cpu().numpy().astype(np.float64)
-    return keys, vals, [bs for _, bs in pairs]
+    return keys, hf.Readback(flat), [bs for _, bs in pairs]
 
 
 class VAE(AE):
@@ -124,9 +127,11 @@ class VAE(AE):
             if accumulate_grad:
                 deferred.append(loss)
             pairs.append(({'loss': loss, 'loss_ll': loss_ll, 'loss_kl': loss_kl}, end - beg))
+        # read-back enqueued between the forwards and the deferred backwards (see AE.loss)
+        keys, vals, sizes = _collect(pairs, batch_size)
         hf.backward_chunks(deferred)
         hf.join_side_streams()
-        keys, vals, sizes = _collect(pairs, batch_size)
+        vals = vals.numpy().astype(np.float64)
         out = {k: 0.0 for k in keys}
         out['loss_mse'] = 0.0
         n_dims = np.prod(x.shape[1:])
@@ -208,9 +213,11 @@ class BetaTCVAE(VAE):
                 deferred.append(loss)
             pairs.append(({'loss': loss, 'loss_ll': ll, 'loss_mi': mi, 'loss_tc': tc,
                            'loss_dwkl': dwkl}, end - beg))
+        # read-back enqueued between the forwards and the deferred backwards (see AE.loss)
+        keys, vals, sizes = _collect(pairs, batch_size)
         hf.backward_chunks(deferred)
         hf.join_side_streams()
-        keys, vals, sizes = _collect(pairs, batch_size)
+        vals = vals.numpy().astype(np.float64)
         out = {k: 0.0 for k in keys}
         out['loss_mse'] = 0.0
         n_dims = np.prod(x.shape[1:])
@@ -339,9 +346,16 @@ class PSVAE(AE):
             pairs.append((t, end - beg))
             y_hat_all.append(y_hat.detach())
 
+        # read-backs enqueued between the forwards and the deferred backwards (see AE.loss)
+        keys, vals, sizes = _collect(pairs, batch_size)
+        y_hat_rb = hf.Readback(torch.cat(y_hat_all, dim=0))
+        y_rb = hf.Readback(y)
+        n_rb = hf.Readback(n) if n is not None else None
         hf.backward_chunks(deferred)
         hf.join_side_streams()
-        keys, vals, sizes = _collect(pairs, batch_size)
+        vals = vals.numpy().astype(np.float64)
+        y_hat_np, y_np = y_hat_rb.numpy(), y_rb.numpy()
+        n_np = n_rb.numpy() if n_rb is not None else None
         order = ['loss', 'loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi',
                  'loss_zu_tc', 'loss_zu_dwkl']
         out = {k: 0.0 for k in order}
@@ -354,10 +368,7 @@ class PSVAE(AE):
             out['loss_data_mse'] += losses.gaussian_ll_to_mse(
                 out['loss_data_ll'] / bs, n_dims) * bs
 
-        y_hat_np = torch.cat(y_hat_all, dim=0).cpu().numpy()
-        y_np = y.detach().cpu().numpy()
         if n is not None:
-            n_np = n.detach().cpu().numpy()
             r2 = _r2_variance_weighted(y_np[n_np == 1], y_hat_np[n_np == 1])
         else:
             r2 = _r2_variance_weighted(y_np, y_hat_np)
