@@ -13,6 +13,8 @@ calls the C ABI (behavenet_amd/_hip.py) for both directions; torch autograd only
 * :class:`ReparamFn`, :class:`KLFn` -- the variational tail (vaes.py:33-35, losses.py:146-147).
 """
 
+import os
+
 import torch
 
 from behavenet_amd import _hip
@@ -84,6 +86,116 @@ class Readback(object):
 
 _use_side_stream = True
 _side_streams = {}
+
+# Chunk pipelines: the 200-frame chunks of one batch are independent until their gradients meet
+# in `param.grad`.  Odd chunks run (forward and, through autograd's stream affinity, backward)
+# on an auxiliary HIP stream so that the workgroups of the 56-frame chunk fill the tails the
+# 200-frame chunk leaves on the 256 CUs.  Every in-place gradient accumulation goes through the
+# single weight-gradient side stream in issue order (chunk 0 first), so the result is the same
+# sum in the same order as the one-stream schedule.
+_use_chunk_streams = os.environ.get('BN_CHUNK_STREAMS', '1') != '0'
+_aux_streams = {}
+_chunk_epoch = {}
+
+
+def begin_chunks(device):
+    """Mark the point on the current stream that the auxiliary chunk stream has to wait for."""
+    if not _use_chunk_streams or torch.device(device).type != 'cuda':
+        return      # (a CPU tensor fails loudly in the first kernel call, not here)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _chunk_epoch[torch.device(device).index] = ev
+
+
+class chunk_stream(object):
+    """Context manager: run the enclosed chunk on its pipeline's stream."""
+
+    def __init__(self, index, device, enabled=True):
+        self._ctx = None
+        key = torch.device(device).index
+        if enabled and _use_chunk_streams and _use_side_stream and (index % 2) == 1 \
+                and key in _chunk_epoch:
+            aux = _aux_streams.get(key)
+            if aux is None:
+                aux = torch.cuda.Stream(device=device)
+                _aux_streams[key] = aux
+            aux.wait_event(_chunk_epoch[key])
+            self._ctx = torch.cuda.stream(aux)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            return self._ctx.__exit__(*exc)
+        return False
+
+
+def reserve_device_pools(model, frames_per_batch, device='cuda', headroom=6.0):
+    """Grow torch's caching-allocator pools of the main and the auxiliary chunk stream ONCE, up
+    front, to `headroom` x the activation bytes of one batch.
+
+    Which cached block a tensor gets depends on when the side streams release theirs, so without
+    this the pools keep growing by an occasional hipMalloc (a 30-60 ms device-wide stall) for the
+    first dozens of steps.  288 GB of HBM make the reservation free: cfg2 at batch 256 asks for
+    ~6 GB + ~3 GB.
+    """
+    per_frame = 0
+    for part in (getattr(model, 'encoding', None), getattr(model, 'decoding', None)):
+        for layer in getattr(part, '_plan', []) or []:
+            per_frame += 4 * (layer.cin * layer.hin * layer.win + layer.cout * layer.hout * layer.wout)
+    if per_frame == 0 or torch.device(device).type != 'cuda':
+        return 0
+    main_bytes = int(headroom * per_frame * frames_per_batch)
+    blocks = [torch.empty(main_bytes, dtype=torch.uint8, device=device)]
+    if _use_chunk_streams:
+        key = torch.device(device).index
+        if key is None:
+            key = torch.cuda.current_device()
+        aux = _aux_streams.get(key)
+        if aux is None:
+            aux = torch.cuda.Stream(device=device)
+            _aux_streams[key] = aux
+        with torch.cuda.stream(aux):
+            blocks.append(torch.empty(main_bytes // 2, dtype=torch.uint8, device=device))
+    total = sum(b.numel() for b in blocks)
+    del blocks
+    return total
+
+
+class ChunkScalars(object):
+    """The per-chunk loss scalars of one ``loss()`` call, still on the device.
+
+    ``add(t)`` is called inside the chunk's stream context with a small 1-d tensor; ``finish``
+    enqueues one read-back per chunk on that chunk's stream (after ALL forwards have been
+    enqueued, so that no device->host copy sits between two forwards), then the deferred
+    backwards, joins every stream and returns the values as a float64 (n_chunks, n_values) array.
+    """
+
+    def __init__(self):
+        self._items = []
+
+    def add(self, t):
+        self._items.append((torch.cuda.current_stream(t.device), t.detach()))
+
+    def finish(self, chunk_losses):
+        import numpy as np
+        rbs = []
+        for stream, t in self._items:
+            with torch.cuda.stream(stream):
+                rbs.append(Readback(t))
+        backward_chunks(chunk_losses)
+        join_chunk_streams()
+        join_side_streams()
+        return np.stack([r.numpy() for r in rbs]).astype(np.float64)
+
+
+def join_chunk_streams():
+    """Make the current stream wait for the auxiliary chunk stream(s)."""
+    for key, s in _aux_streams.items():
+        torch.cuda.current_stream(s.device).wait_stream(s)
 
 
 def _side_stream(device):
@@ -351,8 +463,22 @@ class LinearFn(torch.autograd.Function):
         else:
             dw = torch.empty_like(w) if need_dw else None
             db = torch.empty((w.shape[0],), dtype=w.dtype, device=w.device) if need_db else None
-        dx = _hip.linear_bwd(x, w.contiguous(), dy, need_dx, None, _hip.ACT_NONE, 0.0, dw, db,
-                             direct)
+        wc = w.contiguous()
+        if direct and _use_side_stream:
+            # in-place accumulation into param.grad: on the weight-gradient side stream, like the
+            # convolutions', so that chunks running on different streams never race on it
+            dx = _hip.linear_bwd(x, wc, dy, need_dx, None, _hip.ACT_NONE, 0.0, None, None, False) \
+                if need_dx else None
+            side = _side_stream(w.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(w.device))
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                _hip.linear_bwd(x, wc, dy, False, None, _hip.ACT_NONE, 0.0, dw, db, True)
+            dy.record_stream(side)
+            x.record_stream(side)
+            return dx, None, None
+        dx = _hip.linear_bwd(x, wc, dy, need_dx, None, _hip.ACT_NONE, 0.0, dw, db, direct)
         if direct:
             return dx, None, None
         return dx, dw, db

@@ -16,8 +16,8 @@ import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ConvLayerPlan, Readback, conv_stack, conv_stack_bn, linear, backward_chunks,
-    join_side_streams)
+    ChunkScalars, ConvLayerPlan, conv_stack, conv_stack_bn, linear, begin_chunks, chunk_stream,
+    reserve_device_pools)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
@@ -421,6 +421,22 @@ class AE(BaseModel):
         else:
             raise ValueError('"%s" is an invalid model_type' % self.model_type)
 
+    def _reserve_pools(self, x):
+        """First call (or a larger batch than seen so far): pre-grow the allocator pools."""
+        if x.shape[0] > getattr(self, '_reserved_frames', 0) and x.is_cuda:
+            reserve_device_pools(self, x.shape[0], x.device)
+            self._reserved_frames = int(x.shape[0])
+
+    def _chunk_streams_ok(self):
+        """Chunks may run on two HIP streams unless a layer accumulates outside the weight-
+        gradient side stream (batch-norm scale/shift gradients and running statistics) ..."""
+        if self.hparams.get('ae_batch_norm', False):
+            return False
+        # ... and only when every gradient is accumulated in place (param.grad exists, as under
+        # FlatAdamAMSGrad): a first-touch `param.grad = dw` by autograd would not be ordered
+        # against the side stream's in-place adds of the other chunk
+        return all(p.grad is not None for p in self.parameters() if p.requires_grad)
+
     def forward(self, x, dataset=None, **kwargs):
         """-> (x_hat (N,C,H,W), latents (N,n_latents))."""
         if self.model_type == 'conv':
@@ -446,26 +462,25 @@ class AE(BaseModel):
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
 
-        vals, sizes, deferred = [], [], []
+        vals, sizes, deferred = ChunkScalars(), [], []
+        self._reserve_pools(x)
+        begin_chunks(x.device)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
             x_in = x[beg:end]
             m_in = m[beg:end] if m is not None else None
-            with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, _ = self.forward(x_in, dataset=dataset)
-                loss = losses.mse(x_in, x_hat, m_in)
+            with chunk_stream(chunk, x.device, self._chunk_streams_ok()):
+                with torch.set_grad_enabled(bool(accumulate_grad)):
+                    x_hat, _ = self.forward(x_in, dataset=dataset)
+                    loss = losses.mse(x_in, x_hat, m_in)
+                vals.add(loss.detach().reshape(1))
             if accumulate_grad:
                 deferred.append(loss)
-            vals.append(loss.detach())
             sizes.append(end - beg)
-
         # the loss values only need the forwards: their read-back is enqueued before the
         # (deferred) backwards and waited for after every backward launch is queued
-        vals = Readback(torch.stack(vals))
-        backward_chunks(deferred)
-        join_side_streams()
-        vals = vals.numpy().astype(np.float64)
+        vals = vals.finish(deferred)[:, 0]
         loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
         return {'loss': loss_val}
 
@@ -499,26 +514,26 @@ class ConditionalAE(AE):
             else None
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
-        vals, sizes, deferred = [], [], []
+        vals, sizes, deferred = ChunkScalars(), [], []
+        self._reserve_pools(x)
+        begin_chunks(x.device)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
             x_in, y_in = x[beg:end], y[beg:end]
             m_in = m[beg:end] if m is not None else None
             l2d = labels_2d[beg:end] if labels_2d is not None else None
-            with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, _ = self.forward(x_in, dataset=dataset, labels=y_in, labels_2d=l2d)
-                loss = losses.mse(x_in, x_hat, m_in)
+            with chunk_stream(chunk, x.device, self._chunk_streams_ok()):
+                with torch.set_grad_enabled(bool(accumulate_grad)):
+                    x_hat, _ = self.forward(x_in, dataset=dataset, labels=y_in, labels_2d=l2d)
+                    loss = losses.mse(x_in, x_hat, m_in)
+                vals.add(loss.detach().reshape(1))
             if accumulate_grad:
                 deferred.append(loss)
-            vals.append(loss.detach())
             sizes.append(end - beg)
         # the loss values only need the forwards: their read-back is enqueued before the
         # (deferred) backwards and waited for after every backward launch is queued
-        vals = Readback(torch.stack(vals))
-        backward_chunks(deferred)
-        join_side_streams()
-        vals = vals.numpy().astype(np.float64)
+        vals = vals.finish(deferred)[:, 0]
         loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
         return {'loss': loss_val}
 

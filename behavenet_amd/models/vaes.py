@@ -74,15 +74,9 @@ def _anneal_tables(beta, anneal_epochs, max_n_epochs, tail_is_beta):
     return beta_vals, kl_vals
 
 
-def _collect(pairs, batch_size):
-    """One device->host transfer for all per-chunk scalars: [(dict of 0-dim tensors, bs), ...].
-
-    Returns (keys, Readback of the (n_chunks, n_keys) table, chunk sizes); the caller enqueues
-    the backwards and then takes ``.numpy()`` (see hip_functions.Readback).
-    """
-    keys = list(pairs[0][0].keys())
-    flat = torch.stack([torch.stack([d[k].detach().float() for k in keys]) for d, _ in pairs])
-    return keys, hf.Readback(flat), [bs for _, bs in pairs]
+def _stack_scalars(t):
+    """One chunk's 0-dim loss terms as one small device tensor (dict order)."""
+    return torch.stack([v.detach().float() for v in t.values()])
 
 
 class VAE(AE):
@@ -112,26 +106,28 @@ class VAE(AE):
         beta = self.beta_vals[self.curr_epoch]
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
-        pairs, deferred = [], []
+        rbs, sizes, deferred = hf.ChunkScalars(), [], []
+        keys = ['loss', 'loss_ll', 'loss_kl']
+        self._reserve_pools(x)
+        hf.begin_chunks(x.device)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
             x_in = x[beg:end]
             m_in = m[beg:end] if m is not None else None
-            with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, _, mu, logvar = self.forward(
-                    x_in, dataset=dataset, use_mean=False, **fwd_kwargs_fn(beg, end))
-                loss_ll = losses.gaussian_ll(x_in, x_hat, m_in)
-                loss_kl = losses.kl_div_to_std_normal(mu, logvar)
-                loss = -loss_ll + float(beta) * loss_kl
+            with hf.chunk_stream(chunk, x.device, self._chunk_streams_ok()):
+                with torch.set_grad_enabled(bool(accumulate_grad)):
+                    x_hat, _, mu, logvar = self.forward(
+                        x_in, dataset=dataset, use_mean=False, **fwd_kwargs_fn(beg, end))
+                    loss_ll = losses.gaussian_ll(x_in, x_hat, m_in)
+                    loss_kl = losses.kl_div_to_std_normal(mu, logvar)
+                    loss = -loss_ll + float(beta) * loss_kl
+                rbs.add(_stack_scalars({'loss': loss, 'loss_ll': loss_ll, 'loss_kl': loss_kl}))
             if accumulate_grad:
                 deferred.append(loss)
-            pairs.append(({'loss': loss, 'loss_ll': loss_ll, 'loss_kl': loss_kl}, end - beg))
-        # read-back enqueued between the forwards and the deferred backwards (see AE.loss)
-        keys, vals, sizes = _collect(pairs, batch_size)
-        hf.backward_chunks(deferred)
-        hf.join_side_streams()
-        vals = vals.numpy().astype(np.float64)
+            sizes.append(end - beg)
+        # read-backs enqueued with the forwards, collected after the deferred backwards are queued
+        vals = rbs.finish(deferred)
         out = {k: 0.0 for k in keys}
         out['loss_mse'] = 0.0
         n_dims = np.prod(x.shape[1:])
@@ -198,26 +194,28 @@ class BetaTCVAE(VAE):
         kl = self.kl_anneal_vals[self.curr_epoch]
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
-        pairs, deferred = [], []
+        rbs, sizes, deferred = hf.ChunkScalars(), [], []
+        keys = ['loss', 'loss_ll', 'loss_mi', 'loss_tc', 'loss_dwkl']
+        self._reserve_pools(x)
+        hf.begin_chunks(x.device)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
             x_in = x[beg:end]
             m_in = m[beg:end] if m is not None else None
-            with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, sample, mu, logvar = self.forward(x_in, dataset=dataset, use_mean=False)
-                ll = losses.gaussian_ll(x_in, x_hat, m_in)
-                mi, tc, dwkl = losses.decomposed_kl(sample, mu, logvar)
-                loss = -ll + float(kl) * mi + float(beta) * tc + float(kl) * dwkl
+            with hf.chunk_stream(chunk, x.device, self._chunk_streams_ok()):
+                with torch.set_grad_enabled(bool(accumulate_grad)):
+                    x_hat, sample, mu, logvar = self.forward(x_in, dataset=dataset,
+                                                             use_mean=False)
+                    ll = losses.gaussian_ll(x_in, x_hat, m_in)
+                    mi, tc, dwkl = losses.decomposed_kl(sample, mu, logvar)
+                    loss = -ll + float(kl) * mi + float(beta) * tc + float(kl) * dwkl
+                rbs.add(_stack_scalars({'loss': loss, 'loss_ll': ll, 'loss_mi': mi,
+                                            'loss_tc': tc, 'loss_dwkl': dwkl}))
             if accumulate_grad:
                 deferred.append(loss)
-            pairs.append(({'loss': loss, 'loss_ll': ll, 'loss_mi': mi, 'loss_tc': tc,
-                           'loss_dwkl': dwkl}, end - beg))
-        # read-back enqueued between the forwards and the deferred backwards (see AE.loss)
-        keys, vals, sizes = _collect(pairs, batch_size)
-        hf.backward_chunks(deferred)
-        hf.join_side_streams()
-        vals = vals.numpy().astype(np.float64)
+            sizes.append(end - beg)
+        vals = rbs.finish(deferred)
         out = {k: 0.0 for k in keys}
         out['loss_mse'] = 0.0
         n_dims = np.prod(x.shape[1:])
@@ -321,7 +319,10 @@ class PSVAE(AE):
         beta = self.beta_vals[self.curr_epoch]
         kl = self.kl_anneal_vals[self.curr_epoch]
 
-        pairs, y_hat_all, deferred = [], [], []
+        self._reserve_pools(x)
+        rbs, sizes, y_hat_all, deferred = hf.ChunkScalars(), [], [], []
+        keys = ['loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi', 'loss_zu_tc',
+                'loss_zu_dwkl', 'loss']
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
@@ -343,17 +344,17 @@ class PSVAE(AE):
                     + t['loss_zs_kl'] + float(kl) * mi + float(beta) * tc + float(kl) * dwkl
             if accumulate_grad:
                 deferred.append(t['loss'])
-            pairs.append((t, end - beg))
+            assert list(t.keys()) == keys
+            rbs.add(_stack_scalars(t))
+            sizes.append(end - beg)
             y_hat_all.append(y_hat.detach())
 
-        # read-backs enqueued between the forwards and the deferred backwards (see AE.loss)
-        keys, vals, sizes = _collect(pairs, batch_size)
+        # read-backs enqueued between the forwards and the deferred backwards (see AE.loss).
+        # One stream only: the diagonal label head D accumulates through torch's AccumulateGrad.
         y_hat_rb = hf.Readback(torch.cat(y_hat_all, dim=0))
         y_rb = hf.Readback(y)
         n_rb = hf.Readback(n) if n is not None else None
-        hf.backward_chunks(deferred)
-        hf.join_side_streams()
-        vals = vals.numpy().astype(np.float64)
+        vals = rbs.finish(deferred)
         y_hat_np, y_np = y_hat_rb.numpy(), y_rb.numpy()
         n_np = n_rb.numpy() if n_rb is not None else None
         order = ['loss', 'loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi',

@@ -327,6 +327,46 @@ def test_full_size_batch256_properties():
     assert lh == pytest.approx(lo, rel=1e-5)
 
 
+@pytest.mark.parametrize('model_class', ['ae', 'vae'])
+def test_stream_schedule_does_not_change_results(model_class):
+    """The production schedule (gradients accumulated in place into the optimizer's flat arena,
+    weight gradients on a side stream, odd chunks on an auxiliary stream) must give bit-identical
+    losses and gradients to the plain one-stream schedule, run after run."""
+    from behavenet_amd import hip_functions as hf
+    arch = load_handcrafted_arch([1, 128, 128], 12, None, check_memory=False)
+    extra = {'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0, 'max_n_epochs': 10} \
+        if model_class == 'vae' else None
+    hp = base_hparams(arch, model_class, extra)
+    torch.manual_seed(0)
+    model = BUILDERS[model_class](hp).to(DEV)
+    opt = FlatAdamAMSGrad(model.get_parameters(), lr=1e-4, weight_decay=0)
+    x = torch.from_numpy(make_frames(456, [1, 128, 128], seed=12)).to(DEV)   # chunks 200+200+56
+    data = {'images': x[None]}
+    eps = [torch.randn((n, 12), generator=torch.Generator().manual_seed(5 + i)).to(DEV)
+           for i, n in enumerate((200, 200, 56))]
+
+    def run(side, chunks):
+        hf._use_side_stream, hf._use_chunk_streams = side, chunks
+        try:
+            if model_class == 'vae':
+                it = iter(eps)
+                hip_vaes.set_eps_provider(lambda like: next(it))
+            opt.zero_grad()
+            out = model.loss(data, dataset=0, accumulate_grad=True)
+            torch.cuda.synchronize()
+            return out, opt.flat_g.clone()
+        finally:
+            hf._use_side_stream, hf._use_chunk_streams = True, True
+            hip_vaes.set_eps_provider(None)
+
+    ref_out, ref_g = run(False, False)
+    assert float(ref_g.abs().max()) > 0
+    for side, chunks in ((True, False), (True, True), (True, True), (True, True)):
+        out, g = run(side, chunks)
+        assert out == ref_out, (side, chunks)
+        assert torch.equal(g, ref_g), (side, chunks, float((g - ref_g).abs().max()))
+
+
 def test_losses_known_answers_on_device():
     """Closed-form answers of the reference's tests/test_fitting/test_losses.py:8-94."""
     LN2PI = np.log(2 * np.pi)
