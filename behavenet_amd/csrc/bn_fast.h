@@ -25,6 +25,12 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
 int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float* big, float* dw,
                          const BnGeom& g, int accumulate, void* ws, hipStream_t st);
 
+// conv_mfma_wgrad4.hip: 16-byte-DMA generation of the stride-2 weight gradient (tried first by
+// bn_fast_wgrad_plan; plan.variant == 4)
+BnFastPlan bn_wgrad4_plan(const BnGeom& g);
+int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* big, float* dw,
+                     const BnGeom& g, int accumulate, void* ws, hipStream_t st);
+
 // conv_s5.hip: stride == kernel size (non-overlapping windows), direct-from-global MFMA GEMMs
 BnFastPlan bn_s5_up_plan(const BnGeom& g);
 BnFastPlan bn_s5_wgrad_plan(const BnGeom& g);

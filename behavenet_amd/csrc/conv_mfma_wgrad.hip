@@ -16,6 +16,7 @@
 // (x -> (x&1)*HALF + x/2) so the stride-2 gather of four consecutive pixels is bank-conflict
 // free.  Partial tiles go to scratch as [split][tap][a][b]; k_sum_partials combines them in
 // fixed order (deterministic, no atomics) into dW[a][b][tap] (+= when accumulating).
+#include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"
 #include "bn_reduce.h"
@@ -27,7 +28,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define WG_TB 32            // b-channels per workgroup tile
 #define WG_TPX 64           // small-image pixels per stage
 #define WG_SP (WG_TPX + 2)  // small tile row stride (== 2 mod 32: conflict-free A reads)
-#define WG_KB 31            // max big-tile words per thread per stage
+#define WG_SLICES 8         // DMA slices per stage = MFMA-loop trips (2 k-steps of 4 pixels each)
+#define WG_KBS 4            // big-tile words per thread per slice
+#define WG_KB (WG_SLICES * WG_KBS)   // max big-tile words per thread per stage (32)
 #define WG_KS ((WG_TA * WG_TPX) / WG_THREADS)   // small-tile words per thread per stage (8)
 #define WG_MAX_LDS (160 * 1024)
 #define WG_OOB 0x7fffffff
@@ -50,8 +53,10 @@ struct WgradTile {
     int rows_per_b;                // F * IH
     int splits;                    // reduction splits (gridDim.y)
     int buf_floats;                // one LDS stage image: WG_TA*WG_SP + WG_TB*BCH (16-B multiple)
+    int dbg;                       // BN_WGRAD_DBG experiments (0 in production)
 };
 
+template <int LGQ>
 __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
     BnGeom g, WgradTile t) {
@@ -64,7 +69,10 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
     const int n_btiles = (g.Cb + WG_TB - 1) / WG_TB;
     const int atile = blockIdx.x / n_btiles, btile = blockIdx.x - atile * n_btiles;
     const int a0 = atile * WG_TA, b0 = btile * WG_TB;
-    const int Q = g.Ws, PQ = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
+    // small-image width is a template parameter: the 25 tap offsets r*RW + (s&1)*HALF + (s>>1)
+    // of the B reads become instruction immediates on one base address per k-step
+    constexpr int Q = 1 << LGQ, T_HALF = Q + 2, T_RW = 2 * Q + 4;
+    const int PQ = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
 
     floatx4 acc[25];
 #pragma unroll
@@ -75,16 +83,20 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
     const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(
         (void*)big, 0, (int)((size_t)g.N * g.Cb * HWb * 4), 0x00020000);
 
-    // queue the LDS-DMA of one stage into image `buf`
-    auto issue_dma = [&](int st, int buf) {
+    // queue slice `j` (of WG_SLICES) of the LDS-DMA of one stage into image `buf`: small-tile
+    // word k = j and big-tile words k = WG_KBS*j .. WG_KBS*j + WG_KBS-1 of every thread.  The
+    // slices are spread over the MFMA loop of the previous stage: a dword-granular DMA costs the
+    // CU's address unit tens of cycles per wave instruction, and 8 waves queueing all ~39 of
+    // theirs at the top of a stage kept the matrix cores waiting for the queue to drain.
+    auto issue_dma = [&](int st, int buf, int j) {
         const int grp = st / t.tiles_per_frame;
         const int n0 = grp * t.F;
         const int p0 = (st - grp * t.tiles_per_frame) * t.PT_H;
         float* sl = smem + buf * t.buf_floats;
         float* bl = sl + WG_TA * WG_SP;
         // small tile: word (a = 8k + wv, pix = lane); a stage's pixels are contiguous per frame
-#pragma unroll
-        for (int k = 0; k < WG_KS; ++k) {
+        {
+            const int k = j;
             const int a = 8 * k + wv;
             const int f = lane >> t.lgPTQ;
             const int rem = lane & ((1 << t.lgPTQ) - 1);
@@ -96,18 +108,19 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
         // big tile: word e = tid + 512k of bl[b][BCH]:  b = e / BCH, within = e % BCH ->
         // (row rr = f*IH + y, parity-split column xx) -> source pixel (hb, wb)
 #pragma unroll
-        for (int k = 0; k < WG_KB; ++k) {
+        for (int kb = 0; kb < WG_KBS; ++kb) {
+            const int k = WG_KBS * j + kb;
             if (WG_THREADS * k + 64 * wv >= t.big_words) break;      // wave-uniform
             int e = tid + WG_THREADS * k;
-            asm volatile("" : "+v"(e));   // keep the decode inside the stage loop (no hoisting)
+            asm volatile("" : "+v"(e));   // keep the decode next to its load (no hoisting)
             const int b = (int)(((float)e + 0.5f) * t.inv_bch);
             const int within = e - b * t.BCH;
             const int rr = (int)(((float)within + 0.5f) * t.inv_rw);
-            const int xx = within - rr * t.RW;
+            const int xx = within - rr * T_RW;
             const int f = (t.F == 1) ? 0 : (int)(((float)rr + 0.5f) * t.inv_ih);
             const int y = rr - f * t.IH;
-            const int par = xx >= t.HALF ? 1 : 0;
-            const int x = 2 * (xx - par * t.HALF) + par;
+            const int par = xx >= T_HALF ? 1 : 0;
+            const int x = 2 * (xx - par * T_HALF) + par;
             const int hb = 2 * p0 - g.pt + y, wb = x - g.pl;
             const bool ok = (b < WG_TB) && (rr < t.rows_per_b) && (b0 + b < g.Cb) &&
                             (n0 + f < g.N) && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
@@ -122,33 +135,40 @@ __global__ __launch_bounds__(WG_THREADS, 2) void k_wgrad_mfma(
 
     int st = blockIdx.y;
     int cur = 0;
-    if (st < t.n_stages) issue_dma(st, 0);
+    if (st < t.n_stages) {
+#pragma unroll 1
+        for (int j = 0; j < WG_SLICES; ++j) issue_dma(st, 0, j);
+    }
     for (; st < t.n_stages; st += t.splits) {
         // own DMAs of this stage have landed; after the barrier everyone's have, and every wave
         // is done reading the other image (it was computed from in the previous trip)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (st + t.splits < t.n_stages) issue_dma(st + t.splits, cur ^ 1);
+        if (!(t.dbg & 2)) __syncthreads();
+        const bool more = (st + t.splits < t.n_stages) && !(t.dbg & 1);
 
         const float* ap = smem + cur * t.buf_floats + a_off;
         const float* bp = smem + cur * t.buf_floats + b_off;
-#pragma unroll 2
-        for (int ks = 0; ks < WG_TPX / 4; ++ks) {
+#pragma unroll 1
+        for (int j = 0; j < WG_SLICES; ++j) {
+        if (more) issue_dma(st + t.splits, cur ^ 1, j);
+#pragma unroll
+        for (int ks = 2 * j; ks < 2 * j + 2; ++ks) {
             const int pix = 4 * ks + kk;
             const int f = pix >> t.lgPTQ;
             const int rem = pix & ((1 << t.lgPTQ) - 1);
-            const int pj = rem >> t.lgQ, qj = rem & (Q - 1);
+            const int pj = rem >> LGQ, qj = rem & (Q - 1);
             const float av = ap[4 * ks];
-            const float* bq = bp + f * t.FSb + (2 * pj) * t.RW + qj;
+            const float* bq = bp + f * t.FSb + (2 * pj) * T_RW + qj;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
 #pragma unroll
                 for (int s = 0; s < 5; ++s) {
-                    const float bv = bq[r * t.RW + (s & 1) * t.HALF + (s >> 1)];
+                    const float bv = bq[r * T_RW + (s & 1) * T_HALF + (s >> 1)];
                     acc[r * 5 + s] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r * 5 + s],
                                                                           0, 0, 0);
                 }
             }
+        }
         }
         cur ^= 1;
     }
@@ -215,10 +235,27 @@ static int wgrad_splits(const BnGeom& g, const WgradTile& t) {
     return splits;
 }
 
+template <int LGQ>
+static int launch_wgrad(dim3 grid, size_t lds, hipStream_t st, const float* small, const float* big,
+                        float* part, const BnGeom& g, const WgradTile& t) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_mfma<LGQ>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, WG_MAX_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_wgrad_mfma<LGQ>, grid, dim3(WG_THREADS), lds, st, small, big, part, g, t);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 BnFastPlan bn_fast_wgrad_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2) return p;
     if (g.Cs < 16 || g.Cb < 16) return p;
+    const BnFastPlan p4 = bn_wgrad4_plan(g);        // 16-byte DMA generation where it fits
+    if (p4.supported) return p4;
     WgradTile t;
     size_t lds = 0;
     if (!wgrad_tile(g, &t, &lds)) return p;
@@ -231,21 +268,26 @@ BnFastPlan bn_fast_wgrad_plan(const BnGeom& g) {
 
 int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float* big, float* dw,
                          const BnGeom& g, int accumulate, void* ws, hipStream_t st) {
+    if (plan.variant == 4) return bn_launch_wgrad4(plan, small, big, dw, g, accumulate, ws, st);
     WgradTile t;
     size_t lds = 0;
     if (!wgrad_tile(g, &t, &lds)) return BN_E_SHAPE;
     t.splits = plan.d;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_mfma,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, WG_MAX_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("BN_WGRAD_DBG"); dbg = e ? atoi(e) : 0; }
+    t.dbg = dbg;
     const int tiles = ((g.Cs + WG_TA - 1) / WG_TA) * ((g.Cb + WG_TB - 1) / WG_TB);
     dim3 grid(tiles, t.splits);
-    hipLaunchKernelGGL(k_wgrad_mfma, grid, dim3(WG_THREADS), lds, st, small, big, (float*)ws, g, t);
-    BN_LAUNCH_CHECK();
+    int rc = BN_E_SHAPE;
+    switch (t.lgQ) {
+        case 2: rc = launch_wgrad<2>(grid, lds, st, small, big, (float*)ws, g, t); break;
+        case 3: rc = launch_wgrad<3>(grid, lds, st, small, big, (float*)ws, g, t); break;
+        case 4: rc = launch_wgrad<4>(grid, lds, st, small, big, (float*)ws, g, t); break;
+        case 5: rc = launch_wgrad<5>(grid, lds, st, small, big, (float*)ws, g, t); break;
+        case 6: rc = launch_wgrad<6>(grid, lds, st, small, big, (float*)ws, g, t); break;
+        default: break;
+    }
+    if (rc) return rc;
     return bn_launch_sum_partials((const float*)ws, dw, 25 * g.Cs * g.Cb, t.splits, accumulate,
                                   g.Cs * g.Cb, 25, st);
 }

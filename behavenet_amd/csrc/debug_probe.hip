@@ -114,3 +114,72 @@ extern "C" int bn_debug_probe_lds_dma(const float* p, float* o, int n, void* str
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
+
+// ---------------------------------------------------------------------------------------------
+// MFMA + LDS-operand ceiling in the shapes the conv kernels use (no global traffic):
+//  mode 0: 32x32x2, 2x2 register blocking (2 A + 2 B ds_read_b32 per 4 MFMAs)   [k_down_mfma]
+//  mode 1: 16x16x4, 25 accumulators (1 A + 25 B ds_read_b32 per 25 MFMAs)        [k_wgrad_mfma]
+//  mode 2: as 0 but operands stay in registers (pure issue rate, data still random)
+// ---------------------------------------------------------------------------------------------
+typedef float floatx4p __attribute__((ext_vector_type(4)));
+__global__ void k_probe_mfma_lds(float* out, int iters, int mode) {
+    __shared__ float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x)
+        lds[i] = __sinf(0.37f * i + blockIdx.x) + 0.01f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float s = 0.f;
+    if (mode == 0 || mode == 2) {
+        floatx16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const float* ap = lds + wv * 128 + (lane & 31) + 66 * (lane >> 5);
+        const float* bp = lds + 4096 + (lane & 31) + 130 * (lane >> 5);
+        float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+        for (int it = 0; it < iters; ++it) {
+            if (mode == 0) {
+                const int o = (it & 15) * 132;
+                a0 = ap[o]; a1 = ap[o + 32]; b0 = bp[o]; b1 = bp[o + 32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    } else {
+        floatx4p acc[25];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) acc[t] = (floatx4p){0.f, 0.f, 0.f, 0.f};
+        const float* ap = lds + wv * 64 + (lane & 15) * 66 + (lane >> 4);
+        const float* bp = lds + 4096 + (lane & 15) * 34 + (lane >> 4);
+        for (int it = 0; it < iters; ++it) {
+            const int o = (it & 15) * 4;
+            const float av = ap[o];
+#pragma unroll
+            for (int t = 0; t < 25; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[o + 40 * (t / 5) + (t % 5)],
+                                                             acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 25; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// returns FLOP per workgroup-iteration through *flop_per_iter_per_wave
+extern "C" int bn_debug_probe_mfma_lds(float* out, int blocks, int threads, int iters, int mode,
+                                       void* stream) {
+    hipLaunchKernelGGL(k_probe_mfma_lds, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, out,
+                       iters, mode);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
