@@ -38,6 +38,7 @@ struct DownTile {
     int xl_floats;
     int c_per_split;     // channels of the reduction handled by one blockIdx.z
     int splits;
+    int dbg;             // BN_DOWN_DBG experiments (0 in production)
 };
 
 // Software pipeline: the global loads of chunk i+1 (input tile + weight slice) are issued into
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_down_mfma(
     issue_loads(c_beg);
     for (int c0 = c_beg; c0 < c_end; c0 += CC) {
         __syncthreads();   // the previous chunk's MFMA reads of LDS are complete
+        if (!(t.dbg & 1) || c0 == c_beg) {
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
             const bool cok = c0 + cc < c_end;
@@ -164,8 +166,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_down_mfma(
                 }
             }
         }
+        }
         __syncthreads();
-        if (c0 + CC < c_end) issue_loads(c0 + CC);   // in flight behind the MFMAs below
+        if (c0 + CC < c_end && !(t.dbg & 1)) issue_loads(c0 + CC);   // behind the MFMAs below
 
         // MFMA loop, one (channel pair, kernel row) = S taps per "row".  Operands are double
         // buffered by hand: the LDS reads of row i+1 are issued BEFORE the MFMAs of row i (the
@@ -355,6 +358,9 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
     int nwg = 0;
     if (!down_tile(g, MR, NR, CC, &t, &nwg)) return BN_E_SHAPE;
     t.splits = splits;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("BN_DOWN_DBG"); dbg = e ? atoi(e) : 0; }
+    t.dbg = dbg;
     if (splits > 1) {
         int cps = (g.Cb + splits - 1) / splits;
         cps = (cps + CC - 1) / CC * CC;

@@ -29,6 +29,7 @@ struct UpTile {
     int SWp, FS, CHS;             // LDS strides of the small tile (floats)
     int tiles_per_frame;
     int xl_floats;
+    int dbg;              // BN_UP_DBG experiments (0 in production)
 };
 
 template <int MR, int CC>
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
     issue_loads(0);
     for (int c0 = 0; c0 < g.Cs; c0 += CC) {
         __syncthreads();
+        if (!(t.dbg & 1) || c0 == 0) {
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
             const bool cok = c0 + cc < g.Cs;
@@ -118,8 +120,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
                 }
             }
         }
+        }
         __syncthreads();
-        if (c0 + CC < g.Cs) issue_loads(c0 + CC);
+        if (c0 + CC < g.Cs && !(t.dbg & 1)) issue_loads(c0 + CC);
 
 #pragma unroll 1
         for (int cp = 0; cp < CC / 2; ++cp) {
@@ -248,6 +251,9 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
     UpTile t;
     int nwg = 0;
     if (!up_tile(g, MR, CC, &t, &nwg)) return BN_E_SHAPE;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("BN_UP_DBG"); dbg = e ? atoi(e) : 0; }
+    t.dbg = dbg;
     const int groups = (g.N + t.F - 1) / t.F;
     dim3 grid(groups * t.tiles_per_frame, (g.Cb + 32 * MR - 1) / (32 * MR));
     const size_t lds = ((size_t)t.xl_floats + (size_t)CC * 25 * (32 * MR + 1)) * 4;
