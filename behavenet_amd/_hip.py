@@ -61,6 +61,8 @@ SIGNATURES = {
     'bn_kl_rows': (_c_int, [_c_void_p] * 3 + [_c_int, _c_int, _c_void_p]),
     'bn_reparam_bwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
     'bn_kl_bwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_float, _c_void_p, _c_void_p]),
+    'bn_decomposed_kl_fwd': (_c_int, [_c_void_p] * 7 + [_c_int, _c_int, _c_void_p]),
+    'bn_decomposed_kl_bwd': (_c_int, [_c_void_p] * 9 + [_c_int, _c_int, _c_void_p]),
     'bn_adam_amsgrad_step': (
         _c_int, [_c_void_p] * 5 + [_c_size_t] + [_c_float] * 5 + [_c_int, _c_void_p]),
     'bn_u8_to_unit_float': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_void_p]),
@@ -346,6 +348,30 @@ def kl_rows(mu, logvar):
     _check(load().bn_kl_rows(_ptr(mu, 'mu'), _ptr(logvar, 'logvar'), _ptr(out, 'kl_rows'), N, D,
                              _stream()), 'bn_kl_rows')
     return out
+
+
+def decomposed_kl_fwd(z, mu, logvar):
+    """-> (out3, log_qz, lse): the three KL terms and what the backward pass needs."""
+    N, D = z.shape
+    out3 = torch.empty((3,), dtype=torch.float32, device=z.device)
+    log_qz = torch.empty((N,), dtype=torch.float32, device=z.device)
+    lse = torch.empty((N, D), dtype=torch.float32, device=z.device)
+    terms = torch.empty((3 * N,), dtype=torch.float32, device=z.device)
+    _check(load().bn_decomposed_kl_fwd(
+        _ptr(z, 'z'), _ptr(mu, 'mu'), _ptr(logvar, 'logvar'), _ptr(out3, 'out3'),
+        _ptr(log_qz, 'log_qz'), _ptr(lse, 'lse'), _ptr(terms, 'terms'), N, D, _stream()),
+        'bn_decomposed_kl_fwd')
+    return out3, log_qz, lse
+
+
+def decomposed_kl_bwd(z, mu, logvar, log_qz, lse, g3):
+    N, D = z.shape
+    dz, dmu, dlogvar = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+    _check(load().bn_decomposed_kl_bwd(
+        _ptr(z, 'z'), _ptr(mu, 'mu'), _ptr(logvar, 'logvar'), _ptr(log_qz, 'log_qz'),
+        _ptr(lse, 'lse'), _ptr(g3, 'g3'), _ptr(dz, 'dz'), _ptr(dmu, 'dmu'),
+        _ptr(dlogvar, 'dlogvar'), N, D, _stream()), 'bn_decomposed_kl_bwd')
+    return dz, dmu, dlogvar
 
 
 def reparam_bwd(dz, z, mu):

@@ -65,3 +65,10 @@ int bn_launch_bn_act_bwd(const float* x, const float* y, const float* dy, const 
                          const float* invstd, const float* gamma, float* dx, float* dgamma,
                          float* dbeta, int accumulate, int batch_stats, int N, int C, int HW,
                          int act, float slope, void* ws, hipStream_t st);
+
+// decomposed_kl.hip
+int bn_launch_dkl_fwd(const float* z, const float* mu, const float* lv, float* out3,
+                      float* log_qz, float* lse, float* terms, int N, int D, hipStream_t st);
+int bn_launch_dkl_bwd(const float* z, const float* mu, const float* lv, const float* log_qz,
+                      const float* lse, const float* g3, float* dz, float* dmu, float* dlv, int N,
+                      int D, hipStream_t st);

@@ -496,6 +496,25 @@ extern "C" int bn_kl_bwd(const float* mu, const float* logvar, float* dmu, float
     return bn_launch_kl_bwd(mu, logvar, dmu, dlogvar, n, scale, gscale, (hipStream_t)stream);
 }
 
+extern "C" int bn_decomposed_kl_fwd(const float* z, const float* mu, const float* logvar,
+                                    float* out3, float* log_qz, float* lse, float* terms, int N,
+                                    int D, bn_stream_t stream) {
+    if (!z || !mu || !logvar || !out3 || !log_qz || !lse || !terms || N <= 0 || D <= 0)
+        return BN_E_BADARG;
+    return bn_launch_dkl_fwd(z, mu, logvar, out3, log_qz, lse, terms, N, D, (hipStream_t)stream);
+}
+
+extern "C" int bn_decomposed_kl_bwd(const float* z, const float* mu, const float* logvar,
+                                    const float* log_qz, const float* lse, const float* g3,
+                                    float* dz, float* dmu, float* dlogvar, int N, int D,
+                                    bn_stream_t stream) {
+    if (!z || !mu || !logvar || !log_qz || !lse || !g3 || !dz || !dmu || !dlogvar || N <= 0 ||
+        D <= 0)
+        return BN_E_BADARG;
+    return bn_launch_dkl_bwd(z, mu, logvar, log_qz, lse, g3, dz, dmu, dlogvar, N, D,
+                             (hipStream_t)stream);
+}
+
 extern "C" int bn_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vmax,
                                     size_t n, float lr, float beta1, float beta2, float eps,
                                     float weight_decay, int step, bn_stream_t stream) {

@@ -50,56 +50,29 @@ def kl_div_to_std_normal(mu, logvar):
 
 
 # ------------------------------------------------------------------------------------------
-# beta-TC decomposition (ref :150-372).  N <= 200 frames x D <= 64 dims: the (N, N, D) pairwise
-# tensor is < 10 MB, launch-latency bound; expressed with device tensor ops (torch glue) until
-# the dedicated single-workgroup kernel lands (SURVEY.md section 2.1 "decomposed_kl").
+# beta-TC decomposition (ref :150-372): one HIP kernel pair (csrc/decomposed_kl.hip) evaluates the
+# three terms -- and their gradients -- from the (N, D) inputs; the reference's (N, N, D) pairwise
+# tensor and its autograd graph are never materialised.
 # ------------------------------------------------------------------------------------------
-def _gaussian_log_density_unsummed(z, mu, logvar):
-    return -0.5 * (torch.exp(-logvar) * (z - mu) ** 2 + logvar + LN2PI)
-
-
-def _gaussian_log_density_unsummed_std_normal(z):
-    return -0.5 * (z ** 2 + LN2PI)
-
-
-def _pairwise_log_q(z, mu, logvar):
-    # [j, i, l] = log q(z(x_j)_l | x_i)
-    return _gaussian_log_density_unsummed(z[:, None], mu[None, :], logvar[None, :])
+def decomposed_kl(z, mu, logvar):
+    """(index-code MI, total correlation, dimension-wise KL) batch estimates (ref :284-351)."""
+    t = hf.decomposed_kl_terms(z, mu, logvar)
+    return t[0], t[1], t[2]
 
 
 def index_code_mi(z, mu, logvar):
-    lq = _pairwise_log_q(z, mu, logvar)
-    joint = lq.sum(dim=2)
-    log_qz = torch.logsumexp(joint, dim=1)
-    log_qz_cond = torch.diag(joint)
-    return torch.mean(log_qz_cond - log_qz)
+    """ref :150-192"""
+    return decomposed_kl(z, mu, logvar)[0]
 
 
 def total_correlation(z, mu, logvar):
-    lq = _pairwise_log_q(z, mu, logvar)
-    log_qz_product = torch.logsumexp(lq, dim=1).sum(dim=1)
-    log_qz = torch.logsumexp(lq.sum(dim=2), dim=1)
-    return torch.mean(log_qz - log_qz_product)
+    """ref :195-240"""
+    return decomposed_kl(z, mu, logvar)[1]
 
 
 def dimension_wise_kl_to_std_normal(z, mu, logvar):
-    lq = _pairwise_log_q(z, mu, logvar)
-    log_qz_product = torch.logsumexp(lq, dim=1).sum(dim=1)
-    log_pz_product = _gaussian_log_density_unsummed_std_normal(z).sum(dim=1)
-    return torch.mean(log_qz_product - log_pz_product)
-
-
-def decomposed_kl(z, mu, logvar):
-    """(index-code MI, total correlation, dimension-wise KL) batch estimates (ref :284-351)."""
-    lq = _pairwise_log_q(z, mu, logvar)
-    joint = lq.sum(dim=2)
-    log_qz = torch.logsumexp(joint, dim=1)
-    log_qz_cond = torch.diag(joint)
-    log_qz_product = torch.logsumexp(lq, dim=1).sum(dim=1)
-    log_pz_product = _gaussian_log_density_unsummed_std_normal(z).sum(dim=1)
-    return (torch.mean(log_qz_cond - log_qz),
-            torch.mean(log_qz - log_qz_product),
-            torch.mean(log_qz_product - log_pz_product))
+    """ref :243-281"""
+    return decomposed_kl(z, mu, logvar)[2]
 
 
 def subspace_overlap(A, B, C=None):

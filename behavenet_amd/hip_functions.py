@@ -556,5 +556,26 @@ class KLFn(torch.autograd.Function):
         return dmu, dlogvar
 
 
+class DecomposedKLFn(torch.autograd.Function):
+    """(MI, TC, DWKL) of losses.py:284-351 as one (3,) tensor; N x N x D never materialised."""
+
+    @staticmethod
+    def forward(ctx, z, mu, logvar):
+        z, mu, logvar = z.contiguous(), mu.contiguous(), logvar.contiguous()
+        out3, log_qz, lse = _hip.decomposed_kl_fwd(z, mu, logvar)
+        ctx.save_for_backward(z, mu, logvar, log_qz, lse)
+        return out3
+
+    @staticmethod
+    def backward(ctx, g3):
+        z, mu, logvar, log_qz, lse = ctx.saved_tensors
+        dz, dmu, dlogvar = _hip.decomposed_kl_bwd(z, mu, logvar, log_qz, lse, g3.contiguous())
+        return dz, dmu, dlogvar
+
+
+def decomposed_kl_terms(z, mu, logvar):
+    return DecomposedKLFn.apply(z, mu, logvar)
+
+
 def kl_to_std_normal(mu, logvar):
     return KLFn.apply(mu, logvar)

@@ -191,6 +191,18 @@ int bn_reparam_bwd(const float* dz, const float* z, const float* mu, float* dlog
 int bn_kl_bwd(const float* mu, const float* logvar, float* dmu, float* dlogvar, size_t n,
               float scale, const float* gscale, bn_stream_t stream);
 
+/* Decomposed KL of the beta-TC-VAE / PS-VAE (replaces losses.decomposed_kl, losses.py:284-351,
+ * and its autograd graph).  z, mu, logvar: (N, D) fp32, D <= 32.
+ *   fwd: out3 = (index-code MI, total correlation, dimension-wise KL); log_qz (N) and lse (N, D)
+ *        are saved for the backward pass; terms is 3N floats of scratch.
+ *   bwd: g3 = the three upstream gradients (device); dz, dmu, dlogvar: (N, D). */
+int bn_decomposed_kl_fwd(const float* z, const float* mu, const float* logvar, float* out3,
+                         float* log_qz, float* lse, float* terms, int N, int D,
+                         bn_stream_t stream);
+int bn_decomposed_kl_bwd(const float* z, const float* mu, const float* logvar,
+                         const float* log_qz, const float* lse, const float* g3, float* dz,
+                         float* dmu, float* dlogvar, int N, int D, bn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser (replaces torch.optim.Adam(amsgrad=True).step, training.py:284-286,352), over one
  * flat fp32 parameter arena.  `step` is 1-based.  weight_decay adds wd*p to the gradient.

@@ -351,6 +351,32 @@ def test_reparam_and_kl():
     close(dlv, lv.grad, name='kl dlogvar')
 
 
+@pytest.mark.parametrize('N,D', [(200, 12), (56, 12), (7, 3), (200, 32), (1, 4), (300, 16)])
+def test_decomposed_kl(N, D):
+    """bn_decomposed_kl_fwd/bwd against the oracle's (N, N, D) formulation (losses.py:284-351),
+    values and all three input gradients, for arbitrary upstream weights of the three terms."""
+    from oracle import ref_cpu
+    from behavenet_amd.hip_functions import decomposed_kl_terms
+    g = torch.Generator().manual_seed(N * 100 + D)
+    z = torch.randn((N, D), generator=g)
+    mu = torch.randn((N, D), generator=g) * 0.7
+    lv = torch.randn((N, D), generator=g) * 0.5 - 0.3
+    wts = torch.tensor([1.3, -0.4, 2.1])
+    res = {}
+    for key, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        zi, mi, li = (t.detach().clone().to(dt).requires_grad_(True) for t in (z, mu, lv))
+        terms = torch.stack(ref_cpu.decomposed_kl(zi, mi, li))
+        (terms * wts.to(dt)).sum().backward()
+        res[key] = (terms.detach(), zi.grad, mi.grad, li.grad)
+    zh, mh, lh = (t.detach().clone().to(DEV).requires_grad_(True) for t in (z, mu, lv))
+    th = decomposed_kl_terms(zh, mh, lh)
+    (th * wts.to(DEV)).sum().backward()
+    close(th, res['f32'][0], res['f64'][0], name='dkl terms')
+    close(zh.grad, res['f32'][1], res['f64'][1], name='dkl dz')
+    close(mh.grad, res['f32'][2], res['f64'][2], name='dkl dmu')
+    close(lh.grad, res['f32'][3], res['f64'][3], name='dkl dlogvar')
+
+
 @pytest.mark.parametrize('wd', [0.0, 0.01])
 def test_adam_amsgrad_trajectory(wd):
     g = torch.Generator().manual_seed(6)
