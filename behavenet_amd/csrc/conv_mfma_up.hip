@@ -42,8 +42,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
     float* wl = smem + t.xl_floats;
     constexpr int RS = 25;
     constexpr int TM = 32 * MR;
-    constexpr int TMP = TM + 1;
-    constexpr int WPASS = (TM * RS + 64 * 4 - 1) / (64 * 4);   // 64-lane passes per wave per channel
+    // Weight slice of a chunk: for each of the CC channels the TM*25 floats W[c][m0..m0+TM)[tap]
+    // are contiguous in global memory and 16-byte aligned (Cb, m0 multiples of 4); they are
+    // copied AS THEY ARE into LDS by buffer_load_dwordx4 ... lds (no registers, no transpose:
+    // a lane's A operand is word m*25 + tap, and a stride of 25 words over 32 lanes touches
+    // every bank exactly once).  Double buffered: chunk i+1 lands behind chunk i's MFMAs.
+    constexpr int WCH = TM * RS;                        // floats per channel
+    constexpr int WGRP = CC * WCH / 4;                  // 16-byte groups per chunk
+    constexpr int WDMA = (WGRP + MF_THREADS - 1) / MF_THREADS;
+    constexpr int WBUF = ((WDMA * MF_THREADS * 4) + 3) & ~3;   // floats per buffer (whole waves)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
@@ -84,50 +91,48 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
             for (int e = 0; e < 16; ++e) acc[mr][cl][e] = 0.f;
 
     float xr[CC];
-    float wr[CC][WPASS];
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)w, 0, (int)((size_t)g.Cs * g.Cb * RS * 4), 0x00020000);
 
-    auto issue_loads = [&](int c0) {
+    auto issue_loads = [&](int c0, int buf) {
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
             const int c = min(c0 + cc, g.Cs - 1);
             xr[cc] = small[((size_t)n0 * g.Cs + c) * HWs + max(ioff, 0)];
-            // weight rows W[c][m0 .. m0+TM)[tap]: TM*RS contiguous floats per channel
-            const float* wp = w + ((size_t)c * g.Cb + m0) * RS;
+        }
+        // group e = tid + 256 k of the chunk image [cc][m][tap]; a channel past Cs (or a row
+        // past the weight tensor) is out of range and reads 0.0f
 #pragma unroll
-            for (int ps = 0; ps < WPASS; ++ps) {
-                const int e2 = lane + 64 * (wv + 4 * ps);
-                const bool ok = (e2 < TM * RS) && (m0 + e2 / RS < g.Cb);
-                wr[cc][ps] = wp[ok ? e2 : 0];
-            }
+        for (int k = 0; k < WDMA; ++k) {
+            const int e = tid + MF_THREADS * k;
+            const int cc = e / (WCH / 4);
+            const int within = e - cc * (WCH / 4);
+            const bool ok = (e < WGRP) && (c0 + cc < g.Cs);
+            const int off = (((c0 + cc) * g.Cb + m0) * RS + 4 * within) * 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs_w, wl + buf * WBUF + 4 * (MF_THREADS * k + 64 * wv), 16, ok ? off : 0x7fffffff,
+                0, 0, 0);
         }
     };
 
-    issue_loads(0);
+    int cur = 0;
+    issue_loads(0, 0);
     for (int c0 = 0; c0 < g.Cs; c0 += CC) {
-        __syncthreads();
-        if (!(t.dbg & 1) || c0 == 0) {
+        __syncthreads();   // the previous chunk's MFMA reads of xl are complete
 #pragma unroll
         for (int cc = 0; cc < CC; ++cc) {
             const bool cok = c0 + cc < g.Cs;
             if (ioff != -2) xl[cc * t.CHS + tid] = (cok && ioff >= 0) ? xr[cc] : 0.f;
-#pragma unroll
-            for (int ps = 0; ps < WPASS; ++ps) {
-                const int e2 = lane + 64 * (wv + 4 * ps);
-                if (e2 < TM * RS) {
-                    const int m = e2 / RS, tap = e2 - m * RS;
-                    const bool ok = cok && (m0 + m < g.Cb);
-                    wl[(cc * RS + tap) * TMP + m] = ok ? wr[cc][ps] : 0.f;
-                }
-            }
         }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own weight DMA of this chunk landed
         __syncthreads();
-        if (c0 + CC < g.Cs && !(t.dbg & 1)) issue_loads(c0 + CC);
+        if (c0 + CC < g.Cs) issue_loads(c0 + CC, cur ^ 1);
+        const float* wcur = wl + cur * WBUF;
 
 #pragma unroll 1
         for (int cp = 0; cp < CC / 2; ++cp) {
             const float* xb = xl + (2 * cp) * t.CHS + base;
-            const float* wa = wl + ((2 * cp + kk) * RS) * TMP + li;
+            const float* wa = wcur + ((2 * cp + kk) * TM + li) * RS;
             float bv[3][3];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
                             const int dx = ((sig + 1) >> 1) - v + 1;
 #pragma unroll
                             for (int mr = 0; mr < MR; ++mr) {
-                                const float av = wa[(r * 5 + s) * TMP + mr * 32];
+                                const float av = wa[mr * 32 * RS + r * 5 + s];
                                 acc[mr][rho * 2 + sig] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                                     av, bv[dy][dx], acc[mr][rho * 2 + sig], 0, 0, 0);
                             }
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
                 }
             }
         }
+        cur ^= 1;
     }
 
     // ---- epilogue: lane owns output pixels (2a+rho, 2b+sig) of channel m(e, kk); the two
@@ -192,6 +198,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
     }
 }
 
+// xl + two weight buffers of whole-wave DMA rows (see WBUF in the kernel)
+static size_t up_lds_bytes(int xl_floats, int MR, int CC) {
+    const int wgrp = CC * 32 * MR * 25 / 4;
+    const int wdma = (wgrp + MF_THREADS - 1) / MF_THREADS;
+    return ((size_t)xl_floats + 2 * (size_t)wdma * MF_THREADS * 4) * 4;
+}
+
 static bool up_tile(const BnGeom& g, int MR, int CC, UpTile* t, int* n_wg) {
     const int TP = 128;   // positions per workgroup
     const int lgW = ilog2_exact_up(g.Ws), lgH = ilog2_exact_up(g.Hs);
@@ -214,8 +227,10 @@ static bool up_tile(const BnGeom& g, int MR, int CC, UpTile* t, int* n_wg) {
     if (t->CHS > MF_THREADS) return false;          // one tile element per thread
     t->tiles_per_frame = (t->F == 1) ? g.Hs / t->AT_H : 1;
     t->xl_floats = (CC * t->CHS + 3) & ~3;
-    const size_t lds = ((size_t)t->xl_floats + (size_t)CC * 25 * (32 * MR + 1)) * 4;
+    const size_t lds = up_lds_bytes(t->xl_floats, MR, CC);
     if (lds > MF_MAX_LDS) return false;
+    if ((g.Cb & 3) != 0) return false;               // 16-byte aligned weight rows for the DMA
+    if ((size_t)g.Cs * g.Cb * 25 * 4 >= 0x7fffffffull) return false;
     const int groups = (g.N + t->F - 1) / t->F;
     *n_wg = groups * t->tiles_per_frame * ((g.Cb + 32 * MR - 1) / (32 * MR));
     return true;
@@ -256,7 +271,7 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
     t.dbg = dbg;
     const int groups = (g.N + t.F - 1) / t.F;
     dim3 grid(groups * t.tiles_per_frame, (g.Cb + 32 * MR - 1) / (32 * MR));
-    const size_t lds = ((size_t)t.xl_floats + (size_t)CC * 25 * (32 * MR + 1)) * 4;
+    const size_t lds = up_lds_bytes(t.xl_floats, MR, CC);
     if (MR == 2 && CC == 8) {
         hipLaunchKernelGGL((k_up_mfma<2, 8>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                            dact_src, g, t, act, dact, slope);
