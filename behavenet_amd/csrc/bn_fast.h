@@ -22,14 +22,18 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
 int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w,
                       const float* bias, float* out, const float* dact_src, const BnGeom& g,
                       int act, int dact, float slope, void* ws, hipStream_t st);
+// db / bias_side (1: sum `small` per a-channel, 2: sum `big` per b-channel) / bias_done: the
+// kernel may produce the bias gradient as a by-product; *bias_done tells whether it did
 int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float* big, float* dw,
-                         const BnGeom& g, int accumulate, void* ws, hipStream_t st);
+                         const BnGeom& g, int accumulate, void* ws, hipStream_t st,
+                         float* db = nullptr, int bias_side = 0, bool* bias_done = nullptr);
 
 // conv_mfma_wgrad4.hip: 16-byte-DMA generation of the stride-2 weight gradient (tried first by
 // bn_fast_wgrad_plan; plan.variant == 4)
 BnFastPlan bn_wgrad4_plan(const BnGeom& g);
 int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* big, float* dw,
-                     const BnGeom& g, int accumulate, void* ws, hipStream_t st);
+                     const BnGeom& g, int accumulate, void* ws, hipStream_t st, float* db,
+                     int bias_side, bool* bias_done);
 
 // conv_s5.hip: stride == kernel size (non-overlapping windows), direct-from-global MFMA GEMMs
 BnFastPlan bn_s5_up_plan(const BnGeom& g);

@@ -219,7 +219,8 @@ static int run_up(int family, const float* small, const float* w, const float* b
 }
 
 static int run_wgrad(int family, const float* small, const float* big, float* dw,
-                     const BnGeom& g, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                     const BnGeom& g, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+                     float* db, int bias_side, bool* bias_done) {
     if (!force_generic()) {
         const BnFastPlan s5 = bn_s5_wgrad_plan(g);
         if (s5.supported) {
@@ -241,7 +242,8 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
                      st);
     if (plan.supported) {
         if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
-        return bn_launch_wgrad_fast(plan, small, big, dw, g, accumulate, ws, st);
+        return bn_launch_wgrad_fast(plan, small, big, dw, g, accumulate, ws, st, db, bias_side,
+                                    bias_done);
     }
     return bn_launch_wgrad_generic(small, big, dw, g, accumulate, st);
 }
@@ -305,9 +307,12 @@ extern "C" int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
     const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    int rc = run_wgrad(BN_PROF_CONV_BWD_W, dy, x, dw, g, accumulate, ws, ws_bytes, st);
+    bool bias_done = false;   // the MFMA kernel sums dy (its `small` operand) on the way
+    int rc = run_wgrad(BN_PROF_CONV_BWD_W, dy, x, dw, g, accumulate, ws, ws_bytes, st, db, 1,
+                       &bias_done);
     if (rc) return rc;
-    if (db) rc = bn_launch_channel_sum(dy, db, N, K, P * Q, accumulate, ws, ws_bytes, st);
+    if (db && !bias_done)
+        rc = bn_launch_channel_sum(dy, db, N, K, P * Q, accumulate, ws, ws_bytes, st);
     return rc;
 }
 
@@ -342,9 +347,12 @@ extern "C" int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw,
     const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    int rc = run_wgrad(BN_PROF_CONVT_BWD_W, x, dy, dw, g, accumulate, ws, ws_bytes, st);
+    bool bias_done = false;   // here dy is the kernel's `big` operand
+    int rc = run_wgrad(BN_PROF_CONVT_BWD_W, x, dy, dw, g, accumulate, ws, ws_bytes, st, db, 2,
+                       &bias_done);
     if (rc) return rc;
-    if (db) rc = bn_launch_channel_sum(dy, db, N, Co, Ho * Wo, accumulate, ws, ws_bytes, st);
+    if (db && !bias_done)
+        rc = bn_launch_channel_sum(dy, db, N, Co, Ho * Wo, accumulate, ws, ws_bytes, st);
     return rc;
 }
 

@@ -267,8 +267,11 @@ BnFastPlan bn_fast_wgrad_plan(const BnGeom& g) {
 }
 
 int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float* big, float* dw,
-                         const BnGeom& g, int accumulate, void* ws, hipStream_t st) {
-    if (plan.variant == 4) return bn_launch_wgrad4(plan, small, big, dw, g, accumulate, ws, st);
+                         const BnGeom& g, int accumulate, void* ws, hipStream_t st, float* db,
+                         int bias_side, bool* bias_done) {
+    if (plan.variant == 4)
+        return bn_launch_wgrad4(plan, small, big, dw, g, accumulate, ws, st, db, bias_side,
+                                bias_done);
     WgradTile t;
     size_t lds = 0;
     if (!wgrad_tile(g, &t, &lds)) return BN_E_SHAPE;

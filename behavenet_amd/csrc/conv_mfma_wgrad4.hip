@@ -52,12 +52,15 @@ struct Wgrad4Tile {
     float inv_gpb, inv_c4, inv_ih; // reciprocals for the group decode
     int splits;                    // reduction splits (gridDim.y)
     int buf_floats;                // one LDS stage image
+    int bias_side;                 // fused bias gradient: 0 none, 1 sum of `small` per a-channel
+                                   // (Conv2d), 2 sum of `big` per b-channel (ConvTranspose2d)
+    int nbias;                     // channels of that side (stride of the partial bias rows)
 };
 
 template <int LGQ>
 __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
-    BnGeom g, Wgrad4Tile t) {
+    float* __restrict__ bias_part, BnGeom g, Wgrad4Tile t) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int Q = 1 << LGQ, RW = 2 * Q + 8, C4 = RW / 4;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -74,6 +77,10 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
     floatx4 acc[25];
 #pragma unroll
     for (int tp = 0; tp < 25; ++tp) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    // fused bias gradient: the operand values pass through this lane's registers anyway.
+    // side 1: every small pixel is the A operand of exactly one k-step; side 2: the taps
+    // (r,s) in {1,2}^2 of all small pixels tile the big image (2p+r-1, 2q+s-1) exactly once.
+    float bsum = 0.f;
 
     const __amdgpu_buffer_rsrc_t rs_small = __builtin_amdgcn_make_buffer_rsrc(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
                 const int rem = pix & ((1 << t.lgPTQ) - 1);
                 const int pj = rem >> LGQ, qj = rem & (Q - 1);
                 const float av = ap[(ks ^ lj) << 2];
+                if (t.bias_side == 1) bsum += av;
                 // columns (2q-2, 2q-1 | 2q, 2q+1 | 2q+2, 2q+3) of patch row 2p + r
                 const float* bq = bp + f * t.FSb + (2 * pj) * RW + 2 * qj;
 #pragma unroll
@@ -154,6 +162,7 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
                     const floatx2 c0 = *reinterpret_cast<const floatx2*>(bq + r * RW);
                     const floatx2 c1 = *reinterpret_cast<const floatx2*>(bq + r * RW + 2);
                     const floatx2 c2 = *reinterpret_cast<const floatx2*>(bq + r * RW + 4);
+                    if (t.bias_side == 2 && (r == 1 || r == 2)) bsum += c1.x + c1.y;
                     acc[r * 5 + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, c0.y, acc[r * 5 + 0],
                                                                           0, 0, 0);
                     acc[r * 5 + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, c1.x, acc[r * 5 + 1],
@@ -168,6 +177,21 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
             }
         }
         cur ^= 1;
+    }
+
+    if (t.bias_side != 0) {
+        // lanes lj + 16 kk hold the four pixel phases of one channel: fixed-order butterfly
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        float* bdst = bias_part + (size_t)blockIdx.y * t.nbias;
+        if (t.bias_side == 1 && btile == 0 && bblk == 0 && kk == 0) {
+            const int a = a0 + ablk * 16 + lj;
+            if (a < g.Cs) bdst[a] = bsum;
+        }
+        if (t.bias_side == 2 && atile == 0 && ablk == 0 && kk == 0) {
+            const int bb = b0 + bblk * 16 + lj;
+            if (bb < g.Cb) bdst[bb] = bsum;
+        }
     }
 
     // partial tile -> scratch [split][tap][a][b]; lane holds D[i = 4*kk + e][j = lj]
@@ -245,14 +269,16 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     p.supported = true;
     p.variant = 4;
     p.d = wgrad4_splits(g, t);
-    p.ws_bytes = (size_t)p.d * 25 * g.Cs * g.Cb * sizeof(float);
+    // partial dW tiles + partial bias rows (either side) of every split
+    p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
     p.kernel_name = "k_wgrad4_mfma<s2>";
     return p;
 }
 
 template <int LGQ>
 static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* small,
-                         const float* big, float* part, const BnGeom& g, const Wgrad4Tile& t) {
+                         const float* big, float* part, float* bias_part, const BnGeom& g,
+                         const Wgrad4Tile& t) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4_mfma<LGQ>,
@@ -260,28 +286,42 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_wgrad4_mfma<LGQ>, grid, dim3(W4_THREADS), lds, st, small, big, part, g, t);
+    hipLaunchKernelGGL(k_wgrad4_mfma<LGQ>, grid, dim3(W4_THREADS), lds, st, small, big, part,
+                       bias_part, g, t);
     BN_LAUNCH_CHECK();
     return 0;
 }
 
 int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* big, float* dw,
-                     const BnGeom& g, int accumulate, void* ws, hipStream_t st) {
+                     const BnGeom& g, int accumulate, void* ws, hipStream_t st, float* db,
+                     int bias_side, bool* bias_done) {
     Wgrad4Tile t;
     size_t lds = 0;
     if (!wgrad4_tile(g, &t, &lds)) return BN_E_SHAPE;
     t.splits = plan.d;
+    // the taps {1,2}^2 cover the big image only if it is not larger than 2x the small one
+    const bool fuse = db && (bias_side == 1 || (bias_side == 2 && g.Hb <= 2 * g.Hs &&
+                                                g.Wb <= 2 * g.Ws));
+    t.bias_side = fuse ? bias_side : 0;
+    t.nbias = bias_side == 1 ? g.Cs : g.Cb;
+    float* bias_part = (float*)ws + (size_t)t.splits * 25 * g.Cs * g.Cb;
     const int tiles = ((g.Cs + W4_TA - 1) / W4_TA) * ((g.Cb + W4_TB - 1) / W4_TB);
     dim3 grid(tiles, t.splits);
     int rc = BN_E_SHAPE;
     switch (ilog2_exact_w4(g.Ws)) {
-        case 2: rc = launch_wgrad4<2>(grid, lds, st, small, big, (float*)ws, g, t); break;
-        case 3: rc = launch_wgrad4<3>(grid, lds, st, small, big, (float*)ws, g, t); break;
-        case 4: rc = launch_wgrad4<4>(grid, lds, st, small, big, (float*)ws, g, t); break;
-        case 5: rc = launch_wgrad4<5>(grid, lds, st, small, big, (float*)ws, g, t); break;
+        case 2: rc = launch_wgrad4<2>(grid, lds, st, small, big, (float*)ws, bias_part, g, t); break;
+        case 3: rc = launch_wgrad4<3>(grid, lds, st, small, big, (float*)ws, bias_part, g, t); break;
+        case 4: rc = launch_wgrad4<4>(grid, lds, st, small, big, (float*)ws, bias_part, g, t); break;
+        case 5: rc = launch_wgrad4<5>(grid, lds, st, small, big, (float*)ws, bias_part, g, t); break;
         default: break;
     }
     if (rc) return rc;
-    return bn_launch_sum_partials((const float*)ws, dw, 25 * g.Cs * g.Cb, t.splits, accumulate,
-                                  g.Cs * g.Cb, 25, st);
+    rc = bn_launch_sum_partials((const float*)ws, dw, 25 * g.Cs * g.Cb, t.splits, accumulate,
+                                g.Cs * g.Cb, 25, st);
+    if (rc) return rc;
+    if (fuse) {
+        rc = bn_launch_sum_partials(bias_part, db, t.nbias, t.splits, accumulate, 0, 0, st);
+        if (bias_done) *bias_done = true;
+    }
+    return rc;
 }
