@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void k_down_c1(
 #pragma unroll
             for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[qh][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[qh][e] = bz;   // a lane owns ONE channel: bias = init
             const float* ar = aq + (2 * pr) * DC_RW;
 #pragma unroll
             for (int t = 0; t < 13; ++t) {
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(64) void k_down_c1(
                 // lane holds, for channel li, pixels 32*qh + 8*grp + 4*kk + {0..3}
 #pragma unroll
                 for (int grp = 0; grp < 4; ++grp) {
-                    floatx4e v = {acc[qh][4 * grp] + bz, acc[qh][4 * grp + 1] + bz,
-                                  acc[qh][4 * grp + 2] + bz, acc[qh][4 * grp + 3] + bz};
+                    floatx4e v = {acc[qh][4 * grp], acc[qh][4 * grp + 1], acc[qh][4 * grp + 2],
+                                  acc[qh][4 * grp + 3]};
                     if (ACT == BN_ACT_LRELU) {
                         v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
                         v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);

@@ -266,11 +266,21 @@ def _fwd(layer, x, w, b):
     return _hip.convT2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE)
 
 
+def first_layer_forward(plan, x, params):
+    """Layer 1 of a stack for a whole batch, outside autograd (see ConvStackFn's `h1`)."""
+    return _fwd(plan[0], x.contiguous(), params[0].detach(), params[1].detach())
+
+
 class ConvStackFn(torch.autograd.Function):
-    """y = layer_L(...layer_1(x)); params = (w_1, b_1, ..., w_L, b_L)."""
+    """y = layer_L(...layer_1(x)); params = (w_1, b_1, ..., w_L, b_L).
+
+    ``h1`` (optional): the output of layer 1 for these frames, computed beforehand for the whole
+    batch in one launch -- the frames are independent, so a slice of it is bit-identical to what
+    this node would compute; the chunk then starts at layer 2 (backward is unchanged).
+    """
 
     @staticmethod
-    def forward(ctx, plan, x, *params):
+    def forward(ctx, plan, x, h1, *params):
         if x.shape[1:] != (plan[0].cin, plan[0].hin, plan[0].win):
             raise ValueError('conv stack expects input (N,%d,%d,%d), got %s' % (
                 plan[0].cin, plan[0].hin, plan[0].win, tuple(x.shape)))
@@ -278,7 +288,10 @@ class ConvStackFn(torch.autograd.Function):
         acts = [x]
         h = x
         for i, layer in enumerate(plan):
-            h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach())
+            if i == 0 and h1 is not None:
+                h = h1
+            else:
+                h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach())
             acts.append(h)
         ctx.plan = plan
         ctx.need_dx = x.requires_grad
@@ -307,8 +320,8 @@ class ConvStackFn(torch.autograd.Function):
             g = layer.geom(n)
             w = weights[i]
             x_in = acts[i]
-            need_w = ctx.needs_input_grad[2 + 2 * i]
-            need_b = ctx.needs_input_grad[3 + 2 * i]
+            need_w = ctx.needs_input_grad[3 + 2 * i]
+            need_b = ctx.needs_input_grad[4 + 2 * i]
             if need_w:
                 gw = _grad_buffer(ctx.param_refs[2 * i])
                 gb = _grad_buffer(ctx.param_refs[2 * i + 1]) if need_b else None
@@ -347,11 +360,11 @@ class ConvStackFn(torch.autograd.Function):
                 else:
                     dpre = _hip.convT2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
         dx = dpre if ctx.need_dx else None
-        return (None, dx) + tuple(grads)
+        return (None, dx, None) + tuple(grads)
 
 
-def conv_stack(plan, x, params):
-    return ConvStackFn.apply(plan, x, *params)
+def conv_stack(plan, x, params, h1=None):
+    return ConvStackFn.apply(plan, x, h1, *params)
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -428,12 +441,12 @@ def conv_stack_bn(plan, x, params, bn_modules):
             run_plan.append(layer)
             continue
         run_plan.append(layer.with_act(_hip.ACT_NONE))
-        h = ConvStackFn.apply(run_plan, h, *run_params)
+        h = ConvStackFn.apply(run_plan, h, None, *run_params)
         bn = bn_modules[i]
         h = BatchNormActFn.apply(h, bn.weight, bn.bias, bn, layer.act)
         run_plan, run_params = [], []
     if run_plan:
-        h = ConvStackFn.apply(run_plan, h, *run_params)
+        h = ConvStackFn.apply(run_plan, h, None, *run_params)
     return h
 
 

@@ -109,6 +109,7 @@ class VAE(AE):
         rbs, sizes, deferred = hf.ChunkScalars(), [], []
         keys = ['loss', 'loss_ll', 'loss_kl']
         self._reserve_pools(x)
+        self._prepare_first_layer(x, dataset)
         hf.begin_chunks(x.device)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
@@ -128,6 +129,7 @@ class VAE(AE):
             sizes.append(end - beg)
         # read-backs enqueued with the forwards, collected after the deferred backwards are queued
         vals = rbs.finish(deferred)
+        self._release_first_layer()
         out = {k: 0.0 for k in keys}
         out['loss_mse'] = 0.0
         n_dims = np.prod(x.shape[1:])
@@ -197,6 +199,7 @@ class BetaTCVAE(VAE):
         rbs, sizes, deferred = hf.ChunkScalars(), [], []
         keys = ['loss', 'loss_ll', 'loss_mi', 'loss_tc', 'loss_dwkl']
         self._reserve_pools(x)
+        self._prepare_first_layer(x, dataset)
         hf.begin_chunks(x.device)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
@@ -216,6 +219,7 @@ class BetaTCVAE(VAE):
                 deferred.append(loss)
             sizes.append(end - beg)
         vals = rbs.finish(deferred)
+        self._release_first_layer()
         out = {k: 0.0 for k in keys}
         out['loss_mse'] = 0.0
         n_dims = np.prod(x.shape[1:])
@@ -320,6 +324,7 @@ class PSVAE(AE):
         kl = self.kl_anneal_vals[self.curr_epoch]
 
         self._reserve_pools(x)
+        self._prepare_first_layer(x, dataset)
         rbs, sizes, y_hat_all, deferred = hf.ChunkScalars(), [], [], []
         keys = ['loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi', 'loss_zu_tc',
                 'loss_zu_dwkl', 'loss']
@@ -355,6 +360,7 @@ class PSVAE(AE):
         y_rb = hf.Readback(y)
         n_rb = hf.Readback(n) if n is not None else None
         vals = rbs.finish(deferred)
+        self._release_first_layer()
         y_hat_np, y_np = y_hat_rb.numpy(), y_rb.numpy()
         n_np = n_rb.numpy() if n_rb is not None else None
         order = ['loss', 'loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi',

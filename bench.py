@@ -215,7 +215,7 @@ def main():
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(achieved / HBM_PEAK_GBS, 4),
         'launches': conv0_n, 'avg_launch_us': round(conv0_ms * 1e3 / max(conv0_n, 1), 2),
-        'algorithmic_bytes_per_launch_avg': CONV0_BYTES_PER_FRAME * BATCH // 2,
+        'algorithmic_bytes_per_launch_avg': int(conv0_bytes // max(conv0_n, 1)),
         'traffic': traffic}
 
     out = {
