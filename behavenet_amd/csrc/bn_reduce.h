@@ -5,15 +5,17 @@
 #include "bn_common.h"
 
 // ab_elems > 0: part is laid out [z][tap][ab] and out is [ab][ntap] (weight-gradient layout)
+// row_len > 0: output element i goes to (i / row_len) * row_stride + i % row_len
 __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part,
                                                       float* __restrict__ out, int total,
                                                       int splits, int accumulate, int ab_elems,
-                                                      int ntap);
+                                                      int ntap, int row_len, int row_stride);
 
 static inline int bn_launch_sum_partials(const float* part, float* out, int total, int splits,
-                                         int accumulate, int ab_elems, int ntap, hipStream_t st) {
+                                         int accumulate, int ab_elems, int ntap, hipStream_t st,
+                                         int row_len = 0, int row_stride = 0) {
     hipLaunchKernelGGL(k_sum_partials, dim3((total + 63) / 64), dim3(256), 0, st, part, out, total,
-                       splits, accumulate, ab_elems, ntap);
+                       splits, accumulate, ab_elems, ntap, row_len, row_stride);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)big, 0, (int)((size_t)g.N * HWb * 4), 0x00020000);
+        (void*)big, 0, (int)((size_t)g.N * g.Cb * HWb * 4), 0x00020000);
+    const int bch = blockIdx.y;                     // big-side channel (Cb <= 4: 2-channel frames)
 
     floatx16 acc;
 #pragma unroll
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
             const int y = e / WC_RW, x = e - y * WC_RW;
             const int hb = 2 * p0 - g.pt + y, wb = x - g.pl;
             const bool ok = y < WC_IH && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
-            br[k] = ed_ld(rb, ok ? ((n * g.Hb + hb) * g.Wb + wb) * 4 : ED_OOB);
+            br[k] = ed_ld(rb, ok ? (((n * g.Cb + bch) * g.Hb + hb) * g.Wb + wb) * 4 : ED_OOB);
         }
     };
 
@@ -120,25 +121,28 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
             const float v = (red[e * 64 + lane] + red[(16 + e) * 64 + lane]) +
                             (red[(32 + e) * 64 + lane] + red[(48 + e) * 64 + lane]);
             const int a = (e & 3) + 8 * (e >> 2) + 4 * kk;
-            if (a < g.Cs) part[(size_t)blockIdx.x * (g.Cs * 25) + a * 25 + li] = v;
+            if (a < g.Cs)
+                part[((size_t)bch * gridDim.x + blockIdx.x) * (g.Cs * 25) + a * 25 + li] = v;
         }
     }
 }
 
 static int wgrad_c1_grid(const BnGeom& g) {
     const int n_stages = g.N * (g.Hs / WC_ROWS);
-    return n_stages < 768 ? n_stages : 768;     // 3 resident workgroups per CU
+    const int cap = 768 / (g.Cb > 0 ? g.Cb : 1);     // 3 resident workgroups per CU in total
+    return n_stages < cap ? n_stages : cap;
 }
 
 BnFastPlan bn_edge_wgrad_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
-    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb != 1) return p;
+    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb > 4) return p;
     if (g.Cs > 32 || g.Ws != WC_W || (g.Hs % WC_ROWS) != 0) return p;
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
     p.supported = true;
     p.d = wgrad_c1_grid(g);
-    p.ws_bytes = (size_t)p.d * g.Cs * 25 * sizeof(float);
+    p.ws_bytes = (size_t)g.Cb * p.d * g.Cs * 25 * sizeof(float);
     p.kernel_name = "k_wgrad_c1";
     return p;
 }
@@ -146,10 +150,17 @@ BnFastPlan bn_edge_wgrad_plan(const BnGeom& g) {
 int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float* big, float* dw,
                          const BnGeom& g, int accumulate, void* ws, hipStream_t st) {
     const int n_stages = g.N * (g.Hs / WC_ROWS);
-    hipLaunchKernelGGL(k_wgrad_c1, dim3(plan.d), dim3(ED_THREADS), 0, st, small, big, (float*)ws, g,
-                       n_stages, g.Hs / WC_ROWS);
+    hipLaunchKernelGGL(k_wgrad_c1, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
+                       (float*)ws, g, n_stages, g.Hs / WC_ROWS);
     BN_LAUNCH_CHECK();
-    return bn_launch_sum_partials((const float*)ws, dw, g.Cs * 25, plan.d, accumulate, 0, 0, st);
+    // per big-side channel b: partial rows [split][a][tap] -> dW[a][b][tap]
+    for (int b = 0; b < g.Cb; ++b) {
+        const int rc = bn_launch_sum_partials(
+            (const float*)ws + (size_t)b * plan.d * g.Cs * 25, dw + b * 25, g.Cs * 25, plan.d,
+            accumulate, 0, 0, st, 25, g.Cb * 25);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // =============================================================================================
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_up_c1(
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         const int c = 2 * t + kk;
-        av[t] = (li < 25 && c < g.Cs) ? w[c * 25 + li] : 0.f;
+        av[t] = (li < 25 && c < g.Cs) ? w[(c * g.Cb + blockIdx.y) * 25 + li] : 0.f;
     }
 
     for (int blk = wv; blk < UC_NBLK; blk += 4) {
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_up_c1(
 
     // phase 2: thread -> column pair b (w = 2b, 2b+1), wave -> row h_l = 4k + wv
     const int b = lane;
-    const float bs = bias ? bias[0] : 0.f;
+    const float bs = bias ? bias[blockIdx.y] : 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int hl = 4 * k + wv;                 // 0..15
@@ -439,13 +450,14 @@ __global__ __launch_bounds__(ED_THREADS) void k_up_c1(
         float2 v;
         v.x = bn_apply_act(o0 + bs, act, slope);
         v.y = bn_apply_act(o1 + bs, act, slope);
-        *reinterpret_cast<float2*>(out + ((size_t)n * g.Hb + h) * g.Wb + 2 * b) = v;
+        *reinterpret_cast<float2*>(
+            out + (((size_t)n * g.Cb + blockIdx.y) * g.Hb + h) * g.Wb + 2 * b) = v;
     }
 }
 
 BnFastPlan bn_edge_up_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_up_generic", 0, 0, 0, 0, 0, 0};
-    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb != 1 || g.pt != 1 || g.pl != 1) return p;
+    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb > 4 || g.pt != 1 || g.pl != 1) return p;
     if (g.Cs > 32 || g.Ws != UC_W || (g.Hs % UC_TH) != 0) return p;
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
@@ -463,8 +475,8 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_up_c1, dim3(g.N * (g.Hs / UC_TH)), dim3(ED_THREADS), UC_LDS, st, small, w,
-                       bias, out, g, act, slope);
+    hipLaunchKernelGGL(k_up_c1, dim3(g.N * (g.Hs / UC_TH), g.Cb), dim3(ED_THREADS), UC_LDS, st,
+                       small, w, bias, out, g, act, slope);
     BN_LAUNCH_CHECK();
     return 0;
 }

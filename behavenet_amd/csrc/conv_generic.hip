@@ -289,7 +289,7 @@ int bn_launch_channel_sum(const float* t, float* db, int N, int C, int npix, int
 __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part,
                                                       float* __restrict__ out, int total,
                                                       int splits, int accumulate, int ab_elems,
-                                                      int ntap) {
+                                                      int ntap, int row_len, int row_stride) {
     __shared__ float red[4][64];
     const int il = threadIdx.x & 63, zl = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + il;
@@ -312,6 +312,9 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ 
         if (ab_elems > 0) {
             const int tap = i / ab_elems;
             o = (size_t)(i - tap * ab_elems) * ntap + tap;
+        } else if (row_len > 0) {
+            const int row = i / row_len;
+            o = (size_t)row * row_stride + (i - row * row_len);
         }
         out[o] = accumulate ? out[o] + v : v;
     }
