@@ -42,7 +42,7 @@ class accumulate_into_param_grads(object):
         return False
 
 
-def backward_chunks(chunk_losses):
+def backward_chunks(chunk_losses, streams=None):
     """Run the per-chunk backward passes, in chunk order, after ALL chunk forwards.
 
     The reference interleaves forward and backward per chunk (aes.py:748-769); the parameters do
@@ -52,8 +52,16 @@ def backward_chunks(chunk_losses):
     gradients.
     """
     with accumulate_into_param_grads():
-        for loss in chunk_losses:
-            loss.backward()
+        for i, loss in enumerate(chunk_losses):
+            # called from the chunk's own stream: autograd orders the graph's streams after the
+            # CALLING stream, so a backward() issued from the main stream would make the auxiliary
+            # pipeline wait for everything the previous chunk queued there
+            stream = streams[i] if streams is not None and i < len(streams) else None
+            if stream is not None:
+                with torch.cuda.stream(stream):
+                    loss.backward()
+            else:
+                loss.backward()
 
 
 class Readback(object):
@@ -186,7 +194,10 @@ class ChunkScalars(object):
         for stream, t in self._items:
             with torch.cuda.stream(stream):
                 rbs.append(Readback(t))
-        backward_chunks(chunk_losses)
+        # chunk c's backward is issued from chunk c's stream (only when every chunk has one,
+        # i.e. gradients were requested for all of them)
+        streams = [s for s, _ in self._items] if len(chunk_losses) == len(self._items) else None
+        backward_chunks(chunk_losses, streams)
         join_chunk_streams()
         join_side_streams()
         return np.stack([r.numpy() for r in rbs]).astype(np.float64)
