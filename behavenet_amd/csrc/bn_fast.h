@@ -28,6 +28,13 @@ int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float
                          const BnGeom& g, int accumulate, void* ws, hipStream_t st,
                          float* db = nullptr, int bias_side = 0, bool* bias_done = nullptr);
 
+// conv_mfma_down2.hip: 16-byte-DMA generation of the stride-2 gather-down kernel (chosen by
+// bn_fast_down_plan when the geometry fits and no split-K is needed; plan.variant == 2)
+bool bn_down2_supported(const BnGeom& g, int MR, int NR);
+int bn_launch_down2(int MR, int NR, const float* big, const float* w, const float* bias,
+                    float* out, const float* dact_src, const BnGeom& g, int act, int dact,
+                    float slope, hipStream_t st);
+
 // conv_mfma_wgrad4.hip: 16-byte-DMA generation of the stride-2 weight gradient (tried first by
 // bn_fast_wgrad_plan; plan.variant == 4)
 BnFastPlan bn_wgrad4_plan(const BnGeom& g);

@@ -336,6 +336,10 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     p.d = splits;
     p.ws_bytes = splits > 1 ? (size_t)splits * g.N * g.Cs * g.Hs * g.Ws * sizeof(float) : 0;
     p.kernel_name = g.stride == 2 ? "k_down_mfma<s2>" : "k_down_mfma<s5>";
+    if (g.stride == 2 && splits == 1 && CC == 4 && bn_down2_supported(g, p.a, p.b)) {
+        p.variant = 2;
+        p.kernel_name = "k_down2_mfma<s2>";
+    }
     return p;
 }
 
@@ -354,6 +358,8 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
                         const float* bias, float* out, const float* dact_src, const BnGeom& g,
                         int act, int dact, float slope, void* ws, hipStream_t st) {
     const int MR = plan.a, NR = plan.b, CC = plan.c, splits = plan.d;
+    if (plan.variant == 2)
+        return bn_launch_down2(MR, NR, big, w, bias, out, dact_src, g, act, dact, slope, st);
     DownTile t;
     int nwg = 0;
     if (!down_tile(g, MR, NR, CC, &t, &nwg)) return BN_E_SHAPE;
