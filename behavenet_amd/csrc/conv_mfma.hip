@@ -296,18 +296,22 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     if (g.Cb < 2) return p;            // single-channel inputs: conv_edge.hip
     if (g.Cs < 16) return p;
     const int CC = (g.stride == 5) ? 2 : 4;
-    static const int cand[3][2] = {{2, 2}, {2, 1}, {1, 1}};
+    // stride 2: 64 ch x 128 px tiles whenever they give ~100 workgroups -- measured in situ
+    // (bench.py, other streams' kernels fill the machine) they beat both the larger 64x256 tiles
+    // and the 32x128 tiles with more workgroups; stride 5: as many workgroups as possible
+    static const int cand[3][2] = {{2, 1}, {2, 2}, {1, 1}};
+    const int want = 96;
     int best = -1, best_wg = 0;
     DownTile t;
     for (int i = 0; i < 3; ++i) {
         if (cand[i][0] == 2 && g.Cs < 64) continue;
         int nwg = 0;
         if (!down_tile(g, cand[i][0], cand[i][1], CC, &t, &nwg)) continue;
-        if (best < 0 || (best_wg < 384 && nwg > best_wg)) {
+        if (best < 0 || (best_wg < want && nwg > best_wg)) {
             best = i;
             best_wg = nwg;
         }
-        if (best_wg >= 384) break;
+        if (best_wg >= want) break;
     }
     // tuning hook (tools/kbench.py): BN_DOWN_TILE=<candidate index 0..2> pins the tile shape
     if (const char* e = getenv("BN_DOWN_TILE")) {
