@@ -329,8 +329,10 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     p.b = cand[best][1];
     p.c = CC;
     // split the reduction over channels when the grid cannot fill the chip
+    // (stride 2: the second-generation kernel without split is preferred down to ~100
+    // workgroups -- the other chunk's and the weight-gradient stream's kernels fill the machine)
     int splits = 1;
-    if (best_wg < 384) {
+    if (best_wg < (g.stride == 2 ? want : 384)) {
         const int max_splits = g.Cb / (4 * CC) > 0 ? g.Cb / (4 * CC) : 1;
         splits = (512 + best_wg - 1) / best_wg;
         if (splits > max_splits) splits = max_splits;
