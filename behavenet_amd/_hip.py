@@ -50,10 +50,11 @@ SIGNATURES = {
     'bn_batchnorm_act_bwd': (
         _c_int, [_c_void_p] * 9 + [_c_int] * 6 + [_c_float, _c_void_p, _c_size_t, _c_void_p]),
     'bn_act_bwd': (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_int, _c_float, _c_void_p]),
-    'bn_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p]),
+    'bn_linear_ws_bytes': (_c_size_t, [_c_int] * 3),
+    'bn_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
     'bn_linear_bwd': (
         _c_int, [_c_void_p] * 5 + [_c_int, _c_float, _c_void_p, _c_void_p, _c_int] +
-        [_c_int] * 3 + [_c_void_p]),
+        [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
     'bn_sqerr_frame_sums': (_c_int, [_c_void_p] * 4 + [_c_int, _c_size_t, _c_void_p]),
     'bn_sqerr_bwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_float, _c_void_p, _c_void_p]),
     'bn_reduce_sum': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_float, _c_void_p]),
@@ -286,13 +287,27 @@ def act_bwd(dy, y, act, slope, out=None):
     return out
 
 
+def _linear_ws(M, K, N, device):
+    """(pointer, nbytes) of this stream's scratch arena, grown for the split reductions."""
+    nbytes = load().bn_linear_ws_bytes(M, K, N)
+    if nbytes == 0:
+        return None, 0
+    key = (device, torch.cuda.current_stream(device).cuda_stream, 'linear')
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf.data_ptr(), nbytes
+
+
 def linear_fwd(x, w, b):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    ws, nb = _linear_ws(M, K, N, x.device)
     _check(load().bn_linear_fwd(
         _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), M, K, N,
-        _stream()), 'bn_linear_fwd')
+        ws, nb, _stream()), 'bn_linear_fwd')
     return y
 
 
@@ -300,11 +315,12 @@ def linear_bwd(x, w, dy, need_dx, dact_src, dact, slope, dw, db, accumulate):
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty((M, K), dtype=torch.float32, device=dy.device) if need_dx else None
+    ws, nb = _linear_ws(M, K, N, dy.device) if need_dx else (None, 0)
     _check(load().bn_linear_bwd(
         _ptr(x, 'x', allow_none=True), _ptr(w, 'w'), _ptr(dy, 'dy'),
         _ptr(dx, 'dx', allow_none=True), _ptr(dact_src, 'dact_src', allow_none=True), dact, slope,
         _ptr(dw, 'dw', allow_none=True), _ptr(db, 'db', allow_none=True), int(accumulate),
-        M, K, N, _stream()), 'bn_linear_bwd')
+        M, K, N, ws, nb, _stream()), 'bn_linear_bwd')
     return dx
 
 

@@ -12,6 +12,8 @@ struct GemmArgs {
     const float* dact_src;     // nullable, same layout as C
     int dact; float slope;
     int accumulate;
+    float* part;               // set by bn_launch_gemm: partial tiles of a cross-workgroup split
+    int kslice;                // reduction length per workgroup slice
 };
 
 // conv_generic.hip
@@ -28,7 +30,8 @@ int bn_launch_channel_sum(const float* t, float* db, int N, int C, int npix, int
                           void* ws, size_t ws_bytes, hipStream_t st);
 
 // gemm.hip
-int bn_launch_gemm(const GemmArgs& a, hipStream_t st);
+int bn_launch_gemm(const GemmArgs& a, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
+size_t bn_gemm_ws_bytes(int M, int N, int K);
 int bn_launch_col_sum(const float* dy, float* db, int M, int N, int accumulate, hipStream_t st);
 
 // elementwise.hip

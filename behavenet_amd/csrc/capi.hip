@@ -408,8 +408,15 @@ extern "C" int bn_batchnorm_act_bwd(const float* x, const float* y, const float*
 // ------------------------------------------------------------------------------------------
 // linear
 // ------------------------------------------------------------------------------------------
+extern "C" size_t bn_linear_ws_bytes(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    // forward (reduce over K) and data gradient (reduce over N) may split their reduction
+    const size_t f = bn_gemm_ws_bytes(M, N, K), d = bn_gemm_ws_bytes(M, K, N);
+    return f > d ? f : d;
+}
+
 extern "C" int bn_linear_fwd(const float* x, const float* w, const float* b, float* y, int M,
-                             int K, int N, bn_stream_t stream) {
+                             int K, int N, void* ws, size_t ws_bytes, bn_stream_t stream) {
     if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return BN_E_BADARG;
     GemmArgs a;
     a.A = x; a.sai = K; a.sak = 1;
@@ -417,12 +424,13 @@ extern "C" int bn_linear_fwd(const float* x, const float* w, const float* b, flo
     a.C = y; a.sci = N; a.scj = 1;
     a.M = M; a.N = N; a.K = K;
     a.bias_j = b; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f; a.accumulate = 0;
-    return bn_launch_gemm(a, (hipStream_t)stream);
+    return bn_launch_gemm(a, (hipStream_t)stream, ws, ws_bytes);
 }
 
 extern "C" int bn_linear_bwd(const float* x, const float* w, const float* dy, float* dx,
                              const float* dact_src, int dact, float slope, float* dw, float* db,
-                             int accumulate, int M, int K, int N, bn_stream_t stream) {
+                             int accumulate, int M, int K, int N, void* ws, size_t ws_bytes,
+                             bn_stream_t stream) {
     if (!dy || M <= 0 || K <= 0 || N <= 0) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
@@ -435,7 +443,7 @@ extern "C" int bn_linear_bwd(const float* x, const float* w, const float* dy, fl
         a.M = M; a.N = K; a.K = N;
         a.bias_j = nullptr; a.dact_src = dact_src; a.dact = dact; a.slope = slope;
         a.accumulate = 0;
-        rc = bn_launch_gemm(a, st);
+        rc = bn_launch_gemm(a, st, ws, ws_bytes);
         if (rc) return rc;
     }
     if (dw) {

@@ -20,11 +20,14 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     const int li = lane & 31, lk = lane >> 5;
 
-    // this wave's slice of the reduction dimension (even length so k pairs stay aligned)
-    int kper = (a.K + SPLITK - 1) / SPLITK;
-    kper = (kper + 1) & ~1;
-    const int kbeg = ws * kper;
-    const int kend = min(a.K, kbeg + kper);
+    // this workgroup's slice (gridDim.z slices of a.kslice, a multiple of 16) and this wave's
+    // part of it (even length so k pairs stay aligned)
+    const int zbeg = blockIdx.z * a.kslice;
+    const int zend = min(a.K, zbeg + a.kslice);
+    int kper = (zend - zbeg + SPLITK - 1) / SPLITK;
+    kper = (kper + 7) & ~7;
+    const int kbeg = zbeg + ws * kper;
+    const int kend = min(zend, kbeg + kper);
 
     const int ia = i0 + li, jb = j0 + li;
     const bool a_ok = ia < a.M, b_ok = jb < a.N;
@@ -98,6 +101,14 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
 
     const int j = j0 + (lane & 31);
     if (j >= a.N) return;
+    if (a.part) {       // cross-workgroup split: raw partial tile, combined by k_gemm_combine
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int i = i0 + (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5);
+            if (i < a.M) a.part[((size_t)blockIdx.z * a.M + i) * a.N + j] = acc[t];
+        }
+        return;
+    }
     const float bj = a.bias_j ? a.bias_j[j] : 0.f;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -108,6 +119,19 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
         if (a.dact_src) v *= bn_act_grad_from_output(a.dact_src[off], a.dact, a.slope);
         a.C[off] = a.accumulate ? a.C[off] + v : v;
     }
+}
+
+// C[i,j] (+)= epi( sum_z part[z][i][j] )   (fixed order)
+__global__ __launch_bounds__(256) void k_gemm_combine(GemmArgs a, int slices) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.M * a.N) return;
+    const int i = idx / a.N, j = idx - i * a.N;
+    float v = 0.f;
+    for (int z = 0; z < slices; ++z) v += a.part[((size_t)z * a.M + i) * a.N + j];
+    if (a.bias_j) v += a.bias_j[j];
+    const long off = (long)i * a.sci + (long)j * a.scj;
+    if (a.dact_src) v *= bn_act_grad_from_output(a.dact_src[off], a.dact, a.slope);
+    a.C[off] = a.accumulate ? a.C[off] + v : v;
 }
 
 // db[n] (+)= sum_m dy[m,n]   (dy row-major M x N); one wave per column
@@ -122,13 +146,36 @@ __global__ __launch_bounds__(64) void k_col_sum(const float* __restrict__ dy,
     if (threadIdx.x == 0) db[n] = accumulate ? db[n] + acc : acc;
 }
 
-int bn_launch_gemm(const GemmArgs& a, hipStream_t st) {
-    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32);
+// a long reduction feeding only a handful of output tiles (the 2048 -> n_latents projections:
+// 7 tiles) is split over workgroups as well, so that it does not run on 7 of the 256 CUs
+static int gemm_slices(int M, int N, int K) {
+    const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
+    if (K < 1024 || tiles > 32) return 1;
+    int s = K / 128;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+size_t bn_gemm_ws_bytes(int M, int N, int K) {
+    const int s = gemm_slices(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+int bn_launch_gemm(const GemmArgs& a0, hipStream_t st, void* ws, size_t ws_bytes) {
+    GemmArgs a = a0;
+    int slices = gemm_slices(a.M, a.N, a.K);
+    if (slices > 1 && (!ws || ws_bytes < (size_t)slices * a.M * a.N * sizeof(float))) slices = 1;
+    a.kslice = ((a.K + slices - 1) / slices + 15) & ~15;
+    a.part = slices > 1 ? (float*)ws : nullptr;
+    dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, slices);
     if (a.K >= 512) {
         hipLaunchKernelGGL(k_gemm_mfma<8>, grid, dim3(512), 0, st, a);
     } else {
         hipLaunchKernelGGL(k_gemm_mfma<1>, grid, dim3(64), 0, st, a);
     }
+    if (slices > 1)
+        hipLaunchKernelGGL(k_gemm_combine, dim3((a.M * a.N + 255) / 256), dim3(256), 0, st, a,
+                           slices);
     BN_LAUNCH_CHECK();
     return 0;
 }

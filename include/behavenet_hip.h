@@ -151,15 +151,18 @@ int bn_batchnorm_act_bwd(const float* x, const float* y, const float* dy, const 
  * Dense latent projections (replaces nn.Linear, aes.py:121,125,266 and the PS-VAE heads
  * vaes.py:1288-1302).  MFMA (v_mfma_f32_32x32x2_f32: exact fp32).
  *   y[m,n] = b[n] + sum_k x[m,k] * w[n,k]        x:(M,K) w:(N,K) b:(N) or NULL  y:(M,N)
+ *   ws: scratch of bn_linear_ws_bytes(M, K, N) bytes (may be NULL / 0: then a long reduction
+ *       feeding few output tiles is not split over workgroups)
  * ------------------------------------------------------------------------------------------ */
+size_t bn_linear_ws_bytes(int M, int K, int N);
 int bn_linear_fwd(const float* x, const float* w, const float* b, float* y,
-                  int M, int K, int N, bn_stream_t stream);
+                  int M, int K, int N, void* ws, size_t ws_bytes, bn_stream_t stream);
 /* dx[m,k] = act'(dact_src[m,k]) * sum_n dy[m,n] w[n,k]   (dx, dact_src nullable)
  * dw[n,k] (+)= sum_m dy[m,n] x[m,k]   db[n] (+)= sum_m dy[m,n]   (dw, db nullable) */
 int bn_linear_bwd(const float* x, const float* w, const float* dy,
                   float* dx, const float* dact_src, int dact, float slope,
                   float* dw, float* db, int accumulate,
-                  int M, int K, int N, bn_stream_t stream);
+                  int M, int K, int N, void* ws, size_t ws_bytes, bn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pixel losses (replaces losses.mse / losses.gaussian_ll, losses.py:56-59,84-96).
