@@ -298,9 +298,9 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     const int CC = (g.stride == 5) ? 2 : 4;
     // stride 2: 64 ch x 128 px tiles whenever they give ~100 workgroups -- measured in situ
     // (bench.py, other streams' kernels fill the machine) they beat both the larger 64x256 tiles
-    // and the 32x128 tiles with more workgroups; stride 5: as many workgroups as possible
+    // and the 32x128 tiles with more workgroups; stride 5: 64x128 tiles, the reduction split
     static const int cand[3][2] = {{2, 1}, {2, 2}, {1, 1}};
-    const int want = 96;
+    const int want = g.stride == 2 ? 96 : 1;   // stride 5 (K = 6400): the 64x128 tile + split-K
     int best = -1, best_wg = 0;
     DownTile t;
     for (int i = 0; i < 3; ++i) {
