@@ -334,10 +334,14 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     int splits = 1;
     if (best_wg < (g.stride == 2 ? want : 384)) {
         const int max_splits = g.Cb / (4 * CC) > 0 ? g.Cb / (4 * CC) : 1;
-        splits = (512 + best_wg - 1) / best_wg;
+        splits = 512 / best_wg;            // all workgroups resident at once (2 per CU)
         if (splits > max_splits) splits = max_splits;
         if (splits > 16) splits = 16;
         if (splits < 1) splits = 1;
+    }
+    if (const char* e = getenv("BN_DOWN_SPLITS")) {       // tuning hook
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16 && v <= (g.Cb / CC)) splits = v;
     }
     p.d = splits;
     p.ws_bytes = splits > 1 ? (size_t)splits * g.N * g.Cs * g.Hs * g.Ws * sizeof(float) : 0;
