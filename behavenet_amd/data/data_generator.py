@@ -13,6 +13,11 @@ Frames are synthesised like the reference's integration test (tests/integration.
                               data_generator.py:251-263,630-631)
 * ``placement='device_u8'`` -- uint8 resident in HBM, converted per batch by a HIP kernel
 * ``placement='device'``    -- float32 resident in HBM (bench default: inputs already resident)
+* ``placement='host_u8'``   -- uint8 in PINNED host memory (the reference's on-disk dtype,
+                              docs/source/data_structure.rst:17-21): the trial that heads the
+                              queue is copied to the device on a copy stream while the current
+                              one is being trained on (4.2 MB instead of the 16.8 MB float32 copy
+                              of the reference), and converted by ``bn_u8_to_unit_float``
 """
 
 import numpy as np
@@ -74,7 +79,7 @@ class SyntheticSessionsGenerator(object):
     _dtypes = ['train', 'val', 'test']
 
     def __init__(self, sessions, device='cuda', placement='device'):
-        if placement not in ('host', 'device_u8', 'device'):
+        if placement not in ('host', 'device_u8', 'device', 'host_u8'):
             raise ValueError('unknown placement "%s"' % placement)
         self.datasets = list(sessions)
         self.n_datasets = len(self.datasets)
@@ -94,6 +99,8 @@ class SyntheticSessionsGenerator(object):
                         t = t.pin_memory()
                 elif placement == 'device_u8':
                     t = torch.from_numpy(u8).to(device)
+                elif placement == 'host_u8':
+                    t = torch.from_numpy(u8).pin_memory()
                 else:
                     t = torch.from_numpy(u8.astype(np.float32) / 255).to(device)
                 trials.append(t)
@@ -101,6 +108,10 @@ class SyntheticSessionsGenerator(object):
             if ds.labels is not None:
                 labels = [torch.from_numpy(l).to(device) for l in ds.labels]
             self._store.append((trials, labels))
+        # host_u8 prefetcher: two device staging buffers per trial shape, one copy stream
+        self._pf = None          # (key, device uint8 tensor, ready event) of the prefetched trial
+        self._pf_bufs = {}
+        self._pf_stream = None
         self._queues = [{k: [] for k in self._dtypes} for _ in self.datasets]
         for k in self._dtypes:
             self.reset_iterators(k)
@@ -130,7 +141,58 @@ class SyntheticSessionsGenerator(object):
             img = img.to(self.device, non_blocking=True)
         elif self.placement == 'device_u8':
             img = _hip.u8_to_unit_float(img)
+        elif self.placement == 'host_u8':
+            img = self._fetch_host_u8(sess, trial, dtype)
         sample = {'images': img[None], 'batch_idx': torch.tensor([trial])}
         if labels is not None:
             sample['labels'] = labels[trial][None]
         return sample, sess
+
+    # -- pinned uint8 feed with one-trial look-ahead ------------------------------------------
+    def _staging(self, shape, slot):
+        key = (tuple(shape), slot)
+        buf = self._pf_bufs.get(key)
+        if buf is None:
+            buf = torch.empty(shape, dtype=torch.uint8, device=self.device)
+            self._pf_bufs[key] = buf
+        return buf
+
+    def _fetch_host_u8(self, sess, trial, dtype):
+        main = torch.cuda.current_stream()
+        if self._pf_stream is None:
+            self._pf_stream = torch.cuda.Stream()
+            self._pf_slot = 0
+            self._pf_done = [None, None]      # main-stream events: staging slot consumed
+        pf = self._pf
+        self._pf = None
+        if pf is not None and pf[0] == (sess, trial):
+            _, dev_u8, ready, slot = pf
+            main.wait_event(ready)
+        else:
+            # nothing (or something else) was prefetched: copy on the main stream
+            host = self._store[sess][0][trial]
+            slot = self._pf_slot
+            dev_u8 = self._staging(host.shape, slot)
+            if self._pf_done[slot] is not None:
+                main.wait_event(self._pf_done[slot])
+            dev_u8.copy_(host, non_blocking=True)
+        img = _hip.u8_to_unit_float(dev_u8)
+        done = torch.cuda.Event()
+        done.record(main)
+        self._pf_done[slot] = done
+        self._pf_slot = slot ^ 1
+        # look ahead: the head of this session's queue is (very likely) the next trial
+        queue = self._queues[sess][dtype]
+        if queue:
+            nxt = queue[0]
+            host = self._store[sess][0][nxt]
+            nslot = self._pf_slot
+            buf = self._staging(host.shape, nslot)
+            with torch.cuda.stream(self._pf_stream):
+                if self._pf_done[nslot] is not None:
+                    self._pf_stream.wait_event(self._pf_done[nslot])
+                buf.copy_(host, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(self._pf_stream)
+            self._pf = ((sess, nxt), buf, ready, nslot)
+        return img

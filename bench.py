@@ -123,6 +123,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--feed', default='device', choices=['device', 'device_u8', 'host_u8', 'host'],
+                    help="where the trials live (default 'device': resident float32, the headline "
+                         "metric; 'host_u8' = pinned uint8 + prefetch, the PCIe-inclusive rate)")
     ap.add_argument('--cpu-budget', type=float, default=20.0)
     args = ap.parse_args()
 
@@ -145,7 +148,7 @@ def main():
 
     # 20 trials x 256 frames per rank, trial_splits 8;1;1;0 -> 16 train trials
     sess = SyntheticSession(20, BATCH, DIM, seed=100 + rank, trial_splits='8;1;1;0')
-    gen = SyntheticSessionsGenerator([sess], device='cuda', placement='device')
+    gen = SyntheticSessionsGenerator([sess], device='cuda', placement=args.feed)
     torch.manual_seed(1 + rank)
     np.random.seed(1 + rank)
     gen.reset_iterators('train')
@@ -231,7 +234,10 @@ def main():
                    'frames_per_step_per_gpu': BATCH, 'global_frames_per_step': BATCH * world,
                    'sharding': 'one trial per rank per step, RCCL all-reduce(sum) of the flat '
                                '35 MB gradient' if world > 1 else 'single GPU',
-                   'inputs': 'resident in HBM'},
+                   'inputs': {'device': 'resident in HBM (float32)',
+                              'device_u8': 'resident in HBM (uint8, converted per batch)',
+                              'host_u8': 'pinned host uint8, prefetched over PCIe per batch',
+                              'host': 'pinned host float32, copied per batch'}[args.feed]},
         'final_loss': last['loss'] if last else None,
         'whole_step_fp32_tflops': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12, 2),
         'whole_step_fp32_frac': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12 /

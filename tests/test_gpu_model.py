@@ -367,6 +367,32 @@ def test_stream_schedule_does_not_change_results(model_class):
         assert torch.equal(g, ref_g), (side, chunks, float((g - ref_g).abs().max()))
 
 
+def test_host_u8_prefetch_feed_is_bit_identical():
+    """The pinned-uint8 feed with one-trial look-ahead hands out exactly the frames the resident
+    float32 feed does (two epochs over two sessions of ragged trials, same RNG consumption)."""
+    def frames(placement):
+        sessions = [SyntheticSession(10, [5, 7, 3, 9, 4, 6, 8, 5, 7, 4], [1, 32, 32], seed=3 + i,
+                                     trial_splits='8;1;1;0') for i in range(2)]
+        gen = SyntheticSessionsGenerator(sessions, device=DEV, placement=placement)
+        out = []
+        for epoch in range(2):
+            torch.manual_seed(epoch)
+            np.random.seed(epoch)
+            gen.reset_iterators('train')
+            while True:
+                data, sess = gen.next_batch('train')
+                if data is None:
+                    break
+                out.append((sess, int(data['batch_idx'][0]), data['images'][0].clone()))
+        torch.cuda.synchronize()
+        return out
+    a, b = frames('device'), frames('host_u8')
+    assert len(a) == len(b) == 32
+    for (s1, t1, x1), (s2, t2, x2) in zip(a, b):
+        assert (s1, t1) == (s2, t2)
+        assert torch.equal(x1, x2)
+
+
 def test_losses_known_answers_on_device():
     """Closed-form answers of the reference's tests/test_fitting/test_losses.py:8-94."""
     LN2PI = np.log(2 * np.pi)
