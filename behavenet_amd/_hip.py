@@ -49,6 +49,7 @@ SIGNATURES = {
     'bn_batchnorm_act_fwd': (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_float, _c_void_p]),
     'bn_batchnorm_act_bwd': (
         _c_int, [_c_void_p] * 9 + [_c_int] * 6 + [_c_float, _c_void_p, _c_size_t, _c_void_p]),
+    'bn_act_fwd': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_int, _c_float, _c_void_p]),
     'bn_act_bwd': (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_int, _c_float, _c_void_p]),
     'bn_linear_ws_bytes': (_c_size_t, [_c_int] * 3),
     'bn_linear_fwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
@@ -276,6 +277,13 @@ def batchnorm_bwd(x, y, dy, mean, invstd, gamma, dgamma, dbeta, accumulate, batc
         int(accumulate), int(batch_stats), n, c, hw, act, slope, ws, nb, _stream()),
         'bn_batchnorm_act_bwd')
     return dx
+
+
+def act_fwd(x, act, slope):
+    y = torch.empty_like(x)
+    _check(load().bn_act_fwd(_ptr(x, 'x'), _ptr(y, 'y'), x.numel(), act, slope, _stream()),
+           'bn_act_fwd')
+    return y
 
 
 def act_bwd(dy, y, act, slope, out=None):

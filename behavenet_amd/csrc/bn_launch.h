@@ -35,6 +35,7 @@ size_t bn_gemm_ws_bytes(int M, int N, int K);
 int bn_launch_col_sum(const float* dy, float* db, int M, int N, int accumulate, hipStream_t st);
 
 // elementwise.hip
+int bn_launch_act_fwd(const float* x, float* y, size_t n, int act, float slope, hipStream_t st);
 int bn_launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act, float slope,
                       hipStream_t st);
 int bn_launch_sqerr_frame_sums(const float* pred, const float* target, const float* mask,

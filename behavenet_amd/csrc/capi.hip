@@ -356,6 +356,12 @@ extern "C" int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw,
     return rc;
 }
 
+extern "C" int bn_act_fwd(const float* x, float* y, size_t n, int act, float slope,
+                          bn_stream_t stream) {
+    if (!x || !y || n == 0) return BN_E_BADARG;
+    return bn_launch_act_fwd(x, y, n, act, slope, (hipStream_t)stream);
+}
+
 extern "C" int bn_act_bwd(const float* dy, const float* y, float* dpre, size_t n, int act,
                           float slope, bn_stream_t stream) {
     if (!dy || !y || !dpre) return BN_E_BADARG;

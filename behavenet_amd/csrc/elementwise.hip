@@ -248,6 +248,21 @@ int bn_launch_act_bwd(const float* dy, const float* y, float* dpre, size_t n, in
     return 0;
 }
 
+// y = act(x): the sigmoid after the optional last dense decoder layer (aes.py:345-359)
+__global__ __launch_bounds__(EW_THREADS) void k_act_fwd(const float* __restrict__ x,
+                                                        float* __restrict__ y, size_t n, int act,
+                                                        float slope) {
+    const size_t nthreads = (size_t)gridDim.x * EW_THREADS;
+    for (size_t i = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += nthreads)
+        y[i] = bn_apply_act(x[i], act, slope);
+}
+
+int bn_launch_act_fwd(const float* x, float* y, size_t n, int act, float slope, hipStream_t st) {
+    hipLaunchKernelGGL(k_act_fwd, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, st, x, y, n, act, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 int bn_launch_sqerr_frame_sums(const float* pred, const float* target, const float* mask,
                                float* frame_sums, int N, size_t D, hipStream_t st) {
     const int vec = aligned16(pred) && aligned16(target) && (!mask || aligned16(mask)) &&

@@ -580,6 +580,26 @@ class KLFn(torch.autograd.Function):
         return dmu, dlogvar
 
 
+class ActFn(torch.autograd.Function):
+    """y = act(x) as its own node (the Sigmoid behind the optional dense last decoder layer)."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        y = _hip.act_fwd(x.contiguous(), act, LRELU_SLOPE)
+        ctx.act = act
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return _hip.act_bwd(dy.contiguous(), y, ctx.act, LRELU_SLOPE), None
+
+
+def activation(x, act):
+    return ActFn.apply(x, act)
+
+
 class DecomposedKLFn(torch.autograd.Function):
     """(MI, TC, DWKL) of losses.py:284-351 as one (3,) tensor; N x N x D never materialised."""
 

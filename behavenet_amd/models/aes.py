@@ -16,8 +16,8 @@ import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ChunkScalars, ConvLayerPlan, conv_stack, conv_stack_bn, first_layer_forward, linear,
-    begin_chunks, chunk_stream, reserve_device_pools)
+    ChunkScalars, ConvLayerPlan, activation, conv_stack, conv_stack_bn, first_layer_forward,
+    linear, begin_chunks, chunk_stream, reserve_device_pools)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
@@ -348,15 +348,21 @@ class ConvAEDecoder(BaseModule):
         hp = self.hparams
         if any(t == 'unpool' for t in hp['ae_decoding_layer_type']):
             _unsupported_on_hip('max-pooling architectures')
-        if hp['ae_decoding_last_FF_layer']:
-            _unsupported_on_hip('ae_decoding_last_FF_layer=1')
         start = hp['ae_decoding_starting_dim']
         h = linear(x, self.FF.weight, self.FF.bias)
         h = h.view(h.size(0), start[0], start[1], start[2])
         if hp['ae_batch_norm']:
-            return conv_stack_bn(self._plan, h, self._stack_params(dataset),
-                                 _bn_modules(self.decoder, self._layer_names))
-        return conv_stack(self._plan, h, self._stack_params(dataset))
+            h = conv_stack_bn(self._plan, h, self._stack_params(dataset),
+                              _bn_modules(self.decoder, self._layer_names))
+        else:
+            h = conv_stack(self._plan, h, self._stack_params(dataset))
+        if hp['ae_decoding_last_FF_layer']:
+            # dense last layer + Sigmoid (ref aes.py:345-359,478-486)
+            ff = getattr(self.decoder, self._last_ff_name)
+            h = activation(linear(h.reshape(h.size(0), -1), ff.weight, ff.bias),
+                           _hip.ACT_SIGMOID)
+            h = h.view(-1, hp['ae_input_dim'][0], hp['ae_input_dim'][1], hp['ae_input_dim'][2])
+        return h
 
 
 class LinearAEEncoder(BaseModule):

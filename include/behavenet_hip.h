@@ -118,6 +118,8 @@ int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw, float* db,
 
 /* dpre[i] = dy[i] * act'(y[i]) where y is the saved POST-activation output
  * (autograd of LeakyReLU / Sigmoid at the top of a conv stack).  In-place (dpre == dy) allowed. */
+/* y = act(x)  (the Sigmoid after the optional dense last decoder layer, aes.py:345-359) */
+int bn_act_fwd(const float* x, float* y, size_t n, int act, float slope, bn_stream_t stream);
 int bn_act_bwd(const float* dy, const float* y, float* dpre, size_t n,
                int act, float slope, bn_stream_t stream);
 

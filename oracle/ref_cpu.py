@@ -229,8 +229,9 @@ class ConvDecoder(nn.Module):
         self.FF = nn.Linear(hp['hidden_layer_size'], start[0] * start[1] * start[2])
         self.decoder = nn.ModuleList()
         self.layers = []   # (name, crop or None, bn or None, is_last)
-        if hp['ae_decoding_last_FF_layer']:
-            raise NotImplementedError('oracle does not cover ae_decoding_last_FF_layer')
+        last_ff = bool(hp['ae_decoding_last_FF_layer'])        # ref aes.py:326-330,345-359
+        if last_ff and hp.get('fit_sess_io_layers', False):
+            raise NotImplementedError
         n = len(hp['ae_decoding_n_channels'])
         g = 0
         for i in range(n):
@@ -259,7 +260,7 @@ class ConvDecoder(nn.Module):
             mk = lambda: nn.ConvTranspose2d(                                     # noqa: E731
                 cin, hp['ae_decoding_n_channels'][i], (k, k), stride=(s, s), padding=pad,
                 output_padding=opad)
-            is_last = i == n - 1
+            is_last = i == n - 1 and not last_ff
             if hp.get('fit_sess_io_layers', False) and is_last:
                 name = 'convtranspose%i_sess_io_layers' % g
                 self.decoder.add_module(name, nn.ModuleList(
@@ -280,6 +281,16 @@ class ConvDecoder(nn.Module):
                 self.decoder.add_module('relu%i' % g, nn.LeakyReLU(SLOPE))
             self.layers.append((name, crop, bn, is_last))
             g += 1
+        if last_ff:
+            # "have last layer be feedforward if this is 1" (ref aes.py:345-359)
+            self.decoder.add_module('last_ff%i' % g, nn.Linear(
+                hp['ae_decoding_x_dim'][-1] * hp['ae_decoding_y_dim'][-1] *
+                hp['ae_decoding_n_channels'][-1],
+                hp['ae_input_dim'][0] * hp['ae_input_dim'][1] * hp['ae_input_dim'][2]))
+            self.decoder.add_module('sigmoid%i' % g, nn.Sigmoid())
+            self.last_ff = 'last_ff%i' % g
+        else:
+            self.last_ff = None
 
     def forward(self, z, pool_idx=None, target_output_size=None, dataset=None, taps=None):
         start = self.hp['ae_decoding_starting_dim']
@@ -300,6 +311,11 @@ class ConvDecoder(nn.Module):
                 x = F.leaky_relu(x, SLOPE)
             if taps is not None:
                 taps.append(x)
+        if self.last_ff is not None:                     # ref aes.py:478-486
+            ff = getattr(self.decoder, self.last_ff)
+            x = torch.sigmoid(F.linear(x.reshape(x.shape[0], -1), ff.weight, ff.bias))
+            x = x.view(-1, self.hp['ae_input_dim'][0], self.hp['ae_input_dim'][1],
+                       self.hp['ae_input_dim'][2])
         return x
 
 

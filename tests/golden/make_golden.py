@@ -284,6 +284,11 @@ if __name__ == '__main__':
                    extra_hp={'ae_batch_norm': True, 'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0,
                              'max_n_epochs': 10})
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'lastff':
+        # dense last decoder layer (aes.py:345-359): 1x32x32 -> Linear(1024, 1024) + Sigmoid
+        model_case('ae_cfg1_lastff', RefAE, [1, 32, 32], 8, 8, 'ae',
+                   extra_hp={'ae_decoding_last_FF_layer': 1})
+        sys.exit(0)
     planner_fixture()
     model_case('ae_cfg1', RefAE, [1, 32, 32], 8, 8, 'ae')
     model_case('ae_cfg1_b210', RefAE, [1, 32, 32], 8, 210, 'ae', store_xhat=True)

@@ -58,7 +58,7 @@ def _bias_before_batchnorm(key, names):
 
 
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
-         'condvae_cfg1', 'psvae_cfg4', 'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn']
+         'condvae_cfg1', 'psvae_cfg4', 'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff']
 
 
 @pytest.mark.parametrize('name', CASES)
