@@ -1,2 +1,2 @@
-from behavenet_amd.models.aes import AE, ConditionalAE  # noqa: F401
+from behavenet_amd.models.aes import AE, ConditionalAE, AEMSP  # noqa: F401
 from behavenet_amd.models.vaes import VAE, ConditionalVAE, BetaTCVAE, PSVAE  # noqa: F401

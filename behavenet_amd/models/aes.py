@@ -16,11 +16,12 @@ import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ChunkScalars, ConvLayerPlan, activation, conv_stack, conv_stack_bn, first_layer_forward,
-    linear, begin_chunks, chunk_stream, reserve_device_pools)
+    ChunkScalars, ConvLayerPlan, Readback, activation, conv_stack, conv_stack_bn,
+    first_layer_forward, linear, begin_chunks, chunk_stream, reserve_device_pools)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
+    'AEMSP',
     'load_pretrained_ae']
 
 
@@ -590,6 +591,143 @@ class ConditionalAE(AE):
         self._release_first_layer()
         loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
         return {'loss': loss_val}
+
+
+class AEMSP(AE):
+    """Autoencoder with matrix subspace projection (ref aes.py:901-1217, Li et al. 2019).
+
+    ``y_hat = P z`` (no bias) predicts the labels from the latents; the MSP loss
+    ``mse(y, y_hat) + mse(z, y_hat P)`` pushes the label information into the row space of P.
+    ``model_class = 'cond-ae-msp'``; conv encoder/decoder only.
+    """
+
+    def __init__(self, hparams):
+        if hparams['model_type'] == 'linear':
+            raise NotImplementedError
+        if hparams['n_ae_latents'] < hparams['n_labels']:
+            raise ValueError('AEMSP model must contain at least as many latents as labels')
+        self.n_latents = hparams['n_ae_latents']
+        self.n_labels = hparams['n_labels']
+        self.projection = None
+        self.U = None
+        super().__init__(hparams)
+
+    def build_model(self):
+        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
+        self.encoding = ConvAEEncoder(self.hparams)
+        self.decoding = ConvAEDecoder(self.hparams)
+        self.projection = nn.Linear(self.n_latents, self.n_labels, bias=False)
+        # in the state dict from the start, overwritten by create_orthogonal_matrix (ref :950-954)
+        with torch.no_grad():
+            self.U = nn.Linear(self.n_latents, self.n_latents, bias=False)
+
+    def _chunk_streams_ok(self):
+        return False     # `projection` is used twice per chunk and accumulates through torch
+
+    def forward(self, x, dataset=None, **kwargs):
+        """-> (x_hat, z, y_hat)."""
+        z, pool_idx, outsize = self.encoding(x, dataset=dataset)
+        y = linear(z, self._P(), None)
+        x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+        return x_hat, z, y
+
+    def _P(self):
+        # a non-leaf alias of the projection: it enters two GEMMs per chunk, and both gradients
+        # must reach `projection.weight.grad` through ONE torch accumulation, not through the
+        # kernels' in-place side-stream path and torch's AccumulateGrad at the same time
+        return self.projection.weight.clone()
+
+    def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
+        """mse + msp.alpha * (mse(y, y_hat) + mse(z, y_hat P)) per 200-frame chunk (ref :979-1060);
+        returns ``loss, loss_mse, loss_msp, labels_r2``."""
+        from behavenet_amd.models.vaes import _r2_variance_weighted
+        x = data['images'][0]
+        y = data['labels'][0]
+        m = data['masks'][0] if 'masks' in data else None
+        batch_size = x.shape[0]
+        n_chunks = int(np.ceil(batch_size / chunk_size))
+        alpha = self.hparams['msp.alpha']
+        self._reserve_pools(x)
+        self._prepare_first_layer(x, dataset)
+        rbs, sizes, deferred, y_hat_all = ChunkScalars(), [], [], []
+        for chunk in range(n_chunks):
+            beg = chunk * chunk_size
+            end = min((chunk + 1) * chunk_size, batch_size)
+            x_in, y_in = x[beg:end], y[beg:end]
+            m_in = m[beg:end] if m is not None else None
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                P = self._P()
+                z, pool_idx, outsize = self.encoding(x_in, dataset=dataset)
+                y_hat = linear(z, P, None)
+                x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+                loss_mse = losses.mse(x_in, x_hat, m_in)
+                # y_hat P: (N, n_labels) x (n_labels, n_latents); nn.Linear stores P as
+                # (n_labels, n_latents), so the "transposed layer" is P itself (ref :1035-1037)
+                z_back = linear(y_hat, P.t().contiguous(), None)
+                loss_msp = losses.mse(y_in, y_hat) + losses.mse(z, z_back)
+                loss = loss_mse + float(alpha) * loss_msp
+            if accumulate_grad:
+                deferred.append(loss)
+            rbs.add(torch.stack([loss.detach(), loss_mse.detach(), loss_msp.detach()]))
+            sizes.append(end - beg)
+            y_hat_all.append(y_hat.detach())
+        y_hat_rb = Readback(torch.cat(y_hat_all, dim=0))
+        y_rb = Readback(y)
+        vals = rbs.finish(deferred)
+        self._release_first_layer()
+        w = np.asarray(sizes, dtype=np.float64)[:, None]
+        tot = (vals * w).sum(axis=0) / batch_size
+        r2 = _r2_variance_weighted(y_rb.numpy(), y_hat_rb.numpy())
+        return {'loss': float(tot[0]), 'loss_mse': float(tot[1]), 'loss_msp': float(tot[2]),
+                'labels_r2': r2}
+
+    def save(self, filepath):
+        """Build the complete orthogonal matrix U before saving (ref :1062-1065)."""
+        self.create_orthogonal_matrix()
+        super().save(filepath)
+
+    def create_orthogonal_matrix(self):
+        """U = [P; null_space(P)^T] (ref :1067-1080)."""
+        from scipy.linalg import null_space
+        M = self.projection.weight.data.detach().cpu().numpy()
+        N = null_space(M)
+        U = np.concatenate([M, N.T], axis=0)
+        with torch.no_grad():
+            self.U.weight = nn.Parameter(torch.from_numpy(U).float(), requires_grad=False)
+        self.U.to(self.hparams['device'])
+
+    def get_transformed_latents(self, inputs, dataset=None, as_numpy=True):
+        """Latents in the transformed space U z (ref :1082-1122); images or latents in."""
+        if not isinstance(inputs, torch.Tensor):
+            inputs = torch.Tensor(inputs)
+        if len(inputs.shape) == 2:
+            latents_og = inputs
+        else:
+            latents_og, _, _ = self.encoding(inputs, dataset=dataset)
+        latents_tr = linear(latents_og, self.U.weight, None)
+        return latents_tr.cpu().detach().numpy() if as_numpy else latents_tr
+
+    def get_inverse_transformed_latents(self, latents, as_numpy=True):
+        """Back to the original latent space: latents U (ref :1124-1146)."""
+        if not isinstance(latents, torch.Tensor):
+            latents = torch.Tensor(latents)
+        latents_og = linear(latents, self.U.weight.t().contiguous(), None)
+        return latents_og.cpu().detach().numpy() if as_numpy else latents_og
+
+    def sample(self, x=None, dataset=None, latents=None, labels=None, labels_2d=None):
+        """Decode user-defined labels and/or transformed latents (ref :1148-1217)."""
+        if latents is None or labels is None:
+            latents_tr = self.get_transformed_latents(x, dataset)
+        else:
+            latents_tr = np.full(shape=(latents.shape[0], self.n_latents), fill_value=np.nan)
+        if labels is not None:
+            latents_tr[:, :self.n_labels] = labels
+        if latents is not None:
+            latents_tr[:, self.n_labels:] = latents
+        dev = self.U.weight.device
+        latents_og = self.get_inverse_transformed_latents(
+            torch.from_numpy(latents_tr).float().to(dev), as_numpy=False)
+        return self.decoding(latents_og, None, None, dataset=dataset)
 
 
 def load_pretrained_ae(model, hparams):

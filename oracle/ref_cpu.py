@@ -571,8 +571,50 @@ class PSVAE(AE):
         return out
 
 
+class AEMSP(AE):
+    """Matrix subspace projection AE (ref aes.py:901-1060)."""
+
+    def build_model(self):
+        self.n_latents = self.hparams['n_ae_latents']
+        self.n_labels = self.hparams['n_labels']
+        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
+        self.encoding = ConvEncoder(self.hparams)
+        self.decoding = ConvDecoder(self.hparams)
+        self.projection = nn.Linear(self.n_latents, self.n_labels, bias=False)
+        with torch.no_grad():
+            self.U = nn.Linear(self.n_latents, self.n_latents, bias=False)
+
+    def forward(self, x, dataset=None, **kwargs):
+        z, pi, os_ = self.encoding(x, dataset=dataset)
+        y = self.projection(z)
+        return self.decoding(z, pi, os_, dataset=dataset), z, y
+
+    def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
+        from sklearn.metrics import r2_score
+        x, y = data['images'][0], data['labels'][0]
+        m = data['masks'][0] if 'masks' in data else None
+        B = x.shape[0]
+        tot = np.zeros(3)
+        y_hat_all = []
+        for beg, end in _chunks(B, chunk_size):
+            x_in, y_in = x[beg:end], y[beg:end]
+            m_in = m[beg:end] if m is not None else None
+            x_hat, z, y_hat = self.forward(x_in, dataset=dataset)
+            loss_mse = mse(x_in, x_hat, m_in)
+            loss_msp = mse(y_in, y_hat) + mse(z, torch.matmul(y_hat, self.projection.weight))
+            loss = loss_mse + self.hparams['msp.alpha'] * loss_msp
+            if accumulate_grad:
+                loss.backward()
+            tot += np.array([loss.item(), loss_mse.item(), loss_msp.item()]) * (end - beg)
+            y_hat_all.append(y_hat.detach().numpy())
+        tot /= B
+        r2 = r2_score(y.detach().numpy(), np.concatenate(y_hat_all, axis=0),
+                      multioutput='variance_weighted')
+        return {'loss': tot[0], 'loss_mse': tot[1], 'loss_msp': tot[2], 'labels_r2': r2}
+
+
 MODEL_CLASSES = {'ae': AE, 'cond-ae': ConditionalAE, 'vae': VAE, 'cond-vae': ConditionalVAE,
-                 'beta-tcvae': BetaTCVAE, 'ps-vae': PSVAE}
+                 'beta-tcvae': BetaTCVAE, 'ps-vae': PSVAE, 'cond-ae-msp': AEMSP}
 
 
 def build_model(hparams):

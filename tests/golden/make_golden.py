@@ -171,7 +171,8 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
     else:
         store['fwd/x_hat_first'] = x_hat[:1].numpy().astype(np.float32)
     store['fwd/x_hat/checksum'] = checksum(x_hat.numpy())
-    names = {2: ['z'], 4: ['z', 'mu', 'logvar'], 5: ['z', 'mu', 'logvar', 'y_hat']}[len(out)]
+    names = {2: ['z'], 3: ['z', 'y_hat'], 4: ['z', 'mu', 'logvar'],
+             5: ['z', 'mu', 'logvar', 'y_hat']}[len(out)]
     for nm, t in zip(names, out[1:]):
         store['fwd/' + nm] = t.numpy().astype(np.float32)
     if variational:
@@ -214,6 +215,8 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
             continue
         tensor_record(store, 'adam/param/' + k, p, full_limit=1024)
         st = opt.state[p]
+        if not st:            # a parameter that never receives a gradient (AEMSP.U)
+            continue
         for sk in ('exp_avg', 'exp_avg_sq', 'max_exp_avg_sq'):
             store['adam/%s/%s/checksum' % (sk, k)] = checksum(st[sk].numpy())
 
@@ -283,6 +286,11 @@ if __name__ == '__main__':
         model_case('vae_1x64x48_bn', RefVAE, [1, 64, 48], 8, 6, 'vae',
                    extra_hp={'ae_batch_norm': True, 'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0,
                              'max_n_epochs': 10})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'msp':
+        from behavenet.models.aes import AEMSP as RefAEMSP
+        model_case('aemsp_cfg1', RefAEMSP, [1, 32, 32], 8, 8, 'cond-ae-msp', n_labels=4,
+                   extra_hp={'msp.alpha': 0.01, 'device': 'cpu'})
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'lastff':
         # dense last decoder layer (aes.py:345-359): 1x32x32 -> Linear(1024, 1024) + Sigmoid
