@@ -9,6 +9,7 @@ What it restates (reference file:line -> here):
   * ConvAEDecoder.forward   behavenet/models/aes.py:432-488   -> ConvDecoder.forward
   * AE / AE.loss            behavenet/models/aes.py:616-773   -> AE
   * ConditionalAE           behavenet/models/aes.py:776-898   -> ConditionalAE
+  * AEMSP                   behavenet/models/aes.py:901-1060  -> AEMSP
   * reparameterize, VAE, ConditionalVAE, BetaTCVAE, PSVAE, ConvAEPSEncoder
                             behavenet/models/vaes.py:17-35,38-208,211-364,367-503,506-729,1276-1363
   * mse, gaussian_ll, gaussian_ll_to_mse, kl_div_to_std_normal, decomposed_kl
