@@ -342,8 +342,8 @@ def sqerr_frame_sums(pred, target, mask):
     return out
 
 
-def sqerr_bwd(pred, target, mask, scale, gscale):
-    dpred = torch.empty_like(pred)
+def sqerr_bwd(pred, target, mask, scale, gscale, out=None):
+    dpred = torch.empty_like(pred) if out is None else out
     _check(load().bn_sqerr_bwd(
         _ptr(pred, 'pred'), _ptr(target, 'target'), _ptr(mask, 'mask', allow_none=True),
         _ptr(dpred, 'dpred'), pred.numel(), float(scale), _ptr(gscale, 'gscale', allow_none=True),

@@ -25,6 +25,14 @@ def mse(y_pred, y_true, masks=None):
     return hf.sq_err(y_pred, y_true, masks, 1.0 / y_pred.numel())
 
 
+def mse_chunks(y_pred, y_true, masks, bounds):
+    """``mse`` of every contiguous frame range in ``bounds`` (same divisor convention) as one
+    (n_chunks,) device tensor -- for a batch whose forward ran in a single pass."""
+    per_frame = y_pred[0].numel()
+    return hf.chunked_sq_err(y_pred, y_true, masks, bounds,
+                             [1.0 / ((end - beg) * per_frame) for beg, end in bounds])
+
+
 def gaussian_ll(y_pred, y_mean, masks=None, std=1):
     """Diagonal-Gaussian log-likelihood, summed over dims, averaged over frames (ref :62-96)."""
     n_frames = y_pred.shape[0]

@@ -540,6 +540,41 @@ def sq_err(a, b, mask, scale):
     return SqErrFn.apply(a, b, mask, scale)
 
 
+class ChunkedSqErrFn(torch.autograd.Function):
+    """out[c] = scales[c] * sum_{frames in chunk c} (a - b)^2 * mask for contiguous frame ranges
+    ``bounds`` -- the per-chunk pixel losses of a batch whose forward ran in ONE pass."""
+
+    @staticmethod
+    def forward(ctx, a, b, mask, bounds, scales):
+        a, b = a.contiguous(), b.contiguous()
+        mask = mask.contiguous() if mask is not None else None
+        ctx.save_for_backward(a, b, mask)
+        ctx.bounds, ctx.scales = list(bounds), [float(s) for s in scales]
+        sums = _hip.sqerr_frame_sums(a, b, mask)
+        return torch.stack([_hip.reduce_sum(sums[beg:end], s)
+                            for (beg, end), s in zip(ctx.bounds, ctx.scales)])
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, mask = ctx.saved_tensors
+        g = g.contiguous()
+        grads = []
+        for need, p, t in ((ctx.needs_input_grad[0], a, b), (ctx.needs_input_grad[1], b, a)):
+            if not need:
+                grads.append(None)
+                continue
+            d = torch.empty_like(p)
+            for i, ((beg, end), s) in enumerate(zip(ctx.bounds, ctx.scales)):
+                _hip.sqerr_bwd(p[beg:end], t[beg:end], mask[beg:end] if mask is not None else None,
+                               s, g[i:i + 1], out=d[beg:end])
+            grads.append(d)
+        return grads[0], grads[1], None, None, None
+
+
+def chunked_sq_err(a, b, mask, bounds, scales):
+    return ChunkedSqErrFn.apply(a, b, mask, bounds, scales)
+
+
 class ReparamFn(torch.autograd.Function):
     """z = mu + eps * exp(logvar)  (std = exp(logvar) as in the reference, vaes.py:33)."""
 

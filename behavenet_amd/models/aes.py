@@ -8,6 +8,8 @@ checkpoint loads here and vice versa.  The ``nn.Conv2d`` / ``nn.ConvTranspose2d`
 The arithmetic runs through :mod:`behavenet_amd.hip_functions`.
 """
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -16,8 +18,9 @@ import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ChunkScalars, ConvLayerPlan, Readback, activation, conv_stack, conv_stack_bn,
-    first_layer_forward, linear, begin_chunks, chunk_stream, reserve_device_pools)
+    ChunkScalars, ConvLayerPlan, Readback, activation, backward_chunks, conv_stack, conv_stack_bn,
+    first_layer_forward, join_side_streams, linear, begin_chunks, chunk_stream,
+    reserve_device_pools)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
@@ -478,6 +481,34 @@ class AE(BaseModel):
         if self.model_type == 'conv':
             self.encoding.release_first_layer()
 
+    def _whole_batch_ok(self, x):
+        """Frames are independent through this model (no batch norm): the chunks of the reference
+        only bound ITS memory use, and only the loss normalisation depends on them."""
+        return self.model_type == 'conv' and x.is_cuda and type(self) is AE and \
+            not self.hparams.get('ae_batch_norm', False) and \
+            os.environ.get('BN_WHOLE_BATCH', '1') != '0'
+
+    def _loss_whole_batch(self, x, m, dataset, accumulate_grad, chunk_size):
+        """ONE forward and ONE backward pass over the whole batch with the reference's per-chunk
+        loss normalisation (ref aes.py:748-771): the gradient is the same
+        sum_chunks grad(mean_chunk) and the reported loss the same frame-weighted mean, but
+        every kernel sees all frames at once (256 frames on 256 CUs) and there is one set of
+        weight-gradient launches and partial sums per step instead of one per chunk."""
+        batch_size = x.shape[0]
+        bounds = [(beg, min(beg + chunk_size, batch_size))
+                  for beg in range(0, batch_size, chunk_size)]
+        self._reserve_pools(x)
+        with torch.set_grad_enabled(bool(accumulate_grad)):
+            x_hat, _ = self.forward(x, dataset=dataset)
+            chunk_losses = losses.mse_chunks(x, x_hat, m, bounds)
+        vals = Readback(chunk_losses.detach())
+        if accumulate_grad:
+            backward_chunks([chunk_losses.sum()])
+        join_side_streams()
+        vals = vals.numpy().astype(np.float64)
+        sizes = np.asarray([end - beg for beg, end in bounds], dtype=np.float64)
+        return {'loss': float(np.sum(vals * sizes) / batch_size)}
+
     def _chunk_streams_ok(self):
         """Chunks may run on two HIP streams unless a layer accumulates outside the weight-
         gradient side stream (batch-norm scale/shift gradients and running statistics) ..."""
@@ -512,6 +543,8 @@ class AE(BaseModel):
         m = data['masks'][0] if 'masks' in data else None
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
+        if self._whole_batch_ok(x):
+            return self._loss_whole_batch(x, m, dataset, accumulate_grad, chunk_size)
 
         vals, sizes, deferred = ChunkScalars(), [], []
         self._reserve_pools(x)

@@ -6,8 +6,9 @@
 
 One "step" is one pass of the reference's hot loop over one 256-frame trial
 (training.py:336-352 with i_epoch > 0): zero_grad -> next_batch -> AE.loss(accumulate_grad=True)
-(chunks of 200 + 56 frames, forward + backward per chunk) -> [RCCL all-reduce of the flat
-gradient] -> Adam(amsgrad) step.  Trials are synthetic uint8-noise frames (float32/255) already
+(the reference's per-chunk loss normalisation, chunks of 200 + 56 frames; here ONE forward and
+ONE backward pass over all 256 frames produce the same sum of per-chunk-mean gradients) ->
+[RCCL all-reduce of the flat gradient] -> Adam(amsgrad) step.  Trials are synthetic uint8-noise frames (float32/255) already
 resident in HBM.  With N > 1 every rank consumes its own trial per step (weak scaling) and the
 gradients are summed over ranks before the identical optimizer step.
 
@@ -229,7 +230,8 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'configs[1]: conv AE (default arch 32-64-128-256-512, k5, strides '
                                '2,2,2,2,5), 1x128x128 uint8-noise frames as float32/255, 12 '
-                               'latents, one 256-frame trial per step per GPU (chunks 200+56), '
+                               'latents, one 256-frame trial per step per GPU (the reference\'s 200+56 '
+                               'chunk loss normalisation; one forward/backward pass), '
                                'Adam(amsgrad) lr 1e-4',
                    'frames_per_step_per_gpu': BATCH, 'global_frames_per_step': BATCH * world,
                    'sharding': 'one trial per rank per step, RCCL all-reduce(sum) of the flat '

