@@ -42,6 +42,16 @@ def gaussian_ll(y_pred, y_mean, masks=None, std=1):
     return hf.sq_err(y_pred, y_mean, masks, -(0.5 / (std ** 2)) / n_frames) + float(const)
 
 
+def gaussian_ll_chunks(y_pred, y_mean, masks, bounds, std=1):
+    """``gaussian_ll`` of every contiguous frame range in ``bounds`` as one (n_chunks,) tensor."""
+    n_dims = int(np.prod(y_pred.shape[1:]))
+    log_var = np.log(std ** 2)
+    const = -(0.5 * LN2PI + 0.5 * log_var) * n_dims
+    return hf.chunked_sq_err(y_pred, y_mean, masks, bounds,
+                             [-(0.5 / (std ** 2)) / (end - beg) for beg, end in bounds]) \
+        + float(const)
+
+
 def gaussian_ll_to_mse(ll, n_dims, gaussian_std=1, mse_std=1):
     """Strip the Gaussian constants from a log-likelihood value (ref :99-127); host floats."""
     llc = np.copy(ll)

@@ -431,6 +431,8 @@ class LinearAEDecoder(BaseModule):
 class AE(BaseModel):
     """Base autoencoder class (ref aes.py:616-773)."""
 
+    _whole_batch = True      # loss() implements the single-pass schedule (see _loss_whole_batch)
+
     def __init__(self, hparams):
         super().__init__()
         self.hparams = hparams
@@ -484,7 +486,7 @@ class AE(BaseModel):
     def _whole_batch_ok(self, x):
         """Frames are independent through this model (no batch norm): the chunks of the reference
         only bound ITS memory use, and only the loss normalisation depends on them."""
-        return self.model_type == 'conv' and x.is_cuda and type(self) is AE and \
+        return self.model_type == 'conv' and x.is_cuda and self._whole_batch and \
             not self.hparams.get('ae_batch_norm', False) and \
             os.environ.get('BN_WHOLE_BATCH', '1') != '0'
 
@@ -574,6 +576,8 @@ class AE(BaseModel):
 class ConditionalAE(AE):
     """Conditional autoencoder: labels are appended to the latents (ref aes.py:776-898)."""
 
+    _whole_batch = False
+
     def __init__(self, hparams):
         if hparams['model_type'] == 'linear':
             raise NotImplementedError
@@ -633,6 +637,8 @@ class AEMSP(AE):
     ``mse(y, y_hat) + mse(z, y_hat P)`` pushes the label information into the row space of P.
     ``model_class = 'cond-ae-msp'``; conv encoder/decoder only.
     """
+
+    _whole_batch = False
 
     def __init__(self, hparams):
         if hparams['model_type'] == 'linear':

@@ -46,6 +46,30 @@ def reparameterize(mu, logvar, eps=None):
     return hf.reparameterize_with_eps(mu, logvar, eps)
 
 
+def _sample(mu, logvar, use_mean, bounds):
+    """Latents for a whole batch: the mean, or one ``reparameterize`` draw per chunk (the
+    reference samples chunk by chunk; keeping that keeps the RNG / eps-provider sequence)."""
+    if use_mean:
+        return mu
+    if bounds is None:
+        return reparameterize(mu, logvar)
+    return torch.cat([reparameterize(mu[b:e].contiguous(), logvar[b:e].contiguous())
+                      for b, e in bounds], dim=0)
+
+
+def _bounds(batch_size, chunk_size):
+    return [(beg, min(beg + chunk_size, batch_size)) for beg in range(0, batch_size, chunk_size)]
+
+
+def _finish_whole(table, total, accumulate_grad):
+    """Read back the (n_chunks, n_keys) scalar table, run the single backward, join streams."""
+    rb = hf.Readback(table.detach())
+    if accumulate_grad:
+        hf.backward_chunks([total])
+    hf.join_side_streams()
+    return rb.numpy().astype(np.float64)
+
+
 def _r2_variance_weighted(y_true, y_pred):
     """sklearn.metrics.r2_score(..., multioutput='variance_weighted') in numpy."""
     y_true = np.asarray(y_true, dtype=np.float64)
@@ -96,7 +120,7 @@ class VAE(AE):
     def forward(self, x, dataset=None, use_mean=False, **kwargs):
         """-> (x_hat, z, mu, logvar)."""
         mu, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
-        z = mu if use_mean else reparameterize(mu, logvar)
+        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
         x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
         return x_hat, z, mu, logvar
 
@@ -109,8 +133,26 @@ class VAE(AE):
         rbs, sizes, deferred = hf.ChunkScalars(), [], []
         keys = ['loss', 'loss_ll', 'loss_kl']
         self._reserve_pools(x)
-        self._prepare_first_layer(x, dataset)
-        hf.begin_chunks(x.device)
+        whole = self._whole_batch_ok(x)
+        if whole:
+            # one pass over the whole batch, latents sampled and losses normalised per chunk
+            # (see AE._loss_whole_batch)
+            bounds = _bounds(batch_size, chunk_size)
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                x_hat, _, mu, logvar = self.forward(
+                    x, dataset=dataset, use_mean=False, sample_bounds=bounds,
+                    **fwd_kwargs_fn(0, batch_size))
+                ll = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
+                klv = torch.stack([losses.kl_div_to_std_normal(
+                    mu[b:e].contiguous(), logvar[b:e].contiguous()) for b, e in bounds])
+                lossv = -ll + float(beta) * klv
+            vals = _finish_whole(torch.stack([lossv, ll, klv], dim=1), lossv.sum(),
+                                 accumulate_grad)
+            sizes = [e - b for b, e in bounds]
+            n_chunks = 0
+        else:
+            self._prepare_first_layer(x, dataset)
+            hf.begin_chunks(x.device)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
@@ -127,9 +169,10 @@ class VAE(AE):
             if accumulate_grad:
                 deferred.append(loss)
             sizes.append(end - beg)
-        # read-backs enqueued with the forwards, collected after the deferred backwards are queued
-        vals = rbs.finish(deferred)
-        self._release_first_layer()
+        if not whole:
+            # read-backs enqueued with the forwards, collected after the deferred backwards
+            vals = rbs.finish(deferred)
+            self._release_first_layer()
         out = {k: 0.0 for k in keys}
         out['loss_mse'] = 0.0
         n_dims = np.prod(x.shape[1:])
@@ -162,7 +205,7 @@ class ConditionalVAE(VAE):
         if self.hparams['conditional_encoder']:
             x = torch.cat((x, labels_2d), dim=1)
         mu, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
-        z = mu if use_mean else reparameterize(mu, logvar)
+        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
         z_aug = torch.cat((z, labels), dim=1)
         x_hat = self.decoding(z_aug, pool_idx, outsize, dataset=dataset)
         return x_hat, z, mu, logvar
@@ -199,8 +242,23 @@ class BetaTCVAE(VAE):
         rbs, sizes, deferred = hf.ChunkScalars(), [], []
         keys = ['loss', 'loss_ll', 'loss_mi', 'loss_tc', 'loss_dwkl']
         self._reserve_pools(x)
-        self._prepare_first_layer(x, dataset)
-        hf.begin_chunks(x.device)
+        whole = self._whole_batch_ok(x)
+        if whole:
+            bounds = _bounds(batch_size, chunk_size)
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                x_hat, sample, mu, logvar = self.forward(x, dataset=dataset, use_mean=False,
+                                                         sample_bounds=bounds)
+                ll = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
+                dk = torch.stack([torch.stack(losses.decomposed_kl(
+                    sample[b:e], mu[b:e], logvar[b:e])) for b, e in bounds])   # (n_chunks, 3)
+                lossv = -ll + float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
+            vals = _finish_whole(torch.cat([lossv[:, None], ll[:, None], dk], dim=1),
+                                 lossv.sum(), accumulate_grad)
+            sizes = [e - b for b, e in bounds]
+            n_chunks = 0
+        else:
+            self._prepare_first_layer(x, dataset)
+            hf.begin_chunks(x.device)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
@@ -218,8 +276,9 @@ class BetaTCVAE(VAE):
             if accumulate_grad:
                 deferred.append(loss)
             sizes.append(end - beg)
-        vals = rbs.finish(deferred)
-        self._release_first_layer()
+        if not whole:
+            vals = rbs.finish(deferred)
+            self._release_first_layer()
         out = {k: 0.0 for k in keys}
         out['loss_mse'] = 0.0
         n_dims = np.prod(x.shape[1:])
@@ -305,7 +364,7 @@ class PSVAE(AE):
         """-> (x_hat, z, mu, logvar, y_hat)."""
         y, w, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
         mu = torch.cat([y, w], dim=1)
-        z = mu if use_mean else reparameterize(mu, logvar)
+        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
         x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
         y_hat = self.encoding.D(y)
         return x_hat, z, mu, logvar, y_hat
@@ -324,10 +383,37 @@ class PSVAE(AE):
         kl = self.kl_anneal_vals[self.curr_epoch]
 
         self._reserve_pools(x)
-        self._prepare_first_layer(x, dataset)
         rbs, sizes, y_hat_all, deferred = hf.ChunkScalars(), [], [], []
         keys = ['loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi', 'loss_zu_tc',
                 'loss_zu_dwkl', 'loss']
+        whole = self._whole_batch_ok(x)
+        if whole:
+            # one pass over the whole batch; latents sampled, and every term normalised, per
+            # chunk (see AE._loss_whole_batch)
+            bounds = _bounds(batch_size, chunk_size)
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                x_hat, sample, mu, logvar, y_hat = self.forward(
+                    x, dataset=dataset, use_mean=False, sample_bounds=bounds)
+                ll_x = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
+                ll_y = losses.gaussian_ll_chunks(y, y_hat, n, bounds)
+                zs = torch.stack([losses.kl_div_to_std_normal(
+                    mu[b:e, :n_labels].contiguous(), logvar[b:e, :n_labels].contiguous())
+                    for b, e in bounds])
+                dk = torch.stack([torch.stack(losses.decomposed_kl(
+                    sample[b:e, n_labels:], mu[b:e, n_labels:], logvar[b:e, n_labels:]))
+                    for b, e in bounds])                                   # (n_chunks, 3)
+                lossv = -ll_x - float(alpha) * ll_y + zs + float(kl) * dk[:, 0] \
+                    + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
+            y_hat_rb = hf.Readback(y_hat)
+            y_rb = hf.Readback(y)
+            n_rb = hf.Readback(n) if n is not None else None
+            vals = _finish_whole(
+                torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk, lossv[:, None]], dim=1),
+                lossv.sum(), accumulate_grad)
+            sizes = [e - b for b, e in bounds]
+            n_chunks = 0
+        else:
+            self._prepare_first_layer(x, dataset)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
             end = min((chunk + 1) * chunk_size, batch_size)
@@ -354,13 +440,14 @@ class PSVAE(AE):
             sizes.append(end - beg)
             y_hat_all.append(y_hat.detach())
 
-        # read-backs enqueued between the forwards and the deferred backwards (see AE.loss).
-        # One stream only: the diagonal label head D accumulates through torch's AccumulateGrad.
-        y_hat_rb = hf.Readback(torch.cat(y_hat_all, dim=0))
-        y_rb = hf.Readback(y)
-        n_rb = hf.Readback(n) if n is not None else None
-        vals = rbs.finish(deferred)
-        self._release_first_layer()
+        if not whole:
+            # read-backs enqueued between the forwards and the deferred backwards (see AE.loss).
+            # One stream only: the diagonal label head D accumulates through AccumulateGrad.
+            y_hat_rb = hf.Readback(torch.cat(y_hat_all, dim=0))
+            y_rb = hf.Readback(y)
+            n_rb = hf.Readback(n) if n is not None else None
+            vals = rbs.finish(deferred)
+            self._release_first_layer()
         y_hat_np, y_np = y_hat_rb.numpy(), y_rb.numpy()
         n_np = n_rb.numpy() if n_rb is not None else None
         order = ['loss', 'loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi',

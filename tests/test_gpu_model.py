@@ -376,6 +376,51 @@ def test_stream_schedule_does_not_change_results(model_class):
         assert torch.equal(g, ref_g), (side, chunks, float((g - ref_g).abs().max()))
 
 
+@pytest.mark.parametrize('model_class', ['vae', 'beta-tcvae', 'ps-vae', 'cond-vae'])
+def test_multichunk_variational_vs_oracle(model_class):
+    """Two-chunk batches (200 + 10 frames) of the variational models: the single-pass schedule
+    (latents sampled and every loss term normalised per chunk) against the oracle's
+    chunk-by-chunk loop, same eps per chunk: loss dict and accumulated gradients."""
+    from tests.golden_utils import make_labels
+    dim, n_lat, n_frames = [1, 32, 32], 8, 210
+    extra = {'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0, 'max_n_epochs': 10,
+             'beta_tcvae.beta': 3.0, 'beta_tcvae.beta_anneal_epochs': 5,
+             'ps_vae.alpha': 10, 'ps_vae.beta': 5, 'ps_vae.anneal_epochs': 5,
+             'conditional_encoder': False}
+    n_labels = 4 if model_class in ('ps-vae', 'cond-vae') else 0
+    meta = {'dim': dim, 'n_lat': n_lat, 'model_class': model_class, 'extra_hp': extra,
+            'n_labels': n_labels, 'n_frames': n_frames}
+    hip, ora, hp = _pair(meta)
+    data_c = case_data(meta)
+    data_g = {k: v.to(DEV) for k, v in data_c.items()}
+    # One LeakyReLU pre-activation out of ~3e6 that lands within fp32 rounding of zero (seen:
+    # -1e-10 in float64, +9e-10 here, layer maximum 4e-2) flips its slope and moves the decoder
+    # gradients by 1e-3 (tools/diag_condvae2.py); the eps seeds below give batches without one.
+    seed = int(os.environ.get('BN_TEST_EPS_SEED', {'cond-vae': 10}.get(model_class, 9)))
+    g = torch.Generator().manual_seed(seed)
+    eps = [torch.randn((n, n_lat), generator=g).numpy() for n in (200, 10)]
+    hip.train()
+    ora.train()
+    hip.curr_epoch = ora.curr_epoch = 3
+    ora.eps_fn = EpsReplay(eps)
+    hip_vaes.set_eps_provider(EpsReplay(eps, DEV))
+    try:
+        hip.zero_grad()
+        ora.zero_grad()
+        loss_o = ora.loss(data_c, dataset=0, accumulate_grad=True)
+        loss_h = hip.loss(data_g, dataset=0, accumulate_grad=True)
+    finally:
+        hip_vaes.set_eps_provider(None)
+    assert sorted(loss_h.keys()) == sorted(loss_o.keys())
+    for k in loss_o:
+        assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-6), k
+    for (k, ph), (_, po) in zip(hip.named_parameters(), ora.named_parameters()):
+        if po.grad is None:
+            assert ph.grad is None or not ph.requires_grad
+            continue
+        close(ph.grad, po.grad, name='%s grad %s' % (model_class, k))
+
+
 def test_host_u8_prefetch_feed_is_bit_identical():
     """The pinned-uint8 feed with one-trial look-ahead hands out exactly the frames the resident
     float32 feed does (two epochs over two sessions of ragged trials, same RNG consumption)."""
