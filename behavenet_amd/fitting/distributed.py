@@ -22,8 +22,14 @@ import torch
 import torch.distributed as dist
 
 
+# BN_DIST_FORCE=1 keeps the collective code paths on for a world of ONE rank (a 1-GPU box then
+# runs the real RCCL launches and stream hand-offs; used by tests/test_gpu_model.py)
+_FORCE = os.environ.get('BN_DIST_FORCE', '0') == '1'
+
+
 def is_active():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and \
+        (dist.get_world_size() > 1 or _FORCE)
 
 
 def world_size():
@@ -39,8 +45,9 @@ def init_from_env(backend=None):
     if dist.is_initialized():
         return rank(), world_size()
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1:
+    if ws <= 1 and not _FORCE:
         return 0, 1
+    os.environ.setdefault('RANK', '0')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
@@ -70,6 +77,147 @@ def all_reduce_flat_(flat, average=False):
     if average:
         flat.div_(world_size())
     return flat
+
+
+class BucketedGradReducer(object):
+    """All-reduce of the flat gradient arena in buckets, overlapped with the backward pass.
+
+    The arena (``FlatAdamAMSGrad.flat_g``) holds the parameters in ``get_parameters()`` order --
+    encoder first, decoder last -- and the backward pass finishes them in (nearly) the reverse
+    order, so buckets are contiguous arena segments cut from the END of the arena every
+    ``bucket_bytes``.  A bucket goes out as soon as the kernels that write its last gradient have
+    been ISSUED (``hip_functions`` reports each parameter through ``grad_ready``): the collective
+    is launched on a stream that waits for the main and the weight-gradient streams at that
+    point, and RCCL moves it over xGMI while the rest of the backward pass computes.  Whatever
+    was not reported (chunked schedules, gradients produced by plain autograd) is reduced by
+    ``finish()``, in arena order, so every rank issues the same sequence of collectives.
+    """
+
+    def __init__(self, optimizer, bucket_bytes=None):
+        self.opt = optimizer
+        self.flat = optimizer.flat_g
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get('BN_BUCKET_MB', '4')) * (1 << 20))
+        # cut from the end of the arena
+        self.buckets = []            # [lo, hi) element ranges, in launch (= reverse arena) order
+        self._bucket_of = {}
+        hi, acc, members = self.flat.numel(), 0, []
+        params = list(zip(optimizer.params, optimizer.offsets))
+        for p, off in reversed(params):
+            members.append(p)
+            acc += p.numel() * 4
+            if acc >= bucket_bytes or off == 0:
+                self._add_bucket(off, hi, members)
+                hi, acc, members = off, 0, []
+        self._pending = []
+        self._missing = None
+        self._launched = None
+        self._stream = None
+        self.begin()
+
+    def _add_bucket(self, lo, hi, members):
+        index = len(self.buckets)
+        self.buckets.append((lo, hi, len(members)))
+        for p in members:
+            self._bucket_of[id(p)] = index
+
+    def begin(self):
+        """Start of a step (before any backward pass): nothing reported, nothing in flight."""
+        self._drain()
+        self._missing = [n for _, _, n in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._seen = set()
+        self.n_overlapped = 0        # buckets of this step that went out during the backward pass
+        if self.flat.is_cuda:
+            from behavenet_amd import hip_functions as hf
+            hf.reset_grad_ready()
+
+    def grad_ready(self, p):
+        """The kernels writing ``p.grad`` for this step have all been issued."""
+        if not is_active():
+            return
+        b = self._bucket_of.get(id(p))
+        if b is None or id(p) in self._seen or self._launched[b]:
+            return
+        self._seen.add(id(p))
+        self._missing[b] -= 1
+        # in order only: every rank must issue the same sequence of collectives
+        while True:
+            nxt = self._launched.index(False) if False in self._launched else None
+            if nxt is None or self._missing[nxt] > 0:
+                break
+            self._launch(nxt, overlapped=True)
+
+    def _launch(self, b, overlapped):
+        lo, hi, _ = self.buckets[b]
+        seg = self.flat[lo:hi]
+        self._launched[b] = True
+        self.n_overlapped += int(overlapped)
+        if seg.is_cuda and overlapped:
+            from behavenet_amd import hip_functions as hf
+            dev = seg.device
+            main = torch.cuda.current_stream(dev)
+            ev_main = torch.cuda.Event()
+            ev_main.record(main)
+            side = hf._side_streams.get(dev.index)
+            if os.environ.get('BN_COMM_VIA_SIDE', '0') == '1' and side is not None:
+                launch = side
+                launch.wait_event(ev_main)
+            else:
+                if self._stream is None:
+                    self._stream = torch.cuda.Stream(device=dev)
+                launch = self._stream
+                launch.wait_event(ev_main)
+                if side is not None:
+                    ev_side = torch.cuda.Event()
+                    ev_side.record(side)
+                    launch.wait_event(ev_side)
+            with torch.cuda.stream(launch):
+                work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+        self._pending.append(work)
+
+    def _drain(self):
+        for work in self._pending:
+            work.wait()
+        self._pending = []
+
+    def finish(self):
+        """Before ``optimizer.step()``: reduce what is left and wait for everything."""
+        if not is_active():
+            return
+        if self.flat.is_cuda:
+            from behavenet_amd.hip_functions import join_side_streams
+            join_side_streams()
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b, overlapped=False)
+        self._drain()
+
+
+def attach_reducer(optimizer):
+    """Give a flat-arena optimizer an overlapped bucketed reducer (BN_OVERLAP_ALLREDUCE=0: one
+    flat all-reduce after the backward pass instead)."""
+    if not is_active() or getattr(optimizer, 'flat_g', None) is None:
+        return None
+    if os.environ.get('BN_OVERLAP_ALLREDUCE', '1') == '0':
+        return None
+    reducer = BucketedGradReducer(optimizer)
+    optimizer.reducer = reducer
+    if optimizer.flat_g.is_cuda:
+        from behavenet_amd import hip_functions as hf
+        hf.set_grad_ready_callback(reducer.grad_ready)
+    return reducer
+
+
+def reduce_gradients(optimizer):
+    """Sum the gradients over ranks before ``optimizer.step()``."""
+    reducer = getattr(optimizer, 'reducer', None)
+    if reducer is not None:
+        reducer.finish()
+    elif getattr(optimizer, 'flat_g', None) is not None:
+        all_reduce_flat_(optimizer.flat_g)
 
 
 def all_reduce_scalars(values):

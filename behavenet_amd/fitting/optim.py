@@ -64,6 +64,8 @@ class FlatAdamAMSGrad(object):
 
     def zero_grad(self):
         join_side_streams()   # pending side-stream accumulations must not race the memset
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.begin()   # collectives of a step that was not applied are waited for
         self._grads_in_arena()
         self.flat_g.zero_()
 

@@ -135,6 +135,7 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
     flat_g = getattr(optimizer, 'flat_g', None)
     if bdist.is_active() and getattr(optimizer, 'flat_p', None) is not None:
         bdist.broadcast_parameters_(optimizer.flat_p)
+        bdist.attach_reducer(optimizer)
 
     logger = Logger(n_datasets=data_generator.n_datasets)
     early_stop = None
@@ -185,7 +186,7 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
                 logger.update_metrics('train', loss_dict, dataset=dataset)
                 if i_epoch > 0:
                     if flat_g is not None:
-                        bdist.all_reduce_flat_(flat_g)
+                        bdist.reduce_gradients(optimizer)
                     optimizer.step()
 
             if (i_train + 1) % n_train == 0:

@@ -42,7 +42,54 @@ class accumulate_into_param_grads(object):
         return False
 
 
-def backward_chunks(chunk_losses, streams=None):
+# Single-pass schedule only (ONE backward per step): number of bottom layers of the LAST stack in
+# the backward order (the encoder) whose weight gradients are issued on the main stream, after
+# its data-gradient chain, instead of on the side stream.  The side stream lags the main one, so
+# without this the last ~0.6 ms of a step run one weight-gradient kernel at a time.
+_tail_on_main = 0
+_TAIL_LAYERS = int(os.environ.get('BN_WGRAD_TAIL', '2'))
+
+# Data-parallel runs: fitting/distributed.BucketedGradReducer asks to be told when the kernels
+# that complete a parameter's gradient have been issued, so that it can start that bucket's
+# all-reduce under the rest of the backward pass.  Reported only in the single-pass schedule (one
+# backward per step) and only for gradients the kernels write in place; a parameter used by
+# several nodes of one graph is reported by the last of them.
+_single_pass = False
+_grad_ready_cb = None
+_param_uses = {}
+
+
+def set_grad_ready_callback(fn):
+    global _grad_ready_cb
+    _grad_ready_cb = fn
+    _param_uses.clear()
+
+
+def reset_grad_ready():
+    _param_uses.clear()
+
+
+def _note_use(params, needed):
+    """Called from Function.forward: `needed` is false under no_grad (no backward will come)."""
+    if _grad_ready_cb is not None and needed:
+        for p in params:
+            if p is not None:
+                _param_uses[id(p)] = _param_uses.get(id(p), 0) + 1
+
+
+def _report_ready(params):
+    if _grad_ready_cb is None or not _single_pass:
+        return
+    for p in params:
+        if p is None:
+            continue
+        left = _param_uses.get(id(p), 0) - 1
+        _param_uses[id(p)] = left
+        if left == 0:
+            _grad_ready_cb(p)
+
+
+def backward_chunks(chunk_losses, streams=None, single_pass=False):
     """Run the per-chunk backward passes, in chunk order, after ALL chunk forwards.
 
     The reference interleaves forward and backward per chunk (aes.py:748-769); the parameters do
@@ -51,6 +98,9 @@ def backward_chunks(chunk_losses, streams=None):
     stream idle and the tail of chunk c's weight gradients overlaps the head of chunk c+1's data
     gradients.
     """
+    global _tail_on_main, _single_pass
+    _single_pass = bool(single_pass and len(chunk_losses) == 1)
+    _tail_on_main = _TAIL_LAYERS if _single_pass else 0
     with accumulate_into_param_grads():
         for i, loss in enumerate(chunk_losses):
             # called from the chunk's own stream: autograd orders the graph's streams after the
@@ -62,6 +112,8 @@ def backward_chunks(chunk_losses, streams=None):
                     loss.backward()
             else:
                 loss.backward()
+    _tail_on_main = 0
+    _single_pass = False
 
 
 class Readback(object):
@@ -307,6 +359,7 @@ class ConvStackFn(torch.autograd.Function):
         ctx.plan = plan
         ctx.need_dx = x.requires_grad
         ctx.param_refs = params
+        _note_use(params, any(ctx.needs_input_grad[3:]))
         ctx.save_for_backward(*acts, *params[0::2])
         return h
 
@@ -326,6 +379,7 @@ class ConvStackFn(torch.autograd.Function):
             dpre = dout
 
         grads = [None] * (2 * n_layers)
+        tail = []     # weight gradients deferred to the main stream (see _tail_on_main)
         for i in range(n_layers - 1, -1, -1):
             layer = plan[i]
             g = layer.geom(n)
@@ -345,7 +399,9 @@ class ConvStackFn(torch.autograd.Function):
                         else None
                 wgrad = _hip.conv2d_bwd_weight if layer.kind == 'conv' else _hip.convT2d_bwd_weight
                 side = _side_stream(w.device) if (direct and _use_side_stream) else None
-                if side is not None:
+                if side is not None and not ctx.need_dx and i < _tail_on_main:
+                    tail.append(((wgrad, x_in, dpre, dw, db, g), ctx.param_refs[2 * i:2 * i + 2]))
+                elif side is not None:
                     # weight gradients go to a second HIP stream: they only depend on dpre and the
                     # saved input, while the main stream continues down the data-gradient chain;
                     # the tail of one kernel is filled by workgroups of the other.  Gradients
@@ -358,8 +414,11 @@ class ConvStackFn(torch.autograd.Function):
                         wgrad(x_in, dpre, dw, db, g, True)
                     dpre.record_stream(side)
                     x_in.record_stream(side)
+                    _report_ready(ctx.param_refs[2 * i:2 * i + 2])
                 else:
                     wgrad(x_in, dpre, dw, db, g, direct)
+                    if direct:
+                        _report_ready(ctx.param_refs[2 * i:2 * i + 2])
                 if not direct:
                     grads[2 * i], grads[2 * i + 1] = dw, db
             if i > 0 or ctx.need_dx:
@@ -370,6 +429,9 @@ class ConvStackFn(torch.autograd.Function):
                     dpre = _hip.conv2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
                 else:
                     dpre = _hip.convT2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
+        for (wgrad, x_in, dy, dw, db, g), refs in tail:
+            wgrad(x_in, dy, dw, db, g, True)
+            _report_ready(refs)
         dx = dpre if ctx.need_dx else None
         return (None, dx, None) + tuple(grads)
 
@@ -470,6 +532,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
         ctx.param_refs = (w, b)
+        _note_use((w, b), ctx.needs_input_grad[1])
         return _hip.linear_fwd(x, w.detach().contiguous(),
                                b.detach() if b is not None else None)
 
@@ -501,9 +564,11 @@ class LinearFn(torch.autograd.Function):
                 _hip.linear_bwd(x, wc, dy, False, None, _hip.ACT_NONE, 0.0, dw, db, True)
             dy.record_stream(side)
             x.record_stream(side)
+            _report_ready(ctx.param_refs)
             return dx, None, None
         dx = _hip.linear_bwd(x, wc, dy, need_dx, None, _hip.ACT_NONE, 0.0, dw, db, direct)
         if direct:
+            _report_ready(ctx.param_refs)
             return dx, None, None
         return dx, dw, db
 

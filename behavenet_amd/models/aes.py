@@ -505,7 +505,7 @@ class AE(BaseModel):
             chunk_losses = losses.mse_chunks(x, x_hat, m, bounds)
         vals = Readback(chunk_losses.detach())
         if accumulate_grad:
-            backward_chunks([chunk_losses.sum()])
+            backward_chunks([chunk_losses.sum()], single_pass=True)
         join_side_streams()
         vals = vals.numpy().astype(np.float64)
         sizes = np.asarray([end - beg for beg, end in bounds], dtype=np.float64)

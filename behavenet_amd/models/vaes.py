@@ -65,7 +65,7 @@ def _finish_whole(table, total, accumulate_grad):
     """Read back the (n_chunks, n_keys) scalar table, run the single backward, join streams."""
     rb = hf.Readback(table.detach())
     if accumulate_grad:
-        hf.backward_chunks([total])
+        hf.backward_chunks([total], single_pass=True)
     hf.join_side_streams()
     return rb.numpy().astype(np.float64)
 

@@ -73,7 +73,7 @@ def one_step(model, opt, gen):
     if t: t.append(time.perf_counter())
     loss = model.loss(data, dataset=dataset, accumulate_grad=True)
     if t: t.append(time.perf_counter())
-    bdist.all_reduce_flat_(opt.flat_g)
+    bdist.reduce_gradients(opt)
     opt.step()
     if t:
         t.append(time.perf_counter())
@@ -146,6 +146,7 @@ def main():
     opt = FlatAdamAMSGrad(model.get_parameters(), lr=hp['learning_rate'],
                           weight_decay=hp['l2_reg'])
     bdist.broadcast_parameters_(opt.flat_p)
+    bdist.attach_reducer(opt)
 
     # 20 trials x 256 frames per rank, trial_splits 8;1;1;0 -> 16 train trials
     sess = SyntheticSession(20, BATCH, DIM, seed=100 + rank, trial_splits='8;1;1;0')

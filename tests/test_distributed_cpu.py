@@ -94,3 +94,72 @@ def test_shard_bounds_partition():
             assert edges[0][0] == 10 and edges[-1][1] == 10 + n
             for a, b in zip(edges[:-1], edges[1:]):
                 assert a[1] == b[0]
+
+
+class _ArenaStub(object):
+    """What BucketedGradReducer reads of FlatAdamAMSGrad: params, offsets, flat_g."""
+
+    def __init__(self, sizes, align=64):
+        self.params = [torch.nn.Parameter(torch.zeros(n)) for n in sizes]
+        self.offsets, total = [], 0
+        for n in sizes:
+            self.offsets.append(total)
+            total += (n + align - 1) // align * align
+        self.flat_g = torch.zeros(total)
+
+
+def _reducer_worker(rank, world, port, out):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+                       'RANK': str(rank), 'WORLD_SIZE': str(world)})
+    torch.set_num_threads(1)
+    bdist.init_from_env(backend='gloo')
+    # encoder-like then decoder-like sizes (floats); 4 KiB buckets
+    sizes = [100, 800, 3000, 50, 60, 2500, 900, 30]
+    opt = _ArenaStub(sizes)
+    red = bdist.BucketedGradReducer(opt, bucket_bytes=4096)
+    spans = sorted((lo, hi) for lo, hi, _ in red.buckets)
+    assert spans[0][0] == 0 and spans[-1][1] == opt.flat_g.numel()
+    assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+    results = []
+    for step, order in enumerate([[7, 6, 5, 4, 3, 2, 1, 0],       # everything reported, in order
+                                  [5, 7, 6, 3, 4],                # out of order, three missing
+                                  []]):                           # chunked schedule: none
+        red.begin()
+        g = torch.Generator().manual_seed(10 * step + rank)
+        opt.flat_g.copy_(torch.randn(opt.flat_g.shape, generator=g))
+        launched_before_finish = []
+        for i in order:
+            red.grad_ready(opt.params[i])
+            launched_before_finish.append(sum(red._launched))
+        n_early = sum(red._launched)
+        red.finish()
+        assert all(red._launched)
+        results.append((opt.flat_g.clone().numpy(), n_early, launched_before_finish))
+    if rank == 0:
+        out.put(results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_reducer_equals_flat_all_reduce():
+    """Overlapped bucket launches + finish() == one all-reduce of the arena, whatever subset of
+    parameters was reported and in whatever order (collectives stay in bucket order)."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = out.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = results[0][0].shape[0]
+    for step, (got, n_early, trace) in enumerate(results):
+        want = sum(torch.randn((n,), generator=torch.Generator().manual_seed(10 * step + r))
+                   for r in range(2)).numpy()
+        np.testing.assert_allclose(got, want, rtol=0, atol=0)
+        assert trace == sorted(trace)
+    assert results[0][1] == max(results[0][2]) >= 3     # every bucket went out before finish()
+    assert 0 < results[1][1] < results[0][1]     # a missing parameter holds its bucket and later ones
+    assert results[2][1] == 0

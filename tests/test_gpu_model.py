@@ -421,6 +421,24 @@ def test_multichunk_variational_vs_oracle(model_class):
         close(ph.grad, po.grad, name='%s grad %s' % (model_class, k))
 
 
+def test_overlapped_bucketed_all_reduce_single_rank_rccl():
+    """The data-parallel gradient exchange on the real RCCL path (a one-rank process group): every
+    bucket but the last goes out during the backward pass and the trained parameters are
+    bit-identical to the run without it.  (World size 2 is covered on gloo, CPU suite.)"""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dist_single_rank_check.py')
+    env = dict(os.environ, BN_DIST_FORCE='1', BN_BUCKET_MB='4')
+    res = subprocess.run([sys.executable, script, '210'], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1])
+    assert out['identical'] and out['losses_identical'], out
+    assert out['n_buckets'] >= 3
+    # single-pass schedule: all buckets are launched from inside the backward pass
+    assert all(n == out['n_buckets'] for n in out['overlapped_per_step']), out
+
+
 def test_host_u8_prefetch_feed_is_bit_identical():
     """The pinned-uint8 feed with one-trial look-ahead hands out exactly the frames the resident
     float32 feed does (two epochs over two sessions of ragged trials, same RNG consumption)."""
