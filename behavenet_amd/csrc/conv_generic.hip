@@ -254,7 +254,7 @@ __global__ void k_channel_sum_final(const float* __restrict__ part, float* __res
 static int channel_sum_splits(int N, int C, int npix) {
     if ((long)N * npix < 32768) return 1;
     int s = 1024 / C;
-    if (s > 64) s = 64;
+    if (s > 256) s = 256;     // one channel (dec.convT4's bias): 256 frame slices
     if (s > N) s = N;
     return s < 1 ? 1 : s;
 }
@@ -286,26 +286,30 @@ int bn_launch_channel_sum(const float* t, float* db, int N, int C, int npix, int
 // second pass of split reductions (declared in bn_reduce.h)
 // ---------------------------------------------------------------------------------------------
 #include "bn_reduce.h"
-__global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part,
-                                                      float* __restrict__ out, int total,
-                                                      int splits, int accumulate, int ab_elems,
-                                                      int ntap, int row_len, int row_stride) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__ part,
+                                                       float* __restrict__ out, int total,
+                                                       int splits, int accumulate, int ab_elems,
+                                                       int ntap, int row_len, int row_stride) {
+    __shared__ float red[16][64];
     const int il = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const int nz = blockDim.x >> 6;                 // z-lanes: 4, or 16 for many partials
     const int i = blockIdx.x * 64 + il;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < total) {
         int z = zl;
-        for (; z + 12 < splits; z += 16) {
+        for (; z + 3 * nz < splits; z += 4 * nz) {
             s0 += part[(size_t)z * total + i];
-            s1 += part[(size_t)(z + 4) * total + i];
-            s2 += part[(size_t)(z + 8) * total + i];
-            s3 += part[(size_t)(z + 12) * total + i];
+            s1 += part[(size_t)(z + nz) * total + i];
+            s2 += part[(size_t)(z + 2 * nz) * total + i];
+            s3 += part[(size_t)(z + 3 * nz) * total + i];
         }
-        for (; z < splits; z += 4) s0 += part[(size_t)z * total + i];
+        for (; z < splits; z += nz) s0 += part[(size_t)z * total + i];
     }
     red[zl][il] = (s0 + s1) + (s2 + s3);
     __syncthreads();
+    if (nz == 16 && zl < 4)
+        red[zl][il] = (red[zl][il] + red[zl + 4][il]) + (red[zl + 8][il] + red[zl + 12][il]);
+    if (nz == 16) __syncthreads();
     if (zl == 0 && i < total) {
         const float v = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
         size_t o = i;

@@ -334,6 +334,11 @@ def first_layer_forward(plan, x, params):
     return _fwd(plan[0], x.contiguous(), params[0].detach(), params[1].detach())
 
 
+# Tests only (tests/branches.py): when a dict, every ConvStackFn.forward records the sign of its
+# LeakyReLU outputs, keyed by id(plan), one list per layer in call order.
+_sign_tap = None
+
+
 class ConvStackFn(torch.autograd.Function):
     """y = layer_L(...layer_1(x)); params = (w_1, b_1, ..., w_L, b_L).
 
@@ -356,6 +361,11 @@ class ConvStackFn(torch.autograd.Function):
             else:
                 h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach())
             acts.append(h)
+        if _sign_tap is not None:
+            rec = _sign_tap.setdefault(id(plan), [[] for _ in plan])
+            for i, layer in enumerate(plan):
+                if layer.act == _hip.ACT_LRELU:
+                    rec[i].append((acts[i + 1] > 0).cpu())
         ctx.plan = plan
         ctx.need_dx = x.requires_grad
         ctx.param_refs = params

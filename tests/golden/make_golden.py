@@ -238,6 +238,52 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
     print('%s written (%.1f KB)' % (path, os.path.getsize(path) / 1024))
 
 
+def decoder_case(name, dim, n_labels, n_frames, n_fwd=8):
+    """ConvDecoder (labels -> images, ref decoders.py:355-496): parameters from the seed, forward,
+    loss, gradients and a 3-step Adam(amsgrad) trajectory."""
+    from behavenet.models.decoders import ConvDecoder as RefConvDecoder
+    arch = ref_arch.load_handcrafted_arch(list(dim), 8, None, check_memory=False)
+    hp = base_hparams(arch, 'conv-decoder', None)
+    hp['n_labels'] = n_labels
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = RefConvDecoder(hp)
+    model.train()
+    store = {}
+    for k, v in model.state_dict().items():
+        tensor_record(store, 'param0/' + k, v, full_limit=1024)
+    x = torch.from_numpy(make_frames(n_frames, dim, seed=1))
+    y = torch.from_numpy(make_labels(n_frames, n_labels, seed=2))
+    data = {'images': x[None], 'labels': y[None]}
+    with torch.no_grad():
+        out = model(y[:n_fwd], dataset=0)
+    store['fwd/x_hat'] = out.numpy().astype(np.float32)
+    store['fwd/x_hat/checksum'] = checksum(out.numpy())
+    model.zero_grad()
+    loss_dict = model.loss(data, dataset=0, accumulate_grad=True)
+    store['loss/keys'] = np.array(sorted(loss_dict.keys()))
+    store['loss/vals'] = np.array([float(loss_dict[k]) for k in sorted(loss_dict.keys())],
+                                  dtype=np.float64)
+    for k, p in model.named_parameters():
+        tensor_record(store, 'grad/' + k, p.grad, full_limit=4096)
+    opt = torch.optim.Adam(model.get_parameters(), lr=hp['learning_rate'],
+                           weight_decay=hp.get('l2_reg', 0), amsgrad=True)
+    traj = []
+    for step in range(3):
+        opt.zero_grad()
+        traj.append(float(model.loss(data, dataset=0, accumulate_grad=True)['loss']))
+        opt.step()
+    store['adam/losses'] = np.array(traj, dtype=np.float64)
+    for k, p in model.named_parameters():
+        tensor_record(store, 'adam/param/' + k, p, full_limit=1024)
+    meta = {'dim': list(dim), 'n_lat': 8, 'n_frames': n_frames, 'model_class': 'conv-decoder',
+            'n_labels': n_labels, 'extra_hp': {}, 'n_fwd': n_fwd, 'curr_epoch': 0}
+    store['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **store)
+    print('%s written (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+
+
 class ListExp(object):
     """Stand-in for test_tube.Experiment: collects rows."""
     version = 0
@@ -286,6 +332,9 @@ if __name__ == '__main__':
         model_case('vae_1x64x48_bn', RefVAE, [1, 64, 48], 8, 6, 'vae',
                    extra_hp={'ae_batch_norm': True, 'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0,
                              'max_n_epochs': 10})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'convdec':
+        decoder_case('convdecoder_cfg1', [1, 32, 32], 4, 210)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'msp':
         from behavenet.models.aes import AEMSP as RefAEMSP

@@ -21,18 +21,19 @@ from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSession
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
 from behavenet_amd.fitting.training import fit
 from behavenet_amd.fitting import losses
-from behavenet_amd.models import AE, AEMSP, VAE, ConditionalVAE, BetaTCVAE, PSVAE
+from behavenet_amd.models import AE, AEMSP, VAE, ConditionalVAE, BetaTCVAE, PSVAE, ConvDecoder
 from behavenet_amd.models import vaes as hip_vaes
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from oracle import ref_cpu
 from tests.cases import load_case, case_hparams, case_data, seeded_build, EpsReplay, eps_list
 from tests.golden_utils import base_hparams, checksum, checksum_close, make_frames
 from tests.test_gpu_kernels import close
+from tests.branches import record_branches, BranchReplay
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 BUILDERS = {'ae': AE, 'vae': VAE, 'cond-vae': ConditionalVAE, 'beta-tcvae': BetaTCVAE,
-            'ps-vae': PSVAE, 'cond-ae-msp': AEMSP}
+            'ps-vae': PSVAE, 'cond-ae-msp': AEMSP, 'conv-decoder': ConvDecoder}
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
@@ -55,6 +56,19 @@ def _bias_before_batchnorm(key, names):
     head = '.'.join(parts[:-2])
     num = ''.join(ch for ch in parts[-2].split('_')[0] if ch.isdigit())
     return '%s.batchnorm%s.weight' % (head, num) in names
+
+
+def grads_close_on_same_branches(hip, ora64, name, tol=2e-5):
+    """Gradients of the HIP model against a float64 oracle that was run on the branch pattern the
+    HIP forward took (tests/branches.py): what remains is rounding, so the bar is 2e-5 of each
+    tensor's maximum instead of the 1e-4 of the plain comparisons."""
+    for (k, ph), (_, po) in zip(hip.named_parameters(), ora64.named_parameters()):
+        if po.grad is None:
+            assert ph.grad is None or not ph.requires_grad
+            continue
+        w = po.grad.numpy()
+        err = np.abs(ph.grad.cpu().double().numpy() - w).max() / max(np.abs(w).max(), 1e-30)
+        assert err <= tol, '%s grad %s: normalised max err %.3e' % (name, k, err)
 
 
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
@@ -393,32 +407,91 @@ def test_multichunk_variational_vs_oracle(model_class):
     hip, ora, hp = _pair(meta)
     data_c = case_data(meta)
     data_g = {k: v.to(DEV) for k, v in data_c.items()}
-    # One LeakyReLU pre-activation out of ~3e6 that lands within fp32 rounding of zero (seen:
-    # -1e-10 in float64, +9e-10 here, layer maximum 4e-2) flips its slope and moves the decoder
-    # gradients by 1e-3 (tools/diag_condvae2.py); the eps seeds below give batches without one.
-    seed = int(os.environ.get('BN_TEST_EPS_SEED', {'cond-vae': 10}.get(model_class, 9)))
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator().manual_seed(9)
     eps = [torch.randn((n, n_lat), generator=g).numpy() for n in (200, 10)]
-    hip.train()
-    ora.train()
-    hip.curr_epoch = ora.curr_epoch = 3
+    # float64 oracle: on 210 noise frames a LeakyReLU pre-activation within fp32 rounding of zero
+    # is the rule, not the exception (for cond-vae with this seed: -1e-10 in float64, +9e-10 on
+    # the device, layer maximum 4e-2, and the decoder gradients move by 1e-3), so the gradients
+    # are compared on the branch pattern the device took, and that pattern is checked to differ
+    # from the oracle's own only at such ties
+    ora64 = seeded_build(ref_cpu.build_model, case_hparams(meta)).double()
+    data64 = {k: v.double() for k, v in data_c.items()}
+    for m in (hip, ora, ora64):
+        m.train()
+        m.curr_epoch = 3
     ora.eps_fn = EpsReplay(eps)
+    ora64.eps_fn = EpsReplay([e.astype(np.float64) for e in eps])
     hip_vaes.set_eps_provider(EpsReplay(eps, DEV))
     try:
         hip.zero_grad()
         ora.zero_grad()
-        loss_o = ora.loss(data_c, dataset=0, accumulate_grad=True)
-        loss_h = hip.loss(data_g, dataset=0, accumulate_grad=True)
+        ora64.zero_grad()
+        loss_o = ora.loss(data_c, dataset=0, accumulate_grad=False)
+        with record_branches(hip) as rec:
+            loss_h = hip.loss(data_g, dataset=0, accumulate_grad=True)
+        with BranchReplay(rec) as br:
+            ora64.loss(data64, dataset=0, accumulate_grad=True)
     finally:
         hip_vaes.set_eps_provider(None)
+    assert sorted(rec.keys()) == ['decoding', 'encoding']
+    br.assert_only_ties()
     assert sorted(loss_h.keys()) == sorted(loss_o.keys())
     for k in loss_o:
         assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-6), k
+    grads_close_on_same_branches(hip, ora64, model_class)
+
+
+def test_conv_decoder_vs_oracle_and_golden():
+    """ConvDecoder (labels -> images, ref decoders.py:355-496), 210 frames = two chunks: forward,
+    loss, accumulated gradients and the Adam(amsgrad) trajectory against the oracle and the
+    vectors recorded from the reference."""
+    z, meta = load_case('convdecoder_cfg1')
+    hip, ora, hp = _pair(meta)
+    data_c = case_data(meta)
+    data_g = {k: v.to(DEV) for k, v in data_c.items()}
+    n_fwd = meta['n_fwd']
+    hip.train()
+    ora.train()
+    with torch.no_grad():
+        out_h = hip(data_g['labels'][0][:n_fwd], dataset=0)
+        out_o = ora(data_c['labels'][0][:n_fwd], dataset=0)
+    assert isinstance(out_h, torch.Tensor)
+    close(out_h, out_o, name='convdecoder fwd')
+    close(out_h, torch.from_numpy(z['fwd/x_hat']), name='convdecoder fwd golden')
+    hip.zero_grad()
+    ora.zero_grad()
+    loss_h = hip.loss(data_g, dataset=0, accumulate_grad=True)
+    loss_o = ora.loss(data_c, dataset=0, accumulate_grad=True)
+    assert sorted(loss_h.keys()) == ['loss']
+    assert loss_h['loss'] == pytest.approx(loss_o['loss'], rel=1e-4)
+    assert loss_h['loss'] == pytest.approx(float(z['loss/vals'][0]), rel=1e-4)
+    # gradients: on the branch pattern the device took (see tests/branches.py); the golden
+    # checksums of the reference's gradients are matched by the plain oracle on the CPU
+    # (tests/test_oracle_golden.py)
+    ora64 = seeded_build(ref_cpu.build_model, case_hparams(meta)).double()
+    ora64.train()
+    hip.zero_grad()
+    with record_branches(hip) as rec:
+        hip.loss(data_g, dataset=0, accumulate_grad=True)
+    with BranchReplay(rec) as br:
+        ora64.loss({k: v.double() for k, v in data_c.items()}, dataset=0, accumulate_grad=True)
+    br.assert_only_ties()
+    grads_close_on_same_branches(hip, ora64, 'convdecoder')
     for (k, ph), (_, po) in zip(hip.named_parameters(), ora.named_parameters()):
-        if po.grad is None:
-            assert ph.grad is None or not ph.requires_grad
-            continue
-        close(ph.grad, po.grad, name='%s grad %s' % (model_class, k))
+        close(ph.grad, po.grad, name='convdecoder grad ' + k, norm_tol=2e-3)
+    # no gradient side effects without accumulate_grad
+    hip.zero_grad()
+    val = hip.loss(data_g, dataset=0, accumulate_grad=False)
+    assert val['loss'] == pytest.approx(loss_h['loss'], rel=1e-6)
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0 for p in hip.parameters())
+    opt = FlatAdamAMSGrad(hip.get_parameters(), lr=hp['learning_rate'],
+                          weight_decay=hp.get('l2_reg', 0))
+    traj = []
+    for _ in range(3):
+        opt.zero_grad()
+        traj.append(hip.loss(data_g, dataset=0, accumulate_grad=True)['loss'])
+        opt.step()
+    np.testing.assert_allclose(traj, z['adam/losses'], rtol=1e-4)
 
 
 def test_overlapped_bucketed_all_reduce_single_rank_rccl():

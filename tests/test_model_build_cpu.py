@@ -105,3 +105,84 @@ def test_deepcopy_and_state_dict_roundtrip(tmp_path):
     other.load_state_dict(loaded)
     for k, v in other.state_dict().items():
         assert torch.equal(v, model.state_dict()[k])
+
+
+def test_conv_decoder_initial_parameters_bit_exact():
+    from behavenet_amd.models import ConvDecoder
+    z, meta = load_case('convdecoder_cfg1')
+    model = seeded_build(ConvDecoder, case_hparams(meta))
+    assert model.hparams['hidden_layer_size'] == meta['n_labels']
+    sd = model.state_dict()
+    want = sorted(k[len('param0/'):-len('/checksum')] for k in z.files
+                  if k.startswith('param0/') and k.endswith('/checksum'))
+    assert sorted(sd.keys()) == want
+    for k, v in sd.items():
+        np.testing.assert_array_equal(checksum(v.numpy()), z['param0/' + k + '/checksum'], k)
+    assert 'Convolutional decoder architecture' in str(model)
+
+
+class _LabelGen(object):
+    """Minimal generator: what build_model reads of it."""
+    n_datasets = 3
+
+    def __init__(self, n_labels):
+        self.n_labels, self.calls = n_labels, []
+
+    def next_batch(self, dtype):
+        self.calls.append(dtype)
+        return {'labels': torch.zeros((1, 5, self.n_labels))}, 0
+
+
+def test_model_dispatch_like_ae_grid_search(tmp_path):
+    """ref ae_grid_search.py:52-95: class by ``model_class``, seeding, n_datasets, n_labels from
+    one validation batch, pretrained weights, NotImplementedError for unknown classes."""
+    from behavenet_amd.fitting import ae_grid_search as ags
+    from behavenet_amd import models
+    z, meta = load_case('ae_cfg1')
+    extra = {'device': 'cpu', 'max_n_epochs': 2, 'vae.beta': 1, 'vae.beta_anneal_epochs': 0,
+             'beta_tcvae.beta': 1, 'beta_tcvae.beta_anneal_epochs': 0, 'ps_vae.alpha': 1,
+             'ps_vae.beta': 1, 'ps_vae.anneal_epochs': 0, 'msp.alpha': 0.1,
+             'conditional_encoder': False, 'rng_seed_model': 0}
+    want = {'ae': models.AE, 'vae': models.VAE, 'beta-tcvae': models.BetaTCVAE,
+            'ps-vae': models.PSVAE, 'cond-vae': models.ConditionalVAE,
+            'cond-ae': models.ConditionalAE, 'cond-ae-msp': models.AEMSP,
+            'conv-decoder': models.ConvDecoder}
+    assert sorted(want) == sorted(ags.MODEL_CLASSES)
+    for mc, cls in want.items():
+        hp = case_hparams(meta)
+        hp.update(extra)
+        hp['model_class'] = mc
+        gen = _LabelGen(4)
+        model = ags.build_model(hp, gen)
+        assert type(model) is cls
+        assert hp['n_datasets'] == 3
+        assert gen.calls == (['val'] if mc in ags.NEEDS_LABELS else [])
+        if mc in ags.NEEDS_LABELS:
+            assert hp['n_labels'] == 4
+        assert 'model_build_rng_seed' in hp and 'training_rng_seed' in hp
+    # same seed -> same parameters as a direct, seeded construction
+    hp = case_hparams(meta)
+    hp.update(extra)
+    model = ags.build_model(hp, n_datasets=1)
+    ref = seeded_build(models.AE, case_hparams(meta))
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), k
+    # pretrained weights (ref aes.py:1220-1265)
+    path = str(tmp_path / 'pre.pt')
+    with torch.no_grad():
+        ref.encoding.FF.bias.add_(1.0)
+    ref.save(path)
+    hp = case_hparams(meta)
+    hp.update(extra)
+    hp['pretrained_weights_path'] = path
+    model = ags.build_model(hp, n_datasets=1)
+    assert torch.equal(model.encoding.FF.bias, ref.encoding.FF.bias)
+    hp = case_hparams(meta)
+    hp.update(extra)
+    hp['model_class'] = 'msps-vae'
+    with pytest.raises(NotImplementedError):
+        ags.build_model(hp, n_datasets=2)
+    hp['model_class'] = 'cond-vae'
+    hp.pop('n_labels', None)
+    with pytest.raises(ValueError):
+        ags.build_model(hp, n_datasets=1)

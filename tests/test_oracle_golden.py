@@ -149,3 +149,33 @@ def test_oracle_loss_known_answers():
     assert ref_cpu.index_code_mi(zz, mu, lv).item() == mi.item()
     assert ref_cpu.total_correlation(zz, mu, lv).item() == tc.item()
     assert ref_cpu.dimension_wise_kl_to_std_normal(zz, mu, lv).item() == dw.item()
+
+
+def test_oracle_conv_decoder_matches_reference():
+    """ConvDecoder (labels -> images, ref decoders.py:355-496) on a two-chunk batch."""
+    torch.set_num_threads(8)
+    z, meta = load_case('convdecoder_cfg1')
+    hp = case_hparams(meta)
+    model = seeded_build(ref_cpu.build_model, hp)
+    sd = model.state_dict()
+    want_keys = sorted(k[len('param0/'):-len('/checksum')] for k in z.files
+                       if k.startswith('param0/') and k.endswith('/checksum'))
+    assert sorted(sd.keys()) == want_keys
+    for k, v in sd.items():
+        _check_tensor(z, 'param0/' + k, v, rtol=0.0, atol=0.0)
+    data = case_data(meta)
+    model.train()
+    with torch.no_grad():
+        out = model(data['labels'][0][:meta['n_fwd']], dataset=0)
+    np.testing.assert_allclose(out.numpy(), z['fwd/x_hat'], rtol=1e-5, atol=1e-6)
+    model.zero_grad()
+    loss = model.loss(data, dataset=0, accumulate_grad=True)
+    assert sorted(loss.keys()) == [str(k) for k in z['loss/keys']] == ['loss']
+    np.testing.assert_allclose(loss['loss'], z['loss/vals'][0], rtol=1e-6)
+    for k, p in model.named_parameters():
+        _check_tensor(z, 'grad/' + k, p.grad, rtol=2e-5, atol=1e-9)
+    opt = ref_cpu.make_optimizer(model, hp)
+    traj = [ref_cpu.train_step(model, opt, data)['loss'] for _ in range(3)]
+    np.testing.assert_allclose(traj, z['adam/losses'], rtol=1e-6)
+    for k, p in model.named_parameters():
+        _check_tensor(z, 'adam/param/' + k, p, rtol=1e-6, atol=1e-8)
