@@ -78,9 +78,12 @@ class SyntheticSessionsGenerator(object):
 
     _dtypes = ['train', 'val', 'test']
 
-    def __init__(self, sessions, device='cuda', placement='device'):
+    def __init__(self, sessions, device='cuda', placement='device', n_sessions_per_batch=1):
         if placement not in ('host', 'device_u8', 'device', 'host_u8'):
             raise ValueError('unknown placement "%s"' % placement)
+        if n_sessions_per_batch > 4:
+            raise NotImplementedError   # losses.triplet_loss covers 2-4 sessions (ref :687-689)
+        self.n_sessions_per_batch = int(n_sessions_per_batch)
         self.datasets = list(sessions)
         self.n_datasets = len(self.datasets)
         self.device = device
@@ -89,6 +92,10 @@ class SyntheticSessionsGenerator(object):
             k: sum(ds.n_batches[k] for ds in self.datasets) for k in self._dtypes}
         tot = float(sum(ds.n_batches['train'] for ds in self.datasets))
         self.batch_ratios = [ds.n_batches['train'] / tot for ds in self.datasets]
+        if self.n_sessions_per_batch > 1:
+            # several batches are served per training iteration (ref data_generator.py:697-699)
+            self.n_tot_batches['train'] = int(
+                self.n_tot_batches['train'] / self.n_sessions_per_batch)
         self._store = []
         for ds in self.datasets:
             trials = []
@@ -127,7 +134,28 @@ class SyntheticSessionsGenerator(object):
                 order = torch.randperm(len(idxs)).tolist()
                 self._queues[i][k] = [int(idxs[j]) for j in order]
 
-    def next_batch(self, dtype):
+    def next_batch(self, dtype, return_multiple=True):
+        """One trial, or -- for training with ``n_sessions_per_batch`` > 1 -- a list of trials
+        from that many DIFFERENT sessions plus the list of their ids (the multi-session batches
+        of the MSPS-VAE, ref data_generator.py:712-790): sessions are drawn without replacement
+        by ``batch_ratios``; ``(None, None)`` once too few sessions have trials left."""
+        if self.n_sessions_per_batch > 1 and dtype == 'train' and return_multiple:
+            samples, sessions = [], []
+            ratios = np.array(self.batch_ratios, dtype=np.float64)
+            for k in range(self.n_sessions_per_batch):
+                while True:
+                    if np.sum(ratios > 0) < self.n_sessions_per_batch - k:
+                        return None, None
+                    sess = int(np.random.choice(np.arange(self.n_datasets), p=ratios))
+                    ratios[sess] = 0
+                    if np.sum(ratios) > 0:
+                        ratios = ratios / np.sum(ratios)
+                    if self._queues[sess][dtype]:
+                        trial = self._queues[sess][dtype].pop(0)
+                        break
+                samples.append(self._sample(sess, trial, dtype))
+                sessions.append(sess)
+            return samples, sessions
         if all(len(q[dtype]) == 0 for q in self._queues):
             return None, None
         while True:
@@ -135,6 +163,9 @@ class SyntheticSessionsGenerator(object):
             if self._queues[sess][dtype]:
                 trial = self._queues[sess][dtype].pop(0)
                 break
+        return self._sample(sess, trial, dtype), sess
+
+    def _sample(self, sess, trial, dtype):
         trials, labels = self._store[sess]
         img = trials[trial]
         if self.placement == 'host':
@@ -146,7 +177,7 @@ class SyntheticSessionsGenerator(object):
         sample = {'images': img[None], 'batch_idx': torch.tensor([trial])}
         if labels is not None:
             sample['labels'] = labels[trial][None]
-        return sample, sess
+        return sample
 
     # -- pinned uint8 feed with one-trial look-ahead ------------------------------------------
     def _staging(self, shape, slot):

@@ -16,13 +16,14 @@ MODEL_CLASSES = {
     'vae': ('behavenet_amd.models.vaes', 'VAE'),
     'beta-tcvae': ('behavenet_amd.models.vaes', 'BetaTCVAE'),
     'ps-vae': ('behavenet_amd.models.vaes', 'PSVAE'),
+    'msps-vae': ('behavenet_amd.models.vaes', 'MSPSVAE'),
     'cond-vae': ('behavenet_amd.models.vaes', 'ConditionalVAE'),
     'cond-ae': ('behavenet_amd.models.aes', 'ConditionalAE'),
     'cond-ae-msp': ('behavenet_amd.models.aes', 'AEMSP'),
     'conv-decoder': ('behavenet_amd.models.decoders', 'ConvDecoder'),   # decoder_grid_search.py
 }
 # classes whose constructor needs hparams['n_labels'] (ref ae_grid_search.py:52-55,68-84)
-NEEDS_LABELS = ('ps-vae', 'cond-vae', 'cond-ae', 'cond-ae-msp', 'conv-decoder')
+NEEDS_LABELS = ('ps-vae', 'msps-vae', 'cond-vae', 'cond-ae', 'cond-ae-msp', 'conv-decoder')
 
 
 def _set_n_labels(data_generator, hparams):
@@ -46,8 +47,6 @@ def build_model(hparams, data_generator=None, n_datasets=None):
 
     model_class = hparams['model_class']
     if model_class not in MODEL_CLASSES:
-        # 'msps-vae' (multi-session PS-VAE) is not implemented here; everything else the
-        # reference dispatches is (ref :62-86)
         raise NotImplementedError(
             'The model class "%s" is not currently implemented' % model_class)
     torch.manual_seed(hparams['rng_seed_model'])

@@ -36,6 +36,8 @@ def encode_trial(model, y, sess=None, labels_2d=None, chunk_size=200):
             out = model.encoding(y_in, dataset=sess)
             if mc == 'ps-vae':
                 cur = torch.cat([out[0], out[1]], dim=1)
+            elif mc == 'msps-vae':
+                cur = torch.cat([out[0], out[1], out[2]], dim=1)
             else:
                 cur = out[0]
             if mc == 'cond-ae-msp':
@@ -46,8 +48,11 @@ def encode_trial(model, y, sess=None, labels_2d=None, chunk_size=200):
 
 def export_latents(data_generator, model, filename=None):
     """Encode train/val/test trials of every session and pickle them (ref eval.py:6-118)."""
-    if model.hparams['model_class'] == 'msps-vae':
-        return model.export_latents(data_generator, filename=filename)
+    # multi-session generators serve lists of batches for training; latents are exported trial by
+    # trial (the reference's MSPSVAE.export_latents rebuilds a one-session-per-batch generator,
+    # vaes.py:1198-1216)
+    single = {'return_multiple': False} \
+        if getattr(data_generator, 'n_sessions_per_batch', 1) > 1 else {}
     model.eval()
     rank, world = bdist.rank(), bdist.world_size()
 
@@ -57,8 +62,11 @@ def export_latents(data_generator, model, filename=None):
     counter = 0
     for dtype in ['train', 'val', 'test']:
         data_generator.reset_iterators(dtype)
-        for _ in range(data_generator.n_tot_batches[dtype]):
-            data, sess = data_generator.next_batch(dtype)
+        n_batches = data_generator.n_tot_batches[dtype]
+        if single and dtype == 'train':      # the multi generator counts training ITERATIONS
+            n_batches = sum(ds.n_batches['train'] for ds in data_generator.datasets)
+        for _ in range(n_batches):
+            data, sess = data_generator.next_batch(dtype, **single)
             mine = (counter % world) == rank
             counter += 1
             if not mine:

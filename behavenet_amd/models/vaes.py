@@ -1,7 +1,8 @@
 """Variational autoencoder models on the MI355X HIP kernels.
 
 Host-side mirror of the reference ``behavenet/models/vaes.py`` for the classes on the hot path:
-``VAE``, ``ConditionalVAE``, ``BetaTCVAE``, ``PSVAE`` (+ ``ConvAEPSEncoder``).  Quirks of the
+``VAE``, ``ConditionalVAE``, ``BetaTCVAE``, ``PSVAE`` (+ ``ConvAEPSEncoder``), ``MSPSVAE``
+(+ ``ConvAEMSPSEncoder``).  Quirks of the
 reference that are reproduced on purpose:
 
 * ``reparameterize`` uses ``std = exp(logvar)`` while the KL terms treat ``logvar`` as a
@@ -23,7 +24,7 @@ from behavenet_amd.models.base import DiagLinear
 
 __all__ = [
     'reparameterize', 'VAE', 'ConditionalVAE', 'BetaTCVAE', 'PSVAE', 'ConvAEPSEncoder',
-    'set_eps_provider']
+    'MSPSVAE', 'ConvAEMSPSEncoder', 'set_eps_provider']
 
 _eps_provider = None
 
@@ -484,6 +485,7 @@ class PSVAE(AE):
         """Latents with the supervised block mapped to label space by D (ref vaes.py:755-800)."""
         if not isinstance(inputs, torch.Tensor):
             inputs = torch.Tensor(inputs)
+        inputs = inputs.to(self.encoding.D.bias.device)
         if len(inputs.shape) == 2:
             y_og = inputs[:, :self.hparams['n_labels']]
             w_og = inputs[:, self.hparams['n_labels']:]
@@ -498,8 +500,189 @@ class PSVAE(AE):
             inputs = torch.Tensor(inputs)
         if len(inputs.shape) != 2:
             raise NotImplementedError
+        inputs = inputs.to(self.encoding.D.bias.device)
         y_og = inputs[:, :self.hparams['n_labels']]
         w_og = inputs[:, self.hparams['n_labels']:]
         y_new = torch.div(torch.sub(y_og, self.encoding.D.bias), self.encoding.D.weight)
         out = torch.cat([y_new, w_og], dim=1)
         return out.cpu().detach().numpy() if as_numpy else out
+
+
+class ConvAEMSPSEncoder(ConvAEEncoder):
+    """PS encoder with a background head: frozen orthogonal rows A (labels), C (background,
+    trainable bias) and B (rest), diagonal label map D (ref vaes.py:1366-1470)."""
+
+    def __init__(self, hparams):
+        super().__init__(hparams)
+        n_latents = self.hparams['n_ae_latents']
+        n_labels = self.hparams['n_labels']
+        n_background = self.hparams['n_background']
+        # construction order = the reference's: it fixes the torch RNG stream of C.bias
+        self.A = nn.Linear(n_latents, n_labels, bias=False)
+        self.B = nn.Linear(n_latents, n_latents - n_labels - n_background, bias=False)
+        self.C = nn.Linear(n_latents, n_background, bias=True)
+        self.D = DiagLinear(n_labels, bias=True)
+        from scipy.stats import ortho_group
+        m = ortho_group.rvs(dim=n_latents).astype('float32')
+        with torch.no_grad():
+            self.A.weight = nn.Parameter(torch.from_numpy(m[:n_labels, :]), requires_grad=False)
+            self.B.weight = nn.Parameter(
+                torch.from_numpy(m[n_labels + n_background:, :]), requires_grad=False)
+            self.C.weight = nn.Parameter(
+                torch.from_numpy(m[n_labels:n_labels + n_background, :]), requires_grad=False)
+
+    def __str__(self):
+        out = 'Encoder architecture:\n'
+        i = 0
+        for i, module in enumerate(self.encoder):
+            out += '    {:02d}: {}\n'.format(i, module)
+        i += 1
+        out += '    {:02d}: {}\n'.format(i, self.FF)
+        out += '    {:02d}: {} (to supervised latents)\n'.format(i, self.A)
+        out += '    {:02d}: {} (to unsupervised latents)\n'.format(i, self.B)
+        out += '    {:02d}: {} (to background latents)\n'.format(i, self.C)
+        out += '    {:02d}: {} (supervised latents to labels)\n'.format(i, self.D)
+        return out
+
+    def forward(self, x, dataset=None):
+        """-> (z_s, z_b, z_u, logvar, pool_idx, output_sizes)."""
+        x1 = self._features(x, dataset)
+        h = linear(x1, self.FF.weight, self.FF.bias)
+        z_s = linear(h, self.A.weight, None)
+        z_u = linear(h, self.B.weight, None)
+        z_b = linear(h, self.C.weight, self.C.bias)
+        return z_s, z_b, z_u, linear(x1, self.logvar.weight, self.logvar.bias), [], []
+
+
+class MSPSVAE(PSVAE):
+    """Multi-session PS-VAE (ref vaes.py:849-1273): a training batch is a LIST of per-session
+    batches, concatenated and run through the network in one pass (the reference does not chunk
+    this model); a triplet loss on the background latents separates the sessions."""
+
+    def __init__(self, hparams):
+        if hparams['n_sessions_per_batch'] == 1:
+            raise ValueError('must choose "n_sessions_per_batch" > 1 in hparams')
+        hparams['n_background'] = hparams.get('n_background', 4)   # saved with the hparams
+        super().__init__(hparams)
+        self.TripletLoss = nn.TripletMarginLoss(margin=1.0, p=2)
+
+    def build_model(self):
+        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
+        if self.model_type == 'conv':
+            self.encoding = ConvAEMSPSEncoder(self.hparams)
+            self.decoding = ConvAEDecoder(self.hparams)
+        elif self.model_type == 'linear':
+            raise NotImplementedError
+        else:
+            raise ValueError('"%s" is an invalid model_type' % self.model_type)
+
+    def forward(self, x, dataset=None, use_mean=False, **kwargs):
+        """-> (x_hat, z, mu, logvar, y_hat); mu = [z_s | z_b | z_u]."""
+        z_s, z_b, z_u, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
+        mu = torch.cat([z_s, z_b, z_u], dim=1)
+        z = _sample(mu, logvar, use_mean, None)
+        x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+        y_hat = self.encoding.D(z_s)
+        return x_hat, z, mu, logvar, y_hat
+
+    def loss(self, datas, dataset=None, accumulate_grad=True, chunk_size=None):
+        """Modified ELBO + triplet term (ref vaes.py:916-1098).  ``datas``: list of data dicts
+        (training; ``dataset`` = list of their session ids) or one dict (validation / test; no
+        triplet term, the key is reported as 0 like the reference)."""
+        multi = isinstance(datas, list)
+        if multi:
+            x = torch.cat([d['images'][0] for d in datas], dim=0)
+            y = torch.cat([d['labels'][0] for d in datas], dim=0)
+            m = torch.cat([d['masks'][0] for d in datas], dim=0) if 'masks' in datas[0] else None
+            n = torch.cat([d['labels_masks'][0] for d in datas], dim=0) \
+                if 'labels_masks' in datas[0] else None
+            sess_ids = np.concatenate(
+                [d * np.ones(datas[i]['images'].shape[1]) for i, d in enumerate(dataset)])
+        else:
+            x, y = datas['images'][0], datas['labels'][0]
+            m = datas['masks'][0] if 'masks' in datas else None
+            n = datas['labels_masks'][0] if 'labels_masks' in datas else None
+            sess_ids = None
+        n_labels = self.hparams['n_labels']
+        n_bg = self.hparams['n_background']
+        alpha = self.hparams['ps_vae.alpha']
+        delta = self.hparams['ps_vae.delta']
+        beta = self.beta_vals[self.curr_epoch]
+        kl = self.kl_anneal_vals[self.curr_epoch]
+
+        self._reserve_pools(x)
+        u0 = n_labels + n_bg
+        with torch.set_grad_enabled(bool(accumulate_grad)):
+            x_hat, sample, mu, logvar, y_hat = self.forward(x, dataset=None, use_mean=False)
+            t = {}
+            t['loss_data_ll'] = losses.gaussian_ll(x, x_hat, m)
+            t['loss_label_ll'] = losses.gaussian_ll(y, y_hat, n)
+            t['loss_zs_kl'] = losses.kl_div_to_std_normal(
+                mu[:, :n_labels].contiguous(), logvar[:, :n_labels].contiguous())
+            mi, tc, dwkl = losses.decomposed_kl(sample[:, u0:], mu[:, u0:], logvar[:, u0:])
+            t['loss_zu_mi'], t['loss_zu_tc'], t['loss_zu_dwkl'] = mi, tc, dwkl
+            total = -t['loss_data_ll'] - float(alpha) * t['loss_label_ll'] + t['loss_zs_kl'] \
+                + float(kl) * mi + float(beta) * tc + float(kl) * dwkl
+            if multi:
+                t['loss_triplet'] = losses.triplet_loss(
+                    self.TripletLoss, mu[:, n_labels:u0], sess_ids)
+                total = total + float(delta) * t['loss_triplet']
+            t['loss'] = total
+        keys = list(t.keys())
+        table = _stack_scalars(t)
+        y_hat_rb, y_rb = hf.Readback(y_hat), hf.Readback(y)
+        n_rb = hf.Readback(n) if n is not None else None
+        vals = _finish_whole(table.reshape(1, -1), total, accumulate_grad)[0]
+        out = {'loss': 0.0}
+        out.update({k: float(v) for k, v in zip(keys, vals)})
+        out.setdefault('loss_triplet', 0)
+        out['loss_data_mse'] = losses.gaussian_ll_to_mse(out['loss_data_ll'], np.prod(x.shape[1:]))
+        y_hat_np, y_np = y_hat_rb.numpy(), y_rb.numpy()
+        if n is not None:
+            n_np = n_rb.numpy()
+            r2 = _r2_variance_weighted(y_np[n_np == 1], y_hat_np[n_np == 1])
+        else:
+            r2 = _r2_variance_weighted(y_np, y_hat_np)
+        out.update({'alpha': alpha, 'beta': beta, 'delta': delta, 'label_r2': r2})
+        return out
+
+    def get_predicted_labels(self, x, dataset=None, use_mean=True):
+        z_s, _, _, logvar, _, _ = self.encoding(x, dataset=dataset)
+        if not use_mean:
+            z_s = reparameterize(z_s, logvar[:, :self.n_labels].contiguous())
+        return self.encoding.D(z_s)
+
+    def _split_latents(self, inputs, dataset):
+        n_labels, n_bg = self.hparams['n_labels'], self.hparams['n_background']
+        if not isinstance(inputs, torch.Tensor):
+            inputs = torch.Tensor(inputs)
+        inputs = inputs.to(self.encoding.D.bias.device)
+        if len(inputs.shape) == 2:
+            return inputs[:, :n_labels], inputs[:, n_labels:n_labels + n_bg], \
+                inputs[:, n_labels + n_bg:], True
+        z_s, z_b, z_u, _, _, _ = self.encoding(inputs, dataset=dataset)
+        return z_s, z_b, z_u, False
+
+    def get_transformed_latents(self, inputs, dataset=None, as_numpy=True):
+        """Latents with the supervised block mapped to label space by D (ref vaes.py:1100-1147)."""
+        z_s, z_b, z_u, _ = self._split_latents(inputs, dataset)
+        out = torch.cat([self.encoding.D(z_s), z_b, z_u], dim=1)
+        return out.cpu().detach().numpy() if as_numpy else out
+
+    def get_inverse_transformed_latents(self, inputs, dataset=None, as_numpy=True):
+        """Inverse of :meth:`get_transformed_latents`, latent inputs only (ref :1149-1196)."""
+        if not isinstance(inputs, torch.Tensor):
+            inputs = torch.Tensor(inputs)
+        if len(inputs.shape) != 2:
+            raise NotImplementedError
+        z_s, z_b, z_u, _ = self._split_latents(inputs, dataset)
+        z_new = torch.div(torch.sub(z_s, self.encoding.D.bias), self.encoding.D.weight)
+        out = torch.cat([z_new, z_b, z_u], dim=1)
+        return out.cpu().detach().numpy() if as_numpy else out
+
+    def export_latents(self, data_generator, filename=None):
+        """Latents [z_s | z_b | z_u] of every trial of every session, one pickle per session
+        (ref vaes.py:1198-1273; the reference rebuilds a one-session-per-batch generator from
+        disk, here the generator is asked for single batches: ``return_multiple=False``)."""
+        from behavenet_amd.fitting.eval import export_latents
+        return export_latents(data_generator, self, filename=filename)

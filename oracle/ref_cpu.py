@@ -589,6 +589,136 @@ class PSVAE(AE):
         return out
 
 
+def triplet_loss(triplet_loss_obj, z, datasets):
+    """Session-separation loss on the background latents (ref losses.py:402-511).
+
+    Per session: its shuffled sample indices are dealt into 3*(n-1) interleaved chunks of equal
+    length; chunks (2j, 2j+1) are anchor/positive for the j-th OTHER session, whose next unused
+    chunk from index 2*(n-1) on is the negative; plus the mean anchor-positive distance of every
+    pair.  Divided by n*(n-1) terms, except the reference's "legacy" 3 for two sessions.
+    """
+    ids = np.unique(datasets)
+    n = len(ids)
+    if n not in (2, 3, 4):
+        raise NotImplementedError
+    n_chunks = 3 * (n - 1)
+    perms = [np.random.permutation(np.where(datasets == i)[0]) for i in ids]
+    m = np.min([len(p) // n_chunks for p in perms])
+    idxs = [[p[i::n_chunks][:m] for i in range(n_chunks)] for p in perms]
+    next_neg = [2 * (n - 1)] * n
+    loss = 0
+    pairs = []
+    for a in range(n):
+        j = 0
+        for b in range(n):
+            if b == a:
+                continue
+            loss = loss + triplet_loss_obj(z[idxs[a][2 * j]], z[idxs[a][2 * j + 1]],
+                                           z[idxs[b][next_neg[b]]])
+            next_neg[b] += 1
+            pairs.append((a, j))
+            j += 1
+    for a, j in pairs:
+        loss = loss + F.pairwise_distance(z[idxs[a][2 * j]], z[idxs[a][2 * j + 1]]).mean()
+    return loss / (3 if n == 2 else n * (n - 1))
+
+
+class ConvMSPSEncoder(ConvEncoder):
+    """PS encoder with a background head C (ref vaes.py:1366-1470)."""
+
+    def __init__(self, hp):
+        super().__init__(hp)
+        n_lat, n_lab, n_bg = hp['n_ae_latents'], hp['n_labels'], hp['n_background']
+        self.A = nn.Linear(n_lat, n_lab, bias=False)
+        self.B = nn.Linear(n_lat, n_lat - n_lab - n_bg, bias=False)
+        self.C = nn.Linear(n_lat, n_bg, bias=True)
+        self.D = DiagLinear(n_lab, bias=True)
+        from scipy.stats import ortho_group
+        m = ortho_group.rvs(dim=n_lat).astype('float32')
+        with torch.no_grad():
+            self.A.weight = nn.Parameter(torch.from_numpy(m[:n_lab, :]), requires_grad=False)
+            self.B.weight = nn.Parameter(torch.from_numpy(m[n_lab + n_bg:, :]),
+                                         requires_grad=False)
+            self.C.weight = nn.Parameter(torch.from_numpy(m[n_lab:n_lab + n_bg, :]),
+                                         requires_grad=False)
+
+    def forward(self, x, dataset=None, taps=None):
+        x1 = self.features(x, dataset, taps)
+        h = F.linear(x1, self.FF.weight, self.FF.bias)
+        return F.linear(h, self.A.weight), F.linear(h, self.C.weight, self.C.bias), \
+            F.linear(h, self.B.weight), F.linear(x1, self.logvar.weight, self.logvar.bias), [], []
+
+
+class MSPSVAE(PSVAE):
+    """Multi-session PS-VAE (ref vaes.py:849-1098): one pass over the concatenated sessions."""
+
+    def __init__(self, hparams):
+        if hparams['n_sessions_per_batch'] == 1:
+            raise ValueError('must choose "n_sessions_per_batch" > 1 in hparams')
+        hparams['n_background'] = hparams.get('n_background', 4)
+        super().__init__(hparams)
+        self.TripletLoss = nn.TripletMarginLoss(margin=1.0, p=2)
+
+    def build_model(self):
+        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
+        self.encoding = ConvMSPSEncoder(self.hparams)
+        self.decoding = ConvDecoder(self.hparams)
+
+    def forward(self, x, dataset=None, use_mean=False, **kwargs):
+        z_s, z_b, z_u, logvar, pi, os_ = self.encoding(x, dataset=dataset)
+        mu = torch.cat([z_s, z_b, z_u], dim=1)
+        if use_mean:
+            z = mu
+        else:
+            z = reparameterize(mu, logvar, self.eps_fn(logvar) if self.eps_fn else None)
+        return self.decoding(z, pi, os_, dataset=dataset), z, mu, logvar, self.encoding.D(z_s)
+
+    def loss(self, datas, dataset=None, accumulate_grad=True, chunk_size=None):
+        from sklearn.metrics import r2_score
+        multi = isinstance(datas, list)
+        if multi:
+            x = torch.cat([d['images'][0] for d in datas], dim=0)
+            y = torch.cat([d['labels'][0] for d in datas], dim=0)
+            m = torch.cat([d['masks'][0] for d in datas], dim=0) if 'masks' in datas[0] else None
+            n = torch.cat([d['labels_masks'][0] for d in datas], dim=0) \
+                if 'labels_masks' in datas[0] else None
+            sess = np.concatenate([d * np.ones(datas[i]['images'].shape[1])
+                                   for i, d in enumerate(dataset)])
+        else:
+            x, y = datas['images'][0], datas['labels'][0]
+            m = datas['masks'][0] if 'masks' in datas else None
+            n = datas['labels_masks'][0] if 'labels_masks' in datas else None
+        L, G = self.hparams['n_labels'], self.hparams['n_background']
+        alpha, delta = self.hparams['ps_vae.alpha'], self.hparams['ps_vae.delta']
+        beta, kl = self.beta_vals[self.curr_epoch], self.kl_anneal_vals[self.curr_epoch]
+        x_hat, sample, mu, logvar, y_hat = self.forward(x, dataset=None, use_mean=False)
+        t = {}
+        t['loss_data_ll'] = gaussian_ll(x, x_hat, m)
+        t['loss_label_ll'] = gaussian_ll(y, y_hat, n)
+        t['loss_zs_kl'] = kl_div_to_std_normal(mu[:, :L], logvar[:, :L])
+        t['loss_zu_mi'], t['loss_zu_tc'], t['loss_zu_dwkl'] = decomposed_kl(
+            sample[:, L + G:], mu[:, L + G:], logvar[:, L + G:])
+        t['loss'] = -t['loss_data_ll'] - alpha * t['loss_label_ll'] + t['loss_zs_kl'] \
+            + kl * t['loss_zu_mi'] + beta * t['loss_zu_tc'] + kl * t['loss_zu_dwkl']
+        if multi:
+            t['loss_triplet'] = triplet_loss(self.TripletLoss, mu[:, L:L + G], sess)
+            t['loss'] = t['loss'] + delta * t['loss_triplet']
+        if accumulate_grad:
+            t['loss'].backward()
+        out = {k: v.item() for k, v in t.items()}
+        # the key stays in the reference's value dict (as 0) when the term is not computed
+        out.setdefault('loss_triplet', 0)
+        out['loss_data_mse'] = gaussian_ll_to_mse(out['loss_data_ll'], np.prod(x.shape[1:]))
+        y_hat_np, y_np = y_hat.detach().numpy(), y.detach().numpy()
+        if n is not None:
+            n_np = n.detach().numpy()
+            r2 = r2_score(y_np[n_np == 1], y_hat_np[n_np == 1], multioutput='variance_weighted')
+        else:
+            r2 = r2_score(y_np, y_hat_np, multioutput='variance_weighted')
+        out.update({'alpha': alpha, 'beta': beta, 'delta': delta, 'label_r2': r2})
+        return out
+
+
 class AEMSP(AE):
     """Matrix subspace projection AE (ref aes.py:901-1060)."""
 
@@ -663,7 +793,8 @@ class ConvDecoderModel(nn.Module):
 
 
 MODEL_CLASSES = {'conv-decoder': ConvDecoderModel, 'ae': AE, 'cond-ae': ConditionalAE, 'vae': VAE, 'cond-vae': ConditionalVAE,
-                 'beta-tcvae': BetaTCVAE, 'ps-vae': PSVAE, 'cond-ae-msp': AEMSP}
+                 'beta-tcvae': BetaTCVAE, 'ps-vae': PSVAE, 'msps-vae': MSPSVAE,
+                 'cond-ae-msp': AEMSP}
 
 
 def build_model(hparams):

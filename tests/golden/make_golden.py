@@ -284,6 +284,106 @@ def decoder_case(name, dim, n_labels, n_frames, n_fwd=8):
     print('%s written (%.1f KB)' % (path, os.path.getsize(path) / 1024))
 
 
+def msps_case(name='mspsvae_cfg1'):
+    """Multi-session PS-VAE (ref vaes.py:849-1098) on a two-session batch, plus known answers of
+    losses.triplet_loss for 2, 3 and 4 sessions."""
+    import behavenet.models.vaes as ref_vaes
+    from behavenet.fitting import losses as ref_losses
+    dim, n_lat, n_labels = [1, 32, 32], 8, 2
+    extra = {'n_background': 2, 'n_sessions_per_batch': 2, 'ps_vae.alpha': 10, 'ps_vae.beta': 5,
+             'ps_vae.delta': 50, 'ps_vae.anneal_epochs': 5, 'max_n_epochs': 10,
+             'ps_vae.ms_loss': 'triplet'}
+    arch = ref_arch.load_handcrafted_arch(list(dim), n_lat, None, check_memory=False)
+    hp = base_hparams(arch, 'msps-vae', extra)
+    hp['n_labels'] = n_labels
+    np.random.seed(0)
+    torch.manual_seed(0)
+    model = ref_vaes.MSPSVAE(hp)
+    model.train()
+    store = {}
+    for k, v in model.state_dict().items():
+        tensor_record(store, 'param0/' + k, v, full_limit=1024)
+    frames = [18, 15]
+    datas = []
+    for i, t in enumerate(frames):
+        datas.append({'images': torch.from_numpy(make_frames(t, dim, seed=1 + i))[None],
+                      'labels': torch.from_numpy(make_labels(t, n_labels, seed=5 + i))[None]})
+    sess = [1, 0]            # dataset ids of the two batches, as the generator hands them over
+
+    eps_log = []
+    orig = ref_vaes.reparameterize
+
+    def recording(mu, logvar):
+        std = torch.exp(logvar)
+        eps = torch.randn_like(std)
+        eps_log.append(eps.clone())
+        return eps.mul(std).add_(mu)
+    ref_vaes.reparameterize = recording
+
+    torch.manual_seed(123)
+    with torch.no_grad():
+        out = model(datas[0]['images'][0][:8], dataset=None)
+    for nm, t in zip(['x_hat', 'z', 'mu', 'logvar', 'y_hat'], out):
+        store['fwd/' + nm] = t.numpy().astype(np.float32)
+    store['fwd/eps'] = eps_log[0].numpy()
+    eps_log.clear()
+
+    model.curr_epoch = 3
+    torch.manual_seed(124)
+    np.random.seed(11)
+    model.zero_grad()
+    ld = model.loss(datas, dataset=sess, accumulate_grad=True)
+    store['loss/keys'] = np.array(sorted(ld.keys()))
+    store['loss/vals'] = np.array([float(ld[k]) for k in sorted(ld.keys())], dtype=np.float64)
+    store['loss/eps0'] = eps_log[0].numpy()
+    eps_log.clear()
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            tensor_record(store, 'grad/' + k, p.grad, full_limit=4096)
+    # validation-style call: one session, no triplet term
+    torch.manual_seed(125)
+    ld1 = model.loss(datas[0], dataset=1, accumulate_grad=False)
+    store['loss1/keys'] = np.array(sorted(ld1.keys()))
+    store['loss1/vals'] = np.array([float(ld1[k]) for k in sorted(ld1.keys())], dtype=np.float64)
+    store['loss1/eps0'] = eps_log[0].numpy()
+    eps_log.clear()
+
+    opt = torch.optim.Adam(model.get_parameters(), lr=hp['learning_rate'],
+                           weight_decay=hp.get('l2_reg', 0), amsgrad=True)
+    traj = []
+    for step in range(3):
+        torch.manual_seed(200 + step)
+        np.random.seed(20 + step)
+        opt.zero_grad()
+        traj.append(float(model.loss(datas, dataset=sess, accumulate_grad=True)['loss']))
+        opt.step()
+        store['adam/eps_step%d_0' % step] = eps_log[0].numpy()
+        eps_log.clear()
+    store['adam/losses'] = np.array(traj, dtype=np.float64)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            tensor_record(store, 'adam/param/' + k, p, full_limit=1024)
+    ref_vaes.reparameterize = orig
+
+    # losses.triplet_loss known answers
+    obj = torch.nn.TripletMarginLoss(margin=1.0, p=2)
+    g = torch.Generator().manual_seed(5)
+    for n_sess in (2, 3, 4):
+        z = torch.randn((40 * n_sess, 3), generator=g)
+        ids = np.repeat(np.arange(n_sess), 40)[np.random.RandomState(n_sess).permutation(40 * n_sess)]
+        np.random.seed(30 + n_sess)
+        store['triplet/%d/z' % n_sess] = z.numpy()
+        store['triplet/%d/ids' % n_sess] = ids.astype(np.float64)
+        store['triplet/%d/val' % n_sess] = np.float64(ref_losses.triplet_loss(obj, z, ids).item())
+
+    meta = {'dim': dim, 'n_lat': n_lat, 'n_frames': frames, 'model_class': 'msps-vae',
+            'n_labels': n_labels, 'extra_hp': extra, 'n_fwd': 8, 'curr_epoch': 3, 'sess': sess}
+    store['meta'] = np.array(json.dumps(meta))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **store)
+    print('%s written (%.1f KB)' % (path, os.path.getsize(path) / 1024))
+
+
 class ListExp(object):
     """Stand-in for test_tube.Experiment: collects rows."""
     version = 0
@@ -332,6 +432,9 @@ if __name__ == '__main__':
         model_case('vae_1x64x48_bn', RefVAE, [1, 64, 48], 8, 6, 'vae',
                    extra_hp={'ae_batch_norm': True, 'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0,
                              'max_n_epochs': 10})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'msps':
+        msps_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'convdec':
         decoder_case('convdecoder_cfg1', [1, 32, 32], 4, 210)

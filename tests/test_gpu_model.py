@@ -21,7 +21,7 @@ from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSession
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
 from behavenet_amd.fitting.training import fit
 from behavenet_amd.fitting import losses
-from behavenet_amd.models import AE, AEMSP, VAE, ConditionalVAE, BetaTCVAE, PSVAE, ConvDecoder
+from behavenet_amd.models import AE, AEMSP, VAE, ConditionalVAE, BetaTCVAE, PSVAE, MSPSVAE, ConvDecoder
 from behavenet_amd.models import vaes as hip_vaes
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from oracle import ref_cpu
@@ -33,7 +33,8 @@ from tests.branches import record_branches, BranchReplay
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 BUILDERS = {'ae': AE, 'vae': VAE, 'cond-vae': ConditionalVAE, 'beta-tcvae': BetaTCVAE,
-            'ps-vae': PSVAE, 'cond-ae-msp': AEMSP, 'conv-decoder': ConvDecoder}
+            'ps-vae': PSVAE, 'msps-vae': MSPSVAE, 'cond-ae-msp': AEMSP,
+            'conv-decoder': ConvDecoder}
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
@@ -439,6 +440,137 @@ def test_multichunk_variational_vs_oracle(model_class):
     for k in loss_o:
         assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-6), k
     grads_close_on_same_branches(hip, ora64, model_class)
+
+
+def test_mspsvae_vs_oracle_and_golden():
+    """Multi-session PS-VAE (ref vaes.py:849-1098) on a two-session batch (18 + 15 frames):
+    forward, the 13-key loss dict incl. the triplet term (same numpy permutations), gradients,
+    the single-session (validation) loss and the Adam trajectory, against the oracle and the
+    vectors recorded from the reference."""
+    from tests.test_oracle_golden import _msps_case
+    z, meta, datas_c = _msps_case()
+    hip, ora, hp = _pair(meta)
+    datas_g = [{k: v.to(DEV) for k, v in d.items()} for d in datas_c]
+    sess = meta['sess']
+    n_fwd = meta['n_fwd']
+    hip.train()
+    ora.train()
+    try:
+        ora.eps_fn = EpsReplay([z['fwd/eps']])
+        hip_vaes.set_eps_provider(EpsReplay([z['fwd/eps']], DEV))
+        with torch.no_grad():
+            out_o = ora(datas_c[0]['images'][0][:n_fwd], dataset=None)
+            out_h = hip(datas_g[0]['images'][0][:n_fwd], dataset=None)
+        for nm, a, b in zip(['x_hat', 'z', 'mu', 'logvar', 'y_hat'], out_h, out_o):
+            close(a, b, name='mspsvae fwd ' + nm)
+            close(a, torch.from_numpy(z['fwd/' + nm]), name='mspsvae fwd golden ' + nm)
+
+        hip.curr_epoch = ora.curr_epoch = meta['curr_epoch']
+        ora.eps_fn = EpsReplay([z['loss/eps0']])
+        hip_vaes.set_eps_provider(EpsReplay([z['loss/eps0']], DEV))
+        hip.zero_grad()
+        ora.zero_grad()
+        np.random.seed(11)
+        loss_o = ora.loss(datas_c, dataset=sess, accumulate_grad=True)
+        np.random.seed(11)
+        loss_h = hip.loss(datas_g, dataset=sess, accumulate_grad=True)
+        keys = [str(k) for k in z['loss/keys']]
+        assert sorted(loss_h.keys()) == sorted(loss_o.keys()) == keys
+        for k, want in zip(keys, z['loss/vals']):
+            assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-6), k
+            assert loss_h[k] == pytest.approx(float(want), rel=1e-4, abs=1e-6), k
+        assert loss_h['loss_triplet'] > 0
+        for (k, ph), (_, po) in zip(hip.named_parameters(), ora.named_parameters()):
+            if po.grad is None:
+                assert ph.grad is None or not ph.requires_grad, k
+                continue
+            if k == 'encoding.C.bias':
+                # a shift of all background latents leaves every triplet / pairwise distance
+                # unchanged: the O(delta) summands of this gradient cancel analytically and what
+                # is left is the (1e-5 times smaller) reconstruction part plus rounding noise of
+                # the cancellation -- judged against the size of the summands
+                tol = 1e-5 * hp['ps_vae.delta']
+                assert float((ph.grad.cpu() - po.grad).abs().max()) <= tol, k
+                assert float(po.grad.abs().max()) <= 100 * tol
+                continue
+            close(ph.grad, po.grad, name='mspsvae grad ' + k)
+            assert checksum_close(checksum(ph.grad.cpu().numpy()), z['grad/' + k + '/checksum'],
+                                  1e-4), k
+
+        # one session (validation): no triplet term, key reported as 0, no gradient side effects
+        hip_vaes.set_eps_provider(EpsReplay([z['loss1/eps0']], DEV))
+        hip.zero_grad()
+        loss1 = hip.loss(datas_g[0], dataset=1, accumulate_grad=False)
+        keys1 = [str(k) for k in z['loss1/keys']]
+        assert sorted(loss1.keys()) == keys1 and loss1['loss_triplet'] == 0
+        for k, want in zip(keys1, z['loss1/vals']):
+            assert loss1[k] == pytest.approx(float(want), rel=1e-4, abs=1e-6), k
+        assert all(p.grad is None or float(p.grad.abs().max()) == 0 for p in hip.parameters())
+
+        opt = FlatAdamAMSGrad(hip.get_parameters(), lr=hp['learning_rate'],
+                              weight_decay=hp.get('l2_reg', 0))
+        traj = []
+        for step in range(3):
+            hip_vaes.set_eps_provider(EpsReplay([z['adam/eps_step%d_0' % step]], DEV))
+            np.random.seed(20 + step)
+            opt.zero_grad()
+            traj.append(hip.loss(datas_g, dataset=sess, accumulate_grad=True)['loss'])
+            opt.step()
+        np.testing.assert_allclose(traj, z['adam/losses'], rtol=1e-4)
+    finally:
+        hip_vaes.set_eps_provider(None)
+    # latents handed to downstream tools: [z_s | z_b | z_u], supervised block through D
+    with torch.no_grad():
+        lat = hip.get_transformed_latents(datas_g[0]['images'][0][:4], as_numpy=True)
+    assert lat.shape == (4, meta['n_lat'])
+    back = hip.get_inverse_transformed_latents(lat, as_numpy=True)
+    assert back.shape == lat.shape
+
+
+def test_mspsvae_fit_and_export_on_multi_session_batches(tmp_path):
+    """`fit_model` (the reference's ae_grid_search.main minus test-tube) for 'msps-vae' on a
+    three-session generator serving two sessions per training batch: metric rows carry the
+    triplet term, the best model is saved, latents [z_s | z_b | z_u] are exported per session."""
+    from behavenet_amd.fitting.ae_grid_search import fit_model
+    dim = [1, 32, 32]
+    arch = load_handcrafted_arch(list(dim), 8, None, check_memory=False)
+    hp = base_hparams(arch, 'msps-vae', {
+        'n_background': 2, 'n_sessions_per_batch': 2, 'ps_vae.alpha': 10, 'ps_vae.beta': 5,
+        'ps_vae.delta': 50, 'ps_vae.anneal_epochs': 1, 'ps_vae.ms_loss': 'triplet'})
+    hp.update({'expt_dir': str(tmp_path), 'max_n_epochs': 1, 'min_n_epochs': 0,
+               'val_check_interval': 1, 'enable_early_stop': False, 'early_stop_history': 10,
+               'rng_seed_train': 0, 'rng_seed_model': 0, 'export_latents': True,
+               'progress_bar': False, 'device': 'cuda', 'n_parallel_gpus': 1})
+    os.makedirs(os.path.join(str(tmp_path), 'version_0'))
+    sessions = [SyntheticSession(10, 12, dim, seed=i, n_labels=2, trial_splits='8;1;1;0',
+                                 name=('lab', 'expt', 'animal', 'sess-%d' % i)) for i in range(3)]
+    gen = SyntheticSessionsGenerator(sessions, device=DEV, placement='device_u8',
+                                     n_sessions_per_batch=2)
+
+    class Exp(object):
+        version = 0
+        rows = []
+
+        def log(self, row):
+            self.rows.append(dict(row))
+
+        def save(self):
+            pass
+    exp = Exp()
+    model = fit_model(hp, gen, exp)
+    assert type(model) is MSPSVAE and hp['n_labels'] == 2 and hp['training_completed']
+    train_rows = [r for r in exp.rows if r.get('dataset') == -1 and 'tr_loss' in r]
+    assert len(train_rows) == 2 and all(np.isfinite(r['tr_loss']) for r in train_rows)
+    assert all(r['tr_loss_triplet'] > 0 for r in train_rows)
+    val_rows = [r for r in exp.rows if r.get('dataset') == -1 and 'val_loss' in r]
+    assert val_rows and all(r['val_loss_triplet'] == 0 for r in val_rows)
+    assert os.path.exists(os.path.join(str(tmp_path), 'version_0', 'best_val_model.pt'))
+    for i in range(3):
+        pkl = os.path.join(str(tmp_path), 'version_0', 'lab_expt_animal_sess-%d_latents.pkl' % i)
+        with open(pkl, 'rb') as f:
+            lat = pickle.load(f)
+        assert len(lat['latents']) == 10
+        assert all(a.shape == (12, 8) and np.all(np.isfinite(a)) for a in lat['latents'])
 
 
 def test_conv_decoder_vs_oracle_and_golden():

@@ -142,9 +142,11 @@ def test_model_dispatch_like_ae_grid_search(tmp_path):
     extra = {'device': 'cpu', 'max_n_epochs': 2, 'vae.beta': 1, 'vae.beta_anneal_epochs': 0,
              'beta_tcvae.beta': 1, 'beta_tcvae.beta_anneal_epochs': 0, 'ps_vae.alpha': 1,
              'ps_vae.beta': 1, 'ps_vae.anneal_epochs': 0, 'msp.alpha': 0.1,
-             'conditional_encoder': False, 'rng_seed_model': 0}
+             'conditional_encoder': False, 'rng_seed_model': 0, 'n_sessions_per_batch': 2,
+             'n_background': 2, 'ps_vae.delta': 1}
     want = {'ae': models.AE, 'vae': models.VAE, 'beta-tcvae': models.BetaTCVAE,
-            'ps-vae': models.PSVAE, 'cond-vae': models.ConditionalVAE,
+            'ps-vae': models.PSVAE, 'msps-vae': models.MSPSVAE,
+            'cond-vae': models.ConditionalVAE,
             'cond-ae': models.ConditionalAE, 'cond-ae-msp': models.AEMSP,
             'conv-decoder': models.ConvDecoder}
     assert sorted(want) == sorted(ags.MODEL_CLASSES)
@@ -179,7 +181,7 @@ def test_model_dispatch_like_ae_grid_search(tmp_path):
     assert torch.equal(model.encoding.FF.bias, ref.encoding.FF.bias)
     hp = case_hparams(meta)
     hp.update(extra)
-    hp['model_class'] = 'msps-vae'
+    hp['model_class'] = 'labels-images'
     with pytest.raises(NotImplementedError):
         ags.build_model(hp, n_datasets=2)
     hp['model_class'] = 'cond-vae'

@@ -179,3 +179,82 @@ def test_oracle_conv_decoder_matches_reference():
     np.testing.assert_allclose(traj, z['adam/losses'], rtol=1e-6)
     for k, p in model.named_parameters():
         _check_tensor(z, 'adam/param/' + k, p, rtol=1e-6, atol=1e-8)
+
+
+def _msps_case():
+    from tests.golden_utils import make_labels, make_frames
+    z, meta = load_case('mspsvae_cfg1')
+    datas = []
+    for i, t in enumerate(meta['n_frames']):
+        datas.append({
+            'images': torch.from_numpy(make_frames(t, meta['dim'], seed=1 + i))[None],
+            'labels': torch.from_numpy(make_labels(t, meta['n_labels'], seed=5 + i))[None]})
+    return z, meta, datas
+
+
+def test_oracle_triplet_loss_known_answers():
+    """losses.triplet_loss (ref losses.py:402-511) for 2, 3 and 4 sessions."""
+    z, _ = load_case('mspsvae_cfg1')
+    obj = torch.nn.TripletMarginLoss(margin=1.0, p=2)
+    for n_sess in (2, 3, 4):
+        np.random.seed(30 + n_sess)
+        got = ref_cpu.triplet_loss(obj, torch.from_numpy(z['triplet/%d/z' % n_sess]),
+                                   z['triplet/%d/ids' % n_sess]).item()
+        np.testing.assert_allclose(got, float(z['triplet/%d/val' % n_sess]), rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        ref_cpu.triplet_loss(obj, torch.zeros((10, 3)), np.arange(10) % 5)
+
+
+def test_oracle_mspsvae_matches_reference():
+    """Multi-session PS-VAE (ref vaes.py:849-1098): parameters, forward, the 13-key loss dict of a
+    two-session batch (with the triplet term), gradients, the single-session (validation) loss
+    and three Adam steps."""
+    torch.set_num_threads(8)
+    z, meta, datas = _msps_case()
+    hp = case_hparams(meta)
+    model = seeded_build(ref_cpu.build_model, hp)
+    sd = model.state_dict()
+    want_keys = sorted(k[len('param0/'):-len('/checksum')] for k in z.files
+                       if k.startswith('param0/') and k.endswith('/checksum'))
+    assert sorted(sd.keys()) == want_keys
+    for k, v in sd.items():
+        _check_tensor(z, 'param0/' + k, v, rtol=0.0, atol=0.0)
+    model.train()
+    model.eps_fn = EpsReplay([z['fwd/eps']])
+    with torch.no_grad():
+        out = model(datas[0]['images'][0][:meta['n_fwd']], dataset=None)
+    for nm, t in zip(['x_hat', 'z', 'mu', 'logvar', 'y_hat'], out):
+        np.testing.assert_allclose(t.numpy(), z['fwd/' + nm], rtol=1e-5, atol=1e-6, err_msg=nm)
+    model.curr_epoch = meta['curr_epoch']
+    model.eps_fn = EpsReplay([z['loss/eps0']])
+    np.random.seed(11)
+    model.zero_grad()
+    loss = model.loss(datas, dataset=meta['sess'], accumulate_grad=True)
+    keys = [str(k) for k in z['loss/keys']]
+    assert sorted(loss.keys()) == keys and 'loss_triplet' in keys and 'delta' in keys
+    np.testing.assert_allclose([float(loss[k]) for k in keys], z['loss/vals'], rtol=2e-6,
+                               atol=1e-9)
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            _check_tensor(z, 'grad/' + k, p.grad, rtol=2e-5, atol=1e-9)
+        else:
+            assert 'grad/' + k + '/checksum' not in z.files
+    model.eps_fn = EpsReplay([z['loss1/eps0']])
+    loss1 = model.loss(datas[0], dataset=1, accumulate_grad=False)
+    keys1 = [str(k) for k in z['loss1/keys']]
+    assert sorted(loss1.keys()) == keys1 and loss1['loss_triplet'] == 0
+    np.testing.assert_allclose([float(loss1[k]) for k in keys1], z['loss1/vals'], rtol=2e-6,
+                               atol=1e-9)
+    opt = ref_cpu.make_optimizer(model, hp)
+    traj = []
+    for step in range(3):
+        model.eps_fn = EpsReplay([z['adam/eps_step%d_0' % step]])
+        np.random.seed(20 + step)
+        model.train()
+        opt.zero_grad()
+        traj.append(model.loss(datas, dataset=meta['sess'], accumulate_grad=True)['loss'])
+        opt.step()
+    np.testing.assert_allclose(traj, z['adam/losses'], rtol=2e-6)
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            _check_tensor(z, 'adam/param/' + k, p, rtol=1e-6, atol=1e-8)
