@@ -20,12 +20,16 @@ Frames are synthesised like the reference's integration test (tests/integration.
                               of the reference), and converted by ``bn_u8_to_unit_float``
 """
 
+import os
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
 from behavenet_amd import _hip
 
-__all__ = ['split_trials', 'SyntheticSession', 'SyntheticSessionsGenerator']
+__all__ = ['split_trials', 'SyntheticSession', 'SyntheticSessionsGenerator',
+           'SingleSessionDatasetBatchedLoad', 'ConcatSessionsGenerator']
 
 
 def split_trials(n_trials, rng_seed=0, train_tr=8, val_tr=1, test_tr=1, gap_tr=0):
@@ -96,25 +100,7 @@ class SyntheticSessionsGenerator(object):
             # several batches are served per training iteration (ref data_generator.py:697-699)
             self.n_tot_batches['train'] = int(
                 self.n_tot_batches['train'] / self.n_sessions_per_batch)
-        self._store = []
-        for ds in self.datasets:
-            trials = []
-            for u8 in ds.images_u8:
-                if placement == 'host':
-                    t = torch.from_numpy(u8.astype(np.float32) / 255)
-                    if device == 'cuda':
-                        t = t.pin_memory()
-                elif placement == 'device_u8':
-                    t = torch.from_numpy(u8).to(device)
-                elif placement == 'host_u8':
-                    t = torch.from_numpy(u8).pin_memory()
-                else:
-                    t = torch.from_numpy(u8.astype(np.float32) / 255).to(device)
-                trials.append(t)
-            labels = None
-            if ds.labels is not None:
-                labels = [torch.from_numpy(l).to(device) for l in ds.labels]
-            self._store.append((trials, labels))
+        self._store = [self._load_session(ds) for ds in self.datasets]
         # host_u8 prefetcher: two device staging buffers per trial shape, one copy stream
         self._pf = None          # (key, device uint8 tensor, ready event) of the prefetched trial
         self._pf_bufs = {}
@@ -122,6 +108,27 @@ class SyntheticSessionsGenerator(object):
         self._queues = [{k: [] for k in self._dtypes} for _ in self.datasets]
         for k in self._dtypes:
             self.reset_iterators(k)
+
+    def _load_session(self, ds):
+        """(image trials, label trials | None) in the chosen placement."""
+        placement, device = self.placement, self.device
+        trials = []
+        for u8 in ds.images_u8:
+            if placement == 'host':
+                t = torch.from_numpy(u8.astype(np.float32) / 255)
+                if device == 'cuda':
+                    t = t.pin_memory()
+            elif placement == 'device_u8':
+                t = torch.from_numpy(u8).to(device)
+            elif placement == 'host_u8':
+                t = torch.from_numpy(u8).pin_memory()
+            else:
+                t = torch.from_numpy(u8.astype(np.float32) / 255).to(device)
+            trials.append(t)
+        labels = None
+        if ds.labels is not None:
+            labels = [torch.from_numpy(l).to(device) for l in ds.labels]
+        return trials, labels
 
     def __len__(self):
         return self.n_datasets
@@ -177,7 +184,11 @@ class SyntheticSessionsGenerator(object):
         sample = {'images': img[None], 'batch_idx': torch.tensor([trial])}
         if labels is not None:
             sample['labels'] = labels[trial][None]
+        self._extra_signals(sample, sess, trial)
         return sample
+
+    def _extra_signals(self, sample, sess, trial):
+        pass
 
     # -- pinned uint8 feed with one-trial look-ahead ------------------------------------------
     def _staging(self, shape, slot):
@@ -227,3 +238,210 @@ class SyntheticSessionsGenerator(object):
                 ready.record(self._pf_stream)
             self._pf = ((sess, nxt), buf, ready, nslot)
         return img
+
+
+# ---------------------------------------------------------------------------------------------
+# file-backed sessions
+# ---------------------------------------------------------------------------------------------
+_FRAME_SIGNALS = ('images', 'masks', 'labels', 'labels_sc', 'labels_masks')
+
+
+class _LazyTrials(object):
+    """List-like over the trials of one signal: read from the store on first use, then kept (the
+    images as PINNED uint8 -- 1 byte per pixel, a quarter of the reference's float32 batches)."""
+
+    def __init__(self, dataset, signal, convert):
+        self.dataset, self.signal, self.convert = dataset, signal, convert
+        self.cache = {}
+
+    def __len__(self):
+        return self.dataset.n_trials
+
+    def __getitem__(self, trial):
+        t = self.cache.get(trial)
+        if t is None:
+            t = self.convert(self.dataset.read(self.signal, trial))
+            if self.dataset.keep_in_memory:
+                self.cache[trial] = t
+        return t
+
+
+class SingleSessionDatasetBatchedLoad(object):
+    """One session on disk, one trial per read (ref data_generator.py:137-343).
+
+    ``paths`` may name the reference's ``data.hdf5`` (needs h5py) or its ``data.npz`` mirror
+    (behavenet_amd/data/trial_store.py); if the hdf5 is absent the mirror next to it is used.
+    Signals on the autoencoder path only: images, masks, labels, labels_sc, labels_masks.
+    """
+
+    def __init__(self, data_dir, lab='', expt='', animal='', session='', signals=None,
+                 transforms=None, paths=None, device='cpu', as_numpy=False, keep_in_memory=True):
+        from behavenet_amd.data.trial_store import open_trial_store
+        self.lab, self.expt, self.animal, self.session = lab, expt, animal, session
+        self.data_dir = os.path.join(data_dir, lab, expt, animal, session)
+        self.name = os.path.join(lab, expt, animal, session)
+        self.sess_str = '%s_%s_%s_%s' % (lab, expt, animal, session)
+        self.signals = list(signals) if signals is not None else ['images']
+        transforms = transforms if transforms is not None else [None] * len(self.signals)
+        paths = paths if paths is not None else \
+            [os.path.join(self.data_dir, 'data.hdf5')] * len(self.signals)
+        self.transforms = OrderedDict(zip(self.signals, transforms))
+        self.paths = OrderedDict(zip(self.signals, paths))
+        for signal in self.signals:
+            if signal not in _FRAME_SIGNALS:
+                raise NotImplementedError(
+                    'signal "%s" is outside the autoencoder path (supported: %s)' % (
+                        signal, ', '.join(_FRAME_SIGNALS)))
+        self._stores = {}
+        self.n_trials = None
+        for signal in self.signals:
+            if self.n_trials is None and signal != 'masks':
+                self.n_trials = self._store(signal).n_trials(signal)
+        if self.n_trials is None:
+            self.n_trials = self._store(self.signals[0]).n_trials(self.signals[0])
+        self.batch_idxs = None
+        self.n_batches = None
+        self.device = device
+        self.as_numpy = as_numpy
+        self.keep_in_memory = keep_in_memory
+
+    def _store(self, signal):
+        from behavenet_amd.data.trial_store import open_trial_store
+        path = self.paths[signal]
+        if path not in self._stores:
+            self._stores[path] = open_trial_store(path)
+        return self._stores[path]
+
+    def __str__(self):
+        out = '%s\n' % self.sess_str
+        out += '    signals: {}\n'.format(self.signals)
+        out += '    transforms: {}\n'.format(self.transforms)
+        out += '    paths: {}\n'.format(self.paths)
+        return out
+
+    def __len__(self):
+        return self.n_trials
+
+    def read(self, signal, trial):
+        """Raw array of one trial as stored (images: uint8)."""
+        return np.asarray(self._store(signal).read(signal, trial))
+
+    def __getitem__(self, idx):
+        """The reference's sample dict for one trial on the HOST: images float32/255, the other
+        signals float32, transforms applied, ``batch_idx`` (ref :222-300)."""
+        if idx is None:
+            raise NotImplementedError('Cannot currently load all data as torch tensors')
+        sample = OrderedDict()
+        for signal in self.signals:
+            arr = self.read(signal, idx).astype('float32')
+            if signal == 'images':
+                arr = arr / 255
+            if self.transforms[signal]:
+                arr = self.transforms[signal](arr)
+            sample[signal] = arr if self.as_numpy else torch.from_numpy(arr).float()
+        sample['batch_idx'] = idx
+        return sample
+
+
+class ConcatSessionsGenerator(SyntheticSessionsGenerator):
+    """File-backed sessions behind the same iteration logic (ref data_generator.py:432-633).
+
+    Same constructor surface as the reference (``ids_list`` of {'lab','expt','animal','session'}
+    dicts, ``signals_list`` / ``transforms_list`` / ``paths_list`` per session, ``trial_splits``
+    dict, ``train_frac``, ``rng_seed``).  Images stay uint8 end to end: read from the store,
+    pinned on the host, copied to the device one trial ahead on a copy stream, converted by
+    ``bn_u8_to_unit_float`` (``placement='host_u8'``, the default); transforms on the images are
+    therefore not supported on this path (``SingleSessionDatasetBatchedLoad.__getitem__`` applies
+    them on the host for other uses).
+    """
+
+    def __init__(self, data_dir, ids_list, signals_list=None, transforms_list=None,
+                 paths_list=None, device='cuda', as_numpy=False, batch_load=True, rng_seed=0,
+                 trial_splits=None, train_frac=1.0, placement='host_u8', n_sessions_per_batch=1,
+                 keep_in_memory=True):
+        if as_numpy:
+            raise NotImplementedError('as_numpy generators are outside the training path')
+        if isinstance(ids_list, dict):
+            ids_list = [ids_list]
+        n = len(ids_list)
+        self.ids = ids_list
+        self.as_numpy, self.batch_load = as_numpy, batch_load
+        self.signals = signals_list if signals_list is not None else [['images']] * n
+        self.transforms = transforms_list if transforms_list is not None else \
+            [[None] * len(sig) for sig in self.signals]
+        self.paths = paths_list if paths_list is not None else [None] * n
+        datasets = []
+        self.datasets_info = []
+        for ids, signals, transforms, paths in zip(ids_list, self.signals, self.transforms,
+                                                   self.paths):
+            if transforms is not None and 'images' in signals and \
+                    transforms[list(signals).index('images')] is not None:
+                raise NotImplementedError('image transforms are not supported on the uint8 feed')
+            datasets.append(SingleSessionDatasetBatchedLoad(
+                data_dir, lab=ids['lab'], expt=ids['expt'], animal=ids['animal'],
+                session=ids['session'], signals=signals, transforms=transforms, paths=paths,
+                device=device, as_numpy=False, keep_in_memory=keep_in_memory))
+            self.datasets_info.append({k: ids[k] for k in ('lab', 'expt', 'animal', 'session')})
+        if trial_splits is None:
+            trial_splits = {'train_tr': 8, 'val_tr': 1, 'test_tr': 1, 'gap_tr': 0}
+        for ds in datasets:
+            ds.batch_idxs = split_trials(len(ds), rng_seed=rng_seed, **trial_splits)
+            n_train = len(ds.batch_idxs['train'])
+            if train_frac != 1.0:
+                # subsample the training trials (ref :520-534; numpy global RNG as seeded by
+                # split_trials)
+                if train_frac < 1.0:
+                    n_idxs = int(np.floor(train_frac * n_train))
+                    if n_idxs <= 0:
+                        print('warning: attempting to use invalid number of training ' +
+                              'batches; defaulting to all training batches')
+                        n_idxs = n_train
+                else:
+                    n_idxs = int(min(train_frac, n_train))
+                keep = np.random.choice(n_train, size=n_idxs, replace=False)
+                ds.batch_idxs['train'] = ds.batch_idxs['train'][keep]
+            ds.n_batches = {k: len(v) for k, v in ds.batch_idxs.items()}
+        super().__init__(datasets, device=device, placement=placement,
+                         n_sessions_per_batch=n_sessions_per_batch)
+
+    def _load_session(self, ds):
+        device = self.device
+
+        def images(u8):
+            if u8.dtype != np.uint8:
+                raise ValueError('images must be stored as uint8 (got %s)' % u8.dtype)
+            if self.placement == 'host_u8':
+                t = torch.from_numpy(np.ascontiguousarray(u8))
+                return t.pin_memory() if device == 'cuda' else t
+            if self.placement == 'device_u8':
+                return torch.from_numpy(np.ascontiguousarray(u8)).to(device)
+            t = torch.from_numpy(u8.astype(np.float32) / 255)
+            if self.placement == 'host':
+                return t.pin_memory() if device == 'cuda' else t
+            return t.to(device)
+
+        def floats(signal):
+            tr = ds.transforms[signal]
+
+            def conv(a):
+                a = a.astype(np.float32)
+                if tr:
+                    a = tr(a)
+                return torch.from_numpy(np.ascontiguousarray(a)).float().to(device)
+            return conv
+        self._extra = getattr(self, '_extra', [])
+        extra = {sig: _LazyTrials(ds, sig, floats(sig)) for sig in ds.signals
+                 if sig not in ('images', 'labels')}
+        self._extra.append(extra)
+        labels = _LazyTrials(ds, 'labels', floats('labels')) if 'labels' in ds.signals else None
+        return _LazyTrials(ds, 'images', images), labels
+
+    def _extra_signals(self, sample, sess, trial):
+        for signal, trials in self._extra[sess].items():
+            sample[signal] = trials[trial][None]
+
+    def __str__(self):
+        out = 'Generator contains %i SingleSessionDatasetBatchedLoad objects:\n' % self.n_datasets
+        for ds in self.datasets:
+            out += ds.__str__()
+        return out

@@ -670,6 +670,55 @@ def test_host_u8_prefetch_feed_is_bit_identical():
         assert torch.equal(x1, x2)
 
 
+def test_file_backed_uint8_feed_on_device(tmp_path):
+    """ConcatSessionsGenerator over data.npz session files, images uint8 from disk -> pinned host
+    -> device one trial ahead -> bn_u8_to_unit_float: bit-identical batches to the resident
+    float32 feed over two epochs, and a short fit() through it."""
+    from behavenet_amd.data.data_generator import ConcatSessionsGenerator
+    from tests.test_fit_host import _write_sessions, _epoch
+    root = str(tmp_path)
+    ids, sessions = _write_sessions(root, n_sessions=2, n_trials=10, dim=(1, 32, 32), n_labels=0)
+    gen_f = ConcatSessionsGenerator(root, ids, device=DEV)            # placement='host_u8'
+    gen_m = SyntheticSessionsGenerator(sessions, device=DEV, placement='device')
+    for seed in (0, 1):
+        a, b = _epoch(gen_f, 'train', seed), _epoch(gen_m, 'train', seed)
+        torch.cuda.synchronize()
+        assert len(a) == len(b) == 16
+        for (s1, t1, d1), (s2, t2, d2) in zip(a, b):
+            assert (s1, t1) == (s2, t2)
+            assert d1['images'].is_cuda and torch.equal(d1['images'], d2['images'])
+    arch = load_handcrafted_arch([1, 32, 32], 8, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    hp.update({'expt_dir': root, 'max_n_epochs': 1, 'min_n_epochs': 0, 'val_check_interval': 1,
+               'enable_early_stop': False, 'early_stop_history': 10, 'rng_seed_train': 0,
+               'export_latents': False, 'progress_bar': False, 'device': 'cuda'})
+    os.makedirs(os.path.join(root, 'version_0'), exist_ok=True)
+
+    def run(gen):
+        torch.manual_seed(0)
+        model = AE(dict(hp)).to(DEV)
+        model.version = 0
+
+        class Exp(object):
+            version = 0
+
+            def __init__(self):
+                self.rows = []
+
+            def log(self, row):
+                self.rows.append(dict(row))
+
+            def save(self):
+                pass
+        exp = Exp()
+        fit(dict(hp), model, gen, exp, method='ae')
+        return [r for r in exp.rows if 'tr_loss' in r or 'val_loss' in r]
+    rows_f, rows_m = run(gen_f), run(gen_m)
+    assert len(rows_f) == len(rows_m) > 0
+    for rf, rm in zip(rows_f, rows_m):
+        assert rf == rm
+
+
 def test_losses_known_answers_on_device():
     """Closed-form answers of the reference's tests/test_fitting/test_losses.py:8-94."""
     LN2PI = np.log(2 * np.pi)
