@@ -490,7 +490,7 @@ class AE(BaseModel):
             not self.hparams.get('ae_batch_norm', False) and \
             os.environ.get('BN_WHOLE_BATCH', '1') != '0'
 
-    def _loss_whole_batch(self, x, m, dataset, accumulate_grad, chunk_size):
+    def _loss_whole_batch(self, x, m, dataset, accumulate_grad, chunk_size, **fwd_kwargs):
         """ONE forward and ONE backward pass over the whole batch with the reference's per-chunk
         loss normalisation (ref aes.py:748-771): the gradient is the same
         sum_chunks grad(mean_chunk) and the reported loss the same frame-weighted mean, but
@@ -501,7 +501,7 @@ class AE(BaseModel):
                   for beg in range(0, batch_size, chunk_size)]
         self._reserve_pools(x)
         with torch.set_grad_enabled(bool(accumulate_grad)):
-            x_hat, _ = self.forward(x, dataset=dataset)
+            x_hat, _ = self.forward(x, dataset=dataset, **fwd_kwargs)
             chunk_losses = losses.mse_chunks(x, x_hat, m, bounds)
         vals = Readback(chunk_losses.detach())
         if accumulate_grad:
@@ -576,8 +576,6 @@ class AE(BaseModel):
 class ConditionalAE(AE):
     """Conditional autoencoder: labels are appended to the latents (ref aes.py:776-898)."""
 
-    _whole_batch = False
-
     def __init__(self, hparams):
         if hparams['model_type'] == 'linear':
             raise NotImplementedError
@@ -604,6 +602,10 @@ class ConditionalAE(AE):
             else None
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
+        if self._whole_batch_ok(x):
+            # labels ride along frame by frame: same single-pass schedule as AE.loss
+            return self._loss_whole_batch(x, m, dataset, accumulate_grad, chunk_size,
+                                          labels=y, labels_2d=labels_2d)
         vals, sizes, deferred = ChunkScalars(), [], []
         self._reserve_pools(x)
         self._prepare_first_layer(x, dataset)

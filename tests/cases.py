@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
-from tests.golden_utils import base_hparams, make_frames, make_labels
+from tests.golden_utils import base_hparams, make_frames, make_labels, make_labels_sc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -32,7 +32,21 @@ def case_data(meta, device='cpu'):
     if meta['n_labels']:
         y = torch.from_numpy(make_labels(meta['n_frames'], meta['n_labels'], seed=2)).to(device)
         data['labels'] = y[None]
+    if meta['extra_hp'].get('conditional_encoder') and meta['model_class'] == 'cond-ae':
+        y2 = torch.from_numpy(make_labels_sc(
+            meta['n_frames'], meta['n_labels'] // 2, meta['dim'], seed=3)).to(device)
+        data['labels_sc'] = y2[None]
     return data
+
+
+def forward_kwargs(meta, data, n_fwd):
+    """Extra forward() arguments of the label-conditioned classes."""
+    if meta['model_class'] not in ('cond-vae', 'cond-ae'):
+        return {}
+    kw = {'labels': data['labels'][0][:n_fwd], 'labels_2d': None}
+    if 'labels_sc' in data:
+        kw['labels_2d'] = data['labels_sc'][0][:n_fwd]
+    return kw
 
 
 def seeded_build(builder, hp):

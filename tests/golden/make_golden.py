@@ -129,6 +129,10 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
     if n_labels:
         y = torch.from_numpy(make_labels(n_frames, n_labels, seed=2))
         data['labels'] = y[None]
+    if model_class == 'cond-ae' and (extra_hp or {}).get('conditional_encoder'):
+        from tests.golden_utils import make_labels_sc
+        data['labels_sc'] = torch.from_numpy(
+            make_labels_sc(n_frames, n_labels // 2, dim, seed=3))[None]
 
     # eps: record what torch's CPU generator hands to reparameterize so that the oracle and the
     # device run can be fed the same noise
@@ -155,11 +159,13 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
     torch.manual_seed(123)
     with torch.no_grad():
         kw = {}
-        if model_class == 'cond-vae':
+        if model_class in ('cond-vae', 'cond-ae'):
             kw = {'labels': data['labels'][0], 'labels_2d': None}
         n_fwd = min(n_frames, 8)
-        if model_class == 'cond-vae':
+        if model_class in ('cond-vae', 'cond-ae'):
             kw['labels'] = kw['labels'][:n_fwd]
+            if 'labels_sc' in data:
+                kw['labels_2d'] = data['labels_sc'][0][:n_fwd]
         out = model(x[:n_fwd], dataset=0, **kw)
     for h in hooks:
         h.remove()
@@ -432,6 +438,13 @@ if __name__ == '__main__':
         model_case('vae_1x64x48_bn', RefVAE, [1, 64, 48], 8, 6, 'vae',
                    extra_hp={'ae_batch_norm': True, 'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0,
                              'max_n_epochs': 10})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'condae':
+        from behavenet.models.aes import ConditionalAE as RefCondAE
+        model_case('condae_cfg1', RefCondAE, [1, 32, 32], 8, 210, 'cond-ae', n_labels=4,
+                   extra_hp={'conditional_encoder': False}, store_xhat=True)
+        model_case('condae_enc_cfg1', RefCondAE, [1, 32, 32], 8, 12, 'cond-ae', n_labels=4,
+                   extra_hp={'conditional_encoder': True}, store_xhat=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'msps':
         msps_case()

@@ -38,6 +38,19 @@ def make_labels(n_frames, n_labels, seed):
     return rng.standard_normal((n_frames, n_labels)).astype(np.float32)
 
 
+def make_labels_sc(n_frames, n_maps, dim, seed):
+    """One-hot label maps (N, n_maps, H, W): one pixel set per frame and map (the `labels_sc`
+    signal of the conditional encoder, ref aes.py:818-826)."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n_frames, n_maps, dim[1], dim[2]), dtype=np.float32)
+    ys = rng.integers(0, dim[1], size=(n_frames, n_maps))
+    xs = rng.integers(0, dim[2], size=(n_frames, n_maps))
+    for n in range(n_frames):
+        for k in range(n_maps):
+            out[n, k, ys[n, k], xs[n, k]] = 1.0
+    return out
+
+
 def base_hparams(arch, model_class, extra=None):
     hp = dict(arch)
     hp.update({

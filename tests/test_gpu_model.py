@@ -21,18 +21,18 @@ from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSession
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
 from behavenet_amd.fitting.training import fit
 from behavenet_amd.fitting import losses
-from behavenet_amd.models import AE, AEMSP, VAE, ConditionalVAE, BetaTCVAE, PSVAE, MSPSVAE, ConvDecoder
+from behavenet_amd.models import AE, ConditionalAE, AEMSP, VAE, ConditionalVAE, BetaTCVAE, PSVAE, MSPSVAE, ConvDecoder
 from behavenet_amd.models import vaes as hip_vaes
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from oracle import ref_cpu
-from tests.cases import load_case, case_hparams, case_data, seeded_build, EpsReplay, eps_list
+from tests.cases import forward_kwargs, load_case, case_hparams, case_data, seeded_build, EpsReplay, eps_list
 from tests.golden_utils import base_hparams, checksum, checksum_close, make_frames
 from tests.test_gpu_kernels import close
 from tests.branches import record_branches, BranchReplay
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
-BUILDERS = {'ae': AE, 'vae': VAE, 'cond-vae': ConditionalVAE, 'beta-tcvae': BetaTCVAE,
+BUILDERS = {'ae': AE, 'cond-ae': ConditionalAE, 'vae': VAE, 'cond-vae': ConditionalVAE, 'beta-tcvae': BetaTCVAE,
             'ps-vae': PSVAE, 'msps-vae': MSPSVAE, 'cond-ae-msp': AEMSP,
             'conv-decoder': ConvDecoder}
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -73,7 +73,8 @@ def grads_close_on_same_branches(hip, ora64, name, tol=2e-5):
 
 
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
-         'condvae_cfg1', 'psvae_cfg4', 'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff', 'aemsp_cfg1']
+         'condvae_cfg1', 'psvae_cfg4', 'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff', 'aemsp_cfg1',
+         'condae_cfg1', 'condae_enc_cfg1']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -84,10 +85,7 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
     data_c = case_data(meta)
     data_g = {k: v.to(DEV) for k, v in data_c.items()}
     n_fwd = meta['n_fwd']
-    kw_c, kw_g = {}, {}
-    if meta['model_class'] == 'cond-vae':
-        kw_c = {'labels': data_c['labels'][0][:n_fwd], 'labels_2d': None}
-        kw_g = {'labels': data_g['labels'][0][:n_fwd], 'labels_2d': None}
+    kw_c, kw_g = forward_kwargs(meta, data_c, n_fwd), forward_kwargs(meta, data_g, n_fwd)
 
     # forward (same eps on both sides, the one the reference drew)
     hip.train()

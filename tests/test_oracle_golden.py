@@ -10,12 +10,13 @@ import pytest
 import torch
 
 from oracle import ref_cpu
-from tests.cases import load_case, case_hparams, case_data, seeded_build, EpsReplay, eps_list
+from tests.cases import forward_kwargs, load_case, case_hparams, case_data, seeded_build, EpsReplay, eps_list
 from tests.golden_utils import checksum, checksum_close, strided_sample
 
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
          'condvae_cfg1', 'psvae_cfg4',
-         'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff', 'aemsp_cfg1']
+         'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff', 'aemsp_cfg1',
+         'condae_cfg1', 'condae_enc_cfg1']
 
 
 def _check_tensor(z, prefix, t, rtol, atol=1e-7):
@@ -56,12 +57,13 @@ def test_oracle_matches_reference(name):
             model.eps_fn = EpsReplay([z['fwd/eps']])
         # the extra encoder pass (for the per-layer taps) must not count as a batch-norm update
         bufs = {k: v.clone() for k, v in model.named_buffers()}
-        enc_out = model.encoding(x[:n_fwd], dataset=0, taps=taps_e)
+        x_enc = x[:n_fwd]
+        if 'labels_sc' in data:
+            x_enc = torch.cat((x_enc, data['labels_sc'][0][:n_fwd]), dim=1)
+        enc_out = model.encoding(x_enc, dataset=0, taps=taps_e)
         for k, v in model.named_buffers():
             v.copy_(bufs[k])
-        kw = {}
-        if meta['model_class'] == 'cond-vae':
-            kw = {'labels': data['labels'][0][:n_fwd], 'labels_2d': None}
+        kw = forward_kwargs(meta, data, n_fwd)
         out = model(x[:n_fwd], dataset=0, **kw)
     act_keys = [k for k in z.files if k.startswith('act/encoding')]
     assert len(act_keys) == len(taps_e)
