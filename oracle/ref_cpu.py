@@ -342,17 +342,48 @@ def _chunks(batch_size, chunk_size):
         yield beg, min(beg + chunk_size, batch_size)
 
 
+class LinearEncoder(nn.Module):
+    """Dense encoder (ref aes.py:491-544)."""
+
+    def __init__(self, n_latents, input_size):
+        super().__init__()
+        self.encoder = nn.Linear(int(np.prod(input_size)), n_latents, bias=True)
+
+    def forward(self, x, dataset=None, taps=None):
+        return self.encoder(x.view(x.size(0), -1)), None, None
+
+
+class LinearDecoder(nn.Module):
+    """Dense decoder on the transposed encoder weights plus its own bias (ref aes.py:547-613)."""
+
+    def __init__(self, n_latents, output_size, encoder):
+        super().__init__()
+        self.output_size = tuple(output_size)
+        self.encoder = encoder
+        self.bias = nn.Parameter(torch.zeros(int(np.prod(output_size))), requires_grad=True)
+
+    def forward(self, x, dataset=None):
+        x = F.linear(x, self.encoder.encoder.weight.t()) + self.bias
+        return x.view(x.size(0), *self.output_size)
+
+
 class AE(nn.Module):
     def __init__(self, hparams):
         super().__init__()
         self.hparams = hparams
         self.model_type = hparams['model_type']
-        if self.model_type != 'conv':
-            raise NotImplementedError('oracle covers model_type="conv"')
+        if self.model_type == 'linear' and type(self) is not AE:
+            raise NotImplementedError('oracle covers model_type="linear" for the plain AE only')
         self.build_model()
 
     def build_model(self):
         self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
+        if self.model_type == 'linear':
+            size = (self.hparams['n_input_channels'], self.hparams['y_pixels'],
+                    self.hparams['x_pixels'])
+            self.encoding = LinearEncoder(self.hparams['n_ae_latents'], size)
+            self.decoding = LinearDecoder(self.hparams['n_ae_latents'], size, self.encoding)
+            return
         self.encoding = ConvEncoder(self.hparams)
         self.decoding = ConvDecoder(self.hparams)
 
@@ -361,6 +392,8 @@ class AE(nn.Module):
 
     def forward(self, x, dataset=None, **kwargs):
         z, pi, os_ = self.encoding(x, dataset=dataset)
+        if self.model_type == 'linear':
+            return self.decoding(z), z
         return self.decoding(z, pi, os_, dataset=dataset), z
 
     def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):

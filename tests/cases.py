@@ -7,7 +7,8 @@ import numpy as np
 import torch
 
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
-from tests.golden_utils import base_hparams, make_frames, make_labels, make_labels_sc
+from tests.golden_utils import (
+    base_hparams, make_frames, make_labels, make_labels_sc, make_masks)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -19,7 +20,8 @@ def load_case(name):
 
 
 def case_hparams(meta):
-    arch = load_handcrafted_arch(list(meta['dim']), meta['n_lat'], None, check_memory=False)
+    arch_json = os.path.join(GOLDEN, meta['arch_json']) if meta.get('arch_json') else None
+    arch = load_handcrafted_arch(list(meta['dim']), meta['n_lat'], arch_json, check_memory=False)
     hp = base_hparams(arch, meta['model_class'], meta['extra_hp'])
     if meta['n_labels']:
         hp['n_labels'] = meta['n_labels']
@@ -32,6 +34,9 @@ def case_data(meta, device='cpu'):
     if meta['n_labels']:
         y = torch.from_numpy(make_labels(meta['n_frames'], meta['n_labels'], seed=2)).to(device)
         data['labels'] = y[None]
+    if meta.get('masks'):
+        data['masks'] = torch.from_numpy(
+            make_masks(meta['n_frames'], meta['dim'], seed=4)).to(device)[None]
     if meta['extra_hp'].get('conditional_encoder') and meta['model_class'] == 'cond-ae':
         y2 = torch.from_numpy(make_labels_sc(
             meta['n_frames'], meta['n_labels'] // 2, meta['dim'], seed=3)).to(device)

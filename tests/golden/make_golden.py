@@ -111,8 +111,10 @@ def tensor_record(store, prefix, t, full_limit=4096):
 
 
 def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None, n_labels=0,
-               chunked=False, store_xhat=True):
-    arch = ref_arch.load_handcrafted_arch(list(dim), n_lat, None, check_memory=False)
+               chunked=False, store_xhat=True, dataset=0, masks=False, arch_json=None):
+    arch = ref_arch.load_handcrafted_arch(
+        list(dim), n_lat, os.path.join(HERE, arch_json) if arch_json else None,
+        check_memory=False)
     hp = base_hparams(arch, model_class, extra_hp)
     if n_labels:
         hp['n_labels'] = n_labels
@@ -129,6 +131,9 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
     if n_labels:
         y = torch.from_numpy(make_labels(n_frames, n_labels, seed=2))
         data['labels'] = y[None]
+    if masks:
+        from tests.golden_utils import make_masks
+        data['masks'] = torch.from_numpy(make_masks(n_frames, dim, seed=4))[None]
     if model_class == 'cond-ae' and (extra_hp or {}).get('conditional_encoder'):
         from tests.golden_utils import make_labels_sc
         data['labels_sc'] = torch.from_numpy(
@@ -166,7 +171,7 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
             kw['labels'] = kw['labels'][:n_fwd]
             if 'labels_sc' in data:
                 kw['labels_2d'] = data['labels_sc'][0][:n_fwd]
-        out = model(x[:n_fwd], dataset=0, **kw)
+        out = model(x[:n_fwd], dataset=dataset, **kw)
     for h in hooks:
         h.remove()
     for nm, a in acts:
@@ -189,7 +194,7 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
     torch.manual_seed(124)
     model.zero_grad()
     model.curr_epoch = 3 if variational else 0
-    loss_dict = model.loss(data, dataset=0, accumulate_grad=True)
+    loss_dict = model.loss(data, dataset=dataset, accumulate_grad=True)
     store['loss/keys'] = np.array(sorted(loss_dict.keys()))
     store['loss/vals'] = np.array([float(loss_dict[k]) for k in sorted(loss_dict.keys())],
                                   dtype=np.float64)
@@ -208,7 +213,7 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
     for step in range(3):
         torch.manual_seed(200 + step)
         opt.zero_grad()
-        ld = model.loss(data, dataset=0, accumulate_grad=True)
+        ld = model.loss(data, dataset=dataset, accumulate_grad=True)
         opt.step()
         traj.append(float(ld['loss']))
         if variational:
@@ -237,7 +242,8 @@ def model_case(name, RefModel, dim, n_lat, n_frames, model_class, extra_hp=None,
 
     meta = {'dim': list(dim), 'n_lat': n_lat, 'n_frames': n_frames, 'model_class': model_class,
             'n_labels': n_labels, 'extra_hp': extra_hp or {}, 'n_fwd': n_fwd,
-            'curr_epoch': model.curr_epoch if variational else 0}
+            'curr_epoch': model.curr_epoch if variational else 0, 'dataset': dataset,
+            'masks': bool(masks), 'arch_json': arch_json}
     store['meta'] = np.array(json.dumps(meta))
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **store)
@@ -438,6 +444,14 @@ if __name__ == '__main__':
         model_case('vae_1x64x48_bn', RefVAE, [1, 64, 48], 8, 6, 'vae',
                    extra_hp={'ae_batch_norm': True, 'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0,
                              'max_n_epochs': 10})
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'options':
+        # session-specific input/output layers (dataset 1 of 2) with pixel masks; linear AE
+        model_case('ae_sessio_masks', RefAE, [1, 32, 32], 8, 210, 'ae',
+                   extra_hp={'fit_sess_io_layers': True, 'n_datasets': 2}, dataset=1, masks=True)
+        model_case('ae_linear', RefAE, [1, 32, 32], 8, 12, 'ae',
+                   extra_hp={'model_type': 'linear'})
+        model_case('ae_valid_1x30x26', RefAE, [1, 30, 26], 6, 12, 'ae', arch_json='arch_valid.json')
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'condae':
         from behavenet.models.aes import ConditionalAE as RefCondAE

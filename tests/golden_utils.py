@@ -38,6 +38,12 @@ def make_labels(n_frames, n_labels, seed):
     return rng.standard_normal((n_frames, n_labels)).astype(np.float32)
 
 
+def make_masks(n_frames, dim, seed):
+    """0/1 pixel masks, ~70 % ones (the `masks` signal, ref losses.py:56-59)."""
+    rng = np.random.default_rng(seed)
+    return (rng.random((n_frames,) + tuple(dim)) < 0.7).astype(np.float32)
+
+
 def make_labels_sc(n_frames, n_maps, dim, seed):
     """One-hot label maps (N, n_maps, H, W): one pixel set per frame and map (the `labels_sc`
     signal of the conditional encoder, ref aes.py:818-826)."""

@@ -74,12 +74,13 @@ def grads_close_on_same_branches(hip, ora64, name, tol=2e-5):
 
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
          'condvae_cfg1', 'psvae_cfg4', 'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff', 'aemsp_cfg1',
-         'condae_cfg1', 'condae_enc_cfg1']
+         'condae_cfg1', 'condae_enc_cfg1', 'ae_sessio_masks', 'ae_linear', 'ae_valid_1x30x26']
 
 
 @pytest.mark.parametrize('name', CASES)
 def test_forward_loss_grads_vs_oracle_and_golden(name):
     z, meta = load_case(name)
+    DS = meta.get('dataset', 0)
     hip, ora, hp = _pair(meta)
     variational = meta['model_class'] in ('vae', 'ps-vae', 'cond-vae', 'beta-tcvae')
     data_c = case_data(meta)
@@ -95,8 +96,8 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
         hip_vaes.set_eps_provider(EpsReplay([z['fwd/eps']], DEV))
     try:
         with torch.no_grad():
-            out_o = ora(data_c['images'][0][:n_fwd], dataset=0, **kw_c)
-            out_h = hip(data_g['images'][0][:n_fwd], dataset=0, **kw_g)
+            out_o = ora(data_c['images'][0][:n_fwd], dataset=DS, **kw_c)
+            out_h = hip(data_g['images'][0][:n_fwd], dataset=DS, **kw_g)
         for i, (a, b) in enumerate(zip(out_h, out_o)):
             close(a, b, name='%s fwd out%d' % (name, i))
         # against the reference itself
@@ -112,8 +113,8 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
             hip.curr_epoch = ora.curr_epoch = meta['curr_epoch']
             ora.eps_fn = EpsReplay(eps_list(z, 'loss/eps'))
             hip_vaes.set_eps_provider(EpsReplay(eps_list(z, 'loss/eps'), DEV))
-        loss_o = ora.loss(data_c, dataset=0, accumulate_grad=True)
-        loss_h = hip.loss(data_g, dataset=0, accumulate_grad=True)
+        loss_o = ora.loss(data_c, dataset=DS, accumulate_grad=True)
+        loss_h = hip.loss(data_g, dataset=DS, accumulate_grad=True)
     finally:
         hip_vaes.set_eps_provider(None)
     assert sorted(loss_h.keys()) == sorted(loss_o.keys()) == [str(k) for k in z['loss/keys']]
@@ -129,9 +130,9 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
         ora64.train()
         data64 = {k: v.double() for k, v in data_c.items()}
         with torch.no_grad():
-            ora64(data64['images'][0][:n_fwd], dataset=0)
+            ora64(data64['images'][0][:n_fwd], dataset=DS)
         ora64.zero_grad()
-        ora64.loss(data64, dataset=0, accumulate_grad=True)
+        ora64.loss(data64, dataset=DS, accumulate_grad=True)
         g64 = {k: p.grad for k, p in ora64.named_parameters()}
     names = set(k for k, _ in ora.named_parameters())
     for (k, ph), (_, po) in zip(hip.named_parameters(), ora.named_parameters()):

@@ -16,7 +16,7 @@ from tests.golden_utils import checksum, checksum_close, strided_sample
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
          'condvae_cfg1', 'psvae_cfg4',
          'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff', 'aemsp_cfg1',
-         'condae_cfg1', 'condae_enc_cfg1']
+         'condae_cfg1', 'condae_enc_cfg1', 'ae_sessio_masks', 'ae_linear', 'ae_valid_1x30x26']
 
 
 def _check_tensor(z, prefix, t, rtol, atol=1e-7):
@@ -33,6 +33,7 @@ def _check_tensor(z, prefix, t, rtol, atol=1e-7):
 def test_oracle_matches_reference(name):
     torch.set_num_threads(8)
     z, meta = load_case(name)
+    DS = meta.get('dataset', 0)
     hp = case_hparams(meta)
     model = seeded_build(ref_cpu.build_model, hp)
     variational = meta['model_class'] in ('vae', 'ps-vae', 'cond-vae', 'beta-tcvae')
@@ -60,11 +61,11 @@ def test_oracle_matches_reference(name):
         x_enc = x[:n_fwd]
         if 'labels_sc' in data:
             x_enc = torch.cat((x_enc, data['labels_sc'][0][:n_fwd]), dim=1)
-        enc_out = model.encoding(x_enc, dataset=0, taps=taps_e)
+        enc_out = model.encoding(x_enc, dataset=DS, taps=taps_e)
         for k, v in model.named_buffers():
             v.copy_(bufs[k])
         kw = forward_kwargs(meta, data, n_fwd)
-        out = model(x[:n_fwd], dataset=0, **kw)
+        out = model(x[:n_fwd], dataset=DS, **kw)
     act_keys = [k for k in z.files if k.startswith('act/encoding')]
     assert len(act_keys) == len(taps_e)
     for i, t in enumerate(taps_e):
@@ -85,7 +86,7 @@ def test_oracle_matches_reference(name):
     if variational:
         model.curr_epoch = meta['curr_epoch']
         model.eps_fn = EpsReplay(eps_list(z, 'loss/eps'))
-    loss = model.loss(data, dataset=0, accumulate_grad=True)
+    loss = model.loss(data, dataset=DS, accumulate_grad=True)
     keys = [str(k) for k in z['loss/keys']]
     assert sorted(loss.keys()) == keys
     got = np.array([float(loss[k]) for k in keys])
@@ -100,7 +101,7 @@ def test_oracle_matches_reference(name):
     for step in range(3):
         if variational:
             model.eps_fn = EpsReplay(eps_list(z, 'adam/eps_step%d_' % step))
-        losses.append(ref_cpu.train_step(model, opt, data)['loss'])
+        losses.append(ref_cpu.train_step(model, opt, data, dataset=DS)['loss'])
     np.testing.assert_allclose(losses, z['adam/losses'], rtol=1e-6)
     for k, p in model.named_parameters():
         if p.requires_grad:
