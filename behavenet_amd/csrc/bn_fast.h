@@ -62,3 +62,16 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
 BnFastPlan bn_edge_up_plan(const BnGeom& g);
 int bn_launch_edge_up(const float* small, const float* w, const float* bias, float* out,
                       const BnGeom& g, int act, float slope, hipStream_t st);
+
+// conv_qgemm.hip: stride == kernel (5x5 s5) between an 8x8 and a 2x2 map: four dense 16-tap
+// quadrant GEMMs per role (skips the taps that only ever meet padding)
+bool bn_qgemm_supported(const BnGeom& g);
+size_t bn_qgemm_ws_bytes(int role, const BnGeom& g);     // role: 0 down, 1 up, 2 wgrad
+int bn_launch_qgemm_down(const float* big, const float* w, const float* bias, float* out,
+                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                         void* ws, hipStream_t st);
+int bn_launch_qgemm_up(const float* small, const float* w, const float* bias, float* out,
+                       const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                       void* ws, hipStream_t st);
+int bn_launch_qgemm_wgrad(const float* small, const float* big, float* dw, const BnGeom& g,
+                          int accumulate, void* ws, hipStream_t st);

@@ -181,6 +181,11 @@ static int run_down(int family, const float* big, const float* w, const float* b
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }
     }
+    if (!force_generic() && bn_qgemm_supported(g)) {
+        if (!ws || ws_bytes < bn_qgemm_ws_bytes(0, g)) return BN_E_WORKSPACE;
+        BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<down>", st);
+        return bn_launch_qgemm_down(big, w, bias, out, dact_src, g, act, dact, slope, ws, st);
+    }
     BnFastPlan plan = bn_fast_down_plan(g);
     if (force_generic()) plan.supported = false;
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_down_generic", st);
@@ -194,6 +199,11 @@ static int run_down(int family, const float* big, const float* w, const float* b
 static int run_up(int family, const float* small, const float* w, const float* bias, float* out,
                   const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                   void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!force_generic() && bn_qgemm_supported(g)) {
+        if (!ws || ws_bytes < bn_qgemm_ws_bytes(1, g)) return BN_E_WORKSPACE;
+        BnProfScope prof(family, g.Cs, g.Cb, "k_qgemm<up>", st);
+        return bn_launch_qgemm_up(small, w, bias, out, dact_src, g, act, dact, slope, ws, st);
+    }
     if (!force_generic()) {
         const BnFastPlan s5 = bn_s5_up_plan(g);
         if (s5.supported) {
@@ -221,6 +231,11 @@ static int run_up(int family, const float* small, const float* w, const float* b
 static int run_wgrad(int family, const float* small, const float* big, float* dw,
                      const BnGeom& g, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
                      float* db, int bias_side, bool* bias_done) {
+    if (!force_generic() && bn_qgemm_supported(g)) {
+        if (!ws || ws_bytes < bn_qgemm_ws_bytes(2, g)) return BN_E_WORKSPACE;
+        BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<wgrad>", st);
+        return bn_launch_qgemm_wgrad(small, big, dw, g, accumulate, ws, st);
+    }
     if (!force_generic()) {
         const BnFastPlan s5 = bn_s5_wgrad_plan(g);
         if (s5.supported) {
@@ -264,6 +279,12 @@ extern "C" size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, in
     if (op == BN_OP_CONV_BWD_W) bias_ws = bn_channel_sum_ws_bytes(N, K, P * Q);
     if (op == BN_OP_CONVT_BWD_W) bias_ws = bn_channel_sum_ws_bytes(N, K, P * Q);
     if (force_generic()) return bias_ws;
+    if (bn_qgemm_supported(g)) {
+        const int role = (op == BN_OP_CONV_FWD || op == BN_OP_CONVT_BWD_D) ? 0 :
+                         (op == BN_OP_CONV_BWD_D || op == BN_OP_CONVT_FWD) ? 1 : 2;
+        const size_t need = bn_qgemm_ws_bytes(role, g);
+        return need > bias_ws ? need : bias_ws;
+    }
     BnFastPlan plan;
     switch (op) {
         case BN_OP_CONV_FWD: case BN_OP_CONVT_BWD_D: plan = bn_fast_down_plan(g); break;

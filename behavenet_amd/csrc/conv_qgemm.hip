@@ -1,0 +1,327 @@
+// Stride == kernel (5x5, stride 5) layers between an 8x8 and a 2x2 map with offset 1: enc.conv4 and
+// dec.convT0 of the default architecture at 128x128 frames, all three roles.
+//
+// The windows of the four small-side pixels do not overlap: small pixel (p, q) sees the 4x4 block
+// (4p..4p+3, 4q..4q+3) of the 8x8 map through the taps r = y - 5p + 1, s = x - 5q + 1, and the
+// fifth row / column of every window lies in the padding.  Only 16 of the 25 taps of a window
+// ever meet data, so each role is four DENSE GEMMs (one per quadrant z = 2p + q) over 16-tap
+// weight slices -- 64 % of the multiply-adds of the zero-padded formulation (4.3 instead of 6.7
+// GFLOP per role at 256 frames), every operand element used exactly once:
+//
+//   down  (conv fwd, convT bwd-data)   S[n][m][z]      = sum_{c,j} B[n][c][pix(z,j)] W[m][c][tap(z,j)]
+//   up    (convT fwd, conv bwd-data)   B[n][c][pix]    = sum_m     S[n][m][z]        W[m][c][tap(z,j)]
+//   wgrad                              dWz[z][m][c][j] = sum_n     S[n][m][z]        B[n][c][pix(z,j)]
+//
+// One tiled MFMA kernel (v_mfma_f32_32x32x2_f32, 64x64 tile per workgroup of four waves, 32-deep
+// stages through LDS, next stage's global loads in flight during the matrix work) serves the
+// three roles; only the address functions differ.  It writes raw tiles to a packed scratch
+// [split][z][M][N]; a role-specific second kernel adds the splits in fixed order, applies bias /
+// activation / activation derivative and scatters to the NCHW tensor (for the weight gradient:
+// adds the quadrants that share a tap, in fixed order).
+#include <stdlib.h>
+#include "bn_common.h"
+#include "bn_fast.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define QG_T 64          // tile edge
+#define QG_KS 32         // reduction depth of a stage
+#define QG_LD 33         // LDS row stride: odd -> the 32 rows x 2 k of an MFMA operand read hit
+                         // 64 distinct banks
+enum { QG_DOWN = 0, QG_UP = 1, QG_WGRAD = 2 };
+
+struct QGArgs {
+    const float* small;
+    const float* big;
+    const float* w;
+    float* part;
+    int N, Cs, Cb;
+    int M, Nc, K;        // GEMM sizes of one quadrant
+    int kper;            // reduction elements per split (multiple of QG_KS)
+};
+
+__device__ __forceinline__ int qg_pix(int z, int j) {
+    return (4 * (z >> 1) + (j >> 2)) * 8 + 4 * (z & 1) + (j & 3);
+}
+__device__ __forceinline__ int qg_tap(int z, int j) {
+    return (((z >> 1) ? 0 : 1) + (j >> 2)) * 5 + ((z & 1) ? 0 : 1) + (j & 3);
+}
+
+typedef float floatx4a __attribute__((ext_vector_type(4)));
+typedef float floatx4u __attribute__((ext_vector_type(4), aligned(4)));   // tap runs: 4-byte aligned
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
+    __shared__ float As[QG_T * QG_LD];
+    __shared__ float Bs[QG_T * QG_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lk = lane >> 5;
+    const int z = blockIdx.z & 3, ks = blockIdx.z >> 2;
+    const int i0 = blockIdx.y * QG_T, j0 = blockIdx.x * QG_T;
+    const int kbeg = ks * a.kper;
+    const int kend = min(a.K, kbeg + a.kper);
+    const int zp = z >> 1, zq = z & 1;
+
+    // staging assignment: 8 elements of each operand tile per thread, as two 16-byte loads along
+    // the contiguous direction of the tensor wherever there is one.  `a.small` is the z-major
+    // copy [z][n][m] written by k_qg_split_small.
+    //   A tile As[row][k]: thread (ar, ak..ak+7);  B tile Bs[col][k]: down (br, bk..bk+7),
+    //   up / wgrad: k row bk, columns br..br+7
+    int ar, ak, br, bk;
+    if (MODE == QG_WGRAD) { ar = tid & 63; ak = (tid >> 6) * 8; }
+    else                  { ar = tid >> 2; ak = (tid & 3) * 8; }
+    if (MODE == QG_DOWN)  { br = tid >> 2; bk = (tid & 3) * 8; }
+    else                  { bk = tid >> 3; br = (tid & 7) * 8; }
+    const bool a_ok = (i0 + ar) < a.M;
+    const size_t plane = (size_t)a.N * a.Cs;            // one quadrant of the z-major small copy
+
+    float ra[8], rb[8];
+    auto fetch = [&](int k0) {
+        floatx4a v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (MODE == QG_DOWN) {
+            // A = big[n][c][4x4 block of quadrant z]: k = 16 c + 4 y' + x'
+            const int k = k0 + ak;
+            if (a_ok) {
+                const float* src = a.big + ((size_t)(i0 + ar) * a.Cb + (k >> 4)) * 64 +
+                                   (4 * zp + ((k & 15) >> 2)) * 8 + 4 * zq;
+                v0 = *reinterpret_cast<const floatx4a*>(src);
+                v1 = *reinterpret_cast<const floatx4a*>(src + 8);
+            }
+        } else if (MODE == QG_UP) {
+            if (a_ok) {
+                const float* src = a.small + (size_t)z * plane + (size_t)(i0 + ar) * a.Cs + k0 + ak;
+                v0 = *reinterpret_cast<const floatx4a*>(src);
+                v1 = *reinterpret_cast<const floatx4a*>(src + 4);
+            }
+        }
+        if (MODE == QG_WGRAD) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + ak + e;
+                ra[e] = (k < kend) ? a.small[(size_t)z * plane + (size_t)k * a.Cs + i0 + ar] : 0.f;
+            }
+        } else {
+            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v0.z; ra[3] = v0.w;
+            ra[4] = v1.x; ra[5] = v1.y; ra[6] = v1.z; ra[7] = v1.w;
+        }
+
+        floatx4a w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+        if (MODE == QG_DOWN) {
+            // B = W[m][c][16 taps of quadrant z]: two runs of four taps, five floats apart
+            const int k = k0 + bk;
+            const float* src = a.w + ((size_t)(j0 + br) * a.Cb + (k >> 4)) * 25 +
+                               ((zp ? 0 : 1) + ((k & 15) >> 2)) * 5 + (zq ? 0 : 1);
+            w0 = *reinterpret_cast<const floatx4u*>(src);
+            w1 = *reinterpret_cast<const floatx4u*>(src + 5);
+        } else if (MODE == QG_UP) {
+            const int k = k0 + bk, j = j0 + br;
+            const float* src = a.w + ((size_t)k * a.Cb + (j >> 4)) * 25 +
+                               ((zp ? 0 : 1) + ((j & 15) >> 2)) * 5 + (zq ? 0 : 1);
+            w0 = *reinterpret_cast<const floatx4u*>(src);
+            w1 = *reinterpret_cast<const floatx4u*>(src + 5);
+        } else {
+            const int k = k0 + bk, j = j0 + br;
+            if (k < kend) {
+                const float* src = a.big + ((size_t)k * a.Cb + (j >> 4)) * 64 +
+                                   (4 * zp + ((j & 15) >> 2)) * 8 + 4 * zq;
+                w0 = *reinterpret_cast<const floatx4a*>(src);
+                w1 = *reinterpret_cast<const floatx4a*>(src + 8);
+            }
+        }
+        rb[0] = w0.x; rb[1] = w0.y; rb[2] = w0.z; rb[3] = w0.w;
+        rb[4] = w1.x; rb[5] = w1.y; rb[6] = w1.z; rb[7] = w1.w;
+    };
+
+    floatx16 acc;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+    const float* ap = As + ((wv >> 1) * 32 + li) * QG_LD + lk;
+    const float* bp = Bs + ((wv & 1) * 32 + li) * QG_LD + lk;
+
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += QG_KS) {
+        __syncthreads();                       // everyone is done reading the previous stage
+#pragma unroll
+        for (int e = 0; e < 8; ++e) As[ar * QG_LD + ak + e] = ra[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (MODE == QG_DOWN) Bs[br * QG_LD + bk + e] = rb[e];
+            else                 Bs[(br + e) * QG_LD + bk] = rb[e];
+        }
+        __syncthreads();
+        if (k0 + QG_KS < kend) fetch(k0 + QG_KS);
+#pragma unroll
+        for (int t = 0; t < QG_KS / 2; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t], bp[2 * t], acc, 0, 0, 0);
+    }
+
+    // raw tile -> scratch [ks][z][M][Nc]; lane holds C[(t&3) + 8*(t>>2) + 4*lk][li]
+    float* dst = a.part + ((size_t)(ks * 4 + z) * a.M) * a.Nc;
+    const int j = j0 + (wv & 1) * 32 + li;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int i = i0 + (wv >> 1) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lk;
+        if (i < a.M) dst[(size_t)i * a.Nc + j] = acc[t];
+    }
+}
+
+// small[n][m][z] -> z-major copy [z][n][m] (the A operand of the up / wgrad roles is then
+// contiguous along its GEMM row or reduction index)
+__global__ __launch_bounds__(256) void k_qg_split_small(const float* __restrict__ small,
+                                                        float* __restrict__ dst, size_t nm) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nm) return;
+    const floatx4a v = *reinterpret_cast<const floatx4a*>(small + 4 * idx);
+    dst[idx] = v.x; dst[nm + idx] = v.y; dst[2 * nm + idx] = v.z; dst[3 * nm + idx] = v.w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// second pass
+// ---------------------------------------------------------------------------------------------
+// out_s[n][m][z] = epi( sum_split P[split][z][n][m] + bias[m] )
+__global__ __launch_bounds__(256) void k_qg_finish_down(
+    const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+    const float* __restrict__ dact_src, int N, int Cs, int splits, int act, int dact,
+    float slope) {
+    const size_t total = (size_t)N * Cs * 4;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int z = (int)(idx & 3);
+    const size_t nm = idx >> 2;                       // n * Cs + m
+    const size_t plane = (size_t)N * Cs;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += part[(size_t)(s * 4 + z) * plane + nm];
+    if (bias) v += bias[nm % Cs];
+    v = bn_apply_act(v, act, slope);
+    if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
+    out[idx] = v;
+}
+
+// out_b[n][c][y][x] = epi( P[z(y,x)][n][c*16 + j(y,x)] + bias[c] )
+__global__ __launch_bounds__(256) void k_qg_finish_up(
+    const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+    const float* __restrict__ dact_src, int N, int Cb, int act, int dact, float slope) {
+    const size_t total = (size_t)N * Cb * 64;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int pix = (int)(idx & 63);
+    const size_t nc = idx >> 6;
+    const int c = (int)(nc % Cb);
+    const size_t n = nc / Cb;
+    const int y = pix >> 3, x = pix & 7;
+    const int z = 2 * (y >> 2) + (x >> 2), j = 4 * (y & 3) + (x & 3);
+    float v = part[((size_t)z * N + n) * ((size_t)Cb * 16) + c * 16 + j];
+    if (bias) v += bias[c];
+    v = bn_apply_act(v, act, slope);
+    if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
+    out[idx] = v;
+}
+
+// dW[m][c][r][s] (+)= sum over the quadrants whose window has tap (r, s), fixed order
+__global__ __launch_bounds__(256) void k_qg_finish_wgrad(
+    const float* __restrict__ part, float* __restrict__ dw, int Cs, int Cb, int accumulate) {
+    const size_t total = (size_t)Cs * Cb * 25;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int tap = (int)(idx % 25);
+    const size_t mc = idx / 25;                       // m * Cb + c
+    const int r = tap / 5, s = tap - 5 * r;
+    const size_t plane = (size_t)Cs * Cb * 16;
+    float v = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int yy = r - (p ? 0 : 1);
+        if (yy < 0 || yy > 3) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int xx = s - (q ? 0 : 1);
+            if (xx < 0 || xx > 3) continue;
+            v += part[(size_t)(2 * p + q) * plane + mc * 16 + 4 * yy + xx];
+        }
+    }
+    dw[idx] = accumulate ? dw[idx] + v : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+bool bn_qgemm_supported(const BnGeom& g) {
+    static int disabled = -1;                          // BN_QGEMM=0: previous s5 kernels
+    if (disabled < 0) { const char* e = getenv("BN_QGEMM"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (disabled) return false;
+    if (g.R != 5 || g.S != 5 || g.stride != 5) return false;
+    if (g.Hs != 2 || g.Ws != 2 || g.Hb != 8 || g.Wb != 8 || g.pt != 1 || g.pl != 1) return false;
+    if ((g.Cs % QG_T) != 0 || (g.Cb % 4) != 0) return false;
+    if ((size_t)g.N * g.Cb * 64 * 4 >= 0x7fffffffull) return false;
+    return true;
+}
+
+// reduction splits of the down role: a function of the channel counts only, NOT of the number of
+// frames -- a frame's result then does not depend on the batch it is in (tile rows are independent),
+// which keeps whole-batch and chunked passes bit-identical through these layers
+static int qg_down_splits(const BnGeom& g) {
+    return (g.Cb * 16 >= 2048 && (g.Cs / QG_T) * 4 < 64) ? 2 : 1;
+}
+
+size_t bn_qgemm_ws_bytes(int role, const BnGeom& g) {
+    if (role == QG_DOWN) return (size_t)qg_down_splits(g) * 4 * g.N * g.Cs * sizeof(float);
+    const size_t split_small = (size_t)4 * g.N * g.Cs * sizeof(float);
+    if (role == QG_UP) return (size_t)4 * g.N * g.Cb * 16 * sizeof(float) + split_small;
+    return (size_t)4 * g.Cs * g.Cb * 16 * sizeof(float) + split_small;
+}
+
+int bn_launch_qgemm_down(const float* big, const float* w, const float* bias, float* out,
+                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                         void* ws, hipStream_t st) {
+    const int splits = qg_down_splits(g);
+    QGArgs a = {nullptr, big, w, (float*)ws, g.N, g.Cs, g.Cb, g.N, g.Cs, g.Cb * 16, 0};
+    a.kper = ((a.K / splits + QG_KS - 1) / QG_KS) * QG_KS;
+    const dim3 grid(a.Nc / QG_T, (a.M + QG_T - 1) / QG_T, 4 * splits);
+    hipLaunchKernelGGL(k_qgemm<QG_DOWN>, grid, dim3(256), 0, st, a);
+    BN_LAUNCH_CHECK();
+    const size_t total = (size_t)g.N * g.Cs * 4;
+    hipLaunchKernelGGL(k_qg_finish_down, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, bias, out, dact_src, g.N, g.Cs, splits, act, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_launch_qgemm_up(const float* small, const float* w, const float* bias, float* out,
+                       const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                       void* ws, hipStream_t st) {
+    float* zsmall = (float*)ws + (size_t)4 * g.N * g.Cb * 16;
+    const size_t nm = (size_t)g.N * g.Cs;
+    hipLaunchKernelGGL(k_qg_split_small, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, small,
+                       zsmall, nm);
+    BN_LAUNCH_CHECK();
+    QGArgs a = {zsmall, nullptr, w, (float*)ws, g.N, g.Cs, g.Cb, g.N, g.Cb * 16, g.Cs, 0};
+    a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
+    const dim3 grid(a.Nc / QG_T, (a.M + QG_T - 1) / QG_T, 4);
+    hipLaunchKernelGGL(k_qgemm<QG_UP>, grid, dim3(256), 0, st, a);
+    BN_LAUNCH_CHECK();
+    const size_t total = (size_t)g.N * g.Cb * 64;
+    hipLaunchKernelGGL(k_qg_finish_up, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, bias, out, dact_src, g.N, g.Cb, act, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_launch_qgemm_wgrad(const float* small, const float* big, float* dw, const BnGeom& g,
+                          int accumulate, void* ws, hipStream_t st) {
+    float* zsmall = (float*)ws + (size_t)4 * g.Cs * g.Cb * 16;
+    const size_t nm = (size_t)g.N * g.Cs;
+    hipLaunchKernelGGL(k_qg_split_small, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, small,
+                       zsmall, nm);
+    BN_LAUNCH_CHECK();
+    QGArgs a = {zsmall, big, nullptr, (float*)ws, g.N, g.Cs, g.Cb, g.Cs, g.Cb * 16, g.N, 0};
+    a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
+    const dim3 grid(a.Nc / QG_T, (a.M + QG_T - 1) / QG_T, 4);
+    hipLaunchKernelGGL(k_qgemm<QG_WGRAD>, grid, dim3(256), 0, st, a);
+    BN_LAUNCH_CHECK();
+    const size_t total = (size_t)g.Cs * g.Cb * 25;
+    hipLaunchKernelGGL(k_qg_finish_wgrad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       (const float*)ws, dw, g.Cs, g.Cb, accumulate);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
