@@ -303,7 +303,19 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     const int want = g.stride == 2 ? 96 : 1;   // stride 5 (K = 6400): the 64x128 tile + split-K
     int best = -1, best_wg = 0;
     DownTile t;
-    for (int i = 0; i < 3; ++i) {
+    // whole-batch launches (256 frames) of the layers with 16-pixel or wider small maps: the
+    // 64 ch x 256 px tile halves the per-workgroup prologue / epilogue share and still gives
+    // >= 2 workgroups per CU (E1 322 -> 290 us, E2 286 -> 260 us at 256 frames; the 8x8 maps of
+    // E3 / D1 are faster with 128-pixel tiles)
+    if (g.stride == 2 && g.Ws >= 16 && g.Cs >= 64 && !getenv("BN_DOWN_TILE")) {
+        int nwg = 0;
+        if (down_tile(g, 2, 2, CC, &t, &nwg) && nwg >= 512) {
+            best = 1;
+            best_wg = nwg;
+        }
+    }
+    const bool preset = best >= 0;
+    for (int i = 0; i < 3 && !preset; ++i) {
         if (cand[i][0] == 2 && g.Cs < 64) continue;
         int nwg = 0;
         if (!down_tile(g, cand[i][0], cand[i][1], CC, &t, &nwg)) continue;
@@ -313,6 +325,7 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
         }
         if (best_wg >= want) break;
     }
+    if (best >= 0) down_tile(g, cand[best][0], cand[best][1], CC, &t, &best_wg);
     // tuning hook (tools/kbench.py): BN_DOWN_TILE=<candidate index 0..2> pins the tile shape
     if (const char* e = getenv("BN_DOWN_TILE")) {
         const int i = e[0] - '0';

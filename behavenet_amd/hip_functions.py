@@ -48,6 +48,7 @@ class accumulate_into_param_grads(object):
 # without this the last ~0.6 ms of a step run one weight-gradient kernel at a time.
 _tail_on_main = 0
 _TAIL_LAYERS = int(os.environ.get('BN_WGRAD_TAIL', '2'))
+_SINGLE_PASS_SIDE = os.environ.get('BN_SINGLE_PASS_SIDE', '0') == '1'
 
 # Data-parallel runs: fitting/distributed.BucketedGradReducer asks to be told when the kernels
 # that complete a parameter's gradient have been issued, so that it can start that bucket's
@@ -98,22 +99,31 @@ def backward_chunks(chunk_losses, streams=None, single_pass=False):
     stream idle and the tail of chunk c's weight gradients overlaps the head of chunk c+1's data
     gradients.
     """
-    global _tail_on_main, _single_pass
+    global _tail_on_main, _single_pass, _use_side_stream
     _single_pass = bool(single_pass and len(chunk_losses) == 1)
     _tail_on_main = _TAIL_LAYERS if _single_pass else 0
-    with accumulate_into_param_grads():
-        for i, loss in enumerate(chunk_losses):
-            # called from the chunk's own stream: autograd orders the graph's streams after the
-            # CALLING stream, so a backward() issued from the main stream would make the auxiliary
-            # pipeline wait for everything the previous chunk queued there
-            stream = streams[i] if streams is not None and i < len(streams) else None
-            if stream is not None:
-                with torch.cuda.stream(stream):
+    # single-pass schedule: every kernel sees the whole batch and fills the chip on its own; a
+    # second stream of weight-gradient kernels then only competes for LDS and wave slots (5.45 ->
+    # 5.43 ms for the AE, 6.39 -> 6.19 ms for the PS-VAE).  BN_SINGLE_PASS_SIDE=1 keeps it.
+    saved_side = _use_side_stream
+    if _single_pass and not _SINGLE_PASS_SIDE:
+        _use_side_stream = False
+    try:
+        with accumulate_into_param_grads():
+            for i, loss in enumerate(chunk_losses):
+                # called from the chunk's own stream: autograd orders the graph's streams after
+                # the CALLING stream, so a backward() issued from the main stream would make the
+                # auxiliary pipeline wait for everything the previous chunk queued there
+                stream = streams[i] if streams is not None and i < len(streams) else None
+                if stream is not None:
+                    with torch.cuda.stream(stream):
+                        loss.backward()
+                else:
                     loss.backward()
-            else:
-                loss.backward()
-    _tail_on_main = 0
-    _single_pass = False
+    finally:
+        _tail_on_main = 0
+        _single_pass = False
+        _use_side_stream = saved_side
 
 
 class Readback(object):
@@ -144,7 +154,7 @@ class Readback(object):
         return out
 
 
-_use_side_stream = True
+_use_side_stream = os.environ.get('BN_SIDE_STREAM', '1') != '0'
 _side_streams = {}
 
 # Chunk pipelines: the 200-frame chunks of one batch are independent until their gradients meet
