@@ -19,8 +19,8 @@ for _ in range(5):
 torch.cuda.synchronize()
 orig_bwd = hf.backward_chunks
 acc = {'bwd': 0.0, 'n': 0}
-def timed_bwd(d):
-    t = time.perf_counter(); orig_bwd(d); acc['bwd'] += time.perf_counter() - t; acc['n'] += 1
+def timed_bwd(d, *a, **k):
+    t = time.perf_counter(); orig_bwd(d, *a, **k); acc['bwd'] += time.perf_counter() - t; acc['n'] += 1
 import behavenet_amd.models.aes as aes
 aes.backward_chunks = timed_bwd
 x = gen.next_batch('train')[0]
