@@ -49,6 +49,10 @@ SIGNATURES = {
     'bn_batchnorm_act_fwd': (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_float, _c_void_p]),
     'bn_batchnorm_act_bwd': (
         _c_int, [_c_void_p] * 9 + [_c_int] * 6 + [_c_float, _c_void_p, _c_size_t, _c_void_p]),
+    'bn_maxpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
+    'bn_maxpool2d_bwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
+    'bn_maxunpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
+    'bn_maxunpool2d_bwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
     'bn_act_fwd': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_int, _c_float, _c_void_p]),
     'bn_act_bwd': (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_int, _c_float, _c_void_p]),
     'bn_linear_ws_bytes': (_c_size_t, [_c_int] * 3),
@@ -438,3 +442,46 @@ def prof_read():
     _check(load().bn_prof_read(ctypes.byref(ms), ctypes.byref(n)), 'bn_prof_read')
     name = load().bn_prof_kernel_name()
     return ms.value, n.value, (name.decode() if name else '')
+
+
+# ------------------------------------------------------------------------------------------
+# max pooling with indices / unpooling ('max_pooling' architectures)
+# ------------------------------------------------------------------------------------------
+def maxpool2d_fwd(x, k, stride, pad, out_hw):
+    """x (N,C,H,W) -> (y (N,C,Ho,Wo), idx int32 (N,C,Ho,Wo)); pad = (top, left)."""
+    N, C, H, W = x.shape
+    Ho, Wo = out_hw
+    y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, C, Ho, Wo), dtype=torch.int32, device=x.device)
+    _check(load().bn_maxpool2d_fwd(_ptr(x, 'x'), _ptr(y, 'y'), _ptr(idx, 'idx', torch.int32),
+                                   N * C, H, W, Ho, Wo, k, stride, pad[0], pad[1], _stream()),
+           'bn_maxpool2d_fwd')
+    return y, idx
+
+
+def maxpool2d_bwd(dy, idx, in_hw, k, stride, pad):
+    N, C, Ho, Wo = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    _check(load().bn_maxpool2d_bwd(_ptr(dy, 'dy'), _ptr(idx, 'idx', torch.int32), _ptr(dx, 'dx'),
+                                   N * C, H, W, Ho, Wo, k, stride, pad[0], pad[1], _stream()),
+           'bn_maxpool2d_bwd')
+    return dx
+
+
+def maxunpool2d_fwd(x, idx, out_hw):
+    N, C, Hi, Wi = x.shape
+    Ho, Wo = out_hw
+    y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    _check(load().bn_maxunpool2d_fwd(_ptr(x, 'x'), _ptr(idx, 'idx', torch.int32), _ptr(y, 'y'),
+                                     N * C, Hi * Wi, Ho * Wo, _stream()), 'bn_maxunpool2d_fwd')
+    return y
+
+
+def maxunpool2d_bwd(dy, idx):
+    N, C, Ho, Wo = dy.shape
+    dx = torch.empty(idx.shape, dtype=torch.float32, device=dy.device)
+    _check(load().bn_maxunpool2d_bwd(_ptr(dy, 'dy'), _ptr(idx, 'idx', torch.int32), _ptr(dx, 'dx'),
+                                     N * C, idx.shape[2] * idx.shape[3], Ho * Wo, _stream()),
+           'bn_maxunpool2d_bwd')
+    return dx

@@ -720,6 +720,52 @@ def activation(x, act):
     return ActFn.apply(x, act)
 
 
+class MaxPoolFn(torch.autograd.Function):
+    """nn.MaxPool2d(return_indices=True) (ref aes.py:99-110,204-207) -> (y, idx int32)."""
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, out_hw):
+        x = x.contiguous()
+        y, idx = _hip.maxpool2d_fwd(x, k, stride, pad, out_hw)
+        ctx.save_for_backward(idx)
+        ctx.args = (tuple(x.shape[2:]), k, stride, pad)
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, dy, _didx):
+        idx, = ctx.saved_tensors
+        in_hw, k, stride, pad = ctx.args
+        return _hip.maxpool2d_bwd(dy.contiguous(), idx, in_hw, k, stride, pad), None, None, None, \
+            None
+
+
+def max_pool(x, k, stride, pad, out_hw):
+    return MaxPoolFn.apply(x, int(k), int(stride), (int(pad[0]), int(pad[1])),
+                           (int(out_hw[0]), int(out_hw[1])))
+
+
+class MaxUnpoolFn(torch.autograd.Function):
+    """nn.MaxUnpool2d with the encoder's indices and pre-pool size (ref aes.py:281-294,460-464)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, out_hw):
+        ctx.save_for_backward(idx)
+        return _hip.maxunpool2d_fwd(x.contiguous(), idx, out_hw)
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        return _hip.maxunpool2d_bwd(dy.contiguous(), idx), None, None
+
+
+def max_unpool(x, idx, out_hw):
+    if tuple(idx.shape) != tuple(x.shape):
+        raise ValueError('unpool indices %s do not match the input %s' % (
+            tuple(idx.shape), tuple(x.shape)))
+    return MaxUnpoolFn.apply(x, idx, (int(out_hw[0]), int(out_hw[1])))
+
+
 class DecomposedKLFn(torch.autograd.Function):
     """(MI, TC, DWKL) of losses.py:284-351 as one (3,) tensor; N x N x D never materialised."""
 

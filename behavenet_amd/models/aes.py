@@ -20,7 +20,7 @@ from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
     ChunkScalars, ConvLayerPlan, Readback, activation, backward_chunks, conv_stack, conv_stack_bn,
     first_layer_forward, join_side_streams, linear, begin_chunks, chunk_stream,
-    reserve_device_pools)
+    max_pool, max_unpool, reserve_device_pools)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
@@ -69,6 +69,7 @@ class ConvAEEncoder(BaseModule):
         self.encoder = nn.ModuleList()
         self._layer_names = []   # conv module name per fused layer
         self._plan = []
+        self._pool_after = []    # per conv layer: None or (kernel, stride, (pad_t, pad_l), (Ho, Wo))
         n_layers = len(hp['ae_encoding_n_channels'])
         gnum = 0
         for i in range(n_layers):
@@ -87,9 +88,15 @@ class ConvAEEncoder(BaseModule):
                     hp['ae_encoding_n_channels'][i],
                     momentum=hp.get('ae_batch_norm_momentum', 0.1),
                     track_running_stats=hp.get('track_running_stats', True)))
+            pool = None
             if i < n_layers - 1 and hp['ae_encoding_layer_type'][i + 1] == 'maxpool':
-                self.encoder.add_module('maxpool%i' % gnum, _mark_footprint(nn.MaxPool2d(
-                    **self._get_maxpool2d_args(i))))
+                pargs = self._get_maxpool2d_args(i)
+                self.encoder.add_module('maxpool%i' % gnum, _mark_footprint(nn.MaxPool2d(**pargs)))
+                if not pargs['ceil_mode']:
+                    raise NotImplementedError('max pooling with ae_padding_type="valid"')
+                pool = (pargs['kernel_size'], pargs['stride'], pargs['padding'],
+                        (hp['ae_encoding_y_dim'][i + 1], hp['ae_encoding_x_dim'][i + 1]))
+            self._pool_after.append(pool)
             self.encoder.add_module('relu%i' % gnum, nn.LeakyReLU(0.05))
 
             if i == 0:
@@ -157,11 +164,13 @@ class ConvAEEncoder(BaseModule):
         return params
 
     def _features(self, x, dataset=None):
-        """Run the conv stack -> (N, C*H*W) post-LeakyReLU features."""
+        """Run the conv stack -> (N, C*H*W) post-LeakyReLU features.  For max-pooling
+        architectures the pooling indices and pre-pool sizes are left in ``self._pool_state``
+        (see :meth:`_pool_out`)."""
         hp = self.hparams
-        if hp.get('ae_network_type', 'strides_only') == 'max_pooling' or \
-                any(t == 'maxpool' for t in hp['ae_encoding_layer_type']):
-            _unsupported_on_hip('max-pooling architectures')
+        self._pool_state = ([], [])
+        if any(p is not None for p in self._pool_after):
+            return self._features_pooled(x, dataset)
         if hp['ae_batch_norm']:
             h = conv_stack_bn(self._plan, x, self._stack_params(dataset),
                               _bn_modules(self.encoder, self._layer_names))
@@ -169,6 +178,35 @@ class ConvAEEncoder(BaseModule):
             h = conv_stack(self._plan, x, self._stack_params(dataset),
                            h1=self._first_layer_slice(x, dataset))
         return h.view(h.size(0), -1)
+
+    def _features_pooled(self, x, dataset):
+        """conv [-> batch norm] -> max pool (indices kept) -> LeakyReLU, layer by layer
+        (ref aes.py:99-114,200-211: the activation follows the pooling)."""
+        params = self._stack_params(dataset)
+        bns = _bn_modules(self.encoder, self._layer_names)
+        pool_idx, sizes = [], []
+        h = x
+        for j, layer in enumerate(self._plan):
+            pool = self._pool_after[j]
+            one = [layer.with_act(_hip.ACT_NONE) if pool is not None else layer]
+            if bns[j] is not None:
+                h = conv_stack_bn(one, h, params[2 * j:2 * j + 2], [bns[j]])
+            else:
+                h = conv_stack(one, h, params[2 * j:2 * j + 2])
+            if pool is not None:
+                k, stride, pad, out_hw = pool
+                sizes.append(h.size())
+                h, idx = max_pool(h, k, stride, pad, out_hw)
+                pool_idx.append(idx)
+                h = activation(h, _hip.ACT_LRELU)
+        self._pool_state = (pool_idx, sizes)
+        return h.reshape(h.size(0), -1)
+
+    def _pool_out(self):
+        """(pool_idx, output_sizes) of the last forward: what the decoder's unpooling needs."""
+        state = getattr(self, '_pool_state', ([], []))
+        self._pool_state = ([], [])
+        return state
 
     # -- whole-batch first layer ----------------------------------------------------------
     # enc.conv0 is HBM-bound (512 KB written per frame) and frames are independent, so the
@@ -206,10 +244,11 @@ class ConvAEEncoder(BaseModule):
     def forward(self, x, dataset=None):
         """-> (latents, pool_idx, output_sizes) or (mu, logvar, pool_idx, output_sizes)."""
         x1 = self._features(x, dataset)
+        pool_idx, sizes = self._pool_out()
         if self.hparams.get('variational', False):
             return (linear(x1, self.FF.weight, self.FF.bias),
-                    linear(x1, self.logvar.weight, self.logvar.bias), [], [])
-        return linear(x1, self.FF.weight, self.FF.bias), [], []
+                    linear(x1, self.logvar.weight, self.logvar.bias), pool_idx, sizes)
+        return linear(x1, self.FF.weight, self.FF.bias), pool_idx, sizes
 
 
 class ConvAEDecoder(BaseModule):
@@ -236,11 +275,13 @@ class ConvAEDecoder(BaseModule):
         self.conv_t_pads = {}
         self._layer_names = []
         self._plan = []
+        self._unpool_before = []     # per convT layer: a MaxUnpool2d precedes it
         n_layers = len(hp['ae_decoding_n_channels'])
         gnum = 0
         for i in range(n_layers):
             if hp['ae_decoding_layer_type'][i] != 'convtranspose':
                 continue
+            self._unpool_before.append(i > 0 and hp['ae_decoding_layer_type'][i - 1] == 'unpool')
             if i > 0 and hp['ae_decoding_layer_type'][i - 1] == 'unpool':
                 k = int(hp['ae_decoding_kernel_size'][i - 1])
                 s = int(hp['ae_decoding_stride_size'][i - 1])
@@ -350,16 +391,29 @@ class ConvAEDecoder(BaseModule):
 
     def forward(self, x, pool_idx=None, target_output_size=None, dataset=None):
         hp = self.hparams
-        if any(t == 'unpool' for t in hp['ae_decoding_layer_type']):
-            _unsupported_on_hip('max-pooling architectures')
         start = hp['ae_decoding_starting_dim']
         h = linear(x, self.FF.weight, self.FF.bias)
         h = h.view(h.size(0), start[0], start[1], start[2])
-        if hp['ae_batch_norm']:
-            h = conv_stack_bn(self._plan, h, self._stack_params(dataset),
-                              _bn_modules(self.decoder, self._layer_names))
+        params = self._stack_params(dataset)
+        if any(self._unpool_before):
+            # max-pooling architectures: MaxUnpool2d with the encoder's indices (last pooled first)
+            # in front of its transposed convolution, layer by layer (ref aes.py:460-476)
+            pool_idx = list(pool_idx) if pool_idx is not None else []
+            sizes = list(target_output_size) if target_output_size is not None else []
+            bns = _bn_modules(self.decoder, self._layer_names)
+            for j, layer in enumerate(self._plan):
+                if self._unpool_before[j]:
+                    idx = pool_idx.pop(-1)
+                    outsize = sizes.pop(-1)
+                    h = max_unpool(h, idx, (outsize[2], outsize[3]))
+                if bns[j] is not None:
+                    h = conv_stack_bn([layer], h, params[2 * j:2 * j + 2], [bns[j]])
+                else:
+                    h = conv_stack([layer], h, params[2 * j:2 * j + 2])
+        elif hp['ae_batch_norm']:
+            h = conv_stack_bn(self._plan, h, params, _bn_modules(self.decoder, self._layer_names))
         else:
-            h = conv_stack(self._plan, h, self._stack_params(dataset))
+            h = conv_stack(self._plan, h, params)
         if hp['ae_decoding_last_FF_layer']:
             # dense last layer + Sigmoid (ref aes.py:345-359,478-486)
             ff = getattr(self.decoder, self._last_ff_name)

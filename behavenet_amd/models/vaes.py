@@ -331,7 +331,8 @@ class ConvAEPSEncoder(ConvAEEncoder):
         h = linear(x1, self.FF.weight, self.FF.bias)
         y = linear(h, self.A.weight, None)
         w = linear(h, self.B.weight, None)
-        return y, w, linear(x1, self.logvar.weight, self.logvar.bias), [], []
+        pool_idx, sizes = self._pool_out()
+        return y, w, linear(x1, self.logvar.weight, self.logvar.bias), pool_idx, sizes
 
 
 class PSVAE(AE):
@@ -551,7 +552,8 @@ class ConvAEMSPSEncoder(ConvAEEncoder):
         z_s = linear(h, self.A.weight, None)
         z_u = linear(h, self.B.weight, None)
         z_b = linear(h, self.C.weight, self.C.bias)
-        return z_s, z_b, z_u, linear(x1, self.logvar.weight, self.logvar.bias), [], []
+        pool_idx, sizes = self._pool_out()
+        return z_s, z_b, z_u, linear(x1, self.logvar.weight, self.logvar.bias), pool_idx, sizes
 
 
 class MSPSVAE(PSVAE):

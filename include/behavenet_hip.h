@@ -124,6 +124,22 @@ int bn_act_bwd(const float* dy, const float* y, float* dpre, size_t n,
                int act, float slope, bn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * nn.MaxPool2d(return_indices=True, ceil_mode) / nn.MaxUnpool2d of 'max_pooling' architectures
+ * (aes.py:99-110,196-208,281-294,460-464).  planes = N*C; x: planes x (H,W); y: planes x (Ho,Wo);
+ * idx: int32 position h*W+w of each maximum inside its (H,W) plane (torch's convention; ties go
+ * to the first maximum in row-major window order).  The unpool pair works on flat planes:
+ * in_plane = pooled H*W, out_plane = H*W of the tensor that was pooled.
+ * ------------------------------------------------------------------------------------------ */
+int bn_maxpool2d_fwd(const float* x, float* y, int* idx, int planes, int H, int W, int Ho, int Wo,
+                     int k, int stride, int pad_t, int pad_l, bn_stream_t stream);
+int bn_maxpool2d_bwd(const float* dy, const int* idx, float* dx, int planes, int H, int W,
+                     int Ho, int Wo, int k, int stride, int pad_t, int pad_l, bn_stream_t stream);
+int bn_maxunpool2d_fwd(const float* x, const int* idx, float* y, int planes, int in_plane,
+                       int out_plane, bn_stream_t stream);
+int bn_maxunpool2d_bwd(const float* dy, const int* idx, float* dx, int planes, int in_plane,
+                       int out_plane, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * BatchNorm2d + activation for `ae_batch_norm = 1` architectures (replaces nn.BatchNorm2d +
  * LeakyReLU, aes.py:90-97,113-114,332-341).  x,y,dy,dx: (N,C,HW) fp32; per-channel vectors: (C).
  *   stats:    mean[c], var[c] (biased) over (N, HW) -- two-pass, deterministic

@@ -155,7 +155,7 @@ class ConvEncoder(nn.Module):
         n = len(hp['ae_encoding_n_channels'])
         for i in range(n):
             if hp['ae_encoding_layer_type'][i] != 'conv':
-                raise NotImplementedError('oracle covers strides_only architectures')
+                continue                      # 'maxpool' entries are attached to the conv before
             if i == 0:
                 extra = 0
                 if hp['model_class'] == 'cond-ae' and hp.get('conditional_encoder', False):
@@ -185,8 +185,18 @@ class ConvEncoder(nn.Module):
                     hp['ae_encoding_n_channels'][i],
                     momentum=hp.get('ae_batch_norm_momentum', 0.1),
                     track_running_stats=hp.get('track_running_stats', True)))
+            pool = None
+            if i < n - 1 and hp['ae_encoding_layer_type'][i + 1] == 'maxpool':
+                # ref aes.py:99-110,165-179: kernel / stride / padding of the NEXT list entry
+                pool = 'maxpool%i' % g
+                self.encoder.add_module(pool, nn.MaxPool2d(
+                    kernel_size=int(hp['ae_encoding_kernel_size'][i + 1]),
+                    stride=int(hp['ae_encoding_stride_size'][i + 1]),
+                    padding=(hp['ae_encoding_y_padding'][i + 1][0],
+                             hp['ae_encoding_x_padding'][i + 1][0]),
+                    return_indices=True, ceil_mode=hp['ae_padding_type'] != 'valid'))
             self.encoder.add_module('relu%i' % g, nn.LeakyReLU(SLOPE))
-            self.layers.append((name, None if sym else (x0, x1, y0, y1), bn))
+            self.layers.append((name, None if sym else (x0, x1, y0, y1), bn, pool))
             g += 1
         last = hp['ae_encoding_n_channels'][-1] * hp['ae_encoding_y_dim'][-1] * \
             hp['ae_encoding_x_dim'][-1]
@@ -195,7 +205,8 @@ class ConvEncoder(nn.Module):
             self.logvar = nn.Linear(last, hp['n_ae_latents'])
 
     def features(self, x, dataset=None, taps=None):
-        for li, (name, pad, bn) in enumerate(self.layers):
+        self.pool_idx, self.pool_sizes = [], []
+        for li, (name, pad, bn, pool) in enumerate(self.layers):
             conv = getattr(self.encoder, name)
             if isinstance(conv, nn.ModuleList):
                 conv = conv[dataset]
@@ -204,6 +215,10 @@ class ConvEncoder(nn.Module):
             x = F.conv2d(x, conv.weight, conv.bias, stride=conv.stride, padding=conv.padding)
             if bn is not None:
                 x = getattr(self.encoder, bn)(x)
+            if pool is not None:                    # conv -> [bn] -> pool -> relu (ref :200-211)
+                self.pool_sizes.append(x.size())
+                x, idx = getattr(self.encoder, pool)(x)
+                self.pool_idx.append(idx)
             x = _lrelu(x, 'encoding', li)
             if taps is not None:
                 taps.append(x)
@@ -213,8 +228,8 @@ class ConvEncoder(nn.Module):
         x1 = self.features(x, dataset, taps)
         if self.hp.get('variational', False):
             return F.linear(x1, self.FF.weight, self.FF.bias), \
-                F.linear(x1, self.logvar.weight, self.logvar.bias), [], []
-        return F.linear(x1, self.FF.weight, self.FF.bias), [], []
+                F.linear(x1, self.logvar.weight, self.logvar.bias), self.pool_idx, self.pool_sizes
+        return F.linear(x1, self.FF.weight, self.FF.bias), self.pool_idx, self.pool_sizes
 
 
 class ConvPSEncoder(ConvEncoder):
@@ -234,7 +249,7 @@ class ConvPSEncoder(ConvEncoder):
         x1 = self.features(x, dataset, taps)
         h = F.linear(x1, self.FF.weight, self.FF.bias)
         return F.linear(h, self.A.weight), F.linear(h, self.B.weight), \
-            F.linear(x1, self.logvar.weight, self.logvar.bias), [], []
+            F.linear(x1, self.logvar.weight, self.logvar.bias), self.pool_idx, self.pool_sizes
 
 
 class ConvDecoder(nn.Module):
@@ -254,7 +269,16 @@ class ConvDecoder(nn.Module):
         g = 0
         for i in range(n):
             if hp['ae_decoding_layer_type'][i] != 'convtranspose':
-                raise NotImplementedError('oracle covers strides_only architectures')
+                continue                      # 'unpool' entries precede the next convtranspose
+            unpool = None
+            if i > 0 and hp['ae_decoding_layer_type'][i - 1] == 'unpool':     # ref aes.py:281-294
+                unpool = 'maxunpool%i' % g
+                ku, su = int(hp['ae_decoding_kernel_size'][i - 1]), \
+                    int(hp['ae_decoding_stride_size'][i - 1])
+                self.decoder.add_module(unpool, nn.MaxUnpool2d(
+                    kernel_size=(ku, ku), stride=(su, su),
+                    padding=(hp['ae_decoding_y_padding'][i - 1][0],
+                             hp['ae_decoding_x_padding'][i - 1][0])))
             cin = start[0] if i == 0 else hp['ae_decoding_n_channels'][i - 1]
             k, s = hp['ae_decoding_kernel_size'][i], hp['ae_decoding_stride_size'][i]
             x0, x1 = hp['ae_decoding_x_padding'][i]
@@ -297,7 +321,7 @@ class ConvDecoder(nn.Module):
                         momentum=hp.get('ae_batch_norm_momentum', 0.1),
                         track_running_stats=hp.get('track_running_stats', True)))
                 self.decoder.add_module('relu%i' % g, nn.LeakyReLU(SLOPE))
-            self.layers.append((name, crop, bn, is_last))
+            self.layers.append((name, crop, bn, is_last, unpool))
             g += 1
         if last_ff:
             # "have last layer be feedforward if this is 1" (ref aes.py:345-359)
@@ -313,7 +337,11 @@ class ConvDecoder(nn.Module):
     def forward(self, z, pool_idx=None, target_output_size=None, dataset=None, taps=None):
         start = self.hp['ae_decoding_starting_dim']
         x = F.linear(z, self.FF.weight, self.FF.bias).view(-1, start[0], start[1], start[2])
-        for li, (name, crop, bn, is_last) in enumerate(self.layers):
+        pool_idx = list(pool_idx) if pool_idx is not None else []
+        sizes = list(target_output_size) if target_output_size is not None else []
+        for li, (name, crop, bn, is_last, unpool) in enumerate(self.layers):
+            if unpool is not None:                                  # ref aes.py:460-464
+                x = getattr(self.decoder, unpool)(x, pool_idx.pop(-1), sizes.pop(-1))
             ct = getattr(self.decoder, name)
             if isinstance(ct, nn.ModuleList):
                 ct = ct[dataset]
@@ -679,7 +707,8 @@ class ConvMSPSEncoder(ConvEncoder):
         x1 = self.features(x, dataset, taps)
         h = F.linear(x1, self.FF.weight, self.FF.bias)
         return F.linear(h, self.A.weight), F.linear(h, self.C.weight, self.C.bias), \
-            F.linear(h, self.B.weight), F.linear(x1, self.logvar.weight, self.logvar.bias), [], []
+            F.linear(h, self.B.weight), F.linear(x1, self.logvar.weight, self.logvar.bias), \
+            self.pool_idx, self.pool_sizes
 
 
 class MSPSVAE(PSVAE):

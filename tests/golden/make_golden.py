@@ -452,6 +452,7 @@ if __name__ == '__main__':
         model_case('ae_linear', RefAE, [1, 32, 32], 8, 12, 'ae',
                    extra_hp={'model_type': 'linear'})
         model_case('ae_valid_1x30x26', RefAE, [1, 30, 26], 6, 12, 'ae', arch_json='arch_valid.json')
+        model_case('ae_maxpool', RefAE, [1, 32, 32], 8, 12, 'ae', arch_json='arch_maxpool.json')
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'condae':
         from behavenet.models.aes import ConditionalAE as RefCondAE

@@ -421,3 +421,37 @@ def test_errors_are_loud():
         _hip.conv2d_fwd(xd, wd, None, (1, 1, 8, 8, 1, 11, 11, 1, 5, 5, 8, 8), 0, 0.0)
     with pytest.raises(_hip.HipLibraryError):
         _hip.conv2d_fwd(xd.double(), wd, None, (1, 1, 8, 8, 1, 11, 11, 1, 5, 5, 8, 8), 0, 0.0)
+
+
+@pytest.mark.parametrize('shape,k,s,pad', [
+    ((3, 5, 32, 32), 2, 2, (0, 0)),       # the non-overlapping pooling of the reference archs
+    ((2, 4, 17, 13), 2, 2, (0, 0)),       # ceil_mode: clipped last windows
+    ((2, 3, 16, 20), 3, 2, (1, 1)),       # overlapping windows with padding
+    ((1, 2, 9, 9), 3, 3, (0, 0)),
+])
+def test_maxpool_unpool_vs_torch(shape, k, s, pad):
+    """bn_maxpool2d_fwd/bwd and bn_maxunpool2d_fwd/bwd against F.max_pool2d(return_indices=True,
+    ceil_mode=True) / F.max_unpool2d and their autograd (bit-exact: selections and copies)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref, idx_ref = F.max_pool2d(xr, k, s, padding=pad, return_indices=True, ceil_mode=True)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    y, idx = _hip.maxpool2d_fwd(x.to(DEV), k, s, pad, tuple(y_ref.shape[2:]))
+    assert idx.dtype == torch.int32
+    assert torch.equal(y.cpu(), y_ref.detach())
+    assert torch.equal(idx.cpu().long(), idx_ref)
+    dx = _hip.maxpool2d_bwd(dy.to(DEV), idx, tuple(shape[2:]), k, s, pad)
+    close(dx, xr.grad, norm_tol=1e-6, name='maxpool bwd')
+    if k == s and pad == (0, 0):
+        # unpooling (indices unique for non-overlapping windows)
+        v = torch.randn(y_ref.shape, generator=g)
+        vr = v.clone().requires_grad_(True)
+        u_ref = F.max_unpool2d(vr, idx_ref, k, s, output_size=shape[2:])
+        du = torch.randn(u_ref.shape, generator=g)
+        u_ref.backward(du)
+        u = _hip.maxunpool2d_fwd(v.to(DEV), idx, tuple(shape[2:]))
+        assert torch.equal(u.cpu(), u_ref.detach())
+        dv = _hip.maxunpool2d_bwd(du.to(DEV), idx)
+        assert torch.equal(dv.cpu(), vr.grad)
