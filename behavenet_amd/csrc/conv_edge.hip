@@ -197,7 +197,7 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx4e __attribute__((ext_vector_type(4)));
 
 template <int ACT, bool MASK>
-__global__ __launch_bounds__(64) void k_down_c1(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_down_c1(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope,
     int units) {

@@ -96,6 +96,38 @@ extern "C" int bn_debug_probe_fill3(float* out, int n_frames, void* stream) {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// E0-like store streams with different contiguity per store instruction (one wave = one workgroup,
+// persistent over "units" of ROWS output rows x 64 px x 32 channels, as k_down_c1):
+//   mode 0: 4 channels x 256 B (one image row each)       -- what k_down_c1 does
+//   mode 1: 2 channels x 512 B (two adjacent rows each)
+//   mode 2: 1 channel  x 1 KB  (four adjacent rows)
+__global__ __launch_bounds__(64) void k_probe_fill4(float* out, int n_frames, int mode) {
+    const int lane = threadIdx.x;
+    const int rows = mode == 0 ? 1 : (mode == 1 ? 2 : 4);     // rows per store instruction
+    const int upf = 64 / 4;                                   // units of 4 rows per frame
+    const int units = n_frames * upf;
+    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int n = u / upf, p0 = 4 * (u - n * upf);
+        // 4 rows x 32 channels x 256 B = 32 KB per unit = 32 store instructions of 1 KB
+        for (int r0 = 0; r0 < 4; r0 += rows) {
+            const int chans = 4 / rows;                        // channels per instruction
+            for (int c0 = 0; c0 < 32; c0 += chans) {
+                const int per = 64 / chans;                    // lanes per channel
+                const int ch = c0 + lane / per;
+                const size_t off = (((size_t)n * 32 + ch) * 64 + (p0 + r0)) * 64 + 4 * (lane % per);
+                *reinterpret_cast<float4*>(out + off) = v;
+            }
+        }
+    }
+}
+extern "C" int bn_debug_probe_fill4(float* out, int n_frames, int mode, int grid, void* stream) {
+    hipLaunchKernelGGL(k_probe_fill4, dim3(grid), dim3(64), 0, (hipStream_t)stream, out, n_frames,
+                       mode);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // LDS-DMA semantics probe: odd lanes use an out-of-range offset; LDS is pre-filled with 7.0
 __global__ void k_probe_lds_dma(const float* p, float* o, int n) {
     __shared__ float lds[256];
