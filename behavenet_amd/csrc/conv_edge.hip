@@ -191,18 +191,28 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
 #define DC_NLD ((DC_IH * DC_C4 + 63) / 64)   // float4 loads per lane per unit (4)
 #define DC_TS (DC_W + 4)                 // transpose slab row stride (68: b128-conflict-free)
 #define DC_SLAB (32 * DC_TS)
+#ifndef DC_HALF
+#define DC_HALF 1                        // 1: half-row transposition slab, 4 waves per SIMD
+#endif
+#if DC_HALF
+#define DC_MAX_WAVES_PER_CU 16           // 8.4 KB of LDS per wave, <= 128 VGPRs
+#define DC_WPE 4
+#else
 #define DC_MAX_WAVES_PER_CU 12           // 12.5 KB of LDS per wave, <= 168 VGPRs
+#define DC_WPE 3
+#endif
+#define DC_HTS 36                        // half-row slab row stride
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx4e __attribute__((ext_vector_type(4)));
 
 template <int ACT, bool MASK>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_down_c1(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_WPE))) void k_down_c1(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope,
     int units) {
     __shared__ __attribute__((aligned(16))) float bl[DC_IH * DC_RW];
-    __shared__ __attribute__((aligned(16))) float tw[DC_SLAB];
+    __shared__ __attribute__((aligned(16))) float tw[DC_HALF ? 32 * DC_HTS : DC_SLAB];
     const int lane = threadIdx.x;
     const int li = lane & 31, kk = lane >> 5;
     const int upf = g.Hs / DC_ROWS;                  // units per frame
@@ -282,6 +292,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     acc[qh] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[toff[t] + 64 * qh], wv_[t],
                                                                    acc[qh], 0, 0, 0);
             }
+#if DC_HALF
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    floatx4e v = {acc[qh][4 * grp], acc[qh][4 * grp + 1], acc[qh][4 * grp + 2],
+                                  acc[qh][4 * grp + 3]};
+                    if (ACT == BN_ACT_LRELU) {
+                        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
+                        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                    }
+                    *reinterpret_cast<floatx4e*>(tw + li * DC_HTS + 8 * grp + 4 * kk) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // 8 lanes x 16 B = one 128-byte half row; 8 channels per store instruction
+                const size_t row0 = ((size_t)n * g.Cs * g.Hs + (p0 + pr)) * DC_W + 32 * qh +
+                                    4 * (lane & 7);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ch = 8 * i + (lane >> 3);
+                    floatx4e v = *reinterpret_cast<const floatx4e*>(tw + ch * DC_HTS + 4 * (lane & 7));
+                    if (ch < g.Cs) {
+                        const size_t o = row0 + (size_t)ch * PQ;
+                        if (MASK) {
+                            const floatx4e d = *reinterpret_cast<const floatx4e*>(dact_src + o);
+                            v.x *= d.x > 0.f ? 1.f : slope; v.y *= d.y > 0.f ? 1.f : slope;
+                            v.z *= d.z > 0.f ? 1.f : slope; v.w *= d.w > 0.f ? 1.f : slope;
+                        }
+                        *reinterpret_cast<floatx4e*>(out + o) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#else
 #pragma unroll
             for (int qh = 0; qh < 2; ++qh) {
                 // lane holds, for channel li, pixels 32*qh + 8*grp + 4*kk + {0..3}
@@ -314,6 +358,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         }
     }
 }
