@@ -694,8 +694,6 @@ class AEMSP(AE):
     ``model_class = 'cond-ae-msp'``; conv encoder/decoder only.
     """
 
-    _whole_batch = False
-
     def __init__(self, hparams):
         if hparams['model_type'] == 'linear':
             raise NotImplementedError
@@ -743,6 +741,33 @@ class AEMSP(AE):
         n_chunks = int(np.ceil(batch_size / chunk_size))
         alpha = self.hparams['msp.alpha']
         self._reserve_pools(x)
+        if self._whole_batch_ok(x):
+            # single pass (see AE._loss_whole_batch): every map here is frame-wise, the two MSP
+            # terms are means over a chunk's rows like the pixel term
+            bounds = [(beg, min(beg + chunk_size, batch_size))
+                      for beg in range(0, batch_size, chunk_size)]
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                P = self._P()
+                z, pool_idx, outsize = self.encoding(x, dataset=dataset)
+                y_hat = linear(z, P, None)
+                x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+                z_back = linear(y_hat, P.t().contiguous(), None)
+                l_mse = losses.mse_chunks(x, x_hat, m, bounds)
+                l_msp = torch.stack([
+                    losses.mse(y[b:e], y_hat[b:e]) + losses.mse(z[b:e], z_back[b:e])
+                    for b, e in bounds])
+                lossv = l_mse + float(alpha) * l_msp
+            table = Readback(torch.stack([lossv.detach(), l_mse.detach(), l_msp.detach()], dim=1))
+            y_hat_rb, y_rb = Readback(y_hat.detach()), Readback(y)
+            if accumulate_grad:
+                backward_chunks([lossv.sum()], single_pass=True)
+            join_side_streams()
+            vals = table.numpy().astype(np.float64)
+            w = np.asarray([e - b for b, e in bounds], dtype=np.float64)[:, None]
+            tot = (vals * w).sum(axis=0) / batch_size
+            r2 = _r2_variance_weighted(y_rb.numpy(), y_hat_rb.numpy())
+            return {'loss': float(tot[0]), 'loss_mse': float(tot[1]), 'loss_msp': float(tot[2]),
+                    'labels_r2': r2}
         self._prepare_first_layer(x, dataset)
         rbs, sizes, deferred, y_hat_all = ChunkScalars(), [], [], []
         for chunk in range(n_chunks):

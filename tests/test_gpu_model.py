@@ -441,6 +441,33 @@ def test_multichunk_variational_vs_oracle(model_class):
     grads_close_on_same_branches(hip, ora64, model_class)
 
 
+@pytest.mark.parametrize('model_class', ['cond-ae-msp', 'cond-ae'])
+def test_multichunk_label_models_vs_oracle(model_class):
+    """Two-chunk batches (200 + 10 frames) of the label-conditioned deterministic models: the
+    single-pass schedule against the oracle's chunk loop (loss dict, gradients on the device's
+    LeakyReLU branch pattern, see tests/branches.py)."""
+    extra = {'msp.alpha': 0.05, 'conditional_encoder': False}
+    meta = {'dim': [1, 32, 32], 'n_lat': 8, 'model_class': model_class, 'extra_hp': extra,
+            'n_labels': 4, 'n_frames': 210}
+    hip, ora, hp = _pair(meta)
+    data_c = case_data(meta)
+    data_g = {k: v.to(DEV) for k, v in data_c.items()}
+    ora64 = seeded_build(ref_cpu.build_model, case_hparams(meta)).double()
+    for m in (hip, ora, ora64):
+        m.train()
+    hip.zero_grad()
+    loss_o = ora.loss(data_c, dataset=0, accumulate_grad=False)
+    with record_branches(hip) as rec:
+        loss_h = hip.loss(data_g, dataset=0, accumulate_grad=True)
+    with BranchReplay(rec) as br:
+        ora64.loss({k: v.double() for k, v in data_c.items()}, dataset=0, accumulate_grad=True)
+    br.assert_only_ties()
+    assert sorted(loss_h.keys()) == sorted(loss_o.keys())
+    for k in loss_o:
+        assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-6), k
+    grads_close_on_same_branches(hip, ora64, model_class)
+
+
 def test_mspsvae_vs_oracle_and_golden():
     """Multi-session PS-VAE (ref vaes.py:849-1098) on a two-session batch (18 + 15 frames):
     forward, the 13-key loss dict incl. the triplet term (same numpy permutations), gradients,
