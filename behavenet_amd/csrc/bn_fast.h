@@ -54,7 +54,8 @@ int bn_launch_wgrad_s5(const float* small, const float* big, float* dw, const Bn
 // conv_edge.hip: HBM-bound single-channel-side layers (enc.conv0 / dec.convT4)
 BnFastPlan bn_edge_wgrad_plan(const BnGeom& g);
 int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float* big, float* dw,
-                         const BnGeom& g, int accumulate, void* ws, hipStream_t st);
+                         const BnGeom& g, int accumulate, void* ws, hipStream_t st,
+                         float* db = nullptr, int bias_side = 0, bool* bias_done = nullptr);
 BnFastPlan bn_edge_down_plan(const BnGeom& g);
 int bn_launch_edge_down(const float* big, const float* w, const float* bias, float* out,
                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,

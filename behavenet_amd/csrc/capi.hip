@@ -248,7 +248,8 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         if (ed.supported) {
             if (!ws_ok(ed, ws, ws_bytes)) return BN_E_WORKSPACE;
             BnProfScope prof(family, g.Cb, g.Cs, ed.kernel_name, st);
-            return bn_launch_edge_wgrad(ed, small, big, dw, g, accumulate, ws, st);
+            return bn_launch_edge_wgrad(ed, small, big, dw, g, accumulate, ws, st, db, bias_side,
+                                        bias_done);
         }
     }
     BnFastPlan plan = bn_fast_wgrad_plan(g);

@@ -41,7 +41,7 @@ __device__ __forceinline__ float ed_ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
 
 __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
-    BnGeom g, int n_stages, int stages_per_frame) {
+    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame) {
     __shared__ float sl[32 * WC_SP];
     __shared__ float bl[WC_IH * WC_RW];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -58,6 +58,9 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     floatx16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    // fused bias gradient of a Conv2d (sum of `small` per channel): every small element is the A
+    // operand of exactly one lane and step, so it is summed on its way through the registers
+    float bsum = 0.f;
 
     float sr[WC_KS];
     float br[WC_KB];
@@ -105,8 +108,11 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
         __syncthreads();
         if (st + (int)gridDim.x < n_stages) issue_loads(st + gridDim.x);
 #pragma unroll 8
-        for (int t = 0; t < WC_W / 2; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[2 * t], bq[4 * t], acc, 0, 0, 0);
+        for (int t = 0; t < WC_W / 2; ++t) {
+            const float av = aq[2 * t];
+            if (bias_part) bsum += av;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[4 * t], acc, 0, 0, 0);
+        }
     }
 
     // combine the four waves (fixed order) and emit this workgroup's partial [a][tap]
@@ -125,6 +131,16 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
                 part[((size_t)bch * gridDim.x + blockIdx.x) * (g.Cs * 25) + a * 25 + li] = v;
         }
     }
+    if (bias_part && bch == 0) {
+        // lanes (li, kk) of the four waves hold partial sums of channel li: fixed-order combine
+        bsum += __shfl_xor(bsum, 32, 64);
+        __syncthreads();
+        if (lane < 32) red[wv * 32 + lane] = bsum;
+        __syncthreads();
+        if (tid < 32 && tid < g.Cs)
+            bias_part[(size_t)blockIdx.x * g.Cs + tid] =
+                (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    }
 }
 
 static int wgrad_c1_grid(const BnGeom& g) {
@@ -142,17 +158,26 @@ BnFastPlan bn_edge_wgrad_plan(const BnGeom& g) {
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
     p.supported = true;
     p.d = wgrad_c1_grid(g);
-    p.ws_bytes = (size_t)g.Cb * p.d * g.Cs * 25 * sizeof(float);
+    p.ws_bytes = ((size_t)g.Cb * p.d * g.Cs * 25 + (size_t)p.d * 32) * sizeof(float);
     p.kernel_name = "k_wgrad_c1";
     return p;
 }
 
 int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float* big, float* dw,
-                         const BnGeom& g, int accumulate, void* ws, hipStream_t st) {
+                         const BnGeom& g, int accumulate, void* ws, hipStream_t st, float* db,
+                         int bias_side, bool* bias_done) {
     const int n_stages = g.N * (g.Hs / WC_ROWS);
+    // Conv2d bias gradient (sum of the small side) as a by-product
+    float* bias_part = (db && bias_side == 1)
+        ? (float*)ws + (size_t)g.Cb * plan.d * g.Cs * 25 : nullptr;
     hipLaunchKernelGGL(k_wgrad_c1, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
-                       (float*)ws, g, n_stages, g.Hs / WC_ROWS);
+                       (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
     BN_LAUNCH_CHECK();
+    if (bias_part) {
+        const int rc = bn_launch_sum_partials(bias_part, db, g.Cs, plan.d, accumulate, 0, 0, st);
+        if (rc) return rc;
+        if (bias_done) *bias_done = true;
+    }
     // per big-side channel b: partial rows [split][a][tap] -> dW[a][b][tap]
     for (int b = 0; b < g.Cb; ++b) {
         const int rc = bn_launch_sum_partials(
