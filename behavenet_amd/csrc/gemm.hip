@@ -170,6 +170,10 @@ int bn_launch_gemm(const GemmArgs& a0, hipStream_t st, void* ws, size_t ws_bytes
     dim3 grid((a.N + 31) / 32, (a.M + 31) / 32, slices);
     if (a.K >= 512) {
         hipLaunchKernelGGL(k_gemm_mfma<8>, grid, dim3(512), 0, st, a);
+    } else if (a.K >= 128) {
+        // e.g. the FF weight gradients (reduction over the 256 frames of a batch): four waves
+        // share the reduction instead of one wave walking it alone (20 -> 7 us)
+        hipLaunchKernelGGL(k_gemm_mfma<4>, grid, dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL(k_gemm_mfma<1>, grid, dim3(64), 0, st, a);
     }
