@@ -75,6 +75,7 @@ SIGNATURES = {
     'bn_prof_select': (_c_int, [_c_int] * 3),
     'bn_prof_read': (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
     'bn_prof_kernel_name': (ctypes.c_char_p, []),
+    'bn_prof_dispatch_overhead_us': (ctypes.c_double, [_c_int, _c_void_p]),
 }
 
 

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <hip/hip_ext.h>
 #include "bn_common.h"
 #include "bn_launch.h"
 #include "bn_fast.h"
@@ -111,6 +112,26 @@ extern "C" int bn_prof_read(double* total_ms, long* launches) {
 }
 
 extern "C" const char* bn_prof_kernel_name(void) { return g_prof.kernel_name; }
+
+// Constant part of a dispatch-attached event interval: the same start/stop events around an EMPTY
+// kernel (minimum over `iters` launches, microseconds).  bench.py reports it next to the raw
+// enc.conv0 interval; rocprofv3's kernel timestamps do not contain it.
+__global__ void k_prof_empty() {}
+extern "C" double bn_prof_dispatch_overhead_us(int iters, bn_stream_t stream) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0;
+    double best = 1e30;
+    for (int i = 0; i < iters; ++i) {
+        hipExtLaunchKernelGGL(k_prof_empty, dim3(1), dim3(64), 0, (hipStream_t)stream, e0, e1, 0);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { best = -1.0; break; }
+        if (ms * 1e3 < best) best = ms * 1e3;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return best;
+}
 
 // ------------------------------------------------------------------------------------------
 // info

@@ -221,7 +221,11 @@ def main():
         'frac': round(achieved / HBM_PEAK_GBS, 4),
         'launches': conv0_n, 'avg_launch_us': round(conv0_ms * 1e3 / max(conv0_n, 1), 2),
         'algorithmic_bytes_per_launch_avg': int(conv0_bytes // max(conv0_n, 1)),
-        'traffic': traffic}
+        'traffic': traffic,
+        # what the same dispatch-attached events read around an EMPTY kernel: avg_launch_us is the
+        # raw interval (not corrected); rocprofv3's kernel timestamps come out ~1.5-2 us lower
+        'event_interval_of_empty_kernel_us': round(float(_hip.load().bn_prof_dispatch_overhead_us(
+            50, torch.cuda.current_stream().cuda_stream)), 2)}
 
     out = {
         'metric': 'AE training frames/sec (128x128x1, batch 256)',

@@ -254,6 +254,8 @@ int bn_prof_select(int family, int C, int K);
 int bn_prof_read(double* total_ms, long* launches);
 /* name of the device kernel that served the most recent launch of the selected family */
 const char* bn_prof_kernel_name(void);
+/* constant part of a dispatch-attached event interval (empty kernel, minimum over iters), us */
+double bn_prof_dispatch_overhead_us(int iters, bn_stream_t stream);
 
 #ifdef __cplusplus
 }
