@@ -356,8 +356,9 @@ def sqerr_bwd(pred, target, mask, scale, gscale, out=None):
     return dpred
 
 
-def reduce_sum(t, scale=1.0):
-    out = torch.empty((), dtype=torch.float32, device=t.device)
+def reduce_sum(t, scale=1.0, out=None):
+    if out is None:
+        out = torch.empty((), dtype=torch.float32, device=t.device)
     _check(load().bn_reduce_sum(_ptr(t, 'in'), _ptr(out, 'out'), t.numel(), float(scale),
                                 _stream()), 'bn_reduce_sum')
     return out

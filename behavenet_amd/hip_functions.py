@@ -90,6 +90,18 @@ def _report_ready(params):
             _grad_ready_cb(p)
 
 
+_ones_cache = {}
+
+
+def _ones_like(t):
+    key = (t.device, tuple(t.shape))
+    o = _ones_cache.get(key)
+    if o is None:
+        o = torch.ones_like(t.detach())
+        _ones_cache[key] = o
+    return o
+
+
 def backward_chunks(chunk_losses, streams=None, single_pass=False):
     """Run the per-chunk backward passes, in chunk order, after ALL chunk forwards.
 
@@ -115,11 +127,14 @@ def backward_chunks(chunk_losses, streams=None, single_pass=False):
                 # the CALLING stream, so a backward() issued from the main stream would make the
                 # auxiliary pipeline wait for everything the previous chunk queued there
                 stream = streams[i] if streams is not None and i < len(streams) else None
+                # a vector of per-chunk losses stands for their sum: seeding its backward with
+                # ones saves the sum kernel and its expand in the graph
+                seed = _ones_like(loss) if loss.dim() > 0 else None
                 if stream is not None:
                     with torch.cuda.stream(stream):
-                        loss.backward()
+                        loss.backward(seed)
                 else:
-                    loss.backward()
+                    loss.backward(seed)
     finally:
         _tail_on_main = 0
         _single_pass = False
@@ -636,8 +651,10 @@ class ChunkedSqErrFn(torch.autograd.Function):
         ctx.save_for_backward(a, b, mask)
         ctx.bounds, ctx.scales = list(bounds), [float(s) for s in scales]
         sums = _hip.sqerr_frame_sums(a, b, mask)
-        return torch.stack([_hip.reduce_sum(sums[beg:end], s)
-                            for (beg, end), s in zip(ctx.bounds, ctx.scales)])
+        out = torch.empty((len(ctx.bounds),), dtype=torch.float32, device=a.device)
+        for i, ((beg, end), s) in enumerate(zip(ctx.bounds, ctx.scales)):
+            _hip.reduce_sum(sums[beg:end], s, out=out[i:i + 1])
+        return out
 
     @staticmethod
     def backward(ctx, g):

@@ -559,7 +559,7 @@ class AE(BaseModel):
             chunk_losses = losses.mse_chunks(x, x_hat, m, bounds)
         vals = Readback(chunk_losses.detach())
         if accumulate_grad:
-            backward_chunks([chunk_losses.sum()], single_pass=True)
+            backward_chunks([chunk_losses], single_pass=True)
         join_side_streams()
         vals = vals.numpy().astype(np.float64)
         sizes = np.asarray([end - beg for beg, end in bounds], dtype=np.float64)
@@ -760,7 +760,7 @@ class AEMSP(AE):
             table = Readback(torch.stack([lossv.detach(), l_mse.detach(), l_msp.detach()], dim=1))
             y_hat_rb, y_rb = Readback(y_hat.detach()), Readback(y)
             if accumulate_grad:
-                backward_chunks([lossv.sum()], single_pass=True)
+                backward_chunks([lossv], single_pass=True)
             join_side_streams()
             vals = table.numpy().astype(np.float64)
             w = np.asarray([e - b for b, e in bounds], dtype=np.float64)[:, None]

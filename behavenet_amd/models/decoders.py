@@ -81,7 +81,7 @@ class ConvDecoder(BaseModel):
                 chunk_losses = losses.mse_chunks(x, x_hat, m, bounds)
             vals = Readback(chunk_losses.detach())
             if accumulate_grad:
-                backward_chunks([chunk_losses.sum()], single_pass=True)
+                backward_chunks([chunk_losses], single_pass=True)
             join_side_streams()
             vals = vals.numpy().astype(np.float64)
         else:

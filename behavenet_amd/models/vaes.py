@@ -147,7 +147,7 @@ class VAE(AE):
                 klv = torch.stack([losses.kl_div_to_std_normal(
                     mu[b:e].contiguous(), logvar[b:e].contiguous()) for b, e in bounds])
                 lossv = -ll + float(beta) * klv
-            vals = _finish_whole(torch.stack([lossv, ll, klv], dim=1), lossv.sum(),
+            vals = _finish_whole(torch.stack([lossv, ll, klv], dim=1), lossv,
                                  accumulate_grad)
             sizes = [e - b for b, e in bounds]
             n_chunks = 0
@@ -254,7 +254,7 @@ class BetaTCVAE(VAE):
                     sample[b:e], mu[b:e], logvar[b:e])) for b, e in bounds])   # (n_chunks, 3)
                 lossv = -ll + float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
             vals = _finish_whole(torch.cat([lossv[:, None], ll[:, None], dk], dim=1),
-                                 lossv.sum(), accumulate_grad)
+                                 lossv, accumulate_grad)
             sizes = [e - b for b, e in bounds]
             n_chunks = 0
         else:
@@ -411,7 +411,7 @@ class PSVAE(AE):
             n_rb = hf.Readback(n) if n is not None else None
             vals = _finish_whole(
                 torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk, lossv[:, None]], dim=1),
-                lossv.sum(), accumulate_grad)
+                lossv, accumulate_grad)
             sizes = [e - b for b, e in bounds]
             n_chunks = 0
         else:
