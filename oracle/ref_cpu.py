@@ -14,6 +14,11 @@ What it restates (reference file:line -> here):
                             behavenet/models/vaes.py:17-35,38-208,211-364,367-503,506-729,1276-1363
   * mse, gaussian_ll, gaussian_ll_to_mse, kl_div_to_std_normal, decomposed_kl
                             behavenet/fitting/losses.py:36-147,284-372
+  * MSPSVAE, ConvAEMSPSEncoder behavenet/models/vaes.py:849-1098,1366-1470 -> MSPSVAE, ConvMSPSEncoder
+  * triplet_loss            behavenet/fitting/losses.py:402-511 -> triplet_loss
+  * ConvDecoder (labels -> images) behavenet/models/decoders.py:355-496 -> ConvDecoderModel
+  * LinearAEEncoder/Decoder behavenet/models/aes.py:491-613   -> LinearEncoder / LinearDecoder
+  * MaxPool2d / MaxUnpool2d architectures behavenet/models/aes.py:99-110,196-208,281-294,460-464
   * DiagLinear              behavenet/models/base.py:70-103
   * the SGD inner loop      behavenet/fitting/training.py:284-286,336-352 -> train_step / Adam
 
