@@ -11,6 +11,7 @@
 // VALU and LDS out of the way of the stream.  Every global access is a full 128/256-byte
 // wavefront row; padding, halos and tails come from raw-buffer out-of-range zeros.
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"
 #include "bn_reduce.h"
@@ -402,6 +403,9 @@ BnFastPlan bn_edge_down_plan(const BnGeom& g) {
 
 // grid = waves; every CU should get the same number of units in the fewest rounds
 static int down_c1_grid(int units) {
+    static int env_grid = -1;                       // tuning hook: BN_E0_GRID=<waves>
+    if (env_grid < 0) { const char* e = getenv("BN_E0_GRID"); env_grid = e ? atoi(e) : 0; }
+    if (env_grid > 0) return env_grid < units ? env_grid : units;
     const int n_cu = 256;
     const int per_cu = (units + n_cu - 1) / n_cu;
     const int rounds = (per_cu + DC_MAX_WAVES_PER_CU - 1) / DC_MAX_WAVES_PER_CU;
