@@ -261,7 +261,11 @@ bool bn_qgemm_supported(const BnGeom& g) {
 // frames -- a frame's result then does not depend on the batch it is in (tile rows are independent),
 // which keeps whole-batch and chunked passes bit-identical through these layers
 static int qg_down_splits(const BnGeom& g) {
-    return (g.Cb * 16 >= 2048 && (g.Cs / QG_T) * 4 < 64) ? 2 : 1;
+    static int env = -1;                             // tuning hook: BN_QG_SPLITS
+    if (env < 0) { const char* e = getenv("BN_QG_SPLITS"); env = e ? atoi(e) : 0; }
+    if (env > 0) return env;
+    if ((g.Cs / QG_T) * 4 >= 64) return 1;
+    return g.Cb * 16 >= 4096 ? 4 : (g.Cb * 16 >= 2048 ? 2 : 1);
 }
 
 size_t bn_qgemm_ws_bytes(int role, const BnGeom& g) {
