@@ -72,6 +72,20 @@ def grads_close_on_same_branches(hip, ora64, name, tol=2e-5):
         assert err <= tol, '%s grad %s: normalised max err %.3e' % (name, k, err)
 
 
+def _assert_grads_on_device_branches(hip, meta, data_c, data_g, dataset, name):
+    ora64 = seeded_build(ref_cpu.build_model, case_hparams(meta)).double()
+    ora64.train()
+    hip.zero_grad()
+    with record_branches(hip) as rec:
+        hip.loss(data_g, dataset=dataset, accumulate_grad=True)
+    with BranchReplay(rec) as br:
+        ora64.loss({k: v.double() for k, v in data_c.items()}, dataset=dataset,
+                   accumulate_grad=True)
+    br.assert_only_ties()
+    assert len(br.flips) > 0, 'gradient mismatch without a branch difference'
+    grads_close_on_same_branches(hip, ora64, name)
+
+
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
          'condvae_cfg1', 'psvae_cfg4', 'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff', 'aemsp_cfg1',
          'condae_cfg1', 'condae_enc_cfg1', 'ae_sessio_masks', 'ae_linear', 'ae_valid_1x30x26', 'ae_maxpool']
@@ -150,10 +164,19 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
             e_ref = np.abs(po.grad.double().numpy() - w64).max() / max(np.abs(w64).max(), 1e-30)
             ctol = max(1e-4, 4 * e_ref)
         else:
-            close(ph.grad, po.grad, name='%s grad %s' % (name, k))
-            ctol = 1e-4
-        assert checksum_close(checksum(ph.grad.cpu().numpy()), z['grad/' + k + '/checksum'],
-                              ctol), k
+            try:
+                close(ph.grad, po.grad, name='%s grad %s' % (name, k))
+                ctol = 1e-4
+                assert checksum_close(checksum(ph.grad.cpu().numpy()),
+                                      z['grad/' + k + '/checksum'], ctol), k
+            except AssertionError:
+                # a LeakyReLU pre-activation at a tie took the other branch (see
+                # tests/branches.py): accept only if the gradients agree with the float64 oracle
+                # on the device's branch pattern and that pattern differs at ties only
+                if variational or meta['extra_hp'].get('ae_batch_norm'):
+                    raise
+                _assert_grads_on_device_branches(hip, meta, data_c, data_g, DS, name)
+                break
     # batch-norm running statistics after the same call sequence (one forward, one loss call)
     for (k, bh), (_, bo) in zip(hip.named_buffers(), ora.named_buffers()):
         if 'running_' in k or 'num_batches' in k:
