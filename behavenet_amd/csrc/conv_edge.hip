@@ -272,14 +272,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
     // B operand: weights of output channel li for taps (2t + kk); lane-constant tap offsets of
     // the A gather (pixel li of the block, tap 2t + kk)
     float wv_[13];
-    int toff[13];
 #pragma unroll
     for (int t = 0; t < 13; ++t) {
         const int tap = 2 * t + kk;
         wv_[t] = (tap < 25 && li < g.Cs) ? w[li * 25 + tap] : 0.f;
-        const int tc = tap < 25 ? tap : 0;
-        toff[t] = (tc / 5) * DC_RW + (tc % 5);
     }
+    // patch offset of tap 2t + kk = offset of tap 2t (a compile-time constant, folded into the
+    // ds_read offset field) + kk * (1, or DC_RW - 4 when tap 2t ends a kernel row): two
+    // lane-dependent base pointers instead of thirteen offset registers
+    const int kkA = kk, kkB = kk * (DC_RW - 4);
     const float bz = (bias && li < g.Cs) ? bias[li] : 0.f;
     const int a_col = DC_X0 - g.pl + 2 * li;
 
@@ -311,11 +312,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[qh][e] = bz;   // a lane owns ONE channel: bias = init
             const float* ar = aq + (2 * pr) * DC_RW;
+            const float* arA = ar + kkA;
+            const float* arB = ar + kkB;
 #pragma unroll
             for (int t = 0; t < 13; ++t) {
+                // tap 24 + kk = 25 (t = 12, kk = 1) has a zero weight but must still read a FINITE
+                // value: it takes the next column of the last patch row, which is always written
+                const int t0 = ((2 * t) / 5) * DC_RW + (2 * t) % 5;
+                const float* at = ((2 * t) % 5 == 4 && t != 12) ? arB : arA;
 #pragma unroll
                 for (int qh = 0; qh < 2; ++qh)
-                    acc[qh] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[toff[t] + 64 * qh], wv_[t],
+                    acc[qh] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[t0 + 64 * qh], wv_[t],
                                                                    acc[qh], 0, 0, 0);
             }
 #if DC_HALF

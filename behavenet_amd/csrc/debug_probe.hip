@@ -128,6 +128,29 @@ extern "C" int bn_debug_probe_fill4(float* out, int n_frames, int mode, int grid
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// test aid: leave NaNs in (most of) every CU's LDS, so that a kernel reading LDS it never wrote
+// (e.g. a padded tap with a zero weight: 0 * NaN) shows up as NaN in the parity tests
+__global__ __launch_bounds__(256) void k_poison_lds(float* sink) {
+    extern __shared__ float l[];
+    const float qnan = __builtin_nanf("");
+    for (int i = threadIdx.x; i < 160 * 256 - 64; i += 256) l[i] = qnan;
+    __syncthreads();
+    if (sink && l[threadIdx.x] == 0.f) sink[0] = 1.f;      // keeps the stores alive
+}
+extern "C" int bn_debug_poison_lds(float* sink, void* stream) {
+    static bool attr_set = false;
+    const size_t bytes = (160 * 256 - 64) * sizeof(float);      // just under the 160 KB of a CU
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_poison_lds,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(256), bytes, (hipStream_t)stream, sink);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // LDS-DMA semantics probe: odd lanes use an out-of-range offset; LDS is pre-filled with 7.0
 __global__ void k_probe_lds_dma(const float* p, float* o, int n) {
     __shared__ float lds[256];
