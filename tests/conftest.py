@@ -33,3 +33,23 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_lds(request):
+    """Every GPU test starts with NaNs in the CUs' LDS: a kernel that reads LDS it did not write
+    (a padded tap with a zero weight, a halo it skipped) then fails instead of passing on whatever
+    finite values the previous kernel left there."""
+    if 'gpu' not in request.keywords or not _has_gpu():
+        yield
+        return
+    import ctypes
+    import torch
+    from behavenet_amd import _hip
+    lib = ctypes.CDLL(_hip.lib_path())
+    lib.bn_debug_poison_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    sink = torch.zeros(1, device='cuda')
+    rc = lib.bn_debug_poison_lds(sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    yield

@@ -23,21 +23,6 @@ DEV = 'cuda'
 SLOPE = 0.05
 
 
-@pytest.fixture(autouse=True)
-def _poisoned_lds():
-    """Every kernel test starts with NaNs in the CUs' LDS: a kernel that reads LDS it did not
-    write (a padded tap with a zero weight, a halo it skipped) then fails instead of passing on
-    whatever finite values the previous kernel left there."""
-    import ctypes
-    lib = ctypes.CDLL(_hip.lib_path())
-    lib.bn_debug_poison_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    sink = torch.zeros(1, device=DEV)
-    rc = lib.bn_debug_poison_lds(sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    assert rc == 0
-    torch.cuda.synchronize()
-    yield
-
-
 def close(got, want, want64=None, rtol=1e-4, norm_tol=1e-4, name='', cond=False):
     got = got.detach().cpu().double().numpy()
     want = want.detach().cpu().double().numpy()

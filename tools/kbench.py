@@ -52,6 +52,20 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+_poison_lib = None
+
+
+def _poison():
+    global _poison_lib
+    import ctypes
+    if _poison_lib is None:
+        _poison_lib = ctypes.CDLL(_hip.lib_path())
+        _poison_lib.bn_debug_poison_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    sink = torch.zeros(1, device='cuda')
+    _poison_lib.bn_debug_poison_lds(sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
 def relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
@@ -105,6 +119,8 @@ def main():
             fn = ops[op]
             err = None
             if not args.no_check:
+                # the checked run starts from NaN-filled LDS (see tests/test_gpu_kernels.py)
+                _poison()
                 got = fn().clone()
                 prev = _hip.set_force_generic(True)
                 want = fn().clone()
