@@ -12,7 +12,7 @@
 //   up    (convT fwd, conv bwd-data)   B[n][c][pix]    = sum_m     S[n][m][z]        W[m][c][tap(z,j)]
 //   wgrad                              dWz[z][m][c][j] = sum_n     S[n][m][z]        B[n][c][pix(z,j)]
 //
-// One tiled MFMA kernel (v_mfma_f32_32x32x2_f32, 64x64 tile per workgroup of four waves, 32-deep
+// One tiled MFMA kernel (v_mfma_f32_32x32x2_f32, 64x128 tile per workgroup of four waves, 32-deep
 // stages through LDS, next stage's global loads in flight during the matrix work) serves the
 // three roles; only the address functions differ.  It writes raw tiles to a packed scratch
 // [split][z][M][N]; a role-specific second kernel adds the splits in fixed order, applies bias /
@@ -24,7 +24,8 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-#define QG_T 64          // tile edge
+#define QG_T 64          // tile rows (and the column granule)
+#define QG_NB 2          // column granules per workgroup tile: 64 x 128, a wave owns 32 x 64
 #define QG_KS 32         // reduction depth of a stage
 #define QG_LD 33         // LDS row stride: odd -> the 32 rows x 2 k of an MFMA operand read hit
                          // 64 distinct banks
@@ -53,12 +54,12 @@ typedef float floatx4u __attribute__((ext_vector_type(4), aligned(4)));   // tap
 template <int MODE>
 __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
     __shared__ float As[QG_T * QG_LD];
-    __shared__ float Bs[QG_T * QG_LD];
+    __shared__ float Bs[QG_NB * QG_T * QG_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lk = lane >> 5;
     const int z = blockIdx.z & 3, ks = blockIdx.z >> 2;
-    const int i0 = blockIdx.y * QG_T, j0 = blockIdx.x * QG_T;
+    const int i0 = blockIdx.y * QG_T, j0 = blockIdx.x * (QG_NB * QG_T);
     const int kbeg = ks * a.kper;
     const int kend = min(a.K, kbeg + a.kper);
     const int zp = z >> 1, zq = z & 1;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
     const bool a_ok = (i0 + ar) < a.M;
     const size_t plane = (size_t)a.N * a.Cs;            // one quadrant of the z-major small copy
 
-    float ra[8], rb[8];
+    float ra[8], rb[QG_NB][8];
     auto fetch = [&](int k0) {
         floatx4a v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
         if (MODE == QG_DOWN) {
@@ -106,36 +107,43 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
             ra[4] = v1.x; ra[5] = v1.y; ra[6] = v1.z; ra[7] = v1.w;
         }
 
-        floatx4a w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
-        if (MODE == QG_DOWN) {
-            // B = W[m][c][16 taps of quadrant z]: two runs of four taps, five floats apart
-            const int k = k0 + bk;
-            const float* src = a.w + ((size_t)(j0 + br) * a.Cb + (k >> 4)) * 25 +
-                               ((zp ? 0 : 1) + ((k & 15) >> 2)) * 5 + (zq ? 0 : 1);
-            w0 = *reinterpret_cast<const floatx4u*>(src);
-            w1 = *reinterpret_cast<const floatx4u*>(src + 5);
-        } else if (MODE == QG_UP) {
-            const int k = k0 + bk, j = j0 + br;
-            const float* src = a.w + ((size_t)k * a.Cb + (j >> 4)) * 25 +
-                               ((zp ? 0 : 1) + ((j & 15) >> 2)) * 5 + (zq ? 0 : 1);
-            w0 = *reinterpret_cast<const floatx4u*>(src);
-            w1 = *reinterpret_cast<const floatx4u*>(src + 5);
-        } else {
-            const int k = k0 + bk, j = j0 + br;
-            if (k < kend) {
-                const float* src = a.big + ((size_t)k * a.Cb + (j >> 4)) * 64 +
-                                   (4 * zp + ((j & 15) >> 2)) * 8 + 4 * zq;
-                w0 = *reinterpret_cast<const floatx4a*>(src);
-                w1 = *reinterpret_cast<const floatx4a*>(src + 8);
+#pragma unroll
+        for (int h = 0; h < QG_NB; ++h) {
+            const int jc = j0 + QG_T * h + br;          // this thread's (first) column of granule h
+            floatx4a w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
+            if (MODE == QG_DOWN) {
+                // B = W[m][c][16 taps of quadrant z]: two runs of four taps, five floats apart
+                const int k = k0 + bk;
+                const float* src = a.w + ((size_t)jc * a.Cb + (k >> 4)) * 25 +
+                                   ((zp ? 0 : 1) + ((k & 15) >> 2)) * 5 + (zq ? 0 : 1);
+                w0 = *reinterpret_cast<const floatx4u*>(src);
+                w1 = *reinterpret_cast<const floatx4u*>(src + 5);
+            } else if (MODE == QG_UP) {
+                const int k = k0 + bk;
+                const float* src = a.w + ((size_t)k * a.Cb + (jc >> 4)) * 25 +
+                                   ((zp ? 0 : 1) + ((jc & 15) >> 2)) * 5 + (zq ? 0 : 1);
+                w0 = *reinterpret_cast<const floatx4u*>(src);
+                w1 = *reinterpret_cast<const floatx4u*>(src + 5);
+            } else {
+                const int k = k0 + bk;
+                if (k < kend) {
+                    const float* src = a.big + ((size_t)k * a.Cb + (jc >> 4)) * 64 +
+                                       (4 * zp + ((jc & 15) >> 2)) * 8 + 4 * zq;
+                    w0 = *reinterpret_cast<const floatx4a*>(src);
+                    w1 = *reinterpret_cast<const floatx4a*>(src + 8);
+                }
             }
+            rb[h][0] = w0.x; rb[h][1] = w0.y; rb[h][2] = w0.z; rb[h][3] = w0.w;
+            rb[h][4] = w1.x; rb[h][5] = w1.y; rb[h][6] = w1.z; rb[h][7] = w1.w;
         }
-        rb[0] = w0.x; rb[1] = w0.y; rb[2] = w0.z; rb[3] = w0.w;
-        rb[4] = w1.x; rb[5] = w1.y; rb[6] = w1.z; rb[7] = w1.w;
     };
 
-    floatx16 acc;
+    floatx16 acc[QG_NB];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+    for (int h = 0; h < QG_NB; ++h)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[h][t] = 0.f;
+    // wave (wv >> 1, wv & 1): rows 32 (wv >> 1).., columns 32 (wv & 1).. of EVERY granule
     const float* ap = As + ((wv >> 1) * 32 + li) * QG_LD + lk;
     const float* bp = Bs + ((wv & 1) * 32 + li) * QG_LD + lk;
 
@@ -145,24 +153,34 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) As[ar * QG_LD + ak + e] = ra[e];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (MODE == QG_DOWN) Bs[br * QG_LD + bk + e] = rb[e];
-            else                 Bs[(br + e) * QG_LD + bk] = rb[e];
-        }
+        for (int h = 0; h < QG_NB; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (MODE == QG_DOWN) Bs[(QG_T * h + br) * QG_LD + bk + e] = rb[h][e];
+                else                 Bs[(QG_T * h + br + e) * QG_LD + bk] = rb[h][e];
+            }
         __syncthreads();
         if (k0 + QG_KS < kend) fetch(k0 + QG_KS);
 #pragma unroll
-        for (int t = 0; t < QG_KS / 2; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t], bp[2 * t], acc, 0, 0, 0);
+        for (int t = 0; t < QG_KS / 2; ++t) {
+            const float av = ap[2 * t];
+#pragma unroll
+            for (int h = 0; h < QG_NB; ++h)
+                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[QG_T * h * QG_LD + 2 * t],
+                                                              acc[h], 0, 0, 0);
+        }
     }
 
     // raw tile -> scratch [ks][z][M][Nc]; lane holds C[(t&3) + 8*(t>>2) + 4*lk][li]
     float* dst = a.part + ((size_t)(ks * 4 + z) * a.M) * a.Nc;
-    const int j = j0 + (wv & 1) * 32 + li;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int i = i0 + (wv >> 1) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lk;
-        if (i < a.M) dst[(size_t)i * a.Nc + j] = acc[t];
+    for (int h = 0; h < QG_NB; ++h) {
+        const int j = j0 + QG_T * h + (wv & 1) * 32 + li;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int i = i0 + (wv >> 1) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lk;
+            if (i < a.M) dst[(size_t)i * a.Nc + j] = acc[h][t];
+        }
     }
 }
 
@@ -252,7 +270,7 @@ bool bn_qgemm_supported(const BnGeom& g) {
     if (disabled) return false;
     if (g.R != 5 || g.S != 5 || g.stride != 5) return false;
     if (g.Hs != 2 || g.Ws != 2 || g.Hb != 8 || g.Wb != 8 || g.pt != 1 || g.pl != 1) return false;
-    if ((g.Cs % QG_T) != 0 || (g.Cb % 4) != 0) return false;
+    if ((g.Cs % (QG_NB * QG_T)) != 0 || (g.Cb % (4 * QG_NB)) != 0) return false;
     if ((size_t)g.N * g.Cb * 64 * 4 >= 0x7fffffffull) return false;
     return true;
 }
@@ -281,7 +299,7 @@ int bn_launch_qgemm_down(const float* big, const float* w, const float* bias, fl
     const int splits = qg_down_splits(g);
     QGArgs a = {nullptr, big, w, (float*)ws, g.N, g.Cs, g.Cb, g.N, g.Cs, g.Cb * 16, 0};
     a.kper = ((a.K / splits + QG_KS - 1) / QG_KS) * QG_KS;
-    const dim3 grid(a.Nc / QG_T, (a.M + QG_T - 1) / QG_T, 4 * splits);
+    const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4 * splits);
     hipLaunchKernelGGL(k_qgemm<QG_DOWN>, grid, dim3(256), 0, st, a);
     BN_LAUNCH_CHECK();
     const size_t total = (size_t)g.N * g.Cs * 4;
@@ -301,7 +319,7 @@ int bn_launch_qgemm_up(const float* small, const float* w, const float* bias, fl
     BN_LAUNCH_CHECK();
     QGArgs a = {zsmall, nullptr, w, (float*)ws, g.N, g.Cs, g.Cb, g.N, g.Cb * 16, g.Cs, 0};
     a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
-    const dim3 grid(a.Nc / QG_T, (a.M + QG_T - 1) / QG_T, 4);
+    const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4);
     hipLaunchKernelGGL(k_qgemm<QG_UP>, grid, dim3(256), 0, st, a);
     BN_LAUNCH_CHECK();
     const size_t total = (size_t)g.N * g.Cb * 64;
@@ -320,7 +338,7 @@ int bn_launch_qgemm_wgrad(const float* small, const float* big, float* dw, const
     BN_LAUNCH_CHECK();
     QGArgs a = {zsmall, big, nullptr, (float*)ws, g.N, g.Cs, g.Cb, g.Cs, g.Cb * 16, g.N, 0};
     a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
-    const dim3 grid(a.Nc / QG_T, (a.M + QG_T - 1) / QG_T, 4);
+    const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4);
     hipLaunchKernelGGL(k_qgemm<QG_WGRAD>, grid, dim3(256), 0, st, a);
     BN_LAUNCH_CHECK();
     const size_t total = (size_t)g.Cs * g.Cb * 25;
