@@ -14,10 +14,11 @@
 //
 // One tiled MFMA kernel (v_mfma_f32_32x32x2_f32, 64x128 tile per workgroup of four waves, 32-deep
 // stages through LDS, next stage's global loads in flight during the matrix work) serves the
-// three roles; only the address functions differ.  It writes raw tiles to a packed scratch
-// [split][z][M][N]; a role-specific second kernel adds the splits in fixed order, applies bias /
-// activation / activation derivative and scatters to the NCHW tensor (for the weight gradient:
-// adds the quadrants that share a tap, in fixed order).
+// three roles; only the address functions differ.  The up role applies its epilogue in the kernel
+// and scatters straight to NCHW; the down role (reduction split over workgroups) and the weight
+// gradient write raw tiles to a packed scratch [split][z][M][N], and a small second kernel adds
+// the splits in fixed order and applies bias / activation / derivative (weight gradient: adds the
+// quadrants that share a tap, in fixed order).
 #include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"
@@ -39,6 +40,12 @@ struct QGArgs {
     int N, Cs, Cb;
     int M, Nc, K;        // GEMM sizes of one quadrant
     int kper;            // reduction elements per split (multiple of QG_KS)
+    // up role: the epilogue is applied in the kernel and the result scattered straight to NCHW
+    float* out;
+    const float* bias;
+    const float* dact_src;
+    int act, dact;
+    float slope;
 };
 
 __device__ __forceinline__ int qg_pix(int z, int j) {
@@ -171,6 +178,27 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
         }
     }
 
+    if (MODE == QG_UP) {
+        // out_b[n][c][pix(z, j & 15)] = epi(acc + bias[c]): 16-byte runs per lane group; the other
+        // half of each 32-byte sector belongs to the neighbouring quadrant's workgroup
+#pragma unroll
+        for (int h = 0; h < QG_NB; ++h) {
+            const int j = j0 + QG_T * h + (wv & 1) * 32 + li;
+            const int c = j >> 4;
+            const float bj = a.bias ? a.bias[c] : 0.f;
+            const size_t col = (size_t)c * 64 + qg_pix(z, j & 15);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int i = i0 + (wv >> 1) * 32 + (t & 3) + 8 * (t >> 2) + 4 * lk;
+                if (i >= a.M) continue;
+                const size_t o = (size_t)i * a.Cb * 64 + col;
+                float v = bn_apply_act(acc[h][t] + bj, a.act, a.slope);
+                if (a.dact_src) v *= bn_act_grad_from_output(a.dact_src[o], a.dact, a.slope);
+                a.out[o] = v;
+            }
+        }
+        return;
+    }
     // raw tile -> scratch [ks][z][M][Nc]; lane holds C[(t&3) + 8*(t>>2) + 4*lk][li]
     float* dst = a.part + ((size_t)(ks * 4 + z) * a.M) * a.Nc;
 #pragma unroll
@@ -211,26 +239,6 @@ __global__ __launch_bounds__(256) void k_qg_finish_down(
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += part[(size_t)(s * 4 + z) * plane + nm];
     if (bias) v += bias[nm % Cs];
-    v = bn_apply_act(v, act, slope);
-    if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
-    out[idx] = v;
-}
-
-// out_b[n][c][y][x] = epi( P[z(y,x)][n][c*16 + j(y,x)] + bias[c] )
-__global__ __launch_bounds__(256) void k_qg_finish_up(
-    const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
-    const float* __restrict__ dact_src, int N, int Cb, int act, int dact, float slope) {
-    const size_t total = (size_t)N * Cb * 64;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int pix = (int)(idx & 63);
-    const size_t nc = idx >> 6;
-    const int c = (int)(nc % Cb);
-    const size_t n = nc / Cb;
-    const int y = pix >> 3, x = pix & 7;
-    const int z = 2 * (y >> 2) + (x >> 2), j = 4 * (y & 3) + (x & 3);
-    float v = part[((size_t)z * N + n) * ((size_t)Cb * 16) + c * 16 + j];
-    if (bias) v += bias[c];
     v = bn_apply_act(v, act, slope);
     if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
     out[idx] = v;
@@ -289,7 +297,7 @@ static int qg_down_splits(const BnGeom& g) {
 size_t bn_qgemm_ws_bytes(int role, const BnGeom& g) {
     if (role == QG_DOWN) return (size_t)qg_down_splits(g) * 4 * g.N * g.Cs * sizeof(float);
     const size_t split_small = (size_t)4 * g.N * g.Cs * sizeof(float);
-    if (role == QG_UP) return (size_t)4 * g.N * g.Cb * 16 * sizeof(float) + split_small;
+    if (role == QG_UP) return split_small;
     return (size_t)4 * g.Cs * g.Cb * 16 * sizeof(float) + split_small;
 }
 
@@ -297,7 +305,8 @@ int bn_launch_qgemm_down(const float* big, const float* w, const float* bias, fl
                          const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                          void* ws, hipStream_t st) {
     const int splits = qg_down_splits(g);
-    QGArgs a = {nullptr, big, w, (float*)ws, g.N, g.Cs, g.Cb, g.N, g.Cs, g.Cb * 16, 0};
+    QGArgs a = {nullptr, big, w, (float*)ws, g.N, g.Cs, g.Cb, g.N, g.Cs, g.Cb * 16, 0,
+                nullptr, nullptr, nullptr, 0, 0, 0.f};
     a.kper = ((a.K / splits + QG_KS - 1) / QG_KS) * QG_KS;
     const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4 * splits);
     hipLaunchKernelGGL(k_qgemm<QG_DOWN>, grid, dim3(256), 0, st, a);
@@ -312,19 +321,16 @@ int bn_launch_qgemm_down(const float* big, const float* w, const float* bias, fl
 int bn_launch_qgemm_up(const float* small, const float* w, const float* bias, float* out,
                        const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                        void* ws, hipStream_t st) {
-    float* zsmall = (float*)ws + (size_t)4 * g.N * g.Cb * 16;
+    float* zsmall = (float*)ws;
     const size_t nm = (size_t)g.N * g.Cs;
     hipLaunchKernelGGL(k_qg_split_small, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, small,
                        zsmall, nm);
     BN_LAUNCH_CHECK();
-    QGArgs a = {zsmall, nullptr, w, (float*)ws, g.N, g.Cs, g.Cb, g.N, g.Cb * 16, g.Cs, 0};
+    QGArgs a = {zsmall, nullptr, w, nullptr, g.N, g.Cs, g.Cb, g.N, g.Cb * 16, g.Cs, 0,
+                out, bias, dact_src, act, dact, slope};
     a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
     const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4);
     hipLaunchKernelGGL(k_qgemm<QG_UP>, grid, dim3(256), 0, st, a);
-    BN_LAUNCH_CHECK();
-    const size_t total = (size_t)g.N * g.Cb * 64;
-    hipLaunchKernelGGL(k_qg_finish_up, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       (const float*)ws, bias, out, dact_src, g.N, g.Cb, act, dact, slope);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -336,7 +342,8 @@ int bn_launch_qgemm_wgrad(const float* small, const float* big, float* dw, const
     hipLaunchKernelGGL(k_qg_split_small, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, small,
                        zsmall, nm);
     BN_LAUNCH_CHECK();
-    QGArgs a = {zsmall, big, nullptr, (float*)ws, g.N, g.Cs, g.Cb, g.Cs, g.Cb * 16, g.N, 0};
+    QGArgs a = {zsmall, big, nullptr, (float*)ws, g.N, g.Cs, g.Cb, g.Cs, g.Cb * 16, g.N, 0,
+                nullptr, nullptr, nullptr, 0, 0, 0.f};
     a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
     const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4);
     hipLaunchKernelGGL(k_qgemm<QG_WGRAD>, grid, dim3(256), 0, st, a);
