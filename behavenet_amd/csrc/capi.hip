@@ -198,13 +198,15 @@ static int run_down(int family, const float* big, const float* w, const float* b
         const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
                                      : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
         if (ed.supported && epi_ok) {
-            BnProfScope prof(family, g.Cb, g.Cs, ed.kernel_name, st, /*on_dispatch=*/true);
+            const char* name = dact_src ? "k_down_c1<0, true>"
+                               : (act == BN_ACT_LRELU ? "k_down_c1<1, false>" : "k_down_c1<0, false>");
+            BnProfScope prof(family, g.Cb, g.Cs, name, st, /*on_dispatch=*/true);
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }
     }
     if (!force_generic() && bn_qgemm_supported(g)) {
         if (!ws || ws_bytes < bn_qgemm_ws_bytes(0, g)) return BN_E_WORKSPACE;
-        BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<down>", st);
+        BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<0>", st);
         return bn_launch_qgemm_down(big, w, bias, out, dact_src, g, act, dact, slope, ws, st);
     }
     BnFastPlan plan = bn_fast_down_plan(g);
@@ -222,7 +224,7 @@ static int run_up(int family, const float* small, const float* w, const float* b
                   void* ws, size_t ws_bytes, hipStream_t st) {
     if (!force_generic() && bn_qgemm_supported(g)) {
         if (!ws || ws_bytes < bn_qgemm_ws_bytes(1, g)) return BN_E_WORKSPACE;
-        BnProfScope prof(family, g.Cs, g.Cb, "k_qgemm<up>", st);
+        BnProfScope prof(family, g.Cs, g.Cb, "k_qgemm<1>", st);
         return bn_launch_qgemm_up(small, w, bias, out, dact_src, g, act, dact, slope, ws, st);
     }
     if (!force_generic()) {
@@ -254,7 +256,7 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
                      float* db, int bias_side, bool* bias_done) {
     if (!force_generic() && bn_qgemm_supported(g)) {
         if (!ws || ws_bytes < bn_qgemm_ws_bytes(2, g)) return BN_E_WORKSPACE;
-        BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<wgrad>", st);
+        BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<2>", st);
         return bn_launch_qgemm_wgrad(small, big, dw, g, accumulate, ws, st);
     }
     if (!force_generic()) {

@@ -358,10 +358,16 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     }
     p.d = splits;
     p.ws_bytes = splits > 1 ? (size_t)splits * g.N * g.Cs * g.Hs * g.Ws * sizeof(float) : 0;
-    p.kernel_name = g.stride == 2 ? "k_down_mfma<s2>" : "k_down_mfma<s5>";
+    // names as rocprofv3 prints the instantiations (leading template arguments)
+    static const char* const names1[2][3] = {
+        {"k_down_mfma<2, 1, 4, 2>", "k_down_mfma<2, 2, 4, 2>", "k_down_mfma<1, 1, 4, 2>"},
+        {"k_down_mfma<2, 1, 2, 5>", "k_down_mfma<2, 2, 2, 5>", "k_down_mfma<1, 1, 2, 5>"}};
+    static const char* const names2[3] = {"k_down2_mfma<2, 1>", "k_down2_mfma<2, 2>",
+                                          "k_down2_mfma<1, 1>"};
+    p.kernel_name = names1[g.stride == 2 ? 0 : 1][best];
     if (g.stride == 2 && splits == 1 && CC == 4 && bn_down2_supported(g, p.a, p.b)) {
         p.variant = 2;
-        p.kernel_name = "k_down2_mfma<s2>";
+        p.kernel_name = names2[best];
     }
     return p;
 }

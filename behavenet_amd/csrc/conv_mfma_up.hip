@@ -254,7 +254,8 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
     if (env_mr == 2 && ok2) p.a = 2;
     if (env_mr == 1 && ok1) p.a = 1;
     p.c = cc;
-    p.kernel_name = "k_up_mfma<s2>";
+    p.kernel_name = p.a == 2 ? (cc == 8 ? "k_up_mfma<2, 8>" : "k_up_mfma<2, 4>")
+                             : (cc == 8 ? "k_up_mfma<1, 8>" : "k_up_mfma<1, 4>");
     return p;
 }
 

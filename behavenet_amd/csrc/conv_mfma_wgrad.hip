@@ -262,7 +262,7 @@ BnFastPlan bn_fast_wgrad_plan(const BnGeom& g) {
     p.supported = true;
     p.d = wgrad_splits(g, t);
     p.ws_bytes = (size_t)p.d * 25 * g.Cs * g.Cb * sizeof(float);
-    p.kernel_name = "k_wgrad_mfma<s2>";
+    p.kernel_name = "k_wgrad_mfma";
     return p;
 }
 

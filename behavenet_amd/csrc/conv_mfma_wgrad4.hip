@@ -271,7 +271,10 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     p.d = wgrad4_splits(g, t);
     // partial dW tiles + partial bias rows (either side) of every split
     p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
-    p.kernel_name = "k_wgrad4_mfma<s2>";
+    static const char* const names[6] = {"k_wgrad4_mfma<?>", "k_wgrad4_mfma<?>", "k_wgrad4_mfma<2>",
+                                         "k_wgrad4_mfma<3>", "k_wgrad4_mfma<4>", "k_wgrad4_mfma<5>"};
+    const int lgq = ilog2_exact_w4(g.Ws);
+    p.kernel_name = names[(lgq >= 2 && lgq <= 5) ? lgq : 0];
     return p;
 }
 

@@ -43,13 +43,6 @@ def _poisoned_lds(request):
     if 'gpu' not in request.keywords or not _has_gpu():
         yield
         return
-    import ctypes
-    import torch
-    from behavenet_amd import _hip
-    lib = ctypes.CDLL(_hip.lib_path())
-    lib.bn_debug_poison_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    sink = torch.zeros(1, device='cuda')
-    rc = lib.bn_debug_poison_lds(sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    assert rc == 0
-    torch.cuda.synchronize()
+    from tests import debug_lib
+    debug_lib.poison_lds('cuda')
     yield

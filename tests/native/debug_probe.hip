@@ -1,5 +1,7 @@
-// Hardware probes used by tools/ (not part of the product path): pure-MFMA issue-rate ceiling.
-#include "bn_common.h"
+// Test-only library (tests/native/libbn_debug.so, include/behavenet_hip_debug.h): hardware probes used
+// by tools/ and the LDS-poisoning aid of the GPU tests.  NOT linked into libbehavenet_hip.so.
+#include "../../behavenet_amd/csrc/bn_common.h"
+#include "../../include/behavenet_hip_debug.h"
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void k_probe_mfma(float* out, int iters, float a0, float b0) {

@@ -10,8 +10,8 @@ from behavenet_amd import _hip
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    with open(os.path.join(REPO, 'include', 'behavenet_hip.h')) as f:
+def _declared_symbols(header='behavenet_hip.h'):
+    with open(os.path.join(REPO, 'include', header)) as f:
         text = f.read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     names = re.findall(r'\b(bn_[a-zA-Z0-9_]+)\s*\(', text)
@@ -42,3 +42,21 @@ def test_info_calls():
     assert lib.bn_conv2d_fwd(None, None, None, None, *([1] * 12), 0, 0.0, None, 0, None) == -1
     assert lib.bn_conv_ws_bytes(99, *([1] * 12)) == 0
     assert lib.bn_prof_select(99, 0, 0) == -1
+
+
+def test_product_library_has_no_debug_symbols():
+    """The probes / LDS poisoning live in the TEST-ONLY tests/native/libbn_debug.so."""
+    lib = ctypes.CDLL(_hip.lib_path())
+    for n in _declared_symbols('behavenet_hip_debug.h'):
+        assert not hasattr(lib, n), 'product library exports the debug symbol %s' % n
+
+
+def test_debug_library_matches_its_header():
+    from tests import debug_lib
+    names = _declared_symbols('behavenet_hip_debug.h')
+    assert os.path.exists(debug_lib.lib_path()), 'run `make -C tests/native`'
+    lib = ctypes.CDLL(debug_lib.lib_path())
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(debug_lib.SIGNATURES.keys()) == names
+    debug_lib.load()

@@ -1,0 +1,289 @@
+"""Oracle parity AT THE SIZES THE BENCHMARK RUNS (BASELINE configs[1]: batch 256 = chunks 200 + 56).
+
+Tile shapes, reduction splits and kernel variants are chosen from the batch size, so the kernels
+`bench.py` times at 256 frames per launch are not the ones the small-batch kernel tests
+(tests/test_gpu_kernels.py, N = 2..5) exercise.  Here every convolution role of E0-E4 / D0-D4
+of the default architecture is called through the C ABI at N = 256, 200 and 56 and compared with
+the CPU oracle's operator (``F.conv2d`` / ``F.conv_transpose2d`` + ``F.pad`` as
+oracle/ref_cpu.py calls them; reference aes.py:81-86,153,315-330,466-470) in fp32 and float64
+with the same ``close()`` gate as the kernel tests:
+
+  * forward and data gradient: the device runs all N frames, the oracle a subset of frames that
+    covers the first / last frames, the 200|56 chunk seam and both halves of every tile group;
+  * weight (+bias) gradient: the FULL reduction over all N frames;
+  * the dispatched kernel is the one the benchmark profile lists
+    (profiles/*_bench_kernel_stats.csv), read back through ``bn_prof_kernel_name``;
+  * every fast kernel against the shape-agnostic kernels on the device
+    (``bn_set_force_generic``), formerly only in tools/kbench.py;
+  * one whole-model batch-256 loss + gradient comparison against the oracle (float64 oracle on
+    the device's LeakyReLU branch pattern, as in ``smoke()``).
+"""
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from behavenet_amd import _hip
+from tests.test_gpu_kernels import close, act_ref, SLOPE
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+# name: (kind, Cin, Hin, Win, Cout, Hout, Wout, stride, off)   -- SURVEY.md section 8(a), cfg2
+LAYERS = {
+    'E0': ('conv', 1, 128, 128, 32, 64, 64, 2, 1),
+    'E1': ('conv', 32, 64, 64, 64, 32, 32, 2, 1),
+    'E2': ('conv', 64, 32, 32, 128, 16, 16, 2, 1),
+    'E3': ('conv', 128, 16, 16, 256, 8, 8, 2, 1),
+    'E4': ('conv', 256, 8, 8, 512, 2, 2, 5, 1),
+    'D0': ('convT', 512, 2, 2, 256, 8, 8, 5, 1),
+    'D1': ('convT', 256, 8, 8, 128, 16, 16, 2, 1),
+    'D2': ('convT', 128, 16, 16, 64, 32, 32, 2, 1),
+    'D3': ('convT', 64, 32, 32, 32, 64, 64, 2, 1),
+    'D4': ('convT', 32, 64, 64, 1, 128, 128, 2, 1),
+}
+SIZES = [256, 200, 56]
+
+# (layer, role) -> kernel at N = 256: the instantiations of profiles/r01_bench_kernel_stats.csv
+# (the single-pass schedule of bench.py launches every layer once over the whole 256-frame batch)
+KERNELS_256 = {
+    ('E0', 'fwd'): 'k_down_c1<1, false>', ('E0', 'bwd_w'): 'k_wgrad_c1',
+    ('E1', 'fwd'): 'k_down2_mfma<2, 2>', ('E2', 'fwd'): 'k_down2_mfma<2, 2>',
+    ('E3', 'fwd'): 'k_down2_mfma<2, 1>',
+    ('E1', 'bwd_d'): 'k_up_mfma<1, 4>', ('E2', 'bwd_d'): 'k_up_mfma<1, 4>',
+    ('E3', 'bwd_d'): 'k_up_mfma<1, 4>',
+    ('E1', 'bwd_w'): 'k_wgrad4_mfma<5>', ('E2', 'bwd_w'): 'k_wgrad4_mfma<4>',
+    ('E3', 'bwd_w'): 'k_wgrad4_mfma<3>',
+    ('E4', 'fwd'): 'k_qgemm<0>', ('E4', 'bwd_d'): 'k_qgemm<1>', ('E4', 'bwd_w'): 'k_qgemm<2>',
+    ('D0', 'fwd'): 'k_qgemm<1>', ('D0', 'bwd_d'): 'k_qgemm<0>', ('D0', 'bwd_w'): 'k_qgemm<2>',
+    ('D1', 'fwd'): 'k_up_mfma<1, 4>', ('D2', 'fwd'): 'k_up_mfma<1, 4>',
+    ('D3', 'fwd'): 'k_up_mfma<1, 4>',
+    ('D1', 'bwd_d'): 'k_down2_mfma<2, 1>', ('D2', 'bwd_d'): 'k_down2_mfma<2, 2>',
+    ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
+    ('D1', 'bwd_w'): 'k_wgrad4_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4_mfma<4>',
+    ('D3', 'bwd_w'): 'k_wgrad4_mfma<5>',
+    ('D4', 'fwd'): 'k_up_c1', ('D4', 'bwd_d'): 'k_down_c1<0, true>', ('D4', 'bwd_w'): 'k_wgrad_c1',
+}
+# the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
+# frames, smaller tiles where the grid would not fill the chip
+FAMILY = {k: v.split('<')[0] for k, v in KERNELS_256.items()}
+
+PROF = {('conv', 'fwd'): _hip.PROF_CONV_FWD, ('conv', 'bwd_d'): _hip.PROF_CONV_BWD_D,
+        ('conv', 'bwd_w'): _hip.PROF_CONV_BWD_W, ('convT', 'fwd'): _hip.PROF_CONVT_FWD,
+        ('convT', 'bwd_d'): _hip.PROF_CONVT_BWD_D, ('convT', 'bwd_w'): _hip.PROF_CONVT_BWD_W}
+
+
+def frame_subset(n):
+    """Frames the oracle evaluates for forward / data-gradient checks."""
+    idx = {0, 1, 2, 3, n // 2 - 1, n // 2, n - 4, n - 3, n - 2, n - 1}
+    idx |= {i for i in (7, 8, 31, 32, 63, 64, 127, 128, 198, 199, 200, 201) if i < n}
+    return sorted(i for i in idx if 0 <= i < n)
+
+
+def make_layer(name, n, seed=0):
+    kind, ci, hi, wi, co, ho, wo, st, off = LAYERS[name]
+    g = torch.Generator().manual_seed(seed + 17 * n)
+    x = torch.rand((n, ci, hi, wi), generator=g) - 0.3
+    if kind == 'conv':
+        w = (torch.rand((co, ci, 5, 5), generator=g) - 0.5) * (2.0 / np.sqrt(ci * 25))
+    else:
+        w = (torch.rand((ci, co, 5, 5), generator=g) - 0.5) * (2.0 / np.sqrt(ci * 25 / st / st))
+    b = torch.rand((co,), generator=g) - 0.5
+    dy = torch.rand((n, co, ho, wo), generator=g) - 0.5
+    geom = (n, ci, hi, wi, co, 5, 5, st, off, off, ho, wo)
+    return kind, x, w, b, dy, geom
+
+
+def oracle_op(name):
+    """The layer as the oracle computes it (pre-activation)."""
+    kind, ci, hi, wi, co, ho, wo, st, off = LAYERS[name]
+    if kind == 'conv':
+        pad_hi = (ho - 1) * st + 5 - hi - off
+        pad_wi = (wo - 1) * st + 5 - wi - off
+
+        def op(x, w, b):
+            return F.conv2d(F.pad(x, (off, pad_wi, off, pad_hi)), w, b, stride=st)
+    else:
+        full_h, full_w = (hi - 1) * st + 5, (wi - 1) * st + 5
+        crop = [off, full_w - wo - off, off, full_h - ho - off]
+
+        def op(x, w, b):
+            y = F.conv_transpose2d(x, w, b, stride=st)
+            return F.pad(y, [-c for c in crop])
+    return op
+
+
+def dispatched(kind, role, ci, co, fn):
+    """Run fn() with the profiling hook on; -> (result, kernel name the dispatcher chose)."""
+    _hip.prof_select(PROF[(kind, role)], 0, 0)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        _, n, name = _hip.prof_read()
+    finally:
+        _hip.prof_select(_hip.PROF_NONE)
+    assert n >= 1, 'no launch recorded'
+    return out, name
+
+
+def check_kernel_name(layer, role, n, name):
+    if n == 256:
+        assert name == KERNELS_256[(layer, role)], (layer, role, n, name)
+    else:
+        assert name.split('<')[0] == FAMILY[(layer, role)], (layer, role, n, name)
+
+
+@pytest.mark.parametrize('n', SIZES)
+@pytest.mark.parametrize('layer', list(LAYERS))
+def test_forward_at_bench_sizes(layer, n):
+    kind, x, w, b, dy, geom = make_layer(layer, n)
+    act = _hip.ACT_SIGMOID if layer == 'D4' else _hip.ACT_LRELU
+    fwd = _hip.conv2d_fwd if kind == 'conv' else _hip.convT2d_fwd
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    got, name = dispatched(kind, 'fwd', geom[1], geom[4],
+                           lambda: fwd(xd, wd, bd, geom, act, SLOPE))
+    check_kernel_name(layer, 'fwd', n, name)
+    sub = frame_subset(n)
+    op = oracle_op(layer)
+    want = act_ref(op(x[sub], w, b), act)
+    want64 = act_ref(op(x[sub].double(), w.double(), b.double()), act)
+    close(got[sub], want, want64, name='%s fwd N=%d' % (layer, n))
+    # and the un-checked frames are not garbage: same statistics as the checked ones
+    assert torch.isfinite(got).all()
+    assert float(got.abs().max()) <= 2.0 * max(float(want.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize('n', SIZES)
+@pytest.mark.parametrize('layer', [l for l in LAYERS if l != 'E0'])
+def test_data_gradient_at_bench_sizes(layer, n):
+    """dL/d(input), with the LeakyReLU' of the layer below fused into the epilogue (the form the
+    training step uses) and without."""
+    kind, x, w, b, dy, geom = make_layer(layer, n, seed=1)
+    bwd = _hip.conv2d_bwd_data if kind == 'conv' else _hip.convT2d_bwd_data
+    op = oracle_op(layer)
+    sub = frame_subset(n)
+
+    def grads(dt):
+        xs = x[sub].to(dt).requires_grad_(True)
+        xin = F.leaky_relu(xs, SLOPE)       # x = post-LeakyReLU activation of the layer below
+        xin.retain_grad()
+        op(xin, w.to(dt), b.to(dt)).backward(dy[sub].to(dt))
+        return xin.detach(), xin.grad, xs.grad
+    xin, dxin, dx = grads(torch.float32)
+    _, dxin64, dx64 = grads(torch.float64)
+    xin_all = F.leaky_relu(x, SLOPE).to(DEV).contiguous()
+    dyd, wd = dy.to(DEV), w.to(DEV)
+    got, name = dispatched(kind, 'bwd_d', geom[1], geom[4],
+                           lambda: bwd(dyd, wd, geom, xin_all, _hip.ACT_LRELU, SLOPE))
+    check_kernel_name(layer, 'bwd_d', n, name)
+    close(got[sub], dx, dx64, name='%s dx*lrelu N=%d' % (layer, n))
+    got = bwd(dyd, wd, geom, None, _hip.ACT_NONE, SLOPE)
+    close(got[sub], dxin, dxin64, name='%s dx N=%d' % (layer, n))
+
+
+@pytest.mark.parametrize('n', SIZES)
+@pytest.mark.parametrize('layer', list(LAYERS))
+def test_weight_gradient_full_reduction_at_bench_sizes(layer, n):
+    kind, x, w, b, dy, geom = make_layer(layer, n, seed=2)
+    wgrad = _hip.conv2d_bwd_weight if kind == 'conv' else _hip.convT2d_bwd_weight
+    op = oracle_op(layer)
+
+    def grads(dt):
+        ww, bb = w.to(dt).requires_grad_(True), b.to(dt).requires_grad_(True)
+        op(x.to(dt), ww, bb).backward(dy.to(dt))
+        return ww.grad, bb.grad
+    dw32, db32 = grads(torch.float32)
+    dw64, db64 = grads(torch.float64)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    dw = torch.full(w.shape, 7.0, device=DEV)
+    db = torch.full(b.shape, 7.0, device=DEV)
+    _, name = dispatched(kind, 'bwd_w', geom[1], geom[4],
+                         lambda: wgrad(xd, dyd, dw, db, geom, False))
+    check_kernel_name(layer, 'bwd_w', n, name)
+    close(dw, dw32, dw64, name='%s dw N=%d' % (layer, n))
+    close(db, db32, db64, name='%s db N=%d' % (layer, n))
+    wgrad(xd, dyd, dw, db, geom, True)          # cross-chunk accumulation
+    close(dw, 2 * dw32, 2 * dw64, name='%s dw acc N=%d' % (layer, n))
+    close(db, 2 * db32, 2 * db64, name='%s db acc N=%d' % (layer, n))
+
+
+@pytest.mark.parametrize('n', [256, 56])
+@pytest.mark.parametrize('layer', list(LAYERS))
+def test_fast_kernels_vs_shape_agnostic_kernels(layer, n):
+    """Every specialised kernel against the generic direct-loop kernels on the device, whole
+    tensors (the cross-check of tools/kbench.py as a test).  Both are fp32 sums in different
+    orders: the bar is rounding level, 2e-5 of the tensor's maximum."""
+    from tests import debug_lib
+    kind, x, w, b, dy, geom = make_layer(layer, n, seed=3)
+    xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+    act = _hip.ACT_SIGMOID if layer == 'D4' else _hip.ACT_LRELU
+    if kind == 'conv':
+        ops = {'fwd': lambda: _hip.conv2d_fwd(xd, wd, bd, geom, act, SLOPE),
+               'bwd_d': lambda: _hip.conv2d_bwd_data(dyd, wd, geom, xd, _hip.ACT_LRELU, SLOPE),
+               'bwd_w': lambda: _wg(_hip.conv2d_bwd_weight, xd, dyd, wd, bd, geom)}
+    else:
+        ops = {'fwd': lambda: _hip.convT2d_fwd(xd, wd, bd, geom, act, SLOPE),
+               'bwd_d': lambda: _hip.convT2d_bwd_data(dyd, wd, geom, xd, _hip.ACT_LRELU, SLOPE),
+               'bwd_w': lambda: _wg(_hip.convT2d_bwd_weight, xd, dyd, wd, bd, geom)}
+    for role, fn in ops.items():
+        if layer == 'E0' and role == 'bwd_d':
+            continue
+        debug_lib.poison_lds(DEV)
+        got = fn()
+        prev = _hip.set_force_generic(True)
+        try:
+            want = fn()
+        finally:
+            _hip.set_force_generic(prev)
+        for a, c in zip(got if isinstance(got, tuple) else (got,),
+                        want if isinstance(want, tuple) else (want,)):
+            close(a, c, norm_tol=2e-5, name='%s %s N=%d fast vs generic' % (layer, role, n))
+
+
+def _wg(fn, xd, dyd, wd, bd, geom):
+    dw, db = torch.empty_like(wd), torch.empty_like(bd)
+    fn(xd, dyd, dw, db, geom, False)
+    return dw, db
+
+
+def test_whole_model_batch256_loss_and_gradients_vs_oracle():
+    """BASELINE configs[1] at full size through ``AE.loss`` (one forward / one backward pass over
+    256 frames, the reference's 200 + 56 chunk normalisation; reference aes.py:722-773): loss
+    against the fp32 oracle's chunk loop, every parameter gradient against the float64 oracle run
+    on the LeakyReLU branch pattern the device took (tests/branches.py)."""
+    from behavenet_amd.models import AE
+    from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+    from oracle import ref_cpu
+    from tests.branches import record_branches, BranchReplay
+    from tests.golden_utils import base_hparams, make_frames
+    from tests.test_gpu_model import grads_close_on_same_branches
+
+    dim = [1, 128, 128]
+    arch = load_handcrafted_arch(list(dim), 12, None, check_memory=False)
+    torch.manual_seed(0)
+    hip = AE(base_hparams(arch, 'ae')).to(DEV)
+    torch.manual_seed(0)
+    ora = ref_cpu.AE(base_hparams(dict(arch), 'ae'))
+    torch.manual_seed(0)
+    ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae')).double()
+    x = torch.from_numpy(make_frames(256, dim, seed=21))
+
+    hip.train()
+    hip.zero_grad(set_to_none=True)
+    with record_branches(hip) as rec:
+        lh = hip.loss({'images': x.to(DEV)[None]}, dataset=0, accumulate_grad=True)['loss']
+    lo = ora.loss({'images': x[None]}, dataset=0, accumulate_grad=False)['loss']
+    assert lh == pytest.approx(lo, rel=1e-5)
+    with BranchReplay(rec) as br:
+        l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True)['loss']
+    br.assert_only_ties()
+    assert lh == pytest.approx(l64, rel=1e-5)
+    grads_close_on_same_branches(hip, ora64, 'AE batch 256')
+    # the single pass used the whole-batch variants
+    _hip.prof_select(_hip.PROF_CONV_FWD, 32, 64)
+    hip.loss({'images': x.to(DEV)[None]}, dataset=0, accumulate_grad=False)
+    torch.cuda.synchronize()
+    _, n, name = _hip.prof_read()
+    _hip.prof_select(_hip.PROF_NONE)
+    assert n == 1 and name == KERNELS_256[('E1', 'fwd')], (n, name)

@@ -52,18 +52,9 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-_poison_lib = None
-
-
 def _poison():
-    global _poison_lib
-    import ctypes
-    if _poison_lib is None:
-        _poison_lib = ctypes.CDLL(_hip.lib_path())
-        _poison_lib.bn_debug_poison_lds.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    sink = torch.zeros(1, device='cuda')
-    _poison_lib.bn_debug_poison_lds(sink.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    from tests import debug_lib
+    debug_lib.poison_lds('cuda')
 
 
 def relerr(a, b):

@@ -1,9 +1,8 @@
 """Write ceiling with and without Infinity-Cache residency: one 105 MB buffer vs a ring of 5."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from behavenet_amd import _hip
-lib = ctypes.CDLL(_hip.lib_path())
-lib.bn_debug_probe_fill2.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+from tests import debug_lib
+lib = debug_lib.load()
 st = torch.cuda.current_stream().cuda_stream
 n = 200 * 32 * 64 * 64
 def t(bufs, mode, blocks, it=40):

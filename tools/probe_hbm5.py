@@ -2,9 +2,8 @@
 64 x 64 floats = 134 MB), ring of 3 buffers: 4 x 256 B vs 2 x 512 B vs 1 x 1 KB per wave store."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from behavenet_amd import _hip
-lib = ctypes.CDLL(_hip.lib_path())
-lib.bn_debug_probe_fill4.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+from tests import debug_lib
+lib = debug_lib.load()
 st = torch.cuda.current_stream().cuda_stream
 nf = 256
 bufs = [torch.empty(nf * 32 * 64 * 64, device='cuda') for _ in range(3)]

@@ -1,8 +1,7 @@
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from behavenet_amd import _hip
-lib = ctypes.CDLL(_hip.lib_path())
-lib.bn_debug_probe_lds_dma.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+from tests import debug_lib
+lib = debug_lib.load()
 src = torch.arange(256, dtype=torch.float32, device='cuda') + 100
 out = torch.zeros(256, device='cuda')
 lib.bn_debug_probe_lds_dma(src.data_ptr(), out.data_ptr(), 256, torch.cuda.current_stream().cuda_stream)

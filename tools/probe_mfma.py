@@ -1,8 +1,7 @@
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from behavenet_amd import _hip
-lib = ctypes.CDLL(_hip.lib_path())
-lib.bn_debug_probe_mfma.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+from tests import debug_lib
+lib = debug_lib.load()
 out = torch.empty(4096 * 256, device='cuda')
 for blocks in (256, 512, 1024, 2048):
     iters = 20000

@@ -1,9 +1,8 @@
 """MFMA + LDS-operand ceilings in the conv kernels' shapes (see debug_probe.hip)."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from behavenet_amd import _hip
-lib = ctypes.CDLL(_hip.lib_path())
-lib.bn_debug_probe_mfma_lds.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+from tests import debug_lib
+lib = debug_lib.load()
 out = torch.empty(4096 * 512, device='cuda')
 st = torch.cuda.current_stream().cuda_stream
 names = {0: '32x32x2 2x2 + LDS operands', 1: '16x16x4 x25 + LDS operands', 2: '32x32x2 2x2 register operands'}
