@@ -1,15 +1,27 @@
-"""Model construction and the fit entry point of the reference's ``ae_grid_search.main``
-(ref behavenet/fitting/ae_grid_search.py:40-118), without the test-tube bookkeeping around it
-(experiment folders, hyperparameter grid, SLURM: SURVEY.md section 2, out of scope).
+"""The reference's ``behavenet/fitting/ae_grid_search.py``: fit one autoencoder per grid point.
 
-``build_model`` is the ``model_class`` string -> class dispatch with the reference's seeding,
-``n_datasets`` / ``n_labels`` discovery, device move and pretrained-weight loading;
-``fit_model`` chains it with ``fit``.
+    python -m behavenet_amd.fitting.ae_grid_search --data_config D.json --model_config M.json \
+        --training_config T.json --compute_config C.json
+
+``main(hparams)`` is the reference's ``main`` (ref :20-118): merge the architecture dict, create
+the experiment version (skipping grid points that were fitted already), build the data generator
+and the model, export the hparams, ``fit``, mark the version complete.  ``build_model`` is the
+``model_class`` string -> class dispatch with the reference's seeding, ``n_datasets`` /
+``n_labels`` discovery, device move and pretrained-weight loading; ``fit_model`` chains it with
+``fit`` for callers that bring their own generator / experiment object.
+
+Grid execution (ref :150-198 hands the grid to test-tube's process pool / SLURM; not used here):
+the grid points are run one after another in this process; under ``torchrun`` (WORLD_SIZE > 1)
+rank r takes the points r, r + W, ... -- one model per GPU, no communication.
+Data-parallel training of ONE model over several GPUs is a different mode
+(``n_parallel_gpus`` > 1 with an initialised process group, see fitting/distributed.py).
 """
+
+import os
 
 import torch
 
-__all__ = ['MODEL_CLASSES', 'NEEDS_LABELS', 'build_model', 'fit_model']
+__all__ = ['MODEL_CLASSES', 'NEEDS_LABELS', 'build_model', 'fit_model', 'main', 'run_grid']
 
 MODEL_CLASSES = {
     'ae': ('behavenet_amd.models.aes', 'AE'),
@@ -80,3 +92,71 @@ def fit_model(hparams, data_generator, exp):
     fit(hparams, model, data_generator, exp, method='ae')
     hparams['training_completed'] = True
     return model
+
+
+def main(hparams, *args):
+    """Fit the model one grid point describes (ref ae_grid_search.py:20-118)."""
+    from behavenet_amd.data.utils import build_data_generator
+    from behavenet_amd.fitting.hyperparam_utils import trial_hparams
+    from behavenet_amd.fitting.training import fit
+    from behavenet_amd.fitting.utils import (
+        _clean_tt_dir, _print_hparams, create_experiment, export_hparams)
+
+    if not isinstance(hparams, dict):
+        hparams = trial_hparams(hparams)
+    elif hparams.get('model_type') == 'conv' and \
+            isinstance(hparams.get('architecture_params'), dict):
+        hparams = {**hparams['architecture_params'], **hparams}
+    _print_hparams(hparams)
+    if hparams['model_type'] == 'conv' and hparams['n_ae_latents'] > hparams['max_latents']:
+        raise ValueError('Number of latents higher than max latents, architecture will not work')
+
+    hparams, sess_ids, exp = create_experiment(hparams)
+    if hparams is None:
+        print('Experiment exists! Aborting fit')
+        return None
+    data_generator = build_data_generator(hparams, sess_ids)
+
+    print('constructing model...', end='')
+    model = build_model(hparams, data_generator, n_datasets=len(sess_ids))
+    model.version = exp.version
+    hparams['training_completed'] = False
+    export_hparams(hparams, exp)
+    print('done')
+    print(model)
+
+    fit(hparams, model, data_generator, exp, method='ae')
+
+    hparams['training_completed'] = True
+    export_hparams(hparams, exp)
+    _clean_tt_dir(hparams)
+    if hparams.get('export_train_plots', False):
+        # plotting is outside the hot path (SURVEY.md section 2); metrics.csv holds the curves
+        print('training curves: %s' % os.path.join(
+            hparams['expt_dir'], 'version_%i' % hparams['version'], 'metrics.csv'))
+    return model
+
+
+def run_grid(hyperparams, max_trials=None):
+    """Run ``main`` over the grid of a parsed namespace; -> list of (hparams dict, model | None).
+    With WORLD_SIZE > 1 in the environment each rank runs its own slice on its own GPU."""
+    from behavenet_amd.fitting.hyperparam_utils import trial_hparams
+    if getattr(hyperparams, 'device', None) == 'gpu':
+        hyperparams.device = 'cuda'
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1 and torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    n = max_trials if max_trials is not None else getattr(hyperparams, 'tt_n_gpu_trials', None)
+    results = []
+    for i, trial in enumerate(hyperparams.trials(n)):
+        if i % world != rank:
+            continue
+        hp = trial_hparams(trial)
+        results.append((hp, main(hp)))
+    return results
+
+
+if __name__ == '__main__':
+    from behavenet_amd.fitting.hyperparam_utils import get_all_params
+    run_grid(get_all_params('grid_search'))

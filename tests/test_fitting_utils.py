@@ -1,0 +1,274 @@
+"""Paths and experiment bookkeeping (behavenet_amd/fitting/utils.py, experiment.py) against the
+known answers of the reference's tests/test_fitting/test_utils_fitting.py (same directory tree,
+same expected session / experiment directories) for the autoencoder classes, plus the version
+bookkeeping (`experiment_exists`, `get_best_model_version`) over files written by the csv
+experiment logger."""
+
+import os
+import pickle
+
+import pytest
+
+from behavenet_amd.fitting import utils
+from behavenet_amd.fitting.experiment import Experiment
+
+IDS = [
+    {'lab': 'lab0', 'expt': 'expt0', 'animal': 'animal0', 'session': 'session-00'},
+    {'lab': 'lab0', 'expt': 'expt0', 'animal': 'animal0', 'session': 'session-01'},
+    {'lab': 'lab0', 'expt': 'expt0', 'animal': 'animal0', 'session': 'session-02'},
+    {'lab': 'lab0', 'expt': 'expt0', 'animal': 'animal1', 'session': 'session-00'},
+    {'lab': 'lab0', 'expt': 'expt1', 'animal': 'animal0', 'session': 'session-00'},
+    {'lab': 'lab0', 'expt': 'expt1', 'animal': 'animal1', 'session': 'session-00'},
+    {'lab': 'lab1', 'expt': 'expt0', 'animal': 'animal0', 'session': 'session-00'},
+    {'lab': 'lab1', 'expt': 'expt0', 'animal': 'animal0', 'session': 'session-01'},
+]
+# multisession directories of the reference's fixture: relative path -> indices into IDS
+MULTI = {
+    'lab0/expt0/animal0/multisession-00': [0, 1, 2],
+    'lab0/expt0/animal0/multisession-01': [1, 2],
+    'lab0/expt0/animal1/multisession-03': [3],
+    'lab0/expt0/animal1/multisession-04': [3],
+    'lab0/expt0/multisession-00': [0, 1, 2, 3],
+    'lab0/expt0/multisession-01': [0, 3],
+    'lab0/multisession-00': [0, 1, 2, 3, 4, 5],
+    'multisession-06': [0, 1, 2, 3, 4, 5, 6],
+}
+
+
+@pytest.fixture
+def tree(tmp_path):
+    root = str(tmp_path)
+    for ids in IDS:
+        os.makedirs(os.path.join(root, ids['lab'], ids['expt'], ids['animal'], ids['session']))
+    for rel, idxs in MULTI.items():
+        utils.export_session_info_to_csv(os.path.join(root, rel), [IDS[i] for i in idxs])
+    return root
+
+
+def _key(d):
+    return ''.join(str(v) for v in d.values())
+
+
+def test_get_subdirs(tree):
+    with pytest.raises(StopIteration):
+        utils.get_subdirs(os.path.join(tree, 'lab0', 'multisession-00'))
+    assert sorted(utils.get_subdirs(os.path.join(tree, 'lab0'))) == \
+        ['expt0', 'expt1', 'multisession-00']
+    with pytest.raises(NotADirectoryError):
+        utils.get_subdirs('/ZzZtestingZzZ')
+
+
+def test_get_multisession_paths(tree):
+    assert utils._get_multisession_paths(os.path.join(tree, 'lab1')) == []
+    assert utils._get_multisession_paths(tree, lab='lab0') == \
+        [os.path.join(tree, 'lab0', 'multisession-00')]
+    e0 = os.path.join(tree, 'lab0', 'expt0')
+    assert sorted(utils._get_multisession_paths(tree, lab='lab0', expt='expt0')) == \
+        [os.path.join(e0, 'multisession-00'), os.path.join(e0, 'multisession-01')]
+    a1 = os.path.join(e0, 'animal1')
+    assert sorted(utils._get_multisession_paths(tree, lab='lab0', expt='expt0', animal='animal1')) \
+        == [os.path.join(a1, 'multisession-03'), os.path.join(a1, 'multisession-04')]
+    assert utils._get_multisession_paths(tree, lab='lab1', expt='expt0', animal='animal0') == []
+    assert utils._get_multisession_paths('fakepath', lab='lab1', expt='expt0') == []
+
+
+def test_get_single_sessions(tree):
+    found = utils._get_single_sessions(tree, depth=4, curr_depth=0)
+    for ids in IDS:
+        assert ids in found
+
+
+def test_get_session_dir_from_csv(tree):
+    hp = {'data_dir': tree, 'save_dir': tree}
+    cases = [   # (csv relative dir, expected session dir)
+        ('lab0/expt0/animal1/multisession-03', 'lab0/expt0/animal1/session-00'),
+        ('lab0/expt0/animal0/multisession-00', 'lab0/expt0/animal0/multisession-00'),
+        ('lab0/expt0/multisession-00', 'lab0/expt0/multisession-00'),
+        ('lab0/multisession-00', 'lab0/multisession-00'),
+    ]
+    for rel, want in cases:
+        hp['sessions_csv'] = os.path.join(tree, rel, 'session_info.csv')
+        sess_dir, single = utils.get_session_dir(hp, session_source='save')
+        assert sess_dir == os.path.join(tree, want)
+        assert single == [IDS[i] for i in MULTI[rel]]
+    hp['sessions_csv'] = os.path.join(tree, 'multisession-06', 'session_info.csv')
+    with pytest.raises(NotImplementedError):          # several labs
+        utils.get_session_dir(hp, session_source='save')
+
+
+def test_get_session_dir_from_all_keys(tree):
+    hp = {'data_dir': tree, 'save_dir': tree, 'sessions_csv': '', 'lab': 'all', 'expt': 'all',
+          'animal': 'all', 'session': 'all'}
+    with pytest.raises(NotImplementedError):
+        utils.get_session_dir(hp)
+    cases = [   # (lab, expt, animal, session) -> (dir, indices)
+        (('lab0', 'all', '', ''), 'lab0/multisession-00', [0, 1, 2, 3, 4, 5]),
+        (('lab0', 'expt0', 'all', ''), 'lab0/expt0/multisession-00', [0, 1, 2, 3]),
+        (('lab0', 'expt0', 'animal0', 'all'), 'lab0/expt0/animal0/multisession-00', [0, 1, 2]),
+        (('lab0', 'expt0', 'animal0', 'session-00'), 'lab0/expt0/animal0/session-00', [0]),
+        # no multisession with this session set yet: the next free index (0)
+        (('lab1', 'expt0', 'animal0', 'all'), 'lab1/expt0/animal0/multisession-00', [6, 7]),
+    ]
+    for (lab, expt, animal, session), want, idxs in cases:
+        hp.update({'lab': lab, 'expt': expt, 'animal': animal, 'session': session})
+        sess_dir, single = utils.get_session_dir(hp, session_source='save')
+        assert sess_dir == os.path.join(tree, want)
+        assert sorted(_key(d) for d in single) == sorted(_key(IDS[i]) for i in idxs)
+    # an explicitly requested existing multisession
+    hp.update({'lab': 'lab0', 'expt': 'expt0', 'animal': 'animal0', 'session': 'all',
+               'multisession': 1})
+    sess_dir, single = utils.get_session_dir(hp)
+    assert sess_dir == os.path.join(tree, 'lab0/expt0/animal0/multisession-01')
+    assert sorted(_key(d) for d in single) == sorted(_key(IDS[i]) for i in (1, 2))
+    with pytest.raises(ValueError):
+        utils.get_session_dir(hp, session_source='test')
+
+
+def test_get_expt_dir(tree):
+    hp = {'data_dir': 'ddir', 'save_dir': 'sdir', 'lab': 'lab0', 'expt': 'expt0',
+          'animal': 'animal0', 'session': 'session-00', 'experiment_name': 'tt_expt'}
+    session_dir = os.path.join('ddir', 'lab0', 'expt0', 'animal0', 'session-00')
+    hp['session_dir'] = session_dir
+    for model_class, n_lat in (('ae', 8), ('vae', 10), ('beta-tcvae', 10), ('cond-vae', 8),
+                               ('cond-ae', 8), ('cond-ae-msp', 8), ('ps-vae', 10),
+                               ('msps-vae', 11)):
+        hp.update({'model_class': model_class, 'model_type': 'conv', 'n_ae_latents': n_lat})
+        want = os.path.join(session_dir, model_class, 'conv', '%02i_latents' % n_lat, 'tt_expt')
+        assert utils.get_expt_dir(hp) == want
+        assert utils.get_expt_dir(hp, model_class=model_class, model_type='conv',
+                                  expt_name='tt_expt') == want
+    # multisession autoencoder
+    hp.update({'model_class': 'ae', 'n_ae_latents': 8, 'save_dir': tree, 'ae_multisession': 0})
+    assert utils.get_expt_dir(hp) == os.path.join(
+        tree, 'lab0', 'expt0', 'animal0', 'multisession-00', 'ae', 'conv', '08_latents', 'tt_expt')
+    hp['ae_multisession'] = None
+    for out_of_scope in ('arhmm', 'neural-ae', 'arhmm-labels', 'bayesian-decoding'):
+        with pytest.raises(NotImplementedError):
+            utils.get_expt_dir(hp, model_class=out_of_scope, model_type='mlp')
+    with pytest.raises(ValueError):
+        utils.get_expt_dir(hp, model_class='testing', model_type='mlp')
+
+
+def test_contains_session_and_find_session_dirs(tree):
+    multi = os.path.join(tree, 'lab0', 'expt0', 'animal0', 'multisession-01')
+    assert utils.contains_session(multi, IDS[1])
+    assert not utils.contains_session(multi, IDS[0])
+    hp = dict(IDS[0], save_dir=tree)
+    dirs, ids = utils.find_session_dirs(hp)
+    want = ['lab0/multisession-00', 'lab0/expt0/multisession-00', 'lab0/expt0/multisession-01',
+            'lab0/expt0/animal0/multisession-00', 'lab0/expt0/animal0/session-00']
+    assert sorted(dirs) == sorted(os.path.join(tree, w) for w in want)
+    assert sum(i['multisession'] is None for i in ids) == 1
+
+
+def _hparams(tree, **kw):
+    hp = {'save_dir': tree, 'data_dir': tree, 'sessions_csv': '', 'all_source': 'save',
+          'experiment_name': 'grid', 'model_class': 'ae', 'model_type': 'conv',
+          'n_ae_latents': 8, 'rng_seed_data': 0, 'trial_splits': '8;1;1;0', 'train_frac': 1.0,
+          'rng_seed_model': 0, 'fit_sess_io_layers': False, 'learning_rate': 1e-4, 'l2_reg': 0.0}
+    hp.update(IDS[0])
+    hp.update(kw)
+    return hp
+
+
+def test_get_model_params():
+    hp = _hparams('x', model_class='ps-vae', **{'ps_vae.alpha': 1000, 'ps_vae.beta': 5})
+    less = utils.get_model_params(hp)
+    assert less['ps_vae.alpha'] == 1000 and less['ps_vae.beta'] == 5 and 'vae.beta' not in less
+    assert set(less) == {'rng_seed_data', 'trial_splits', 'train_frac', 'rng_seed_model',
+                         'model_class', 'model_type', 'n_ae_latents', 'fit_sess_io_layers',
+                         'learning_rate', 'l2_reg', 'ps_vae.alpha', 'ps_vae.beta'}
+    assert 'vae.beta' in utils.get_model_params(_hparams('x', model_class='vae', **{'vae.beta': 2}))
+    assert utils.get_model_params(_hparams('x', model_class='cond-ae'))['conditional_encoder'] \
+        is False
+    with pytest.raises(NotImplementedError):
+        utils.get_model_params(_hparams('x', model_class='arhmm'))
+
+
+def test_experiment_versions_and_bookkeeping(tree):
+    """create_experiment -> version_0; a finished fit makes the same grid point 'exist'; another
+    grid point gets version_1; get_best_model_version reads metrics.csv."""
+    hp = _hparams(tree)
+    with pytest.raises(NotADirectoryError):      # as the reference: the directory must exist
+        utils.experiment_exists(dict(hp))
+    hp0, sess_ids, exp = utils.create_experiment(hp)
+    assert sess_ids == [IDS[0]] and exp.version == 0 and hp0['version'] == 0
+    vdir = os.path.join(tree, 'lab0', 'expt0', 'animal0', 'session-00', 'ae', 'conv',
+                        '08_latents', 'grid', 'version_0')
+    assert os.path.isdir(vdir)
+    hp0['training_completed'] = False
+    utils.export_hparams(hp0, exp)
+    assert utils.experiment_exists(_hparams(tree)) is False          # not finished yet
+    for epoch, val in enumerate([0.5, 0.3, 0.4]):
+        exp.log({'epoch': epoch, 'tr_loss': val + 0.1, 'dataset': -1})
+        exp.log({'epoch': epoch, 'val_loss': val, 'best_val_epoch': 1, 'dataset': -1})
+    exp.save()
+    hp0['training_completed'] = True
+    utils.export_hparams(hp0, exp)
+    with open(os.path.join(vdir, 'meta_tags.pkl'), 'rb') as f:
+        assert pickle.load(f)['training_completed'] is True
+    assert os.path.exists(os.path.join(vdir, 'meta_tags.csv'))
+    assert utils.experiment_exists(_hparams(tree), which_version=True) == (True, 0)
+    assert utils.create_experiment(_hparams(tree)) == (None, None, None)   # fitted already
+
+    hp1, _, exp1 = utils.create_experiment(_hparams(tree, learning_rate=1e-3))
+    assert exp1.version == 1
+    hp1['training_completed'] = True
+    utils.export_hparams(hp1, exp1)
+    exp1.log({'epoch': 0, 'val_loss': 0.2, 'dataset': -1})
+    exp1.save()
+    assert utils.experiment_exists(_hparams(tree, learning_rate=1e-3), which_version=True) == \
+        (True, 1)
+    assert utils.experiment_exists(_hparams(tree, learning_rate=3e-3), which_version=True) == \
+        (False, None)
+    expt_dir = os.path.dirname(vdir)
+    assert utils.get_best_model_version(expt_dir) == [1]
+    assert utils.get_best_model_version(expt_dir, n_best=2) == [1, 0]
+    assert utils.get_best_model_version(expt_dir, best_def='max') == [0]
+
+
+def test_experiment_logger_files(tmp_path):
+    import pandas as pd
+    exp = Experiment(name='e', save_dir=str(tmp_path))
+    assert exp.version == 0
+    exp.log({'epoch': 0, 'tr_loss': 1.0})
+    exp.log({'epoch': 0, 'val_loss': 2.0, 'best_val_epoch': 0})
+    exp.tag({'learning_rate': 1e-4, 'model_class': 'ae'})
+    exp.save()
+    df = pd.read_csv(os.path.join(str(tmp_path), 'e', 'version_0', 'metrics.csv'))
+    assert list(df['epoch']) == [0, 0] and df['val_loss'].min() == 2.0
+    assert pd.isna(df['val_loss'][0]) and df['tr_loss'][0] == 1.0
+    tags = pd.read_csv(os.path.join(str(tmp_path), 'e', 'version_0', 'meta_tags.csv'))
+    assert set(tags['key']) == {'learning_rate', 'model_class'}
+    assert Experiment(name='e', save_dir=str(tmp_path)).version == 1
+    assert Experiment(name='e', save_dir=str(tmp_path), version=7).version == 7
+
+
+def test_data_generator_inputs():
+    from behavenet_amd.data.utils import get_data_generator_inputs
+    from behavenet_amd.data.transforms import MakeOneHot2D
+    hp = {'data_dir': 'd', 'model_class': 'ae'}
+    _, sig, tr, paths = get_data_generator_inputs(hp, IDS[:2])
+    assert sig == [['images'], ['images']] and tr == [[None], [None]]
+    assert paths[1] == [os.path.join('d', 'lab0', 'expt0', 'animal0', 'session-01', 'data.hdf5')]
+    hp = {'data_dir': 'd', 'model_class': 'ps-vae', 'use_output_mask': True,
+          'use_label_mask': True}
+    _, sig, _, _ = get_data_generator_inputs(hp, IDS[:1])
+    assert sig == [['images', 'labels', 'masks', 'labels_masks']]
+    hp = {'data_dir': 'd', 'model_class': 'cond-ae', 'conditional_encoder': True,
+          'y_pixels': 4, 'x_pixels': 6, 'use_label_mask': True}
+    _, sig, tr, _ = get_data_generator_inputs(hp, IDS[:1])
+    assert sig == [['images', 'labels', 'labels_sc']] and isinstance(tr[0][2], MakeOneHot2D)
+    with pytest.raises(NotImplementedError):
+        get_data_generator_inputs({'data_dir': 'd', 'model_class': 'neural-ae'}, IDS[:1])
+
+
+def test_make_one_hot_2d():
+    """The docstring example of the reference transform (transforms.py:192-195)."""
+    import numpy as np
+    from behavenet_amd.data.transforms import MakeOneHot2D
+    out = MakeOneHot2D(128, 128)(np.array([[64., 34., 56., 102.]]))
+    assert out.shape == (1, 2, 128, 128) and out.sum() == 2
+    assert out[0, 0, 56, 64] == 1 and out[0, 1, 102, 34] == 1
+    out = MakeOneHot2D(8, 8)(np.array([[np.nan, 100., -3., 2.4]]))     # nan / clip / round
+    assert out[0, 0, 0, 0] == 1 and out[0, 1, 2, 7] == 1

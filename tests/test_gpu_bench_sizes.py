@@ -190,7 +190,8 @@ def test_weight_gradient_full_reduction_at_bench_sizes(layer, n):
     op = oracle_op(layer)
 
     def grads(dt):
-        ww, bb = w.to(dt).requires_grad_(True), b.to(dt).requires_grad_(True)
+        ww = w.detach().clone().to(dt).requires_grad_(True)
+        bb = b.detach().clone().to(dt).requires_grad_(True)
         op(x.to(dt), ww, bb).backward(dy.to(dt))
         return ww.grad, bb.grad
     dw32, db32 = grads(torch.float32)
