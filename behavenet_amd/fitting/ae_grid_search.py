@@ -153,7 +153,9 @@ def run_grid(hyperparams, max_trials=None):
         if i % world != rank:
             continue
         hp = trial_hparams(trial)
-        results.append((hp, main(hp)))
+        model = main(hp)
+        # main() works on its own merged copy of the dict: report the one the model carries
+        results.append((model.hparams if model is not None else hp, model))
     return results
 
 
