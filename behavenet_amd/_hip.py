@@ -62,6 +62,11 @@ SIGNATURES = {
         [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
     'bn_sqerr_frame_sums': (_c_int, [_c_void_p] * 4 + [_c_int, _c_size_t, _c_void_p]),
     'bn_sqerr_bwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_float, _c_void_p, _c_void_p]),
+    'bn_convT2d_fwd_sqerr_parts': (_c_int, _CONV_GEOM),
+    'bn_convT2d_fwd_sqerr_ws_bytes': (_c_size_t, _CONV_GEOM + [_c_int]),
+    'bn_convT2d_fwd_sqerr': (
+        _c_int, [_c_void_p] * 8 + _CONV_GEOM + [_c_int, _c_float, _c_void_p, _c_size_t, _c_void_p]),
+    'bn_scale_frames': (_c_int, [_c_void_p] * 4 + [_c_int, _c_size_t, _c_void_p]),
     'bn_reduce_sum': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_float, _c_void_p]),
     'bn_reparam_fwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
     'bn_kl_rows': (_c_int, [_c_void_p] * 3 + [_c_int, _c_int, _c_void_p]),
@@ -354,6 +359,47 @@ def sqerr_bwd(pred, target, mask, scale, gscale, out=None):
         _ptr(dpred, 'dpred'), pred.numel(), float(scale), _ptr(gscale, 'gscale', allow_none=True),
         _stream()), 'bn_sqerr_bwd')
     return dpred
+
+
+def convT2d_fwd_sqerr(x, w, b, target, mask, geom, act, slope, want_xhat):
+    """Last decoder layer + squared error in one pass -> (xhat | None, dpre, part (N, P)):
+    ``part[n].sum()`` is frame n's masked squared error, ``dpre`` its gradient with respect to the
+    layer's pre-activation (see include/behavenet_hip.h)."""
+    N, Ci, Hi, Wi, Co, R, S, st, ct, cl, Ho, Wo = geom
+    lib = load()
+    P = lib.bn_convT2d_fwd_sqerr_parts(*geom)
+    if P <= 0:
+        raise HipLibraryError('bn_convT2d_fwd_sqerr_parts: bad geometry %s' % (geom,))
+    xhat = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device) if want_xhat \
+        else None
+    dpre = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
+    part = torch.empty((N, P), dtype=torch.float32, device=x.device)
+    nbytes = lib.bn_convT2d_fwd_sqerr_ws_bytes(*geom, int(want_xhat))
+    ws = None
+    if nbytes:
+        key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, 'fwd_sqerr')
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)
+            _ws_cache[key] = buf
+        ws = buf.data_ptr()
+    _check(lib.bn_convT2d_fwd_sqerr(
+        _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(target, 'target'),
+        _ptr(mask, 'mask', allow_none=True), _ptr(xhat, 'xhat', allow_none=True),
+        _ptr(dpre, 'dpre'), _ptr(part, 'part'), *geom, act, slope, ws, nbytes, _stream()),
+        'bn_convT2d_fwd_sqerr')
+    return xhat, dpre, part
+
+
+def scale_frames(t, frame_scale, group_scale=None, group_of_frame=None):
+    """In place: t[n] *= frame_scale[n] * group_scale[group_of_frame[n]]."""
+    N = t.shape[0]
+    _check(load().bn_scale_frames(
+        _ptr(t, 't'), _ptr(frame_scale, 'frame_scale'),
+        _ptr(group_scale, 'group_scale', allow_none=True),
+        _ptr(group_of_frame, 'group_of_frame', dtype=torch.int32, allow_none=True),
+        N, t.numel() // N, _stream()), 'bn_scale_frames')
+    return t
 
 
 def reduce_sum(t, scale=1.0, out=None):

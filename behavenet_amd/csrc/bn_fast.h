@@ -62,7 +62,10 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
                         hipStream_t st);
 BnFastPlan bn_edge_up_plan(const BnGeom& g);
 int bn_launch_edge_up(const float* small, const float* w, const float* bias, float* out,
-                      const BnGeom& g, int act, float slope, hipStream_t st);
+                      const BnGeom& g, int act, float slope, hipStream_t st,
+                      const float* target = nullptr, const float* mask = nullptr,
+                      float* dpre = nullptr, float* partial = nullptr);
+int bn_edge_up_parts_per_frame(const BnGeom& g);
 
 // conv_qgemm.hip: stride == kernel (5x5 s5) between an 8x8 and a 2x2 map: four dense 16-tap
 // quadrant GEMMs per role (skips the taps that only ever meet padding)

@@ -42,6 +42,8 @@ int bn_launch_sqerr_frame_sums(const float* pred, const float* target, const flo
                                float* frame_sums, int N, size_t D, hipStream_t st);
 int bn_launch_sqerr_bwd(const float* pred, const float* target, const float* mask, float* dpred,
                         size_t n, float scale, const float* gscale, hipStream_t st);
+int bn_launch_scale_frames(float* t, const float* frame_scale, const float* group_scale,
+                           const int* group_of_frame, int N, size_t D, hipStream_t st);
 int bn_launch_reduce_sum(const float* in, float* out, size_t n, float scale, hipStream_t st);
 int bn_launch_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z,
                           size_t n, hipStream_t st);

@@ -530,6 +530,71 @@ extern "C" int bn_sqerr_bwd(const float* pred, const float* target, const float*
     return bn_launch_sqerr_bwd(pred, target, mask, dpred, n, scale, gscale, (hipStream_t)stream);
 }
 
+// Last decoder layer + pixel loss.  Fast path: the VALU edge kernel with the loss epilogue; any
+// other geometry: the same result composed from the stand-alone kernels (xhat goes through `ws`
+// if the caller does not want it).
+static bool fused_sqerr_fast(const BnGeom& g) {
+    return !force_generic() && !bn_qgemm_supported(g) && !bn_s5_up_plan(g).supported &&
+           bn_edge_up_plan(g).supported;
+}
+
+extern "C" int bn_convT2d_fwd_sqerr_parts(int N, int Ci, int Hi, int Wi, int Co, int R, int S,
+                                          int stride, int crop_t, int crop_l, int Ho, int Wo) {
+    const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
+    if (!bn_geom_ok(g)) return 0;
+    return fused_sqerr_fast(g) ? bn_edge_up_parts_per_frame(g) : 1;
+}
+
+extern "C" size_t bn_convT2d_fwd_sqerr_ws_bytes(int N, int Ci, int Hi, int Wi, int Co, int R,
+                                                int S, int stride, int crop_t, int crop_l, int Ho,
+                                                int Wo, int with_xhat) {
+    const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
+    if (!bn_geom_ok(g) || fused_sqerr_fast(g)) return 0;
+    size_t conv = bn_conv_ws_bytes(BN_OP_CONVT_FWD, N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l,
+                                   Ho, Wo);
+    conv = (conv + 255) & ~(size_t)255;
+    return conv + (with_xhat ? 0 : (size_t)N * Co * Ho * Wo * sizeof(float));
+}
+
+extern "C" int bn_convT2d_fwd_sqerr(const float* x, const float* w, const float* b,
+                                    const float* target, const float* mask, float* xhat,
+                                    float* dpre, float* part, int N, int Ci, int Hi, int Wi,
+                                    int Co, int R, int S, int stride, int crop_t, int crop_l,
+                                    int Ho, int Wo, int act, float slope, void* ws,
+                                    size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !w || !target || !dpre || !part) return BN_E_BADARG;
+    const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (fused_sqerr_fast(g)) {
+        BnProfScope prof(BN_PROF_CONVT_FWD, g.Cs, g.Cb, "k_up_c1v<8, true>", st);
+        return bn_launch_edge_up(x, w, b, xhat, g, act, slope, st, target, mask, dpre, part);
+    }
+    const size_t need = bn_convT2d_fwd_sqerr_ws_bytes(N, Ci, Hi, Wi, Co, R, S, stride, crop_t,
+                                                      crop_l, Ho, Wo, xhat != nullptr);
+    if (need && (!ws || ws_bytes < need)) return BN_E_WORKSPACE;
+    const size_t n_out = (size_t)N * Co * Ho * Wo;
+    const size_t conv_ws = need - (xhat ? 0 : n_out * sizeof(float));
+    float* xh = xhat ? xhat : (float*)((char*)ws + conv_ws);
+    int rc = run_up(BN_PROF_CONVT_FWD, x, w, b, xh, nullptr, g, act, BN_ACT_NONE, slope, ws,
+                    conv_ws, st);
+    if (rc) return rc;
+    rc = bn_launch_sqerr_frame_sums(xh, target, mask, part, N, (size_t)Co * Ho * Wo, st);
+    if (rc) return rc;
+    rc = bn_launch_sqerr_bwd(xh, target, mask, dpre, n_out, 1.f, nullptr, st);
+    if (rc) return rc;
+    if (act != BN_ACT_NONE) rc = bn_launch_act_bwd(dpre, xh, dpre, n_out, act, slope, st);
+    return rc;
+}
+
+extern "C" int bn_scale_frames(float* t, const float* frame_scale, const float* group_scale,
+                               const int* group_of_frame, int N, size_t D, bn_stream_t stream) {
+    if (!t || !frame_scale || N <= 0 || D == 0) return BN_E_BADARG;
+    if ((group_scale == nullptr) != (group_of_frame == nullptr)) return BN_E_BADARG;
+    return bn_launch_scale_frames(t, frame_scale, group_scale, group_of_frame, N, D,
+                                  (hipStream_t)stream);
+}
+
 extern "C" int bn_reduce_sum(const float* in, float* out, size_t n, float scale,
                              bn_stream_t stream) {
     if (!in || !out) return BN_E_BADARG;

@@ -536,28 +536,186 @@ __global__ __launch_bounds__(ED_THREADS) void k_up_c1(
     }
 }
 
+// =============================================================================================
+// gather-up with few big-side channels, second generation (dec.convT4 forward [+ loss epilogue]):
+//   out[n,b,h,w] = act( bias[b] + sum_{c,r,s} small[n,c,p,q] * W[c][b][r][s] ),
+//   2p + r = h + 1, 2q + s = w + 1
+// 11 FLOP per byte and ONE output channel: there is no matrix shape to feed, so this generation
+// is a register-resident VALU kernel that touches neither LDS nor the matrix cores:
+//  * a workgroup is ONE wave, lane q = column q of the 64-wide small image; a unit is a strip of
+//    R small-image rows of one frame (plus one halo row above and below, of which only the taps
+//    that reach the strip's 2R output rows are evaluated: 7 % extra FMAs at R = 8);
+//  * the wave's 2R x 128 output pixels live in 4R accumulator registers per lane (columns 2q and
+//    2q+1 of every row) for the whole unit;
+//  * per input channel the 25 weights are wave-uniform SGPR operands of v_fmac (s_load from the
+//    scalar cache), the R + 2 input rows are full 256-byte wave rows (one buffer_load_dword per
+//    row, the next channel's rows in flight while this one is multiplied), and the column
+//    neighbours q-1 / q+1 come from DPP wave shifts (zero shifted in at the image border);
+//  * epilogue: bias, activation, one 512-byte float2 store per output row.  LOSS variant
+//    (training): the target (and mask) rows are read instead, the squared error is summed per
+//    unit, and dL/dpre = 2 (xhat - target) mask xhat (1 - xhat) is written -- xhat itself never
+//    goes to memory unless asked for (reference aes.py:330 + losses.py:56-59).
+// =============================================================================================
+#define UV_W 64
+
+__device__ __forceinline__ float uv_shift_from_left(float v) {      // lane q <- lane q-1, 0 at q=0
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+        __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float uv_shift_from_right(float v) {     // lane q <- lane q+1, 0 at q=63
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
+        __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+}
+
+template <int R, bool LOSS>
+__global__ __launch_bounds__(64) void k_up_c1v(
+    const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, const float* __restrict__ target, const float* __restrict__ mask,
+    float* __restrict__ dpre, float* __restrict__ partial, BnGeom g, int act, float slope,
+    int units) {
+    constexpr int NR = R + 2;                        // strip rows + halo above / below
+    const int lane = threadIdx.x;
+    const int strips = g.Hs / R;
+    const int row_bytes = g.Ws * 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)g.N * g.Cs * g.Hs * g.Ws * 4), 0x00020000);
+
+#pragma unroll 1
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int strip = u % strips;
+        const int nb = u / strips;
+        const int bch = nb % g.Cb, n = nb / g.Cb;
+        const int p0 = strip * R;
+
+        float acc[2 * R][2];
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) acc[j][0] = acc[j][1] = 0.f;
+
+        // rows p0-1 .. p0+R of channel c (zero outside the image: out-of-range buffer loads)
+        auto load_rows = [&](int c, float (&x)[NR]) {
+            const int base = ((n * g.Cs + c) * g.Hs + p0 - 1) * row_bytes;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int p = p0 - 1 + i;
+                const bool ok = c < g.Cs && p >= 0 && p < g.Hs;
+                x[i] = ed_ld(rs, ok ? base + i * row_bytes + lane * 4 : ED_OOB);
+            }
+        };
+        auto fma_rows = [&](int c, const float (&x)[NR]) {
+            const float* wc = w + ((size_t)(c < g.Cs ? c : 0) * g.Cb + bch) * 25;   // wave-uniform
+            float wk[25];
+#pragma unroll
+            for (int t = 0; t < 25; ++t) wk[t] = wc[t];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const float xc = x[i];
+                const float xm = uv_shift_from_left(xc);       // small[.., q-1]
+                const float xp = uv_shift_from_right(xc);      // small[.., q+1]
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const int j = 2 * i + r - 3;               // output row 2*p0 + j
+                    if (j < 0 || j >= 2 * R) continue;         // (compile-time)
+                    // column 2q   (w+1 odd):  s = 1 -> q,   s = 3 -> q-1
+                    acc[j][0] = fmaf(wk[r * 5 + 1], xc, acc[j][0]);
+                    acc[j][0] = fmaf(wk[r * 5 + 3], xm, acc[j][0]);
+                    // column 2q+1 (w+1 even): s = 0 -> q+1, s = 2 -> q, s = 4 -> q-1
+                    acc[j][1] = fmaf(wk[r * 5 + 0], xp, acc[j][1]);
+                    acc[j][1] = fmaf(wk[r * 5 + 2], xc, acc[j][1]);
+                    acc[j][1] = fmaf(wk[r * 5 + 4], xm, acc[j][1]);
+                }
+            }
+        };
+
+        float xa[NR], xb[NR];
+        load_rows(0, xa);
+#pragma unroll 1
+        for (int c = 0; c < g.Cs; c += 2) {
+            load_rows(c + 1, xb);
+            fma_rows(c, xa);
+            load_rows(c + 2, xa);
+            fma_rows(c + 1, xb);
+        }
+
+        const float bs = bias ? bias[bch] : 0.f;
+        const size_t o0 = (((size_t)n * g.Cb + bch) * g.Hb + 2 * p0) * g.Wb + 2 * lane;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) {
+            float2 v;
+            v.x = bn_apply_act(acc[j][0] + bs, act, slope);
+            v.y = bn_apply_act(acc[j][1] + bs, act, slope);
+            const size_t o = o0 + (size_t)j * g.Wb;
+            if (out) *reinterpret_cast<float2*>(out + o) = v;
+            if (LOSS) {
+                const float2 t = *reinterpret_cast<const float2*>(target + o);
+                float dx = v.x - t.x, dy = v.y - t.y;
+                float mx = 1.f, my = 1.f;
+                if (mask) {
+                    const float2 m = *reinterpret_cast<const float2*>(mask + o);
+                    mx = m.x; my = m.y;
+                }
+                sq += dx * dx * mx + dy * dy * my;
+                float2 d;
+                d.x = 2.f * dx * mx * bn_act_grad_from_output(v.x, act, slope);
+                d.y = 2.f * dy * my * bn_act_grad_from_output(v.y, act, slope);
+                *reinterpret_cast<float2*>(dpre + o) = d;
+            }
+        }
+        if (LOSS) {
+            // fixed-order butterfly over the 64 lanes, then one value per unit
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+            if (lane == 0) partial[u] = sq;
+        }
+    }
+}
+
 BnFastPlan bn_edge_up_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_up_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb > 4 || g.pt != 1 || g.pl != 1) return p;
-    if (g.Cs > 32 || g.Ws != UC_W || (g.Hs % UC_TH) != 0) return p;
+    if (g.Ws != UV_W || (g.Hs % 8) != 0) return p;
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
     p.supported = true;
-    p.kernel_name = "k_up_c1";
+    p.kernel_name = "k_up_c1v<8, false>";
     return p;
 }
 
+#define UV_R 8          // strip height of the production instantiation
+
+int bn_edge_up_parts_per_frame(const BnGeom& g) { return g.Cb * (g.Hs / UV_R); }
+
+// target == nullptr: plain forward (out required).  Otherwise the loss epilogue: `dpre` and
+// `partial` (N * bn_edge_up_parts_per_frame floats) are written, `out` only if non-null.
 int bn_launch_edge_up(const float* small, const float* w, const float* bias, float* out,
-                      const BnGeom& g, int act, float slope, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_up_c1,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, UC_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+                      const BnGeom& g, int act, float slope, hipStream_t st, const float* target,
+                      const float* mask, float* dpre, float* partial) {
+#ifdef BN_TUNING
+    static int old = -1;
+    if (old < 0) { const char* e = getenv("BN_UP_C1_OLD"); old = (e && e[0] == '1') ? 1 : 0; }
+    if (old && !target) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_up_c1,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, UC_LDS);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_up_c1, dim3(g.N * (g.Hs / UC_TH), g.Cb), dim3(ED_THREADS), UC_LDS, st,
+                           small, w, bias, out, g, act, slope);
+        BN_LAUNCH_CHECK();
+        return 0;
     }
-    hipLaunchKernelGGL(k_up_c1, dim3(g.N * (g.Hs / UC_TH), g.Cb), dim3(ED_THREADS), UC_LDS, st,
-                       small, w, bias, out, g, act, slope);
+#endif
+    const int units = g.N * g.Cb * (g.Hs / UV_R);
+    const int grid = units < 256 * 16 ? units : 256 * 16;
+    if (target) {
+        hipLaunchKernelGGL((k_up_c1v<UV_R, true>), dim3(grid), dim3(64), 0, st, small, w, bias, out,
+                           target, mask, dpre, partial, g, act, slope, units);
+    } else {
+        hipLaunchKernelGGL((k_up_c1v<UV_R, false>), dim3(grid), dim3(64), 0, st, small, w, bias, out,
+                           nullptr, nullptr, nullptr, nullptr, g, act, slope, units);
+    }
     BN_LAUNCH_CHECK();
     return 0;
 }

@@ -283,6 +283,42 @@ int bn_launch_sqerr_bwd(const float* pred, const float* target, const float* mas
     return 0;
 }
 
+// t[n, :] *= frame_scale[n] * group_scale[group_of_frame[n]]: the per-chunk loss normalisation and
+// upstream gradient applied to the fused loss epilogue's dL/dpre (grid.y = frame)
+__global__ __launch_bounds__(EW_THREADS) void k_scale_frames(
+    float* __restrict__ t, const float* __restrict__ frame_scale,
+    const float* __restrict__ group_scale, const int* __restrict__ group_of_frame, size_t D,
+    int vec) {
+    const int n = blockIdx.y;
+    float sc = frame_scale[n];
+    if (group_scale) sc *= group_scale[group_of_frame[n]];
+    float* row = t + (size_t)n * D;
+    const size_t tid = (size_t)blockIdx.x * EW_THREADS + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * EW_THREADS;
+    if (vec) {
+        float4* r4 = reinterpret_cast<float4*>(row);
+        for (size_t i = tid; i < (D >> 2); i += nthreads) {
+            float4 v = r4[i];
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+            r4[i] = v;
+        }
+    } else {
+        for (size_t i = tid; i < D; i += nthreads) row[i] *= sc;
+    }
+}
+
+int bn_launch_scale_frames(float* t, const float* frame_scale, const float* group_scale,
+                           const int* group_of_frame, int N, size_t D, hipStream_t st) {
+    const int vec = aligned16(t) && (D % 4 == 0);
+    const size_t per = vec ? D / 4 : D;
+    int bx = (int)((per + EW_THREADS - 1) / EW_THREADS);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_scale_frames, dim3(bx, N), dim3(EW_THREADS), 0, st, t, frame_scale,
+                       group_scale, group_of_frame, D, vec);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 int bn_launch_reduce_sum(const float* in, float* out, size_t n, float scale, hipStream_t st) {
     hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(EW_THREADS), 0, st, in, out, n, scale);
     BN_LAUNCH_CHECK();

@@ -401,78 +401,197 @@ class ConvStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         plan = ctx.plan
-        n_layers = len(plan)
-        saved = ctx.saved_tensors
-        acts, weights = saved[:n_layers + 1], saved[n_layers + 1:]
         dout = dout.contiguous()
-        n = dout.shape[0]
-
         top = plan[-1]
         if top.act != _hip.ACT_NONE:
-            dpre = _hip.act_bwd(dout, acts[-1], top.act, LRELU_SLOPE)
+            dpre = _hip.act_bwd(dout, ctx.saved_tensors[len(plan)], top.act, LRELU_SLOPE)
         else:
             dpre = dout
-
-        grads = [None] * (2 * n_layers)
-        tail = []     # weight gradients deferred to the main stream (see _tail_on_main)
-        for i in range(n_layers - 1, -1, -1):
-            layer = plan[i]
-            g = layer.geom(n)
-            w = weights[i]
-            x_in = acts[i]
-            need_w = ctx.needs_input_grad[3 + 2 * i]
-            need_b = ctx.needs_input_grad[4 + 2 * i]
-            if need_w:
-                gw = _grad_buffer(ctx.param_refs[2 * i])
-                gb = _grad_buffer(ctx.param_refs[2 * i + 1]) if need_b else None
-                direct = gw is not None and (gb is not None or not need_b)
-                if direct:
-                    dw, db = gw, gb
-                else:
-                    dw = torch.empty_like(w)
-                    db = torch.empty((layer.cout,), dtype=w.dtype, device=w.device) if need_b \
-                        else None
-                wgrad = _hip.conv2d_bwd_weight if layer.kind == 'conv' else _hip.convT2d_bwd_weight
-                side = _side_stream(w.device) if (direct and _use_side_stream) else None
-                if side is not None and not ctx.need_dx and i < _tail_on_main:
-                    tail.append(((wgrad, x_in, dpre, dw, db, g), ctx.param_refs[2 * i:2 * i + 2]))
-                elif side is not None:
-                    # weight gradients go to a second HIP stream: they only depend on dpre and the
-                    # saved input, while the main stream continues down the data-gradient chain;
-                    # the tail of one kernel is filled by workgroups of the other.  Gradients
-                    # land in param.grad in stream order; join_side_streams() publishes them.
-                    main = torch.cuda.current_stream(w.device)
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    with torch.cuda.stream(side):
-                        side.wait_event(ev)
-                        wgrad(x_in, dpre, dw, db, g, True)
-                    dpre.record_stream(side)
-                    x_in.record_stream(side)
-                    _report_ready(ctx.param_refs[2 * i:2 * i + 2])
-                else:
-                    wgrad(x_in, dpre, dw, db, g, direct)
-                    if direct:
-                        _report_ready(ctx.param_refs[2 * i:2 * i + 2])
-                if not direct:
-                    grads[2 * i], grads[2 * i + 1] = dw, db
-            if i > 0 or ctx.need_dx:
-                # fuse the derivative of the layer below into this kernel's epilogue
-                dact_src = acts[i] if i > 0 else None
-                dact = plan[i - 1].act if i > 0 else _hip.ACT_NONE
-                if layer.kind == 'conv':
-                    dpre = _hip.conv2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
-                else:
-                    dpre = _hip.convT2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
-        for (wgrad, x_in, dy, dw, db, g), refs in tail:
-            wgrad(x_in, dy, dw, db, g, True)
-            _report_ready(refs)
-        dx = dpre if ctx.need_dx else None
+        dx, grads = _stack_backward(ctx, dpre, first_param=3)
         return (None, dx, None) + tuple(grads)
+
+
+def _stack_backward(ctx, dpre, first_param):
+    """Backward pass of a fused conv stack from ``dpre`` = dL/d(pre-activation of the top layer):
+    per layer the weight (+bias) gradient, then the data gradient with the activation derivative
+    of the layer below fused into its epilogue.  -> (dx | None, [dw_1, db_1, ..., dw_L, db_L])
+    with None for gradients the kernels accumulated straight into ``param.grad``."""
+    plan = ctx.plan
+    n_layers = len(plan)
+    saved = ctx.saved_tensors
+    acts, weights = saved[:n_layers + 1], saved[n_layers + 1:2 * n_layers + 1]
+    n = dpre.shape[0]
+    grads = [None] * (2 * n_layers)
+    tail = []     # weight gradients deferred to the main stream (see _tail_on_main)
+    for i in range(n_layers - 1, -1, -1):
+        layer = plan[i]
+        g = layer.geom(n)
+        w = weights[i]
+        x_in = acts[i]
+        need_w = ctx.needs_input_grad[first_param + 2 * i]
+        need_b = ctx.needs_input_grad[first_param + 1 + 2 * i]
+        if need_w:
+            gw = _grad_buffer(ctx.param_refs[2 * i])
+            gb = _grad_buffer(ctx.param_refs[2 * i + 1]) if need_b else None
+            direct = gw is not None and (gb is not None or not need_b)
+            if direct:
+                dw, db = gw, gb
+            else:
+                dw = torch.empty_like(w)
+                db = torch.empty((layer.cout,), dtype=w.dtype, device=w.device) if need_b \
+                    else None
+            wgrad = _hip.conv2d_bwd_weight if layer.kind == 'conv' else _hip.convT2d_bwd_weight
+            side = _side_stream(w.device) if (direct and _use_side_stream) else None
+            if side is not None and not ctx.need_dx and i < _tail_on_main:
+                tail.append(((wgrad, x_in, dpre, dw, db, g), ctx.param_refs[2 * i:2 * i + 2]))
+            elif side is not None:
+                # weight gradients go to a second HIP stream: they only depend on dpre and the
+                # saved input, while the main stream continues down the data-gradient chain;
+                # the tail of one kernel is filled by workgroups of the other.  Gradients
+                # land in param.grad in stream order; join_side_streams() publishes them.
+                main = torch.cuda.current_stream(w.device)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    wgrad(x_in, dpre, dw, db, g, True)
+                dpre.record_stream(side)
+                x_in.record_stream(side)
+                _report_ready(ctx.param_refs[2 * i:2 * i + 2])
+            else:
+                wgrad(x_in, dpre, dw, db, g, direct)
+                if direct:
+                    _report_ready(ctx.param_refs[2 * i:2 * i + 2])
+            if not direct:
+                grads[2 * i], grads[2 * i + 1] = dw, db
+        if i > 0 or ctx.need_dx:
+            # fuse the derivative of the layer below into this kernel's epilogue
+            dact_src = acts[i] if i > 0 else None
+            dact = plan[i - 1].act if i > 0 else _hip.ACT_NONE
+            if layer.kind == 'conv':
+                dpre = _hip.conv2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
+            else:
+                dpre = _hip.convT2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
+    for (wgrad, x_in, dy, dw, db, g), refs in tail:
+        wgrad(x_in, dy, dw, db, g, True)
+        _report_ready(refs)
+    return (dpre if ctx.need_dx else None), grads
 
 
 def conv_stack(plan, x, params, h1=None):
     return ConvStackFn.apply(plan, x, h1, *params)
+
+
+_frame_scale_cache = {}
+
+
+def _frame_scales(n, bounds, scales, device):
+    """(per-frame loss scale (N,) float32, chunk index of every frame (N,) int32) on `device`."""
+    key = (torch.device(device), int(n), tuple(bounds), tuple(float(s) for s in scales))
+    hit = _frame_scale_cache.get(key)
+    if hit is None:
+        fs = torch.zeros(n, dtype=torch.float32)
+        ci = torch.zeros(n, dtype=torch.int32)
+        for c, ((beg, end), sc) in enumerate(zip(bounds, scales)):
+            fs[beg:end] = float(sc)
+            ci[beg:end] = c
+        hit = (fs.to(device), ci.to(device))
+        if len(_frame_scale_cache) > 64:
+            _frame_scale_cache.clear()
+        _frame_scale_cache[key] = hit
+    return hit
+
+
+class ConvStackSqErrFn(torch.autograd.Function):
+    """A decoder stack whose LAST layer is fused with the pixel loss (csrc: ``k_up_c1v<R, true>``;
+    reference aes.py:460-476 + losses.py:56-59 / 84-96):
+
+        out[c] = scales[c] * sum_{frames of chunk c} sum_pixels (x_hat - target)^2 * mask
+
+    for the contiguous frame ranges ``bounds``; also returns ``x_hat`` if ``want_xhat`` (not
+    differentiable through this node), else None.  The forward kernel already leaves dL/dpre of
+    the last layer (up to the per-chunk factor), so the backward pass starts at the top layer's
+    weight gradient: no sigmoid / squared-error backward kernels, and x_hat is never re-read.
+    """
+
+    @staticmethod
+    def forward(ctx, plan, x, target, mask, bounds, scales, want_xhat, *params):
+        if plan[-1].kind != 'convT':
+            raise ValueError('the fused pixel loss follows a transposed convolution')
+        x = x.contiguous()
+        target = target.contiguous()
+        mask = mask.contiguous() if mask is not None else None
+        acts = [x]
+        h = x
+        for i, layer in enumerate(plan[:-1]):
+            h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach())
+            acts.append(h)
+        top = plan[-1]
+        n = h.shape[0]
+        xhat, dpre, part = _hip.convT2d_fwd_sqerr(
+            h, params[-2].detach(), params[-1].detach(), target, mask, top.geom(n), top.act,
+            LRELU_SLOPE, bool(want_xhat))
+        if _sign_tap is not None:
+            rec = _sign_tap.setdefault(id(plan), [[] for _ in plan])
+            for i, layer in enumerate(plan[:-1]):
+                if layer.act == _hip.ACT_LRELU:
+                    rec[i].append((acts[i + 1] > 0).cpu())
+        out = torch.empty((len(bounds),), dtype=torch.float32, device=x.device)
+        for c, ((beg, end), sc) in enumerate(zip(bounds, scales)):
+            _hip.reduce_sum(part[beg:end], float(sc), out=out[c:c + 1])
+        ctx.plan = plan
+        ctx.need_dx = x.requires_grad
+        ctx.param_refs = params
+        ctx.bounds, ctx.scales = list(bounds), [float(sc) for sc in scales]
+        ctx.consumed = False
+        _note_use(params, any(ctx.needs_input_grad[7:]))
+        # slot n_layers of `acts` (the top layer's output) is not needed by the backward pass:
+        # dpre stands in for it so that _stack_backward's indexing stays the ConvStackFn one
+        ctx.save_for_backward(*acts, dpre, *params[0::2])
+        if xhat is not None:
+            ctx.mark_non_differentiable(xhat)
+        return out, xhat
+
+    @staticmethod
+    def backward(ctx, g, _g_xhat):
+        if ctx.consumed:
+            raise RuntimeError('ConvStackSqErrFn: backward twice (dL/dpre is scaled in place)')
+        ctx.consumed = True
+        n_layers = len(ctx.plan)
+        dpre = ctx.saved_tensors[n_layers]
+        fs, ci = _frame_scales(dpre.shape[0], ctx.bounds, ctx.scales, dpre.device)
+        _hip.scale_frames(dpre, fs, g.contiguous(), ci)
+        dx, grads = _stack_backward(ctx, dpre, first_param=7)
+        return (None, dx, None, None, None, None, None) + tuple(grads)
+
+
+def conv_stack_sq_err(plan, x, params, target, mask, bounds, scales, want_xhat=False):
+    """-> (per-chunk scaled squared-error sums (n_chunks,), x_hat | None)."""
+    return ConvStackSqErrFn.apply(plan, x, target, mask, tuple(bounds), tuple(scales),
+                                  bool(want_xhat), *params)
+
+
+class FusedPixelLoss(object):
+    """What a decoder returns in place of ``x_hat`` when it was asked for the pixel loss of a
+    batch (``pixel_loss=`` argument): the per-chunk loss terms (already normalised:
+    ``kind='mse'`` -> mean squared error of each chunk, ``kind='ll'`` -> the data-dependent part
+    of ``losses.gaussian_ll``) and ``x_hat`` itself only if it was requested."""
+
+    def __init__(self, x_hat, chunk_terms, kind, bounds):
+        self.x_hat = x_hat
+        self.chunk_terms = chunk_terms
+        self.kind = kind
+        self.bounds = list(bounds)
+
+
+def pixel_loss_scales(kind, bounds, per_frame):
+    """Per-chunk factors of the squared-error sums: 'mse' -> 1 / (frames * pixels) (reference
+    losses.py:56-59: mean over ALL elements), 'll' -> -0.5 / frames (losses.py:84-96, std = 1)."""
+    if kind == 'mse':
+        return [1.0 / ((end - beg) * per_frame) for beg, end in bounds]
+    if kind == 'll':
+        return [-0.5 / (end - beg) for beg, end in bounds]
+    raise ValueError('unknown pixel loss kind "%s"' % kind)
 
 
 class BatchNormActFn(torch.autograd.Function):

@@ -18,9 +18,10 @@ import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ChunkScalars, ConvLayerPlan, Readback, activation, backward_chunks, conv_stack, conv_stack_bn,
-    first_layer_forward, join_side_streams, linear, begin_chunks, chunk_stream,
-    max_pool, max_unpool, reserve_device_pools)
+    ChunkScalars, ConvLayerPlan, FusedPixelLoss, Readback, activation, backward_chunks,
+    chunked_sq_err, conv_stack, conv_stack_bn, conv_stack_sq_err, first_layer_forward,
+    join_side_streams, linear, begin_chunks, chunk_stream, max_pool, max_unpool,
+    pixel_loss_scales, reserve_device_pools)
 
 __all__ = [
     'ConvAEEncoder', 'ConvAEDecoder', 'LinearAEEncoder', 'LinearAEDecoder', 'AE', 'ConditionalAE',
@@ -389,12 +390,29 @@ class ConvAEDecoder(BaseModule):
             params += [mod.weight, mod.bias]
         return params
 
-    def forward(self, x, pool_idx=None, target_output_size=None, dataset=None):
+    def forward(self, x, pool_idx=None, target_output_size=None, dataset=None, pixel_loss=None):
+        """-> x_hat; or, with ``pixel_loss = {'target', 'mask', 'bounds', 'kind', 'want_xhat'}``
+        (the single-pass training schedule), a :class:`FusedPixelLoss`: the per-chunk pixel loss
+        evaluated in the epilogue of the last transposed convolution (x_hat is then not written
+        unless asked for)."""
         hp = self.hparams
         start = hp['ae_decoding_starting_dim']
         h = linear(x, self.FF.weight, self.FF.bias)
         h = h.view(h.size(0), start[0], start[1], start[2])
         params = self._stack_params(dataset)
+        if pixel_loss is not None:
+            target, bounds, kind = pixel_loss['target'], pixel_loss['bounds'], pixel_loss['kind']
+            scales = pixel_loss_scales(kind, bounds, target[0].numel())
+            if not any(self._unpool_before) and not hp['ae_batch_norm'] and \
+                    not hp['ae_decoding_last_FF_layer'] and \
+                    os.environ.get('BN_FUSED_LOSS', '1') != '0':
+                terms, x_hat = conv_stack_sq_err(
+                    self._plan, h, params, target, pixel_loss.get('mask'), bounds, scales,
+                    pixel_loss.get('want_xhat', False))
+                return FusedPixelLoss(x_hat, terms, kind, bounds)
+            x_hat = self.forward(x, pool_idx, target_output_size, dataset=dataset)
+            return FusedPixelLoss(x_hat, chunked_sq_err(
+                x_hat, target, pixel_loss.get('mask'), bounds, scales), kind, bounds)
         if any(self._unpool_before):
             # max-pooling architectures: MaxUnpool2d with the encoder's indices (last pooled first)
             # in front of its transposed convolution, layer by layer (ref aes.py:460-476)
@@ -555,7 +573,11 @@ class AE(BaseModel):
                   for beg in range(0, batch_size, chunk_size)]
         self._reserve_pools(x)
         with torch.set_grad_enabled(bool(accumulate_grad)):
-            x_hat, _ = self.forward(x, dataset=dataset, **fwd_kwargs)
+            # the pixel loss rides in the epilogue of the last decoder layer
+            x_hat, _ = self.forward(
+                x, dataset=dataset,
+                pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'mse'},
+                **fwd_kwargs)
             chunk_losses = losses.mse_chunks(x, x_hat, m, bounds)
         vals = Readback(chunk_losses.detach())
         if accumulate_grad:
@@ -579,7 +601,8 @@ class AE(BaseModel):
         """-> (x_hat (N,C,H,W), latents (N,n_latents))."""
         if self.model_type == 'conv':
             z, pool_idx, outsize = self.encoding(x, dataset=dataset)
-            y = self.decoding(z, pool_idx, outsize, dataset=dataset)
+            y = self.decoding(z, pool_idx, outsize, dataset=dataset,
+                              pixel_loss=kwargs.get('pixel_loss'))
         elif self.model_type == 'linear':
             z, _, _ = self.encoding(x)
             y = self.decoding(z)
@@ -645,7 +668,8 @@ class ConditionalAE(AE):
             x = torch.cat((x, labels_2d), dim=1)
         z, pool_idx, outsize = self.encoding(x, dataset=dataset)
         z_aug = torch.cat((z, labels), dim=1)
-        y = self.decoding(z_aug, pool_idx, outsize, dataset=dataset)
+        y = self.decoding(z_aug, pool_idx, outsize, dataset=dataset,
+                          pixel_loss=kwargs.get('pixel_loss'))
         return y, z
 
     def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
@@ -750,7 +774,9 @@ class AEMSP(AE):
                 P = self._P()
                 z, pool_idx, outsize = self.encoding(x, dataset=dataset)
                 y_hat = linear(z, P, None)
-                x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+                x_hat = self.decoding(
+                    z, pool_idx, outsize, dataset=dataset,
+                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'mse'})
                 z_back = linear(y_hat, P.t().contiguous(), None)
                 l_mse = losses.mse_chunks(x, x_hat, m, bounds)
                 l_msp = torch.stack([

@@ -122,7 +122,8 @@ class VAE(AE):
         """-> (x_hat, z, mu, logvar)."""
         mu, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
         z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
-        x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+        x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset,
+                              pixel_loss=kwargs.get('pixel_loss'))
         return x_hat, z, mu, logvar
 
     def _elbo_loss(self, data, dataset, accumulate_grad, chunk_size, fwd_kwargs_fn):
@@ -142,6 +143,7 @@ class VAE(AE):
             with torch.set_grad_enabled(bool(accumulate_grad)):
                 x_hat, _, mu, logvar = self.forward(
                     x, dataset=dataset, use_mean=False, sample_bounds=bounds,
+                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'll'},
                     **fwd_kwargs_fn(0, batch_size))
                 ll = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
                 klv = torch.stack([losses.kl_div_to_std_normal(
@@ -208,7 +210,8 @@ class ConditionalVAE(VAE):
         mu, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
         z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
         z_aug = torch.cat((z, labels), dim=1)
-        x_hat = self.decoding(z_aug, pool_idx, outsize, dataset=dataset)
+        x_hat = self.decoding(z_aug, pool_idx, outsize, dataset=dataset,
+                              pixel_loss=kwargs.get('pixel_loss'))
         return x_hat, z, mu, logvar
 
     def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
@@ -247,8 +250,9 @@ class BetaTCVAE(VAE):
         if whole:
             bounds = _bounds(batch_size, chunk_size)
             with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, sample, mu, logvar = self.forward(x, dataset=dataset, use_mean=False,
-                                                         sample_bounds=bounds)
+                x_hat, sample, mu, logvar = self.forward(
+                    x, dataset=dataset, use_mean=False, sample_bounds=bounds,
+                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'll'})
                 ll = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
                 dk = torch.stack([torch.stack(losses.decomposed_kl(
                     sample[b:e], mu[b:e], logvar[b:e])) for b, e in bounds])   # (n_chunks, 3)
@@ -367,7 +371,8 @@ class PSVAE(AE):
         y, w, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
         mu = torch.cat([y, w], dim=1)
         z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
-        x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset)
+        x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset,
+                              pixel_loss=kwargs.get('pixel_loss'))
         y_hat = self.encoding.D(y)
         return x_hat, z, mu, logvar, y_hat
 
@@ -395,7 +400,8 @@ class PSVAE(AE):
             bounds = _bounds(batch_size, chunk_size)
             with torch.set_grad_enabled(bool(accumulate_grad)):
                 x_hat, sample, mu, logvar, y_hat = self.forward(
-                    x, dataset=dataset, use_mean=False, sample_bounds=bounds)
+                    x, dataset=dataset, use_mean=False, sample_bounds=bounds,
+                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'll'})
                 ll_x = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
                 ll_y = losses.gaussian_ll_chunks(y, y_hat, n, bounds)
                 zs = torch.stack([losses.kl_div_to_std_normal(

@@ -225,6 +225,33 @@ int bn_decomposed_kl_bwd(const float* z, const float* mu, const float* logvar,
                          float* dmu, float* dlogvar, int N, int D, bn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Last decoder layer fused with the pixel loss (replaces, in ONE pass, the ConvTranspose2d + crop
+ * + Sigmoid of aes.py:315-330,466-470 and the squared error of losses.py:56-59 / 84-96 together
+ * with their derivatives): for every frame n
+ *     xhat   = act(convT(x, w, b))                     written only if xhat != NULL
+ *     part[n][j], j < P:  sum_j part[n][j] = sum_{c,h,w} (xhat - target)^2 * mask
+ *     dpre   = 2 (xhat - target) mask act'(xhat)       = d(frame sum)/d(pre-activation)
+ * so that training never writes or re-reads xhat.  P = bn_convT2d_fwd_sqerr_parts(geometry)
+ * (partial sums per frame, summed by the caller in index order: deterministic).  mask nullable.
+ * `ws`: bn_convT2d_fwd_sqerr_ws_bytes(geometry, xhat != NULL) bytes (0 for the benchmark layer).
+ * bn_scale_frames: t[n, :] *= frame_scale[n] * (group_scale ? group_scale[group_of_frame[n]] : 1)
+ * -- the backward pass applies the per-chunk loss normalisation and the upstream gradient of a
+ * frame's chunk to dpre with it (aes.py:751-771: one mean per 200-frame chunk).
+ * ------------------------------------------------------------------------------------------ */
+int bn_convT2d_fwd_sqerr_parts(int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
+                               int crop_t, int crop_l, int Ho, int Wo);
+size_t bn_convT2d_fwd_sqerr_ws_bytes(int N, int Ci, int Hi, int Wi, int Co, int R, int S,
+                                     int stride, int crop_t, int crop_l, int Ho, int Wo,
+                                     int with_xhat);
+int bn_convT2d_fwd_sqerr(const float* x, const float* w, const float* b, const float* target,
+                         const float* mask, float* xhat, float* dpre, float* part,
+                         int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
+                         int crop_t, int crop_l, int Ho, int Wo, int act, float slope,
+                         void* ws, size_t ws_bytes, bn_stream_t stream);
+int bn_scale_frames(float* t, const float* frame_scale, const float* group_scale,
+                    const int* group_of_frame, int N, size_t D, bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimiser (replaces torch.optim.Adam(amsgrad=True).step, training.py:284-286,352), over one
  * flat fp32 parameter arena.  `step` is 1-based.  weight_decay adds wd*p to the gradient.
  * ------------------------------------------------------------------------------------------ */

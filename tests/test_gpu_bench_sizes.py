@@ -63,7 +63,7 @@ KERNELS_256 = {
     ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D1', 'bwd_w'): 'k_wgrad4_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4_mfma<4>',
     ('D3', 'bwd_w'): 'k_wgrad4_mfma<5>',
-    ('D4', 'fwd'): 'k_up_c1', ('D4', 'bwd_d'): 'k_down_c1<0, true>', ('D4', 'bwd_w'): 'k_wgrad_c1',
+    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1<0, true>', ('D4', 'bwd_w'): 'k_wgrad_c1',
 }
 # the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
 # frames, smaller tiles where the grid would not fill the chip
@@ -288,3 +288,29 @@ def test_whole_model_batch256_loss_and_gradients_vs_oracle():
     _, n, name = _hip.prof_read()
     _hip.prof_select(_hip.PROF_NONE)
     assert n == 1 and name == KERNELS_256[('E1', 'fwd')], (n, name)
+
+
+@pytest.mark.parametrize('n', SIZES)
+def test_fused_last_layer_loss_at_bench_sizes(n):
+    """dec.convT4 + Sigmoid + squared error in one pass (the training path of the benchmark):
+    frame sums and dL/dpre of ALL frames against the oracle's operators."""
+    kind, x, w, b, dy, geom = make_layer('D4', n, seed=4)
+    g = torch.Generator().manual_seed(n)
+    target = torch.rand(dy.shape, generator=g)
+    op = oracle_op('D4')
+
+    def oracle(dt):
+        pre = op(x.to(dt), w.to(dt), b.to(dt)).requires_grad_(True)
+        xh = torch.sigmoid(pre)
+        sums = ((xh - target.to(dt)) ** 2).reshape(n, -1).sum(dim=1)
+        sums.sum().backward()
+        return sums.detach(), pre.grad
+    s32, d32 = oracle(torch.float32)
+    s64, d64 = oracle(torch.float64)
+    (xh, dpre, part), name = dispatched(
+        kind, 'fwd', geom[1], geom[4],
+        lambda: _hip.convT2d_fwd_sqerr(x.to(DEV), w.to(DEV), b.to(DEV), target.to(DEV), None, geom,
+                                       _hip.ACT_SIGMOID, SLOPE, False))
+    assert xh is None and name == 'k_up_c1v<8, true>'
+    close(part.sum(dim=1), s32, s64, name='frame sums N=%d' % n)
+    close(dpre, d32, d64, name='dpre N=%d' % n)

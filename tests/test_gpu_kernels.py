@@ -214,6 +214,89 @@ def test_convT2d_bwd(case):
     close(dw, 2 * dwr, 2 * dw64, name=case[0] + ' dw acc')
 
 
+@pytest.mark.parametrize('case_name', ['D4', 'D4_2ch', 'k4s2', 'D1'])
+@pytest.mark.parametrize('masked', [False, True])
+@pytest.mark.parametrize('act', [_hip.ACT_SIGMOID, _hip.ACT_LRELU])
+def test_convT2d_fwd_sqerr(case_name, masked, act):
+    """Last decoder layer fused with the pixel loss (bn_convT2d_fwd_sqerr; reference
+    aes.py:315-330,466-470 + losses.py:56-59): x_hat, the per-frame squared-error sums and
+    d(frame sum)/d(pre-activation) against the oracle's operators -- on the fused VALU kernel
+    (D4 geometries) and on the composed fallback (any other geometry)."""
+    case = [c for c in CONVT_CASES if c[0] == case_name][0]
+    x, w, b, geom, ref = _convT_setup(case, seed=3)
+    N, Co, Ho, Wo = geom[0], geom[4], geom[10], geom[11]
+    g = torch.Generator().manual_seed(9)
+    target = torch.rand((N, Co, Ho, Wo), generator=g)
+    mask = (torch.rand((N, Co, Ho, Wo), generator=g) > 0.3).float() if masked else None
+
+    def oracle(dt):
+        pre = ref(x.to(dt), w.to(dt), b.to(dt)).requires_grad_(True)
+        xh = act_ref(pre, act)
+        d = (xh - target.to(dt)) ** 2
+        if mask is not None:
+            d = d * mask.to(dt)
+        sums = d.reshape(N, -1).sum(dim=1)
+        sums.sum().backward()
+        return xh.detach(), sums.detach(), pre.grad
+    xh32, s32, d32 = oracle(torch.float32)
+    xh64, s64, d64 = oracle(torch.float64)
+    md = mask.to(DEV) if mask is not None else None
+    for want in (True, False):
+        xh, dpre, part = _hip.convT2d_fwd_sqerr(
+            x.to(DEV), w.to(DEV), b.to(DEV), target.to(DEV), md, geom, act, SLOPE, want)
+        assert (xh is not None) == want
+        if want:
+            close(xh, xh32, xh64, name=case_name + ' xhat')
+        assert part.shape[0] == N
+        close(part.sum(dim=1), s32, s64, name=case_name + ' frame sums')
+        close(dpre, d32, d64, name=case_name + ' dpre')
+    # backward-side helper: per-frame scale x per-chunk upstream gradient, in place
+    fs = torch.rand((N,), generator=g) + 0.5
+    gs = torch.rand((2,), generator=g) + 0.5
+    grp = torch.tensor([0 if i < (N + 1) // 2 else 1 for i in range(N)], dtype=torch.int32)
+    want_scaled = d32 * (fs * gs[grp.long()]).reshape(N, 1, 1, 1)
+    _hip.scale_frames(dpre, fs.to(DEV), gs.to(DEV), grp.to(DEV))
+    close(dpre, want_scaled, name=case_name + ' scaled dpre')
+    t = d32.clone().to(DEV)
+    _hip.scale_frames(t, fs.to(DEV))
+    close(t, d32 * fs.reshape(N, 1, 1, 1), name='scale_frames without groups')
+
+
+def test_conv_stack_sq_err_matches_unfused_path():
+    """ConvStackSqErrFn (decoder stack + fused loss) against ConvStackFn + ChunkedSqErrFn on the
+    same parameters: chunk losses, x_hat and every gradient (incl. the stack's input)."""
+    from behavenet_amd import hip_functions as hf
+    g = torch.Generator().manual_seed(2)
+    n = 7
+    plan = [hf.ConvLayerPlan('convT', 8, 32, 32, 32, 64, 64, 5, 5, 2, 1, 1, _hip.ACT_LRELU),
+            hf.ConvLayerPlan('convT', 32, 64, 64, 1, 128, 128, 5, 5, 2, 1, 1, _hip.ACT_SIGMOID)]
+    mk = lambda *sh: ((torch.rand(sh, generator=g) - 0.5) * 0.2).to(DEV)
+    base = [mk(8, 32, 5, 5), mk(32), mk(32, 1, 5, 5), mk(1)]
+    x0 = (torch.rand((n, 8, 32, 32), generator=g) - 0.3).to(DEV)
+    target = torch.rand((n, 1, 128, 128), generator=g).to(DEV)
+    mask = (torch.rand((n, 1, 128, 128), generator=g) > 0.2).float().to(DEV)
+    bounds = [(0, 4), (4, 7)]
+    scales = [1.0 / (4 * 128 * 128), 1.0 / (3 * 128 * 128)]
+    wts = torch.tensor([1.3, 0.6], device=DEV)
+    res = []
+    for fused in (False, True):
+        params = [p.clone().requires_grad_(True) for p in base]
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            terms, xh = hf.conv_stack_sq_err(plan, x, params, target, mask, bounds, scales, True)
+        else:
+            xh = hf.conv_stack(plan, x, params)
+            terms = hf.chunked_sq_err(xh, target, mask, bounds, scales)
+        (terms * wts).sum().backward()
+        res.append((terms.detach(), xh.detach(), x.grad, [p.grad for p in params]))
+    (t0, xh0, dx0, g0), (t1, xh1, dx1, g1) = res
+    close(t1, t0, norm_tol=1e-6, name='chunk terms')
+    close(xh1, xh0, norm_tol=1e-6, name='x_hat')
+    close(dx1, dx0, norm_tol=2e-5, name='dx')
+    for a, b_ in zip(g1, g0):
+        close(a, b_, norm_tol=2e-5, name='param grad')
+
+
 BN_CASES = [  # (N, C, H, W, momentum, training, affine)
     (200, 32, 16, 16, 0.1, True, True),
     (7, 64, 9, 5, 0.1, True, True),

@@ -104,7 +104,13 @@ def main():
                 'bwd_d': lambda: _hip.convT2d_bwd_data(dy, w, geom, x, _hip.ACT_LRELU, SLOPE),
                 'bwd_w': lambda: (_hip.convT2d_bwd_weight(x, dy, dw, db, geom, False), dw)[1],
             }
+            if co <= 4:
+                tgt = torch.rand((N, co, ho, wo), device=dev)
+                ops['fwd_sqerr'] = lambda: _hip.convT2d_fwd_sqerr(
+                    x, w, b, tgt, None, geom, _hip.ACT_SIGMOID, SLOPE, False)[1]
         for op in args.ops.split(','):
+            if op not in ops:
+                continue
             if name == 'E0' and op == 'bwd_d':
                 continue
             fn = ops[op]
