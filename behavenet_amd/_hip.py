@@ -12,7 +12,9 @@ import os
 import torch
 
 _LIB_NAME = 'libbehavenet_hip.so'
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+# BN_HIP_LIB: an alternative build of the same ABI (csrc `make tuning`: experiment hooks compiled in)
+_LIB_PATH = os.environ.get('BN_HIP_LIB') or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 _lib = None
 
 ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
@@ -36,6 +38,8 @@ SIGNATURES = {
     'bn_set_force_generic': (_c_int, [_c_int]),
     'bn_conv_ws_bytes': (_c_size_t, [_c_int] + _CONV_GEOM),
     'bn_conv2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
+    'bn_conv2d_fwd_u8_ws_bytes': (_c_size_t, _CONV_GEOM),
+    'bn_conv2d_fwd_u8': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_conv2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_conv2d_bwd_weight': (
         _c_int, [_c_void_p] * 4 + _CONV_GEOM + [_c_int, _c_void_p, _c_size_t, _c_void_p]),
@@ -168,6 +172,26 @@ def conv2d_fwd(x, w, b, geom, act, slope):
     _check(load().bn_conv2d_fwd(
         _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), *geom,
         act, slope, ws, nb, _stream()), 'bn_conv2d_fwd')
+    return y
+
+
+def conv2d_fwd_u8(x_u8, w, b, geom, act, slope):
+    """First encoder layer from uint8 frames (value / 255 fused into the patch load)."""
+    N, C, H, W, K, R, S, st, pt, pl, P, Q = geom
+    y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x_u8.device)
+    lib = load()
+    nbytes = lib.bn_conv2d_fwd_u8_ws_bytes(*geom)
+    ws = None
+    if nbytes:
+        key = (x_u8.device, torch.cuda.current_stream(x_u8.device).cuda_stream, 'fwd_u8')
+        buf = _ws_cache.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=x_u8.device)
+            _ws_cache[key] = buf
+        ws = buf.data_ptr()
+    _check(lib.bn_conv2d_fwd_u8(
+        _ptr(x_u8, 'x', dtype=torch.uint8), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True),
+        _ptr(y, 'y'), *geom, act, slope, ws, nbytes, _stream()), 'bn_conv2d_fwd_u8')
     return y
 
 

@@ -59,7 +59,7 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
 BnFastPlan bn_edge_down_plan(const BnGeom& g);
 int bn_launch_edge_down(const float* big, const float* w, const float* bias, float* out,
                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
-                        hipStream_t st);
+                        hipStream_t st, const unsigned char* u8 = nullptr);
 BnFastPlan bn_edge_up_plan(const BnGeom& g);
 int bn_launch_edge_up(const float* small, const float* w, const float* bias, float* out,
                       const BnGeom& g, int act, float slope, hipStream_t st,

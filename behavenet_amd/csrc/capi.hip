@@ -198,8 +198,9 @@ static int run_down(int family, const float* big, const float* w, const float* b
         const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
                                      : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
         if (ed.supported && epi_ok) {
-            const char* name = dact_src ? "k_down_c1<0, true>"
-                               : (act == BN_ACT_LRELU ? "k_down_c1<1, false>" : "k_down_c1<0, false>");
+            const char* name = dact_src ? "k_down_c1s<0, true, false, 4>"
+                               : (act == BN_ACT_LRELU ? "k_down_c1s<1, false, false, 4>"
+                                                      : "k_down_c1s<0, false, false, 4>");
             BnProfScope prof(family, g.Cb, g.Cs, name, st, /*on_dispatch=*/true);
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }
@@ -331,6 +332,46 @@ extern "C" int bn_conv2d_fwd(const float* x, const float* w, const float* b, flo
     if (!bn_geom_ok(g)) return BN_E_BADARG;
     return run_down(BN_PROF_CONV_FWD, x, w, b, y, nullptr, g, act, BN_ACT_NONE, slope, ws,
                     ws_bytes, (hipStream_t)stream);
+}
+
+static bool u8_fast(const BnGeom& g, int act) {
+    return !force_generic() && bn_edge_down_plan(g).supported &&
+           (act == BN_ACT_NONE || act == BN_ACT_LRELU);
+}
+
+extern "C" size_t bn_conv2d_fwd_u8_ws_bytes(int N, int C, int H, int W, int K, int R, int S,
+                                            int stride, int pad_t, int pad_l, int P, int Q) {
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g)) return 0;
+    if (u8_fast(g, BN_ACT_NONE)) return 0;
+    size_t conv = bn_conv_ws_bytes(BN_OP_CONV_FWD, N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    conv = (conv + 255) & ~(size_t)255;
+    return conv + (size_t)N * C * H * W * sizeof(float);
+}
+
+extern "C" int bn_conv2d_fwd_u8(const unsigned char* x, const float* w, const float* b, float* y,
+                                int N, int C, int H, int W, int K, int R, int S, int stride,
+                                int pad_t, int pad_l, int P, int Q, int act, float slope, void* ws,
+                                size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !w || !y) return BN_E_BADARG;
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (u8_fast(g, act)) {
+        BnProfScope prof(BN_PROF_CONV_FWD, g.Cb, g.Cs,
+                         act == BN_ACT_LRELU ? "k_down_c1s<1, false, true, 4>"
+                                             : "k_down_c1s<0, false, true, 4>", st, true);
+        return bn_launch_edge_down(nullptr, w, b, y, nullptr, g, act, BN_ACT_NONE, slope, st, x);
+    }
+    const size_t need = bn_conv2d_fwd_u8_ws_bytes(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!ws || ws_bytes < need) return BN_E_WORKSPACE;
+    const size_t n_in = (size_t)N * C * H * W;
+    const size_t conv_ws = need - n_in * sizeof(float);
+    float* xf = (float*)((char*)ws + conv_ws);
+    int rc = bn_launch_u8_to_unit_float(x, xf, n_in, st);
+    if (rc) return rc;
+    return run_down(BN_PROF_CONV_FWD, xf, w, b, y, nullptr, g, act, BN_ACT_NONE, slope, ws, conv_ws,
+                    st);
 }
 
 extern "C" int bn_conv2d_bwd_data(const float* dy, const float* w, float* dx,

@@ -228,6 +228,9 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
 #define DC_WPE 3
 #endif
 #define DC_HTS 36                        // half-row slab row stride
+#ifndef DC_VARIANT
+#define DC_VARIANT 2                     // product build: second generation, 4-row units
+#endif
 
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx4e __attribute__((ext_vector_type(4)));
@@ -396,6 +399,164 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// second generation of the gather-down edge kernel: the MFMA roles are swapped -- rows = output
+// CHANNELS (A = weights, lane-resident), columns = 32 output PIXELS of one image row (B = the
+// gathered input) -- so that an accumulator register holds one channel's value for 32 adjacent
+// pixels across 32 lanes: every accumulator goes to HBM with ONE dword store whose two lane halves
+// are two full 128-byte lines (channels ch and ch + 4).  No transposition slab, no LDS traffic in
+// the epilogue: the wave's LDS arena is the input patch only (3.8 / 6 KB for 2- / 4-row units).
+// U8: the frames are read as stored on disk (uint8, reference data_generator.py:251-263) and
+// converted in flight, value / 255 with an IEEE division = numpy's astype(float32) / 255.
+// ---------------------------------------------------------------------------------------------
+template <int ACT, bool MASK, bool U8, int ROWS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_down_c1s(
+    const void* __restrict__ big_, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope,
+    int units) {
+    constexpr int IH = 2 * ROWS + 3;                     // patch rows
+    constexpr int NLD = U8 ? (IH * 8 + 63) / 64 : (IH * (DC_W / 2) + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float bl[IH * DC_RW];
+    const int lane = threadIdx.x;
+    const int li = lane & 31, kk = lane >> 5;
+    const int upf = g.Hs / ROWS;                         // units per frame
+    const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
+
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)big_, 0, (int)((size_t)g.N * HWb * (U8 ? 1 : 4)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)out, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(MASK ? dact_src : out), 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+
+    // the zero columns left and right of the image never change: written once
+    for (int e = lane; e < IH * 8; e += 64) {
+        const int y = e >> 3, c = e & 7;
+        bl[y * DC_RW + (c < 4 ? c : DC_X0 + 2 * DC_W + c - 4)] = 0.f;
+    }
+
+    // lane-constant part of the patch decode: slot e = lane + 64k -> (row y, 16-byte column)
+    int ld_y[NLD], ld_off[NLD], ld_lds[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = lane + 64 * k;
+        constexpr int PER_ROW = U8 ? 8 : DC_W / 2;       // 16-byte loads per image row
+        const int y = e / PER_ROW, c = e - y * PER_ROW;
+        ld_y[k] = e < IH * PER_ROW ? y : -0x10000;       // fails the row test below
+        ld_off[k] = U8 ? (y * g.Wb + 16 * c) : (y * g.Wb + 4 * c) * 4;
+        ld_lds[k] = y * DC_RW + DC_X0 + (U8 ? 16 : 4) * c;
+    }
+    auto issue = [&](int u, intx4 (&st)[NLD]) {
+        const int n = u / upf;
+        const int hb0 = 2 * ROWS * (u - n * upf) - g.pt;             // image row of patch row 0
+        const int base = (n * g.Hb + hb0) * g.Wb * (U8 ? 1 : 4);
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int hb = hb0 + ld_y[k];
+            const bool ok = hb >= 0 && hb < g.Hb;
+            st[k] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? base + ld_off[k] : ED_OOB, 0, 0);
+        }
+    };
+    auto to_lds = [&](const intx4 (&st)[NLD]) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            if (ld_y[k] < 0) continue;
+            if (U8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned v = (unsigned)st[k][j];
+                    floatx4e f = {(float)(v & 255u) / 255.f, (float)((v >> 8) & 255u) / 255.f,
+                                  (float)((v >> 16) & 255u) / 255.f, (float)(v >> 24) / 255.f};
+                    *reinterpret_cast<floatx4e*>(bl + ld_lds[k] + 4 * j) = f;
+                }
+            } else {
+                *reinterpret_cast<intx4*>(bl + ld_lds[k]) = st[k];
+            }
+        }
+    };
+
+    // A operand: weights of output channel li for taps (2t + kk)
+    float wv_[13];
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+        const int tap = 2 * t + kk;
+        wv_[t] = (tap < 25 && li < g.Cs) ? w[li * 25 + tap] : 0.f;
+    }
+    // accumulator register e of this lane = channel (e&3) + 8*(e>>2) + 4*kk, pixel li
+    float bz[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int ch = (e & 3) + 8 * (e >> 2) + 4 * kk;
+        bz[e] = (bias && ch < g.Cs) ? bias[ch] : 0.f;
+    }
+    const int kkA = kk, kkB = kk * (DC_RW - 4);
+    const int a_col = DC_X0 - g.pl + 2 * li;
+    const int st_lane = (4 * kk * PQ + li) * 4;          // byte offset of this lane's column
+
+    intx4 stage[NLD];
+    int u = blockIdx.x;
+    if (u < units) issue(u, stage);
+#pragma unroll 1
+    for (; u < units; u += gridDim.x) {
+        // LDS operations of one wave execute in order: the previous unit's reads are done
+        to_lds(stage);
+        if (u + (int)gridDim.x < units) issue(u + gridDim.x, stage);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        const int n = u / upf;
+        const int p0 = ROWS * (u - n * upf);
+        const float* aq = bl + a_col;
+#pragma unroll 1
+        for (int pr = 0; pr < ROWS; ++pr) {
+            floatx16 acc[2];
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[qh][e] = bz[e];
+            const float* ar = aq + (2 * pr) * DC_RW;
+            const float* arA = ar + kkA;
+            const float* arB = ar + kkB;
+#pragma unroll
+            for (int t = 0; t < 13; ++t) {
+                // tap 24 + kk = 25 (t = 12, kk = 1) has a zero weight but must still read a FINITE
+                // value: it takes the next column of the last patch row, which is always written
+                const int t0 = ((2 * t) / 5) * DC_RW + (2 * t) % 5;
+                const float* at = ((2 * t) % 5 == 4 && t != 12) ? arB : arA;
+#pragma unroll
+                for (int qh = 0; qh < 2; ++qh)
+                    acc[qh] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[t], at[t0 + 64 * qh],
+                                                                   acc[qh], 0, 0, 0);
+            }
+            // 16 x 2 dword stores: lanes 0-31 one 128-byte line of channel ch, lanes 32-63 of ch+4
+            const int row_off = ((n * g.Cs * g.Hs + (p0 + pr)) * DC_W) * 4;
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+                float d[16];
+                if (MASK) {         // all 16 mask loads of the half row in flight together
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int chb = (e & 3) + 8 * (e >> 2);
+                        const bool ok = chb + 4 * kk < g.Cs;
+                        d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rd, ok ? st_lane : ED_OOB, row_off + (chb * PQ + 32 * qh) * 4, 0));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int chb = (e & 3) + 8 * (e >> 2);           // + 4*kk in st_lane
+                    const int so = row_off + (chb * PQ + 32 * qh) * 4;
+                    const bool ok = chb + 4 * kk < g.Cs;
+                    float v = acc[qh][e];
+                    if (ACT == BN_ACT_LRELU) v = fmaxf(v, v * slope);
+                    if (MASK) v *= d[e] > 0.f ? 1.f : slope;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro,
+                                                          ok ? st_lane : ED_OOB, so, 0);
+                }
+            }
+        }
+    }
+}
+
 BnFastPlan bn_edge_down_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_down_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb != 1) return p;
@@ -403,6 +564,7 @@ BnFastPlan bn_edge_down_plan(const BnGeom& g) {
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if (g.pl < 0 || g.pl > DC_X0 || g.pt < 0) return p;
     if ((size_t)g.N * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
     p.supported = true;
     p.kernel_name = "k_down_c1";
     return p;
@@ -410,9 +572,11 @@ BnFastPlan bn_edge_down_plan(const BnGeom& g) {
 
 // grid = waves; every CU should get the same number of units in the fewest rounds
 static int down_c1_grid(int units) {
-    static int env_grid = -1;                       // tuning hook: BN_E0_GRID=<waves>
+#ifdef BN_TUNING
+    static int env_grid = -1;                       // BN_E0_GRID=<waves>
     if (env_grid < 0) { const char* e = getenv("BN_E0_GRID"); env_grid = e ? atoi(e) : 0; }
     if (env_grid > 0) return env_grid < units ? env_grid : units;
+#endif
     const int n_cu = 256;
     const int per_cu = (units + n_cu - 1) / n_cu;
     const int rounds = (per_cu + DC_MAX_WAVES_PER_CU - 1) / DC_MAX_WAVES_PER_CU;
@@ -421,13 +585,57 @@ static int down_c1_grid(int units) {
     return grid < units ? grid : units;
 }
 
+template <int ACT, bool MASK, bool U8, int ROWS>
+static int launch_down_c1s(const void* big, const float* w, const float* bias, float* out,
+                           const float* dact_src, const BnGeom& g, float slope, hipStream_t st,
+                           hipEvent_t e0, hipEvent_t e1) {
+    const int units = g.N * (g.Hs / ROWS);
+    int grid = 256 * DC_MAX_WAVES_PER_CU;
+    if (grid > units) grid = units;
+    hipExtLaunchKernelGGL((k_down_c1s<ACT, MASK, U8, ROWS>), dim3(grid), dim3(64), 0, st, e0, e1,
+                          0, big, w, bias, out, dact_src, g, slope, units);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// u8 != nullptr: the frames are uint8 (converted in flight, value / 255); else `big` is float.
 int bn_launch_edge_down(const float* big, const float* w, const float* bias, float* out,
                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
-                        hipStream_t st) {
-    const int units = g.N * (g.Hs / DC_ROWS);
-    const dim3 grid(down_c1_grid(units));
+                        hipStream_t st, const unsigned char* u8) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bn_prof_take_dispatch_events(&e0, &e1);   // stay null unless bench.py's hook is armed
+    int variant = DC_VARIANT;
+#ifdef BN_TUNING
+    static int env_v = -1;                    // BN_E0_V=0: first generation, 1: 2-row, 2: 4-row units
+    if (env_v < 0) { const char* e = getenv("BN_E0_V"); env_v = e ? atoi(e) : DC_VARIANT; }
+    variant = env_v;
+#endif
+    if (variant == 2 && (g.Hs % 4) != 0) variant = 1;
+    if (u8) {
+        if (variant == 2)
+            return act == BN_ACT_LRELU
+                ? launch_down_c1s<BN_ACT_LRELU, false, true, 4>(u8, w, bias, out, nullptr, g, slope, st, e0, e1)
+                : launch_down_c1s<BN_ACT_NONE, false, true, 4>(u8, w, bias, out, nullptr, g, slope, st, e0, e1);
+        return act == BN_ACT_LRELU
+            ? launch_down_c1s<BN_ACT_LRELU, false, true, 2>(u8, w, bias, out, nullptr, g, slope, st, e0, e1)
+            : launch_down_c1s<BN_ACT_NONE, false, true, 2>(u8, w, bias, out, nullptr, g, slope, st, e0, e1);
+    }
+    if (variant == 2) {
+        if (act == BN_ACT_LRELU && !dact_src)
+            return launch_down_c1s<BN_ACT_LRELU, false, false, 4>(big, w, bias, out, nullptr, g, slope, st, e0, e1);
+        if (!dact_src)
+            return launch_down_c1s<BN_ACT_NONE, false, false, 4>(big, w, bias, out, nullptr, g, slope, st, e0, e1);
+        return launch_down_c1s<BN_ACT_NONE, true, false, 4>(big, w, bias, out, dact_src, g, slope, st, e0, e1);
+    }
+    if (variant == 1) {
+        if (act == BN_ACT_LRELU && !dact_src)
+            return launch_down_c1s<BN_ACT_LRELU, false, false, 2>(big, w, bias, out, nullptr, g, slope, st, e0, e1);
+        if (!dact_src)
+            return launch_down_c1s<BN_ACT_NONE, false, false, 2>(big, w, bias, out, nullptr, g, slope, st, e0, e1);
+        return launch_down_c1s<BN_ACT_NONE, true, false, 2>(big, w, bias, out, dact_src, g, slope, st, e0, e1);
+    }
+    const int units = g.N * (g.Hs / DC_ROWS);
+    const dim3 grid(down_c1_grid(units));
     if (act == BN_ACT_LRELU && !dact_src) {
         hipExtLaunchKernelGGL((k_down_c1<BN_ACT_LRELU, false>), grid, dim3(64), 0, st, e0, e1, 0,
                               big, w, bias, out, dact_src, g, slope, units);
@@ -576,9 +784,15 @@ __global__ __launch_bounds__(64) void k_up_c1v(
     constexpr int NR = R + 2;                        // strip rows + halo above / below
     const int lane = threadIdx.x;
     const int strips = g.Hs / R;
-    const int row_bytes = g.Ws * 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * g.Hs * g.Ws * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)w, 0, (int)((size_t)g.Cs * g.Cb * 25 * 4), 0x00020000);
+
+    // one channel's operands: the R + 2 input rows (lane = column) and, in lanes 0..24, the 25
+    // weights of that channel (broadcast to SGPRs by v_readlane when the channel is multiplied:
+    // no scalar-memory latency anywhere in the loop)
+    struct Chan { float x[NR]; float wl; };
 
 #pragma unroll 1
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
@@ -591,24 +805,41 @@ __global__ __launch_bounds__(64) void k_up_c1v(
 #pragma unroll
         for (int j = 0; j < 2 * R; ++j) acc[j][0] = acc[j][1] = 0.f;
 
-        // rows p0-1 .. p0+R of channel c (zero outside the image: out-of-range buffer loads)
-        auto load_rows = [&](int c, float (&x)[NR]) {
-            const int base = ((n * g.Cs + c) * g.Hs + p0 - 1) * row_bytes;
+        // Addresses: the lane part (column, 4 * lane, plus the row's compile-time 256 * i in the
+        // instruction's offset field) is per unit, the channel part is ONE scalar offset per
+        // channel.  Rows above / below the image (first / last strip) use an out-of-range lane
+        // offset: they read as zero without touching memory.
+        // (the scalar offset is unsigned: it points at row p0-1, or at row p0 for the first strip,
+        // whose rows then sit one row earlier in the lane offsets)
+        const int sh = p0 > 0 ? 0 : -(UV_W * 4);
+        const int vo_mid = lane * 4 + sh;
+        const int vo_top = p0 > 0 ? lane * 4 : ED_OOB;
+        const int vo_bot = p0 + R < g.Hs ? lane * 4 + sh + (NR - 1) * (UV_W * 4) : ED_OOB;
+        const int vo_w = lane < 25 ? lane * 4 : ED_OOB;
+        const int frame_row0 = (n * g.Cs * g.Hs + (p0 > 0 ? p0 - 1 : 0)) * (UV_W * 4);
+        auto load_chan = [&](int c, Chan& ch) {
+            // channels past the last one (the 3-way unrolled loop overshoots): zero weights, and
+            // the rows of the last channel again (finite whenever the frame is)
+            const int cx = c < g.Cs ? c : g.Cs - 1;
+            const int so = frame_row0 + cx * g.Hs * (UV_W * 4);
+            ch.x[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo_top, so, 0));
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int p = p0 - 1 + i;
-                const bool ok = c < g.Cs && p >= 0 && p < g.Hs;
-                x[i] = ed_ld(rs, ok ? base + i * row_bytes + lane * 4 : ED_OOB);
-            }
+            for (int i = 1; i < NR - 1; ++i)
+                ch.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, vo_mid + i * (UV_W * 4), so, 0));
+            ch.x[NR - 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo_bot, so, 0));
+            ch.wl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rw, c < g.Cs ? vo_w : ED_OOB, (cx * g.Cb + bch) * 100, 0));
         };
-        auto fma_rows = [&](int c, const float (&x)[NR]) {
-            const float* wc = w + ((size_t)(c < g.Cs ? c : 0) * g.Cb + bch) * 25;   // wave-uniform
+        auto fma_chan = [&](const Chan& ch) {
             float wk[25];
 #pragma unroll
-            for (int t = 0; t < 25; ++t) wk[t] = wc[t];
+            for (int t = 0; t < 25; ++t)
+                wk[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
+                    __builtin_bit_cast(int, ch.wl), t));
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                const float xc = x[i];
+                const float xc = ch.x[i];
                 const float xm = uv_shift_from_left(xc);       // small[.., q-1]
                 const float xp = uv_shift_from_right(xc);      // small[.., q+1]
 #pragma unroll
@@ -626,14 +857,21 @@ __global__ __launch_bounds__(64) void k_up_c1v(
             }
         };
 
-        float xa[NR], xb[NR];
-        load_rows(0, xa);
+        // three register sets: channel c is multiplied while c+1 and c+2 are in flight
+        Chan ca, cb, cc;
+        load_chan(0, ca);
+        load_chan(1, cb);
 #pragma unroll 1
-        for (int c = 0; c < g.Cs; c += 2) {
-            load_rows(c + 1, xb);
-            fma_rows(c, xa);
-            load_rows(c + 2, xa);
-            fma_rows(c + 1, xb);
+        for (int c = 0; c < g.Cs; c += 3) {
+            load_chan(c + 2, cc);
+            fma_chan(ca);
+            __builtin_amdgcn_sched_barrier(0);     // keep each channel's 25 readlanes with its FMAs
+            load_chan(c + 3, ca);
+            fma_chan(cb);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chan(c + 4, cb);
+            fma_chan(cc);
+            __builtin_amdgcn_sched_barrier(0);
         }
 
         const float bs = bias ? bias[bch] : 0.f;
@@ -642,8 +880,16 @@ __global__ __launch_bounds__(64) void k_up_c1v(
 #pragma unroll
         for (int j = 0; j < 2 * R; ++j) {
             float2 v;
-            v.x = bn_apply_act(acc[j][0] + bs, act, slope);
-            v.y = bn_apply_act(acc[j][1] + bs, act, slope);
+            v.x = acc[j][0] + bs;
+            v.y = acc[j][1] + bs;
+            if (act == BN_ACT_SIGMOID) {
+                // rcp instead of the IEEE division of bn_apply_act: 1 ulp, a tenth of the code
+                v.x = __builtin_amdgcn_rcpf(1.f + __expf(-v.x));
+                v.y = __builtin_amdgcn_rcpf(1.f + __expf(-v.y));
+            } else {
+                v.x = bn_apply_act(v.x, act, slope);
+                v.y = bn_apply_act(v.y, act, slope);
+            }
             const size_t o = o0 + (size_t)j * g.Wb;
             if (out) *reinterpret_cast<float2*>(out + o) = v;
             if (LOSS) {
@@ -713,6 +959,18 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
         hipLaunchKernelGGL((k_up_c1v<UV_R, true>), dim3(grid), dim3(64), 0, st, small, w, bias, out,
                            target, mask, dpre, partial, g, act, slope, units);
     } else {
+#ifdef BN_TUNING
+        static int r4 = -1;
+        if (r4 < 0) { const char* e = getenv("BN_UP_C1_R4"); r4 = (e && e[0] == '1') ? 1 : 0; }
+        if (r4) {
+            const int units4 = g.N * g.Cb * (g.Hs / 4);
+            hipLaunchKernelGGL((k_up_c1v<4, false>), dim3(units4 < 256 * 24 ? units4 : 256 * 24),
+                               dim3(64), 0, st, small, w, bias, out, nullptr, nullptr, nullptr,
+                               nullptr, g, act, slope, units4);
+            BN_LAUNCH_CHECK();
+            return 0;
+        }
+#endif
         hipLaunchKernelGGL((k_up_c1v<UV_R, false>), dim3(grid), dim3(64), 0, st, small, w, bias, out,
                            nullptr, nullptr, nullptr, nullptr, g, act, slope, units);
     }

@@ -23,7 +23,10 @@ __all__ = ['export_latents', 'encode_trial']
 def encode_trial(model, y, sess=None, labels_2d=None, chunk_size=200):
     """Latents (T x D numpy) of one trial, encoded in 200-frame chunks (ref eval.py:51-97)."""
     mc = model.hparams['model_class']
-    if y.dtype == torch.uint8:
+    if y.dtype == torch.uint8 and (labels_2d is not None or
+                                   model.hparams.get('model_type', 'conv') != 'conv'):
+        # (conv encoders take the stored uint8 frames as they are: value / 255 is fused into the
+        # first layer, csrc k_down_c1s<.., U8>; extra input channels need the float tensor)
         y = _hip.u8_to_unit_float(y.contiguous())
     n = y.shape[0]
     parts = []

@@ -29,10 +29,11 @@ def mse(y_pred, y_true, masks=None):
 def mse_chunks(y_pred, y_true, masks, bounds):
     """``mse`` of every contiguous frame range in ``bounds`` (same divisor convention) as one
     (n_chunks,) device tensor -- for a batch whose forward ran in a single pass."""
-    if isinstance(y_pred, hf.FusedPixelLoss):
+    fused = y_pred if isinstance(y_pred, hf.FusedPixelLoss) else y_true
+    if isinstance(fused, hf.FusedPixelLoss):
         # the decoder evaluated it in the epilogue of its last layer (csrc: k_up_c1v<R, true>)
-        assert y_pred.kind == 'mse' and y_pred.bounds == list(bounds)
-        return y_pred.chunk_terms
+        assert fused.kind == 'mse' and fused.bounds == list(bounds)
+        return fused.chunk_terms
     per_frame = y_pred[0].numel()
     return hf.chunked_sq_err(y_pred, y_true, masks, bounds,
                              [1.0 / ((end - beg) * per_frame) for beg, end in bounds])
@@ -49,12 +50,14 @@ def gaussian_ll(y_pred, y_mean, masks=None, std=1):
 
 def gaussian_ll_chunks(y_pred, y_mean, masks, bounds, std=1):
     """``gaussian_ll`` of every contiguous frame range in ``bounds`` as one (n_chunks,) tensor."""
-    n_dims = int(np.prod(y_mean.shape[1:]))
+    fused = y_pred if isinstance(y_pred, hf.FusedPixelLoss) else y_mean
+    images = y_mean if fused is y_pred else y_pred
+    n_dims = int(np.prod(images.shape[1:]))
     log_var = np.log(std ** 2)
     const = -(0.5 * LN2PI + 0.5 * log_var) * n_dims
-    if isinstance(y_pred, hf.FusedPixelLoss):
-        assert y_pred.kind == 'll' and y_pred.bounds == list(bounds) and std == 1
-        return y_pred.chunk_terms + float(const)
+    if isinstance(fused, hf.FusedPixelLoss):
+        assert fused.kind == 'll' and fused.bounds == list(bounds) and std == 1
+        return fused.chunk_terms + float(const)
     return hf.chunked_sq_err(y_pred, y_mean, masks, bounds,
                              [-(0.5 / (std ** 2)) / (end - beg) for beg, end in bounds]) \
         + float(const)

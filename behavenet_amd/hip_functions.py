@@ -350,6 +350,9 @@ class ConvLayerPlan(object):
 def _fwd(layer, x, w, b):
     g = layer.geom(x.shape[0])
     if layer.kind == 'conv':
+        if x.dtype == torch.uint8:
+            # frames as stored on disk: value / 255 is fused into the first layer's patch load
+            return _hip.conv2d_fwd_u8(x, w, b, g, layer.act, LRELU_SLOPE)
         return _hip.conv2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE)
     return _hip.convT2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE)
 
@@ -428,6 +431,11 @@ def _stack_backward(ctx, dpre, first_param):
         g = layer.geom(n)
         w = weights[i]
         x_in = acts[i]
+        if x_in.dtype == torch.uint8:
+            # uint8 frames went straight into the first layer; its weight gradient multiplies the
+            # float values (the only place a float copy of the batch is made)
+            x_in = _hip.u8_to_unit_float(x_in) \
+                if ctx.needs_input_grad[first_param + 2 * i] else None
         need_w = ctx.needs_input_grad[first_param + 2 * i]
         need_b = ctx.needs_input_grad[first_param + 1 + 2 * i]
         if need_w:

@@ -259,6 +259,20 @@ int bn_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vm
                          float lr, float beta1, float beta2, float eps, float weight_decay,
                          int step, bn_stream_t stream);
 
+/* First encoder layer straight from the stored uint8 frames: y = act(conv(x_u8 / 255) + b).  The
+ * reference converts every batch on the host (data_generator.py:251-263: astype(float32) / 255)
+ * and feeds the float copy to nn.Conv2d (aes.py:81-86,153); here the conversion (an IEEE division,
+ * bit-identical to numpy's) happens while the input patch is staged, so a frame is read as 1 byte
+ * per pixel and no float copy of it is ever written.  Same geometry arguments as bn_conv2d_fwd;
+ * `ws`: bn_conv2d_fwd_u8_ws_bytes() bytes (0 for the benchmark layer; other geometries convert
+ * into it and run the float kernels). */
+size_t bn_conv2d_fwd_u8_ws_bytes(int N, int C, int H, int W, int K, int R, int S, int stride,
+                                 int pad_t, int pad_l, int P, int Q);
+int bn_conv2d_fwd_u8(const unsigned char* x, const float* w, const float* b, float* y,
+                     int N, int C, int H, int W, int K, int R, int S, int stride,
+                     int pad_t, int pad_l, int P, int Q, int act, float slope,
+                     void* ws, size_t ws_bytes, bn_stream_t stream);
+
 /* uint8 frames -> float32/255 (replaces the host-side astype(float32)/255 of
  * data_generator.py:251-263 for device-resident uint8 trials) */
 int bn_u8_to_unit_float(const unsigned char* in, float* out, size_t n, bn_stream_t stream);

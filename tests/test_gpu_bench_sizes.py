@@ -45,10 +45,10 @@ LAYERS = {
 }
 SIZES = [256, 200, 56]
 
-# (layer, role) -> kernel at N = 256: the instantiations of profiles/r01_bench_kernel_stats.csv
+# (layer, role) -> kernel at N = 256: the instantiations of profiles/r02_bench_kernel_stats.csv
 # (the single-pass schedule of bench.py launches every layer once over the whole 256-frame batch)
 KERNELS_256 = {
-    ('E0', 'fwd'): 'k_down_c1<1, false>', ('E0', 'bwd_w'): 'k_wgrad_c1',
+    ('E0', 'fwd'): 'k_down_c1s<1, false, false, 4>', ('E0', 'bwd_w'): 'k_wgrad_c1',
     ('E1', 'fwd'): 'k_down2_mfma<2, 2>', ('E2', 'fwd'): 'k_down2_mfma<2, 2>',
     ('E3', 'fwd'): 'k_down2_mfma<2, 1>',
     ('E1', 'bwd_d'): 'k_up_mfma<1, 4>', ('E2', 'bwd_d'): 'k_up_mfma<1, 4>',
@@ -63,7 +63,7 @@ KERNELS_256 = {
     ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D1', 'bwd_w'): 'k_wgrad4_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4_mfma<4>',
     ('D3', 'bwd_w'): 'k_wgrad4_mfma<5>',
-    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1<0, true>', ('D4', 'bwd_w'): 'k_wgrad_c1',
+    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 4>', ('D4', 'bwd_w'): 'k_wgrad_c1',
 }
 # the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
 # frames, smaller tiles where the grid would not fill the chip
@@ -314,3 +314,22 @@ def test_fused_last_layer_loss_at_bench_sizes(n):
     assert xh is None and name == 'k_up_c1v<8, true>'
     close(part.sum(dim=1), s32, s64, name='frame sums N=%d' % n)
     close(dpre, d32, d64, name='dpre N=%d' % n)
+
+
+@pytest.mark.parametrize('n', [256, 56])
+def test_first_layer_from_uint8_frames_at_bench_sizes(n):
+    """enc.conv0 reading the stored uint8 frames (cfg5: encode-only feeds, 16 KB per frame)."""
+    kind, _, w, b, dy, geom = make_layer('E0', n, seed=6)
+    rng = np.random.default_rng(n)
+    u8 = rng.integers(0, 256, size=(n, 1, 128, 128), dtype=np.uint8)
+    x = torch.from_numpy(u8.astype(np.float32) / 255)
+    sub = frame_subset(n)
+    op = oracle_op('E0')
+    want = F.leaky_relu(op(x[sub], w, b), SLOPE)
+    want64 = F.leaky_relu(op(x[sub].double(), w.double(), b.double()), SLOPE)
+    got, name = dispatched(kind, 'fwd', 1, 32, lambda: _hip.conv2d_fwd_u8(
+        torch.from_numpy(u8).to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE))
+    assert name == 'k_down_c1s<1, false, true, 4>'
+    close(got[sub], want, want64, name='E0 u8 N=%d' % n)
+    assert torch.equal(got, _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom,
+                                            _hip.ACT_LRELU, SLOPE))

@@ -494,6 +494,27 @@ def test_u8_to_unit_float_bit_exact():
     assert np.array_equal(got, allv.astype(np.float32) / 255)
 
 
+@pytest.mark.parametrize('case_name', ['E0', 'E0_2ch', 'k3s1', 'E1'])
+@pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_NONE])
+def test_conv2d_fwd_u8(case_name, act):
+    """First encoder layer from uint8 frames (bn_conv2d_fwd_u8): bit-identical to the float
+    kernel on ``u8.astype(float32) / 255`` (reference data_generator.py:251-263) and within the
+    kernel tolerance of the oracle's operator; E0 = the fused kernel, others = the fallback."""
+    case = [c for c in CONV_CASES if c[0] == case_name][0]
+    _, w, b, geom, pad = _conv_setup(case)
+    N, C, H, W = geom[:4]
+    rng = np.random.default_rng(5)
+    u8 = rng.integers(0, 256, size=(N, C, H, W), dtype=np.uint8)
+    u8[0, 0, 0, :4] = [0, 1, 254, 255]
+    x = torch.from_numpy(u8.astype(np.float32) / 255)
+    want = act_ref(F.conv2d(F.pad(x, pad), w, b, stride=geom[7]), act)
+    want64 = act_ref(F.conv2d(F.pad(x.double(), pad), w.double(), b.double(), stride=geom[7]), act)
+    got = _hip.conv2d_fwd_u8(torch.from_numpy(u8).to(DEV), w.to(DEV), b.to(DEV), geom, act, SLOPE)
+    close(got, want, want64, name=case_name + ' u8')
+    via_float = _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, act, SLOPE)
+    assert torch.equal(got, via_float), 'u8 path differs from the float kernel on u8/255'
+
+
 def test_errors_are_loud():
     x = torch.zeros((1, 1, 8, 8))
     with pytest.raises(_hip.HipLibraryError):
