@@ -192,10 +192,19 @@ class SyntheticSessionsGenerator(object):
 
     # -- pinned uint8 feed with one-trial look-ahead ------------------------------------------
     def _staging(self, shape, slot):
+        """Device staging buffer of one trial shape and slot (kept for the generator's life).
+
+        Allocated under the COPY stream: the caching allocator hands a stream's freed blocks only
+        to later allocations of the same stream, so a block that backed an activation of the
+        previous step on the compute stream (whose kernels may still be running) can never
+        become a staging buffer that the copy stream overwrites out of order.  (It did, once per
+        buffer, when these were allocated on the compute stream: raw frame bytes landed in live
+        activations -- 0.4 % of random byte quadruples are NaN bit patterns.)"""
         key = (tuple(shape), slot)
         buf = self._pf_bufs.get(key)
         if buf is None:
-            buf = torch.empty(shape, dtype=torch.uint8, device=self.device)
+            with torch.cuda.stream(self._pf_stream):
+                buf = torch.empty(shape, dtype=torch.uint8, device=self.device)
             self._pf_bufs[key] = buf
         return buf
 
@@ -215,6 +224,10 @@ class SyntheticSessionsGenerator(object):
             host = self._store[sess][0][trial]
             slot = self._pf_slot
             dev_u8 = self._staging(host.shape, slot)
+            if pf is not None:
+                # the discarded look-ahead copy targets this slot: let it land first, or it could
+                # overwrite the trial copied below
+                main.wait_event(pf[2])
             if self._pf_done[slot] is not None:
                 main.wait_event(self._pf_done[slot])
             dev_u8.copy_(host, non_blocking=True)

@@ -58,12 +58,128 @@ def init_from_env(backend=None):
     return rank(), world_size()
 
 
+# ------------------------------------------------------------------------------------------
+# sharding mode
+# ------------------------------------------------------------------------------------------
+_MODES = ('trial', 'frames')
+_mode = os.environ.get('BN_DP_SHARD', 'trial')
+_emulated = None          # (rank, world): tests run the ranks of a 'frames' step one after another
+
+
+def set_shard_mode(mode):
+    """'trial' (weak scaling: one trial per rank per step) or 'frames' (strong scaling,
+    parity-exact: every rank sees the same trial and takes its slice of every 200-frame chunk);
+    returns the previous mode.  Also read from hparams['dp_shard'] by ``fit``."""
+    global _mode
+    if mode not in _MODES:
+        raise ValueError('dp shard mode must be one of %s, got "%s"' % (_MODES, mode))
+    prev, _mode = _mode, mode
+    return prev
+
+
+def shard_mode():
+    return _mode
+
+
+class emulate_rank(object):
+    """Context manager (tests): behave like rank ``r`` of ``R`` in 'frames' mode WITHOUT a process
+    group.  Collectives are identities, so what a model returns / accumulates inside is that
+    rank's local contribution; the test adds the contributions of all ranks itself.  Terms that
+    need other ranks' data inside the step (batch-norm statistics, the decomposed KL) cannot be
+    emulated this way and raise."""
+
+    def __init__(self, r, R):
+        self.pair = (int(r), int(R))
+
+    def __enter__(self):
+        global _emulated
+        self._prev, _emulated = _emulated, self.pair
+        return self
+
+    def __exit__(self, *exc):
+        global _emulated
+        _emulated = self._prev
+        return False
+
+
+def frames_sharded():
+    """Is the current ``loss()`` call one rank's share of a frame-sharded step?"""
+    if _emulated is not None:
+        return _emulated[1] > 1
+    return _mode == 'frames' and is_active() and world_size() > 1
+
+
+def shard_rank_world():
+    if _emulated is not None:
+        return _emulated
+    return rank(), world_size()
+
+
 def shard_bounds(beg, end, r=None, R=None):
     """Contiguous slice of frames [beg, end) owned by rank r of R ('frames' mode)."""
-    r = rank() if r is None else r
-    R = world_size() if R is None else R
+    if r is None or R is None:
+        r0, R0 = shard_rank_world()
+        r = r0 if r is None else r
+        R = R0 if R is None else R
     n = end - beg
     return beg + (r * n) // R, beg + ((r + 1) * n) // R
+
+
+def shard_chunks(batch_size, chunk_size):
+    """The reference's chunks of a batch (aes.py:748-753) and this rank's slice of each.
+
+    -> (bounds, local, sizes): ``bounds`` the global [beg, end) of every chunk, ``local`` this
+    rank's contiguous [beg, end) inside it (== bounds when not sharded), ``sizes`` the GLOBAL chunk
+    lengths that normalise the chunk's loss terms (the chunk mean is the global one, so that the
+    sum over ranks of the local gradients is the single-device gradient)."""
+    bounds = [(b, min(b + chunk_size, batch_size)) for b in range(0, batch_size, chunk_size)]
+    sizes = [e - b for b, e in bounds]
+    if not frames_sharded():
+        return bounds, list(bounds), sizes
+    return bounds, [shard_bounds(b, e) for b, e in bounds], sizes
+
+
+def _backend():
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+
+
+def all_reduce_(t, op=None):
+    """In-place sum over ranks of a (device or host) tensor; identity without a process group or
+    under ``emulate_rank``.  Under gloo (CPU rendezvous, e.g. two test processes sharing one GPU)
+    device tensors are staged through the host."""
+    if _emulated is not None or not is_active():
+        return t
+    op = dist.ReduceOp.SUM if op is None else op
+    if _backend() == 'gloo' and t.is_cuda:
+        tmp = t.detach().cpu()
+        dist.all_reduce(tmp, op=op)
+        t.copy_(tmp)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
+def all_gather_rows(t):
+    """Concatenation over ranks (rank order) of 2-d tensors that may differ in their row count.
+    -> (gathered, row offset of this rank's block)."""
+    if _emulated is not None:
+        raise RuntimeError('emulate_rank cannot provide the other ranks\' rows (all-gather)')
+    if not is_active() or world_size() == 1:
+        return t, 0
+    W = world_size()
+    staged = _backend() == 'gloo' and t.is_cuda
+    src = t.detach().cpu() if staged else t.detach().contiguous()
+    counts = torch.zeros(W, dtype=torch.int64, device=src.device)
+    counts[rank()] = src.shape[0]
+    dist.all_reduce(counts)
+    counts = [int(c) for c in counts.tolist()]
+    parts = [torch.empty((c,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+             for c in counts]
+    dist.all_gather(parts, src)
+    out = torch.cat(parts, dim=0)
+    if staged:
+        out = out.to(t.device)
+    return out, sum(counts[:rank()])
 
 
 def all_reduce_flat_(flat, average=False):
@@ -73,7 +189,7 @@ def all_reduce_flat_(flat, average=False):
     if flat.is_cuda:
         from behavenet_amd.hip_functions import join_side_streams
         join_side_streams()
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    all_reduce_(flat)
     if average:
         flat.div_(world_size())
     return flat
@@ -203,6 +319,8 @@ def attach_reducer(optimizer):
         return None
     if os.environ.get('BN_OVERLAP_ALLREDUCE', '1') == '0':
         return None
+    if _backend() == 'gloo' and optimizer.flat_g.is_cuda:
+        return None      # host-staged collectives (tests): one flat all-reduce after the backward
     reducer = BucketedGradReducer(optimizer)
     optimizer.reducer = reducer
     if optimizer.flat_g.is_cuda:
@@ -211,18 +329,24 @@ def attach_reducer(optimizer):
     return reducer
 
 
-def reduce_gradients(optimizer):
-    """Sum the gradients over ranks before ``optimizer.step()``."""
+def reduce_gradients(optimizer, average=False):
+    """Sum (or average) the gradients over ranks before ``optimizer.step()``.
+
+    'frames' mode sums: every rank holds its share of ONE trial's gradient.  'trial' mode averages:
+    every rank holds the gradient of its own trial, and the mean keeps the step size and the
+    weight decay (added by the optimizer after this) those of a single-trial step."""
     reducer = getattr(optimizer, 'reducer', None)
     if reducer is not None:
         reducer.finish()
+        if average and is_active():
+            optimizer.flat_g.div_(world_size())
     elif getattr(optimizer, 'flat_g', None) is not None:
-        all_reduce_flat_(optimizer.flat_g)
+        all_reduce_flat_(optimizer.flat_g, average=average)
 
 
 def all_reduce_scalars(values):
     """Sum a short list of python floats over ranks (loss bookkeeping)."""
-    if not is_active():
+    if not is_active() or _emulated is not None:
         return list(values)
     dev = torch.device('cuda', torch.cuda.current_device()) \
         if dist.get_backend() == 'nccl' else torch.device('cpu')
@@ -234,5 +358,10 @@ def all_reduce_scalars(values):
 def broadcast_parameters_(flat, src=0):
     """Make every rank start from rank ``src``'s parameters."""
     if is_active():
-        dist.broadcast(flat, src=src)
+        if _backend() == 'gloo' and flat.is_cuda:
+            tmp = flat.detach().cpu()
+            dist.broadcast(tmp, src=src)
+            flat.copy_(tmp)
+        else:
+            dist.broadcast(flat, src=src)
     return flat

@@ -26,9 +26,11 @@ def mse(y_pred, y_true, masks=None):
     return hf.sq_err(y_pred, y_true, masks, 1.0 / y_pred.numel())
 
 
-def mse_chunks(y_pred, y_true, masks, bounds):
+def mse_chunks(y_pred, y_true, masks, bounds, chunk_sizes=None):
     """``mse`` of every contiguous frame range in ``bounds`` (same divisor convention) as one
-    (n_chunks,) device tensor -- for a batch whose forward ran in a single pass."""
+    (n_chunks,) device tensor -- for a batch whose forward ran in a single pass.
+    ``chunk_sizes``: frame counts to divide by when ``bounds`` hold only this rank's share of
+    each chunk (frame-sharded data parallelism)."""
     fused = y_pred if isinstance(y_pred, hf.FusedPixelLoss) else y_true
     if isinstance(fused, hf.FusedPixelLoss):
         # the decoder evaluated it in the epilogue of its last layer (csrc: k_up_c1v<R, true>)
@@ -36,7 +38,7 @@ def mse_chunks(y_pred, y_true, masks, bounds):
         return fused.chunk_terms
     per_frame = y_pred[0].numel()
     return hf.chunked_sq_err(y_pred, y_true, masks, bounds,
-                             [1.0 / ((end - beg) * per_frame) for beg, end in bounds])
+                             hf.pixel_loss_scales('mse', bounds, per_frame, chunk_sizes))
 
 
 def gaussian_ll(y_pred, y_mean, masks=None, std=1):
@@ -48,19 +50,27 @@ def gaussian_ll(y_pred, y_mean, masks=None, std=1):
     return hf.sq_err(y_pred, y_mean, masks, -(0.5 / (std ** 2)) / n_frames) + float(const)
 
 
-def gaussian_ll_chunks(y_pred, y_mean, masks, bounds, std=1):
-    """``gaussian_ll`` of every contiguous frame range in ``bounds`` as one (n_chunks,) tensor."""
+def gaussian_ll_chunks(y_pred, y_mean, masks, bounds, std=1, chunk_sizes=None, const_share=None):
+    """``gaussian_ll`` of every contiguous frame range in ``bounds`` as one (n_chunks,) tensor.
+    Frame-sharded data parallelism: ``chunk_sizes`` = the global chunk lengths to average over,
+    ``const_share`` = per-chunk fraction of the additive constant this rank accounts for (its
+    share of the chunk's frames), so that the sum over ranks is the single-device value."""
     fused = y_pred if isinstance(y_pred, hf.FusedPixelLoss) else y_mean
     images = y_mean if fused is y_pred else y_pred
     n_dims = int(np.prod(images.shape[1:]))
     log_var = np.log(std ** 2)
     const = -(0.5 * LN2PI + 0.5 * log_var) * n_dims
+    if const_share is None:
+        const_t = float(const)
+    else:
+        const_t = torch.tensor([float(const) * float(f) for f in const_share],
+                               dtype=torch.float32, device=images.device)
     if isinstance(fused, hf.FusedPixelLoss):
         assert fused.kind == 'll' and fused.bounds == list(bounds) and std == 1
-        return fused.chunk_terms + float(const)
+        return fused.chunk_terms + const_t
+    sizes = chunk_sizes if chunk_sizes is not None else [end - beg for beg, end in bounds]
     return hf.chunked_sq_err(y_pred, y_mean, masks, bounds,
-                             [-(0.5 / (std ** 2)) / (end - beg) for beg, end in bounds]) \
-        + float(const)
+                             [-(0.5 / (std ** 2)) / n for n in sizes]) + const_t
 
 
 def gaussian_ll_to_mse(ll, n_dims, gaussian_std=1, mse_std=1):

@@ -592,13 +592,16 @@ class FusedPixelLoss(object):
         self.bounds = list(bounds)
 
 
-def pixel_loss_scales(kind, bounds, per_frame):
+def pixel_loss_scales(kind, bounds, per_frame, chunk_sizes=None):
     """Per-chunk factors of the squared-error sums: 'mse' -> 1 / (frames * pixels) (reference
-    losses.py:56-59: mean over ALL elements), 'll' -> -0.5 / frames (losses.py:84-96, std = 1)."""
+    losses.py:56-59: mean over ALL elements), 'll' -> -0.5 / frames (losses.py:84-96, std = 1).
+    ``chunk_sizes``: the frame counts to normalise by if they are not the lengths of ``bounds``
+    (frame-sharded data parallelism: the GLOBAL chunk lengths)."""
+    sizes = chunk_sizes if chunk_sizes is not None else [end - beg for beg, end in bounds]
     if kind == 'mse':
-        return [1.0 / ((end - beg) * per_frame) for beg, end in bounds]
+        return [1.0 / (n * per_frame) for n in sizes]
     if kind == 'll':
-        return [-0.5 / (end - beg) for beg, end in bounds]
+        return [-0.5 / n for n in sizes]
     raise ValueError('unknown pixel loss kind "%s"' % kind)
 
 

@@ -16,6 +16,7 @@ from torch import nn
 
 import behavenet_amd.fitting.losses as losses
 from behavenet_amd import _hip
+from behavenet_amd.fitting import distributed as bdist
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
     ChunkScalars, ConvLayerPlan, FusedPixelLoss, Readback, activation, backward_chunks,
@@ -402,7 +403,9 @@ class ConvAEDecoder(BaseModule):
         params = self._stack_params(dataset)
         if pixel_loss is not None:
             target, bounds, kind = pixel_loss['target'], pixel_loss['bounds'], pixel_loss['kind']
-            scales = pixel_loss_scales(kind, bounds, target[0].numel())
+            # (chunk_sizes: the GLOBAL chunk lengths when the frames are sharded over ranks)
+            scales = pixel_loss_scales(kind, bounds, target[0].numel(),
+                                       pixel_loss.get('chunk_sizes'))
             if not any(self._unpool_before) and not hp['ae_batch_norm'] and \
                     not hp['ae_decoding_last_FF_layer'] and \
                     os.environ.get('BN_FUSED_LOSS', '1') != '0':
@@ -562,30 +565,60 @@ class AE(BaseModel):
             not self.hparams.get('ae_batch_norm', False) and \
             os.environ.get('BN_WHOLE_BATCH', '1') != '0'
 
+    @staticmethod
+    def _local_frames(local, *tensors):
+        """This rank's frames of a frame-sharded batch: the local slice of every chunk, packed
+        (-> packed tensors, the chunks' [beg, end) in the packed order)."""
+        packed_bounds, pos = [], 0
+        for b, e in local:
+            packed_bounds.append((pos, pos + e - b))
+            pos += e - b
+        out = []
+        for t in tensors:
+            out.append(None if t is None else
+                       torch.cat([t[b:e] for b, e in local], dim=0).contiguous())
+        return out, packed_bounds
+
     def _loss_whole_batch(self, x, m, dataset, accumulate_grad, chunk_size, **fwd_kwargs):
         """ONE forward and ONE backward pass over the whole batch with the reference's per-chunk
         loss normalisation (ref aes.py:748-771): the gradient is the same
         sum_chunks grad(mean_chunk) and the reported loss the same frame-weighted mean, but
         every kernel sees all frames at once (256 frames on 256 CUs) and there is one set of
-        weight-gradient launches and partial sums per step instead of one per chunk."""
+        weight-gradient launches and partial sums per step instead of one per chunk.
+
+        Frame-sharded data parallelism (fitting/distributed.py, 'frames' mode): this rank runs
+        its slice of every chunk, every chunk term is normalised by the GLOBAL chunk length, and
+        the chunk losses are summed over ranks -- so the gradients all-reduced before the
+        optimizer step, and the returned loss, are those of the single-device step."""
         batch_size = x.shape[0]
-        bounds = [(beg, min(beg + chunk_size, batch_size))
-                  for beg in range(0, batch_size, chunk_size)]
+        bounds, local, sizes = bdist.shard_chunks(batch_size, chunk_size)
+        if local != bounds:
+            keys = [k for k in ('labels', 'labels_2d') if fwd_kwargs.get(k) is not None]
+            (x, m, *rest), bounds_l = self._local_frames(local, x, m,
+                                                         *[fwd_kwargs[k] for k in keys])
+            fwd_kwargs = dict(fwd_kwargs, **dict(zip(keys, rest)))
+        else:
+            bounds_l = bounds
         self._reserve_pools(x)
-        with torch.set_grad_enabled(bool(accumulate_grad)):
-            # the pixel loss rides in the epilogue of the last decoder layer
-            x_hat, _ = self.forward(
-                x, dataset=dataset,
-                pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'mse'},
-                **fwd_kwargs)
-            chunk_losses = losses.mse_chunks(x, x_hat, m, bounds)
-        vals = Readback(chunk_losses.detach())
-        if accumulate_grad:
+        if x.shape[0] > 0:
+            with torch.set_grad_enabled(bool(accumulate_grad)):
+                # the pixel loss rides in the epilogue of the last decoder layer
+                x_hat, _ = self.forward(
+                    x, dataset=dataset,
+                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds_l, 'kind': 'mse',
+                                'chunk_sizes': sizes},
+                    **fwd_kwargs)
+                chunk_losses = losses.mse_chunks(x, x_hat, m, bounds_l, sizes)
+            totals = bdist.all_reduce_(chunk_losses.detach().clone())
+        else:       # more ranks than frames: nothing local, but the collectives still line up
+            chunk_losses = None
+            totals = bdist.all_reduce_(torch.zeros(len(bounds), device=x.device))
+        vals = Readback(totals)
+        if accumulate_grad and chunk_losses is not None:
             backward_chunks([chunk_losses], single_pass=True)
         join_side_streams()
         vals = vals.numpy().astype(np.float64)
-        sizes = np.asarray([end - beg for beg, end in bounds], dtype=np.float64)
-        return {'loss': float(np.sum(vals * sizes) / batch_size)}
+        return {'loss': float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)}
 
     def _chunk_streams_ok(self):
         """Chunks may run on two HIP streams unless a layer accumulates outside the weight-

@@ -719,6 +719,46 @@ def test_host_u8_prefetch_feed_is_bit_identical():
         assert torch.equal(x1, x2)
 
 
+def test_host_u8_feed_with_ragged_trials_runs_ahead_safely():
+    """Pinned-uint8 feed with look-ahead copies on a second stream, trials of different lengths,
+    and NO host synchronisation between steps (the host runs ahead of the device as in ``fit``):
+    the staging buffers must never alias memory the compute stream still uses.  (Regression: they
+    were allocated on the compute stream, and the first look-ahead copy into a fresh buffer
+    overwrote live activations of the previous step with raw frame bytes -> NaN gradients.)"""
+    dim = [1, 32, 32]
+    arch = load_handcrafted_arch(list(dim), 4, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    sess = SyntheticSession(10, [5 + (t % 3) for t in range(10)], dim, seed=40,
+                            trial_splits='8;1;1;0')
+    gen = SyntheticSessionsGenerator([sess], device=DEV, placement='host_u8')
+    refs = [torch.from_numpy(u.astype(np.float32) / 255).to(DEV) for u in sess.images_u8]
+    torch.manual_seed(0)
+    model = AE(hp).to(DEV)
+    opt = FlatAdamAMSGrad(model.get_parameters(), lr=1e-4)
+    flags = []
+    for epoch in range(3):
+        torch.manual_seed(epoch)
+        np.random.seed(epoch)
+        gen.reset_iterators('train')
+        for _ in range(gen.n_tot_batches['train']):
+            model.train()
+            opt.zero_grad()
+            data, ds = gen.next_batch('train')
+            x_ok = (data['images'][0] == refs[int(data['batch_idx'][0])]).all()
+            model.loss(data, dataset=ds, accumulate_grad=True)
+            flags.append((x_ok, torch.isfinite(opt.flat_g).all()))
+            if epoch > 0:
+                opt.step()
+        gen.reset_iterators('val')
+        data, ds = gen.next_batch('val')
+        model.loss(data, dataset=ds, accumulate_grad=False)
+    torch.cuda.synchronize()
+    for i, (x_ok, g_ok) in enumerate(flags):
+        assert bool(x_ok), 'step %d: wrong frames served' % i
+        assert bool(g_ok), 'step %d: non-finite gradients' % i
+    assert bool(torch.isfinite(opt.flat_p).all())
+
+
 def test_file_backed_uint8_feed_on_device(tmp_path):
     """ConcatSessionsGenerator over data.npz session files, images uint8 from disk -> pinned host
     -> device one trial ahead -> bn_u8_to_unit_float: bit-identical batches to the resident
