@@ -53,6 +53,11 @@ SIGNATURES = {
     'bn_batchnorm_act_fwd': (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_float, _c_void_p]),
     'bn_batchnorm_act_bwd': (
         _c_int, [_c_void_p] * 9 + [_c_int] * 6 + [_c_float, _c_void_p, _c_size_t, _c_void_p]),
+    'bn_batchnorm_moment': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
+    'bn_batchnorm_bwd_reduce': (
+        _c_int, [_c_void_p] * 7 + [_c_int] * 4 + [_c_float, _c_void_p, _c_size_t, _c_void_p]),
+    'bn_batchnorm_bwd_apply': (
+        _c_int, [_c_void_p] * 9 + [_c_int] * 3 + [_c_float, _c_int, _c_float, _c_void_p]),
     'bn_maxpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
     'bn_maxpool2d_bwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
     'bn_maxunpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
@@ -311,6 +316,70 @@ def batchnorm_bwd(x, y, dy, mean, invstd, gamma, dgamma, dbeta, accumulate, batc
         int(accumulate), int(batch_stats), n, c, hw, act, slope, ws, nb, _stream()),
         'bn_batchnorm_act_bwd')
     return dx
+
+
+def batchnorm_sync_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope,
+                             all_reduce):
+    """Train-mode batch norm whose statistics are taken over the frames of ALL ranks:
+    ``all_reduce(t)`` sums a small device tensor over ranks in place.  -> (y, mean, invstd,
+    global count); x may hold zero frames on this rank."""
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // max(n * c, 1) if n else int(x.shape[2] * x.shape[3])
+    dev = x.device
+    s1 = torch.zeros((c + 1,), dtype=torch.float32, device=dev)     # channel sums + frame count
+    if n:
+        ws, nb = _bn_ws(n, c, dev)
+        _check(load().bn_batchnorm_moment(_ptr(x, 'x'), None, _ptr(s1, 'sums'), n, c, hw, ws, nb,
+                                          _stream()), 'bn_batchnorm_moment')
+        s1[c] = float(n)
+    all_reduce(s1)
+    count = s1[c] * hw
+    mean = (s1[:c] / count).contiguous()
+    s2 = torch.zeros((c,), dtype=torch.float32, device=dev)
+    if n:
+        _check(load().bn_batchnorm_moment(_ptr(x, 'x'), _ptr(mean, 'mean'), _ptr(s2, 'sums'), n, c,
+                                          hw, ws, nb, _stream()), 'bn_batchnorm_moment')
+    all_reduce(s2)
+    var = (s2 / count).contiguous()
+    cnt = float(count.item())
+    unbias = cnt / (cnt - 1.0) if cnt > 1 else 1.0
+    invstd = torch.empty_like(mean)
+    _check(load().bn_batchnorm_finalize(
+        _ptr(mean, 'mean'), _ptr(var, 'var'), _ptr(invstd, 'invstd'),
+        _ptr(running_mean, 'running_mean', allow_none=True),
+        _ptr(running_var, 'running_var', allow_none=True), c, eps, momentum, unbias, _stream()),
+        'bn_batchnorm_finalize')
+    y = torch.empty_like(x)
+    if n:
+        _check(load().bn_batchnorm_act_fwd(
+            _ptr(x, 'x'), _ptr(mean, 'mean'), _ptr(invstd, 'invstd'),
+            _ptr(gamma, 'gamma', allow_none=True), _ptr(beta, 'beta', allow_none=True),
+            _ptr(y, 'y'), n, c, hw, act, slope, _stream()), 'bn_batchnorm_act_fwd')
+    return y, mean, invstd, cnt
+
+
+def batchnorm_sync_bwd(x, y, dy, mean, invstd, gamma, count, act, slope, all_reduce):
+    """-> (dx, this rank's sum_dz, sum_dzx): dx uses the sums of ALL ranks, the parameter
+    gradients (dbeta = sum_dz, dgamma = sum_dzx) stay local -- they are summed with every other
+    gradient by the all-reduce before the optimizer step."""
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // max(n * c, 1) if n else 1
+    local = torch.zeros((2, c), dtype=torch.float32, device=x.device)
+    if n:
+        ws, nb = _bn_ws(n, c, x.device)
+        _check(load().bn_batchnorm_bwd_reduce(
+            _ptr(x, 'x'), _ptr(y, 'y'), _ptr(dy, 'dy'), _ptr(mean, 'mean'),
+            _ptr(invstd, 'invstd'), _ptr(local[0], 'sum_dz'), _ptr(local[1], 'sum_dzx'), n, c, hw,
+            act, slope, ws, nb, _stream()), 'bn_batchnorm_bwd_reduce')
+    total = all_reduce(local.clone())
+    dx = torch.empty_like(x)
+    if n:
+        _check(load().bn_batchnorm_bwd_apply(
+            _ptr(x, 'x'), _ptr(y, 'y'), _ptr(dy, 'dy'), _ptr(mean, 'mean'),
+            _ptr(invstd, 'invstd'), _ptr(gamma, 'gamma', allow_none=True),
+            _ptr(total[0], 'sum_dz'), _ptr(total[1], 'sum_dzx'), _ptr(dx, 'dx'), n, c, hw,
+            1.0 / float(count), act, slope, _stream()), 'bn_batchnorm_bwd_apply')
+    return dx, local[0], local[1]
 
 
 def act_fwd(x, act, slope):

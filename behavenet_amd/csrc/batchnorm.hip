@@ -229,3 +229,50 @@ int bn_launch_bn_act_bwd(const float* x, const float* y, const float* dy, const 
     BN_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Split forms for statistics synchronised over ranks (frame-sharded data parallelism): the
+// caller all-reduces the per-channel SUMS between the passes.
+// ---------------------------------------------------------------------------------------------
+// sums[c] = sum over (n, pixels) of x (center == nullptr) or of (x - center[c])^2; not divided
+int bn_launch_bn_moment(const float* x, const float* center, float* sums, int N, int C, int HW,
+                        void* ws, hipStream_t st) {
+    const int S = bn_splits(N, C);
+    float* part = (float*)ws;
+    if (center)
+        hipLaunchKernelGGL(k_bn_moment_part<2>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, center,
+                           part, N, C, HW, S);
+    else
+        hipLaunchKernelGGL(k_bn_moment_part<1>, dim3(C, S), dim3(BNK_THREADS), 0, st, x,
+                           (const float*)nullptr, part, N, C, HW, S);
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part, sums, C, S, 1.0f);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// sum_dz[c] = sum dy act'(y), sum_dzx[c] = sum dy act'(y) xhat  (this rank's frames)
+int bn_launch_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
+                            const float* invstd, float* sum_dz, float* sum_dzx, int N, int C,
+                            int HW, int act, float slope, void* ws, hipStream_t st) {
+    const int S = bn_splits(N, C);
+    float* part0 = (float*)ws;
+    float* part1 = part0 + (size_t)C * S;
+    hipLaunchKernelGGL(k_bn_bwd_part, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
+                       part0, part1, N, C, HW, S, act, slope);
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, sum_dz, C, S, 1.0f);
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part1, sum_dzx, C, S,
+                       1.0f);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// dx from the (global) sums; inv_count = 1 / (frames * pixels the statistics were taken over)
+int bn_launch_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
+                           const float* invstd, const float* gamma, const float* sum_dz,
+                           const float* sum_dzx, float* dx, int N, int C, int HW, float inv_count,
+                           int act, float slope, hipStream_t st) {
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(N * C), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
+                       gamma, sum_dz, sum_dzx, dx, C, HW, inv_count, act, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}

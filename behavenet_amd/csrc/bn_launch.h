@@ -72,6 +72,16 @@ int bn_launch_bn_act_bwd(const float* x, const float* y, const float* dy, const 
                          float* dbeta, int accumulate, int batch_stats, int N, int C, int HW,
                          int act, float slope, void* ws, hipStream_t st);
 
+int bn_launch_bn_moment(const float* x, const float* center, float* sums, int N, int C, int HW,
+                        void* ws, hipStream_t st);
+int bn_launch_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
+                            const float* invstd, float* sum_dz, float* sum_dzx, int N, int C,
+                            int HW, int act, float slope, void* ws, hipStream_t st);
+int bn_launch_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
+                           const float* invstd, const float* gamma, const float* sum_dz,
+                           const float* sum_dzx, float* dx, int N, int C, int HW, float inv_count,
+                           int act, float slope, hipStream_t st);
+
 // decomposed_kl.hip
 int bn_launch_dkl_fwd(const float* z, const float* mu, const float* lv, float* out3,
                       float* log_qz, float* lse, float* terms, int N, int D, hipStream_t st);

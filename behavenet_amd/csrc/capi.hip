@@ -497,6 +497,36 @@ extern "C" int bn_batchnorm_act_bwd(const float* x, const float* y, const float*
                                 batch_stats, N, C, HW, act, slope, ws, (hipStream_t)stream);
 }
 
+extern "C" int bn_batchnorm_moment(const float* x, const float* center, float* sums, int N, int C,
+                                   int HW, void* ws, size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !sums || N <= 0 || C <= 0 || HW <= 0) return BN_E_BADARG;
+    if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(N, C)) return BN_E_WORKSPACE;
+    return bn_launch_bn_moment(x, center, sums, N, C, HW, ws, (hipStream_t)stream);
+}
+
+extern "C" int bn_batchnorm_bwd_reduce(const float* x, const float* y, const float* dy,
+                                       const float* mean, const float* invstd, float* sum_dz,
+                                       float* sum_dzx, int N, int C, int HW, int act, float slope,
+                                       void* ws, size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !y || !dy || !mean || !invstd || !sum_dz || !sum_dzx || N <= 0 || C <= 0 || HW <= 0)
+        return BN_E_BADARG;
+    if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(N, C)) return BN_E_WORKSPACE;
+    return bn_launch_bn_bwd_reduce(x, y, dy, mean, invstd, sum_dz, sum_dzx, N, C, HW, act, slope, ws,
+                                   (hipStream_t)stream);
+}
+
+extern "C" int bn_batchnorm_bwd_apply(const float* x, const float* y, const float* dy,
+                                      const float* mean, const float* invstd, const float* gamma,
+                                      const float* sum_dz, const float* sum_dzx, float* dx, int N,
+                                      int C, int HW, float inv_count, int act, float slope,
+                                      bn_stream_t stream) {
+    if (!x || !y || !dy || !mean || !invstd || !sum_dz || !sum_dzx || !dx || N <= 0 || C <= 0 ||
+        HW <= 0)
+        return BN_E_BADARG;
+    return bn_launch_bn_bwd_apply(x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx, N, C, HW,
+                                  inv_count, act, slope, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------------------
 // linear
 // ------------------------------------------------------------------------------------------

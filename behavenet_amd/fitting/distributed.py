@@ -355,6 +355,15 @@ def all_reduce_scalars(values):
     return t.cpu().tolist()
 
 
+def broadcast_object(obj, src=0):
+    """A small python object from rank ``src`` to everyone."""
+    if not is_active() or _emulated is not None:
+        return obj
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def broadcast_parameters_(flat, src=0):
     """Make every rank start from rank ``src``'s parameters."""
     if is_active():

@@ -62,7 +62,12 @@ def export_latents(data_generator, model, filename=None):
     latents = [[np.array([]) for _ in range(ds.n_trials)] for ds in data_generator.datasets]
     cond_enc = model.hparams['model_class'] == 'cond-ae' and \
         model.hparams.get('conditional_encoder', False)
-    counter = 0
+    # which rank encodes a trial is a function of the trial's identity (its position in the
+    # sorted list of all (session, trial) pairs), not of the order in which the generator
+    # happens to serve it on this rank
+    wanted = sorted((s_, int(t)) for s_, ds in enumerate(data_generator.datasets)
+                    for dt in ('train', 'val', 'test') for t in ds.batch_idxs[dt])
+    owner = {key: i % world for i, key in enumerate(wanted)}
     for dtype in ['train', 'val', 'test']:
         data_generator.reset_iterators(dtype)
         n_batches = data_generator.n_tot_batches[dtype]
@@ -70,12 +75,10 @@ def export_latents(data_generator, model, filename=None):
             n_batches = sum(ds.n_batches['train'] for ds in data_generator.datasets)
         for _ in range(n_batches):
             data, sess = data_generator.next_batch(dtype, **single)
-            mine = (counter % world) == rank
-            counter += 1
-            if not mine:
-                continue
             idx = data['batch_idx']
             idx = idx.item() if hasattr(idx, 'item') else int(idx)
+            if owner[(sess, idx)] != rank:
+                continue
             labels_2d = data['labels_sc'][0] if cond_enc else None
             latents[sess][idx] = encode_trial(model, data['images'][0], sess, labels_2d)
 
@@ -90,6 +93,10 @@ def export_latents(data_generator, model, filename=None):
                 for i, arr in enumerate(per_sess):
                     if arr.size:
                         latents[s][i] = arr
+        missing = [key for key in wanted if latents[key[0]][key[1]].size == 0]
+        if missing:
+            raise RuntimeError('export_latents: %d trials were encoded by no rank, e.g. %s' % (
+                len(missing), missing[:3]))
 
     filenames = []
     for sess, dataset in enumerate(data_generator.datasets):

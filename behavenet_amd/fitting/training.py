@@ -6,8 +6,16 @@ the same metric rows, early stopping and checkpoint files.  Differences, all bel
 reference's Python surface:
 
 * the optimizer is :class:`behavenet_amd.fitting.optim.FlatAdamAMSGrad` (one HIP launch);
-* with ``torch.distributed`` initialised, gradients are all-reduced over RCCL before each step;
-* ``model.loss`` synchronises with the host once per call instead of once per chunk.
+* ``model.loss`` synchronises with the host once per call instead of once per chunk;
+* with ``torch.distributed`` initialised the fit is data parallel (fitting/distributed.py),
+  ``hparams['dp_shard']``:
+    'frames' -- every rank sees the same trial and runs its slice of every 200-frame chunk; the
+                summed gradients, the metric rows and the fitted weights are the single-device
+                ones (up to fp32 summation order);
+    'trial'  -- (default) the training trials of an epoch are dealt round-robin to the ranks, W
+                at a time: one optimizer step per W trials on the AVERAGE of their gradients
+                (not step-for-step the reference, which steps once per trial); validation and
+                test trials are evaluated by every rank.
 """
 
 import copy
@@ -111,6 +119,32 @@ def _snapshot(model, hparams):
     return snap
 
 
+def _save_checkpoint(model, path, is_main):
+    """``model.save`` on the main rank.  Classes whose ``save`` also finalises derived state
+    (AEMSP builds its orthogonal matrix U there, ref aes.py:1062-1065) do that on EVERY rank, so
+    that the snapshots the other ranks keep (and export latents through) carry it too."""
+    if is_main:
+        model.save(path)
+    elif hasattr(model, 'create_orthogonal_matrix'):
+        model.create_orthogonal_matrix()
+
+
+def _merge_rank_metrics(logger, dtype):
+    """'trial' mode: every rank logged the trials it trained on; give every rank the totals."""
+    import torch.distributed as dist
+    mine = [logger.metrics[dtype]] + [per[dtype] for per in logger.metrics_by_dataset]
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    for slot, target in enumerate(mine):
+        keys = []
+        for other in everyone:
+            for k in other[slot]:
+                if k not in keys:
+                    keys.append(k)
+        for k in keys:
+            target[k] = sum(other[slot].get(k, 0) for other in everyone)
+
+
 def _progress(iterable, enabled):
     if not enabled:
         return iterable
@@ -133,6 +167,11 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
             model.get_parameters(), lr=hparams['learning_rate'],
             weight_decay=hparams.get('l2_reg', 0))
     flat_g = getattr(optimizer, 'flat_g', None)
+    if hparams.get('dp_shard') is not None:
+        bdist.set_shard_mode(hparams['dp_shard'])
+    world = bdist.world_size() if bdist.is_active() else 1
+    rank = bdist.rank()
+    trial_mode = world > 1 and bdist.shard_mode() == 'trial'
     if bdist.is_active() and getattr(optimizer, 'flat_p', None) is not None:
         bdist.broadcast_parameters_(optimizer.flat_p)
         bdist.attach_reducer(optimizer)
@@ -143,7 +182,9 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
         early_stop = EarlyStopping(
             patience=hparams['early_stop_history'], min_epochs=hparams['min_n_epochs'])
 
-    n_train = data_generator.n_tot_batches['train']
+    n_trials_train = data_generator.n_tot_batches['train']
+    # optimizer steps per epoch: in 'trial' mode W trials are consumed per step
+    n_train = -(-n_trials_train // world) if trial_mode else n_trials_train
     max_epochs = hparams['max_n_epochs']
     interval = hparams['val_check_interval']
     val_check_batch = np.append(
@@ -157,6 +198,8 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
 
     if hparams.get('rng_seed_train', None) is None:
         rng_train = np.random.randint(0, 10000)
+        if world > 1:       # every rank must walk the same trial order: rank 0's draw
+            rng_train = int(bdist.broadcast_object(rng_train))
     else:
         rng_train = int(hparams['rng_seed_train'])
     torch.manual_seed(rng_train)
@@ -180,16 +223,34 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
         for i_train in _progress(range(n_train), show_bar):
             model.train()
             optimizer.zero_grad()
-            data, dataset = data_generator.next_batch('train')
+            if trial_mode:
+                # every rank draws the same W trials (same seeds, same generator state) and
+                # keeps the one at its own position: disjoint trials, nothing communicated
+                group = [data_generator.next_batch('train')
+                         for _ in range(min(world, n_trials_train - i_train * world))]
+                data, dataset = group[rank] if rank < len(group) else (None, None)
+                stepping = any(d is not None for d, _ in group)
+                n_in_step = sum(d is not None for d, _ in group)
+            else:
+                data, dataset = data_generator.next_batch('train')
+                stepping = data is not None
+                n_in_step = 1
             if data is not None:
                 loss_dict = model.loss(data, dataset=dataset, accumulate_grad=True)
                 logger.update_metrics('train', loss_dict, dataset=dataset)
-                if i_epoch > 0:
-                    if flat_g is not None:
+            if stepping and i_epoch > 0:
+                if flat_g is not None:
+                    if trial_mode:
+                        # mean over the trials of this step (a rank without one adds zeros)
                         bdist.reduce_gradients(optimizer)
-                    optimizer.step()
+                        optimizer.flat_g.div_(float(n_in_step))
+                    else:
+                        bdist.reduce_gradients(optimizer)
+                optimizer.step()
 
             if (i_train + 1) % n_train == 0:
+                if trial_mode:
+                    _merge_rank_metrics(logger, 'train')
                 exp.log(logger.create_metric_row(
                     'train', i_epoch, i_train, -1, trial=-1,
                     by_dataset=False, best_epoch=best_val_epoch))
@@ -213,8 +274,7 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
 
                 if logger.get_loss('val') < best_val_loss:
                     best_val_loss = logger.get_loss('val')
-                    if is_main:
-                        model.save(os.path.join(expt_dir, 'best_val_model.pt'))
+                    _save_checkpoint(model, os.path.join(expt_dir, 'best_val_model.pt'), is_main)
                     best_model_saved = True
                     best_val_model = _snapshot(model, hparams)
                     best_val_epoch = i_epoch
@@ -236,12 +296,11 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
                 break
 
     if not best_model_saved:
-        if is_main:
-            model.save(os.path.join(expt_dir, 'best_val_model.pt'))
+        _save_checkpoint(model, os.path.join(expt_dir, 'best_val_model.pt'), is_main)
         best_val_model = _snapshot(model, hparams)
 
-    if hparams.get('save_last_model', False) and is_main:
-        model.save(os.path.join(expt_dir, 'last_model.pt'))
+    if hparams.get('save_last_model', False):
+        _save_checkpoint(model, os.path.join(expt_dir, 'last_model.pt'), is_main)
 
     # test loss, one row per test trial.  NB the reference evaluates `model`, not
     # `best_val_model`, here (training.py:433,442) -- kept.

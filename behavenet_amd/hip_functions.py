@@ -630,9 +630,22 @@ class BatchNormActFn(torch.autograd.Function):
                     factor = float(module.momentum)
             else:
                 rm = rv = None
-            y, mean, invstd = _hip.batchnorm_train_fwd(
-                x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE)
+            from behavenet_amd.fitting import distributed as bdist
+            ctx.sync_count = None
+            if bdist.frames_sharded():
+                # the chunk's frames are spread over the ranks: statistics over all of them
+                # (per-channel sums all-reduced), as the single device sees them
+                if bdist._emulated is not None:
+                    raise RuntimeError('batch-norm statistics need the other ranks\' frames: '
+                                       'not available under emulate_rank')
+                y, mean, invstd, ctx.sync_count = _hip.batchnorm_sync_train_fwd(
+                    x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE,
+                    bdist.all_reduce_)
+            else:
+                y, mean, invstd = _hip.batchnorm_train_fwd(
+                    x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE)
         else:
+            ctx.sync_count = None
             mean = rm
             y, invstd = _hip.batchnorm_eval_fwd(x, g, b, rm, rv, float(module.eps), act,
                                                 LRELU_SLOPE)
@@ -653,6 +666,19 @@ class BatchNormActFn(torch.autograd.Function):
         gb = _grad_buffer(beta) if need_b else None
         direct = (need_g or need_b) and (gg is not None or not need_g) and \
             (gb is not None or not need_b)
+        if getattr(ctx, 'sync_count', None) is not None:
+            from behavenet_amd.fitting import distributed as bdist
+            dx, sum_dz, sum_dzx = _hip.batchnorm_sync_bwd(
+                x, y, dy.contiguous(), mean, invstd, g, ctx.sync_count, ctx.act, LRELU_SLOPE,
+                bdist.all_reduce_)
+            if direct:
+                if need_g:
+                    gg.add_(sum_dzx)
+                if need_b:
+                    gb.add_(sum_dz)
+                return (dx if ctx.needs_input_grad[0] else None), None, None, None, None
+            return (dx if ctx.needs_input_grad[0] else None), \
+                (sum_dzx if need_g else None), (sum_dz if need_b else None), None, None
         if direct:
             dgamma, dbeta = gg, gb
         else:

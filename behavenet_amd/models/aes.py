@@ -40,6 +40,15 @@ def _unsupported_on_hip(what):
         '%s is not implemented by the MI355X kernels yet (SURVEY.md section 8(f), rank 3)' % what)
 
 
+def _no_sharded_chunk_loop(model):
+    """The chunk-by-chunk schedules (batch-norm variants) of the classes other than the plain AE
+    are not frame-sharded: refuse instead of silently using per-rank statistics."""
+    if bdist.frames_sharded():
+        raise NotImplementedError(
+            'frame-sharded data parallelism of %s with ae_batch_norm=1 is not implemented '
+            '(use dp_shard="trial", or the plain AE)' % type(model).__name__)
+
+
 def _bn_modules(container, layer_names):
     """nn.BatchNorm2d following each (transposed) convolution of the stack, or None."""
     out = []
@@ -658,26 +667,39 @@ class AE(BaseModel):
         if self._whole_batch_ok(x):
             return self._loss_whole_batch(x, m, dataset, accumulate_grad, chunk_size)
 
+        # chunk loop (batch-norm models: the statistics are per chunk).  Frame-sharded data
+        # parallelism: this rank runs its slice of every chunk, the batch-norm layers take their
+        # statistics over all ranks' frames (hip_functions.BatchNormActFn), the chunk loss is this
+        # rank's part of the global chunk mean.
+        bounds, local, csizes = bdist.shard_chunks(batch_size, chunk_size)
+        sharded = local != bounds
         vals, sizes, deferred = ChunkScalars(), [], []
         self._reserve_pools(x)
-        self._prepare_first_layer(x, dataset)
+        if not sharded:
+            self._prepare_first_layer(x, dataset)
         begin_chunks(x.device)
-        for chunk in range(n_chunks):
-            beg = chunk * chunk_size
-            end = min((chunk + 1) * chunk_size, batch_size)
+        for chunk, ((beg, end), n_c) in enumerate(zip(local, csizes)):
+            if end == beg:
+                raise NotImplementedError(
+                    'a chunk of %d frames cannot be sharded over %d ranks' % (
+                        n_c, bdist.shard_rank_world()[1]))
             x_in = x[beg:end]
             m_in = m[beg:end] if m is not None else None
-            with chunk_stream(chunk, x.device, self._chunk_streams_ok()):
+            with chunk_stream(chunk, x.device, self._chunk_streams_ok() and not sharded):
                 with torch.set_grad_enabled(bool(accumulate_grad)):
                     x_hat, _ = self.forward(x_in, dataset=dataset)
                     loss = losses.mse(x_in, x_hat, m_in)
+                    if sharded:
+                        loss = loss * ((end - beg) / float(n_c))
                 vals.add(loss.detach().reshape(1))
             if accumulate_grad:
                 deferred.append(loss)
-            sizes.append(end - beg)
+            sizes.append(n_c)
         # the loss values only need the forwards: their read-back is enqueued before the
         # (deferred) backwards and waited for after every backward launch is queued
         vals = vals.finish(deferred)[:, 0]
+        if sharded:
+            vals = np.asarray(bdist.all_reduce_scalars(vals.tolist()))
         self._release_first_layer()
         loss_val = float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)
         return {'loss': loss_val}
@@ -717,6 +739,7 @@ class ConditionalAE(AE):
             # labels ride along frame by frame: same single-pass schedule as AE.loss
             return self._loss_whole_batch(x, m, dataset, accumulate_grad, chunk_size,
                                           labels=y, labels_2d=labels_2d)
+        _no_sharded_chunk_loop(self)
         vals, sizes, deferred = ChunkScalars(), [], []
         self._reserve_pools(x)
         self._prepare_first_layer(x, dataset)
@@ -797,6 +820,9 @@ class AEMSP(AE):
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
         alpha = self.hparams['msp.alpha']
+        if bdist.frames_sharded():
+            raise NotImplementedError('frame-sharded data parallelism of AEMSP is not '
+                                      'implemented (use dp_shard="trial")')
         self._reserve_pools(x)
         if self._whole_batch_ok(x):
             # single pass (see AE._loss_whole_batch): every map here is frame-wise, the two MSP
@@ -827,6 +853,7 @@ class AEMSP(AE):
             r2 = _r2_variance_weighted(y_rb.numpy(), y_hat_rb.numpy())
             return {'loss': float(tot[0]), 'loss_mse': float(tot[1]), 'loss_msp': float(tot[2]),
                     'labels_r2': r2}
+        _no_sharded_chunk_loop(self)
         self._prepare_first_layer(x, dataset)
         rbs, sizes, deferred, y_hat_all = ChunkScalars(), [], [], []
         for chunk in range(n_chunks):

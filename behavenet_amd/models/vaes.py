@@ -18,8 +18,9 @@ from torch import nn
 
 import behavenet_amd.fitting.losses as losses
 from behavenet_amd import hip_functions as hf
+from behavenet_amd.fitting import distributed as bdist
 from behavenet_amd.hip_functions import linear
-from behavenet_amd.models.aes import AE, ConvAEDecoder, ConvAEEncoder
+from behavenet_amd.models.aes import AE, ConvAEDecoder, ConvAEEncoder, _no_sharded_chunk_loop
 from behavenet_amd.models.base import DiagLinear
 
 __all__ = [
@@ -47,15 +48,87 @@ def reparameterize(mu, logvar, eps=None):
     return hf.reparameterize_with_eps(mu, logvar, eps)
 
 
-def _sample(mu, logvar, use_mean, bounds):
+def _sample(mu, logvar, use_mean, bounds, shards=None):
     """Latents for a whole batch: the mean, or one ``reparameterize`` draw per chunk (the
-    reference samples chunk by chunk; keeping that keeps the RNG / eps-provider sequence)."""
+    reference samples chunk by chunk; keeping that keeps the RNG / eps-provider sequence).
+
+    ``shards`` (frame-sharded data parallelism): ``mu`` holds only this rank's rows of every
+    chunk; eps is still drawn for the WHOLE chunk (every rank consumes the same random stream)
+    and this rank's rows are cut out of it, so the ranks together use the single-device eps."""
     if use_mean:
         return mu
+    if shards is not None and shards.sharded:
+        parts = []
+        for (b, e), (lb, le), (pb, pe) in zip(shards.bounds, shards.local, shards.bounds_l):
+            like = torch.empty((e - b, logvar.shape[1]), dtype=logvar.dtype, device=logvar.device)
+            eps = _eps_provider(like) if _eps_provider is not None else torch.randn_like(like)
+            if pe > pb:
+                parts.append(hf.reparameterize_with_eps(
+                    mu[pb:pe].contiguous(), logvar[pb:pe].contiguous(),
+                    eps[lb - b:le - b].contiguous()))
+        return torch.cat(parts, dim=0) if parts else mu
     if bounds is None:
         return reparameterize(mu, logvar)
     return torch.cat([reparameterize(mu[b:e].contiguous(), logvar[b:e].contiguous())
                       for b, e in bounds], dim=0)
+
+
+class _FrameShards(object):
+    """The chunks of one batch and this rank's part of them (fitting/distributed.py, 'frames'
+    mode).  ``bounds``: global [beg, end) of every chunk; ``local``: this rank's slice of it;
+    ``bounds_l``: where those slices sit once packed back to back (what the model is run on);
+    ``sizes``: global chunk lengths (every chunk term is a mean over the GLOBAL chunk);
+    ``share``: this rank's fraction of each chunk (weights terms that every rank evaluates)."""
+
+    def __init__(self, batch_size, chunk_size):
+        self.bounds, self.local, self.sizes = bdist.shard_chunks(batch_size, chunk_size)
+        self.sharded = self.local != self.bounds
+        self.bounds_l, pos = [], 0
+        for b, e in self.local:
+            self.bounds_l.append((pos, pos + e - b))
+            pos += e - b
+        self.n_local = pos
+        self.share = [(le - lb) / float(n) for (lb, le), n in zip(self.local, self.sizes)]
+
+    def take(self, *tensors):
+        """This rank's rows of batch-leading tensors, packed (None stays None)."""
+        if not self.sharded:
+            return list(tensors)
+        return [None if t is None else
+                torch.cat([t[b:e] for b, e in self.local], dim=0).contiguous() for t in tensors]
+
+    def share_t(self, device):
+        return torch.tensor(self.share, dtype=torch.float32, device=device)
+
+    def all_rows(self, t):
+        """The rows of every rank (metrics over the whole batch); identity when not sharded."""
+        return bdist.all_gather_rows(t.contiguous())[0] if self.sharded else t
+
+    def row_terms(self, fn, *tensors):
+        """(n_chunks,) tensor of ``fn(rows of chunk c)`` (a mean over those rows) weighted by
+        this rank's share, i.e. its part of the global chunk mean; 0 for an empty slice."""
+        out = []
+        for (pb, pe), w in zip(self.bounds_l, self.share):
+            if pe > pb:
+                out.append(fn(*[t[pb:pe].contiguous() for t in tensors]) * float(w))
+            else:
+                out.append(torch.zeros((), dtype=torch.float32, device=tensors[0].device))
+        return torch.stack(out)
+
+    def gathered(self, c, *tensors):
+        """Chunk ``c``'s rows of every rank (rank order = frame order), with THIS rank's rows
+        still attached to the graph: batch-coupled terms (the decomposed KL) are evaluated on
+        the whole chunk by every rank and back-propagated through the local rows only -- the
+        ranks' gradients then add up to the single-device gradient."""
+        pb, pe = self.bounds_l[c]
+        if not self.sharded:
+            return [t[pb:pe] for t in tensors]
+        out = []
+        for t in tensors:
+            mine = t[pb:pe]
+            full, off = bdist.all_gather_rows(mine)
+            out.append(torch.cat([full[:off], mine, full[off + mine.shape[0]:]], dim=0))
+        return out
 
 
 def _bounds(batch_size, chunk_size):
@@ -63,8 +136,10 @@ def _bounds(batch_size, chunk_size):
 
 
 def _finish_whole(table, total, accumulate_grad):
-    """Read back the (n_chunks, n_keys) scalar table, run the single backward, join streams."""
-    rb = hf.Readback(table.detach())
+    """Read back the (n_chunks, n_keys) scalar table (summed over ranks when the frames are
+    sharded: every entry is this rank's part of a global chunk mean), run the single backward,
+    join streams."""
+    rb = hf.Readback(bdist.all_reduce_(table.detach().clone()))
     if accumulate_grad:
         hf.backward_chunks([total], single_pass=True)
     hf.join_side_streams()
@@ -121,7 +196,7 @@ class VAE(AE):
     def forward(self, x, dataset=None, use_mean=False, **kwargs):
         """-> (x_hat, z, mu, logvar)."""
         mu, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
-        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
+        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'), kwargs.get('sample_shards'))
         x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset,
                               pixel_loss=kwargs.get('pixel_loss'))
         return x_hat, z, mu, logvar
@@ -139,21 +214,26 @@ class VAE(AE):
         if whole:
             # one pass over the whole batch, latents sampled and losses normalised per chunk
             # (see AE._loss_whole_batch)
-            bounds = _bounds(batch_size, chunk_size)
+            sh = _FrameShards(batch_size, chunk_size)
+            bounds = sh.bounds_l
+            kw = fwd_kwargs_fn(0, batch_size)
+            xl, ml, *kw_l = sh.take(x, m, *kw.values())
+            kw = dict(zip(kw.keys(), kw_l))
             with torch.set_grad_enabled(bool(accumulate_grad)):
                 x_hat, _, mu, logvar = self.forward(
-                    x, dataset=dataset, use_mean=False, sample_bounds=bounds,
-                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'll'},
-                    **fwd_kwargs_fn(0, batch_size))
-                ll = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
-                klv = torch.stack([losses.kl_div_to_std_normal(
-                    mu[b:e].contiguous(), logvar[b:e].contiguous()) for b, e in bounds])
+                    xl, dataset=dataset, use_mean=False, sample_bounds=bounds, sample_shards=sh,
+                    pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
+                                'chunk_sizes': sh.sizes}, **kw)
+                ll = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
+                                               const_share=sh.share if sh.sharded else None)
+                klv = sh.row_terms(losses.kl_div_to_std_normal, mu, logvar)
                 lossv = -ll + float(beta) * klv
             vals = _finish_whole(torch.stack([lossv, ll, klv], dim=1), lossv,
                                  accumulate_grad)
-            sizes = [e - b for b, e in bounds]
+            sizes = sh.sizes
             n_chunks = 0
         else:
+            _no_sharded_chunk_loop(self)
             self._prepare_first_layer(x, dataset)
             hf.begin_chunks(x.device)
         for chunk in range(n_chunks):
@@ -208,7 +288,7 @@ class ConditionalVAE(VAE):
         if self.hparams['conditional_encoder']:
             x = torch.cat((x, labels_2d), dim=1)
         mu, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
-        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
+        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'), kwargs.get('sample_shards'))
         z_aug = torch.cat((z, labels), dim=1)
         x_hat = self.decoding(z_aug, pool_idx, outsize, dataset=dataset,
                               pixel_loss=kwargs.get('pixel_loss'))
@@ -248,20 +328,32 @@ class BetaTCVAE(VAE):
         self._reserve_pools(x)
         whole = self._whole_batch_ok(x)
         if whole:
-            bounds = _bounds(batch_size, chunk_size)
+            sh = _FrameShards(batch_size, chunk_size)
+            bounds = sh.bounds_l
+            xl, ml = sh.take(x, m)
             with torch.set_grad_enabled(bool(accumulate_grad)):
                 x_hat, sample, mu, logvar = self.forward(
-                    x, dataset=dataset, use_mean=False, sample_bounds=bounds,
-                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'll'})
-                ll = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
+                    xl, dataset=dataset, use_mean=False, sample_bounds=bounds, sample_shards=sh,
+                    pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
+                                'chunk_sizes': sh.sizes})
+                ll = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
+                                               const_share=sh.share if sh.sharded else None)
+                # the decomposed KL couples all samples of a chunk: every rank evaluates it on
+                # the gathered chunk (gradients flow through its own rows only)
                 dk = torch.stack([torch.stack(losses.decomposed_kl(
-                    sample[b:e], mu[b:e], logvar[b:e])) for b, e in bounds])   # (n_chunks, 3)
-                lossv = -ll + float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
-            vals = _finish_whole(torch.cat([lossv[:, None], ll[:, None], dk], dim=1),
-                                 lossv, accumulate_grad)
-            sizes = [e - b for b, e in bounds]
+                    *sh.gathered(c, sample, mu, logvar))) for c in range(len(bounds))])
+                kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
+                lossv = -ll + kl_terms
+                # what is REPORTED is summed over ranks: the shared terms enter with this rank's
+                # share of the chunk
+                w = sh.share_t(x.device)
+                table = torch.cat([(-ll + w * kl_terms)[:, None], ll[:, None], dk * w[:, None]],
+                                  dim=1)
+            vals = _finish_whole(table, lossv, accumulate_grad)
+            sizes = sh.sizes
             n_chunks = 0
         else:
+            _no_sharded_chunk_loop(self)
             self._prepare_first_layer(x, dataset)
             hf.begin_chunks(x.device)
         for chunk in range(n_chunks):
@@ -370,7 +462,7 @@ class PSVAE(AE):
         """-> (x_hat, z, mu, logvar, y_hat)."""
         y, w, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
         mu = torch.cat([y, w], dim=1)
-        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'))
+        z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'), kwargs.get('sample_shards'))
         x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset,
                               pixel_loss=kwargs.get('pixel_loss'))
         y_hat = self.encoding.D(y)
@@ -397,30 +489,40 @@ class PSVAE(AE):
         if whole:
             # one pass over the whole batch; latents sampled, and every term normalised, per
             # chunk (see AE._loss_whole_batch)
-            bounds = _bounds(batch_size, chunk_size)
+            sh = _FrameShards(batch_size, chunk_size)
+            bounds = sh.bounds_l
+            xl, yl, ml, nl = sh.take(x, y, m, n)
+            share = sh.share if sh.sharded else None
             with torch.set_grad_enabled(bool(accumulate_grad)):
                 x_hat, sample, mu, logvar, y_hat = self.forward(
-                    x, dataset=dataset, use_mean=False, sample_bounds=bounds,
-                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'll'})
-                ll_x = losses.gaussian_ll_chunks(x, x_hat, m, bounds)
-                ll_y = losses.gaussian_ll_chunks(y, y_hat, n, bounds)
-                zs = torch.stack([losses.kl_div_to_std_normal(
-                    mu[b:e, :n_labels].contiguous(), logvar[b:e, :n_labels].contiguous())
-                    for b, e in bounds])
-                dk = torch.stack([torch.stack(losses.decomposed_kl(
-                    sample[b:e, n_labels:], mu[b:e, n_labels:], logvar[b:e, n_labels:]))
-                    for b, e in bounds])                                   # (n_chunks, 3)
-                lossv = -ll_x - float(alpha) * ll_y + zs + float(kl) * dk[:, 0] \
-                    + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
-            y_hat_rb = hf.Readback(y_hat)
-            y_rb = hf.Readback(y)
-            n_rb = hf.Readback(n) if n is not None else None
-            vals = _finish_whole(
-                torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk, lossv[:, None]], dim=1),
-                lossv, accumulate_grad)
-            sizes = [e - b for b, e in bounds]
+                    xl, dataset=dataset, use_mean=False, sample_bounds=bounds, sample_shards=sh,
+                    pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
+                                'chunk_sizes': sh.sizes})
+                ll_x = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
+                                                 const_share=share)
+                ll_y = losses.gaussian_ll_chunks(yl, y_hat, nl, bounds, chunk_sizes=sh.sizes,
+                                                 const_share=share)
+                zs = sh.row_terms(losses.kl_div_to_std_normal, mu[:, :n_labels],
+                                  logvar[:, :n_labels])
+                # batch-coupled: evaluated on the gathered chunk by every rank (see BetaTCVAE)
+                dk = torch.stack([torch.stack(losses.decomposed_kl(*sh.gathered(
+                    c, sample[:, n_labels:], mu[:, n_labels:], logvar[:, n_labels:])))
+                    for c in range(len(bounds))])                           # (n_chunks, 3)
+                kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
+                lossv = -ll_x - float(alpha) * ll_y + zs + kl_terms
+                w = sh.share_t(x.device)
+                table = torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk * w[:, None],
+                                   (-ll_x - float(alpha) * ll_y + zs + w * kl_terms)[:, None]],
+                                  dim=1)
+            # label r^2 over the whole batch: the ranks' rows are gathered (a few KB)
+            y_hat_rb = hf.Readback(sh.all_rows(y_hat.detach()))
+            y_rb = hf.Readback(sh.all_rows(yl))
+            n_rb = hf.Readback(sh.all_rows(nl)) if n is not None else None
+            vals = _finish_whole(table, lossv, accumulate_grad)
+            sizes = sh.sizes
             n_chunks = 0
         else:
+            _no_sharded_chunk_loop(self)
             self._prepare_first_layer(x, dataset)
         for chunk in range(n_chunks):
             beg = chunk * chunk_size
@@ -597,6 +699,9 @@ class MSPSVAE(PSVAE):
         """Modified ELBO + triplet term (ref vaes.py:916-1098).  ``datas``: list of data dicts
         (training; ``dataset`` = list of their session ids) or one dict (validation / test; no
         triplet term, the key is reported as 0 like the reference)."""
+        if bdist.frames_sharded():
+            raise NotImplementedError('frame-sharded data parallelism of MSPSVAE is not '
+                                      'implemented (use dp_shard="trial")')
         multi = isinstance(datas, list)
         if multi:
             x = torch.cat([d['images'][0] for d in datas], dim=0)

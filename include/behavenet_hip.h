@@ -165,6 +165,25 @@ int bn_batchnorm_act_bwd(const float* x, const float* y, const float* dy, const 
                          float* dbeta, int accumulate, int batch_stats, int N, int C, int HW,
                          int act, float slope, void* ws, size_t ws_bytes, bn_stream_t stream);
 
+/* Split forms of the two reductions above for statistics taken over ALL ranks' frames (frame-sharded
+ * data parallelism; the reference's single-device nn.BatchNorm2d sees the whole chunk, aes.py:90-97):
+ * the caller all-reduces the per-channel SUMS between the passes.
+ *   bn_batchnorm_moment:     sums[c] = sum x            (center == NULL)
+ *                            sums[c] = sum (x-center[c])^2   -- NOT divided by the count
+ *   bn_batchnorm_bwd_reduce: sum_dz[c] = sum dy act'(y),  sum_dzx[c] = sum dy act'(y) xhat
+ *   bn_batchnorm_bwd_apply:  dx = gamma invstd (dz - sum_dz inv_count - xhat sum_dzx inv_count)
+ * ws: bn_batchnorm_ws_bytes(N, C). */
+int bn_batchnorm_moment(const float* x, const float* center, float* sums, int N, int C, int HW,
+                        void* ws, size_t ws_bytes, bn_stream_t stream);
+int bn_batchnorm_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
+                            const float* invstd, float* sum_dz, float* sum_dzx, int N, int C,
+                            int HW, int act, float slope, void* ws, size_t ws_bytes,
+                            bn_stream_t stream);
+int bn_batchnorm_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
+                           const float* invstd, const float* gamma, const float* sum_dz,
+                           const float* sum_dzx, float* dx, int N, int C, int HW, float inv_count,
+                           int act, float slope, bn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense latent projections (replaces nn.Linear, aes.py:121,125,266 and the PS-VAE heads
  * vaes.py:1288-1302).  MFMA (v_mfma_f32_32x32x2_f32: exact fp32).

@@ -1,0 +1,236 @@
+"""world_size-2 gloo checks of ``fit`` / ``export_latents`` under data parallelism (CPU: the
+oracle model stands in for the HIP model, a torch Adam over a flat arena for the HIP optimizer).
+
+* 'trial' mode: the training trials of an epoch are dealt to the ranks W at a time, every trial is
+  used by exactly one rank, one step per W trials on the averaged gradient (weight decay added
+  once), identical parameters and metric rows on all ranks -- equal to a single process that
+  averages the same groups itself.
+* ``export_latents``: trials are owned by identity, gathered on rank 0, none missing."""
+
+import copy
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSessionsGenerator
+from behavenet_amd.fitting import distributed as bdist
+from behavenet_amd.fitting.eval import export_latents
+from behavenet_amd.fitting.training import fit
+from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+from oracle import ref_cpu
+from tests.golden_utils import base_hparams
+from tests.test_distributed_cpu import _free_port
+
+DIM = [1, 32, 32]
+
+
+class _CpuFlatAdam(object):
+    """FlatAdamAMSGrad's interface (params, offsets, flat_p, flat_g, zero_grad, step) on the CPU."""
+
+    def __init__(self, params, lr, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += p.numel()
+        self.flat_p = torch.zeros(total)
+        self.flat_g = torch.zeros(total)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.flat_p[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+        self._leaf = torch.nn.Parameter(self.flat_p)
+        self._leaf.data = self.flat_p
+        self.opt = torch.optim.Adam([self._leaf], lr=lr, weight_decay=weight_decay, amsgrad=True)
+
+    def zero_grad(self):
+        if getattr(self, 'reducer', None) is not None:
+            self.reducer.begin()          # (as FlatAdamAMSGrad.zero_grad does)
+        self.flat_g.zero_()
+
+    def step(self):
+        self._leaf.grad = self.flat_g
+        self.opt.step()
+
+
+class _Tap(object):
+    """Generator wrapper recording which trials reach ``model.loss``."""
+
+    def __init__(self, model):
+        self.model, self.seen = model, []
+        self._loss = model.loss
+
+        def loss(data, dataset=0, accumulate_grad=True, **kw):
+            if accumulate_grad:
+                self.seen.append((dataset, int(data['batch_idx'][0])))
+            return self._loss(data, dataset=dataset, accumulate_grad=accumulate_grad, **kw)
+        model.loss = loss
+
+
+class _Exp(object):
+    version = 0
+
+    def __init__(self):
+        self.rows = []
+
+    def log(self, row):
+        self.rows.append(dict(row))
+
+    def save(self):
+        pass
+
+
+def _setup(tmp, l2=1e-3):
+    arch = load_handcrafted_arch(list(DIM), 4, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    hp.update({'expt_dir': tmp, 'max_n_epochs': 2, 'min_n_epochs': 0, 'val_check_interval': 1,
+               'enable_early_stop': False, 'early_stop_history': 10, 'rng_seed_train': 3,
+               'export_latents': False, 'progress_bar': False, 'device': 'cpu', 'l2_reg': l2,
+               'learning_rate': 1e-3})
+    os.makedirs(os.path.join(tmp, 'version_0'), exist_ok=True)
+    # 10 trials -> 8 train (odd group at the end of an epoch with W = 3; even with W = 2)
+    sess = SyntheticSession(10, 6, DIM, seed=11, trial_splits='8;1;1;0')
+    gen = SyntheticSessionsGenerator([sess], device='cpu', placement='host')
+    torch.manual_seed(0)
+    model = ref_cpu.AE(hp)
+    model.version = 0
+    model.save = lambda path: torch.save(model.state_dict(), path)     # (BaseModel.save)
+    return hp, gen, model
+
+
+def _fit_worker(rank, world, port, tmp, out):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world)})
+    torch.set_num_threads(2)
+    bdist.init_from_env(backend='gloo')
+    hp, gen, model = _setup(os.path.join(tmp, 'r%d' % rank))
+    hp['dp_shard'] = 'trial'
+    tap = _Tap(model)
+    opt = _CpuFlatAdam(model.get_parameters(), hp['learning_rate'], hp['l2_reg'])
+    exp = _Exp()
+    fit(hp, model, gen, exp, method='ae', optimizer=opt)
+    out.put((rank, tap.seen, opt.flat_p.clone().numpy(),
+             [r for r in exp.rows if 'tr_loss' in r]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_trial_mode_two_ranks(tmp_path):
+    world = 2
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, str(tmp_path), out))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, seen0, p0, rows0), (_, seen1, p1, rows1) = res
+    # 3 epochs (0, 1, 2) x 8 training trials: every trial of an epoch on exactly one rank
+    assert len(seen0) == len(seen1) == 12
+    for ep in range(3):
+        a, b = seen0[4 * ep:4 * ep + 4], seen1[4 * ep:4 * ep + 4]
+        assert not set(a) & set(b)
+        assert len(set(a) | set(b)) == 8
+    np.testing.assert_array_equal(p0, p1)
+    assert rows0 == rows1 and len(rows0) == 3
+
+    # single process doing the same by hand: groups of W trials, averaged gradient, one step
+    hp, gen, model = _setup(os.path.join(str(tmp_path), 'ref'))
+    opt = _CpuFlatAdam(model.get_parameters(), hp['learning_rate'], hp['l2_reg'])
+    tr_rows = []
+    for epoch in range(3):
+        torch.manual_seed(3 + epoch)
+        np.random.seed(3 + epoch)
+        gen.reset_iterators('train')
+        tot = 0.0
+        for _ in range(4):
+            opt.zero_grad()
+            for _ in range(world):
+                data, ds = gen.next_batch('train')
+                tot += model.loss(data, dataset=ds, accumulate_grad=True)['loss']
+            if epoch > 0:
+                opt.flat_g.div_(world)
+                opt.step()
+        tr_rows.append(tot / 8)
+    np.testing.assert_allclose(p0, opt.flat_p.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose([r['tr_loss'] for r in rows0], tr_rows, rtol=1e-6)
+
+
+class _StubModel(torch.nn.Module):
+    """What export_latents touches: hparams, version, eval(), encoding(x, dataset=)."""
+
+    def __init__(self, expt_dir):
+        super().__init__()
+        self.hparams = {'model_class': 'ae', 'model_type': 'conv', 'expt_dir': expt_dir}
+        self.version = 0
+        self.proj = torch.nn.Linear(int(np.prod(DIM)), 3)
+        with torch.no_grad():
+            self.proj.weight.copy_(torch.linspace(-1, 1, self.proj.weight.numel()).view_as(
+                self.proj.weight))
+            self.proj.bias.zero_()
+
+    def encoding(self, x, dataset=None):
+        return self.proj(x.reshape(x.shape[0], -1)) + float(dataset or 0), None, None
+
+
+def _two_sessions():
+    sessions = [SyntheticSession(10, [4 + (t % 3) for t in range(10)], DIM, seed=20 + i,
+                                 trial_splits='8;1;1;0', name=('lab', 'expt', 'animal', 's%d' % i))
+                for i in range(2)]
+    return SyntheticSessionsGenerator(sessions, device='cpu', placement='host')
+
+
+def _export_worker(rank, world, port, tmp, out):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world)})
+    torch.set_num_threads(1)
+    bdist.init_from_env(backend='gloo')
+    gen = _two_sessions()
+    # the ranks' generators are deliberately in DIFFERENT random states
+    torch.manual_seed(100 + rank)
+    np.random.seed(100 + rank)
+    os.makedirs(os.path.join(tmp, 'version_0'), exist_ok=True)
+    files = export_latents(gen, _StubModel(tmp))
+    out.put((rank, files))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_export_latents_gathers_every_trial_from_two_ranks(tmp_path):
+    tmp = str(tmp_path)
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_export_worker, args=(r, 2, port, tmp, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] == [] and len(res[0]) == 2
+    # single-process export of the same sessions
+    ref_dir = os.path.join(tmp, 'ref')
+    os.makedirs(os.path.join(ref_dir, 'version_0'))
+    want_files = export_latents(_two_sessions(), _StubModel(ref_dir))
+    for got_f, want_f in zip(res[0], want_files):
+        with open(got_f, 'rb') as f:
+            got = pickle.load(f)
+        with open(want_f, 'rb') as f:
+            want = pickle.load(f)
+        assert set(got['trials']) == {'train', 'val', 'test'}
+        assert len(got['latents']) == len(want['latents']) == 10
+        for a, b in zip(got['latents'], want['latents']):
+            np.testing.assert_allclose(a, b, rtol=0, atol=0)
+        assert all(lat.shape[1] == 3 for lat in got['latents'])
