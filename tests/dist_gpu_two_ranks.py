@@ -1,0 +1,135 @@
+"""One rank of a 2-process data-parallel run on ONE GPU (gloo rendezvous, collectives staged
+through the host): launched twice by tests/test_gpu_sharding.py with RANK=0/1.  Also imported by
+that test for the single-process reference of the same cases."""
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSessionsGenerator  # noqa: E402
+from behavenet_amd.fitting import distributed as bdist  # noqa: E402
+from behavenet_amd.fitting.optim import FlatAdamAMSGrad  # noqa: E402
+from behavenet_amd.fitting.training import fit  # noqa: E402
+from behavenet_amd.models import AE, BetaTCVAE, PSVAE  # noqa: E402
+from behavenet_amd.models import vaes as hip_vaes  # noqa: E402
+from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch  # noqa: E402
+from tests.golden_utils import base_hparams, make_frames, make_labels  # noqa: E402
+
+DEV = 'cuda'
+DIM = [1, 32, 32]
+
+
+class _Eps(object):
+    """Deterministic eps per call index (the same on every rank and in the reference run)."""
+
+    def __init__(self):
+        self.i = 0
+
+    def __call__(self, like):
+        g = torch.Generator().manual_seed(1000 + self.i)
+        self.i += 1
+        return torch.randn(like.shape, generator=g).to(like.device)
+
+
+def build_case(case):
+    """-> (model on the GPU, data dict, loss kwargs): batch 44 in chunks of 30 + 14."""
+    arch = load_handcrafted_arch(list(DIM), 8, None, check_memory=False)
+    x = torch.from_numpy(make_frames(44, DIM, seed=8)).to(DEV)
+    data = {'images': x[None]}
+    kw = {'chunk_size': 30}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    if case == 'ae_bn':
+        model = AE(base_hparams(arch, 'ae', {'ae_batch_norm': True}))
+    elif case == 'psvae':
+        hp = base_hparams(arch, 'ps-vae', {'ps_vae.alpha': 10.0, 'ps_vae.beta': 3.0,
+                                           'ps_vae.anneal_epochs': 0, 'max_n_epochs': 10})
+        hp['n_labels'] = 2
+        model = PSVAE(hp)
+        data['labels'] = torch.from_numpy(make_labels(44, 2, seed=2)).to(DEV)[None]
+        hip_vaes.set_eps_provider(_Eps())
+    elif case == 'betatc':
+        hp = base_hparams(arch, 'beta-tcvae', {'vae.beta': 1.0, 'vae.beta_anneal_epochs': 0,
+                                               'beta_tcvae.beta': 4.0,
+                                               'beta_tcvae.beta_anneal_epochs': 0,
+                                               'max_n_epochs': 10})
+        model = BetaTCVAE(hp)
+        hip_vaes.set_eps_provider(_Eps())
+    else:
+        raise ValueError(case)
+    model = model.to(DEV)
+    model.train()
+    return model, data, kw
+
+
+def flat_grad(model):
+    return torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad])
+
+
+def run_fit(tmp):
+    """fit() of the conv AE on 10 trials x 32 frames, 2 epochs (frames mode when distributed)."""
+    arch = load_handcrafted_arch(list(DIM), 8, None, check_memory=False)
+    hp = base_hparams(arch, 'ae', None)
+    hp.update({'expt_dir': tmp, 'max_n_epochs': 2, 'min_n_epochs': 0, 'val_check_interval': 1,
+               'enable_early_stop': False, 'early_stop_history': 10, 'rng_seed_train': 0,
+               'export_latents': False, 'progress_bar': False, 'device': 'cuda'})
+    os.makedirs(os.path.join(tmp, 'version_0'), exist_ok=True)
+    sess = SyntheticSession(10, 32, DIM, seed=0, trial_splits='8;1;1;0')
+    gen = SyntheticSessionsGenerator([sess], device=DEV, placement='device_u8')
+    torch.manual_seed(0)
+    model = AE(hp).to(DEV)
+    model.version = 0
+
+    class Exp(object):
+        version = 0
+        rows = []
+
+        def log(self, row):
+            self.rows.append(dict(row))
+
+        def save(self):
+            pass
+    exp = Exp()
+    fit(hp, model, gen, exp, method='ae')
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    idx = torch.linspace(0, flat.numel() - 1, 4096).long()
+    rows = [{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in r.items()}
+            for r in exp.rows]
+    return {'rows': rows, 'param_sample': flat[idx.to(flat.device)].cpu().tolist()}
+
+
+def main():
+    case, tmp = sys.argv[1], sys.argv[2]
+    torch.cuda.set_device(0)
+    rank, world = bdist.init_from_env(backend='gloo')
+    assert world == 2 and bdist.shard_mode() == 'frames' and bdist.frames_sharded()
+    if case == 'fit':
+        out = run_fit(os.path.join(tmp, 'rank%d' % rank))
+    else:
+        model, data, kw = build_case(case)
+        opt = FlatAdamAMSGrad(model.get_parameters(), lr=1e-4)
+        opt.zero_grad()
+        loss = model.loss(data, dataset=0, accumulate_grad=True, **kw)
+        bdist.reduce_gradients(opt)
+        g = flat_grad(model).cpu().double().numpy()
+        idx = np.linspace(0, g.size - 1, 8192).astype(np.int64)
+        out = {'loss': loss, 'grad_norm': float(np.linalg.norm(g)), 'grad_index': idx.tolist(),
+               'grad_sample': g[idx].tolist(),
+               'buffers': {k: v.float().reshape(-1)[:64].cpu().tolist()
+                           for k, v in model.named_buffers() if 'running_' in k}}
+    if rank == 0:
+        with open(os.path.join(tmp, case + '_rank0.json'), 'w') as f:
+            json.dump(out, f)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
