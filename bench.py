@@ -107,6 +107,94 @@ def cpu_baseline(hp_template, budget_s=20.0):
                                                                 torch.__version__)}
 
 
+def _timed(fn, warm, steps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary_configs(hp_ae, feed_rates=True):
+    """The other BASELINE configs that fit one GPU, a few steps each, all driver-run:
+    configs[3] (PS-VAE training), configs[4] (encode-only from resident uint8 trials, the
+    per-GPU share of the 1M-frame job) and the PCIe-inclusive training rate of the headline
+    workload (pinned uint8 trials prefetched per batch).  Same synthetic data recipe, same
+    timing brackets (synchronize on both sides) as the headline."""
+    from behavenet_amd.models import PSVAE
+    from tests.golden_utils import base_hparams, make_frames, make_labels
+    out = []
+    # --- configs[3]: PS-VAE, 2x128x128, 16 latents, 4 labels, batch 256
+    dim4 = [2, 128, 128]
+    arch = load_handcrafted_arch(list(dim4), 16, None, check_memory=False)
+    hp = base_hparams(arch, 'ps-vae', {'ps_vae.alpha': 1000, 'ps_vae.beta': 5,
+                                       'ps_vae.anneal_epochs': 100, 'max_n_epochs': 200})
+    hp['n_labels'] = 4
+    hp['device'] = 'cuda'
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = PSVAE(hp).to('cuda')
+    m.curr_epoch = 3
+    opt = FlatAdamAMSGrad(m.get_parameters(), lr=1e-4)
+    data = {'images': torch.from_numpy(make_frames(BATCH, dim4, seed=1)).cuda()[None],
+            'labels': torch.from_numpy(make_labels(BATCH, 4, seed=2)).cuda()[None]}
+
+    def step4():
+        m.train()
+        opt.zero_grad()
+        m.loss(data, dataset=0, accumulate_grad=True)
+        opt.step()
+    t4 = _timed(step4, 30, 20)
+    flop4 = 3 * 0.7079e9        # SURVEY 8(d): fwd 0.7079 GFLOP/frame, training = 3x
+    out.append({'config': 'configs[3]: PS-VAE training, 2x128x128, 16 latents, 4 labels, batch 256 '
+                          '(all 11 loss keys, decomposed KL, Adam(amsgrad))',
+                'value': round(BATCH / t4, 1), 'unit': 'frames/s', 'ms_per_step': round(t4 * 1e3, 3),
+                'steps': 20, 'roofline': {
+                    'bound': 'mfma', 'achieved': round(flop4 * BATCH / t4 / 1e12, 2),
+                    'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(flop4 * BATCH / t4 / 1e12 / FP32_PEAK_TFLOPS, 4),
+                    'note': 'whole step, algorithmic 2.124 GFLOP/frame'}})
+    del m, opt, data
+    # --- configs[4], one GPU's share: encode resident uint8 trials -> latents (no float copy)
+    torch.manual_seed(0)
+    ae = AE(dict(hp_ae)).to('cuda')
+    ae.eval()
+    xu = torch.randint(0, 255, (BATCH, 1, 128, 128), dtype=torch.uint8, device='cuda')
+
+    def enc():
+        with torch.no_grad():
+            ae.encoding(xu, dataset=0)
+    t5 = _timed(enc, 20, 50)
+    out.append({'config': 'configs[4] per GPU: encode-only, 1x128x128 uint8 trials of 256 frames '
+                          '(resident in HBM) -> 12 latents; uint8 -> float fused into enc.conv0',
+                'value': round(BATCH / t5, 1), 'unit': 'frames/s', 'ms_per_trial': round(t5 * 1e3, 3),
+                'steps': 50, 'seconds_per_1M_frames': round(1e6 / (BATCH / t5), 2),
+                'roofline': {'bound': 'mfma', 'achieved': round(0.3474e9 * BATCH / t5 / 1e12, 2),
+                             'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                             'frac': round(0.3474e9 * BATCH / t5 / 1e12 / FP32_PEAK_TFLOPS, 4),
+                             'note': 'encoder forward, algorithmic 0.3474 GFLOP/frame'}})
+    del ae
+    if feed_rates:
+        # --- the headline step fed over PCIe: pinned uint8 trials, one-trial look-ahead
+        torch.manual_seed(0)
+        model = AE(dict(hp_ae)).to('cuda')
+        opt = FlatAdamAMSGrad(model.get_parameters(), lr=hp_ae['learning_rate'])
+        sess = SyntheticSession(20, BATCH, DIM, seed=100, trial_splits='8;1;1;0')
+        gen = SyntheticSessionsGenerator([sess], device='cuda', placement='host_u8')
+        torch.manual_seed(1)
+        np.random.seed(1)
+        gen.reset_iterators('train')
+        tp = _timed(lambda: one_step(model, opt, gen), 20, 20)
+        out.append({'config': 'configs[1] fed over PCIe: same training step, trials in pinned host '
+                              'memory as uint8 (4.2 MB each), copied one trial ahead on a copy stream',
+                    'value': round(BATCH / tp, 1), 'unit': 'frames/s',
+                    'ms_per_step': round(tp * 1e3, 3), 'steps': 20})
+    return out
+
+
 def profile_kernel(model, opt, gen, family, C, K, steps=2):
     """HIP-event time per launch of one kernel family/geometry over a few extra steps."""
     _hip.prof_select(family, C, K)
@@ -124,6 +212,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the secondary configs (PS-VAE, encode-only, PCIe-fed)')
     ap.add_argument('--feed', default='device', choices=['device', 'device_u8', 'host_u8', 'host'],
                     help="where the trials live (default 'device': resident float32, the headline "
                          "metric; 'host_u8' = pinned uint8 + prefetch, the PCIe-inclusive rate)")
@@ -269,6 +359,10 @@ def main():
                               'unit': 'TFLOP/s', 'frac': round(tf / FP32_PEAK_TFLOPS, 4),
                               'avg_launch_us': round(ms * 1e3 / n, 1)})
         out['roofline_other_kernels'] = extra
+        if not args.no_secondary:
+            del model, opt, gen
+            torch.cuda.empty_cache()
+            out['secondary'] = secondary_configs(hp)
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(hp, args.cpu_budget)
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
