@@ -134,12 +134,31 @@ class SyntheticSessionsGenerator(object):
         return self.n_datasets
 
     def reset_iterators(self, dtype):
+        """All trials of ``dtype`` available again, in a fresh random order per session.
+
+        Consumes the random streams exactly as the reference does (pinned by
+        tests/golden/generator.json): its ``reset_iterators`` builds ``iter(DataLoader(...,
+        sampler=SubsetRandomSampler(batch_idxs)))`` per session, which draws ONE int64 from
+        torch's global generator on creation (the loader's base seed), while the permutation
+        itself (``torch.randperm``) is only drawn when the first trial of that session is asked
+        for (data_generator.py:585-599 + torch.utils.data)."""
         kinds = self._dtypes if dtype == 'all' else [dtype]
         for i, ds in enumerate(self.datasets):
             for k in kinds:
-                idxs = ds.batch_idxs[k]
-                order = torch.randperm(len(idxs)).tolist()
-                self._queues[i][k] = [int(idxs[j]) for j in order]
+                torch.empty((), dtype=torch.int64).random_()
+                self._queues[i][k] = None          # permutation pending
+
+    def _queue(self, sess, dtype):
+        q = self._queues[sess][dtype]
+        if q is None:
+            idxs = self.datasets[sess].batch_idxs[dtype]
+            q = [int(idxs[j]) for j in torch.randperm(len(idxs)).tolist()]
+            self._queues[sess][dtype] = q
+        return q
+
+    def _n_left(self, sess, dtype):
+        q = self._queues[sess][dtype]
+        return len(self.datasets[sess].batch_idxs[dtype]) if q is None else len(q)
 
     def next_batch(self, dtype, return_multiple=True):
         """One trial, or -- for training with ``n_sessions_per_batch`` > 1 -- a list of trials
@@ -157,18 +176,18 @@ class SyntheticSessionsGenerator(object):
                     ratios[sess] = 0
                     if np.sum(ratios) > 0:
                         ratios = ratios / np.sum(ratios)
-                    if self._queues[sess][dtype]:
-                        trial = self._queues[sess][dtype].pop(0)
+                    if self._n_left(sess, dtype):
+                        trial = self._queue(sess, dtype).pop(0)
                         break
                 samples.append(self._sample(sess, trial, dtype))
                 sessions.append(sess)
             return samples, sessions
-        if all(len(q[dtype]) == 0 for q in self._queues):
+        if all(self._n_left(i, dtype) == 0 for i in range(self.n_datasets)):
             return None, None
         while True:
             sess = int(np.random.choice(np.arange(self.n_datasets), p=self.batch_ratios))
-            if self._queues[sess][dtype]:
-                trial = self._queues[sess][dtype].pop(0)
+            if self._n_left(sess, dtype):
+                trial = self._queue(sess, dtype).pop(0)
                 break
         return self._sample(sess, trial, dtype), sess
 
@@ -237,7 +256,7 @@ class SyntheticSessionsGenerator(object):
         self._pf_done[slot] = done
         self._pf_slot = slot ^ 1
         # look ahead: the head of this session's queue is (very likely) the next trial
-        queue = self._queues[sess][dtype]
+        queue = self._queues[sess][dtype]      # (None: the session's order is not drawn yet)
         if queue:
             nxt = queue[0]
             host = self._store[sess][0][nxt]
@@ -349,6 +368,8 @@ class SingleSessionDatasetBatchedLoad(object):
             arr = self.read(signal, idx).astype('float32')
             if signal == 'images':
                 arr = arr / 255
+            if signal == 'masks':
+                arr = arr[0]         # the reference's indexing (see ConcatSessionsGenerator)
             if self.transforms[signal]:
                 arr = self.transforms[signal](arr)
             sample[signal] = arr if self.as_numpy else torch.from_numpy(arr).float()
@@ -438,6 +459,11 @@ class ConcatSessionsGenerator(SyntheticSessionsGenerator):
 
             def conv(a):
                 a = a.astype(np.float32)
+                if signal == 'masks':
+                    # as the reference serves them (data_generator.py:264-277,337-340: the array
+                    # is not wrapped in a list before ``sample[signal][0]``): the mask of the
+                    # trial's FIRST frame, (C, H, W); the losses broadcast it over the frames
+                    a = a[0]
                 if tr:
                     a = tr(a)
                 return torch.from_numpy(np.ascontiguousarray(a)).float().to(device)

@@ -49,6 +49,20 @@ def _no_sharded_chunk_loop(model):
             '(use dp_shard="trial", or the plain AE)' % type(model).__name__)
 
 
+def frame_masks(data, x):
+    """``data['masks'][0]`` as an (N, C, H, W) tensor or None.  The reference's generator serves
+    ONE (C, H, W) mask per trial (its first frame's) that the losses broadcast over the frames
+    (losses.py:56-59 with data_generator.py:264-277); per-frame masks pass through."""
+    if 'masks' not in data:
+        return None
+    m = data['masks'][0]
+    if m.dim() == x.dim() - 1:
+        m = m.unsqueeze(0)
+    if m.shape[0] == 1 and x.shape[0] != 1:
+        m = m.expand_as(x)
+    return m.contiguous()
+
+
 def _bn_modules(container, layer_names):
     """nn.BatchNorm2d following each (transposed) convolution of the stack, or None."""
     out = []
@@ -661,7 +675,7 @@ class AE(BaseModel):
         call: one host synchronisation per ``loss()`` instead of one per chunk.
         """
         x = data['images'][0]
-        m = data['masks'][0] if 'masks' in data else None
+        m = frame_masks(data, x)
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
         if self._whole_batch_ok(x):
@@ -730,7 +744,7 @@ class ConditionalAE(AE):
     def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
         x = data['images'][0]
         y = data['labels'][0]
-        m = data['masks'][0] if 'masks' in data else None
+        m = frame_masks(data, x)
         labels_2d = data['labels_sc'][0] if self.hparams.get('conditional_encoder', False) \
             else None
         batch_size = x.shape[0]
@@ -816,7 +830,7 @@ class AEMSP(AE):
         from behavenet_amd.models.vaes import _r2_variance_weighted
         x = data['images'][0]
         y = data['labels'][0]
-        m = data['masks'][0] if 'masks' in data else None
+        m = frame_masks(data, x)
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
         alpha = self.hparams['msp.alpha']

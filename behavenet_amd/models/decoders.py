@@ -11,6 +11,7 @@ import torch
 from behavenet_amd.fitting import losses
 from behavenet_amd.hip_functions import (
     Readback, backward_chunks, join_side_streams, reserve_device_pools, ChunkScalars)
+from behavenet_amd.models.aes import frame_masks
 from behavenet_amd.models.aes import ConvAEDecoder, LinearAEDecoder
 from behavenet_amd.models.base import BaseModel
 
@@ -65,7 +66,7 @@ class ConvDecoder(BaseModel):
         """Pixel MSE with the reference's per-chunk normalisation (ref decoders.py:433-496)."""
         x = data['images'][0]
         y = data['labels'][0]
-        m = data['masks'][0] if 'masks' in data else None
+        m = frame_masks(data, data['images'][0])
         batch_size = x.shape[0]
         bounds = [(beg, min(beg + chunk_size, batch_size))
                   for beg in range(0, batch_size, chunk_size)]

@@ -20,7 +20,8 @@ import behavenet_amd.fitting.losses as losses
 from behavenet_amd import hip_functions as hf
 from behavenet_amd.fitting import distributed as bdist
 from behavenet_amd.hip_functions import linear
-from behavenet_amd.models.aes import AE, ConvAEDecoder, ConvAEEncoder, _no_sharded_chunk_loop
+from behavenet_amd.models.aes import (
+    AE, ConvAEDecoder, ConvAEEncoder, _no_sharded_chunk_loop, frame_masks)
 from behavenet_amd.models.base import DiagLinear
 
 __all__ = [
@@ -203,7 +204,7 @@ class VAE(AE):
 
     def _elbo_loss(self, data, dataset, accumulate_grad, chunk_size, fwd_kwargs_fn):
         x = data['images'][0]
-        m = data['masks'][0] if 'masks' in data else None
+        m = frame_masks(data, x)
         beta = self.beta_vals[self.curr_epoch]
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
@@ -318,7 +319,7 @@ class BetaTCVAE(VAE):
 
     def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
         x = data['images'][0]
-        m = data['masks'][0] if 'masks' in data else None
+        m = frame_masks(data, x)
         beta = self.beta_vals[self.curr_epoch]
         kl = self.kl_anneal_vals[self.curr_epoch]
         batch_size = x.shape[0]
@@ -472,7 +473,7 @@ class PSVAE(AE):
         """Modified ELBO of the PS-VAE (ref vaes.py:603-729); returns the same 11 keys."""
         x = data['images'][0]
         y = data['labels'][0]
-        m = data['masks'][0] if 'masks' in data else None
+        m = frame_masks(data, x)
         n = data['labels_masks'][0] if 'labels_masks' in data else None
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
@@ -706,14 +707,15 @@ class MSPSVAE(PSVAE):
         if multi:
             x = torch.cat([d['images'][0] for d in datas], dim=0)
             y = torch.cat([d['labels'][0] for d in datas], dim=0)
-            m = torch.cat([d['masks'][0] for d in datas], dim=0) if 'masks' in datas[0] else None
+            m = torch.cat([frame_masks(d, d['images'][0]) for d in datas], dim=0) \
+                if 'masks' in datas[0] else None
             n = torch.cat([d['labels_masks'][0] for d in datas], dim=0) \
                 if 'labels_masks' in datas[0] else None
             sess_ids = np.concatenate(
                 [d * np.ones(datas[i]['images'].shape[1]) for i, d in enumerate(dataset)])
         else:
             x, y = datas['images'][0], datas['labels'][0]
-            m = datas['masks'][0] if 'masks' in datas else None
+            m = frame_masks(datas, datas['images'][0])
             n = datas['labels_masks'][0] if 'labels_masks' in datas else None
             sess_ids = None
         n_labels = self.hparams['n_labels']

@@ -433,7 +433,64 @@ def fit_fixture():
     print('fit_cfg1.json written:', len(exp.rows), 'rows')
 
 
+from tests.h5py_stub import install as _install_h5py_shim  # noqa: E402
+
+
+def generator_fixture():
+    """Batch order / trial splits of the reference's OWN ``ConcatSessionsGenerator``
+    (behavenet/data/data_generator.py:432-633) over two sessions on disk, seeded per epoch the
+    way ``fit`` seeds (training.py:329-330), two epochs of train + val + test draws, plus the
+    tensors of a few batches.  ``behavenet_amd``'s generator is pinned to it
+    (tests/test_fit_host.py)."""
+    _install_h5py_shim()
+    from behavenet.data.data_generator import ConcatSessionsGenerator as RefGen
+    from tests.test_fit_host import _write_sessions
+    tmp = tempfile.mkdtemp()
+    ids, sessions = _write_sessions(tmp, n_sessions=2, n_trials=22, dim=(1, 8, 8), n_labels=2)
+    signals = [['images', 'labels', 'masks']] * 2
+    paths = [[os.path.join(tmp, i['lab'], i['expt'], i['animal'], i['session'], 'data.hdf5')] * 3
+             for i in ids]
+    out = {'n_sessions': 2, 'n_trials': 22, 'dim': [1, 8, 8], 'n_labels': 2, 'cases': []}
+    for train_frac, splits in ((1.0, {'train_tr': 8, 'val_tr': 1, 'test_tr': 1, 'gap_tr': 0}),
+                               (0.5, {'train_tr': 5, 'val_tr': 1, 'test_tr': 1, 'gap_tr': 1})):
+        gen = RefGen(tmp, ids, signals_list=signals, transforms_list=[[None] * 3] * 2,
+                     paths_list=paths, device='cpu', as_numpy=False, batch_load=True, rng_seed=0,
+                     trial_splits=splits, train_frac=train_frac)
+        case = {'train_frac': train_frac, 'trial_splits': splits,
+                'n_tot_batches': {k: int(v) for k, v in gen.n_tot_batches.items()},
+                'batch_idxs': [{k: [int(i) for i in v] for k, v in ds.batch_idxs.items()}
+                               for ds in gen.datasets],
+                'epochs': []}
+        for epoch in range(2):
+            torch.manual_seed(7 + epoch)
+            np.random.seed(7 + epoch)
+            rec = {}
+            for dtype in ('train', 'val', 'test'):
+                gen.reset_iterators(dtype)
+                order = []
+                for _ in range(gen.n_tot_batches[dtype]):
+                    data, sess = gen.next_batch(dtype)
+                    entry = [int(sess), int(data['batch_idx'][0])]
+                    if len(order) < 2:
+                        entry.append({k: [float(c) for c in checksum(v.numpy())] for k, v in data.items()
+                                      if k != 'batch_idx'})
+                        entry.append({k: list(v.shape) for k, v in data.items()})
+                    order.append(entry)
+                rec[dtype] = order
+            case['epochs'].append(rec)
+        out['cases'].append(case)
+    with open(os.path.join(HERE, 'generator.json'), 'w') as f:
+        json.dump(jsonable(out), f, indent=1)
+    print('wrote generator.json')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'fit':
+        fit_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'generator':
+        generator_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'bn':
         # batch-norm cases only (added later; the other fixtures are left untouched)
         model_case('ae_cfg1_bn', RefAE, [1, 32, 32], 8, 8, 'ae',
