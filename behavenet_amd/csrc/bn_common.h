@@ -7,6 +7,17 @@
 
 #define BN_WAVE 64
 
+// Experiment hooks.  The dispatch code consults a few environment variables (tile shapes, split
+// counts, kernel generations: tools/README.md) ONLY in the tuning build (`make tuning`,
+// -DBN_TUNING -> ../libbehavenet_hip_tuning.so, selected with BN_HIP_LIB); in the product library
+// this is a constant null pointer, every hook folds to its default and no environment is read.
+#include <stdlib.h>
+#ifdef BN_TUNING
+static inline const char* bn_tune_env(const char* name) { return getenv(name); }
+#else
+static inline const char* bn_tune_env(const char*) { return nullptr; }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // geometry shared by the three kernel families (see DESIGN.md "Kernel families")
 //

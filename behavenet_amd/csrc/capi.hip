@@ -173,7 +173,7 @@ static inline BnGeom convT_geom(int N, int Ci, int Hi, int Wi, int Co, int R, in
 static int g_force_generic = -1;
 static bool force_generic() {
     if (g_force_generic < 0) {
-        const char* e = getenv("BN_FORCE_GENERIC");
+        const char* e = bn_tune_env("BN_FORCE_GENERIC");
         g_force_generic = (e && e[0] == '1') ? 1 : 0;
     }
     return g_force_generic == 1;

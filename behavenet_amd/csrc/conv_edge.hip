@@ -577,7 +577,7 @@ BnFastPlan bn_edge_down_plan(const BnGeom& g) {
 static int down_c1_grid(int units) {
 #ifdef BN_TUNING
     static int env_grid = -1;                       // BN_E0_GRID=<waves>
-    if (env_grid < 0) { const char* e = getenv("BN_E0_GRID"); env_grid = e ? atoi(e) : 0; }
+    if (env_grid < 0) { const char* e = bn_tune_env("BN_E0_GRID"); env_grid = e ? atoi(e) : 0; }
     if (env_grid > 0) return env_grid < units ? env_grid : units;
 #endif
     const int n_cu = 256;
@@ -610,7 +610,7 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
     int variant = DC_VARIANT;
 #ifdef BN_TUNING
     static int env_v = -1;                    // BN_E0_V=0: first generation, 1: 2-row, 2: 4-row units
-    if (env_v < 0) { const char* e = getenv("BN_E0_V"); env_v = e ? atoi(e) : DC_VARIANT; }
+    if (env_v < 0) { const char* e = bn_tune_env("BN_E0_V"); env_v = e ? atoi(e) : DC_VARIANT; }
     variant = env_v;
 #endif
     if (variant == 2 && (g.Hs % 4) != 0) variant = 1;
@@ -941,7 +941,7 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
                       const float* mask, float* dpre, float* partial) {
 #ifdef BN_TUNING
     static int old = -1;
-    if (old < 0) { const char* e = getenv("BN_UP_C1_OLD"); old = (e && e[0] == '1') ? 1 : 0; }
+    if (old < 0) { const char* e = bn_tune_env("BN_UP_C1_OLD"); old = (e && e[0] == '1') ? 1 : 0; }
     if (old && !target) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -964,7 +964,7 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
     } else {
 #ifdef BN_TUNING
         static int r4 = -1;
-        if (r4 < 0) { const char* e = getenv("BN_UP_C1_R4"); r4 = (e && e[0] == '1') ? 1 : 0; }
+        if (r4 < 0) { const char* e = bn_tune_env("BN_UP_C1_R4"); r4 = (e && e[0] == '1') ? 1 : 0; }
         if (r4) {
             const int units4 = g.N * g.Cb * (g.Hs / 4);
             hipLaunchKernelGGL((k_up_c1v<4, false>), dim3(units4 < 256 * 24 ? units4 : 256 * 24),

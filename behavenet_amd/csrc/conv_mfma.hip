@@ -307,7 +307,7 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     // 64 ch x 256 px tile halves the per-workgroup prologue / epilogue share and still gives
     // >= 2 workgroups per CU (E1 322 -> 290 us, E2 286 -> 260 us at 256 frames; the 8x8 maps of
     // E3 / D1 are faster with 128-pixel tiles)
-    if (g.stride == 2 && g.Ws >= 16 && g.Cs >= 64 && !getenv("BN_DOWN_TILE")) {
+    if (g.stride == 2 && g.Ws >= 16 && g.Cs >= 64 && !bn_tune_env("BN_DOWN_TILE")) {
         int nwg = 0;
         if (down_tile(g, 2, 2, CC, &t, &nwg) && nwg >= 512) {
             best = 1;
@@ -327,7 +327,7 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     }
     if (best >= 0) down_tile(g, cand[best][0], cand[best][1], CC, &t, &best_wg);
     // tuning hook (tools/kbench.py): BN_DOWN_TILE=<candidate index 0..2> pins the tile shape
-    if (const char* e = getenv("BN_DOWN_TILE")) {
+    if (const char* e = bn_tune_env("BN_DOWN_TILE")) {
         const int i = e[0] - '0';
         int nwg = 0;
         if (i >= 0 && i < 3 && !(cand[i][0] == 2 && g.Cs < 64) &&
@@ -352,7 +352,7 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
         if (splits > 16) splits = 16;
         if (splits < 1) splits = 1;
     }
-    if (const char* e = getenv("BN_DOWN_SPLITS")) {       // tuning hook
+    if (const char* e = bn_tune_env("BN_DOWN_SPLITS")) {       // tuning hook
         const int v = atoi(e);
         if (v >= 1 && v <= 16 && v <= (g.Cb / CC)) splits = v;
     }
@@ -394,7 +394,7 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
     if (!down_tile(g, MR, NR, CC, &t, &nwg)) return BN_E_SHAPE;
     t.splits = splits;
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("BN_DOWN_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char* e = bn_tune_env("BN_DOWN_DBG"); dbg = e ? atoi(e) : 0; }
     t.dbg = dbg;
     if (splits > 1) {
         int cps = (g.Cb + splits - 1) / splits;

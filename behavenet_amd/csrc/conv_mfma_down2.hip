@@ -264,7 +264,7 @@ static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* ld
 
 bool bn_down2_supported(const BnGeom& g, int MR, int NR) {
     static int disabled = -1;                      // BN_DOWN2=0: first-generation kernel only
-    if (disabled < 0) { const char* e = getenv("BN_DOWN2"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (disabled < 0) { const char* e = bn_tune_env("BN_DOWN2"); disabled = (e && e[0] == '0') ? 1 : 0; }
     if (disabled) return false;
     Down2Tile t;
     size_t lds = 0;

@@ -243,8 +243,8 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
     UpTile t;
     int nwg2 = 0, nwg1 = 0;
     static int env_mr = -1, env_cc = -1;          // tuning hooks: BN_UP_MR=1|2, BN_UP_CC=4|8
-    if (env_mr < 0) { const char* e = getenv("BN_UP_MR"); env_mr = e ? atoi(e) : 0; }
-    if (env_cc < 0) { const char* e = getenv("BN_UP_CC"); env_cc = e ? atoi(e) : 0; }
+    if (env_mr < 0) { const char* e = bn_tune_env("BN_UP_MR"); env_mr = e ? atoi(e) : 0; }
+    if (env_cc < 0) { const char* e = bn_tune_env("BN_UP_CC"); env_cc = e ? atoi(e) : 0; }
     const int cc = (env_cc == 8 && (g.Cs % 8) == 0) ? 8 : 4;
     const bool ok2 = g.Cb >= 64 && up_tile(g, 2, cc, &t, &nwg2);
     const bool ok1 = up_tile(g, 1, cc, &t, &nwg1);
@@ -268,7 +268,7 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
     int nwg = 0;
     if (!up_tile(g, MR, CC, &t, &nwg)) return BN_E_SHAPE;
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("BN_UP_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char* e = bn_tune_env("BN_UP_DBG"); dbg = e ? atoi(e) : 0; }
     t.dbg = dbg;
     const int groups = (g.N + t.F - 1) / t.F;
     dim3 grid(groups * t.tiles_per_frame, (g.Cb + 32 * MR - 1) / (32 * MR));

@@ -277,7 +277,7 @@ int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float
     if (!wgrad_tile(g, &t, &lds)) return BN_E_SHAPE;
     t.splits = plan.d;
     static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("BN_WGRAD_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char* e = bn_tune_env("BN_WGRAD_DBG"); dbg = e ? atoi(e) : 0; }
     t.dbg = dbg;
     const int tiles = ((g.Cs + WG_TA - 1) / WG_TA) * ((g.Cb + WG_TB - 1) / WG_TB);
     dim3 grid(tiles, t.splits);

@@ -261,7 +261,7 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     if (g.R != 5 || g.S != 5 || g.stride != 2) return p;
     if (g.Cs < 16 || g.Cb < 16) return p;
     static int disabled = -1;                          // BN_WGRAD4=0: fall back to the dword-DMA kernel
-    if (disabled < 0) { const char* e = getenv("BN_WGRAD4"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4"); disabled = (e && e[0] == '0') ? 1 : 0; }
     if (disabled) return p;
     Wgrad4Tile t;
     size_t lds = 0;

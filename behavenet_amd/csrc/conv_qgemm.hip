@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_qg_finish_wgrad(
 // ---------------------------------------------------------------------------------------------
 bool bn_qgemm_supported(const BnGeom& g) {
     static int disabled = -1;                          // BN_QGEMM=0: previous s5 kernels
-    if (disabled < 0) { const char* e = getenv("BN_QGEMM"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (disabled < 0) { const char* e = bn_tune_env("BN_QGEMM"); disabled = (e && e[0] == '0') ? 1 : 0; }
     if (disabled) return false;
     if (g.R != 5 || g.S != 5 || g.stride != 5) return false;
     if (g.Hs != 2 || g.Ws != 2 || g.Hb != 8 || g.Wb != 8 || g.pt != 1 || g.pl != 1) return false;
@@ -288,7 +288,7 @@ bool bn_qgemm_supported(const BnGeom& g) {
 // which keeps whole-batch and chunked passes bit-identical through these layers
 static int qg_down_splits(const BnGeom& g) {
     static int env = -1;                             // tuning hook: BN_QG_SPLITS
-    if (env < 0) { const char* e = getenv("BN_QG_SPLITS"); env = e ? atoi(e) : 0; }
+    if (env < 0) { const char* e = bn_tune_env("BN_QG_SPLITS"); env = e ? atoi(e) : 0; }
     if (env > 0) return env;
     if ((g.Cs / QG_T) * 4 >= 64) return 1;
     return g.Cb * 16 >= 4096 ? 4 : (g.Cb * 16 >= 2048 ? 2 : 1);

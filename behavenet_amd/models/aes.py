@@ -117,8 +117,8 @@ class ConvAEEncoder(BaseModule):
             if i < n_layers - 1 and hp['ae_encoding_layer_type'][i + 1] == 'maxpool':
                 pargs = self._get_maxpool2d_args(i)
                 self.encoder.add_module('maxpool%i' % gnum, _mark_footprint(nn.MaxPool2d(**pargs)))
-                if not pargs['ceil_mode']:
-                    raise NotImplementedError('max pooling with ae_padding_type="valid"')
+                # ceil_mode (same) or not (valid): either way the planner's output size says how
+                # many windows there are, and the kernel clips windows at the border
                 pool = (pargs['kernel_size'], pargs['stride'], pargs['padding'],
                         (hp['ae_encoding_y_dim'][i + 1], hp['ae_encoding_x_dim'][i + 1]))
             self._pool_after.append(pool)

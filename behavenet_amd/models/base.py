@@ -65,32 +65,33 @@ class BaseModel(nn.Module):
 
 
 class DiagLinear(nn.Module):
-    """y = x * d + b with a diagonal weight (ref base.py:70-103); PS-VAE label map ``D``."""
+    """Element-wise affine map ``y_i = d_i * x_i + b_i``: the PS-VAE's label head ``D``, which
+    rescales every supervised latent on its own (reference base.py:70-103).
+
+    ``state_dict`` keys ``weight`` / ``bias`` (both of length ``features``); initial values are
+    uniform in +-1/sqrt(features), the weight drawn before the bias -- the order in which the
+    reference consumes the seeded generator, so that a seed reproduces its parameters."""
 
     def __init__(self, features, bias=True):
         super().__init__()
-        self.features = features
-        self.weight = nn.Parameter(torch.empty(features))
-        if bias:
-            self.bias = nn.Parameter(torch.empty(features))
-        else:
-            self.register_parameter('bias', None)
+        self.features = int(features)
+        self.weight = nn.Parameter(torch.empty(self.features))
+        self.bias = nn.Parameter(torch.empty(self.features)) if bias else None
         self.reset_parameters()
 
     def reset_parameters(self):
-        bound = 1 / math.sqrt(self.features)
-        nn.init.uniform_(self.weight, -bound, bound)
-        if self.bias is not None:
-            nn.init.uniform_(self.bias, -bound, bound)
+        half_width = self.features ** -0.5
+        with torch.no_grad():
+            for p in (self.weight, self.bias):
+                if p is not None:
+                    p.uniform_(-half_width, half_width)
 
-    def forward(self, input):
-        out = input.mul(self.weight)
-        if self.bias is not None:
-            out = out + self.bias
-        return out
+    def forward(self, x):
+        y = x * self.weight
+        return y if self.bias is None else y + self.bias
 
     def extra_repr(self):
-        return 'features={}, bias={}'.format(self.features, self.bias is not None)
+        return 'features=%d, bias=%s' % (self.features, self.bias is not None)
 
 
 class CustomDataParallel(nn.Module):

@@ -511,6 +511,12 @@ if __name__ == '__main__':
         model_case('ae_valid_1x30x26', RefAE, [1, 30, 26], 6, 12, 'ae', arch_json='arch_valid.json')
         model_case('ae_maxpool', RefAE, [1, 32, 32], 8, 12, 'ae', arch_json='arch_maxpool.json')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'maxpool_valid':
+        # MaxPool2d(ceil_mode=False) / odd pre-pool sizes (aes.py:173-178): 30x26 -> 26x22 -> 13x11
+        # -> 9x7 -> 4x3 (the pools drop the last row / column)
+        model_case('ae_maxpool_valid', RefAE, [1, 30, 26], 6, 12, 'ae',
+                   arch_json='arch_maxpool_valid.json')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'condae':
         from behavenet.models.aes import ConditionalAE as RefCondAE
         model_case('condae_cfg1', RefCondAE, [1, 32, 32], 8, 210, 'cond-ae', n_labels=4,
