@@ -198,7 +198,7 @@ static int run_down(int family, const float* big, const float* w, const float* b
         const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
                                      : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
         if (ed.supported && epi_ok) {
-            const char* name = dact_src ? "k_down_c1<0, true>"
+            const char* name = dact_src ? "k_down_c1s<0, true, false, 2>"
                                : (act == BN_ACT_LRELU ? "k_down_c1<1, false>" : "k_down_c1<0, false>");
             BnProfScope prof(family, g.Cb, g.Cs, name, st, /*on_dispatch=*/true);
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);

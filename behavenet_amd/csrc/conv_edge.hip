@@ -594,6 +594,7 @@ static int launch_down_c1s(const void* big, const float* w, const float* bias, f
                            hipEvent_t e0, hipEvent_t e1) {
     const int units = g.N * (g.Hs / ROWS);
     int grid = 256 * DC_MAX_WAVES_PER_CU;
+    if (const char* e = bn_tune_env("BN_E0_SGRID")) grid = atoi(e);     // (tuning build only)
     if (grid > units) grid = units;
     hipExtLaunchKernelGGL((k_down_c1s<ACT, MASK, U8, ROWS>), dim3(grid), dim3(64), 0, st, e0, e1,
                           0, big, w, bias, out, dact_src, g, slope, units);
@@ -607,12 +608,11 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
                         hipStream_t st, const unsigned char* u8) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bn_prof_take_dispatch_events(&e0, &e1);   // stay null unless bench.py's hook is armed
-    int variant = DC_VARIANT;
-#ifdef BN_TUNING
-    static int env_v = -1;                    // BN_E0_V=0: first generation, 1: 2-row, 2: 4-row units
-    if (env_v < 0) { const char* e = bn_tune_env("BN_E0_V"); env_v = e ? atoi(e) : DC_VARIANT; }
-    variant = env_v;
-#endif
+    // Product choice, measured INSIDE the training step (rocprofv3, 256 frames; the isolated
+    // ranking differs): plain forward -> first generation (31.7-32.8 us vs 33.7-34.6 us);
+    // data gradient with the LeakyReLU' mask -> second generation, 2-row units (48.2 vs 52.6 us).
+    int variant = dact_src ? 1 : DC_VARIANT;
+    if (const char* e = bn_tune_env("BN_E0_V")) variant = atoi(e);   // (tuning build only)
     if (variant == 2 && (g.Hs % 4) != 0) variant = 1;
     if (u8) {
         if (variant == 2)

@@ -63,7 +63,7 @@ KERNELS_256 = {
     ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D1', 'bwd_w'): 'k_wgrad4_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4_mfma<4>',
     ('D3', 'bwd_w'): 'k_wgrad4_mfma<5>',
-    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1<0, true>', ('D4', 'bwd_w'): 'k_wgrad_c1',
+    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2>', ('D4', 'bwd_w'): 'k_wgrad_c1',
 }
 # the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
 # frames, smaller tiles where the grid would not fill the chip
