@@ -615,7 +615,7 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
     if (const char* e = bn_tune_env("BN_E0_V")) variant = atoi(e);   // (tuning build only)
     if (variant == 2 && (g.Hs % 4) != 0) variant = 1;
     if (u8) {
-        if (variant == 2)
+        if ((g.Hs % 4) == 0)       // uint8 frames: second generation only, 4-row units
             return act == BN_ACT_LRELU
                 ? launch_down_c1s<BN_ACT_LRELU, false, true, 4>(u8, w, bias, out, nullptr, g, slope, st, e0, e1)
                 : launch_down_c1s<BN_ACT_NONE, false, true, 4>(u8, w, bias, out, nullptr, g, slope, st, e0, e1);
@@ -964,12 +964,19 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
     } else {
 #ifdef BN_TUNING
         static int r4 = -1;
-        if (r4 < 0) { const char* e = bn_tune_env("BN_UP_C1_R4"); r4 = (e && e[0] == '1') ? 1 : 0; }
-        if (r4) {
+        if (r4 < 0) { const char* e = bn_tune_env("BN_UP_C1_R4"); r4 = e ? atoi(e) : 0; }
+        if (r4 == 1) {
             const int units4 = g.N * g.Cb * (g.Hs / 4);
             hipLaunchKernelGGL((k_up_c1v<4, false>), dim3(units4 < 256 * 24 ? units4 : 256 * 24),
                                dim3(64), 0, st, small, w, bias, out, nullptr, nullptr, nullptr,
                                nullptr, g, act, slope, units4);
+            BN_LAUNCH_CHECK();
+            return 0;
+        }
+        if (r4 == 16) {
+            const int units16 = g.N * g.Cb * (g.Hs / 16);
+            hipLaunchKernelGGL((k_up_c1v<16, false>), dim3(units16), dim3(64), 0, st, small, w, bias,
+                               out, nullptr, nullptr, nullptr, nullptr, g, act, slope, units16);
             BN_LAUNCH_CHECK();
             return 0;
         }

@@ -23,6 +23,10 @@ P = 'conv2d' if kind == 'conv' else 'convT2d'
 for _ in range(a.iters):
     if a.op == 'fwd':
         getattr(_hip, P + '_fwd')(x, w, b, geom, _hip.ACT_LRELU, SLOPE)
+    elif a.op == 'fwd_sqerr':      # last decoder layer + sigmoid + squared error (training)
+        _hip.convT2d_fwd_sqerr(x, w, b, dy.abs(), None, geom, _hip.ACT_SIGMOID, SLOPE, False)
+    elif a.op == 'fwd_u8':         # first encoder layer from uint8 frames
+        _hip.conv2d_fwd_u8((x.clamp(0, 1) * 255).to(torch.uint8), w, b, geom, _hip.ACT_LRELU, SLOPE)
     elif a.op == 'bwd_d':
         getattr(_hip, P + '_bwd_data')(dy, w, geom, x, _hip.ACT_LRELU, SLOPE)
     else:
