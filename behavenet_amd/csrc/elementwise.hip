@@ -175,6 +175,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_kl_bwd(
 // Follows torch.optim.Adam single-tensor update order (amsgrad=True, maximize=False):
 //   g += wd*p; m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; vmax = max(vmax, v);
 //   denom = sqrt(vmax)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom
+typedef unsigned int adam_u4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(EW_THREADS) void k_adam_amsgrad(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
     float* __restrict__ v, float* __restrict__ vmax, size_t n, float step_size, float b1,
@@ -192,6 +193,10 @@ __global__ __launch_bounds__(EW_THREADS) void k_adam_amsgrad(
         const float denom = sqrtf(X) / bc2_sqrt + eps;           \
         (P) = (P) - step_size * ((M) / denom);                   \
     }
+#define ADAM_ST(VAL, PTR)                                                                       \
+    __builtin_amdgcn_raw_buffer_store_b128(                                                     \
+        __builtin_bit_cast(adam_u4, VAL),                                                       \
+        __builtin_amdgcn_make_buffer_rsrc((void*)(PTR), 0, (int)(n * 4), 0x00020000), o, 0, 16);
     if (vec) {
         const size_t n4 = n >> 2;
         float4* p4 = reinterpret_cast<float4*>(p);
@@ -206,7 +211,15 @@ __global__ __launch_bounds__(EW_THREADS) void k_adam_amsgrad(
             ADAM_ONE(P.y, G.y, M.y, V.y, X.y)
             ADAM_ONE(P.z, G.z, M.z, V.z, X.z)
             ADAM_ONE(P.w, G.w, M.w, V.w, X.w)
-            p4[i] = P; m4[i] = M; v4[i] = V; x4[i] = X;
+            if (vec == 2) {
+                // write-through (sc1) 16-byte stores: the updated arenas are not read again before
+                // the next step, so their lines need not sit dirty in the L2s while the first
+                // kernels of that step stream their own output
+                const int o = (int)(i << 4);
+                ADAM_ST(P, p) ADAM_ST(M, m) ADAM_ST(V, v) ADAM_ST(X, vmax)
+            } else {
+                p4[i] = P; m4[i] = M; v4[i] = V; x4[i] = X;
+            }
         }
         for (size_t i = (n4 << 2) + tid; i < n; i += nthreads)
             ADAM_ONE(p[i], g[i], m[i], v[i], vmax[i])
@@ -214,6 +227,7 @@ __global__ __launch_bounds__(EW_THREADS) void k_adam_amsgrad(
         for (size_t i = tid; i < n; i += nthreads) ADAM_ONE(p[i], g[i], m[i], v[i], vmax[i])
     }
 #undef ADAM_ONE
+#undef ADAM_ST
 }
 
 // ---------------------------------------------------------------- uint8 -> float/255
@@ -365,7 +379,12 @@ int bn_launch_adam(float* p, const float* g, float* m, float* v, float* vmax, si
     const double bc2 = 1.0 - pow((double)b2, (double)step);
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    const int vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && aligned16(vmax);
+    int vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && aligned16(vmax);
+    if (vec && n * 4 < 0x7fffffffull) {
+        vec = 2;                                   // arenas addressable by a buffer descriptor
+        const char* e = bn_tune_env("BN_ADAM_WT");
+        if (e && e[0] == '0') vec = 1;
+    }
     hipLaunchKernelGGL(k_adam_amsgrad, dim3(ew_blocks(vec ? n / 4 + 1 : n)), dim3(EW_THREADS), 0,
                        st, p, g, m, v, vmax, n, step_size, b1, b2, bc2_sqrt, eps, wd, vec);
     BN_LAUNCH_CHECK();

@@ -63,8 +63,7 @@ def gaussian_ll_chunks(y_pred, y_mean, masks, bounds, std=1, chunk_sizes=None, c
     if const_share is None:
         const_t = float(const)
     else:
-        const_t = torch.tensor([float(const) * float(f) for f in const_share],
-                               dtype=torch.float32, device=images.device)
+        const_t = hf.device_constant([float(const) * float(f) for f in const_share], images.device)
     if isinstance(fused, hf.FusedPixelLoss):
         assert fused.kind == 'll' and fused.bounds == list(bounds) and std == 1
         return fused.chunk_terms + const_t

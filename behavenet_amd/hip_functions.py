@@ -592,6 +592,23 @@ class FusedPixelLoss(object):
         self.bounds = list(bounds)
 
 
+_DEVICE_CONSTANTS = {}
+
+
+def device_constant(values, device):
+    """A small float32 device tensor holding ``values``, built once per (values, device) and
+    reused (never written to): ``torch.tensor(list, device='cuda')`` is a synchronous pageable
+    copy, which drains the launch queue when done every step."""
+    key = (tuple(float(v) for v in values), str(device))
+    t = _DEVICE_CONSTANTS.get(key)
+    if t is None:
+        if len(_DEVICE_CONSTANTS) > 256:
+            _DEVICE_CONSTANTS.clear()
+        t = torch.tensor(key[0], dtype=torch.float32, device=device)
+        _DEVICE_CONSTANTS[key] = t
+    return t
+
+
 def pixel_loss_scales(kind, bounds, per_frame, chunk_sizes=None):
     """Per-chunk factors of the squared-error sums: 'mse' -> 1 / (frames * pixels) (reference
     losses.py:56-59: mean over ALL elements), 'll' -> -0.5 / frames (losses.py:84-96, std = 1).

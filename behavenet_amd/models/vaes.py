@@ -99,7 +99,11 @@ class _FrameShards(object):
                 torch.cat([t[b:e] for b, e in self.local], dim=0).contiguous() for t in tensors]
 
     def share_t(self, device):
-        return torch.tensor(self.share, dtype=torch.float32, device=device)
+        """Per-chunk share as a device tensor (cached: building one from host floats is a
+        synchronous copy that would stall the launch queue every step); 1.0 when not sharded."""
+        if not self.sharded:
+            return 1.0
+        return hf.device_constant(self.share, device)
 
     def all_rows(self, t):
         """The rows of every rank (metrics over the whole batch); identity when not sharded."""
@@ -348,7 +352,7 @@ class BetaTCVAE(VAE):
                 # what is REPORTED is summed over ranks: the shared terms enter with this rank's
                 # share of the chunk
                 w = sh.share_t(x.device)
-                table = torch.cat([(-ll + w * kl_terms)[:, None], ll[:, None], dk * w[:, None]],
+                table = torch.cat([(-ll + w * kl_terms)[:, None], ll[:, None], dk * (w if isinstance(w, float) else w[:, None])],
                                   dim=1)
             vals = _finish_whole(table, lossv, accumulate_grad)
             sizes = sh.sizes
@@ -512,7 +516,7 @@ class PSVAE(AE):
                 kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
                 lossv = -ll_x - float(alpha) * ll_y + zs + kl_terms
                 w = sh.share_t(x.device)
-                table = torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk * w[:, None],
+                table = torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk * (w if isinstance(w, float) else w[:, None]),
                                    (-ll_x - float(alpha) * ll_y + zs + w * kl_terms)[:, None]],
                                   dim=1)
             # label r^2 over the whole batch: the ranks' rows are gathered (a few KB)
