@@ -17,8 +17,12 @@
 //    were 2-way bank conflicted; the row stride is chosen == Q (mod 32) so that the 32 pixels of
 //    a half-wave (several image rows when Q < 32) cover the 64 banks exactly once.
 //
-// The weight slice still goes through registers (global order [m][c][tap] has a 100-word row
-// per output channel: no 16-byte-granular copy of it is bank-conflict free for per-lane rows).
+// The weight slice of a chunk is copied by 16-byte LDS-DMA as well, in its global order (see the
+// note at `woff`): the chunk boundary is then a handful of scalar-addressed DMA instructions.  It
+// used to be ~250 vector instructions (32 loads, 32 transposing ds_write, selects), and a wave
+// that is not in its MFMA loop gets about one instruction issued per MFMA of the wave it shares
+// the SIMD with (s_memtime trace: boundary 2.6 k cycles alone, 15.8 k next to a multiplying wave
+// -- longer than the 14.4 k cycle MFMA loop it was meant to hide behind).
 #include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"
@@ -31,11 +35,20 @@ typedef float floatx2d __attribute__((ext_vector_type(2)));
 #define D2_X0 4                 // LDS column of image column 0
 #define D2_XK 8                 // max 16-byte DMA groups per thread per chunk
 #define D2_MAX_LDS (80 * 1024)
+#define D2_XBUF_FLOATS 6912         // fixed LDS distance between the two input images (27 KB: two
+                                   // images + the 25.6 KB weight slice = 80 KB, two workgroups per CU)
 
 static inline int ilog2_exact_d2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
     return ((1 << l) == v) ? l : -1;
+}
+
+// 16-byte LDS-DMA (a plain function: inside the kernel template the builtin's size argument would be
+// checked at instantiation time, where the host pass rejects 16 and silently drops the kernel)
+__device__ __forceinline__ void d2_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voffset,
+                                         int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
 }
 
 struct Down2Tile {
@@ -53,13 +66,23 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, Down2Tile t, int act,
     int dact, float slope) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef D2_TRACE
+    unsigned long long* trc = d2_trace + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * D2_TRACE_SLOTS;
+#define D2_MARK(slot) do { if (threadIdx.x == 0) trc[slot] = __builtin_readcyclecounter(); } while (0)
+    if (threadIdx.x == 0) {
+        trc[0] = __builtin_readcyclecounter();
+        trc[1] = __builtin_amdgcn_s_memrealtime();
+        trc[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    }
+#else
+#define D2_MARK(slot)
+#endif
     constexpr int CC = D2_CC, R = 5, S = 5, RS = 25;
     constexpr int TM = 32 * MR;
-    constexpr int TMP = TM + 1;                       // odd row stride: conflict-free transpose
-    constexpr int WROWS = TM / 4;                     // weight rows per wave
-    constexpr int WPASS = (CC * RS + 63) / 64;        // 64-lane passes along (channel, tap)
-    constexpr int WK = WROWS * WPASS;                 // weight loads per thread per chunk
-    float* wl = smem + 2 * t.xbuf_floats;
+    constexpr int WS = CC * RS;                       // weight row of one output channel (100 words)
+    constexpr int WG = TM * WS / 4;                   // 16-byte groups of the weight slice
+    constexpr int WK = (WG + D2_THREADS - 1) / D2_THREADS;
+    float* wl = smem + 2 * D2_XBUF_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
@@ -105,7 +128,22 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
         const int hb = 2 * p0 - g.pt + y, wb = 4 * c4 - D2_X0;
         const bool ok = e < t.groups && (n0 + f < g.N) && hb >= 0 && hb < g.Hb && wb >= 0 &&
                         wb < g.Wb;
-        xoff[k] = ok ? ((f * g.Cb + cc) * HW + hb * g.Wb + wb) * 4 : -1;
+        xoff[k] = ok ? ((f * g.Cb + cc) * HW + hb * g.Wb + wb) * 4 : 0x7fffffff;
+    }
+    // weight slice of a chunk: rows m0.. of W[m][c0..c0+3][25 taps] = 100 contiguous words per
+    // output channel, copied in that order (25 groups per row).  A lane later reads word
+    // (2cp+kk)*25 + tap of row li: li * 100 words = li * 36 (mod 64) banks -> the 32 lanes of a
+    // half wave fall on 16 bank quads, 2 lanes each -- the best any 16-byte-granular image of
+    // per-lane rows can do, and 2 extra LDS cycles per read are nothing next to the MFMAs.
+    // The two halves (kk) are 25 words apart: disjoint banks.
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)w, 0, (int)((size_t)g.Cs * g.Cb * RS * 4), 0x00020000);
+    int woff[WK];
+#pragma unroll
+    for (int k = 0; k < WK; ++k) {
+        const int e = tid + D2_THREADS * k;
+        const int m = e / (WS / 4), j = e - m * (WS / 4);
+        woff[k] = (e < WG && m0 + m < g.Cs) ? ((m0 + m) * g.Cb * RS + 4 * j) * 4 : 0x7fffffff;
     }
 
     floatx16 acc[MR][NR];
@@ -116,115 +154,217 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[mr][nr][e] = 0.f;
 
-    float wr[WK];
-    auto issue_loads = [&](int c0, int buf) {
-        // input tile: 16-byte LDS-DMA straight into image `buf`
+    // 16-byte LDS-DMA; the chunk-dependent part of the address is the scalar offset (unsigned,
+    // added after the range check: padding / tail groups keep reading 0.0f)
+    auto issue_image = [&](int c0, int buf) {
         const int cbase = (n0 * g.Cb + c0) * HW * 4;
 #pragma unroll
         for (int k = 0; k < D2_XK; ++k) {
             if (D2_THREADS * k + 64 * wv < t.groups)              // wave-uniform
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rbig, smem + buf * t.xbuf_floats + 4 * (D2_THREADS * k + 64 * wv), 16,
-                    xoff[k] >= 0 ? cbase + xoff[k] : 0x7fffffff, 0, 0, 0);
+                d2_dma16(rbig, smem + buf * D2_XBUF_FLOATS + 4 * (D2_THREADS * k + 64 * wv),
+                         xoff[k], cbase);
         }
-        // weights: wave wv fetches rows m = wv, wv+4, ... of the (TM x CC*RS) slice; lanes run
-        // along the contiguous (channel, tap) axis, so the k-dependent address part is scalar
-        const float* wp = w + ((size_t)(m0 + wv) * g.Cb + c0) * RS + lane;
+    };
+    auto issue_weights = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < WROWS; ++k) {
-            const int m = min(m0 + wv + 4 * k, g.Cs - 1) - (m0 + wv);
-            const float* rp = wp + (size_t)m * g.Cb * RS;
-#pragma unroll
-            for (int ps = 0; ps < WPASS; ++ps) {
-                const int r2 = lane + 64 * ps;
-                wr[k * WPASS + ps] = rp[(r2 < CC * RS) ? 64 * ps : -lane];
-            }
+        for (int k = 0; k < WK; ++k) {
+            if (D2_THREADS * k + 64 * wv < WG)
+                d2_dma16(rw, wl + 4 * (D2_THREADS * k + 64 * wv), woff[k], c0 * RS * 4);
         }
     };
 
-    int cur = 0;
-    issue_loads(0, 0);
-    for (int c0 = 0; c0 < g.Cb; c0 += CC) {
-        __syncthreads();   // the previous chunk's MFMA reads of wl (and of image cur^1) are done
+    // LDS addresses of the operand reads, computed ONCE: inside the MFMA loop every vector
+    // instruction that is not an MFMA costs the matrix pipe 6-13 cycles (tools/lab/issue_probe.hip:
+    // 10 v_add per 20 MFMAs = -8 %; LDS reads and scalar instructions are free), and the address
+    // arithmetic of the reads was 10-13 such instructions per 20 MFMAs.  Now a row's reads are
+    // `ds_read vaddr offset:imm` only: the image rows of (pixel block, channel pair, kernel row)
+    // each have an address register, the second LDS image lies a compile-time distance behind the
+    // first, and the weight reads share one lane base.
+    constexpr int NIT = (CC / 2) * R;
+    // (ds_read2 offsets reach 255 words / double words only: one register per image and per
+    // 32-channel weight block, so that no read needs an address add; the asm keeps the compiler
+    // from re-deriving them from one another with an add in front of every read)
+    int xro[2][NR][CC / 2][R];                       // float offsets from smem
 #pragma unroll
-        for (int k = 0; k < WROWS; ++k) {
-            const bool mok = m0 + wv + 4 * k < g.Cs;
+    for (int bf = 0; bf < 2; ++bf)
 #pragma unroll
-            for (int ps = 0; ps < WPASS; ++ps) {
-                const int r2 = lane + 64 * ps;
-                if (r2 < CC * RS) wl[r2 * TMP + wv + 4 * k] = mok ? wr[k * WPASS + ps] : 0.f;
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA groups of this chunk landed
-        __syncthreads();
-        if (c0 + CC < g.Cb) issue_loads(c0 + CC, cur ^ 1);   // in flight behind the MFMAs below
-        const float* xcur = smem + cur * t.xbuf_floats;
-
-        // MFMA loop, one (channel pair, kernel row) = 5 taps per "row"; operands double buffered
-        // by hand: the LDS reads of row i+1 are issued BEFORE the MFMAs of row i
-        constexpr int NIT = (CC / 2) * R;
-        float a0[S][MR], b0[S][NR], a1[S][MR], b1[S][NR];
-        auto load_row = [&](int it, float (&av)[S][MR], float (&bv)[S][NR]) {
-            const int cp = it / R, r = it - cp * R;
-            const float* wa = wl + ((2 * cp + kk) * RS + r * S) * TMP + li;
-            const float* xb = xcur + (2 * cp) * t.CHS + r * t.RW;
+        for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-            for (int s = 0; s < S; ++s)
+            for (int cp = 0; cp < CC / 2; ++cp)
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) av[s][mr] = wa[s * TMP + mr * 32];
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr) {
-                const floatx2d c0p = *reinterpret_cast<const floatx2d*>(xb + base[nr]);
-                const floatx2d c1p = *reinterpret_cast<const floatx2d*>(xb + base[nr] + 2);
-                const floatx2d c2p = *reinterpret_cast<const floatx2d*>(xb + base[nr] + 4);
-                bv[0][nr] = c0p.y; bv[1][nr] = c1p.x; bv[2][nr] = c1p.y;
-                bv[3][nr] = c2p.x; bv[4][nr] = c2p.y;
-            }
-        };
-        auto mfma_row = [&](float (&av)[S][MR], float (&bv)[S][NR]) {
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            av[s][mr], bv[s][nr], acc[mr][nr], 0, 0, 0);
-        };
-        load_row(0, a0, b0);
-#pragma unroll 1
-        for (int it = 0; it < NIT; it += 2) {
-            if (it + 1 < NIT) load_row(it + 1, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (it + 2 < NIT) load_row(it + 2, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (it + 1 < NIT) mfma_row(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        cur ^= 1;
-    }
-
-    // ---- epilogue: lane holds channel (e&3)+8*(e>>2)+4*kk of pixel li for each register e
+                for (int r = 0; r < R; ++r) {
+                    xro[bf][nr][cp][r] = bf * D2_XBUF_FLOATS + base[nr] + (2 * cp) * t.CHS + r * t.RW;
+                    asm volatile("" : "+v"(xro[bf][nr][cp][r]));
+                }
+    int wao[MR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
+        wao[mr] = 2 * D2_XBUF_FLOATS + (li + 32 * mr) * WS + kk * RS;
+        asm volatile("" : "+v"(wao[mr]));
+    }
+
+    // One chunk = NIT rows of 5 taps x (MR x NR) MFMAs, everything unrolled, operand registers
+    // double buffered.  The reads of row i+1 are cut into U units of one LDS instruction each and
+    // placed by hand between the MFMAs of row i; sched_barrier pins that order (the scheduler's
+    // own interleaving put dependent MFMAs back to back).
+    constexpr int NM = S * MR * NR;                  // MFMAs per row
+    constexpr int NU = 3 * MR + 2 * NR;              // read units per row
+    static_assert(NU <= NM, "one read unit per MFMA at most");
+    auto load_unit = [&](const int BUF, const int it, const int u, float (&a)[S][MR],
+                         float (&bq)[S][NR]) __attribute__((always_inline)) {
+        const int cp = it / R, r = it - cp * R;
+        if (u < 3 * MR) {
+            const int mr = u / 3, k = u - 3 * mr;
+            const float* wp = smem + wao[mr] + (2 * cp) * RS + r * S;
+            if (k == 0) { a[0][mr] = wp[0]; a[1][mr] = wp[1]; }
+            else if (k == 1) { a[2][mr] = wp[2]; a[3][mr] = wp[3]; }
+            else a[4][mr] = wp[4];
+        } else {
+            // columns 2q-1 .. 2q+3 = words 1..5 of the aligned six-word run
+            const int v = u - 3 * MR, nr = v / 2;
+            const float* xb = smem + xro[BUF][nr][cp][r];
+            if ((v & 1) == 0) bq[0][nr] = xb[1];
+            else {
+                const floatx2d c1p = *reinterpret_cast<const floatx2d*>(xb + 2);
+                const floatx2d c2p = *reinterpret_cast<const floatx2d*>(xb + 4);
+                bq[1][nr] = c1p.x; bq[2][nr] = c1p.y; bq[3][nr] = c2p.x; bq[4][nr] = c2p.y;
+            }
+        }
+    };
+    auto chunk_rows = [&](const int BUF, const int c0) __attribute__((always_inline)) {
+        float av[2][S][MR], bv[2][S][NR];
 #pragma unroll
-        for (int nr = 0; nr < NR; ++nr) {
-            if (!pvalid[nr]) continue;
+        for (int u = 0; u < NU; ++u) load_unit(BUF, 0, u, av[0], bv[0]);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + mr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-                if (m >= g.Cs) continue;
-                const size_t idx = opix[nr] + (size_t)m * PQ;
-                float v = acc[mr][nr][e];
-                if (bias) v += bias[m];
-                v = bn_apply_act(v, act, slope);
-                if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
-                out[idx] = v;
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                const int s = j / (MR * NR), mr = (j / NR) % MR, nr = j % NR;
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                    av[it & 1][s][mr], bv[it & 1][s][nr], acc[mr][nr], 0, 0, 0);
+                if (it + 1 < NIT) {
+#pragma unroll
+                    for (int u = (j * NU) / NM; u < ((j + 1) * NU) / NM; ++u)
+                        load_unit(BUF, it + 1, u, av[(it + 1) & 1], bv[(it + 1) & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto boundary = [&](int c0, const int BUF) __attribute__((always_inline)) {
+        if (c0 == 2 * CC) D2_MARK(22);
+        __syncthreads();   // the previous chunk's MFMA reads of wl (and of the other image) are done
+        if (c0 == 2 * CC) D2_MARK(23);
+        issue_weights(c0);
+        if (c0 == 2 * CC) D2_MARK(24);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own groups of this chunk landed
+        if (c0 == 2 * CC) D2_MARK(25);
+        __syncthreads();
+        if (c0 == 2 * CC) D2_MARK(26);
+        if (c0 + CC < g.Cb) issue_image(c0 + CC, BUF ^ 1);   // in flight behind the MFMAs below
+        if (c0 == 2 * CC) D2_MARK(27);
+    };
+
+    D2_MARK(3);
+    issue_image(0, 0);
+    for (int c0 = 0; c0 < g.Cb; c0 += 2 * CC) {
+        if (c0 < 6 * CC) D2_MARK(4 + 2 * (c0 / CC));
+        boundary(c0, 0);
+        if (c0 < 6 * CC) D2_MARK(5 + 2 * (c0 / CC));
+        chunk_rows(0, c0);
+        if (c0 + CC < g.Cb) {
+            if (c0 < 4 * CC) D2_MARK(6 + 2 * (c0 / CC));
+            boundary(c0 + CC, 1);
+            if (c0 < 4 * CC) D2_MARK(7 + 2 * (c0 / CC));
+            chunk_rows(1, c0 + CC);
+        }
+    }
+
+    // ---- epilogue: lane holds channel (e&3)+8*(e>>2)+4*kk of pixel li for each register e.
+    // Loads are batched ahead of the stores (bias: all at once; activation-derivative source: 16 per
+    // accumulator block): with a load -> wait -> store chain per element the 64 elements of a lane
+    // cost 64 memory round trips (59 k of the kernel's 490 k cycles, s_memtime trace).
+    D2_MARK(16);
+    if (act != BN_ACT_SIGMOID && dact != BN_ACT_SIGMOID) {             // wave-uniform
+        // branch-free: buffer loads / stores whose lane offset is out of range for lanes (or
+        // channels) that do not exist -- per-element branches made the compiler drain the memory
+        // queue (s_waitcnt vmcnt(0)) in front of every single store
+        const float es = (act == BN_ACT_LRELU) ? slope : 1.f;           // identity = slope 1
+        const float ds = (dact == BN_ACT_LRELU) ? slope : 1.f;
+        const int obytes = (int)((size_t)g.N * g.Cs * PQ * 4);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, obytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)dact_src, 0, dact_src ? obytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)bias, 0, bias ? g.Cs * 4 : 0, 0x00020000);
+        const int mlane = m0 + 4 * kk;
+        float bz[MR][16];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                bz[mr][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rbs, mlane * 4 + (mr * 32 + (e & 3) + 8 * (e >> 2)) * 4, 0, 0));
+#ifdef D2_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        D2_MARK(17);
+#endif
+        int vo[NR];
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+            vo[nr] = pvalid[nr] ? (int)((opix[nr] + (size_t)mlane * PQ) * 4) : 0x7fffffff;
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                float d[16];
+                if (dact_src) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int mo = mr * 32 + (e & 3) + 8 * (e >> 2);
+                        d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rd, (mlane + mo < g.Cs) ? vo[nr] : 0x7fffffff, mo * PQ * 4, 0));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int mo = mr * 32 + (e & 3) + 8 * (e >> 2);
+                    float v = acc[mr][nr][e] + bz[mr][e];
+                    v = v > 0.f ? v : v * es;
+                    if (dact_src) v *= d[e] > 0.f ? 1.f : ds;
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(int, v), ro, (mlane + mo < g.Cs) ? vo[nr] : 0x7fffffff,
+                        mo * PQ * 4, 0);
+                }
+                D2_MARK(18 + mr * NR + nr);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                if (!pvalid[nr]) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + mr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                    if (m >= g.Cs) continue;
+                    const size_t idx = opix[nr] + (size_t)m * PQ;
+                    float v = acc[mr][nr][e];
+                    if (bias) v += bias[m];
+                    v = bn_apply_act(v, act, slope);
+                    if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
+                    out[idx] = v;
+                }
             }
         }
     }
+#ifdef D2_TRACE
+    if (threadIdx.x == 0) {
+        trc[14] = __builtin_readcyclecounter();
+        trc[15] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* lds_bytes) {
@@ -258,7 +398,9 @@ static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* ld
     t->inv_fs4 = 1.0f / (float)(t->FS / 4);
     t->inv_c4 = 1.0f / (float)(rw / 4);
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;
-    *lds_bytes = ((size_t)2 * t->xbuf_floats + (size_t)D2_CC * 25 * (32 * MR + 1)) * 4;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    if (t->xbuf_floats > D2_XBUF_FLOATS) return false;
+    *lds_bytes = ((size_t)2 * D2_XBUF_FLOATS + (size_t)D2_CC * 25 * 32 * MR + 256) * 4;
     return *lds_bytes <= D2_MAX_LDS;
 }
 
