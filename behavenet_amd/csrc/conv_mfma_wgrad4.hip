@@ -209,6 +209,221 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streamlined variant for stages that lie inside one frame (F == 1: Hs * Ws >= 64, the bench
+// layers).  Same tiles, LDS images and MFMA roles as k_wgrad4_mfma above -- and the same partial
+// sums, bit for bit -- but nothing is left for the vector ALU inside the multiply loop:
+//  * on this chip every VALU instruction that is not an MFMA takes 6-13 cycles away from the matrix
+//    pipe (tools/lab/issue_probe.hip), LDS reads and scalar instructions none; the loop above spends
+//    about one VALU instruction per MFMA (pixel decode, operand addresses, the float-multiply group
+//    decode of the DMA) and reaches 65 % matrix utilisation;
+//  * here the geometry of a stage is a compile-time function of LGQ: an operand read is
+//    `ds_read vbase offset:imm` (one base register per LDS image; the A read adds one v_xor for
+//    the swizzle), the DMA source offsets of a thread are computed once and a stage contributes a
+//    scalar offset (buffer soffset) plus a two-compare row test per group;
+//  * the reads of k-step i+1 and the DMA instructions of the next stage are placed by hand between
+//    the 25 MFMAs of k-step i (sched_barrier pins the order), everything unrolled over the 16
+//    k-steps of a stage and over the two LDS images;
+//  * one workgroup per CU by __launch_bounds__ (it needs 150 KB of LDS anyway): 256 registers.
+// ---------------------------------------------------------------------------------------------
+template <int LGQ>
+struct W4S {
+    static constexpr int Q = 1 << LGQ, PT_H = W4_TPX / Q, IH = 2 * (PT_H - 1) + 5;
+    static constexpr int RW = 2 * Q + 8, C4 = RW / 4;
+    static constexpr int ROWG = IH * C4;                         // data groups of a channel image
+    static constexpr int GPB = (ROWG & 1) ? ROWG : ROWG + 1;     // odd: conflict-free b64 reads
+    static constexpr int BCH = 4 * GPB;
+    static constexpr int BIGG = W4_TB * GPB;
+    static constexpr int SMALLW = W4_TA * W4_TPX;
+    static constexpr int BUFW = SMALLW + 4 * ((BIGG + 63) / 64 * 64);
+    static constexpr int NBIG = (BIGG + W4_THREADS - 1) / W4_THREADS;
+    static constexpr int NSM = SMALLW / 4 / W4_THREADS;
+};
+
+__device__ __forceinline__ void w4_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voffset,
+                                         int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
+}
+
+template <int LGQ, int BIAS>
+__global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
+    const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
+    float* __restrict__ bias_part, BnGeom g, int n_stages, int splits, int lg_tpf, int nbias) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using T = W4S<LGQ>;
+    constexpr int Q = T::Q, RW = T::RW, BUFW = T::BUFW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ablk = wv >> 1, bblk = wv & 1;
+    const int lj = lane & 15, kk = lane >> 4;
+
+    const int n_btiles = (g.Cb + W4_TB - 1) / W4_TB;
+    const int atile = blockIdx.x / n_btiles, btile = blockIdx.x - atile * n_btiles;
+    const int a0 = atile * W4_TA, b0 = btile * W4_TB;
+    const int PQ = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
+
+    floatx4 acc[25];
+#pragma unroll
+    for (int tp = 0; tp < 25; ++tp) acc[tp] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    // ---- DMA descriptors of this thread (stage independent) --------------------------------
+    // the big image is addressed from one row above its start (patch row y is image row
+    // 2 p0 - 1 + y): lane offsets stay non-negative, the stage adds a scalar offset
+    const __amdgpu_buffer_rsrc_t rs_small = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(big - g.Wb), 0, (int)(((size_t)g.N * g.Cb * HWb + g.Wb) * 4), 0x00020000);
+    int soff[T::NSM];
+#pragma unroll
+    for (int j = 0; j < T::NSM; ++j) {
+        const int e = tid + W4_THREADS * j;
+        const int a = e >> 4;
+        const int pix0 = 4 * ((e & 15) ^ (a & 15));                  // swizzled source group
+        soff[j] = (a0 + a < g.Cs) ? ((a0 + a) * PQ + pix0) * 4 : W4_OOB;
+    }
+    int voff[T::NBIG], yrow[T::NBIG];
+#pragma unroll
+    for (int j = 0; j < T::NBIG; ++j) {
+        const int e = tid + W4_THREADS * j;
+        const int b = e / T::GPB, within = e - b * T::GPB;
+        const int y = within / T::C4, c4 = within - y * T::C4;
+        const int wb = 4 * c4 - W4_X0;
+        const bool ok = (e < T::BIGG) && (within < T::ROWG) && (b0 + b < g.Cb) && wb >= 0 && wb < g.Wb;
+        voff[j] = ok ? (((b0 + b) * g.Hb + y) * g.Wb + wb) * 4 : W4_OOB;
+        yrow[j] = y;
+    }
+    // one DMA instruction of stage `st` into image `buf`: d < NSM small tile, else big tile
+    auto issue_dma = [&](const int d, const int buf, const int n0, const int p0) __attribute__((always_inline)) {
+        float* sl = smem + buf * BUFW;
+        if (d < T::NSM) {
+            w4_dma16(rs_small, sl + 4 * (W4_THREADS * d + 64 * wv), soff[d], (n0 * g.Cs * PQ + p0 * Q) * 4);
+        } else {
+            const int j = d - T::NSM;
+            if (W4_THREADS * j + 64 * wv < T::BIGG) {                 // wave-uniform
+                // rows above the image (first tile) and below it (last tile) read 0.0f
+                const int ymin = p0 == 0 ? 1 : 0, ylim = g.Hb + 1 - 2 * p0;
+                const int vo = (yrow[j] >= ymin && yrow[j] < ylim) ? voff[j] : W4_OOB;
+                w4_dma16(rs_big, sl + T::SMALLW + 4 * (W4_THREADS * j + 64 * wv), vo,
+                         (n0 * g.Cb * g.Hb + 2 * p0) * g.Wb * 4);
+            }
+        }
+    };
+    constexpr int NDMA = T::NSM + T::NBIG;
+
+    // ---- operand read addresses (A: byte, B: word offsets from smem), one base per LDS image ---
+    int abase[2], bbase[2];
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {
+        abase[bf] = (bf * BUFW + (ablk * 16 + lj) * W4_TPX + 4 * lj + kk) * 4;      // bytes
+        bbase[bf] = bf * BUFW + T::SMALLW + (bblk * 16 + lj) * T::BCH + (W4_X0 - 2) + 2 * kk;
+        asm volatile("" : "+v"(abase[bf]));
+        asm volatile("" : "+v"(bbase[bf]));
+    }
+
+    // Operand registers: the 25 B values of a k-step live in ONE set -- kernel row r of the next
+    // k-step is read into the registers of row r while the MFMAs of row r+1 run (an MFMA has taken
+    // its operands when it issues; the row is needed again 20 MFMAs = 640 cycles later).  The A
+    // value is double buffered.  Two reads per row: word 1, and words 2..5 as two b64.
+    auto load_a = [&](const int ab, const int ks, float& a) __attribute__((always_inline)) {
+        // (4 lj) ^ (4 ks) = 4 (lj ^ ks); volatile: computed here, every time (hoisted out of the
+        // stage loop the 32 addresses would be spilled)
+        int ao;                                                    // byte offsets
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ao) : "n"(16 * ks), "v"(ab));
+        a = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + ao);
+    };
+    auto load_row = [&](const int bb, const int ks, const int r, const int half, float (&bq)[25]) __attribute__((always_inline)) {
+        const int pj = (4 * ks) >> LGQ, q0 = (4 * ks) & (Q - 1);
+        const float* bp = smem + bb + (2 * pj + r) * RW + 2 * q0;
+        if (half == 0) {
+            bq[r * 5 + 0] = bp[1];
+        } else {
+            const floatx2 c1 = *reinterpret_cast<const floatx2*>(bp + 2);
+            const floatx2 c2 = *reinterpret_cast<const floatx2*>(bp + 4);
+            bq[r * 5 + 1] = c1.x; bq[r * 5 + 2] = c1.y; bq[r * 5 + 3] = c2.x; bq[r * 5 + 4] = c2.y;
+        }
+    };
+    auto stage_body = [&](const int ab, const int bb, const int nbuf, const bool more, const int n0n,
+                          const int p0n) __attribute__((always_inline)) {
+        float av[2], bv[25];
+        load_a(ab, 0, av[0]);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) { load_row(bb, 0, r, 0, bv); load_row(bb, 0, r, 1, bv); }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (BIAS == 1) bsum += av[ks & 1];
+            if (BIAS == 2) {                                       // taps (1,1) (1,2) | (2,1) (2,2)
+                bsum += bv[6] + bv[7];
+                bsum += bv[11] + bv[12];
+            }
+#pragma unroll
+            for (int tp = 0; tp < 25; ++tp) {
+                const int r = tp / 5, sx = tp - 5 * r;
+                acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1], bv[tp], acc[tp], 0, 0, 0);
+                // row r-1 of the NEXT k-step goes into its registers during row r (r >= 1); row 4
+                // follows during row 0 of the next k-step
+                if (r >= 1 && ks + 1 < 16 && (sx == 0 || sx == 2)) load_row(bb, ks + 1, r - 1, sx >> 1, bv);
+                if (r == 0 && ks >= 1 && (sx == 0 || sx == 2)) load_row(bb, ks, 4, sx >> 1, bv);
+                if (r == 2 && sx == 4 && ks + 1 < 16) load_a(ab, ks + 1, av[(ks + 1) & 1]);
+                if (r == 3 && sx == 4 && ks < NDMA) {
+                    if (more) issue_dma(ks, nbuf, n0n, p0n);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    const int tpf_mask = (1 << lg_tpf) - 1;
+    int st = blockIdx.y;
+    if (st < n_stages) {
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d) issue_dma(d, 0, st >> lg_tpf, (st & tpf_mask) * T::PT_H);
+    }
+    // one loop trip = one stage; the base registers of the two LDS images swap after each trip
+    int ab_cur = abase[0], ab_oth = abase[1], bb_cur = bbase[0], bb_oth = bbase[1];
+    int cur = 0;
+    for (; st < n_stages; st += splits) {
+        // own DMAs of this stage have landed; after the barrier everyone's have, and every wave
+        // is done reading the other image
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nx = st + splits;
+        stage_body(ab_cur, bb_cur, cur ^ 1, nx < n_stages, nx >> lg_tpf, (nx & tpf_mask) * T::PT_H);
+        cur ^= 1;
+        int tmp = ab_cur; ab_cur = ab_oth; ab_oth = tmp;
+        tmp = bb_cur; bb_cur = bb_oth; bb_oth = tmp;
+    }
+
+    if (BIAS != 0) {
+        // lanes lj + 16 kk hold the four pixel phases of one channel: fixed-order butterfly
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        float* bdst = bias_part + (size_t)blockIdx.y * nbias;
+        if (BIAS == 1 && btile == 0 && bblk == 0 && kk == 0) {
+            const int a = a0 + ablk * 16 + lj;
+            if (a < g.Cs) bdst[a] = bsum;
+        }
+        if (BIAS == 2 && atile == 0 && ablk == 0 && kk == 0) {
+            const int bb = b0 + bblk * 16 + lj;
+            if (bb < g.Cb) bdst[bb] = bsum;
+        }
+    }
+
+    // partial tile -> scratch [split][tap][a][b]; lane holds D[i = 4*kk + e][j = lj]
+    float* dst = part + (size_t)blockIdx.y * 25 * g.Cs * g.Cb;
+    const int b = b0 + bblk * 16 + lj;
+    if (b < g.Cb) {
+#pragma unroll
+        for (int tp = 0; tp < 25; ++tp) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int a = a0 + ablk * 16 + 4 * kk + e;
+                if (a < g.Cs) dst[((size_t)tp * g.Cs + a) * g.Cb + b] = acc[tp][e];
+            }
+        }
+    }
+}
+
 static bool wgrad4_tile(const BnGeom& g, Wgrad4Tile* t, size_t* lds_bytes) {
     const int lgQ = ilog2_exact_w4(g.Ws), lgP = ilog2_exact_w4(g.Hs);
     if (lgQ < 2 || lgQ > 5 || lgP < 0) return false;
@@ -256,6 +471,17 @@ static int wgrad4_splits(const BnGeom& g, const Wgrad4Tile& t) {
     return splits;
 }
 
+// stages inside one frame, geometry = the compile-time one of W4S<LGQ>
+static bool wgrad4s_ok(const BnGeom& g, const Wgrad4Tile& t) {
+    static int disabled = -1;                          // BN_WGRAD4S=0: the general kernel only
+    if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4S"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (disabled) return false;
+    const int lgq = ilog2_exact_w4(g.Ws);
+    if (t.F != 1 || lgq < 3 || lgq > 5) return false;
+    if (ilog2_exact_w4(t.tiles_per_frame) < 0) return false;
+    return true;
+}
+
 BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2) return p;
@@ -273,8 +499,12 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
     static const char* const names[6] = {"k_wgrad4_mfma<?>", "k_wgrad4_mfma<?>", "k_wgrad4_mfma<2>",
                                          "k_wgrad4_mfma<3>", "k_wgrad4_mfma<4>", "k_wgrad4_mfma<5>"};
+    // (the second template argument of the streamlined kernel, the fused bias side, is not part
+    // of the plan's name)
+    static const char* const names_s[6] = {"", "", "", "k_wgrad4s_mfma<3>", "k_wgrad4s_mfma<4>",
+                                           "k_wgrad4s_mfma<5>"};
     const int lgq = ilog2_exact_w4(g.Ws);
-    p.kernel_name = names[(lgq >= 2 && lgq <= 5) ? lgq : 0];
+    p.kernel_name = wgrad4s_ok(g, t) ? names_s[lgq] : names[(lgq >= 2 && lgq <= 5) ? lgq : 0];
     return p;
 }
 
@@ -295,6 +525,24 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
     return 0;
 }
 
+template <int LGQ, int BIAS>
+static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const float* big,
+                          float* part, float* bias_part, const BnGeom& g, int n_stages, int splits,
+                          int lg_tpf, int nbias) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<LGQ, BIAS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_MAX_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_wgrad4s_mfma<LGQ, BIAS>), grid, dim3(W4_THREADS),
+                       (size_t)2 * W4S<LGQ>::BUFW * 4, st, small, big, part, bias_part, g, n_stages,
+                       splits, lg_tpf, nbias);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* big, float* dw,
                      const BnGeom& g, int accumulate, void* ws, hipStream_t st, float* db,
                      int bias_side, bool* bias_done) {
@@ -311,6 +559,16 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     const int tiles = ((g.Cs + W4_TA - 1) / W4_TA) * ((g.Cb + W4_TB - 1) / W4_TB);
     dim3 grid(tiles, t.splits);
     int rc = BN_E_SHAPE;
+    if (wgrad4s_ok(g, t)) {
+        const int lgq = ilog2_exact_w4(g.Ws), lg_tpf = ilog2_exact_w4(t.tiles_per_frame);
+#define W4S_CASE(L, B)                                                                         \
+    if (lgq == L && t.bias_side == B)                                                          \
+        rc = launch_wgrad4s<L, B>(grid, st, small, big, (float*)ws, bias_part, g, t.n_stages,  \
+                                  t.splits, lg_tpf, t.nbias);
+        W4S_CASE(3, 0) W4S_CASE(3, 1) W4S_CASE(3, 2) W4S_CASE(4, 0) W4S_CASE(4, 1) W4S_CASE(4, 2)
+        W4S_CASE(5, 0) W4S_CASE(5, 1) W4S_CASE(5, 2)
+#undef W4S_CASE
+    } else
     switch (ilog2_exact_w4(g.Ws)) {
         case 2: rc = launch_wgrad4<2>(grid, lds, st, small, big, (float*)ws, bias_part, g, t); break;
         case 3: rc = launch_wgrad4<3>(grid, lds, st, small, big, (float*)ws, bias_part, g, t); break;

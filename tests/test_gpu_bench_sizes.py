@@ -53,16 +53,16 @@ KERNELS_256 = {
     ('E3', 'fwd'): 'k_down2_mfma<2, 1>',
     ('E1', 'bwd_d'): 'k_up_mfma<1, 4>', ('E2', 'bwd_d'): 'k_up_mfma<1, 4>',
     ('E3', 'bwd_d'): 'k_up_mfma<1, 4>',
-    ('E1', 'bwd_w'): 'k_wgrad4_mfma<5>', ('E2', 'bwd_w'): 'k_wgrad4_mfma<4>',
-    ('E3', 'bwd_w'): 'k_wgrad4_mfma<3>',
+    ('E1', 'bwd_w'): 'k_wgrad4s_mfma<5>', ('E2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
+    ('E3', 'bwd_w'): 'k_wgrad4s_mfma<3>',
     ('E4', 'fwd'): 'k_qgemm<0>', ('E4', 'bwd_d'): 'k_qgemm<1>', ('E4', 'bwd_w'): 'k_qgemm<2>',
     ('D0', 'fwd'): 'k_qgemm<1>', ('D0', 'bwd_d'): 'k_qgemm<0>', ('D0', 'bwd_w'): 'k_qgemm<2>',
     ('D1', 'fwd'): 'k_up_mfma<1, 4>', ('D2', 'fwd'): 'k_up_mfma<1, 4>',
     ('D3', 'fwd'): 'k_up_mfma<1, 4>',
     ('D1', 'bwd_d'): 'k_down2_mfma<2, 1>', ('D2', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
-    ('D1', 'bwd_w'): 'k_wgrad4_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4_mfma<4>',
-    ('D3', 'bwd_w'): 'k_wgrad4_mfma<5>',
+    ('D1', 'bwd_w'): 'k_wgrad4s_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
+    ('D3', 'bwd_w'): 'k_wgrad4s_mfma<5>',
     ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2>', ('D4', 'bwd_w'): 'k_wgrad_c1',
 }
 # the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
