@@ -198,6 +198,270 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streamlined variant for square small images of 8x8 / 16x16 / 32x32 (the bench layers), 32 output
+// channels per workgroup.  Same tiling, MFMA roles and summation order as k_up_mfma<1, CC> above
+// (results are bit-identical); what changed is everything around the MFMAs:
+//  * a VALU instruction that is not an MFMA costs the matrix pipe 6-13 cycles on this chip, and a
+//    wave that is NOT multiplying cannot issue vector-memory instructions at all while another
+//    wave of its SIMD streams MFMAs (tools/lab/issue_probe.hip, coissue_probe.hip).  The kernel
+//    above spends ~1.5 VALU instructions per MFMA (operand addresses, the group decode of the
+//    weight DMA, the register round trip of the input tile) and issues its loads between two
+//    barriers, outside the MFMA stream;
+//  * here the tile geometry is a compile-time function of LGW, so an operand read is
+//    `ds_read_b32 vbase offset:imm`; the input tile arrives by dword LDS-DMA (halo and padding
+//    = out-of-range reads = 0.0f) next to the 16-byte weight DMA, both double buffered, both with
+//    per-thread offsets computed once plus a scalar chunk offset, and both issued from INSIDE the
+//    MFMA stream of the previous chunk; a chunk boundary is one s_waitcnt and one barrier;
+//  * the operand reads of channel pair i+1 sit between the MFMAs of pair i (A values refresh in
+//    place, an MFMA has taken its operands when it issues); sched_barrier pins the order;
+//  * the epilogue batches its loads and is branch-free (buffer stores with out-of-range lanes).
+// ---------------------------------------------------------------------------------------------
+template <int LGW>
+struct UP2 {
+    static constexpr int Ws = 1 << LGW, HW = Ws * Ws, TP = 128;
+    static constexpr int F = HW >= TP ? 1 : TP / HW;
+    static constexpr int AT_H = HW >= TP ? TP / Ws : Ws;
+    static constexpr int lgATW = (HW >= TP) ? 7 : 2 * LGW;          // log2(AT_H * Ws)
+    static constexpr int SWp = Ws + 2, FS = (AT_H + 2) * SWp, CHS = F * FS;
+    static constexpr int CHSP = (CHS + 63) / 64 * 64;                // channel stride in LDS
+    static constexpr int TPF = (F == 1) ? Ws / AT_H : 1;             // tiles per frame
+};
+
+__device__ __forceinline__ void up_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
+}
+__device__ __forceinline__ void up_dma4(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 4, voffset, soffset, 0, 0);
+}
+
+template <int LGW, int CC>
+__global__ __launch_bounds__(MF_THREADS, 2) void k_up2_mfma(
+    const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, int act, int dact,
+    float slope) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using T = UP2<LGW>;
+    constexpr int RS = 25, TM = 32, Ws = T::Ws, HWs = T::HW, SWp = T::SWp;
+    constexpr int XBUF = CC * T::CHSP;                    // floats per input image
+    constexpr int WCH = TM * RS;                          // weight floats per channel
+    constexpr int WGRP = CC * WCH / 4;                    // 16-byte groups per chunk
+    constexpr int WDMA = (WGRP + MF_THREADS - 1) / MF_THREADS;
+    constexpr int WBUF = WDMA * MF_THREADS * 4;           // floats per weight image (whole waves)
+    constexpr int XW = T::CHSP / 64;                      // waves that copy input elements
+    constexpr int OOB = 0x7fffffff;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+
+    const int grp = blockIdx.x / T::TPF;
+    const int rowt = blockIdx.x - grp * T::TPF;
+    const int n0 = grp * T::F;
+    const int a0 = rowt * T::AT_H;
+    const int m0 = blockIdx.y * TM;
+
+    // lane -> position (frame f, row aj, col bj) of the small image
+    const int pos = 32 * wv + li;
+    const int pf = pos >> T::lgATW;
+    const int prem = pos & ((1 << T::lgATW) - 1);
+    const int aj = prem >> LGW, bj = prem & (Ws - 1);
+    const bool pvalid = (n0 + pf) < g.N;
+
+    // ---- DMA descriptors (chunk independent) ---------------------------------------------------
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)g.N * g.Cs * HWs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)w, 0, (int)((size_t)g.Cs * g.Cb * RS * 4), 0x00020000);
+    int xvo = OOB;                                        // element tid of a channel's tile
+    if (tid < T::CHS) {
+        const int f = tid / T::FS, r2 = tid - f * T::FS;
+        const int y = r2 / SWp, x = r2 - y * SWp;
+        const int p = a0 - 1 + y, q = x - 1;
+        const bool ok = (n0 + f < g.N) && p >= 0 && p < Ws && q >= 0 && q < Ws;
+        if (ok) xvo = (f * (g.Cs * HWs) + p * Ws + q) * 4;
+    }
+    int wvo[WDMA];                                        // group tid + 256 k of [cc][m][tap]
+#pragma unroll
+    for (int k = 0; k < WDMA; ++k) {
+        const int e = tid + MF_THREADS * k;
+        const int cc = e / (WCH / 4), within = e - cc * (WCH / 4);
+        wvo[k] = (e < WGRP) ? ((cc * g.Cb + m0) * RS + 4 * within) * 4 : OOB;
+    }
+    // DMA instruction d of chunk c0 into image pair `buf`: d < CC input channel d, else weight slice
+    auto issue_dma = [&](const int d, const int buf, const int c0) __attribute__((always_inline)) {
+        if (d < CC) {
+            if (wv < XW)
+                up_dma4(rs_x, smem + buf * XBUF + d * T::CHSP + 64 * wv, xvo,
+                        (n0 * g.Cs + c0 + d) * HWs * 4);
+        } else {
+            const int k = d - CC;
+            up_dma16(rs_w, smem + 2 * XBUF + buf * WBUF + 4 * (MF_THREADS * k + 64 * wv), wvo[k],
+                     c0 * g.Cb * RS * 4);
+        }
+    };
+    constexpr int NDMA = CC + WDMA;
+
+    floatx16 acc[4];
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[cl][e] = 0.f;
+
+    // ---- operand read bases (byte offsets from smem), one per LDS image --------------------------
+    int xb_cur = (pf * T::FS + (aj + 1) * SWp + (bj + 1) + kk * T::CHSP) * 4;
+    int xb_oth = xb_cur + XBUF * 4;
+    int wa_cur = (2 * XBUF + (kk * TM + li) * RS) * 4;
+    int wa_oth = wa_cur + WBUF * 4;
+    asm volatile("" : "+v"(xb_cur)); asm volatile("" : "+v"(xb_oth));
+    asm volatile("" : "+v"(wa_cur)); asm volatile("" : "+v"(wa_oth));
+    const char* sm = reinterpret_cast<const char*>(smem);
+
+    // tap list of a channel pair in the order of the MFMAs (classes (rho, sigma) = output parity):
+    //   rho = 0: r in {1,3}, dy = -u      rho = 1: r in {0,2,4}, dy = 1 - u   (same for columns)
+    struct Tap { int r, s, dy, dx, cl; };
+    auto tap_of = [](const int j) {
+        int n = 0;
+        Tap tp = {0, 0, 0, 0, 0};
+        for (int rho = 0; rho < 2; ++rho)
+            for (int u = 0; u < 3; ++u) {
+                const int r = ((rho + 1) & 1) + 2 * u;
+                if (r >= 5) continue;
+                for (int sig = 0; sig < 2; ++sig)
+                    for (int v = 0; v < 3; ++v) {
+                        const int s = ((sig + 1) & 1) + 2 * v;
+                        if (s >= 5) continue;
+                        if (n == j) tp = Tap{r, s, ((rho + 1) >> 1) - u + 1, ((sig + 1) >> 1) - v + 1, rho * 2 + sig};
+                        ++n;
+                    }
+            }
+        return tp;
+    };
+    // issue order: the taps of one class keep their order (same sums as k_up_mfma, bit for bit) but
+    // consecutive MFMAs go to different accumulators (a dependent MFMA waits for its predecessor)
+    constexpr int ORDER[25] = {12, 10, 13, 2, 14, 11, 17, 3, 18, 15, 19, 4, 0, 22, 16, 7, 1, 23, 20, 8, 5, 24, 21, 9, 6};
+    auto load_a = [&](const int wa, const int cp, const int jj, float (&a)[25]) __attribute__((always_inline)) {
+        const int j = ORDER[jj];
+        const Tap tp = tap_of(j);
+        a[j] = *reinterpret_cast<const float*>(sm + wa + ((2 * cp) * TM * RS + tp.r * 5 + tp.s) * 4);
+    };
+    auto load_b = [&](const int xb, const int cp, const int i, float (&b)[9]) __attribute__((always_inline)) {
+        const int dy = i / 3, dx = i - 3 * dy;
+        b[i] = *reinterpret_cast<const float*>(sm + xb + ((2 * cp) * T::CHSP + (dy - 1) * SWp + (dx - 1)) * 4);
+    };
+    auto chunk_body = [&](const int xb, const int wa, const int nbuf, const bool more, const int c0n) __attribute__((always_inline)) {
+        float av[25], bv[2][9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) load_b(xb, 0, i, bv[0]);
+#pragma unroll
+        for (int j = 0; j < 25; ++j) load_a(wa, 0, j, av);
+#pragma unroll
+        for (int cp = 0; cp < CC / 2; ++cp) {
+#pragma unroll
+            for (int j = 0; j < 25; ++j) {
+                const Tap tp = tap_of(ORDER[j]);
+                acc[tp.cl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ORDER[j]], bv[cp & 1][tp.dy * 3 + tp.dx],
+                                                                  acc[tp.cl], 0, 0, 0);
+                if (cp + 1 < CC / 2) {
+                    load_a(wa, cp + 1, j, av);                       // refresh in place
+                    if (j >= 8 && j < 17) load_b(xb, cp + 1, j - 8, bv[(cp + 1) & 1]);
+                }
+                // the next chunk's DMA rides in this wave's own MFMA stream, one instruction per slot
+                if (more && cp * 25 + j >= 2 && cp * 25 + j < 2 + NDMA) issue_dma(cp * 25 + j - 2, nbuf, c0n);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    static_assert(NDMA + 2 <= (CC / 2) * 25, "DMA slots");
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) issue_dma(d, 0, 0);
+    int cur = 0;
+    for (int c0 = 0; c0 < g.Cs; c0 += CC) {
+        // own DMA of this chunk landed; after the barrier everyone's has, and every wave is done
+        // reading the other image pair
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        chunk_body(xb_cur, wa_cur, cur ^ 1, c0 + CC < g.Cs, c0 + CC);
+        cur ^= 1;
+        int tmp = xb_cur; xb_cur = xb_oth; xb_oth = tmp;
+        tmp = wa_cur; wa_cur = wa_oth; wa_oth = tmp;
+    }
+
+    // ---- epilogue: lane owns output pixels (2a+rho, 2b+sig) of channel m(e, kk); the two column
+    // classes are adjacent -> one 8-byte store per (channel, row class)
+    const int Wb = g.Wb, HWb = g.Hb * g.Wb;
+    const int obytes = (int)((size_t)g.N * g.Cb * HWb * 4);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)dact_src, 0, dact_src ? obytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)bias, 0, bias ? g.Cb * 4 : 0, 0x00020000);
+    const int mlane = m0 + 4 * kk;
+    const int n = n0 + pf;
+    const int vo = pvalid ? (int)((((size_t)n * g.Cb + mlane) * HWb + (size_t)(2 * (a0 + aj)) * Wb + 2 * bj) * 4) : OOB;
+    typedef float floatx2u __attribute__((ext_vector_type(2)));
+    typedef unsigned int uintx2u __attribute__((ext_vector_type(2)));
+    if (act != BN_ACT_SIGMOID && dact != BN_ACT_SIGMOID) {             // wave-uniform
+        const float es = (act == BN_ACT_LRELU) ? slope : 1.f;           // identity = slope 1
+        const float ds = (dact == BN_ACT_LRELU) ? slope : 1.f;
+        float bz[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            bz[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rbs, (mlane + (e & 3) + 8 * (e >> 2)) * 4, 0, 0));
+#pragma unroll
+        for (int rho = 0; rho < 2; ++rho) {
+            floatx2u d[16];
+            if (dact_src) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int mo = (e & 3) + 8 * (e >> 2);
+                    d[e] = __builtin_bit_cast(floatx2u, __builtin_amdgcn_raw_buffer_load_b64(
+                        rd, (mlane + mo < g.Cb) ? vo : OOB, (mo * HWb + rho * Wb) * 4, 0));
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int mo = (e & 3) + 8 * (e >> 2);
+                floatx2u v;
+                v.x = acc[rho * 2 + 0][e] + bz[e];
+                v.y = acc[rho * 2 + 1][e] + bz[e];
+                v.x = v.x > 0.f ? v.x : v.x * es;
+                v.y = v.y > 0.f ? v.y : v.y * es;
+                if (dact_src) {
+                    v.x *= d[e].x > 0.f ? 1.f : ds;
+                    v.y *= d[e].y > 0.f ? 1.f : ds;
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uintx2u, v), ro,
+                                                      (mlane + mo < g.Cb) ? vo : OOB,
+                                                      (mo * HWb + rho * Wb) * 4, 0);
+            }
+        }
+    } else {
+        if (!pvalid) return;
+        const int h0 = 2 * (a0 + aj), w0 = 2 * bj;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (m >= g.Cb) continue;
+            const float bm = bias ? bias[m] : 0.f;
+#pragma unroll
+            for (int rho = 0; rho < 2; ++rho) {
+                const size_t idx = ((size_t)n * g.Cb + m) * HWb + (size_t)(h0 + rho) * Wb + w0;
+                float2 v;
+                v.x = bn_apply_act(acc[rho * 2 + 0][e] + bm, act, slope);
+                v.y = bn_apply_act(acc[rho * 2 + 1][e] + bm, act, slope);
+                if (dact_src) {
+                    const float2 d = *reinterpret_cast<const float2*>(dact_src + idx);
+                    v.x *= bn_act_grad_from_output(d.x, dact, slope);
+                    v.y *= bn_act_grad_from_output(d.y, dact, slope);
+                }
+                *reinterpret_cast<float2*>(out + idx) = v;
+            }
+        }
+    }
+}
+
 // xl + two weight buffers of whole-wave DMA rows (see WBUF in the kernel)
 static size_t up_lds_bytes(int xl_floats, int MR, int CC) {
     const int wgrp = CC * 32 * MR * 25 / 4;
@@ -236,6 +500,43 @@ static bool up_tile(const BnGeom& g, int MR, int CC, UpTile* t, int* n_wg) {
     return true;
 }
 
+// streamlined kernel: square 8x8 / 16x16 / 32x32 small images, whole chunks of channels
+static bool up2_ok(const BnGeom& g, int* cc_out) {
+    static int mode = -1;                 // BN_UP2=0: off; BN_UP2=8: 8-channel chunks
+    if (mode < 0) { const char* e = bn_tune_env("BN_UP2"); mode = e ? atoi(e) : 4; }
+    if (mode == 0) return false;
+    const int lgw = ilog2_exact_up(g.Ws);
+    if (g.Hs != g.Ws || lgw < 3 || lgw > 5) return false;
+    const int cc = (mode == 8 && (g.Cs % 8) == 0) ? 8 : 4;
+    if ((g.Cs % cc) != 0 || (g.Cb & 3) != 0) return false;
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    *cc_out = cc;
+    return true;
+}
+
+template <int LGW, int CC>
+static int launch_up2(const float* small, const float* w, const float* bias, float* out,
+                      const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                      hipStream_t st) {
+    using T = UP2<LGW>;
+    constexpr int WDMA = (CC * 32 * 25 / 4 + MF_THREADS - 1) / MF_THREADS;
+    constexpr size_t lds = ((size_t)2 * CC * T::CHSP + (size_t)2 * WDMA * MF_THREADS * 4) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_up2_mfma<LGW, CC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int groups = (g.N + T::F - 1) / T::F;
+    dim3 grid(groups * T::TPF, (g.Cb + 31) / 32);
+    hipLaunchKernelGGL((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+                       dact_src, g, act, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 BnFastPlan bn_fast_up_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_up_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2 || g.pt != 1 || g.pl != 1) return p;
@@ -256,6 +557,13 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
     p.c = cc;
     p.kernel_name = p.a == 2 ? (cc == 8 ? "k_up_mfma<2, 8>" : "k_up_mfma<2, 4>")
                              : (cc == 8 ? "k_up_mfma<1, 8>" : "k_up_mfma<1, 4>");
+    if (p.a == 1 && up2_ok(g, &p.c)) {
+        p.variant = 2;
+        const int lgw = ilog2_exact_up(g.Ws);
+        static const char* const n4[6] = {"", "", "", "k_up2_mfma<3, 4>", "k_up2_mfma<4, 4>", "k_up2_mfma<5, 4>"};
+        static const char* const n8[6] = {"", "", "", "k_up2_mfma<3, 8>", "k_up2_mfma<4, 8>", "k_up2_mfma<5, 8>"};
+        p.kernel_name = p.c == 8 ? n8[lgw] : n4[lgw];
+    }
     return p;
 }
 
@@ -264,6 +572,15 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
                       int act, int dact, float slope, void* ws, hipStream_t st) {
     (void)ws;
     const int MR = plan.a, CC = plan.c;
+    if (plan.variant == 2) {
+        const int lgw = ilog2_exact_up(g.Ws);
+#define UP2_CASE(L, C)                                                                          \
+    if (lgw == L && CC == C)                                                                    \
+        return launch_up2<L, C>(small, w, bias, out, dact_src, g, act, dact, slope, st);
+        UP2_CASE(3, 4) UP2_CASE(4, 4) UP2_CASE(5, 4) UP2_CASE(3, 8) UP2_CASE(4, 8) UP2_CASE(5, 8)
+#undef UP2_CASE
+        return BN_E_SHAPE;
+    }
     UpTile t;
     int nwg = 0;
     if (!up_tile(g, MR, CC, &t, &nwg)) return BN_E_SHAPE;

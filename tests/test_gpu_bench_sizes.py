@@ -51,14 +51,14 @@ KERNELS_256 = {
     ('E0', 'fwd'): 'k_down_c1<1, false>', ('E0', 'bwd_w'): 'k_wgrad_c1',
     ('E1', 'fwd'): 'k_down2_mfma<2, 2>', ('E2', 'fwd'): 'k_down2_mfma<2, 2>',
     ('E3', 'fwd'): 'k_down2_mfma<2, 1>',
-    ('E1', 'bwd_d'): 'k_up_mfma<1, 4>', ('E2', 'bwd_d'): 'k_up_mfma<1, 4>',
-    ('E3', 'bwd_d'): 'k_up_mfma<1, 4>',
+    ('E1', 'bwd_d'): 'k_up2_mfma<5, 4>', ('E2', 'bwd_d'): 'k_up2_mfma<4, 4>',
+    ('E3', 'bwd_d'): 'k_up2_mfma<3, 4>',
     ('E1', 'bwd_w'): 'k_wgrad4s_mfma<5>', ('E2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
     ('E3', 'bwd_w'): 'k_wgrad4s_mfma<3>',
     ('E4', 'fwd'): 'k_qgemm<0>', ('E4', 'bwd_d'): 'k_qgemm<1>', ('E4', 'bwd_w'): 'k_qgemm<2>',
     ('D0', 'fwd'): 'k_qgemm<1>', ('D0', 'bwd_d'): 'k_qgemm<0>', ('D0', 'bwd_w'): 'k_qgemm<2>',
-    ('D1', 'fwd'): 'k_up_mfma<1, 4>', ('D2', 'fwd'): 'k_up_mfma<1, 4>',
-    ('D3', 'fwd'): 'k_up_mfma<1, 4>',
+    ('D1', 'fwd'): 'k_up2_mfma<3, 4>', ('D2', 'fwd'): 'k_up2_mfma<4, 4>',
+    ('D3', 'fwd'): 'k_up2_mfma<5, 4>',
     ('D1', 'bwd_d'): 'k_down2_mfma<2, 1>', ('D2', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D1', 'bwd_w'): 'k_wgrad4s_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
