@@ -184,6 +184,12 @@ extern "C" int bn_set_force_generic(int on) {
     return prev;
 }
 
+// the fast kernels move 16-byte groups (LDS-DMA, float4 / float2 accesses): tensors that are not
+// 16-byte aligned (a view at an odd offset) take the shape-agnostic kernels
+static inline bool aligned16_all(const void* a, const void* b, const void* c, const void* d = nullptr) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15u) == 0;
+}
+
 static inline bool ws_ok(const BnFastPlan& p, void* ws, size_t ws_bytes) {
     return p.ws_bytes == 0 || (ws != nullptr && ws_bytes >= p.ws_bytes);
 }
@@ -191,7 +197,8 @@ static inline bool ws_ok(const BnFastPlan& p, void* ws, size_t ws_bytes) {
 static int run_down(int family, const float* big, const float* w, const float* bias, float* out,
                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                     void* ws, size_t ws_bytes, hipStream_t st) {
-    if (!force_generic()) {
+    const bool generic = force_generic() || !aligned16_all(big, w, out, dact_src);
+    if (!generic) {
         const BnFastPlan ed = bn_edge_down_plan(g);
         // epilogues the edge kernel is instantiated for: plain / LeakyReLU forward, or a data
         // gradient carrying the LeakyReLU' mask of the layer below
@@ -204,13 +211,13 @@ static int run_down(int family, const float* big, const float* w, const float* b
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }
     }
-    if (!force_generic() && bn_qgemm_supported(g)) {
+    if (!generic && bn_qgemm_supported(g)) {
         if (!ws || ws_bytes < bn_qgemm_ws_bytes(0, g)) return BN_E_WORKSPACE;
         BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<0>", st);
         return bn_launch_qgemm_down(big, w, bias, out, dact_src, g, act, dact, slope, ws, st);
     }
     BnFastPlan plan = bn_fast_down_plan(g);
-    if (force_generic()) plan.supported = false;
+    if (generic) plan.supported = false;
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_down_generic", st);
     if (plan.supported) {
         if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
@@ -222,19 +229,20 @@ static int run_down(int family, const float* big, const float* w, const float* b
 static int run_up(int family, const float* small, const float* w, const float* bias, float* out,
                   const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                   void* ws, size_t ws_bytes, hipStream_t st) {
-    if (!force_generic() && bn_qgemm_supported(g)) {
+    const bool generic = force_generic() || !aligned16_all(small, w, out, dact_src);
+    if (!generic && bn_qgemm_supported(g)) {
         if (!ws || ws_bytes < bn_qgemm_ws_bytes(1, g)) return BN_E_WORKSPACE;
         BnProfScope prof(family, g.Cs, g.Cb, "k_qgemm<1>", st);
         return bn_launch_qgemm_up(small, w, bias, out, dact_src, g, act, dact, slope, ws, st);
     }
-    if (!force_generic()) {
+    if (!generic) {
         const BnFastPlan s5 = bn_s5_up_plan(g);
         if (s5.supported) {
             BnProfScope prof(family, g.Cs, g.Cb, s5.kernel_name, st);
             return bn_launch_up_s5(small, w, bias, out, dact_src, g, act, dact, slope, st);
         }
     }
-    if (!force_generic() && !dact_src) {
+    if (!generic && !dact_src) {
         const BnFastPlan ed = bn_edge_up_plan(g);
         if (ed.supported) {
             BnProfScope prof(family, g.Cs, g.Cb, ed.kernel_name, st);
@@ -242,7 +250,7 @@ static int run_up(int family, const float* small, const float* w, const float* b
         }
     }
     BnFastPlan plan = bn_fast_up_plan(g);
-    if (force_generic()) plan.supported = false;
+    if (generic) plan.supported = false;
     BnProfScope prof(family, g.Cs, g.Cb, plan.supported ? plan.kernel_name : "k_up_generic", st);
     if (plan.supported) {
         if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
@@ -254,19 +262,20 @@ static int run_up(int family, const float* small, const float* w, const float* b
 static int run_wgrad(int family, const float* small, const float* big, float* dw,
                      const BnGeom& g, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
                      float* db, int bias_side, bool* bias_done) {
-    if (!force_generic() && bn_qgemm_supported(g)) {
+    const bool generic = force_generic() || !aligned16_all(small, big, dw);
+    if (!generic && bn_qgemm_supported(g)) {
         if (!ws || ws_bytes < bn_qgemm_ws_bytes(2, g)) return BN_E_WORKSPACE;
         BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<2>", st);
         return bn_launch_qgemm_wgrad(small, big, dw, g, accumulate, ws, st);
     }
-    if (!force_generic()) {
+    if (!generic) {
         const BnFastPlan s5 = bn_s5_wgrad_plan(g);
         if (s5.supported) {
             BnProfScope prof(family, g.Cb, g.Cs, s5.kernel_name, st);
             return bn_launch_wgrad_s5(small, big, dw, g, accumulate, st);
         }
     }
-    if (!force_generic()) {
+    if (!generic) {
         const BnFastPlan ed = bn_edge_wgrad_plan(g);
         if (ed.supported) {
             if (!ws_ok(ed, ws, ws_bytes)) return BN_E_WORKSPACE;
@@ -276,7 +285,7 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         }
     }
     BnFastPlan plan = bn_fast_wgrad_plan(g);
-    if (force_generic()) plan.supported = false;
+    if (generic) plan.supported = false;
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_wgrad_generic",
                      st);
     if (plan.supported) {

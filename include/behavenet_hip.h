@@ -9,7 +9,9 @@
  *
  * Conventions (all entry points):
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
- *   - tensors are fp32, contiguous, NCHW (images) or row-major (matrices);
+ *   - tensors are fp32, contiguous, NCHW (images) or row-major (matrices); the fast convolution
+ *     kernels need 16-byte aligned base pointers (any allocator gives that; a view at an odd
+ *     offset is served by the shape-agnostic kernels instead);
  *   - the caller owns every buffer; the library never allocates, frees or synchronises;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream);
  *   - return value: 0 on success, a positive hipError_t if a launch failed, a negative

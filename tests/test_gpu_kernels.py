@@ -515,6 +515,41 @@ def test_conv2d_fwd_u8(case_name, act):
     assert torch.equal(got, via_float), 'u8 path differs from the float kernel on u8/255'
 
 
+def _misaligned(t):
+    """Contiguous copy of ``t`` whose storage starts 4 bytes past a 16-byte boundary."""
+    buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=DEV)
+    v = buf[1:].view(t.shape)
+    v.copy_(t)
+    assert v.data_ptr() % 16 == 4 and v.is_contiguous()
+    return v
+
+
+@pytest.mark.parametrize('case_name', ['E1', 'E3'])
+def test_conv2d_on_unaligned_views(case_name):
+    """Tensors that are not 16-byte aligned (views at an odd offset) must not reach the kernels
+    that move 16-byte groups: forward, data and weight gradient equal the aligned call's oracle."""
+    case = [c for c in CONV_CASES if c[0] == case_name][0]
+    x, w, b, geom, pad = _conv_setup(case, seed=3)
+    want = act_ref(F.conv2d(F.pad(x, pad), w, b, stride=geom[7]), _hip.ACT_LRELU)
+    want64 = act_ref(F.conv2d(F.pad(x.double(), pad), w.double(), b.double(), stride=geom[7]),
+                     _hip.ACT_LRELU)
+    for which in ('x', 'w'):
+        xd = _misaligned(x) if which == 'x' else x.to(DEV)
+        wd = _misaligned(w) if which == 'w' else w.to(DEV)
+        got = _hip.conv2d_fwd(xd, wd, b.to(DEV), geom, _hip.ACT_LRELU, SLOPE)
+        close(got, want, want64, name='%s unaligned %s' % (case_name, which))
+    # transposed-conv direction through the same weights (gather-up family)
+    dy = torch.rand(want.shape, generator=torch.Generator().manual_seed(4)) - 0.5
+    dx_want = torch.nn.grad.conv2d_input(F.pad(x, pad).shape, w, dy, stride=geom[7])
+    pl, pr, pt, pb = pad
+    H, W = geom[2], geom[3]
+    dx_want = dx_want[:, :, pt:pt + H, pl:pl + W]
+    dx64 = torch.nn.grad.conv2d_input(F.pad(x, pad).shape, w.double(), dy.double(), stride=geom[7])
+    dx64 = dx64[:, :, pt:pt + H, pl:pl + W]
+    got = _hip.conv2d_bwd_data(_misaligned(dy), w.to(DEV), geom, None, _hip.ACT_NONE, SLOPE)
+    close(got, dx_want, dx64, name=case_name + ' unaligned dy')
+
+
 def test_errors_are_loud():
     x = torch.zeros((1, 1, 8, 8))
     with pytest.raises(_hip.HipLibraryError):
