@@ -225,6 +225,17 @@ __global__ __launch_bounds__(GEN_THREADS) void k_channel_sum_part(
     const int n_beg = (int)((long)sp * N / S), n_end = (int)((long)(sp + 1) * N / S);
     float acc = 0.f;
     const bool vec = (npix & 3) == 0 && ((((uintptr_t)t) & 15u) == 0);
+    const int per = npix >> 2;                       // float4 groups of one plane
+    if (vec && per < GEN_THREADS && (GEN_THREADS % per) == 0) {
+        // small planes (8x8 maps): a thread keeps its group position and walks the frames, the
+        // block covers GEN_THREADS / per frames per pass (one plane per frame would leave most
+        // lanes idle)
+        const int fpp = GEN_THREADS / per, q = threadIdx.x % per;
+        for (int n = n_beg + threadIdx.x / per; n < n_end; n += fpp) {
+            const float4 v = reinterpret_cast<const float4*>(t + ((size_t)n * C + c) * npix)[q];
+            acc += (v.x + v.y) + (v.z + v.w);
+        }
+    } else
     for (int n = n_beg; n < n_end; ++n) {
         const float* tp = t + ((size_t)n * C + c) * npix;
         if (vec) {
@@ -252,7 +263,7 @@ __global__ void k_channel_sum_final(const float* __restrict__ part, float* __res
 }
 
 static int channel_sum_splits(int N, int C, int npix) {
-    if ((long)N * npix < 32768) return 1;
+    if ((long)N * npix < 8192) return 1;
     int s = 1024 / C;
     if (s > 256) s = 256;     // one channel (dec.convT4's bias): 256 frame slices
     if (s > N) s = N;

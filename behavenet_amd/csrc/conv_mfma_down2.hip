@@ -156,20 +156,29 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
 
     // 16-byte LDS-DMA; the chunk-dependent part of the address is the scalar offset (unsigned,
     // added after the range check: padding / tail groups keep reading 0.0f)
-    auto issue_image = [&](int c0, int buf) {
-        const int cbase = (n0 * g.Cb + c0) * HW * 4;
-#pragma unroll
-        for (int k = 0; k < D2_XK; ++k) {
-            if (D2_THREADS * k + 64 * wv < t.groups)              // wave-uniform
-                d2_dma16(rbig, smem + buf * D2_XBUF_FLOATS + 4 * (D2_THREADS * k + 64 * wv),
-                         xoff[k], cbase);
-        }
+    auto issue_image = [&](const int k, int c0, int buf) __attribute__((always_inline)) {
+        if (D2_THREADS * k + 64 * wv < t.groups)                      // wave-uniform
+            d2_dma16(rbig, smem + buf * D2_XBUF_FLOATS + 4 * (D2_THREADS * k + 64 * wv), xoff[k],
+                     (n0 * g.Cb + c0) * HW * 4);
     };
-    auto issue_weights = [&](int c0) {
+    // The weight slice of the NEXT chunk travels through registers: 16-byte buffer loads issued from
+    // inside this wave's MFMA stream, written to LDS at the chunk boundary.  A wave that is not
+    // multiplying cannot issue vector-memory instructions while the wave it shares the SIMD with is
+    // (tools/lab/coissue_probe.hip) -- with the slice fetched by LDS-DMA at the boundary, the two
+    // workgroups of a CU alternated and every hand-over exposed the DMA latency (1.1 k cycles per
+    // 13.2 k-cycle chunk); LDS writes and barriers are not held up, so a boundary made of those is
+    // finished long before the other workgroup's loop is.
+    typedef unsigned int d2_u4 __attribute__((ext_vector_type(4)));
+    d2_u4 wreg[WK];
+    auto load_weights = [&](const int k, int c0) __attribute__((always_inline)) {
+        if (D2_THREADS * k + 64 * wv < WG)                            // wave-uniform
+            wreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[k], c0 * RS * 4, 0);
+    };
+    auto store_weights = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < WK; ++k) {
             if (D2_THREADS * k + 64 * wv < WG)
-                d2_dma16(rw, wl + 4 * (D2_THREADS * k + 64 * wv), woff[k], c0 * RS * 4);
+                *reinterpret_cast<d2_u4*>(wl + 4 * (D2_THREADS * k + tid)) = wreg[k];
         }
     };
 
@@ -247,34 +256,41 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
                     for (int u = (j * NU) / NM; u < ((j + 1) * NU) / NM; ++u)
                         load_unit(BUF, it + 1, u, av[(it + 1) & 1], bv[(it + 1) & 1]);
                 }
+                // the next chunk's loads ride in this stream, one instruction per slot
+                const int sl = it * NM + j;
+                if (sl >= 1 && sl < 1 + D2_XK) { if (c0 + CC < g.Cb) issue_image(sl - 1, c0 + CC, BUF ^ 1); }
+                if (sl >= 1 + D2_XK && sl < 1 + D2_XK + WK) { if (c0 + CC < g.Cb) load_weights(sl - 1 - D2_XK, c0 + CC); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    auto boundary = [&](int c0, const int BUF) __attribute__((always_inline)) {
+    static_assert(1 + D2_XK + WK <= NIT * NM, "load slots");
+    auto boundary = [&](int c0) __attribute__((always_inline)) {
         if (c0 == 2 * CC) D2_MARK(22);
         __syncthreads();   // the previous chunk's MFMA reads of wl (and of the other image) are done
         if (c0 == 2 * CC) D2_MARK(23);
-        issue_weights(c0);
+        store_weights();
         if (c0 == 2 * CC) D2_MARK(24);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own groups of this chunk landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own image groups landed
         if (c0 == 2 * CC) D2_MARK(25);
         __syncthreads();
         if (c0 == 2 * CC) D2_MARK(26);
-        if (c0 + CC < g.Cb) issue_image(c0 + CC, BUF ^ 1);   // in flight behind the MFMAs below
         if (c0 == 2 * CC) D2_MARK(27);
     };
 
     D2_MARK(3);
-    issue_image(0, 0);
+#pragma unroll
+    for (int k = 0; k < D2_XK; ++k) issue_image(k, 0, 0);
+#pragma unroll
+    for (int k = 0; k < WK; ++k) load_weights(k, 0);
     for (int c0 = 0; c0 < g.Cb; c0 += 2 * CC) {
         if (c0 < 6 * CC) D2_MARK(4 + 2 * (c0 / CC));
-        boundary(c0, 0);
+        boundary(c0);
         if (c0 < 6 * CC) D2_MARK(5 + 2 * (c0 / CC));
         chunk_rows(0, c0);
         if (c0 + CC < g.Cb) {
             if (c0 < 4 * CC) D2_MARK(6 + 2 * (c0 / CC));
-            boundary(c0 + CC, 1);
+            boundary(c0 + CC);
             if (c0 < 4 * CC) D2_MARK(7 + 2 * (c0 / CC));
             chunk_rows(1, c0 + CC);
         }
