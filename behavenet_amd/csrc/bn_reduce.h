@@ -12,6 +12,24 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__
                                                        int splits, int accumulate, int ab_elems,
                                                        int ntap, int row_len, int row_stride);
 
+// the same for two reductions of one launch (a weight gradient and its bias gradient): blocks
+// [0, blocks_a) do job A, the rest job B (plain layout); `splits` is common
+__global__ __launch_bounds__(256) void k_sum_partials_pair(
+    const float* __restrict__ part_a, float* __restrict__ out_a, int total_a, int ab_elems, int ntap,
+    const float* __restrict__ part_b, float* __restrict__ out_b, int total_b, int splits,
+    int accumulate, int blocks_a);
+
+static inline int bn_launch_sum_partials_pair(const float* part_a, float* out_a, int total_a,
+                                              int ab_elems, int ntap, const float* part_b,
+                                              float* out_b, int total_b, int splits, int accumulate,
+                                              hipStream_t st) {
+    const int blocks_a = (total_a + 63) / 64, blocks_b = (total_b + 63) / 64;
+    hipLaunchKernelGGL(k_sum_partials_pair, dim3(blocks_a + blocks_b), dim3(256), 0, st, part_a, out_a,
+                       total_a, ab_elems, ntap, part_b, out_b, total_b, splits, accumulate, blocks_a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 static inline int bn_launch_sum_partials(const float* part, float* out, int total, int splits,
                                          int accumulate, int ab_elems, int ntap, hipStream_t st,
                                          int row_len = 0, int row_stride = 0) {

@@ -231,7 +231,7 @@ static int run_up(int family, const float* small, const float* w, const float* b
                   void* ws, size_t ws_bytes, hipStream_t st) {
     const bool generic = force_generic() || !aligned16_all(small, w, out, dact_src);
     if (!generic && bn_qgemm_supported(g)) {
-        if (!ws || ws_bytes < bn_qgemm_ws_bytes(1, g)) return BN_E_WORKSPACE;
+        if (bn_qgemm_ws_bytes(1, g) && (!ws || ws_bytes < bn_qgemm_ws_bytes(1, g))) return BN_E_WORKSPACE;
         BnProfScope prof(family, g.Cs, g.Cb, "k_qgemm<1>", st);
         return bn_launch_qgemm_up(small, w, bias, out, dact_src, g, act, dact, slope, ws, st);
     }

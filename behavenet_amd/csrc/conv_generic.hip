@@ -334,3 +334,40 @@ __global__ __launch_bounds__(1024) void k_sum_partials(const float* __restrict__
         out[o] = accumulate ? out[o] + v : v;
     }
 }
+
+__global__ __launch_bounds__(256) void k_sum_partials_pair(
+    const float* __restrict__ part_a, float* __restrict__ out_a, int total_a, int ab_elems, int ntap,
+    const float* __restrict__ part_b, float* __restrict__ out_b, int total_b, int splits,
+    int accumulate, int blocks_a) {
+    __shared__ float red[4][64];
+    const bool job_b = (int)blockIdx.x >= blocks_a;                  // block-uniform
+    const float* part = job_b ? part_b : part_a;
+    float* out = job_b ? out_b : out_a;
+    const int total = job_b ? total_b : total_a;
+    const int il = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const int i = (job_b ? (int)blockIdx.x - blocks_a : (int)blockIdx.x) * 64 + il;
+    // same association as k_sum_partials with 4 z-lanes
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+        int z = zl;
+        for (; z + 12 < splits; z += 16) {
+            s0 += part[(size_t)z * total + i];
+            s1 += part[(size_t)(z + 4) * total + i];
+            s2 += part[(size_t)(z + 8) * total + i];
+            s3 += part[(size_t)(z + 12) * total + i];
+        }
+        for (; z < splits; z += 4) s0 += part[(size_t)z * total + i];
+    }
+    red[zl][il] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zl == 0 && i < total) {
+        const float v = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+        size_t o = i;
+        if (!job_b && ab_elems > 0) {
+            const int tap = i / ab_elems;
+            o = (size_t)(i - tap * ab_elems) * ntap + tap;
+        }
+        out[o] = accumulate ? out[o] + v : v;
+    }
+}
+

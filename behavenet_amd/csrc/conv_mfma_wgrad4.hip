@@ -577,12 +577,13 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         default: break;
     }
     if (rc) return rc;
-    rc = bn_launch_sum_partials((const float*)ws, dw, 25 * g.Cs * g.Cb, t.splits, accumulate,
-                                g.Cs * g.Cb, 25, st);
-    if (rc) return rc;
     if (fuse) {
-        rc = bn_launch_sum_partials(bias_part, db, t.nbias, t.splits, accumulate, 0, 0, st);
+        // one launch adds up the partial tiles and the partial bias rows
+        rc = bn_launch_sum_partials_pair((const float*)ws, dw, 25 * g.Cs * g.Cb, g.Cs * g.Cb, 25,
+                                         bias_part, db, t.nbias, t.splits, accumulate, st);
         if (bias_done) *bias_done = true;
+        return rc;
     }
-    return rc;
+    return bn_launch_sum_partials((const float*)ws, dw, 25 * g.Cs * g.Cb, t.splits, accumulate,
+                                  g.Cs * g.Cb, 25, st);
 }

@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
     const int zp = z >> 1, zq = z & 1;
 
     // staging assignment: 8 elements of each operand tile per thread, as two 16-byte loads along
-    // the contiguous direction of the tensor wherever there is one.  `a.small` is the z-major
-    // copy [z][n][m] written by k_qg_split_small.
+    // the contiguous direction of the tensor wherever there is one.  The up role reads the small
+    // side from the z-major copy [z][n][m] written by k_qg_split_small; the weight gradient, whose
+    // loads are scalar either way, reads small[n][m][z] in place.
     //   A tile As[row][k]: thread (ar, ak..ak+7);  B tile Bs[col][k]: down (br, bk..bk+7),
     //   up / wgrad: k row bk, columns br..br+7
     int ar, ak, br, bk;
@@ -82,7 +83,6 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
     if (MODE == QG_DOWN)  { br = tid >> 2; bk = (tid & 3) * 8; }
     else                  { bk = tid >> 3; br = (tid & 7) * 8; }
     const bool a_ok = (i0 + ar) < a.M;
-    const size_t plane = (size_t)a.N * a.Cs;            // one quadrant of the z-major small copy
 
     float ra[8], rb[QG_NB][8];
     auto fetch = [&](int k0) {
@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
             }
         } else if (MODE == QG_UP) {
             if (a_ok) {
-                const float* src = a.small + (size_t)z * plane + (size_t)(i0 + ar) * a.Cs + k0 + ak;
+                // z-major copy [z][n][m] written by k_qg_split_small (in place the eight channels
+                // would be eight dword loads 16 bytes apart: 65 instead of 52 us)
+                const float* src = a.small + (size_t)z * a.N * a.Cs + (size_t)(i0 + ar) * a.Cs + k0 + ak;
                 v0 = *reinterpret_cast<const floatx4a*>(src);
                 v1 = *reinterpret_cast<const floatx4a*>(src + 4);
             }
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = k0 + ak + e;
-                ra[e] = (k < kend) ? a.small[(size_t)z * plane + (size_t)k * a.Cs + i0 + ar] : 0.f;
+                ra[e] = (k < kend) ? a.small[((size_t)k * a.Cs + i0 + ar) * 4 + z] : 0.f;
             }
         } else {
             ra[0] = v0.x; ra[1] = v0.y; ra[2] = v0.z; ra[3] = v0.w;
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
     }
 }
 
-// small[n][m][z] -> z-major copy [z][n][m] (the A operand of the up / wgrad roles is then
-// contiguous along its GEMM row or reduction index)
+// small[n][m][z] -> z-major copy [z][n][m] (the A operand of the up role is then contiguous along
+// its reduction index)
 __global__ __launch_bounds__(256) void k_qg_split_small(const float* __restrict__ small,
                                                         float* __restrict__ dst, size_t nm) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -244,29 +246,60 @@ __global__ __launch_bounds__(256) void k_qg_finish_down(
     out[idx] = v;
 }
 
-// dW[m][c][r][s] (+)= sum over the quadrants whose window has tap (r, s), fixed order
+// dW[m][c][r][s] (+)= sum over the quadrants whose window has tap (r, s), fixed order.
+// A thread owns one (m, c): it reads its four 16-float quadrant blocks with 16-byte loads (rows of
+// consecutive threads are adjacent), the 25 results of a block of 256 pairs go through LDS so that
+// the weight-gradient tensor is read (accumulate) and written in 16-byte runs.
 __global__ __launch_bounds__(256) void k_qg_finish_wgrad(
     const float* __restrict__ part, float* __restrict__ dw, int Cs, int Cb, int accumulate) {
-    const size_t total = (size_t)Cs * Cb * 25;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int tap = (int)(idx % 25);
-    const size_t mc = idx / 25;                       // m * Cb + c
-    const int r = tap / 5, s = tap - 5 * r;
-    const size_t plane = (size_t)Cs * Cb * 16;
-    float v = 0.f;
+    __shared__ __attribute__((aligned(16))) float stage[256 * 25];
+    const size_t npair = (size_t)Cs * Cb;
+    const size_t mc = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t plane = npair * 16;
+    if (mc < npair) {
+        float q[4][16];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int yy = r - (p ? 0 : 1);
-        if (yy < 0 || yy > 3) continue;
+        for (int zq = 0; zq < 4; ++zq)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int xx = s - (q ? 0 : 1);
-            if (xx < 0 || xx > 3) continue;
-            v += part[(size_t)(2 * p + q) * plane + mc * 16 + 4 * yy + xx];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const floatx4a v = *reinterpret_cast<const floatx4a*>(part + zq * plane + mc * 16 + 4 * g4);
+                q[zq][4 * g4 + 0] = v.x; q[zq][4 * g4 + 1] = v.y; q[zq][4 * g4 + 2] = v.z; q[zq][4 * g4 + 3] = v.w;
+            }
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            const int r = tap / 5, s = tap - 5 * r;
+            float v = 0.f;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int yy = r - (p ? 0 : 1);
+                if (yy < 0 || yy > 3) continue;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int xx = s - (qq ? 0 : 1);
+                    if (xx < 0 || xx > 3) continue;
+                    v += q[2 * p + qq][4 * yy + xx];
+                }
+            }
+            stage[threadIdx.x * 25 + tap] = v;
         }
     }
-    dw[idx] = accumulate ? dw[idx] + v : v;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * 256 * 25;           // multiple of 4 floats
+    const size_t total = npair * 25;
+    for (int i = threadIdx.x; i < 256 * 25 / 4; i += 256) {
+        const size_t o = base + 4 * (size_t)i;
+        if (o + 3 < total) {
+            floatx4a v = *reinterpret_cast<const floatx4a*>(stage + 4 * i);
+            if (accumulate) {
+                const floatx4a d = *reinterpret_cast<const floatx4a*>(dw + o);
+                v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+            }
+            *reinterpret_cast<floatx4a*>(dw + o) = v;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (o + e < total) dw[o + e] = accumulate ? dw[o + e] + stage[4 * i + e] : stage[4 * i + e];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -296,9 +329,8 @@ static int qg_down_splits(const BnGeom& g) {
 
 size_t bn_qgemm_ws_bytes(int role, const BnGeom& g) {
     if (role == QG_DOWN) return (size_t)qg_down_splits(g) * 4 * g.N * g.Cs * sizeof(float);
-    const size_t split_small = (size_t)4 * g.N * g.Cs * sizeof(float);
-    if (role == QG_UP) return split_small;
-    return (size_t)4 * g.Cs * g.Cb * 16 * sizeof(float) + split_small;
+    if (role == QG_UP) return (size_t)4 * g.N * g.Cs * sizeof(float);
+    return (size_t)4 * g.Cs * g.Cb * 16 * sizeof(float);
 }
 
 int bn_launch_qgemm_down(const float* big, const float* w, const float* bias, float* out,
@@ -337,19 +369,14 @@ int bn_launch_qgemm_up(const float* small, const float* w, const float* bias, fl
 
 int bn_launch_qgemm_wgrad(const float* small, const float* big, float* dw, const BnGeom& g,
                           int accumulate, void* ws, hipStream_t st) {
-    float* zsmall = (float*)ws + (size_t)4 * g.Cs * g.Cb * 16;
-    const size_t nm = (size_t)g.N * g.Cs;
-    hipLaunchKernelGGL(k_qg_split_small, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, st, small,
-                       zsmall, nm);
-    BN_LAUNCH_CHECK();
-    QGArgs a = {zsmall, big, nullptr, (float*)ws, g.N, g.Cs, g.Cb, g.Cs, g.Cb * 16, g.N, 0,
+    QGArgs a = {small, big, nullptr, (float*)ws, g.N, g.Cs, g.Cb, g.Cs, g.Cb * 16, g.N, 0,
                 nullptr, nullptr, nullptr, 0, 0, 0.f};
     a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
     const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4);
     hipLaunchKernelGGL(k_qgemm<QG_WGRAD>, grid, dim3(256), 0, st, a);
     BN_LAUNCH_CHECK();
-    const size_t total = (size_t)g.Cs * g.Cb * 25;
-    hipLaunchKernelGGL(k_qg_finish_wgrad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+    const size_t npair = (size_t)g.Cs * g.Cb;
+    hipLaunchKernelGGL(k_qg_finish_wgrad, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, st,
                        (const float*)ws, dw, g.Cs, g.Cb, accumulate);
     BN_LAUNCH_CHECK();
     return 0;

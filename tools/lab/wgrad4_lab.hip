@@ -7,6 +7,7 @@
 #include <algorithm>
 #include "../../behavenet_amd/csrc/conv_mfma_wgrad4.hip"
 __global__ __launch_bounds__(1024) void k_sum_partials(const float*, float*, int, int, int, int, int, int, int) {}
+__global__ __launch_bounds__(256) void k_sum_partials_pair(const float*, float*, int, int, int, const float*, float*, int, int, int, int) {}
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
