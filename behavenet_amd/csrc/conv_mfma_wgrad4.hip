@@ -282,7 +282,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         const int pix0 = 4 * ((e & 15) ^ (a & 15));                  // swizzled source group
         soff[j] = (a0 + a < g.Cs) ? ((a0 + a) * PQ + pix0) * 4 : W4_OOB;
     }
-    int voff[T::NBIG], yrow[T::NBIG];
+    // rows above the image exist only in a frame's first tile (patch row 0), rows below it only in
+    // its last tile (the last two patch rows; Hb == 2 Hs): two class bits per group, all groups of
+    // a thread packed into one register
+    int voff[T::NBIG], rowcls = 0;
 #pragma unroll
     for (int j = 0; j < T::NBIG; ++j) {
         const int e = tid + W4_THREADS * j;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         const int wb = 4 * c4 - W4_X0;
         const bool ok = (e < T::BIGG) && (within < T::ROWG) && (b0 + b < g.Cb) && wb >= 0 && wb < g.Wb;
         voff[j] = ok ? (((b0 + b) * g.Hb + y) * g.Wb + wb) * 4 : W4_OOB;
-        yrow[j] = y;
+        rowcls |= ((y == 0 ? 1 : 0) | (y >= T::IH - 2 ? 2 : 0)) << (2 * j);
     }
     // one DMA instruction of stage `st` into image `buf`: d < NSM small tile, else big tile
     auto issue_dma = [&](const int d, const int buf, const int n0, const int p0) __attribute__((always_inline)) {
@@ -302,8 +305,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
             const int j = d - T::NSM;
             if (W4_THREADS * j + 64 * wv < T::BIGG) {                 // wave-uniform
                 // rows above the image (first tile) and below it (last tile) read 0.0f
-                const int ymin = p0 == 0 ? 1 : 0, ylim = g.Hb + 1 - 2 * p0;
-                const int vo = (yrow[j] >= ymin && yrow[j] < ylim) ? voff[j] : W4_OOB;
+                const int smask = ((p0 == 0 ? 1 : 0) | (p0 + T::PT_H >= g.Hs ? 2 : 0)) << (2 * j);
+                const int vo = (rowcls & smask) ? W4_OOB : voff[j];
                 w4_dma16(rs_big, sl + T::SMALLW + 4 * (W4_THREADS * j + 64 * wv), vo,
                          (n0 * g.Cb * g.Hb + 2 * p0) * g.Wb * 4);
             }
@@ -352,14 +355,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             if (BIAS == 1) bsum += av[ks & 1];
-            if (BIAS == 2) {                                       // taps (1,1) (1,2) | (2,1) (2,2)
-                bsum += bv[6] + bv[7];
-                bsum += bv[11] + bv[12];
-            }
 #pragma unroll
             for (int tp = 0; tp < 25; ++tp) {
                 const int r = tp / 5, sx = tp - 5 * r;
                 acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1], bv[tp], acc[tp], 0, 0, 0);
+                // bias side 2: taps (1,1) (1,2), then (2,1) (2,2), right behind their last MFMA
+                if (BIAS == 2 && tp == 7) bsum += bv[6] + bv[7];
+                if (BIAS == 2 && tp == 12) bsum += bv[11] + bv[12];
                 // row r-1 of the NEXT k-step goes into its registers during row r (r >= 1); row 4
                 // follows during row 0 of the next k-step
                 if (r >= 1 && ks + 1 < 16 && (sx == 0 || sx == 2)) load_row(bb, ks + 1, r - 1, sx >> 1, bv);
@@ -478,6 +480,7 @@ static bool wgrad4s_ok(const BnGeom& g, const Wgrad4Tile& t) {
     if (disabled) return false;
     const int lgq = ilog2_exact_w4(g.Ws);
     if (t.F != 1 || lgq < 3 || lgq > 5) return false;
+    if (g.Hb != 2 * g.Hs) return false;                // the row classes of the DMA assume it
     if (ilog2_exact_w4(t.tiles_per_frame) < 0) return false;
     return true;
 }

@@ -182,7 +182,47 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
 
     if (MODE == QG_UP) {
         // out_b[n][c][pix(z, j & 15)] = epi(acc + bias[c]): 16-byte runs per lane group; the other
-        // half of each 32-byte sector belongs to the neighbouring quadrant's workgroup
+        // half of each 32-byte sector belongs to the neighbouring quadrant's workgroup.  Loads are
+        // batched ahead of the stores and everything is branch-free (buffer accesses whose lane
+        // offset is out of range for rows that do not exist): a load -> wait -> store chain per
+        // element drains the memory queue 32 times per lane.
+        const int obytes = (int)((size_t)a.M * a.Cb * 64 * 4);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, obytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.dact_src, 0, a.dact_src ? obytes : 0, 0x00020000);
+        const int row_bytes = a.Cb * 64 * 4;
+        const int irow = i0 + (wv >> 1) * 32 + 4 * lk;                 // + (t&3) + 8*(t>>2)
+        if (a.act != BN_ACT_SIGMOID && a.dact != BN_ACT_SIGMOID) {     // wave-uniform
+            const float es = (a.act == BN_ACT_LRELU) ? a.slope : 1.f;   // identity = slope 1
+            const float ds = (a.dact == BN_ACT_LRELU) ? a.slope : 1.f;
+#pragma unroll
+            for (int h = 0; h < QG_NB; ++h) {
+                const int j = j0 + QG_T * h + (wv & 1) * 32 + li;
+                const int c = j >> 4;
+                const float bj = a.bias ? a.bias[c] : 0.f;
+                const int vo = (irow * a.Cb * 64 + c * 64 + qg_pix(z, j & 15)) * 4;
+                float d[16];
+                if (a.dact_src) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int ro_t = (t & 3) + 8 * (t >> 2);
+                        d[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rd, (irow + ro_t < a.M) ? vo : 0x7fffffff, ro_t * row_bytes, 0));
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int ro_t = (t & 3) + 8 * (t >> 2);
+                    float v = acc[h][t] + bj;
+                    v = v > 0.f ? v : v * es;
+                    if (a.dact_src) v *= d[t] > 0.f ? 1.f : ds;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro,
+                                                          (irow + ro_t < a.M) ? vo : 0x7fffffff,
+                                                          ro_t * row_bytes, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < QG_NB; ++h) {
             const int j = j0 + QG_T * h + (wv & 1) * 32 + li;
