@@ -84,64 +84,75 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
     else                  { bk = tid >> 3; br = (tid & 7) * 8; }
     const bool a_ok = (i0 + ar) < a.M;
 
+    // Global loads of a stage: buffer loads whose lane offsets are computed ONCE; a stage only adds
+    // a scalar offset (every operand advances by a constant number of bytes per 32-deep stage).
+    // They are issued from inside the MFMA stream of the previous stage: between two barriers, as
+    // before, their ~35 address instructions and 6 loads were vector work that no wave can issue
+    // while another wave of its SIMD multiplies (issue rules).
+    constexpr int OOB = 0x7fffffff;
+    const void* a_base = (MODE == QG_DOWN) ? (const void*)a.big : (const void*)a.small;
+    const size_t a_bytes = (MODE == QG_DOWN) ? (size_t)a.N * a.Cb * 64 * 4 : (size_t)a.N * a.Cs * 4 * 4;
+    const void* b_base = (MODE == QG_WGRAD) ? (const void*)a.big : (const void*)a.w;
+    const size_t b_bytes = (MODE == QG_WGRAD) ? (size_t)a.N * a.Cb * 64 * 4 : (size_t)a.Cs * a.Cb * 25 * 4;
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)b_base, 0, (int)b_bytes, 0x00020000);
+    int avo, bvo[QG_NB], a_step, b_step, a_e = 0;                 // bytes
+    if (MODE == QG_DOWN) {
+        // A = big[n][c][4x4 block of quadrant z]: k = 16 c + 4 y' + x'
+        avo = (((i0 + ar) * a.Cb + (ak >> 4)) * 64 + (4 * zp + ((ak & 15) >> 2)) * 8 + 4 * zq) * 4;
+        a_step = 2 * 64 * 4;
+    } else if (MODE == QG_UP) {
+        // z-major copy [z][n][m] written by k_qg_split_small
+        avo = (z * a.N * a.Cs + (i0 + ar) * a.Cs + ak) * 4;
+        a_step = QG_KS * 4;
+    } else {
+        // small[n][m][z] in place: rows k = frames
+        avo = ((ak * a.Cs + i0 + ar) * 4 + z) * 4;
+        a_e = a.Cs * 16;
+        a_step = QG_KS * a.Cs * 16;
+    }
+    if (!a_ok) avo = OOB;
+#pragma unroll
+    for (int h = 0; h < QG_NB; ++h) {
+        const int jc = j0 + QG_T * h + br;              // this thread's (first) column of granule h
+        if (MODE == QG_DOWN)
+            // B = W[m][c][16 taps of quadrant z]: two runs of four taps, five floats apart
+            bvo[h] = ((jc * a.Cb + (bk >> 4)) * 25 + ((zp ? 0 : 1) + ((bk & 15) >> 2)) * 5 + (zq ? 0 : 1)) * 4;
+        else if (MODE == QG_UP)
+            bvo[h] = ((bk * a.Cb + (jc >> 4)) * 25 + ((zp ? 0 : 1) + ((jc & 15) >> 2)) * 5 + (zq ? 0 : 1)) * 4;
+        else
+            bvo[h] = ((bk * a.Cb + (jc >> 4)) * 64 + (4 * zp + ((jc & 15) >> 2)) * 8 + 4 * zq) * 4;
+    }
+    b_step = (MODE == QG_DOWN) ? 2 * 25 * 4 : (MODE == QG_UP ? QG_KS * a.Cb * 25 * 4 : QG_KS * a.Cb * 64 * 4);
+    constexpr int B2ND = (MODE == QG_WGRAD) ? 32 : 20;  // second 16-byte run of the B operand
+
     float ra[8], rb[QG_NB][8];
-    auto fetch = [&](int k0) {
-        floatx4a v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-        if (MODE == QG_DOWN) {
-            // A = big[n][c][4x4 block of quadrant z]: k = 16 c + 4 y' + x'
-            const int k = k0 + ak;
-            if (a_ok) {
-                const float* src = a.big + ((size_t)(i0 + ar) * a.Cb + (k >> 4)) * 64 +
-                                   (4 * zp + ((k & 15) >> 2)) * 8 + 4 * zq;
-                v0 = *reinterpret_cast<const floatx4a*>(src);
-                v1 = *reinterpret_cast<const floatx4a*>(src + 8);
-            }
-        } else if (MODE == QG_UP) {
-            if (a_ok) {
-                // z-major copy [z][n][m] written by k_qg_split_small (in place the eight channels
-                // would be eight dword loads 16 bytes apart: 65 instead of 52 us)
-                const float* src = a.small + (size_t)z * a.N * a.Cs + (size_t)(i0 + ar) * a.Cs + k0 + ak;
-                v0 = *reinterpret_cast<const floatx4a*>(src);
-                v1 = *reinterpret_cast<const floatx4a*>(src + 4);
-            }
-        }
+    // stage number sidx (0 = the split's first); tail: the weight gradient's last stage may reach
+    // past the last frame (K = N): lanes beyond it read 0.0f
+    auto fetch = [&](const int sidx, const int k0) __attribute__((always_inline)) {
+        const int sa = (MODE == QG_DOWN ? (kbeg >> 4) * 256 : (MODE == QG_UP ? kbeg * 4 : kbeg * a.Cs * 16)) + sidx * a_step;
+        const int sb = (MODE == QG_DOWN ? (kbeg >> 4) * 100 : (MODE == QG_UP ? kbeg * a.Cb * 100 : kbeg * a.Cb * 256)) + sidx * b_step;
+        const bool tail = (MODE == QG_WGRAD) && (k0 + QG_KS > kend);          // wave-uniform
         if (MODE == QG_WGRAD) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int k = k0 + ak + e;
-                ra[e] = (k < kend) ? a.small[((size_t)k * a.Cs + i0 + ar) * 4 + z] : 0.f;
+                const int vo = (tail && k0 + ak + e >= kend) ? OOB : avo;
+                ra[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, vo, sa + e * a_e, 0));
             }
         } else {
+            // (whole-vector casts: extracting the components of the builtin's result one by one
+            // makes this compiler emit a single dword load and splat it)
+            const floatx4a v0 = __builtin_bit_cast(floatx4a, __builtin_amdgcn_raw_buffer_load_b128(rsa, avo, sa, 0));
+            const floatx4a v1 = __builtin_bit_cast(floatx4a, __builtin_amdgcn_raw_buffer_load_b128(
+                rsa, avo, sa + (MODE == QG_DOWN ? 32 : 16), 0));
             ra[0] = v0.x; ra[1] = v0.y; ra[2] = v0.z; ra[3] = v0.w;
             ra[4] = v1.x; ra[5] = v1.y; ra[6] = v1.z; ra[7] = v1.w;
         }
-
 #pragma unroll
         for (int h = 0; h < QG_NB; ++h) {
-            const int jc = j0 + QG_T * h + br;          // this thread's (first) column of granule h
-            floatx4a w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0;
-            if (MODE == QG_DOWN) {
-                // B = W[m][c][16 taps of quadrant z]: two runs of four taps, five floats apart
-                const int k = k0 + bk;
-                const float* src = a.w + ((size_t)jc * a.Cb + (k >> 4)) * 25 +
-                                   ((zp ? 0 : 1) + ((k & 15) >> 2)) * 5 + (zq ? 0 : 1);
-                w0 = *reinterpret_cast<const floatx4u*>(src);
-                w1 = *reinterpret_cast<const floatx4u*>(src + 5);
-            } else if (MODE == QG_UP) {
-                const int k = k0 + bk;
-                const float* src = a.w + ((size_t)k * a.Cb + (jc >> 4)) * 25 +
-                                   ((zp ? 0 : 1) + ((jc & 15) >> 2)) * 5 + (zq ? 0 : 1);
-                w0 = *reinterpret_cast<const floatx4u*>(src);
-                w1 = *reinterpret_cast<const floatx4u*>(src + 5);
-            } else {
-                const int k = k0 + bk;
-                if (k < kend) {
-                    const float* src = a.big + ((size_t)k * a.Cb + (jc >> 4)) * 64 +
-                                       (4 * zp + ((jc & 15) >> 2)) * 8 + 4 * zq;
-                    w0 = *reinterpret_cast<const floatx4a*>(src);
-                    w1 = *reinterpret_cast<const floatx4a*>(src + 8);
-                }
-            }
+            const int vo = (tail && k0 + bk >= kend) ? OOB : bvo[h];
+            const floatx4a w0 = __builtin_bit_cast(floatx4a, __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, sb, 0));
+            const floatx4a w1 = __builtin_bit_cast(floatx4a, __builtin_amdgcn_raw_buffer_load_b128(rsb, vo, sb + B2ND, 0));
             rb[h][0] = w0.x; rb[h][1] = w0.y; rb[h][2] = w0.z; rb[h][3] = w0.w;
             rb[h][4] = w1.x; rb[h][5] = w1.y; rb[h][6] = w1.z; rb[h][7] = w1.w;
         }
@@ -156,8 +167,9 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
     const float* ap = As + ((wv >> 1) * 32 + li) * QG_LD + lk;
     const float* bp = Bs + ((wv & 1) * 32 + li) * QG_LD + lk;
 
-    if (kbeg < kend) fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += QG_KS) {
+    if (kbeg < kend) fetch(0, kbeg);
+    int sidx = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += QG_KS, ++sidx) {
         __syncthreads();                       // everyone is done reading the previous stage
 #pragma unroll
         for (int e = 0; e < 8; ++e) As[ar * QG_LD + ak + e] = ra[e];
@@ -169,7 +181,6 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
                 else                 Bs[(QG_T * h + br + e) * QG_LD + bk] = rb[h][e];
             }
         __syncthreads();
-        if (k0 + QG_KS < kend) fetch(k0 + QG_KS);
 #pragma unroll
         for (int t = 0; t < QG_KS / 2; ++t) {
             const float av = ap[2 * t];
@@ -177,6 +188,11 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
             for (int h = 0; h < QG_NB; ++h)
                 acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[QG_T * h * QG_LD + 2 * t],
                                                               acc[h], 0, 0, 0);
+            if (t == 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (k0 + QG_KS < kend) fetch(sidx + 1, k0 + QG_KS);   // rides in this MFMA stream
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
