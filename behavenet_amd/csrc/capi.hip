@@ -205,8 +205,12 @@ static int run_down(int family, const float* big, const float* w, const float* b
         const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
                                      : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
         if (ed.supported && epi_ok) {
-            const char* name = dact_src ? "k_down_c1s<0, true, false, 2>"
-                               : (act == BN_ACT_LRELU ? "k_down_c1<1, false>" : "k_down_c1<0, false>");
+            const char* name = g.Cb == 2
+                ? (dact_src ? "k_down_c1s<0, true, false, 2, 2>"
+                            : (act == BN_ACT_LRELU ? "k_down_c1s<1, false, false, 2, 2>"
+                                                   : "k_down_c1s<0, false, false, 2, 2>"))
+                : (dact_src ? "k_down_c1s<0, true, false, 2>"
+                            : (act == BN_ACT_LRELU ? "k_down_c1<1, false>" : "k_down_c1<0, false>"));
             BnProfScope prof(family, g.Cb, g.Cs, name, st, /*on_dispatch=*/true);
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }
@@ -343,7 +347,7 @@ extern "C" int bn_conv2d_fwd(const float* x, const float* w, const float* b, flo
 }
 
 static bool u8_fast(const BnGeom& g, int act) {
-    return !force_generic() && bn_edge_down_plan(g).supported &&
+    return !force_generic() && g.Cb == 1 && bn_edge_down_plan(g).supported &&
            (act == BN_ACT_NONE || act == BN_ACT_LRELU);
 }
 

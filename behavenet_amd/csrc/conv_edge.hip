@@ -428,29 +428,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
 // U8: the frames are read as stored on disk (uint8, reference data_generator.py:251-263) and
 // converted in flight, value / 255 with an IEEE division = numpy's astype(float32) / 255.
 // ---------------------------------------------------------------------------------------------
-template <int ACT, bool MASK, bool U8, int ROWS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_down_c1s(
+// CB = 2 (two-channel frames, e.g. the PS-VAE's two camera views): the reduction index of the
+// 32x32x2 MFMA is the CHANNEL (lane half kk), one step per tap; a patch per channel in LDS.
+template <int ACT, bool MASK, bool U8, int ROWS, int CB = 1>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 : 3, CB == 1 ? 4 : 3))) void k_down_c1s(
     const void* __restrict__ big_, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope,
     int units) {
     constexpr int IH = 2 * ROWS + 3;                     // patch rows
     constexpr int NLD = U8 ? (IH * 8 + 63) / 64 : (IH * (DC_W / 2) + 63) / 64;
-    __shared__ __attribute__((aligned(16))) float bl[IH * DC_RW];
+    static_assert(CB == 1 || !U8, "uint8 frames: one channel");
+    __shared__ __attribute__((aligned(16))) float bl[CB * IH * DC_RW];
     const int lane = threadIdx.x;
     const int li = lane & 31, kk = lane >> 5;
     const int upf = g.Hs / ROWS;                         // units per frame
     const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
 
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)big_, 0, (int)((size_t)g.N * HWb * (U8 ? 1 : 4)), 0x00020000);
+        (void*)big_, 0, (int)((size_t)g.N * CB * HWb * (U8 ? 1 : 4)), 0x00020000);
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
         (void*)out, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(MASK ? dact_src : out), 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
 
     // the zero columns left and right of the image never change: written once
-    for (int e = lane; e < IH * 8; e += 64) {
-        const int y = e >> 3, c = e & 7;
+    for (int e = lane; e < CB * IH * 8; e += 64) {
+        const int y = e >> 3, c = e & 7;                 // y runs over the rows of all patches
         bl[y * DC_RW + (c < 4 ? c : DC_X0 + 2 * DC_W + c - 4)] = 0.f;
     }
 
@@ -465,18 +468,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         ld_off[k] = U8 ? (y * g.Wb + 16 * c) : (y * g.Wb + 4 * c) * 4;
         ld_lds[k] = y * DC_RW + DC_X0 + (U8 ? 16 : 4) * c;
     }
-    auto issue = [&](int u, intx4 (&st)[NLD]) {
+    auto issue = [&](int u, intx4 (&st)[CB * NLD]) {
         const int n = u / upf;
         const int hb0 = 2 * ROWS * (u - n * upf) - g.pt;             // image row of patch row 0
-        const int base = (n * g.Hb + hb0) * g.Wb * (U8 ? 1 : 4);
+        const int base = (n * CB * g.Hb + hb0) * g.Wb * (U8 ? 1 : 4);
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int hb = hb0 + ld_y[k];
-            const bool ok = hb >= 0 && hb < g.Hb;
-            st[k] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? base + ld_off[k] : ED_OOB, 0, 0);
-        }
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int hb = hb0 + ld_y[k];
+                const bool ok = hb >= 0 && hb < g.Hb;
+                st[c * NLD + k] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rb, ok ? base + ld_off[k] : ED_OOB, c * HWb * (U8 ? 1 : 4), 0);
+            }
     };
-    auto to_lds = [&](const intx4 (&st)[NLD]) {
+    auto to_lds = [&](const intx4 (&st)[CB * NLD]) {
+#pragma unroll
+        for (int c = 1; c < CB; ++c)
+#pragma unroll
+            for (int k = 0; k < NLD; ++k)
+                if (ld_y[k] >= 0) *reinterpret_cast<intx4*>(bl + c * IH * DC_RW + ld_lds[k]) = st[c * NLD + k];
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             if (ld_y[k] < 0) continue;
@@ -494,12 +505,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
     };
 
-    // A operand: weights of output channel li for taps (2t + kk)
-    float wv_[13];
+    // A operand: weights of output channel li for taps (2t + kk); CB = 2: for channel kk, tap t
+    constexpr int NT = CB == 1 ? 13 : 25;
+    float wv_[NT];
 #pragma unroll
-    for (int t = 0; t < 13; ++t) {
-        const int tap = 2 * t + kk;
-        wv_[t] = (tap < 25 && li < g.Cs) ? w[li * 25 + tap] : 0.f;
+    for (int t = 0; t < NT; ++t) {
+        if (CB == 1) {
+            const int tap = 2 * t + kk;
+            wv_[t] = (tap < 25 && li < g.Cs) ? w[li * 25 + tap] : 0.f;
+        } else {
+            wv_[t] = (li < g.Cs) ? w[(li * CB + kk) * 25 + t] : 0.f;
+        }
     }
     // accumulator register e of this lane = channel (e&3) + 8*(e>>2) + 4*kk, pixel li
     float bz[16];
@@ -512,7 +528,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int a_col = DC_X0 - g.pl + 2 * li;
     const int st_lane = (4 * kk * PQ + li) * 4;          // byte offset of this lane's column
 
-    intx4 stage[NLD];
+    intx4 stage[CB * NLD];
     int u = blockIdx.x;
     if (u < units) issue(u, stage);
 #pragma unroll 1
@@ -535,6 +551,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const float* ar = aq + (2 * pr) * DC_RW;
             const float* arA = ar + kkA;
             const float* arB = ar + kkB;
+            if (CB == 2) {
+                const float* ac = ar + kk * (IH * DC_RW);           // this lane half's channel
+#pragma unroll
+                for (int t = 0; t < 25; ++t) {
+#pragma unroll
+                    for (int qh = 0; qh < 2; ++qh)
+                        acc[qh] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            wv_[t], ac[(t / 5) * DC_RW + t % 5 + 64 * qh], acc[qh], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int t = 0; t < 13; ++t) {
                 // tap 24 + kk = 25 (t = 12, kk = 1) has a zero weight but must still read a FINITE
@@ -578,11 +604,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 BnFastPlan bn_edge_down_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_down_generic", 0, 0, 0, 0, 0, 0};
-    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb != 1) return p;
+    if (g.R != 5 || g.S != 5 || g.stride != 2 || (g.Cb != 1 && g.Cb != 2)) return p;
     if (g.Cs > 32 || g.Ws != DC_W || (g.Hs % DC_ROWS) != 0) return p;
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if (g.pl < 0 || g.pl > DC_X0 || g.pt < 0) return p;
-    if ((size_t)g.N * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
     p.supported = true;
     p.kernel_name = "k_down_c1";
@@ -604,7 +630,7 @@ static int down_c1_grid(int units) {
     return grid < units ? grid : units;
 }
 
-template <int ACT, bool MASK, bool U8, int ROWS>
+template <int ACT, bool MASK, bool U8, int ROWS, int CB = 1>
 static int launch_down_c1s(const void* big, const float* w, const float* bias, float* out,
                            const float* dact_src, const BnGeom& g, float slope, hipStream_t st,
                            hipEvent_t e0, hipEvent_t e1) {
@@ -612,7 +638,7 @@ static int launch_down_c1s(const void* big, const float* w, const float* bias, f
     int grid = 256 * DC_MAX_WAVES_PER_CU;
     if (const char* e = bn_tune_env("BN_E0_SGRID")) grid = atoi(e);     // (tuning build only)
     if (grid > units) grid = units;
-    hipExtLaunchKernelGGL((k_down_c1s<ACT, MASK, U8, ROWS>), dim3(grid), dim3(64), 0, st, e0, e1,
+    hipExtLaunchKernelGGL((k_down_c1s<ACT, MASK, U8, ROWS, CB>), dim3(grid), dim3(64), 0, st, e0, e1,
                           0, big, w, bias, out, dact_src, g, slope, units);
     BN_LAUNCH_CHECK();
     return 0;
@@ -627,6 +653,14 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
     // Product choice, measured INSIDE the training step (rocprofv3, 256 frames; the isolated
     // ranking differs): plain forward -> first generation (31.7-32.8 us vs 33.7-34.6 us);
     // data gradient with the LeakyReLU' mask -> second generation, 2-row units (48.2 vs 52.6 us).
+    if (g.Cb == 2) {     // two-channel frames: swapped-role kernel, 2-row units
+        if (u8) return BN_E_SHAPE;
+        if (act == BN_ACT_LRELU && !dact_src)
+            return launch_down_c1s<BN_ACT_LRELU, false, false, 2, 2>(big, w, bias, out, nullptr, g, slope, st, e0, e1);
+        if (!dact_src)
+            return launch_down_c1s<BN_ACT_NONE, false, false, 2, 2>(big, w, bias, out, nullptr, g, slope, st, e0, e1);
+        return launch_down_c1s<BN_ACT_NONE, true, false, 2, 2>(big, w, bias, out, dact_src, g, slope, st, e0, e1);
+    }
     int variant = dact_src ? 1 : DC_VARIANT;
     if (const char* e = bn_tune_env("BN_E0_V")) variant = atoi(e);   // (tuning build only)
     if (variant == 2 && (g.Hs % 4) != 0) variant = 1;

@@ -42,6 +42,9 @@ LAYERS = {
     'D2': ('convT', 128, 16, 16, 64, 32, 32, 2, 1),
     'D3': ('convT', 64, 32, 32, 32, 64, 64, 2, 1),
     'D4': ('convT', 32, 64, 64, 1, 128, 128, 2, 1),
+    # the two-channel edge layers of BASELINE configs[3] (PS-VAE, 2x128x128 frames)
+    'E0c2': ('conv', 2, 128, 128, 32, 64, 64, 2, 1),
+    'D4c2': ('convT', 32, 64, 64, 2, 128, 128, 2, 1),
 }
 SIZES = [256, 200, 56]
 
@@ -63,6 +66,9 @@ KERNELS_256 = {
     ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D1', 'bwd_w'): 'k_wgrad4s_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
     ('D3', 'bwd_w'): 'k_wgrad4s_mfma<5>',
+    ('E0c2', 'fwd'): 'k_down_c1s<1, false, false, 2, 2>', ('E0c2', 'bwd_w'): 'k_wgrad_c1',
+    ('D4c2', 'fwd'): 'k_up_c1v<8, false>', ('D4c2', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 2>',
+    ('D4c2', 'bwd_w'): 'k_wgrad_c1',
     ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2>', ('D4', 'bwd_w'): 'k_wgrad_c1',
 }
 # the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
@@ -138,7 +144,7 @@ def check_kernel_name(layer, role, n, name):
 @pytest.mark.parametrize('layer', list(LAYERS))
 def test_forward_at_bench_sizes(layer, n):
     kind, x, w, b, dy, geom = make_layer(layer, n)
-    act = _hip.ACT_SIGMOID if layer == 'D4' else _hip.ACT_LRELU
+    act = _hip.ACT_SIGMOID if layer.startswith('D4') else _hip.ACT_LRELU
     fwd = _hip.conv2d_fwd if kind == 'conv' else _hip.convT2d_fwd
     xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
     got, name = dispatched(kind, 'fwd', geom[1], geom[4],
@@ -155,7 +161,7 @@ def test_forward_at_bench_sizes(layer, n):
 
 
 @pytest.mark.parametrize('n', SIZES)
-@pytest.mark.parametrize('layer', [l for l in LAYERS if l != 'E0'])
+@pytest.mark.parametrize('layer', [l for l in LAYERS if not l.startswith('E0')])
 def test_data_gradient_at_bench_sizes(layer, n):
     """dL/d(input), with the LeakyReLU' of the layer below fused into the epilogue (the form the
     training step uses) and without."""
@@ -218,7 +224,7 @@ def test_fast_kernels_vs_shape_agnostic_kernels(layer, n):
     from tests import debug_lib
     kind, x, w, b, dy, geom = make_layer(layer, n, seed=3)
     xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
-    act = _hip.ACT_SIGMOID if layer == 'D4' else _hip.ACT_LRELU
+    act = _hip.ACT_SIGMOID if layer.startswith('D4') else _hip.ACT_LRELU
     if kind == 'conv':
         ops = {'fwd': lambda: _hip.conv2d_fwd(xd, wd, bd, geom, act, SLOPE),
                'bwd_d': lambda: _hip.conv2d_bwd_data(dyd, wd, geom, xd, _hip.ACT_LRELU, SLOPE),
@@ -228,7 +234,7 @@ def test_fast_kernels_vs_shape_agnostic_kernels(layer, n):
                'bwd_d': lambda: _hip.convT2d_bwd_data(dyd, wd, geom, xd, _hip.ACT_LRELU, SLOPE),
                'bwd_w': lambda: _wg(_hip.convT2d_bwd_weight, xd, dyd, wd, bd, geom)}
     for role, fn in ops.items():
-        if layer == 'E0' and role == 'bwd_d':
+        if layer.startswith('E0') and role == 'bwd_d':
             continue
         debug_lib.poison_lds(DEV)
         got = fn()
