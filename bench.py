@@ -297,7 +297,7 @@ def main():
     frames = BATCH * world * args.steps
     value = frames / elapsed
 
-    # enc.conv0 roofline: every step launches it once per chunk (200 + 56 frames)
+    # enc.conv0 roofline: one launch per step over the whole 256-frame batch
     conv0_bytes = CONV0_BYTES_PER_FRAME * BATCH * args.steps
     achieved = conv0_bytes / (conv0_ms * 1e-3) / 1e9 if conv0_ms > 0 else 0.0
     traffic = None
@@ -312,6 +312,9 @@ def main():
         'launches': conv0_n, 'avg_launch_us': round(conv0_ms * 1e3 / max(conv0_n, 1), 2),
         'algorithmic_bytes_per_launch_avg': int(conv0_bytes // max(conv0_n, 1)),
         'traffic': traffic,
+        'traffic_source': 'profiles/conv0_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
+                          'over tools/run_layer.py (tools/pmc_hbm.sh), same kernel, 256 frames per launch; '
+                          'counters cannot be collected from inside this process',
         # what the same dispatch-attached events read around an EMPTY kernel: avg_launch_us is the
         # raw interval (not corrected); rocprofv3's kernel timestamps come out ~1.5-2 us lower
         'event_interval_of_empty_kernel_us': round(float(_hip.load().bn_prof_dispatch_overhead_us(
