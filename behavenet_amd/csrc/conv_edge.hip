@@ -144,9 +144,150 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second generation of the weight gradient above (offsets pt = pl = 1): same stages, MFMA roles and
+// partial-sum layout, but the tiles arrive by 16-byte LDS-DMA, double buffered, issued from inside
+// the MFMA stream of the previous stage -- the first generation moved every element with a dword
+// load, five address instructions and a ds_write (38 loads per thread and stage: the vector ALU,
+// not the HBM stream, set its pace: 4.0 TB/s).  Two accumulators break the 32-long dependent MFMA
+// chain of a stage.
+//   small tile: 32 rows (channels) of 256 contiguous floats, row stride 260 words (16-byte multiple;
+//               the A read of 32 rows x 2 pixels is 2-way conflicted, one ds_read_b32 per MFMA);
+//   big tile:   11 patch rows, image column wb at LDS column wb + 4, row stride 136 words; border
+//               groups and rows outside the image are out-of-range reads = 0.0f.
+// ---------------------------------------------------------------------------------------------
+#define WD_SP 260
+#define WD_RW (2 * WC_W + 8)
+#define WD_BG (WC_IH * WD_RW / 4)                     // 374 groups of the big tile
+#define WD_BGP ((WD_BG + 63) / 64 * 64)               // whole wave rows: 384
+#define WD_BUF (32 * WD_SP + 4 * WD_BGP)              // floats per stage image
+#define WD_LDS (2 * WD_BUF * 4)
+
+__device__ __forceinline__ void wd_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
+    const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
+    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int PQ = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
+    const int bch = blockIdx.y;
+    const bool do_bias = BIAS && bch == 0;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+    // the big image is addressed from one row above its start (patch row y = image row 2 p0 - 1 + y)
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(big - g.Wb), 0, (int)(((size_t)g.N * g.Cb * HWb + g.Wb) * 4), 0x00020000);
+
+    // rows of channels that do not exist are never copied: zero them once (both images)
+    for (int e = tid; e < 2 * WD_BUF; e += ED_THREADS) {
+        const int w = e % WD_BUF;
+        if (w < 32 * WD_SP && w / WD_SP >= g.Cs) wsm[e] = 0.f;
+    }
+    // DMA descriptors: small rows a = wv + 4k, group = lane; big groups e = lane + 64 (wv + 4k)
+    const int svo = (wv * PQ + 4 * lane) * 4;
+    int bvo[2], bcls = 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = lane + 64 * (wv + 4 * k);
+        const int y = e / (WD_RW / 4), c = e - y * (WD_RW / 4);
+        const bool ok = e < WD_BG && c >= 1 && c <= 2 * WC_W / 4;
+        bvo[k] = ok ? (y * g.Wb + 4 * (c - 1)) * 4 : ED_OOB;
+        bcls |= ((y == 0 ? 1 : 0) | (y >= WC_IH - 2 ? 2 : 0)) << (2 * k);
+    }
+    auto issue_dma = [&](const int d, const int buf, const int st) __attribute__((always_inline)) {
+        const int n = st / stages_per_frame;
+        const int p0 = (st - n * stages_per_frame) * WC_ROWS;
+        float* img = wsm + buf * WD_BUF;
+        if (d < 8) {
+            if (wv + 4 * d < g.Cs)                                   // wave-uniform
+                wd_dma16(rs, img + (wv + 4 * d) * WD_SP, svo, ((n * g.Cs + 4 * d) * g.Hs + p0) * g.Ws * 4);
+        } else {
+            const int k = d - 8;
+            if (64 * (wv + 4 * k) < WD_BGP) {                        // wave-uniform
+                const int smask = ((p0 == 0 ? 1 : 0) | (p0 + WC_ROWS >= g.Hs ? 2 : 0)) << (2 * k);
+                wd_dma16(rb, img + 32 * WD_SP + 4 * 64 * (wv + 4 * k), (bcls & smask) ? ED_OOB : bvo[k],
+                         ((n * g.Cb + bch) * g.Hb + 2 * p0) * g.Wb * 4);
+            }
+        }
+    };
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;
+    float bsum = 0.f;
+
+    // operand addresses: tap j = li -> (r, s); pixel (row wv, column 2t + kk)
+    const int tap = li < 25 ? li : 0;
+    const int tr = tap / 5, ts = tap - tr * 5;
+    int aq_cur = (li * WD_SP + wv * WC_W + kk) * 4;                              // bytes
+    int bq_cur = (32 * WD_SP + (2 * wv + tr) * WD_RW + ts + 2 * kk + 3) * 4;     // column wb + 4, pl = 1
+    int aq_oth = aq_cur + WD_BUF * 4, bq_oth = bq_cur + WD_BUF * 4;
+    const char* sm = reinterpret_cast<const char*>(wsm);
+
+    int st = blockIdx.x;
+    if (st < n_stages) {
+#pragma unroll
+        for (int d = 0; d < 10; ++d) issue_dma(d, 0, st);
+    }
+    int cur = 0;
+    for (; st < n_stages; st += gridDim.x) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nx = st + gridDim.x;
+        const bool more = nx < n_stages;
+#pragma unroll
+        for (int t = 0; t < WC_W / 2; ++t) {
+            const float av = *reinterpret_cast<const float*>(sm + aq_cur + 8 * t);
+            const float bv = *reinterpret_cast<const float*>(sm + bq_cur + 16 * t);
+            if (do_bias) bsum += av;
+            acc[t & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t & 1], 0, 0, 0);
+            if (t >= 2 && t < 12) { if (more) issue_dma(t - 2, cur ^ 1, nx); }
+        }
+        cur ^= 1;
+        int tmp = aq_cur; aq_cur = aq_oth; aq_oth = tmp;
+        tmp = bq_cur; bq_cur = bq_oth; bq_oth = tmp;
+    }
+
+    // combine the two accumulators, then the four waves (fixed order): partial [a][tap]
+    __syncthreads();
+    float* red = wsm;    // 4 x 16 x 64 floats
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wv * 16 + e) * 64 + lane] = acc[0][e] + acc[1][e];
+    __syncthreads();
+    if (wv == 0 && li < 25) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = (red[e * 64 + lane] + red[(16 + e) * 64 + lane]) +
+                            (red[(32 + e) * 64 + lane] + red[(48 + e) * 64 + lane]);
+            const int a = (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (a < g.Cs)
+                part[((size_t)bch * gridDim.x + blockIdx.x) * (g.Cs * 25) + a * 25 + li] = v;
+        }
+    }
+    if (do_bias) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        __syncthreads();
+        if (lane < 32) red[wv * 32 + lane] = bsum;
+        __syncthreads();
+        if (tid < 32 && tid < g.Cs)
+            bias_part[(size_t)blockIdx.x * g.Cs + tid] =
+                (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+    }
+}
+
 static int wgrad_c1_grid(const BnGeom& g) {
     const int n_stages = g.N * (g.Hs / WC_ROWS);
-    const int cap = 768 / (g.Cb > 0 ? g.Cb : 1);     // 3 resident workgroups per CU in total
+    // resident workgroups per CU in total: 3 (first generation), 2 (DMA generation: 79 KB of LDS)
+    const int cap = ((g.pt == 1 && g.pl == 1) ? 512 : 768) / (g.Cb > 0 ? g.Cb : 1);
     return n_stages < cap ? n_stages : cap;
 }
 
@@ -160,7 +301,7 @@ BnFastPlan bn_edge_wgrad_plan(const BnGeom& g) {
     p.supported = true;
     p.d = wgrad_c1_grid(g);
     p.ws_bytes = ((size_t)g.Cb * p.d * g.Cs * 25 + (size_t)p.d * 32) * sizeof(float);
-    p.kernel_name = "k_wgrad_c1";
+    p.kernel_name = (g.pt == 1 && g.pl == 1) ? "k_wgrad_c1d" : "k_wgrad_c1";
     return p;
 }
 
@@ -171,8 +312,27 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
     // Conv2d bias gradient (sum of the small side) as a by-product
     float* bias_part = (db && bias_side == 1)
         ? (float*)ws + (size_t)g.Cb * plan.d * g.Cs * 25 : nullptr;
-    hipLaunchKernelGGL(k_wgrad_c1, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
-                       (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
+    if (g.pt == 1 && g.pl == 1) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)k_wgrad_c1d<true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, WD_LDS);
+            hipError_t e2 = hipFuncSetAttribute((const void*)k_wgrad_c1d<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, WD_LDS);
+            if (e1 != hipSuccess) return (int)e1;
+            if (e2 != hipSuccess) return (int)e2;
+            attr_set = true;
+        }
+        if (bias_part)
+            hipLaunchKernelGGL(k_wgrad_c1d<true>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
+                               big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
+        else
+            hipLaunchKernelGGL(k_wgrad_c1d<false>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
+                               big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
+    } else {
+        hipLaunchKernelGGL(k_wgrad_c1, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
+                           (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
+    }
     BN_LAUNCH_CHECK();
     if (bias_part) {
         const int rc = bn_launch_sum_partials(bias_part, db, g.Cs, plan.d, accumulate, 0, 0, st);

@@ -51,7 +51,7 @@ SIZES = [256, 200, 56]
 # (layer, role) -> kernel at N = 256: the instantiations of profiles/r02_bench_kernel_stats.csv
 # (the single-pass schedule of bench.py launches every layer once over the whole 256-frame batch)
 KERNELS_256 = {
-    ('E0', 'fwd'): 'k_down_c1<1, false>', ('E0', 'bwd_w'): 'k_wgrad_c1',
+    ('E0', 'fwd'): 'k_down_c1<1, false>', ('E0', 'bwd_w'): 'k_wgrad_c1d',
     ('E1', 'fwd'): 'k_down2_mfma<2, 2>', ('E2', 'fwd'): 'k_down2_mfma<2, 2>',
     ('E3', 'fwd'): 'k_down2_mfma<2, 1>',
     ('E1', 'bwd_d'): 'k_up2_mfma<5, 4>', ('E2', 'bwd_d'): 'k_up2_mfma<4, 4>',
@@ -66,10 +66,10 @@ KERNELS_256 = {
     ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D1', 'bwd_w'): 'k_wgrad4s_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
     ('D3', 'bwd_w'): 'k_wgrad4s_mfma<5>',
-    ('E0c2', 'fwd'): 'k_down_c1s<1, false, false, 2, 2>', ('E0c2', 'bwd_w'): 'k_wgrad_c1',
+    ('E0c2', 'fwd'): 'k_down_c1s<1, false, false, 2, 2>', ('E0c2', 'bwd_w'): 'k_wgrad_c1d',
     ('D4c2', 'fwd'): 'k_up_c1v<8, false>', ('D4c2', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 2>',
-    ('D4c2', 'bwd_w'): 'k_wgrad_c1',
-    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2>', ('D4', 'bwd_w'): 'k_wgrad_c1',
+    ('D4c2', 'bwd_w'): 'k_wgrad_c1d',
+    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2>', ('D4', 'bwd_w'): 'k_wgrad_c1d',
 }
 # the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
 # frames, smaller tiles where the grid would not fill the chip
