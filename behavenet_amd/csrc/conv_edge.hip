@@ -403,6 +403,22 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
                                          // 34.9, sc1 31.5-31.9, sc1+nt (18) 34.2
 #endif
 
+// LeakyReLU of four values, max(v, slope v) for 0 <= slope <= 1: two packed multiplies and four
+// v_max.  `fmaxf(v, v * slope)` costs THREE vector instructions per value (the compiler quiets a
+// possible signalling NaN with an extra v_max): 96 of them per 26 MFMAs in enc.conv0's loop, where
+// every vector instruction takes its cycles from the matrix pipe.
+typedef float floatx2p __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ed_lrelu4(float (&v)[4], float slope) {
+    const floatx2p s2 = {slope, slope};
+    floatx2p lo = {v[0], v[1]}, hi = {v[2], v[3]}, mlo, mhi;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(mlo) : "v"(lo), "v"(s2));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(mhi) : "v"(hi), "v"(s2));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v[0]) : "v"(lo.x), "v"(mlo.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v[1]) : "v"(lo.y), "v"(mlo.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v[2]) : "v"(hi.x), "v"(mhi.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v[3]) : "v"(hi.y), "v"(mhi.y));
+}
+
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx4e __attribute__((ext_vector_type(4)));
 typedef unsigned int uintx4e __attribute__((ext_vector_type(4)));
@@ -508,8 +524,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
                     floatx4e v = {acc[qh][4 * grp], acc[qh][4 * grp + 1], acc[qh][4 * grp + 2],
                                   acc[qh][4 * grp + 3]};
                     if (ACT == BN_ACT_LRELU) {
-                        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
-                        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                        float q[4] = {v.x, v.y, v.z, v.w};
+                        ed_lrelu4(q, slope);
+                        v = (floatx4e){q[0], q[1], q[2], q[3]};
                     }
                     *reinterpret_cast<floatx4e*>(tw + li * DC_HTS + 8 * grp + 4 * kk) = v;
                 }
@@ -549,8 +566,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
                     floatx4e v = {acc[qh][4 * grp], acc[qh][4 * grp + 1], acc[qh][4 * grp + 2],
                                   acc[qh][4 * grp + 3]};
                     if (ACT == BN_ACT_LRELU) {
-                        v.x = fmaxf(v.x, v.x * slope); v.y = fmaxf(v.y, v.y * slope);
-                        v.z = fmaxf(v.z, v.z * slope); v.w = fmaxf(v.w, v.w * slope);
+                        float q[4] = {v.x, v.y, v.z, v.w};
+                        ed_lrelu4(q, slope);
+                        v = (floatx4e){q[0], q[1], q[2], q[3]};
                     }
                     *reinterpret_cast<floatx4e*>(tw + li * DC_TS + 32 * qh + 8 * grp + 4 * kk) = v;
                 }
@@ -746,13 +764,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 
                             rd, ok ? st_lane : ED_OOB, row_off + (chb * PQ + 32 * qh) * 4, 0));
                     }
                 }
+                float av[16];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    float q[4] = {acc[qh][4 * e4], acc[qh][4 * e4 + 1], acc[qh][4 * e4 + 2], acc[qh][4 * e4 + 3]};
+                    if (ACT == BN_ACT_LRELU) ed_lrelu4(q, slope);
+                    av[4 * e4] = q[0]; av[4 * e4 + 1] = q[1]; av[4 * e4 + 2] = q[2]; av[4 * e4 + 3] = q[3];
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int chb = (e & 3) + 8 * (e >> 2);           // + 4*kk in st_lane
                     const int so = row_off + (chb * PQ + 32 * qh) * 4;
                     const bool ok = chb + 4 * kk < g.Cs;
-                    float v = acc[qh][e];
-                    if (ACT == BN_ACT_LRELU) v = fmaxf(v, v * slope);
+                    float v = av[e];
                     if (MASK) v *= d[e] > 0.f ? 1.f : slope;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro,
                                                           ok ? st_lane : ED_OOB, so, 0);

@@ -69,7 +69,7 @@ KERNELS_256 = {
     ('E0c2', 'fwd'): 'k_down_c1s<1, false, false, 2, 2>', ('E0c2', 'bwd_w'): 'k_wgrad_c1d',
     ('D4c2', 'fwd'): 'k_up_c1v<8, false>', ('D4c2', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 2>',
     ('D4c2', 'bwd_w'): 'k_wgrad_c1d',
-    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2>', ('D4', 'bwd_w'): 'k_wgrad_c1d',
+    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 1>', ('D4', 'bwd_w'): 'k_wgrad_c1d',
 }
 # the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
 # frames, smaller tiles where the grid would not fill the chip
@@ -335,7 +335,7 @@ def test_first_layer_from_uint8_frames_at_bench_sizes(n):
     want64 = F.leaky_relu(op(x[sub].double(), w.double(), b.double()), SLOPE)
     got, name = dispatched(kind, 'fwd', 1, 32, lambda: _hip.conv2d_fwd_u8(
         torch.from_numpy(u8).to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE))
-    assert name == 'k_down_c1s<1, false, true, 4>'
+    assert name == 'k_down_c1s<1, false, true, 4, 1>'
     close(got[sub], want, want64, name='E0 u8 N=%d' % n)
     assert torch.equal(got, _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom,
                                             _hip.ACT_LRELU, SLOPE))
