@@ -519,10 +519,11 @@ def kl_rows(mu, logvar):
     return out
 
 
-def decomposed_kl_fwd(z, mu, logvar):
+def decomposed_kl_fwd(z, mu, logvar, out3=None):
     """-> (out3, log_qz, lse): the three KL terms and what the backward pass needs."""
     N, D = z.shape
-    out3 = torch.empty((3,), dtype=torch.float32, device=z.device)
+    if out3 is None:
+        out3 = torch.empty((3,), dtype=torch.float32, device=z.device)
     log_qz = torch.empty((N,), dtype=torch.float32, device=z.device)
     lse = torch.empty((N, D), dtype=torch.float32, device=z.device)
     terms = torch.empty((3 * N,), dtype=torch.float32, device=z.device)
@@ -533,9 +534,10 @@ def decomposed_kl_fwd(z, mu, logvar):
     return out3, log_qz, lse
 
 
-def decomposed_kl_bwd(z, mu, logvar, log_qz, lse, g3):
+def decomposed_kl_bwd(z, mu, logvar, log_qz, lse, g3, out=None):
     N, D = z.shape
-    dz, dmu, dlogvar = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+    dz, dmu, dlogvar = out if out is not None else (
+        torch.empty_like(z), torch.empty_like(z), torch.empty_like(z))
     _check(load().bn_decomposed_kl_bwd(
         _ptr(z, 'z'), _ptr(mu, 'mu'), _ptr(logvar, 'logvar'), _ptr(log_qz, 'log_qz'),
         _ptr(lse, 'lse'), _ptr(g3, 'g3'), _ptr(dz, 'dz'), _ptr(dmu, 'dmu'),
@@ -551,8 +553,8 @@ def reparam_bwd(dz, z, mu):
     return dlogvar
 
 
-def kl_bwd(mu, logvar, scale, gscale):
-    dmu, dlogvar = torch.empty_like(mu), torch.empty_like(mu)
+def kl_bwd(mu, logvar, scale, gscale, out=None):
+    dmu, dlogvar = out if out is not None else (torch.empty_like(mu), torch.empty_like(mu))
     _check(load().bn_kl_bwd(
         _ptr(mu, 'mu'), _ptr(logvar, 'logvar'), _ptr(dmu, 'dmu'), _ptr(dlogvar, 'dlogvar'),
         mu.numel(), float(scale), _ptr(gscale, 'gscale', allow_none=True), _stream()),

@@ -977,5 +977,79 @@ def decomposed_kl_terms(z, mu, logvar):
     return DecomposedKLFn.apply(z, mu, logvar)
 
 
+class KLChunksFn(torch.autograd.Function):
+    """(n_chunks,) tensor of weights[c] * kl_div_to_std_normal(rows of chunk c) for contiguous row
+    ranges `bounds` that tile the batch.  One node instead of a slice / contiguous / KLFn / scale
+    chain per chunk: row slices of a contiguous tensor are pointer offsets for the kernels, and the
+    backward pass writes every chunk's gradient into its rows of ONE buffer (autograd's slice
+    backward allocates a zero tensor of the full size per slice and adds them up)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, bounds, weights):
+        mu, logvar = mu.contiguous(), logvar.contiguous()
+        out = torch.empty((len(bounds),), dtype=torch.float32, device=mu.device)
+        for c, (b, e) in enumerate(bounds):
+            if e > b:
+                _hip.reduce_sum(_hip.kl_rows(mu[b:e], logvar[b:e]), float(weights[c]) / (e - b), out=out[c])
+            else:
+                out[c].zero_()
+        ctx.save_for_backward(mu, logvar)
+        ctx.bounds, ctx.weights = list(bounds), [float(w) for w in weights]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        g = g.contiguous()
+        dmu, dlogvar = torch.empty_like(mu), torch.empty_like(mu)
+        covered = 0
+        for c, (b, e) in enumerate(ctx.bounds):
+            if e > b:
+                _hip.kl_bwd(mu[b:e], logvar[b:e], ctx.weights[c] / (e - b), g[c],
+                            out=(dmu[b:e], dlogvar[b:e]))
+                covered += e - b
+        assert covered == mu.shape[0], 'chunk bounds must tile the rows'
+        return dmu, dlogvar, None, None
+
+
+def kl_chunks(mu, logvar, bounds, weights):
+    return KLChunksFn.apply(mu, logvar, bounds, weights)
+
+
+class DecomposedKLChunksFn(torch.autograd.Function):
+    """(n_chunks, 3) tensor of the decomposed-KL terms of every contiguous row range in `bounds`
+    (they tile the batch); see KLChunksFn for why this is one node."""
+
+    @staticmethod
+    def forward(ctx, z, mu, logvar, bounds):
+        z, mu, logvar = z.contiguous(), mu.contiguous(), logvar.contiguous()
+        out = torch.empty((len(bounds), 3), dtype=torch.float32, device=z.device)
+        saved = []
+        for c, (b, e) in enumerate(bounds):
+            _, log_qz, lse = _hip.decomposed_kl_fwd(z[b:e], mu[b:e], logvar[b:e], out3=out[c])
+            saved += [log_qz, lse]
+        ctx.save_for_backward(z, mu, logvar, *saved)
+        ctx.bounds = list(bounds)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, mu, logvar = ctx.saved_tensors[:3]
+        saved = ctx.saved_tensors[3:]
+        g = g.contiguous()
+        dz, dmu, dlogvar = torch.empty_like(z), torch.empty_like(z), torch.empty_like(z)
+        covered = 0
+        for c, (b, e) in enumerate(ctx.bounds):
+            _hip.decomposed_kl_bwd(z[b:e], mu[b:e], logvar[b:e], saved[2 * c], saved[2 * c + 1], g[c],
+                                   out=(dz[b:e], dmu[b:e], dlogvar[b:e]))
+            covered += e - b
+        assert covered == z.shape[0], 'chunk bounds must tile the rows'
+        return dz, dmu, dlogvar, None
+
+
+def decomposed_kl_chunks(z, mu, logvar, bounds):
+    return DecomposedKLChunksFn.apply(z, mu, logvar, bounds)
+
+
 def kl_to_std_normal(mu, logvar):
     return KLFn.apply(mu, logvar)

@@ -120,6 +120,19 @@ class _FrameShards(object):
                 out.append(torch.zeros((), dtype=torch.float32, device=tensors[0].device))
         return torch.stack(out)
 
+    def kl_terms(self, mu, logvar):
+        """(n_chunks,) tensor: this rank's part of every chunk's mean KL to N(0, 1) (one autograd
+        node; same numbers as ``row_terms(losses.kl_div_to_std_normal, mu, logvar)``)."""
+        return hf.kl_chunks(mu, logvar, self.bounds_l, self.share)
+
+    def decomposed_kl_terms(self, z, mu, logvar):
+        """(n_chunks, 3) tensor of (MI, TC, DWKL) per chunk.  Not sharded: one autograd node over
+        the row ranges; sharded: every rank evaluates the gathered chunk (see ``gathered``)."""
+        if not self.sharded:
+            return hf.decomposed_kl_chunks(z, mu, logvar, self.bounds_l)
+        return torch.stack([torch.stack(losses.decomposed_kl(*self.gathered(c, z, mu, logvar)))
+                            for c in range(len(self.bounds_l))])
+
     def gathered(self, c, *tensors):
         """Chunk ``c``'s rows of every rank (rank order = frame order), with THIS rank's rows
         still attached to the graph: batch-coupled terms (the decomposed KL) are evaluated on
@@ -231,7 +244,7 @@ class VAE(AE):
                                 'chunk_sizes': sh.sizes}, **kw)
                 ll = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
                                                const_share=sh.share if sh.sharded else None)
-                klv = sh.row_terms(losses.kl_div_to_std_normal, mu, logvar)
+                klv = sh.kl_terms(mu, logvar)
                 lossv = -ll + float(beta) * klv
             vals = _finish_whole(torch.stack([lossv, ll, klv], dim=1), lossv,
                                  accumulate_grad)
@@ -345,8 +358,7 @@ class BetaTCVAE(VAE):
                                                const_share=sh.share if sh.sharded else None)
                 # the decomposed KL couples all samples of a chunk: every rank evaluates it on
                 # the gathered chunk (gradients flow through its own rows only)
-                dk = torch.stack([torch.stack(losses.decomposed_kl(
-                    *sh.gathered(c, sample, mu, logvar))) for c in range(len(bounds))])
+                dk = sh.decomposed_kl_terms(sample, mu, logvar)                  # (n_chunks, 3)
                 kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
                 lossv = -ll + kl_terms
                 # what is REPORTED is summed over ranks: the shared terms enter with this rank's
@@ -507,12 +519,11 @@ class PSVAE(AE):
                                                  const_share=share)
                 ll_y = losses.gaussian_ll_chunks(yl, y_hat, nl, bounds, chunk_sizes=sh.sizes,
                                                  const_share=share)
-                zs = sh.row_terms(losses.kl_div_to_std_normal, mu[:, :n_labels],
-                                  logvar[:, :n_labels])
+                # column blocks once for the whole batch (not per chunk)
+                zs = sh.kl_terms(mu[:, :n_labels], logvar[:, :n_labels])
                 # batch-coupled: evaluated on the gathered chunk by every rank (see BetaTCVAE)
-                dk = torch.stack([torch.stack(losses.decomposed_kl(*sh.gathered(
-                    c, sample[:, n_labels:], mu[:, n_labels:], logvar[:, n_labels:])))
-                    for c in range(len(bounds))])                           # (n_chunks, 3)
+                dk = sh.decomposed_kl_terms(sample[:, n_labels:], mu[:, n_labels:],
+                                            logvar[:, n_labels:])             # (n_chunks, 3)
                 kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
                 lossv = -ll_x - float(alpha) * ll_y + zs + kl_terms
                 w = sh.share_t(x.device)
