@@ -51,7 +51,9 @@ def init_from_env(backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        # BN_DIST_BACKEND=gloo: several ranks on ONE GPU (tests; RCCL refuses two ranks per device)
+        backend = os.environ.get('BN_DIST_BACKEND') or (
+            'nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)

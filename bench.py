@@ -227,6 +227,8 @@ def main():
         if rank == 0:
             print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('BN_DIST_BACKEND') == 'gloo':
+        local = 0           # control-flow test of the N > 1 path: all ranks share the one GPU
     torch.cuda.set_device(local)
     _hip.load()
 
@@ -290,7 +292,8 @@ def main():
     _hip.prof_select(_hip.PROF_NONE)
 
     if bdist.is_active():
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cpu' if torch.distributed.get_backend() == 'gloo' else 'cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -187,3 +187,22 @@ def test_fit_in_frames_mode_matches_single_process(tmp_path):
     diff = np.abs(np.asarray(got['param_sample']) - np.asarray(want['param_sample']))
     assert diff.max() <= travel
     assert np.mean(diff > 0.02 * travel + 1e-3 * np.abs(want['param_sample'])) <= 0.02
+
+
+def test_bench_two_ranks_control_flow():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank),
+    with both ranks on the one GPU over gloo: parameter broadcast, per-step gradient all-reduce,
+    barrier-bracketed timing, max over ranks, one JSON line from rank 0 with the whole-job value."""
+    env = dict(os.environ, BN_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29517', os.path.join(REPO, 'bench.py'),
+           '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary']
+    out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                         timeout=600).stdout.decode()
+    lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak'
+    assert d['config']['global_frames_per_step'] == 512
+    assert abs(d['value'] - 512 * 1e3 / d['ms_per_step']) <= 0.01 * d['value']
+    assert np.isfinite(d['final_loss'])
