@@ -217,6 +217,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
 //    place, an MFMA has taken its operands when it issues); sched_barrier pins the order;
 //  * the epilogue batches its loads and is branch-free (buffer stores with out-of-range lanes).
 // ---------------------------------------------------------------------------------------------
+#ifndef UP2_WGS
+#define UP2_WGS 2      // min workgroups per CU for the register budget (4 = 128 VGPRs measured no faster)
+#endif
 template <int LGW>
 struct UP2 {
     static constexpr int Ws = 1 << LGW, HW = Ws * Ws, TP = 128;
@@ -236,7 +239,7 @@ __device__ __forceinline__ void up_dma4(__amdgpu_buffer_rsrc_t rsrc, float* lds,
 }
 
 template <int LGW, int CC>
-__global__ __launch_bounds__(MF_THREADS, 2) void k_up2_mfma(
+__global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, int act, int dact,
     float slope) {
