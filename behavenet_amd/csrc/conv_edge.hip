@@ -1029,7 +1029,8 @@ __global__ __launch_bounds__(64) void k_up_c1v(
     // one channel's operands: the R + 2 input rows (lane = column) and, in lanes 0..24, the 25
     // weights of that channel (broadcast to SGPRs by v_readlane when the channel is multiplied:
     // no scalar-memory latency anywhere in the loop)
-    struct Chan { float x[NR]; float wl; };
+    static_assert((NR & 1) == 0, "input rows are kept as register pairs");
+    struct Chan { floatx2p xx[NR / 2]; float wl; };          // rows (2k, 2k+1) = one register pair
 
 #pragma unroll 1
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
@@ -1038,9 +1039,9 @@ __global__ __launch_bounds__(64) void k_up_c1v(
         const int bch = nb % g.Cb, n = nb / g.Cb;
         const int p0 = strip * R;
 
-        float acc[2 * R][2];
+        floatx2p acc[2 * R];                           // .x = column 2q, .y = column 2q+1
 #pragma unroll
-        for (int j = 0; j < 2 * R; ++j) acc[j][0] = acc[j][1] = 0.f;
+        for (int j = 0; j < 2 * R; ++j) acc[j] = (floatx2p){0.f, 0.f};
 
         // Addresses: the lane part (column, 4 * lane, plus the row's compile-time 256 * i in the
         // instruction's offset field) is per unit, the channel part is ONE scalar offset per
@@ -1059,12 +1060,12 @@ __global__ __launch_bounds__(64) void k_up_c1v(
             // the rows of the last channel again (finite whenever the frame is)
             const int cx = c < g.Cs ? c : g.Cs - 1;
             const int so = frame_row0 + cx * g.Hs * (UV_W * 4);
-            ch.x[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo_top, so, 0));
 #pragma unroll
-            for (int i = 1; i < NR - 1; ++i)
-                ch.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                    rs, vo_mid + i * (UV_W * 4), so, 0));
-            ch.x[NR - 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo_bot, so, 0));
+            for (int i = 0; i < NR; ++i) {
+                const int vo = i == 0 ? vo_top : (i == NR - 1 ? vo_bot : vo_mid + i * (UV_W * 4));
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+                if (i & 1) ch.xx[i >> 1].y = v; else ch.xx[i >> 1].x = v;
+            }
             ch.wl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                 rw, c < g.Cs ? vo_w : ED_OOB, (cx * g.Cb + bch) * 100, 0));
         };
@@ -1074,22 +1075,41 @@ __global__ __launch_bounds__(64) void k_up_c1v(
             for (int t = 0; t < 25; ++t)
                 wk[t] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(
                     __builtin_bit_cast(int, ch.wl), t));
+            // The two columns of an output row are one register pair, and taps (1,2) resp. (3,4)
+            // of a kernel row multiply the SAME input value (column q resp. q-1): each is one
+            // v_pk_fma_f32 with the weight pair as the scalar operand and the input half picked by
+            // op_sel -- 3 instead of 5 vector instructions per (input row, kernel row); the kernel
+            // is bound by vector issue (200 multiply-adds per channel and lane), not by HBM.
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const float xc = ch.x[i];
-                const float xm = uv_shift_from_left(xc);       // small[.., q-1]
-                const float xp = uv_shift_from_right(xc);      // small[.., q+1]
+            for (int ip = 0; ip < NR / 2; ++ip) {
+                const floatx2p xc2 = ch.xx[ip];
+                floatx2p xm2, xp2;
+                xm2.x = uv_shift_from_left(xc2.x);  xm2.y = uv_shift_from_left(xc2.y);     // small[.., q-1]
+                xp2.x = uv_shift_from_right(xc2.x); xp2.y = uv_shift_from_right(xc2.y);    // small[.., q+1]
 #pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    const int j = 2 * i + r - 3;               // output row 2*p0 + j
-                    if (j < 0 || j >= 2 * R) continue;         // (compile-time)
-                    // column 2q   (w+1 odd):  s = 1 -> q,   s = 3 -> q-1
-                    acc[j][0] = fmaf(wk[r * 5 + 1], xc, acc[j][0]);
-                    acc[j][0] = fmaf(wk[r * 5 + 3], xm, acc[j][0]);
-                    // column 2q+1 (w+1 even): s = 0 -> q+1, s = 2 -> q, s = 4 -> q-1
-                    acc[j][1] = fmaf(wk[r * 5 + 0], xp, acc[j][1]);
-                    acc[j][1] = fmaf(wk[r * 5 + 2], xc, acc[j][1]);
-                    acc[j][1] = fmaf(wk[r * 5 + 4], xm, acc[j][1]);
+                for (int h = 0; h < 2; ++h) {
+                    const int i = 2 * ip + h;
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        const int j = 2 * i + r - 3;               // output row 2*p0 + j
+                        if (j < 0 || j >= 2 * R) continue;         // (compile-time)
+                        // column 2q: s = 1 -> q, s = 3 -> q-1; column 2q+1: s = 2 -> q, s = 4 -> q-1
+                        const unsigned long long w12 =
+                            ((unsigned long long)__builtin_bit_cast(unsigned, wk[r * 5 + 2]) << 32) |
+                            __builtin_bit_cast(unsigned, wk[r * 5 + 1]);
+                        const unsigned long long w34 =
+                            ((unsigned long long)__builtin_bit_cast(unsigned, wk[r * 5 + 4]) << 32) |
+                            __builtin_bit_cast(unsigned, wk[r * 5 + 3]);
+                        if (h == 0) {
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[j]) : "s"(w12), "v"(xc2));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[j]) : "s"(w34), "v"(xm2));
+                        } else {
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc[j]) : "s"(w12), "v"(xc2));
+                            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc[j]) : "s"(w34), "v"(xm2));
+                        }
+                        // column 2q+1, s = 0 -> q+1
+                        acc[j].y = fmaf(wk[r * 5 + 0], h ? xp2.y : xp2.x, acc[j].y);
+                    }
                 }
             }
         };
@@ -1117,8 +1137,8 @@ __global__ __launch_bounds__(64) void k_up_c1v(
 #pragma unroll
         for (int j = 0; j < 2 * R; ++j) {
             float2 v;
-            v.x = acc[j][0] + bs;
-            v.y = acc[j][1] + bs;
+            v.x = acc[j].x + bs;
+            v.y = acc[j].y + bs;
             if (act == BN_ACT_SIGMOID) {
                 // rcp instead of the IEEE division of bn_apply_act: 1 ulp, a tenth of the code
                 v.x = __builtin_amdgcn_rcpf(1.f + __expf(-v.x));
