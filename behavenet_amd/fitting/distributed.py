@@ -231,6 +231,12 @@ class BucketedGradReducer(object):
         self._missing = None
         self._launched = None
         self._stream = None
+        # overlap = False: nothing goes out during the backward pass, finish() launches the buckets
+        # (in order) behind it.  A caller can switch per step: persistent kernels whose grids fill
+        # the chip exactly (one or two LDS-filling workgroups per CU) lose a whole round when an
+        # RCCL block holds a CU, so which is faster depends on how many channels RCCL uses --
+        # bench.py measures both during its warm-up and keeps the faster one
+        self.overlap = True
         self.begin()
 
     def _add_bucket(self, lo, hi, members):
@@ -252,7 +258,7 @@ class BucketedGradReducer(object):
 
     def grad_ready(self, p):
         """The kernels writing ``p.grad`` for this step have all been issued."""
-        if not is_active():
+        if not is_active() or not self.overlap:
             return
         b = self._bucket_of.get(id(p))
         if b is None or id(p) in self._seen or self._launched[b]:

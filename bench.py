@@ -254,13 +254,40 @@ def main():
     # the same training trajectory the warm-up continues.
     for _ in range(PRIME_STEPS):
         one_step(model, opt, gen)
-    for _ in range(args.warmup):
-        one_step(model, opt, gen)
 
     def barrier():
         if bdist.is_active():
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    # Setup, N > 1 only: gradient all-reduce overlapped with the backward pass, or launched behind
+    # it?  The overlapped form hides the transfer, but RCCL's blocks take CUs away from kernels
+    # whose grids fill the chip exactly; which wins depends on RCCL's channel count on this node.
+    # Measure both (all ranks agree on the max over ranks) and keep the faster one.
+    allreduce_mode = None
+    reducer = getattr(opt, 'reducer', None)
+    if bdist.is_active() and reducer is not None and os.environ.get('BN_OVERLAP_ALLREDUCE') is None:
+        timing = {}
+        for mode in (True, False):
+            reducer.overlap = mode
+            for _ in range(3):
+                one_step(model, opt, gen)
+            barrier()
+            t_a = time.perf_counter()
+            for _ in range(8):
+                one_step(model, opt, gen)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64,
+                              device='cpu' if torch.distributed.get_backend() == 'gloo' else 'cuda')
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            timing[mode] = float(tt.item()) / 8
+        reducer.overlap = timing[True] <= timing[False]
+        allreduce_mode = {'chosen': 'overlapped with the backward pass' if reducer.overlap
+                          else 'bucketed, launched behind the backward pass',
+                          'ms_per_step_overlapped': round(timing[True] * 1e3, 3),
+                          'ms_per_step_behind': round(timing[False] * 1e3, 3)}
+    for _ in range(args.warmup):
+        one_step(model, opt, gen)
 
     if os.environ.get('BN_BENCH_NOHOOK') != '1':
         _hip.prof_select(_hip.PROF_CONV_FWD, 1, 32)     # enc.conv0 launches inside the timed region
@@ -341,6 +368,7 @@ def main():
                               'device_u8': 'resident in HBM (uint8, converted per batch)',
                               'host_u8': 'pinned host uint8, prefetched over PCIe per batch',
                               'host': 'pinned host float32, copied per batch'}[args.feed]},
+        'allreduce': allreduce_mode,
         'final_loss': last['loss'] if last else None,
         'whole_step_fp32_tflops': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12, 2),
         'whole_step_fp32_frac': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12 /
