@@ -1051,5 +1051,63 @@ def decomposed_kl_chunks(z, mu, logvar, bounds):
     return DecomposedKLChunksFn.apply(z, mu, logvar, bounds)
 
 
+class SplitColsFn(torch.autograd.Function):
+    """(t[:, :k], t[:, k:]) as two contiguous tensors; the backward pass is ONE concatenation
+    (autograd's slice backward would fill a zero tensor of the full size per slice, copy into it
+    and add the two up)."""
+
+    @staticmethod
+    def forward(ctx, t, k):
+        ctx.k, ctx.shape = int(k), t.shape
+        return t[:, :k].contiguous(), t[:, k:].contiguous()
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        n, d = ctx.shape
+        if g1 is None:
+            g1 = torch.zeros((n, ctx.k), dtype=g2.dtype, device=g2.device)
+        if g2 is None:
+            g2 = torch.zeros((n, d - ctx.k), dtype=g1.dtype, device=g1.device)
+        return torch.cat([g1, g2], dim=1), None
+
+
+def split_cols(t, k):
+    return SplitColsFn.apply(t, k)
+
+
+class CombineChunkTermsFn(torch.autograd.Function):
+    """total[c] = sum_i sum_j coefs[i][j] * terms[i][c, j] for per-chunk term tensors of shape
+    (n_chunks,) or (n_chunks, k_i) -> (total (n_chunks,), matrix (n_chunks, sum k_i) of the raw
+    terms, for the metric read-back).  One node and three small kernels instead of a chain of
+    scalar multiplies, adds and negations with a backward node each."""
+
+    @staticmethod
+    def forward(ctx, coefs, *terms):
+        cols = [t[:, None] if t.dim() == 1 else t for t in terms]
+        mat = torch.cat(cols, dim=1)
+        cvec = device_constant([c for cs in coefs for c in cs], mat.device)
+        ctx.widths = [c.shape[1] for c in cols]
+        ctx.flat = [t.dim() == 1 for t in terms]
+        ctx.save_for_backward(cvec)
+        ctx.mark_non_differentiable(mat)
+        return torch.mv(mat, cvec), mat
+
+    @staticmethod
+    def backward(ctx, g, _gmat):
+        (cvec,) = ctx.saved_tensors
+        G = g[:, None] * cvec[None, :]                     # (n_chunks, sum k_i)
+        out, pos = [], 0
+        for width, flat in zip(ctx.widths, ctx.flat):
+            blk = G[:, pos:pos + width]
+            out.append(blk[:, 0] if flat else blk)
+            pos += width
+        return (None,) + tuple(out)
+
+
+def combine_chunk_terms(terms, coefs):
+    """-> (total (n_chunks,), matrix of the terms (n_chunks, K), detached)."""
+    return CombineChunkTermsFn.apply([[float(c) for c in cs] for cs in coefs], *terms)
+
+
 def kl_to_std_normal(mu, logvar):
     return KLFn.apply(mu, logvar)

@@ -477,13 +477,18 @@ class PSVAE(AE):
 
     def forward(self, x, dataset=None, use_mean=False, **kwargs):
         """-> (x_hat, z, mu, logvar, y_hat)."""
+        return self._forward_parts(x, dataset, use_mean, **kwargs)[:5]
+
+    def _forward_parts(self, x, dataset=None, use_mean=False, **kwargs):
+        """forward() plus the two blocks (y, w) that mu is concatenated from: the loss takes the
+        supervised / unsupervised means from them instead of slicing mu apart again."""
         y, w, logvar, pool_idx, outsize = self.encoding(x, dataset=dataset)
         mu = torch.cat([y, w], dim=1)
         z = _sample(mu, logvar, use_mean, kwargs.get('sample_bounds'), kwargs.get('sample_shards'))
         x_hat = self.decoding(z, pool_idx, outsize, dataset=dataset,
                               pixel_loss=kwargs.get('pixel_loss'))
         y_hat = self.encoding.D(y)
-        return x_hat, z, mu, logvar, y_hat
+        return x_hat, z, mu, logvar, y_hat, y, w
 
     def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
         """Modified ELBO of the PS-VAE (ref vaes.py:603-729); returns the same 11 keys."""
@@ -511,7 +516,7 @@ class PSVAE(AE):
             xl, yl, ml, nl = sh.take(x, y, m, n)
             share = sh.share if sh.sharded else None
             with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, sample, mu, logvar, y_hat = self.forward(
+                x_hat, sample, mu, logvar, y_hat, mu_s, mu_u = self._forward_parts(
                     xl, dataset=dataset, use_mean=False, sample_bounds=bounds, sample_shards=sh,
                     pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
                                 'chunk_sizes': sh.sizes})
@@ -519,17 +524,26 @@ class PSVAE(AE):
                                                  const_share=share)
                 ll_y = losses.gaussian_ll_chunks(yl, y_hat, nl, bounds, chunk_sizes=sh.sizes,
                                                  const_share=share)
-                # column blocks once for the whole batch (not per chunk)
-                zs = sh.kl_terms(mu[:, :n_labels], logvar[:, :n_labels])
+                # column blocks once for the whole batch: the means are the encoder's own two
+                # heads, log-variance and sample are split by one node each
+                logvar_s, logvar_u = hf.split_cols(logvar, n_labels)
+                _, sample_u = hf.split_cols(sample, n_labels)
+                zs = sh.kl_terms(mu_s, logvar_s)
                 # batch-coupled: evaluated on the gathered chunk by every rank (see BetaTCVAE)
-                dk = sh.decomposed_kl_terms(sample[:, n_labels:], mu[:, n_labels:],
-                                            logvar[:, n_labels:])             # (n_chunks, 3)
-                kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
-                lossv = -ll_x - float(alpha) * ll_y + zs + kl_terms
+                dk = sh.decomposed_kl_terms(sample_u, mu_u, logvar_u)          # (n_chunks, 3)
                 w = sh.share_t(x.device)
-                table = torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk * (w if isinstance(w, float) else w[:, None]),
-                                   (-ll_x - float(alpha) * ll_y + zs + w * kl_terms)[:, None]],
-                                  dim=1)
+                if isinstance(w, float):
+                    # not sharded: the total and the metric table from one node
+                    lossv, terms = hf.combine_chunk_terms(
+                        [ll_x, ll_y, zs, dk], [[-1.0], [-float(alpha)], [1.0],
+                                               [float(kl), float(beta), float(kl)]])
+                    table = torch.cat([terms, lossv.detach()[:, None]], dim=1)
+                else:
+                    kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
+                    lossv = -ll_x - float(alpha) * ll_y + zs + kl_terms
+                    table = torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk * w[:, None],
+                                       (-ll_x - float(alpha) * ll_y + zs + w * kl_terms)[:, None]],
+                                      dim=1)
             # label r^2 over the whole batch: the ranks' rows are gathered (a few KB)
             y_hat_rb = hf.Readback(sh.all_rows(y_hat.detach()))
             y_rb = hf.Readback(sh.all_rows(yl))
