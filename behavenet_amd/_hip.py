@@ -38,7 +38,7 @@ SIGNATURES = {
     'bn_set_force_generic': (_c_int, [_c_int]),
     'bn_conv_ws_bytes': (_c_size_t, [_c_int] + _CONV_GEOM),
     'bn_conv2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
-    'bn_conv2d_fwd_u8_ws_bytes': (_c_size_t, _CONV_GEOM),
+    'bn_conv2d_fwd_u8_ws_bytes': (_c_size_t, _CONV_GEOM + [_c_int]),
     'bn_conv2d_fwd_u8': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_conv2d_bwd_data': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_conv2d_bwd_weight': (
@@ -185,7 +185,7 @@ def conv2d_fwd_u8(x_u8, w, b, geom, act, slope):
     N, C, H, W, K, R, S, st, pt, pl, P, Q = geom
     y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x_u8.device)
     lib = load()
-    nbytes = lib.bn_conv2d_fwd_u8_ws_bytes(*geom)
+    nbytes = lib.bn_conv2d_fwd_u8_ws_bytes(*geom, act)
     ws = None
     if nbytes:
         key = (x_u8.device, torch.cuda.current_stream(x_u8.device).cuda_stream, 'fwd_u8')

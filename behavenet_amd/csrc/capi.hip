@@ -352,10 +352,11 @@ static bool u8_fast(const BnGeom& g, int act) {
 }
 
 extern "C" size_t bn_conv2d_fwd_u8_ws_bytes(int N, int C, int H, int W, int K, int R, int S,
-                                            int stride, int pad_t, int pad_l, int P, int Q) {
+                                            int stride, int pad_t, int pad_l, int P, int Q,
+                                            int act) {
     const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     if (!bn_geom_ok(g)) return 0;
-    if (u8_fast(g, BN_ACT_NONE)) return 0;
+    if (u8_fast(g, act)) return 0;      // the SAME predicate the launch dispatches on
     size_t conv = bn_conv_ws_bytes(BN_OP_CONV_FWD, N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     conv = (conv + 255) & ~(size_t)255;
     return conv + (size_t)N * C * H * W * sizeof(float);
@@ -375,9 +376,10 @@ extern "C" int bn_conv2d_fwd_u8(const unsigned char* x, const float* w, const fl
                                              : "k_down_c1s<0, false, true, 4, 1>", st, true);
         return bn_launch_edge_down(nullptr, w, b, y, nullptr, g, act, BN_ACT_NONE, slope, st, x);
     }
-    const size_t need = bn_conv2d_fwd_u8_ws_bytes(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
-    if (!ws || ws_bytes < need) return BN_E_WORKSPACE;
+    const size_t need =
+        bn_conv2d_fwd_u8_ws_bytes(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q, act);
     const size_t n_in = (size_t)N * C * H * W;
+    if (!ws || ws_bytes < need || need < n_in * sizeof(float)) return BN_E_WORKSPACE;
     const size_t conv_ws = need - n_in * sizeof(float);
     float* xf = (float*)((char*)ws + conv_ws);
     int rc = bn_launch_u8_to_unit_float(x, xf, n_in, st);

@@ -54,6 +54,16 @@ def split_trials(n_trials, rng_seed=0, train_tr=8, val_tr=1, test_tr=1, gap_tr=0
     return {k: np.concatenate(v, axis=0) for k, v in out.items()}
 
 
+class _Skipped(object):
+    """What ``next_batch(skip=True)`` returns in place of a sample (not None: None = exhausted)."""
+
+    def __repr__(self):
+        return 'SKIPPED'
+
+
+SKIPPED = _Skipped()
+
+
 class SyntheticSession(object):
     """One session of synthetic trials (stands in for ``SingleSessionDatasetBatchedLoad``)."""
 
@@ -103,6 +113,7 @@ class SyntheticSessionsGenerator(object):
         self._store = [self._load_session(ds) for ds in self.datasets]
         # host_u8 prefetcher: two device staging buffers per trial shape, one copy stream
         self._pf = None          # (key, device uint8 tensor, ready event) of the prefetched trial
+        self.lookahead = 0       # queue position of this rank's next trial ('trial' mode: W - 1)
         self._pf_bufs = {}
         self._pf_stream = None
         self._queues = [{k: [] for k in self._dtypes} for _ in self.datasets]
@@ -160,11 +171,15 @@ class SyntheticSessionsGenerator(object):
         q = self._queues[sess][dtype]
         return len(self.datasets[sess].batch_idxs[dtype]) if q is None else len(q)
 
-    def next_batch(self, dtype, return_multiple=True):
+    def next_batch(self, dtype, return_multiple=True, skip=False):
         """One trial, or -- for training with ``n_sessions_per_batch`` > 1 -- a list of trials
         from that many DIFFERENT sessions plus the list of their ids (the multi-session batches
         of the MSPS-VAE, ref data_generator.py:712-790): sessions are drawn without replacement
-        by ``batch_ratios``; ``(None, None)`` once too few sessions have trials left."""
+        by ``batch_ratios``; ``(None, None)`` once too few sessions have trials left.
+
+        ``skip=True`` (data-parallel 'trial' mode: the trial belongs to another rank) advances
+        the generator exactly as a normal call would -- same queue pops, same RNG draws -- but
+        does not read, copy or convert the trial: returns ``(SKIPPED, session)``."""
         if self.n_sessions_per_batch > 1 and dtype == 'train' and return_multiple:
             samples, sessions = [], []
             ratios = np.array(self.batch_ratios, dtype=np.float64)
@@ -179,9 +194,9 @@ class SyntheticSessionsGenerator(object):
                     if self._n_left(sess, dtype):
                         trial = self._queue(sess, dtype).pop(0)
                         break
-                samples.append(self._sample(sess, trial, dtype))
+                samples.append(SKIPPED if skip else self._sample(sess, trial, dtype))
                 sessions.append(sess)
-            return samples, sessions
+            return (SKIPPED if skip else samples), sessions
         if all(self._n_left(i, dtype) == 0 for i in range(self.n_datasets)):
             return None, None
         while True:
@@ -189,6 +204,8 @@ class SyntheticSessionsGenerator(object):
             if self._n_left(sess, dtype):
                 trial = self._queue(sess, dtype).pop(0)
                 break
+        if skip:
+            return SKIPPED, sess
         return self._sample(sess, trial, dtype), sess
 
     def _sample(self, sess, trial, dtype):
@@ -255,10 +272,13 @@ class SyntheticSessionsGenerator(object):
         done.record(main)
         self._pf_done[slot] = done
         self._pf_slot = slot ^ 1
-        # look ahead: the head of this session's queue is (very likely) the next trial
+        # look ahead: the head of this session's queue is (very likely) the next trial -- in
+        # data-parallel 'trial' mode the one `lookahead` = world - 1 places further down (the
+        # trials in between go to the other ranks, `next_batch(skip=True)`)
         queue = self._queues[sess][dtype]      # (None: the session's order is not drawn yet)
-        if queue:
-            nxt = queue[0]
+        ahead = int(getattr(self, 'lookahead', 0))
+        if queue and len(queue) > ahead:
+            nxt = queue[ahead]
             host = self._store[sess][0][nxt]
             nslot = self._pf_slot
             buf = self._staging(host.shape, nslot)

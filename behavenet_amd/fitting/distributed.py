@@ -6,9 +6,11 @@ all-reduce (sum) of the flat gradient arena per optimizer step (35 MB for the de
 
 Two sharding modes:
 
-* ``'trial'`` (weak scaling, default): every rank draws its own trial per step; gradients are
-  summed, i.e. one optimizer step consumes ``world_size`` trials.  Not step-for-step identical
-  to the single-GPU reference (which steps once per trial).
+* ``'trial'`` (weak scaling, default): the training trials of an epoch are dealt to the ranks
+  in groups of ``world_size`` (every rank walks the same order and keeps the trial at its own
+  position), gradients are AVERAGED over the trials of the step (``fit``; a short last group
+  divides by its own size), i.e. one optimizer step consumes up to ``world_size`` trials.  Not
+  step-for-step identical to the single-GPU reference (which steps once per trial).
 * ``'frames'`` (strong scaling, parity-exact): all ranks see the same trial; inside each
   200-frame chunk rank r takes the contiguous slice [r*n_c/R, (r+1)*n_c/R) and its loss is
   scaled to the *global* chunk mean, so the summed gradient equals the single-GPU gradient.

@@ -33,7 +33,19 @@ class Experiment(object):
         self.tags = {}
         self.created_at = time.time()
         root = os.path.join(self.save_dir, self.name)
-        if version is None:
+        if version is None and not self.debug:
+            # Claim the directory atomically: the ranks of a grid search (one grid point per
+            # rank, usually the same experiment name) get here at the same time, and "list, then
+            # create" would hand two of them the same version_K -- `mkdir` either creates the
+            # directory or fails, so exactly one process owns each K.
+            version = self._next_version(root)
+            while True:
+                try:
+                    os.makedirs(self.get_data_path(self.name, version), exist_ok=False)
+                    break
+                except FileExistsError:
+                    version += 1
+        elif version is None:
             version = self._next_version(root)
         self.version = int(version)
         if not self.debug:

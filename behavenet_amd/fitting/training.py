@@ -176,6 +176,18 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
         bdist.broadcast_parameters_(optimizer.flat_p)
         bdist.attach_reducer(optimizer)
 
+    reducer = getattr(optimizer, 'reducer', None)
+    overlap_pref = reducer.overlap if reducer is not None else False
+    can_skip = False
+    if trial_mode:
+        import inspect
+        try:
+            can_skip = 'skip' in inspect.signature(data_generator.next_batch).parameters
+        except (TypeError, ValueError):
+            can_skip = False
+        if can_skip and hasattr(data_generator, 'lookahead'):
+            data_generator.lookahead = world - 1
+
     logger = Logger(n_datasets=data_generator.n_datasets)
     early_stop = None
     if hparams['enable_early_stop']:
@@ -219,15 +231,29 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
         logger.reset_metrics('train')
         data_generator.reset_iterators('train')
         model.curr_epoch = i_epoch
+        if reducer is not None:
+            # Epoch 0 takes no optimizer step, so nothing is reduced in it -- and nothing may be
+            # LAUNCHED either: the overlapped reducer sends a bucket as soon as the backward pass
+            # has completed it, a rank without a trial in the last (short) group of the epoch
+            # runs no backward pass, and the ranks' collective sequences would then differ
+            # (RCCL: hang or mixed-up payloads).  From epoch 1 on every step ends in
+            # `reduce_gradients`, which launches whatever a rank has not sent yet in bucket
+            # order, so ranks with and without a trial issue the same sequence.
+            reducer.overlap = overlap_pref and i_epoch > 0
 
         for i_train in _progress(range(n_train), show_bar):
             model.train()
             optimizer.zero_grad()
             if trial_mode:
-                # every rank draws the same W trials (same seeds, same generator state) and
-                # keeps the one at its own position: disjoint trials, nothing communicated
-                group = [data_generator.next_batch('train')
-                         for _ in range(min(world, n_trials_train - i_train * world))]
+                # every rank walks the same W trials (same seeds, same generator state) and
+                # keeps the one at its own position: disjoint trials, nothing communicated; the
+                # other ranks' trials only advance the generator (no read / copy / conversion)
+                n_group = min(world, n_trials_train - i_train * world)
+                if can_skip:
+                    group = [data_generator.next_batch('train', skip=(j != rank))
+                             for j in range(n_group)]
+                else:
+                    group = [data_generator.next_batch('train') for _ in range(n_group)]
                 data, dataset = group[rank] if rank < len(group) else (None, None)
                 stepping = any(d is not None for d, _ in group)
                 n_in_step = sum(d is not None for d, _ in group)

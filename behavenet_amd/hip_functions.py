@@ -725,6 +725,8 @@ def conv_stack_bn(plan, x, params, bn_modules):
         h = ConvStackFn.apply(run_plan, h, None, *run_params)
         bn = bn_modules[i]
         h = BatchNormActFn.apply(h, bn.weight, bn.bias, bn, layer.act)
+        if _sign_tap is not None and layer.act == _hip.ACT_LRELU:
+            _sign_tap.setdefault(id(plan), [[] for _ in plan])[i].append((h.detach() > 0).cpu())
         run_plan, run_params = [], []
     if run_plan:
         h = ConvStackFn.apply(run_plan, h, None, *run_params)

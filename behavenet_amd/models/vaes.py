@@ -89,6 +89,17 @@ class _FrameShards(object):
             self.bounds_l.append((pos, pos + e - b))
             pos += e - b
         self.n_local = pos
+        if self.sharded:
+            # every rank evaluates this for ALL ranks, so that all of them refuse together (a
+            # rank that raised alone would leave the others waiting in their collectives)
+            _, R = bdist.shard_rank_world()
+            for q in range(R):
+                if all(bdist.shard_bounds(b, e, q, R)[0] == bdist.shard_bounds(b, e, q, R)[1]
+                       for b, e in self.bounds):
+                    raise NotImplementedError(
+                        'frame sharding: a batch of %d frames (chunks of %d) leaves rank %d of '
+                        '%d without a frame; the variational models need one frame per rank'
+                        % (batch_size, chunk_size, q, R))
         self.share = [(le - lb) / float(n) for (lb, le), n in zip(self.local, self.sizes)]
 
     def take(self, *tensors):

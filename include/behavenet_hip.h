@@ -285,10 +285,11 @@ int bn_adam_amsgrad_step(float* p, const float* g, float* m, float* v, float* vm
  * and feeds the float copy to nn.Conv2d (aes.py:81-86,153); here the conversion (an IEEE division,
  * bit-identical to numpy's) happens while the input patch is staged, so a frame is read as 1 byte
  * per pixel and no float copy of it is ever written.  Same geometry arguments as bn_conv2d_fwd;
- * `ws`: bn_conv2d_fwd_u8_ws_bytes() bytes (0 for the benchmark layer; other geometries convert
- * into it and run the float kernels). */
+ * `ws`: bn_conv2d_fwd_u8_ws_bytes(..., act) bytes for the SAME geometry and activation (0 for the
+ * benchmark layer with BN_ACT_NONE / BN_ACT_LRELU; other geometries / activations convert into it
+ * and run the float kernels; BN_E_WORKSPACE if it is missing or too small). */
 size_t bn_conv2d_fwd_u8_ws_bytes(int N, int C, int H, int W, int K, int R, int S, int stride,
-                                 int pad_t, int pad_l, int P, int Q);
+                                 int pad_t, int pad_l, int P, int Q, int act);
 int bn_conv2d_fwd_u8(const unsigned char* x, const float* w, const float* b, float* y,
                      int N, int C, int H, int W, int K, int R, int S, int stride,
                      int pad_t, int pad_l, int P, int Q, int act, float slope,

@@ -35,7 +35,7 @@ class _Eps(object):
     def __call__(self, like):
         g = torch.Generator().manual_seed(1000 + self.i)
         self.i += 1
-        return torch.randn(like.shape, generator=g).to(like.device)
+        return torch.randn(like.shape, generator=g).to(device=like.device, dtype=like.dtype)
 
 
 def build_case(case):
@@ -67,6 +67,36 @@ def build_case(case):
     model = model.to(DEV)
     model.train()
     return model, data, kw
+
+
+def build_oracle(case, dtype=torch.float64):
+    """The CPU oracle of the same case (same seeds => same parameters, same eps per chunk)."""
+    from oracle import ref_cpu
+    arch = load_handcrafted_arch(list(DIM), 8, None, check_memory=False)
+    data = {'images': torch.from_numpy(make_frames(44, DIM, seed=8)).to(dtype)[None]}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    if case == 'ae_bn':
+        model = ref_cpu.AE(base_hparams(arch, 'ae', {'ae_batch_norm': True}))
+    elif case == 'psvae':
+        hp = base_hparams(arch, 'ps-vae', {'ps_vae.alpha': 10.0, 'ps_vae.beta': 3.0,
+                                           'ps_vae.anneal_epochs': 0, 'max_n_epochs': 10})
+        hp['n_labels'] = 2
+        model = ref_cpu.PSVAE(hp)
+        data['labels'] = torch.from_numpy(make_labels(44, 2, seed=2)).to(dtype)[None]
+        model.eps_fn = _Eps()
+    elif case == 'betatc':
+        hp = base_hparams(arch, 'beta-tcvae', {'vae.beta': 1.0, 'vae.beta_anneal_epochs': 0,
+                                               'beta_tcvae.beta': 4.0,
+                                               'beta_tcvae.beta_anneal_epochs': 0,
+                                               'max_n_epochs': 10})
+        model = ref_cpu.BetaTCVAE(hp)
+        model.eps_fn = _Eps()
+    else:
+        raise ValueError(case)
+    model = model.to(dtype)
+    model.train()
+    return model, data, {'chunk_size': 30}
 
 
 def flat_grad(model):
@@ -113,12 +143,20 @@ def main():
     if case == 'fit':
         out = run_fit(os.path.join(tmp, 'rank%d' % rank))
     else:
+        from tests.branches import record_branches
         model, data, kw = build_case(case)
         opt = FlatAdamAMSGrad(model.get_parameters(), lr=1e-4)
         opt.zero_grad()
-        loss = model.loss(data, dataset=0, accumulate_grad=True, **kw)
+        with record_branches(model) as rec:
+            loss = model.loss(data, dataset=0, accumulate_grad=True, **kw)
         bdist.reduce_gradients(opt)
         g = flat_grad(model).cpu().double().numpy()
+        # this rank's LeakyReLU branch pattern (its frames, its processing order) and, from rank
+        # 0, the whole all-reduced gradient: the test runs the float64 oracle on the assembled
+        # pattern (tests/branches.py)
+        torch.save(rec, os.path.join(tmp, '%s_branches_rank%d.pt' % (case, rank)))
+        if rank == 0:
+            np.save(os.path.join(tmp, case + '_grad.npy'), g)
         idx = np.linspace(0, g.size - 1, 8192).astype(np.int64)
         out = {'loss': loss, 'grad_norm': float(np.linalg.norm(g)), 'grad_index': idx.tolist(),
                'grad_sample': g[idx].tolist(),

@@ -43,3 +43,19 @@ def test_combine_chunk_terms_matches_the_written_out_sum():
     want.backward(torch.ones(2))
     for g, t in zip(got, (ll_x, ll_y, zs, dk)):
         assert torch.allclose(g, t.grad, rtol=1e-6, atol=1e-6)
+
+
+def test_frame_shards_refuse_on_every_rank_when_one_rank_has_no_frame():
+    """a chunk with fewer frames than ranks leaves some rank's packed batch empty; the
+    variational losses then must not run zero-row kernels / gathers on that rank alone -- ALL
+    ranks refuse together (same exception everywhere, nobody is left waiting in a collective)."""
+    import pytest
+    from behavenet_amd.fitting import distributed as bdist
+    from behavenet_amd.models.vaes import _FrameShards
+    for r in range(8):
+        with bdist.emulate_rank(r, 8):
+            with pytest.raises(NotImplementedError, match='without a frame'):
+                _FrameShards(4, 200)
+            sh = _FrameShards(210, 200)        # 200 + 10 frames over 8 ranks: everyone has some
+            assert sh.sharded and sh.n_local in (26, 27)
+    assert not _FrameShards(4, 200).sharded    # no process group, no emulation: plain chunks

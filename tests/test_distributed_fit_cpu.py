@@ -167,6 +167,84 @@ def test_fit_trial_mode_two_ranks(tmp_path):
     np.testing.assert_allclose([r['tr_loss'] for r in rows0], tr_rows, rtol=1e-6)
 
 
+def _fit_worker_hooks(rank, world, port, tmp, out):
+    """As _fit_worker, with what the HIP autograd nodes do on the device: every parameter is
+    reported to the bucketed reducer as soon as its gradient is complete, so buckets go out
+    DURING the backward pass (BucketedGradReducer.grad_ready)."""
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'BN_BUCKET_MB': '4'})
+    torch.set_num_threads(2)
+    bdist.init_from_env(backend='gloo')
+    hp, gen, model = _setup(os.path.join(tmp, 'r%d' % rank))
+    hp['dp_shard'] = 'trial'
+    opt = _CpuFlatAdam(model.get_parameters(), hp['learning_rate'], hp['l2_reg'])
+    launched = []
+
+    def report(p):
+        red = getattr(opt, 'reducer', None)
+        if red is not None:
+            red.grad_ready(p)
+            launched.append(red.n_overlapped)
+    for p in opt.params:
+        p.register_post_accumulate_grad_hook(report)
+    exp = _Exp()
+    fit(hp, model, gen, exp, method='ae', optimizer=opt)
+    out.put((rank, opt.flat_p.clone().numpy(), [r for r in exp.rows if 'tr_loss' in r],
+             len(opt.reducer.buckets), max(launched) if launched else 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_trial_mode_short_last_group_with_overlapped_reducer(tmp_path):
+    """8 training trials on W = 3 ranks: groups of 3, 3 and 2 -- in the last step of every epoch
+    rank 2 has no trial and runs no backward pass.  With buckets going out during the backward
+    pass the ranks must still issue the same sequence of collectives, epoch 0 (no optimizer step,
+    hence nothing to reduce) included; a mismatch hangs gloo / RCCL or pairs up the wrong
+    payloads."""
+    world = 3
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker_hooks, args=(r, world, port, str(tmp_path), out))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([out.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    (_, p0, rows0, n_buckets, n_over0), (_, p1, rows1, _, _), (_, p2, rows2, _, _) = res
+    assert n_buckets >= 3 and n_over0 >= 2, 'the overlapped path was not exercised'
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(p0, p2)
+    assert rows0 == rows1 == rows2 and len(rows0) == 3
+
+    # single process doing the same by hand: groups of 3, 3, 2 trials, mean gradient, one step
+    hp, gen, model = _setup(os.path.join(str(tmp_path), 'ref'))
+    opt = _CpuFlatAdam(model.get_parameters(), hp['learning_rate'], hp['l2_reg'])
+    tr_rows = []
+    for epoch in range(3):
+        torch.manual_seed(3 + epoch)
+        np.random.seed(3 + epoch)
+        gen.reset_iterators('train')
+        tot = 0.0
+        for n_group in (3, 3, 2):
+            opt.zero_grad()
+            for _ in range(n_group):
+                data, ds = gen.next_batch('train')
+                tot += model.loss(data, dataset=ds, accumulate_grad=True)['loss']
+            if epoch > 0:
+                opt.flat_g.div_(n_group)
+                opt.step()
+        tr_rows.append(tot / 8)
+    np.testing.assert_allclose(p0, opt.flat_p.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose([r['tr_loss'] for r in rows0], tr_rows, rtol=1e-6)
+
+
 class _StubModel(torch.nn.Module):
     """What export_latents touches: hparams, version, eval(), encoding(x, dataset=)."""
 

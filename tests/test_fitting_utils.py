@@ -244,6 +244,26 @@ def test_experiment_logger_files(tmp_path):
     assert Experiment(name='e', save_dir=str(tmp_path), version=7).version == 7
 
 
+def _claim_version(args):
+    save_dir, barrier_file = args
+    import time
+    while not os.path.exists(barrier_file):     # start all claimants at (nearly) the same time
+        time.sleep(0.001)
+    return Experiment(name='e', save_dir=save_dir).version
+
+
+def test_experiment_versions_are_claimed_atomically(tmp_path):
+    """The ranks of a grid search create their experiments at the same moment under one name
+    (one grid point per rank): every process must get its own version_K."""
+    import multiprocessing as mp
+    flag = os.path.join(str(tmp_path), 'go')
+    with mp.get_context('fork').Pool(8) as pool:
+        res = pool.map_async(_claim_version, [(str(tmp_path), flag)] * 8, chunksize=1)
+        open(flag, 'w').close()
+        versions = res.get(timeout=60)
+    assert sorted(versions) == list(range(8))
+
+
 def test_data_generator_inputs():
     from behavenet_amd.data.utils import get_data_generator_inputs
     from behavenet_amd.data.transforms import MakeOneHot2D

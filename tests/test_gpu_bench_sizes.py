@@ -339,3 +339,111 @@ def test_first_layer_from_uint8_frames_at_bench_sizes(n):
     close(got[sub], want, want64, name='E0 u8 N=%d' % n)
     assert torch.equal(got, _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom,
                                             _hip.ACT_LRELU, SLOPE))
+
+
+def test_whole_model_psvae_batch256_loss_and_gradients_vs_oracle():
+    """BASELINE configs[3] AT THE SIZE bench.py TIMES IT (`secondary[0]`): PS-VAE on 2x128x128
+    frames, 16 latents, 4 labels, batch 256 = chunks 200 + 56, ps_vae.alpha 1000 / beta 5 /
+    anneal 100, epoch 3 (reference vaes.py:603-729: per chunk eps, per chunk decomposed KL and
+    label terms, gradients accumulated over chunks).  The single pass the bench runs against the
+    oracle's chunk-by-chunk loop with the SAME eps per chunk: all 11 loss keys against the fp32
+    oracle, every parameter gradient against the float64 oracle on the device's LeakyReLU
+    branches (tests/branches.py)."""
+    from behavenet_amd.models import PSVAE
+    from behavenet_amd.models import vaes as hip_vaes
+    from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+    from oracle import ref_cpu
+    from tests.branches import record_branches, BranchReplay
+    from tests.cases import EpsReplay, seeded_build
+    from tests.golden_utils import base_hparams, make_frames, make_labels
+    from tests.test_gpu_model import grads_close_on_same_branches
+
+    dim, n_lat, n_labels = [2, 128, 128], 16, 4
+    extra = {'ps_vae.alpha': 1000, 'ps_vae.beta': 5, 'ps_vae.anneal_epochs': 100,
+             'max_n_epochs': 200}
+
+    def hparams():
+        arch = load_handcrafted_arch(list(dim), n_lat, None, check_memory=False)
+        hp = base_hparams(arch, 'ps-vae', extra)
+        hp['n_labels'] = n_labels
+        return hp
+    hip = seeded_build(PSVAE, hparams()).to(DEV)
+    ora = seeded_build(ref_cpu.build_model, hparams())
+    ora64 = seeded_build(ref_cpu.build_model, hparams()).double()
+    for (k1, v1), (k2, v2) in zip(hip.state_dict().items(), ora.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2)
+    data_c = {'images': torch.from_numpy(make_frames(256, dim, seed=1))[None],
+              'labels': torch.from_numpy(make_labels(256, n_labels, seed=2))[None]}
+    data_g = {k: v.to(DEV) for k, v in data_c.items()}
+    g = torch.Generator().manual_seed(9)
+    eps = [torch.randn((n, n_lat), generator=g).numpy() for n in (200, 56)]
+    for m in (hip, ora, ora64):
+        m.train()
+        m.curr_epoch = 3
+    ora.eps_fn = EpsReplay(eps)
+    ora64.eps_fn = EpsReplay([e.astype(np.float64) for e in eps])
+    hip_vaes.set_eps_provider(EpsReplay(eps, DEV))
+    try:
+        hip.zero_grad(set_to_none=True)
+        with record_branches(hip) as rec:
+            loss_h = hip.loss(data_g, dataset=0, accumulate_grad=True)
+        loss_o = ora.loss(data_c, dataset=0, accumulate_grad=False)
+        with BranchReplay(rec) as br:
+            loss_64 = ora64.loss({k: v.double() for k, v in data_c.items()}, dataset=0,
+                                 accumulate_grad=True)
+    finally:
+        hip_vaes.set_eps_provider(None)
+    br.assert_only_ties()
+    assert sorted(loss_h.keys()) == sorted(loss_o.keys()) and len(loss_h) == 11, sorted(loss_h)
+    for k in loss_o:
+        assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-6), ('fp32 oracle', k)
+        assert loss_h[k] == pytest.approx(loss_64[k], rel=1e-4, abs=1e-6), ('float64 oracle', k)
+    grads_close_on_same_branches(hip, ora64, 'PS-VAE batch 256')
+    # the launches were the two-channel edge kernels of the bench profile
+    _hip.prof_select(_hip.PROF_CONV_FWD, 2, 32)
+    hip.loss(data_g, dataset=0, accumulate_grad=False)
+    torch.cuda.synchronize()
+    _, n, name = _hip.prof_read()
+    _hip.prof_select(_hip.PROF_NONE)
+    assert n == 1 and name == KERNELS_256[('E0c2', 'fwd')], (n, name)
+
+
+@pytest.mark.parametrize('n', [256, 56])
+def test_encoding_from_uint8_trials_latents_vs_oracle(n):
+    """BASELINE configs[4] as bench.py times it (`secondary[1]`): ``AE.encoding`` on a resident
+    uint8 trial (reference eval.py:51-90 feeds ``astype(float32) / 255`` frames through
+    ``model.encoding``): the LATENTS of all n frames against the oracle's encoder in fp32 and
+    float64, and bit-equal to the float-frame path."""
+    from behavenet_amd.models import AE
+    from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+    from oracle import ref_cpu
+    from tests.golden_utils import base_hparams
+
+    dim = [1, 128, 128]
+    arch = load_handcrafted_arch(list(dim), 12, None, check_memory=False)
+    torch.manual_seed(0)
+    hip = AE(base_hparams(arch, 'ae')).to(DEV)
+    torch.manual_seed(0)
+    ora = ref_cpu.AE(base_hparams(dict(arch), 'ae'))
+    torch.manual_seed(0)
+    ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae')).double()
+    rng = np.random.default_rng(100 + n)
+    u8 = rng.integers(0, 256, size=(n, 1, 128, 128), dtype=np.uint8)
+    x = torch.from_numpy(u8.astype(np.float32) / 255)
+    for m in (hip, ora, ora64):
+        m.eval()
+    _hip.prof_select(_hip.PROF_CONV_FWD, 1, 32)
+    with torch.no_grad():
+        z_u8 = hip.encoding(torch.from_numpy(u8).to(DEV), dataset=0)[0]
+        torch.cuda.synchronize()
+        _, cnt, name = _hip.prof_read()
+        _hip.prof_select(_hip.PROF_NONE)
+        z_f = hip.encoding(x.to(DEV), dataset=0)[0]
+        z_o = ora.encoding(x, dataset=0)[0]
+        z_64 = ora64.encoding(x.double(), dataset=0)[0]
+    assert cnt == 1 and name == 'k_down_c1s<1, false, true, 4, 1>', (cnt, name)
+    assert z_u8.shape == (n, 12)
+    close(z_u8, z_o, z_64, name='latents from uint8, N=%d' % n)
+    # The float path's first layer runs on another kernel (k_down_c1): same taps, same order ->
+    # bit-equal first layer (test_first_layer_from_uint8_frames_at_bench_sizes), so equal latents
+    assert torch.equal(z_u8, z_f)

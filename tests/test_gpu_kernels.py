@@ -495,7 +495,7 @@ def test_u8_to_unit_float_bit_exact():
 
 
 @pytest.mark.parametrize('case_name', ['E0', 'E0_2ch', 'k3s1', 'E1'])
-@pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_NONE])
+@pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_NONE, _hip.ACT_SIGMOID])
 def test_conv2d_fwd_u8(case_name, act):
     """First encoder layer from uint8 frames (bn_conv2d_fwd_u8): bit-identical to the float
     kernel on ``u8.astype(float32) / 255`` (reference data_generator.py:251-263) and within the

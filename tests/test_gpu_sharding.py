@@ -22,6 +22,7 @@ from behavenet_amd.models import AE, VAE
 from behavenet_amd.models import vaes as hip_vaes
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from oracle import ref_cpu
+from tests.branches import record_branches, BranchReplay
 from tests.golden_utils import base_hparams, make_frames
 from tests.test_gpu_kernels import close
 
@@ -34,23 +35,73 @@ def _grads(model):
     return [p.grad.detach().clone() for p in model.parameters() if p.requires_grad]
 
 
+def _rank_frames(batch, chunk, r, R):
+    """Global frame indices rank r of R processes, in its processing order (its slice of chunk
+    0, then of chunk 1, ...: `shard_chunks`)."""
+    with bdist.emulate_rank(r, R):
+        _, local, _ = bdist.shard_chunks(batch, chunk)
+    return [i for b, e in local for i in range(b, e)]
+
+
+def assemble_branches(per_rank, frames_of_rank, batch):
+    """One whole-batch LeakyReLU branch pattern (tests/branches.py) from the patterns the ranks
+    recorded on their own frames: {stack: [bool (batch, C, H, W) | None per layer]}."""
+    out = {}
+    for stack in per_rank[0]:
+        layers = []
+        for li, first in enumerate(per_rank[0][stack]):
+            if first is None:
+                layers.append(None)
+                continue
+            full = torch.zeros((batch,) + tuple(first.shape[1:]), dtype=torch.bool)
+            seen = torch.zeros(batch, dtype=torch.bool)
+            for rec, frames in zip(per_rank, frames_of_rank):
+                assert rec[stack][li].shape[0] == len(frames)
+                if frames:
+                    full[frames] = rec[stack][li]
+                    seen[frames] = True
+            assert bool(seen.all()), 'shards do not cover the batch'
+            layers.append(full)
+        out[stack] = layers
+    return out
+
+
 def _sum_over_emulated_ranks(model, data, R, chunk_size, **loss_kw):
-    total, loss = None, {}
+    """-> (summed loss dict, summed gradients, whole-batch branch pattern of the R passes)."""
+    total, loss, recs = None, {}, []
+    batch = data['images'].shape[1]
     for r in range(R):
         model.zero_grad(set_to_none=True)
-        with bdist.emulate_rank(r, R):
+        with bdist.emulate_rank(r, R), record_branches(model) as rec:
             out = model.loss(data, dataset=0, accumulate_grad=True, chunk_size=chunk_size, **loss_kw)
+        recs.append(rec)
         g = _grads(model)
         total = g if total is None else [a + b for a, b in zip(total, g)]
         for k, v in out.items():
             loss[k] = loss.get(k, 0.0) + v
-    return loss, total
+    pattern = assemble_branches(recs, [_rank_frames(batch, chunk_size, r, R) for r in range(R)],
+                                batch)
+    return loss, total, pattern
+
+
+def _grads_match_oracle_on_branches(g_sum, ora64, name, tol=2e-5):
+    """The 2e-5 gate of tests/test_gpu_model.py::grads_close_on_same_branches for a gradient list."""
+    for g, (k, po) in zip(g_sum, [(k, p) for k, p in ora64.named_parameters() if p.requires_grad]):
+        w = po.grad.numpy()
+        err = np.abs(g.cpu().double().numpy() - w).max() / max(np.abs(w).max(), 1e-30)
+        assert err <= tol, '%s grad %s: normalised max err %.3e' % (name, k, err)
 
 
 @pytest.mark.parametrize('dim,n_lat,batch,chunk,R', [
     ([1, 32, 32], 8, 210, 200, 2), ([1, 32, 32], 8, 210, 200, 8),
     ([1, 128, 128], 12, 256, 200, 2), ([1, 128, 128], 12, 256, 200, 8)])
 def test_ae_frame_shards_add_up_to_the_single_device_step(dim, n_lat, batch, chunk, R):
+    """Sum over ranks of the frame-sharded losses and gradients == the reference's step
+    (aes.py:751-771).  Every rank's pass picks its own tilings, so each may put a LeakyReLU
+    pre-activation that lies within rounding of zero on either branch; the float64 oracle is
+    therefore run ONCE over the whole batch on the branch pattern assembled from the ranks'
+    passes, the pattern is checked to differ from the oracle's own only at ties, and the summed
+    gradients are then held to the same 2e-5 as every unsharded model test."""
     arch = load_handcrafted_arch(list(dim), n_lat, None, check_memory=False)
     torch.manual_seed(0)
     model = AE(base_hparams(arch, 'ae')).to(DEV)
@@ -58,34 +109,24 @@ def test_ae_frame_shards_add_up_to_the_single_device_step(dim, n_lat, batch, chu
     data = {'images': x.to(DEV)[None]}
     model.zero_grad(set_to_none=True)
     whole = model.loss(data, dataset=0, accumulate_grad=True, chunk_size=chunk)
-    g_whole = _grads(model)
-    shard_loss, g_sum = _sum_over_emulated_ranks(model, data, R, chunk)
+    shard_loss, g_sum, pattern = _sum_over_emulated_ranks(model, data, R, chunk)
     assert shard_loss['loss'] == pytest.approx(whole['loss'], rel=1e-6)
-    for a, b in zip(g_sum, g_whole):
-        # same kernels on fewer frames: fp32 summation order (and LeakyReLU ties, see
-        # tests/branches.py) -- L2 at rounding level, single elements within 1e-3 of the max
-        err = (a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)
-        assert float(err) <= 1e-3
-        close(a, b, norm_tol=2e-3, name='sum of shard gradients')
-    if dim[1] == 32:
-        # and against the oracle's chunk loop (fp32, CPU)
-        torch.manual_seed(0)
-        ora = ref_cpu.AE(base_hparams(dict(arch), 'ae'))
-        lo = ora.loss({'images': x[None]}, dataset=0, accumulate_grad=True, chunk_size=chunk)
-        assert shard_loss['loss'] == pytest.approx(lo['loss'], rel=1e-5)
-        for a, p in zip(g_sum, ora.parameters()):
-            # (fp32 oracle, own LeakyReLU branches at ties: tests/branches.py has the exact form)
-            err = (a.cpu().double() - p.grad.double()).norm() / p.grad.double().norm()
-            assert float(err) <= 2e-3
+    torch.manual_seed(0)
+    ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae')).double()
+    with BranchReplay(pattern) as br:
+        l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True,
+                         chunk_size=chunk)
+    br.assert_only_ties()
+    assert shard_loss['loss'] == pytest.approx(l64['loss'], rel=1e-5)
+    _grads_match_oracle_on_branches(g_sum, ora64, 'AE shards R=%d' % R)
 
 
 def test_vae_frame_shards_use_the_single_device_eps():
     dim, batch, chunk, R = [1, 32, 32], 210, 200, 4
     arch = load_handcrafted_arch(list(dim), 8, None, check_memory=False)
-    hp = base_hparams(arch, 'vae', {'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0,
-                                    'max_n_epochs': 10})
+    extra = {'vae.beta': 2.0, 'vae.beta_anneal_epochs': 0, 'max_n_epochs': 10}
     torch.manual_seed(0)
-    model = VAE(hp).to(DEV)
+    model = VAE(base_hparams(arch, 'vae', extra)).to(DEV)
     x = torch.from_numpy(make_frames(batch, dim, seed=6))
     data = {'images': x.to(DEV)[None]}
     g = torch.Generator().manual_seed(1)
@@ -96,7 +137,7 @@ def test_vae_frame_shards_use_the_single_device_eps():
             self.i = 0
 
         def __call__(self, like):
-            t = eps_chunks[self.i % 2].to(like.device)
+            t = eps_chunks[self.i % 2].to(device=like.device, dtype=like.dtype)
             self.i += 1
             assert t.shape == like.shape
             return t
@@ -104,17 +145,24 @@ def test_vae_frame_shards_use_the_single_device_eps():
         hip_vaes.set_eps_provider(Replay())
         model.zero_grad(set_to_none=True)
         whole = model.loss(data, dataset=0, accumulate_grad=True, chunk_size=chunk)
-        g_whole = _grads(model)
         hip_vaes.set_eps_provider(Replay())
-        shard_loss, g_sum = _sum_over_emulated_ranks(model, data, R, chunk)
+        shard_loss, g_sum, pattern = _sum_over_emulated_ranks(model, data, R, chunk)
     finally:
         hip_vaes.set_eps_provider(None)
     # (loss_mse is an affine function of loss_ll evaluated AFTER the sum over ranks: not additive)
     for k in ('loss', 'loss_ll', 'loss_kl'):
         assert shard_loss[k] == pytest.approx(whole[k], rel=2e-5, abs=1e-6), k
-    for a, b in zip(g_sum, g_whole):
-        err = (a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)
-        assert float(err) <= 1e-4
+    torch.manual_seed(0)
+    ora64 = ref_cpu.VAE(base_hparams(dict(arch), 'vae', extra)).double()
+    ora64.train()
+    ora64.eps_fn = Replay()
+    with BranchReplay(pattern) as br:
+        l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True,
+                         chunk_size=chunk)
+    br.assert_only_ties()
+    for k in ('loss', 'loss_ll', 'loss_kl'):
+        assert shard_loss[k] == pytest.approx(l64[k], rel=2e-5, abs=1e-6), k
+    _grads_match_oracle_on_branches(g_sum, ora64, 'VAE shards R=%d' % R)
 
 
 def test_batch_coupled_terms_refuse_emulation():
@@ -148,23 +196,58 @@ def _run_two_ranks(tmp_path, case):
 
 @pytest.mark.parametrize('case', ['ae_bn', 'psvae', 'betatc'])
 def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, case):
-    """Real collectives (gloo, host-staged) between two processes sharing the GPU."""
+    """Real collectives (gloo, host-staged) between two processes sharing the GPU: the terms
+    emulation cannot provide (SyncBN statistics, the decomposed KL on the all-gathered chunk).
+    Loss dict and running statistics against the single-process HIP step; the all-reduced
+    gradient -- ALL of it -- against the float64 oracle run on the LeakyReLU branch pattern
+    assembled from the two ranks' passes, at the 2e-5 of the unsharded tests."""
     got = _run_two_ranks(tmp_path, case)
-    from tests.dist_gpu_two_ranks import build_case, flat_grad
+    from tests.dist_gpu_two_ranks import build_case, build_oracle
     model, data, kw = build_case(case)
     model.zero_grad(set_to_none=True)
     want = model.loss(data, dataset=0, accumulate_grad=True, **kw)
+    hip_vaes.set_eps_provider(None)
     for k, v in want.items():
         assert got['loss'][k] == pytest.approx(v, rel=5e-5, abs=1e-6), k
-    g = flat_grad(model).cpu().double().numpy()
-    gg = np.asarray(got['grad_sample'])
-    idx = np.asarray(got['grad_index'])
-    scale = np.abs(g).max()
-    assert np.abs(gg - g[idx]).max() <= 2e-4 * scale
-    assert got['grad_norm'] == pytest.approx(float(np.linalg.norm(g)), rel=1e-4)
     for k, v in got.get('buffers', {}).items():          # batch-norm running statistics
         b = dict(model.named_buffers())[k].float().cpu().numpy()
         np.testing.assert_allclose(np.asarray(v), b.reshape(-1)[:len(v)], rtol=1e-4, atol=1e-6)
+
+    recs = [torch.load(os.path.join(str(tmp_path), '%s_branches_rank%d.pt' % (case, r)))
+            for r in range(2)]
+    pattern = assemble_branches(recs, [_rank_frames(44, 30, r, 2) for r in range(2)], 44)
+    g = np.load(os.path.join(str(tmp_path), case + '_grad.npy'))
+
+    def oracle_grads(dtype):
+        ora, data_o, kw_o = build_oracle(case, dtype)
+        with BranchReplay(pattern) as br:
+            loss = ora.loss(data_o, dataset=0, accumulate_grad=True, **kw_o)
+        named = [(k, p.grad.double().numpy()) for k, p in ora.named_parameters()
+                 if p.requires_grad]
+        return loss, named, br
+    l64, g64, br = oracle_grads(torch.float64)
+    br.assert_only_ties()
+    for k, v in l64.items():
+        assert got['loss'][k] == pytest.approx(v, rel=1e-4, abs=1e-6), ('float64 oracle', k)
+    assert sum(w.size for _, w in g64) == g.size
+    g32 = oracle_grads(torch.float32)[1] if case == 'ae_bn' else None
+    names = {k for k, _ in g64}
+    off = 0
+    for i, (k, w) in enumerate(g64):
+        mine = g[off:off + w.size].reshape(w.shape)
+        off += w.size
+        scale = max(np.abs(w).max(), 1e-30)
+        err = np.abs(mine - w).max() / scale
+        tol = 2e-5
+        if g32 is not None:
+            from tests.test_gpu_model import _bias_before_batchnorm
+            if _bias_before_batchnorm(k, names):
+                continue        # analytically zero: both sides compute rounding noise
+            # batch norm over 30 / 14 values per channel at the deepest layers: the fp32
+            # reference is itself off the float64 answer by more than 2e-5 (DESIGN.md section 2,
+            # `cond`) -- the bar is then the reference's own distance, on the same branches
+            tol = max(tol, 2 * np.abs(g32[i][1] - w).max() / scale)
+        assert err <= tol, '%s grad %s: normalised max err %.3e (tol %.1e)' % (case, k, err, tol)
 
 
 def test_fit_in_frames_mode_matches_single_process(tmp_path):
