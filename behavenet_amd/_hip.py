@@ -21,6 +21,7 @@ ACT_NONE, ACT_LRELU, ACT_SIGMOID = 0, 1, 2
 
 PROF_NONE, PROF_CONV_FWD, PROF_CONV_BWD_D, PROF_CONV_BWD_W = 0, 1, 2, 3
 PROF_CONVT_FWD, PROF_CONVT_BWD_D, PROF_CONVT_BWD_W, PROF_ADAM = 4, 5, 6, 7
+PROF_LINEAR_FWD, PROF_LINEAR_BWD = 8, 9
 
 _c_int, _c_float, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 

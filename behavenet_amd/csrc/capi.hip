@@ -92,7 +92,7 @@ BnProfScope::~BnProfScope() {
 }
 
 extern "C" int bn_prof_select(int family, int C, int K) {
-    if (family < BN_PROF_NONE || family > BN_PROF_ADAM) return BN_E_BADARG;
+    if (family < BN_PROF_NONE || family > BN_PROF_LINEAR_BWD) return BN_E_BADARG;
     g_prof.family = family;
     g_prof.C = C;
     g_prof.K = K;
@@ -560,6 +560,7 @@ extern "C" int bn_linear_fwd(const float* x, const float* w, const float* b, flo
     a.C = y; a.sci = N; a.scj = 1;
     a.M = M; a.N = N; a.K = K;
     a.bias_j = b; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f; a.accumulate = 0;
+    BnProfScope prof(BN_PROF_LINEAR_FWD, K, N, "k_gemm_mfma", (hipStream_t)stream);
     return bn_launch_gemm(a, (hipStream_t)stream, ws, ws_bytes);
 }
 
@@ -570,6 +571,8 @@ extern "C" int bn_linear_bwd(const float* x, const float* w, const float* dy, fl
     if (!dy || M <= 0 || K <= 0 || N <= 0) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     int rc = 0;
+    // (one scope over the data-gradient GEMM, the weight-gradient GEMM and the bias column sum)
+    BnProfScope prof(BN_PROF_LINEAR_BWD, K, N, "k_gemm_mfma (dx) + k_gemm_mfma (dw) + k_col_sum", st);
     if (dx) {
         if (!w) return BN_E_BADARG;
         GemmArgs a;                       // dx[m,k] = sum_n dy[m,n] w[n,k]

@@ -1,16 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark: conv-AE training frames/s, 128x128x1 frames, batch (= trial) 256.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--shard trial|frames]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Started plainly with --gpus N > 1 (no WORLD_SIZE in the environment) the script launches its own
+N ranks, one process per GPU, through torch.distributed.run on 127.0.0.1 -- the counterpart of the
+reference's entry point, which forks one process per GPU itself
+(behavenet/fitting/ae_grid_search.py:173-181, configs/ae_jsons/ae_compute.json:10).
 
 One "step" is one pass of the reference's hot loop over one 256-frame trial
 (training.py:336-352 with i_epoch > 0): zero_grad -> next_batch -> AE.loss(accumulate_grad=True)
 (the reference's per-chunk loss normalisation, chunks of 200 + 56 frames; here ONE forward and
 ONE backward pass over all 256 frames produce the same sum of per-chunk-mean gradients) ->
 [RCCL all-reduce of the flat gradient] -> Adam(amsgrad) step.  Trials are synthetic uint8-noise frames (float32/255) already
-resident in HBM.  With N > 1 every rank consumes its own trial per step (weak scaling) and the
-gradients are summed over ranks before the identical optimizer step.
+resident in HBM.  With N > 1: ``--shard trial`` (default; weak scaling) every rank consumes its own
+trial per step and the gradients are averaged over ranks before the identical optimizer step,
+as ``fit()`` does in 'trial' mode; ``--shard frames`` (strong scaling, the parity-exact reading of
+BASELINE configs[2]) all ranks take slices of the SAME 256-frame trial, every chunk term is
+normalised by the global chunk size and the gradients are summed.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline:     enc.conv0 (the HBM-bound encoder conv BASELINE.json targets): algorithmic bytes
@@ -59,6 +67,7 @@ def build_hparams():
 
 
 _PARTS = None    # BN_BENCH_TRACE=1: host time of the components of every step
+_AVERAGE = False  # N > 1, --shard trial: mean over the ranks' trials (fit()'s 'trial' mode)
 
 
 def one_step(model, opt, gen):
@@ -73,7 +82,7 @@ def one_step(model, opt, gen):
     if t: t.append(time.perf_counter())
     loss = model.loss(data, dataset=dataset, accumulate_grad=True)
     if t: t.append(time.perf_counter())
-    bdist.reduce_gradients(opt)
+    bdist.reduce_gradients(opt, average=_AVERAGE)
     opt.step()
     if t:
         t.append(time.perf_counter())
@@ -206,6 +215,51 @@ def profile_kernel(model, opt, gen, family, C, K, steps=2):
     return ms, n, name
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N
+    processes on this node (rendezvous on 127.0.0.1, a free port), same arguments."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL between processes)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
+           str(n_gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+def measure_allreduce(opt, iters=10):
+    """The gradient exchange on its own: `iters` all-reduces of the flat gradient arena exactly as
+    a step issues them (bucketed or flat), bracketed by barrier + synchronize; max over ranks."""
+    import torch.distributed as dist
+    keep = opt.flat_g.clone()
+    reducer = getattr(opt, 'reducer', None)
+
+    def once():
+        if reducer is not None:
+            reducer.begin()
+        bdist.reduce_gradients(opt)
+    once()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        once()
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = (time.perf_counter() - t0) / iters
+    t = torch.tensor([el], dtype=torch.float64,
+                     device='cpu' if dist.get_backend() == 'gloo' else 'cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    opt.flat_g.copy_(keep)
+    return float(t.item()) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -218,14 +272,24 @@ def main():
                     help="where the trials live (default 'device': resident float32, the headline "
                          "metric; 'host_u8' = pinned uint8 + prefetch, the PCIe-inclusive rate)")
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--shard', default='trial', choices=['trial', 'frames'],
+                    help="N > 1: 'trial' = one 256-frame trial per rank per step (weak scaling), "
+                         "'frames' = the ranks share ONE trial, each takes its slice of every "
+                         "200-frame chunk (strong scaling, parity-exact)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args.gpus)          # does not return
     rank, world = bdist.init_from_env()
     if world != max(1, args.gpus):
-        if rank == 0:
-            print('warning: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    global _AVERAGE
+    strong = world > 1 and args.shard == 'frames'
+    if world > 1:
+        bdist.set_shard_mode(args.shard)
+        _AVERAGE = not strong
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('BN_DIST_BACKEND') == 'gloo':
         local = 0           # control-flow test of the N > 1 path: all ranks share the one GPU
@@ -241,10 +305,12 @@ def main():
     bdist.attach_reducer(opt)
 
     # 20 trials x 256 frames per rank, trial_splits 8;1;1;0 -> 16 train trials
-    sess = SyntheticSession(20, BATCH, DIM, seed=100 + rank, trial_splits='8;1;1;0')
+    # ('frames': every rank holds the same trials and walks them in the same order)
+    data_rank = 0 if strong else rank
+    sess = SyntheticSession(20, BATCH, DIM, seed=100 + data_rank, trial_splits='8;1;1;0')
     gen = SyntheticSessionsGenerator([sess], device='cuda', placement=args.feed)
-    torch.manual_seed(1 + rank)
-    np.random.seed(1 + rank)
+    torch.manual_seed(1 + data_rank)
+    np.random.seed(1 + data_rank)
     gen.reset_iterators('train')
 
     # Setup, not measurement: the HIP runtime grows internal pools (signals, kernarg chunks) once
@@ -286,6 +352,19 @@ def main():
                           else 'bucketed, launched behind the backward pass',
                           'ms_per_step_overlapped': round(timing[True] * 1e3, 3),
                           'ms_per_step_behind': round(timing[False] * 1e3, 3)}
+    if bdist.is_active():
+        # what the collective library saw, and the exchange timed on its own
+        allreduce_mode = dict(allreduce_mode or {'chosen': 'one flat all-reduce behind the '
+                                                           'backward pass'})
+        allreduce_mode.update({
+            'world_size': torch.distributed.get_world_size(),
+            'backend': torch.distributed.get_backend() + (
+                ' (RCCL)' if torch.distributed.get_backend() == 'nccl' else ''),
+            'op': 'mean' if _AVERAGE else 'sum',
+            'gradient_bytes': int(opt.flat_g.numel() * 4),
+            'bucket_bytes': [int((hi - lo) * 4) for lo, hi, _ in reducer.buckets]
+            if reducer is not None else [int(opt.flat_g.numel() * 4)],
+            'allreduce_alone_ms': round(measure_allreduce(opt), 3)})
     for _ in range(args.warmup):
         one_step(model, opt, gen)
 
@@ -324,11 +403,14 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    frames = BATCH * world * args.steps
+    frames = BATCH * (1 if strong else world) * args.steps
     value = frames / elapsed
 
     # enc.conv0 roofline: one launch per step over the whole 256-frame batch
-    conv0_bytes = CONV0_BYTES_PER_FRAME * BATCH * args.steps
+    conv0_frames = BATCH
+    if strong:      # rank 0's slice of the two chunks
+        conv0_frames = sum(e - b for b, e in bdist.shard_chunks(BATCH, 200)[1])
+    conv0_bytes = CONV0_BYTES_PER_FRAME * conv0_frames * args.steps
     achieved = conv0_bytes / (conv0_ms * 1e-3) / 1e9 if conv0_ms > 0 else 0.0
     traffic = None
     tr_path = os.path.join(REPO, 'profiles', 'conv0_hbm_traffic.json')
@@ -354,23 +436,30 @@ def main():
         'metric': 'AE training frames/sec (128x128x1, batch 256)',
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
+        'dtype': 'f32',
         'data': 'synthetic',
         'config': {'workload': 'configs[1]: conv AE (default arch 32-64-128-256-512, k5, strides '
                                '2,2,2,2,5), 1x128x128 uint8-noise frames as float32/255, 12 '
                                'latents, one 256-frame trial per step per GPU (the reference\'s 200+56 '
                                'chunk loss normalisation; one forward/backward pass), '
                                'Adam(amsgrad) lr 1e-4',
-                   'frames_per_step_per_gpu': BATCH, 'global_frames_per_step': BATCH * world,
-                   'sharding': 'one trial per rank per step, RCCL all-reduce(sum) of the flat '
-                               '35 MB gradient' if world > 1 else 'single GPU',
+                   'frames_per_step_per_gpu': BATCH // world if strong else BATCH,
+                   'global_frames_per_step': BATCH if strong else BATCH * world,
+                   'sharding': ('single GPU' if world == 1 else
+                                'frames: the ranks share one 256-frame trial per step, rank r takes '
+                                'frames [r n_c/R, (r+1) n_c/R) of each 200-frame chunk, chunk terms '
+                                'normalised globally, all-reduce(sum) of the flat 35 MB gradient'
+                                if strong else
+                                'trial: one 256-frame trial per rank per step, all-reduce(mean) of '
+                                'the flat 35 MB gradient'),
                    'inputs': {'device': 'resident in HBM (float32)',
                               'device_u8': 'resident in HBM (uint8, converted per batch)',
                               'host_u8': 'pinned host uint8, prefetched over PCIe per batch',
                               'host': 'pinned host float32, copied per batch'}[args.feed]},
         'allreduce': allreduce_mode,
         'final_loss': last['loss'] if last else None,
-        'whole_step_fp32_tflops': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12, 2),
+        'whole_step_fp32_tflops_per_gpu': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12, 2),
         'whole_step_fp32_frac': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12 /
                                       FP32_PEAK_TFLOPS, 4),
         'roofline': roofline,
@@ -379,19 +468,56 @@ def main():
     if rank == 0 and world == 1:
         # FLOP-bound middle layers, profiled over two extra (untimed) steps each
         extra = []
+        # (C, K) as the dispatch reports them: gather-down / weight-gradient launches (big,
+        # small) channels, gather-up launches (small, big) -- csrc/capi.hip run_down / run_up
+        E4 = 26214400.0 * 16 / 25       # stride-5 layers: 16 of 25 taps ever meet data
         for label, fam, C, K, flop_per_frame in [
                 ('enc.conv1 fwd', _hip.PROF_CONV_FWD, 32, 64, 104857600.0),
                 ('enc.conv2 fwd', _hip.PROF_CONV_FWD, 64, 128, 104857600.0),
                 ('enc.conv3 fwd', _hip.PROF_CONV_FWD, 128, 256, 104857600.0),
+                ('enc.conv4 fwd (stride 5; executed FLOPs)', _hip.PROF_CONV_FWD, 256, 512, E4),
                 ('enc.conv1 bwd-weight', _hip.PROF_CONV_BWD_W, 32, 64, 104857600.0),
-                ('enc.conv1 bwd-data', _hip.PROF_CONV_BWD_D, 32, 64, 104857600.0)]:
+                ('enc.conv3 bwd-weight', _hip.PROF_CONV_BWD_W, 128, 256, 104857600.0),
+                ('enc.conv1 bwd-data', _hip.PROF_CONV_BWD_D, 64, 32, 104857600.0),
+                ('enc.conv3 bwd-data', _hip.PROF_CONV_BWD_D, 256, 128, 104857600.0),
+                ('dec.convT3 fwd', _hip.PROF_CONVT_FWD, 64, 32, 104857600.0),
+                ('dec.convT0 fwd (stride 5; executed FLOPs)', _hip.PROF_CONVT_FWD, 512, 256, E4),
+                # the true dense GEMMs of the path (north_star: MFMA utilisation of the linear
+                # latent projection): enc.FF 2048 -> 12 and dec.FF 12 -> 2048, 256 rows
+                ('enc.FF fwd (Linear 2048->12)', _hip.PROF_LINEAR_FWD, 2048, N_LATENTS,
+                 2.0 * 2048 * N_LATENTS),
+                ('dec.FF fwd (Linear 12->2048)', _hip.PROF_LINEAR_FWD, N_LATENTS, 2048,
+                 2.0 * 2048 * N_LATENTS),
+                ('enc.FF bwd (dx + dW + db)', _hip.PROF_LINEAR_BWD, 2048, N_LATENTS,
+                 4.0 * 2048 * N_LATENTS),
+                ('dec.FF bwd (dx + dW + db)', _hip.PROF_LINEAR_BWD, N_LATENTS, 2048,
+                 4.0 * 2048 * N_LATENTS)]:
             ms, n, name = profile_kernel(model, opt, gen, fam, C, K)
             if n:
-                tf = flop_per_frame * BATCH * 2 / (ms * 1e-3) / 1e12
+                tf = flop_per_frame * BATCH * n / (ms * 1e-3) / 1e12
                 extra.append({'layer': label, 'kernel': name, 'bound': 'mfma',
-                              'achieved': round(tf, 2), 'peak': FP32_PEAK_TFLOPS,
-                              'unit': 'TFLOP/s', 'frac': round(tf / FP32_PEAK_TFLOPS, 4),
+                              'achieved': round(tf, 3), 'peak': FP32_PEAK_TFLOPS,
+                              'unit': 'TFLOP/s', 'frac': round(tf / FP32_PEAK_TFLOPS, 5),
+                              'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 1)})
+            else:
+                extra.append({'layer': label, 'error': 'no launch matched (%d, %d, %d)' % (fam, C, K)})
+        # the two other HBM-bound edge kernels of the step, same event method as `roofline`
+        D4_LOSS_BYTES = 524288 + 65536 + 65536          # read h (32x64x64), read target, write dpre
+        for label, fam, C, K, bytes_per_frame in [
+                ('dec.convT4 fwd + Sigmoid + pixel loss + dL/dpre', _hip.PROF_CONVT_FWD, 32, 1,
+                 D4_LOSS_BYTES),
+                ('enc.conv0 bwd-weight', _hip.PROF_CONV_BWD_W, 1, 32, CONV0_BYTES_PER_FRAME),
+                ('dec.convT4 bwd-weight', _hip.PROF_CONVT_BWD_W, 1, 32, CONV0_BYTES_PER_FRAME),
+                ('dec.convT4 bwd-data', _hip.PROF_CONVT_BWD_D, 1, 32, 65536 + 2 * 524288)]:
+            ms, n, name = profile_kernel(model, opt, gen, fam, C, K)
+            if n:
+                gbs = bytes_per_frame * BATCH * n / (ms * 1e-3) / 1e9
+                extra.append({'layer': label, 'kernel': name, 'bound': 'hbm',
+                              'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                              'frac': round(gbs / HBM_PEAK_GBS, 4), 'launches': n,
                               'avg_launch_us': round(ms * 1e3 / n, 1)})
+            else:
+                extra.append({'layer': label, 'error': 'no launch matched (%d, %d, %d)' % (fam, C, K)})
         out['roofline_other_kernels'] = extra
         if not args.no_secondary:
             del model, opt, gen

@@ -311,6 +311,8 @@ int bn_u8_to_unit_float(const unsigned char* in, float* out, size_t n, bn_stream
 #define BN_PROF_CONVT_BWD_D 5
 #define BN_PROF_CONVT_BWD_W 6
 #define BN_PROF_ADAM        7
+#define BN_PROF_LINEAR_FWD  8   /* nn.Linear forward; C = in features, K = out features */
+#define BN_PROF_LINEAR_BWD  9   /* nn.Linear backward: all launches of one bn_linear_bwd call */
 /* select family + optional geometry filter (C<=0 / K<=0 = any).  Resets the accumulators. */
 int bn_prof_select(int family, int C, int K);
 /* host-synchronising: total milliseconds and launch count since bn_prof_select */

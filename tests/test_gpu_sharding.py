@@ -272,20 +272,60 @@ def test_fit_in_frames_mode_matches_single_process(tmp_path):
     assert np.mean(diff > 0.02 * travel + 1e-3 * np.abs(want['param_sample'])) <= 0.02
 
 
-def test_bench_two_ranks_control_flow():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank),
-    with both ranks on the one GPU over gloo: parameter broadcast, per-step gradient all-reduce,
-    barrier-bracketed timing, max over ranks, one JSON line from rank 0 with the whole-job value."""
-    env = dict(os.environ, BN_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29517', os.path.join(REPO, 'bench.py'),
-           '--gpus', '2', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary']
+def _bench_line(cmd, env):
     out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                         timeout=600).stdout.decode()
+                         timeout=900).stdout.decode()
     lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
-    assert len(lines) == 1, out[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize('launcher', ['torchrun', 'self'])
+def test_bench_two_ranks_control_flow(launcher):
+    """`bench.py --gpus 2` both ways -- as the driver launches it (torch.distributed.run, one
+    process per rank) and PLAINLY (`python bench.py --gpus 2`: the script starts its own ranks, as
+    the reference's entry point forks its per-GPU processes, ae_grid_search.py:173-181) -- with both
+    ranks on the one GPU over gloo: parameter broadcast, per-step gradient all-reduce (mean over
+    the ranks' trials), barrier-bracketed timing, max over ranks, one JSON line from rank 0 with
+    the whole-job value and what the collective library saw."""
+    env = dict(os.environ, BN_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    tail = [os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
+            '--no-cpu-baseline', '--no-secondary']
+    if launcher == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', '29517'] + tail
+    else:
+        cmd = [sys.executable] + tail
+    d = _bench_line(cmd, env)
     assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak'
     assert d['config']['global_frames_per_step'] == 512
     assert abs(d['value'] - 512 * 1e3 / d['ms_per_step']) <= 0.01 * d['value']
     assert np.isfinite(d['final_loss'])
+    ar = d['allreduce']
+    assert ar['world_size'] == 2 and ar['backend'].startswith('gloo') and ar['op'] == 'mean'
+    assert sum(ar['bucket_bytes']) == ar['gradient_bytes'] == 8758285 * 4
+    assert ar['allreduce_alone_ms'] > 0
+
+
+def test_bench_two_ranks_frame_sharded():
+    """`python bench.py --gpus 2 --shard frames`: the strong-scaling (parity-exact) reading of
+    BASELINE configs[2] -- one 256-frame trial per step, 128 frames per rank, summed gradients;
+    the loss it reports is the single-device loss of the same trajectory."""
+    env = dict(os.environ, BN_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    tail = ['--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary']
+    d2 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--shard',
+                      'frames'] + tail, env)
+    d1 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1'] + tail, env)
+    assert d2['n_gpus'] == 2 and d2['scaling'] == 'strong'
+    assert d2['config']['global_frames_per_step'] == 256
+    assert d2['config']['frames_per_step_per_gpu'] == 128
+    assert abs(d2['value'] - 256 * 1e3 / d2['ms_per_step']) <= 0.01 * d2['value']
+    assert d2['allreduce']['op'] == 'sum' and d2['allreduce']['world_size'] == 2
+    assert d2['roofline']['algorithmic_bytes_per_launch_avg'] == 128 * 589824
+    # same model seed, same trials, same order: after 24 + 1 + 4 steps the two-rank trajectory
+    # reports the single-device loss (Adam on rounding-level gradient differences: 1e-4)
+    assert d2['final_loss'] == pytest.approx(d1['final_loss'], rel=1e-4)
