@@ -205,12 +205,7 @@ static int run_down(int family, const float* big, const float* w, const float* b
         const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
                                      : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
         if (ed.supported && epi_ok) {
-            const char* name = g.Cb == 2
-                ? (dact_src ? "k_down_c1s<0, true, false, 2, 2>"
-                            : (act == BN_ACT_LRELU ? "k_down_c1s<1, false, false, 2, 2>"
-                                                   : "k_down_c1s<0, false, false, 2, 2>"))
-                : (dact_src ? "k_down_c1s<0, true, false, 2, 1>"
-                            : (act == BN_ACT_LRELU ? "k_down_c1<1, false>" : "k_down_c1<0, false>"));
+            const char* name = bn_edge_down_kernel_name(g, act, dact_src != nullptr, false);
             BnProfScope prof(family, g.Cb, g.Cs, name, st, /*on_dispatch=*/true);
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }
@@ -371,9 +366,8 @@ extern "C" int bn_conv2d_fwd_u8(const unsigned char* x, const float* w, const fl
     if (!bn_geom_ok(g)) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (u8_fast(g, act)) {
-        BnProfScope prof(BN_PROF_CONV_FWD, g.Cb, g.Cs,
-                         act == BN_ACT_LRELU ? "k_down_c1s<1, false, true, 4, 1>"
-                                             : "k_down_c1s<0, false, true, 4, 1>", st, true);
+        BnProfScope prof(BN_PROF_CONV_FWD, g.Cb, g.Cs, bn_edge_down_kernel_name(g, act, false, true), st,
+                         true);
         return bn_launch_edge_down(nullptr, w, b, y, nullptr, g, act, BN_ACT_NONE, slope, st, x);
     }
     const size_t need =

@@ -389,10 +389,15 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
 #endif
 #define DC_HTS 36                        // half-row slab row stride
 #ifndef DC_VARIANT
-#define DC_VARIANT 0                     // product build: first generation for float frames (in the
-                                         // training step it measures 32.8 vs 33.7 us; isolated, the
-                                         // second generation is the faster one: 31.8 vs 34.2 us);
-                                         // uint8 frames always take the second generation
+#define DC_VARIANT 5                     // product build, float frames, forward, 32 channels: fourth
+                                         // generation on 8-row strips (k_down_c1p_*_s8; 4 = the same on
+                                         // 16-row strips, 3 = third generation k_down_c1w) where the
+                                         // geometry holds, else the first generation (0).  Same bits.
+                                         // tools/lab/e0_lab.hip, 256 frames, inputs and outputs rotated
+                                         // through > 256 MB, behind clean L2s / a 35 MB memset:
+                                         // generation 1 31.5 / 32.8 us, 2 36.6 / 37.1, 3 31.4 / 33.5,
+                                         // 4 on 16-row strips 30.9 / 31.9, on 8-row strips 27.3 / 27.9.
+                                         // uint8 frames and the masked data gradient: second generation
 #endif
 
 #ifndef DC_ST_AUX
@@ -419,6 +424,14 @@ __device__ __forceinline__ void ed_lrelu4(float (&v)[4], float slope) {
     asm("v_max_f32 %0, %1, %2" : "=v"(v[3]) : "v"(hi.y), "v"(mhi.y));
 }
 
+// tools/lab/e0_lab.hip -DE0_SMALLOUT: every store lands in one 1 MB window (no HBM write stream): what
+// the kernel costs when the output is free
+#ifdef E0_SMALLOUT
+#define E0_OUT_OFFSET(o) ((o) & 0xffff0)
+#else
+#define E0_OUT_OFFSET(o) (o)
+#endif
+
 typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx4e __attribute__((ext_vector_type(4)));
 typedef unsigned int uintx4e __attribute__((ext_vector_type(4)));
@@ -434,6 +447,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
     const int li = lane & 31, kk = lane >> 5;
     const int upf = g.Hs / DC_ROWS;                  // units per frame
     const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
+#ifdef E0_TRACE      // tools/lab/e0_lab.hip: s_memrealtime marks per wave (100 MHz)
+    unsigned long long* trc = e0_trace + (size_t)blockIdx.x * 8;
+#define E0_MARK(slot) do { if (threadIdx.x == 0) trc[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    E0_MARK(0);
+    if (threadIdx.x == 0) trc[7] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+#else
+#define E0_MARK(slot)
+#endif
 
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)big, 0, (int)((size_t)g.N * HWb * 4), 0x00020000);
@@ -488,6 +509,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
         }
         if (u + (int)gridDim.x < units) issue(u + gridDim.x, stage);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (u == (int)blockIdx.x) E0_MARK(1);        // first patch in LDS
 
         const int n = u / upf;
         const int p0 = DC_ROWS * (u - n * upf);
@@ -516,6 +538,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
                     acc[qh] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[t0 + 64 * qh], wv_[t],
                                                                    acc[qh], 0, 0, 0);
             }
+            if (u == (int)blockIdx.x && pr == 0) E0_MARK(2);     // first row multiplied
 #if DC_HALF
 #pragma unroll
             for (int qh = 0; qh < 2; ++qh) {
@@ -549,7 +572,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
                         __builtin_amdgcn_raw_buffer_store_b128(
                             __builtin_bit_cast(uintx4e, v),
                             __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7ffffffc, 0x00020000),
-                            (int)(o * 4), 0, DC_ST_AUX);
+                            E0_OUT_OFFSET((int)(o * 4)), 0, DC_ST_AUX);
 #else
                         *reinterpret_cast<floatx4e*>(out + o) = v;
 #endif
@@ -592,8 +615,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+            if (u == (int)blockIdx.x && pr == 0) E0_MARK(3);     // first row's stores issued
         }
+        if (u == (int)blockIdx.x) E0_MARK(4);                    // first unit done
     }
+    E0_MARK(5);                                                  // all stores issued
+#ifdef E0_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    E0_MARK(6);                                                  // all stores acknowledged
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -786,6 +816,472 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// third generation of the gather-down edge kernel (float frames, forward): ALL input of a launch
+// is requested in its first microsecond.
+//
+// What the per-wave s_memrealtime trace of the first generation showed (tools/lab/e0_lab.hip,
+// 256 frames): the store stream itself is not the limit -- a pure 134 MB write-through stream with
+// this kernel's address pattern runs at 6.5 TB/s, the same as a linear fill -- but the READS are:
+// a wave's 3.5 KB patch took 1.9 us on the idle chip, 5.8 us (median) once the other waves'
+// patches were queued and up to 25 us behind the saturated store queues, and every wave sat idle
+// for that long, twice (2 units per wave).  The input is only 10 % of the bytes but it was on the
+// critical path of every unit.
+//
+// Here a workgroup (4 waves) owns a STRIP of 16 output rows of one frame: its 35 input rows
+// (18.6 KB) are copied into LDS by 16-byte LDS-DMA (`buffer_load ... lds`, no registers), all of
+// them issued before anything else, zero borders included (out-of-range groups and rows read 0).
+// With 4 workgroups per CU the whole launch's input (16.8 MB + 9 % halo) is in flight within the
+// first microsecond, while HBM is otherwise idle; after that the memory system carries only the
+// output stream.  Wave w multiplies strip rows w, w+4, w+8, w+12 (the first ones need only the
+// first two DMA rounds, which are waited for separately); MFMA roles, LDS transposition slab,
+// store instructions (8 channels x 128 B, write-through) and summation order are the first
+// generation's: outputs are bit-identical to k_down_c1.
+// ---------------------------------------------------------------------------------------------
+#define DW_SROWS 16                          // output rows per strip
+#define DW_WAVES 4
+#define DW_IH (2 * DW_SROWS + 3)             // 35 input rows
+#define DW_NG (DW_IH * DC_C4)                // 16-byte groups of the strip image (34 per row)
+#define DW_NDMA ((DW_NG + 64 * DW_WAVES - 1) / (64 * DW_WAVES))      // DMA instructions per wave (5)
+#define DW_IMG (DW_NDMA * DW_WAVES * 64 * 4) // floats of the image incl. the tail of the last round
+#define DW_LDS ((DW_IMG + DW_WAVES * 32 * DC_HTS) * 4)
+
+// s_barrier WITHOUT the memory fence of __syncthreads() (which drains vmcnt: the staged waits
+// below would wait for every DMA round).  LDS-DMA data are visible to the other waves once the
+// issuing wave's vmcnt covers them and a barrier has passed.
+__device__ __forceinline__ void ed_barrier() { asm volatile("s_barrier" ::: "memory"); }
+template <int ACT>
+__global__ __launch_bounds__(64 * DW_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_down_c1w(
+    const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, BnGeom g, float slope, int units) {
+    extern __shared__ __attribute__((aligned(16))) float wsm_[];
+    float* img = wsm_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* tw = wsm_ + DW_IMG + wv * (32 * DC_HTS);
+    const int li = lane & 31, kk = lane >> 5;
+    const int spf = g.Hs / DW_SROWS;                 // strips per frame
+    const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
+#ifdef E0_TRACE
+    unsigned long long* trc = e0_trace + (size_t)(blockIdx.x * DW_WAVES + wv) * 8;
+#undef E0_MARK
+#define E0_MARK(slot) do { if (lane == 0) trc[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    E0_MARK(0);
+#endif
+
+    // the image is addressed from `pt` rows above its start: patch row y of strip (n, s) is image
+    // row 2 * 16 s - pt + y, and the scalar offset of a strip stays non-negative
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(big - g.pt * g.Wb), 0, (int)(((size_t)g.N * HWb + g.pt * g.Wb) * 4), 0x00020000);
+
+    // B operand first (it is needed with the first rows): weights of output channel li, taps 2t + kk
+    float wv_[13];
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+        const int tap = 2 * t + kk;
+        wv_[t] = (tap < 25 && li < g.Cs) ? w[li * 25 + tap] : 0.f;
+    }
+    const float bz = (bias && li < g.Cs) ? bias[li] : 0.f;
+
+    // DMA round k of wave wv: groups e = 64 (wv + 4k) + lane -> (patch row y, 16-byte column c);
+    // columns 0 and 33 are the zero borders (out-of-range source)
+    int dvo[DW_NDMA], dy[DW_NDMA];
+#pragma unroll
+    for (int k = 0; k < DW_NDMA; ++k) {
+        const int e = 64 * (wv + DW_WAVES * k) + lane;
+        const int y = e / DC_C4, c = e - y * DC_C4;
+        const bool ok = e < DW_NG && c >= 1 && c <= DC_W / 2;
+        dy[k] = ok ? y : -0x10000;                    // fails the row test below
+        dvo[k] = (y * g.Wb + 4 * (c - 1)) * 4;
+    }
+    auto issue_dma = [&](int u) __attribute__((always_inline)) {
+        const int n = u / spf;
+        const int hb0 = 2 * DW_SROWS * (u - n * spf) - g.pt;         // image row of patch row 0
+        const int soff = ((n * g.Hb + hb0 + g.pt) * g.Wb) * 4;
+#pragma unroll
+        for (int k = 0; k < DW_NDMA; ++k) {
+            const int hb = hb0 + dy[k];
+            const bool ok = hb >= 0 && hb < g.Hb;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, img + 4 * 64 * (wv + DW_WAVES * k), 16,
+                                                     ok ? dvo[k] : ED_OOB, soff, 0, 0);
+        }
+    };
+
+    const int kkA = kk, kkB = kk * (DC_RW - 4);
+    const int a_col = DC_X0 - g.pl + 2 * li;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7ffffffc, 0x00020000);
+
+    int u = blockIdx.x;
+    if (u < units) issue_dma(u);
+#pragma unroll 1
+    for (; u < units; u += gridDim.x) {
+        const int n = u / spf;
+        const int p0 = DW_SROWS * (u - n * spf);
+        // Rows 0 .. 3 of the strip need patch rows 0 .. 10 = DMA rounds 0 and 1 (15 rows).  Only
+        // loads are in flight here (they return in order), so the count is exact.
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DW_NDMA - 2) : "memory");
+        ed_barrier();
+        if (u == (int)blockIdx.x) E0_MARK(1);
+#pragma unroll 1
+        for (int j = 0; j < DW_SROWS / DW_WAVES; ++j) {
+            const int r = wv + DW_WAVES * j;                 // strip row of this wave
+            if (j == 1) {
+                // the rest of the image, before the first row that needs it.  (The stores of row 0
+                // are in flight too and may retire out of order with loads: wait for everything.)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ed_barrier();
+            }
+            floatx16 acc[2];
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[qh][e] = bz;
+            const float* ar = img + (2 * r) * DC_RW + a_col;
+            const float* arA = ar + kkA;
+            const float* arB = ar + kkB;
+#pragma unroll
+            for (int t = 0; t < 13; ++t) {
+                // (tap 25 = t 12, kk 1: zero weight, reads the next column of the last patch row)
+                const int t0 = ((2 * t) / 5) * DC_RW + (2 * t) % 5;
+                const float* at = ((2 * t) % 5 == 4 && t != 12) ? arB : arA;
+#pragma unroll
+                for (int qh = 0; qh < 2; ++qh)
+                    acc[qh] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[t0 + 64 * qh], wv_[t], acc[qh], 0, 0, 0);
+            }
+            if (u == (int)blockIdx.x && j == 0) E0_MARK(2);
+#pragma unroll
+            for (int qh = 0; qh < 2; ++qh) {
+#pragma unroll
+                for (int grp = 0; grp < 4; ++grp) {
+                    floatx4e v = {acc[qh][4 * grp], acc[qh][4 * grp + 1], acc[qh][4 * grp + 2],
+                                  acc[qh][4 * grp + 3]};
+                    if (ACT == BN_ACT_LRELU) {
+                        float q[4] = {v.x, v.y, v.z, v.w};
+                        ed_lrelu4(q, slope);
+                        v = (floatx4e){q[0], q[1], q[2], q[3]};
+                    }
+                    *reinterpret_cast<floatx4e*>(tw + li * DC_HTS + 8 * grp + 4 * kk) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // 8 lanes x 16 B = one 128-byte half row; 8 channels per store instruction
+                const size_t row0 = ((size_t)n * g.Cs * g.Hs + (p0 + r)) * DC_W + 32 * qh + 4 * (lane & 7);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ch = 8 * i + (lane >> 3);
+                    const floatx4e v = *reinterpret_cast<const floatx4e*>(tw + ch * DC_HTS + 4 * (lane & 7));
+                    if (ch < g.Cs)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4e, v), ro,
+                                                               E0_OUT_OFFSET((int)((row0 + (size_t)ch * PQ) * 4)), 0, DC_ST_AUX);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (u == (int)blockIdx.x && j == 0) E0_MARK(3);
+        }
+        if (u == (int)blockIdx.x) E0_MARK(4);
+        if (u + (int)gridDim.x < units) {
+            // more strips than resident workgroups: the image is reused once every wave has
+            // finished reading it (all stores retired first: the next wait counts loads only)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ed_barrier();
+            issue_dma(u + gridDim.x);
+        }
+    }
+    E0_MARK(5);
+#ifdef E0_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    E0_MARK(6);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// fourth generation (float frames, forward, 32 output channels): the third generation's workgroup
+// strips + swapped MFMA roles + a software pipeline inside every wave.
+//
+// What the s_memrealtime traces and two ablations of the earlier generations showed
+// (tools/lab/e0_lab.hip, buffers rotated through > 256 MB so that the Infinity Cache serves neither
+// stream): with every store redirected into a 1 MB window -- no HBM write stream at all -- the first
+// generation still took 30.4 us of its 31.6: the kernel was never paced by the memory system (a
+// skeleton that only loads the patches and issues the same stores runs in 27.4 us).  It was paced by
+// ISSUE on the SIMDs: a row is 26 MFMAs (1664 cycles) followed by an epilogue (LeakyReLU, LDS
+// transposition with four LDS round trips, 8 stores) that took 2.2 us of wall time per row, because
+// while ONE wave of a SIMD streams MFMAs the other three cannot issue a single vector-ALU or
+// vector-memory instruction (issue rule 2) -- the epilogues of four waves per SIMD and
+// their MFMA bursts excluded each other; and the first patch of a wave arrived 7 us (median) after
+// the launch, 2.5 us of that behind the 13 gathered weight loads of 16 waves in the CU's one
+// vector-memory pipe.
+//
+// Here: (1) weights, bias and all 35 input rows of a strip are requested by LDS-DMA in the first
+// instructions of the kernel; (2) MFMA rows = output channels (A = weights, from LDS into 13
+// registers), columns = 32 pixels, so an accumulator register is one channel x 32 adjacent pixels
+// and goes to HBM as it is -- one dword store instruction = two full 128-byte lines, no LDS
+// transposition, no LDS round trip; (3) the epilogue of a half row (LeakyReLU + 16 stores) is issued from
+// INSIDE the MFMA stream of the next half row of the same wave (LDS reads and stores cost nothing
+// in the shadow of an MFMA; the vector-ALU instructions cost what they would cost anyway), two
+// accumulators alternating -- the first stores leave 13 MFMAs after the data arrived; (4) strips of
+// 8 output rows (19 patch rows, 10 KB), one per workgroup, 2048 workgroups for 256 frames of which
+// 1024 are resident: the dispatcher hands out the second half as the first finishes, which evens
+// out the tail that a static assignment showed (the slowest 10 % of the waves finished 4 us after
+// the rest).  Summation order = the earlier generations': bit-identical outputs.
+// ---------------------------------------------------------------------------------------------
+#ifndef DP_ST_AUX
+#define DP_ST_AUX 16                         // cache policy of the dword output stores: sc1 (write-through),
+                                             // 27.3 / 27.9 us against 29.9 / 31.4 plain (0) behind clean / memset L2s
+#endif
+// STRIP = output rows per strip (16: 35 patch rows in 5 DMA rounds, 4 rows per wave; 8: 19 patch rows in 3
+// rounds, 2 rows per wave)
+template <int STRIP> struct DpGeom {
+    static constexpr int IH = 2 * STRIP + 3;                    // patch rows
+    static constexpr int NG = IH * DC_C4;                    // 16-byte groups of the strip image (34 per row)
+    static constexpr int NDMA = (NG + 64 * DW_WAVES - 1) / (64 * DW_WAVES);    // DMA rounds
+    static constexpr int IMG = NDMA * DW_WAVES * 64 * 4;     // floats of the image incl. the last round's tail
+    // (an LDS-DMA instruction writes all 64 lanes x 16 B, zeros for out-of-range lanes: the four
+    // weight instructions cover 1024 floats, the bias instruction 256)
+    static constexpr int WL = IMG;                           // weights [32][25] behind the image
+    static constexpr int BL = IMG + 1024;                    // bias [32]
+    static constexpr int LDS = (IMG + 1024 + 256) * 4;
+    static constexpr int ROWS = STRIP / DW_WAVES;               // rows per wave
+};
+
+template <int ACT, int STRIP>
+__device__ __forceinline__ void dp_body(
+    const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, const BnGeom& g, const float slope, const int units) {
+    typedef DpGeom<STRIP> G;
+    extern __shared__ __attribute__((aligned(16))) float wsm_[];
+    float* img = wsm_;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int spf = g.Hs / STRIP;
+    const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
+#ifdef E0_TRACE
+    unsigned long long* trc = e0_trace + (size_t)(blockIdx.x * DW_WAVES + wv) * 8;
+#undef E0_MARK
+#define E0_MARK(slot) do { if (lane == 0) trc[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    E0_MARK(0);
+#endif
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(big - g.pt * g.Wb), 0, (int)(((size_t)g.N * HWb + g.pt * g.Wb) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 800 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbi = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(bias ? bias : w), 0, bias ? 32 * 4 : 0, 0x00020000);          // no bias: reads 0
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)out, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+
+    // first instructions: weights (wave wv copies groups 64 wv ..), bias (wave 3's free lanes), image
+    {
+        const int e = 64 * wv + lane;                               // 16-byte group of the weights
+        // (plain ints: an argument of this builtin that depends on a template parameter makes this
+        // hipcc drop the host-side stub of the kernel without a diagnostic)
+        int wl_off = G::WL, bl_off = G::BL;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, wsm_ + wl_off + 4 * 64 * wv, 16,
+                                                 e < 200 ? 16 * e : ED_OOB, 0, 0, 0);
+        if (wv == 0)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbi, wsm_ + bl_off, 16, lane < 8 ? 16 * lane : ED_OOB,
+                                                     0, 0, 0);
+    }
+    int dvo[G::NDMA], dy[G::NDMA];
+#pragma unroll
+    for (int k = 0; k < G::NDMA; ++k) {
+        const int e = 64 * (wv + DW_WAVES * k) + lane;
+        const int y = e / DC_C4, c = e - y * DC_C4;
+        const bool ok = e < G::NG && c >= 1 && c <= DC_W / 2;
+        dy[k] = ok ? y : -0x10000;
+        dvo[k] = (y * g.Wb + 4 * (c - 1)) * 4;
+    }
+    // rounds [k0, k1) of strip u; the row-validity masks of all rounds are computed once per strip
+    auto issue_dma = [&](const int u, const int k0, const int k1) __attribute__((always_inline)) {
+        const int n = u / spf;
+        const int hb0 = 2 * STRIP * (u - n * spf) - g.pt;
+        const int soff = ((n * g.Hb + hb0 + g.pt) * g.Wb) * 4;
+#pragma unroll
+        for (int k = 0; k < G::NDMA; ++k) {
+            if (k < k0 || k >= k1) continue;
+            const int hb = hb0 + dy[k];
+            const bool ok = hb >= 0 && hb < g.Hb;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, img + 4 * 64 * (wv + DW_WAVES * k), 16,
+                                                     ok ? dvo[k] : ED_OOB, soff, 0, 0);
+        }
+    };
+    int u = blockIdx.x;
+    if (u < units) issue_dma(u, 0, G::NDMA);
+
+    const int kkA = kk, kkB = kk * (DC_RW - 4);
+    const int a_col = DC_X0 - g.pl + 2 * li;
+    const int st_lane = (4 * kk * PQ + li) * 4;          // byte offset of this lane's column
+
+    // weights, bias and the whole strip image (10 KB for 8-row strips) before the first MFMA: the
+    // other resident workgroups of the CU are multiplying meanwhile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ed_barrier();
+    E0_MARK(1);
+    // A operand: weights of output channel li for taps (2t + kk); bias per accumulator register
+    float wv_[13];
+#pragma unroll
+    for (int t = 0; t < 13; ++t) {
+        const int tap = 2 * t + kk;
+        wv_[t] = wsm_[G::WL + li * 25 + (tap < 25 ? tap : 24)];
+        if (tap >= 25) wv_[t] = 0.f;
+    }
+    float bz[16];
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        const floatx4e b4 = *reinterpret_cast<const floatx4e*>(wsm_ + G::BL + 8 * e4 + 4 * kk);
+        bz[4 * e4] = b4.x; bz[4 * e4 + 1] = b4.y; bz[4 * e4 + 2] = b4.z; bz[4 * e4 + 3] = b4.w;
+    }
+
+    // one HALF row (32 pixels x 32 channels): 13 MFMAs on one accumulator.  With PREV the epilogue of
+    // the previous half row (accumulator `pv`, byte offset `poff` of its first pixel in channel 0) is
+    // issued from inside the stream: 4 registers -> LeakyReLU (6 vector-ALU instructions) and 4
+    // dword stores behind every third MFMA.
+    auto half = [&](floatx16& cur, const floatx16& pv, const int r, const int qh, const bool PREV,
+                    const int poff) __attribute__((always_inline)) {
+        const float* ar = img + (2 * r) * DC_RW + a_col + 64 * qh;
+        const float* arA = ar + kkA;
+        const float* arB = ar + kkB;
+        float bv[13];
+        auto rd = [&](int t) __attribute__((always_inline)) {
+            // (tap 25 = t 12, kk 1: zero weight, reads the next column of the last patch row)
+            const int t0 = ((2 * t) / 5) * DC_RW + (2 * t) % 5;
+            const float* at = ((2 * t) % 5 == 4 && t != 12) ? arB : arA;
+            bv[t] = at[t0];
+        };
+        rd(0); rd(1);
+#pragma unroll
+        for (int t = 0; t < 13; ++t) {
+            if (t + 2 < 13) rd(t + 2);
+            if (t == 0) {
+                floatx16 init;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) init[e] = bz[e];
+                cur = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[t], bv[t], init, 0, 0, 0);
+            } else {
+                cur = __builtin_amdgcn_mfma_f32_32x32x2f32(wv_[t], bv[t], cur, 0, 0, 0);
+            }
+            if (PREV && (t % 3) == 0 && t / 3 < 4) {
+                const int e4 = t / 3;
+                float q[4] = {pv[4 * e4], pv[4 * e4 + 1], pv[4 * e4 + 2], pv[4 * e4 + 3]};
+                if (ACT == BN_ACT_LRELU) ed_lrelu4(q, slope);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)       // register e = 4 e4 + i: channel (e & 3) + 8 (e >> 2) (+ 4 kk)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, q[i]), ro, st_lane,
+                                                          E0_OUT_OFFSET(poff + (i + 8 * e4) * PQ * 4), DP_ST_AUX);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto flush = [&](const floatx16& pv, const int poff) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            float q[4] = {pv[4 * e4], pv[4 * e4 + 1], pv[4 * e4 + 2], pv[4 * e4 + 3]};
+            if (ACT == BN_ACT_LRELU) ed_lrelu4(q, slope);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, q[i]), ro, st_lane,
+                                                      E0_OUT_OFFSET(poff + (i + 8 * e4) * PQ * 4), DP_ST_AUX);
+        }
+    };
+
+#pragma unroll 1
+    for (; u < units; u += gridDim.x) {
+        const int n = u / spf;
+        const int p0 = STRIP * (u - n * spf);
+        // byte offset of (strip row j of this wave, half qh) in channel 0
+#define DP_OFF(j, qh) (((n * g.Cs * g.Hs + p0 + wv + DW_WAVES * (j)) * DC_W + 32 * (qh)) * 4)
+        floatx16 a0, a1;
+        half(a0, a1, wv, 0, false, 0);
+        if (u == (int)blockIdx.x) E0_MARK(2);
+        half(a1, a0, wv, 1, true, DP_OFF(0, 0));                        // + 16 stores
+#pragma unroll
+        for (int j = 1; j < G::ROWS; ++j) {
+            half(a0, a1, wv + DW_WAVES * j, 0, true, DP_OFF(j - 1, 1));
+            if (u == (int)blockIdx.x && j == 1) E0_MARK(3);
+            half(a1, a0, wv + DW_WAVES * j, 1, true, DP_OFF(j, 0));
+        }
+        flush(a1, DP_OFF(G::ROWS - 1, 1));
+#undef DP_OFF
+        if (u == (int)blockIdx.x) E0_MARK(4);
+        if (u + (int)gridDim.x < units) {
+            // more strips than resident workgroups: the image is reused once every wave is done with it
+            ed_barrier();
+            issue_dma(u + gridDim.x, 0, G::NDMA);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ed_barrier();
+        }
+    }
+    E0_MARK(5);
+#ifdef E0_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    E0_MARK(6);
+#endif
+}
+
+// (Plain kernels around the template body: this hipcc drops the host-side stub of a __global__
+// TEMPLATE without a diagnostic when an argument of the LDS-DMA builtin in its body depends on a
+// template parameter.)
+#define DP_KERNEL(name, ACT, STRIP)                                                                    \
+    __global__ __launch_bounds__(64 * DW_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void name(  \
+        const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,    \
+        float* __restrict__ out, BnGeom g, float slope, int units) {                                   \
+        dp_body<ACT, STRIP>(big, w, bias, out, g, slope, units);                                       \
+    }
+DP_KERNEL(k_down_c1p_lrelu_s16, BN_ACT_LRELU, 16)
+DP_KERNEL(k_down_c1p_none_s16, BN_ACT_NONE, 16)
+DP_KERNEL(k_down_c1p_lrelu_s8, BN_ACT_LRELU, 8)
+DP_KERNEL(k_down_c1p_none_s8, BN_ACT_NONE, 8)
+#undef DP_KERNEL
+
+template <int ACT, int STRIP>
+static int launch_down_c1p(const float* big, const float* w, const float* bias, float* out,
+                           const BnGeom& g, float slope, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    typedef void (*kernel_t)(const float*, const float*, const float*, float*, BnGeom, float, int);
+    const kernel_t kernel = STRIP == 16
+        ? (ACT == BN_ACT_LRELU ? k_down_c1p_lrelu_s16 : k_down_c1p_none_s16)
+        : (ACT == BN_ACT_LRELU ? k_down_c1p_lrelu_s8 : k_down_c1p_none_s8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DpGeom<STRIP>::LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int units = g.N * (g.Hs / STRIP);
+    int grid = units;                                  // one strip per workgroup; the dispatcher balances
+    if (const char* e = bn_tune_env("BN_E0_WGRID")) grid = atoi(e);     // (tuning build only)
+    if (grid > units) grid = units;
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(64 * DW_WAVES), DpGeom<STRIP>::LDS, st, e0, e1, 0,
+                          big, w, bias, out, g, slope, units);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+static bool down_c1w_ok(const BnGeom& g) {
+    return g.Cb == 1 && (g.Hs % DW_SROWS) == 0 && g.pt <= 2 && DC_ST_AUX >= 0;
+}
+static bool down_c1p_ok(const BnGeom& g, int strip) {
+    return g.Cb == 1 && g.Cs == 32 && (g.Hs % strip) == 0 && g.pt <= 2;
+}
+
+template <int ACT>
+static int launch_down_c1w(const float* big, const float* w, const float* bias, float* out,
+                           const BnGeom& g, float slope, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_down_c1w<ACT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int units = g.N * (g.Hs / DW_SROWS);
+    int grid = 256 * 4;                               // 4 workgroups of 38 KB per CU
+    if (const char* e = bn_tune_env("BN_E0_WGRID")) grid = atoi(e);     // (tuning build only)
+    if (grid > units) grid = units;
+    hipExtLaunchKernelGGL((k_down_c1w<ACT>), dim3(grid), dim3(64 * DW_WAVES), DW_LDS, st, e0, e1, 0,
+                          big, w, bias, out, g, slope, units);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 BnFastPlan bn_edge_down_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_down_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2 || (g.Cb != 1 && g.Cb != 2)) return p;
@@ -828,6 +1324,24 @@ static int launch_down_c1s(const void* big, const float* w, const float* bias, f
     return 0;
 }
 
+// name of the kernel bn_launch_edge_down dispatches to (profiling scopes, tests)
+const char* bn_edge_down_kernel_name(const BnGeom& g, int act, bool has_dact, bool u8) {
+    const bool lrelu = act == BN_ACT_LRELU;
+    if (g.Cb == 2)
+        return has_dact ? "k_down_c1s<0, true, false, 2, 2>"
+                        : (lrelu ? "k_down_c1s<1, false, false, 2, 2>" : "k_down_c1s<0, false, false, 2, 2>");
+    if (u8) {
+        if ((g.Hs % 4) == 0)
+            return lrelu ? "k_down_c1s<1, false, true, 4, 1>" : "k_down_c1s<0, false, true, 4, 1>";
+        return lrelu ? "k_down_c1s<1, false, true, 2, 1>" : "k_down_c1s<0, false, true, 2, 1>";
+    }
+    if (has_dact) return "k_down_c1s<0, true, false, 2, 1>";
+    if (DC_VARIANT == 5 && down_c1p_ok(g, 8)) return lrelu ? "k_down_c1p_lrelu_s8" : "k_down_c1p_none_s8";
+    if (DC_VARIANT >= 4 && down_c1p_ok(g, 16)) return lrelu ? "k_down_c1p_lrelu_s16" : "k_down_c1p_none_s16";
+    if (DC_VARIANT >= 3 && down_c1w_ok(g)) return lrelu ? "k_down_c1w<1>" : "k_down_c1w<0>";
+    return lrelu ? "k_down_c1<1, false>" : "k_down_c1<0, false>";
+}
+
 // u8 != nullptr: the frames are uint8 (converted in flight, value / 255); else `big` is float.
 int bn_launch_edge_down(const float* big, const float* w, const float* bias, float* out,
                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
@@ -857,6 +1371,22 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
             ? launch_down_c1s<BN_ACT_LRELU, false, true, 2>(u8, w, bias, out, nullptr, g, slope, st, e0, e1)
             : launch_down_c1s<BN_ACT_NONE, false, true, 2>(u8, w, bias, out, nullptr, g, slope, st, e0, e1);
     }
+    if (variant == 5 && !down_c1p_ok(g, 8)) variant = 4;
+    if ((variant == 4 || variant == 5) && !dact_src && down_c1p_ok(g, variant == 5 ? 8 : 16)) {
+        if (variant == 5)
+            return act == BN_ACT_LRELU
+                ? launch_down_c1p<BN_ACT_LRELU, 8>(big, w, bias, out, g, slope, st, e0, e1)
+                : launch_down_c1p<BN_ACT_NONE, 8>(big, w, bias, out, g, slope, st, e0, e1);
+        return act == BN_ACT_LRELU
+            ? launch_down_c1p<BN_ACT_LRELU, 16>(big, w, bias, out, g, slope, st, e0, e1)
+            : launch_down_c1p<BN_ACT_NONE, 16>(big, w, bias, out, g, slope, st, e0, e1);
+    }
+    if (variant == 4 || variant == 5) variant = 3;
+    if (variant == 3 && !dact_src && down_c1w_ok(g))
+        return act == BN_ACT_LRELU
+            ? launch_down_c1w<BN_ACT_LRELU>(big, w, bias, out, g, slope, st, e0, e1)
+            : launch_down_c1w<BN_ACT_NONE>(big, w, bias, out, g, slope, st, e0, e1);
+    if (variant == 3) variant = dact_src ? 1 : 0;
     if (variant == 2) {
         if (act == BN_ACT_LRELU && !dact_src)
             return launch_down_c1s<BN_ACT_LRELU, false, false, 4>(big, w, bias, out, nullptr, g, slope, st, e0, e1);

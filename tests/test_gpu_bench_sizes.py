@@ -51,7 +51,7 @@ SIZES = [256, 200, 56]
 # (layer, role) -> kernel at N = 256: the instantiations of profiles/r02_bench_kernel_stats.csv
 # (the single-pass schedule of bench.py launches every layer once over the whole 256-frame batch)
 KERNELS_256 = {
-    ('E0', 'fwd'): 'k_down_c1<1, false>', ('E0', 'bwd_w'): 'k_wgrad_c1d',
+    ('E0', 'fwd'): 'k_down_c1p_lrelu_s8', ('E0', 'bwd_w'): 'k_wgrad_c1d',
     ('E1', 'fwd'): 'k_down2_mfma<2, 2>', ('E2', 'fwd'): 'k_down2_mfma<2, 2>',
     ('E3', 'fwd'): 'k_down2_mfma<2, 1>',
     ('E1', 'bwd_d'): 'k_up2_mfma<5, 4>', ('E2', 'bwd_d'): 'k_up2_mfma<4, 4>',

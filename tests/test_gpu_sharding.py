@@ -305,7 +305,9 @@ def test_bench_two_ranks_control_flow(launcher):
     assert np.isfinite(d['final_loss'])
     ar = d['allreduce']
     assert ar['world_size'] == 2 and ar['backend'].startswith('gloo') and ar['op'] == 'mean'
-    assert sum(ar['bucket_bytes']) == ar['gradient_bytes'] == 8758285 * 4
+    # (the flat arena pads every parameter to 16 bytes)
+    assert sum(ar['bucket_bytes']) == ar['gradient_bytes']
+    assert 8758285 * 4 <= ar['gradient_bytes'] <= 8758285 * 4 + 16 * 24
     assert ar['allreduce_alone_ms'] > 0
 
 
