@@ -26,6 +26,10 @@
 #include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"
+#ifndef DOWN2_ST_AUX
+#define DOWN2_ST_AUX 0      // cache policy of the dword output stores of k_down2_mfma
+#endif
+
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx2d __attribute__((ext_vector_type(2)));
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
                     if (dact_src) v *= d[e] > 0.f ? 1.f : ds;
                     __builtin_amdgcn_raw_buffer_store_b32(
                         __builtin_bit_cast(int, v), ro, (mlane + mo < g.Cs) ? vo[nr] : 0x7fffffff,
-                        mo * PQ * 4, 0);
+                        mo * PQ * 4, DOWN2_ST_AUX);
                 }
                 D2_MARK(18 + mr * NR + nr);
             }

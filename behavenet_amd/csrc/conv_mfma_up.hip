@@ -12,6 +12,12 @@
 #include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"
+#ifndef UP2_ST_AUX
+#define UP2_ST_AUX 2        // cache policy of the 8-byte output stores of k_up2_mfma: nt (streaming).  In the
+                            // training step dec.convT3 fwd (134 MB of output) 224 -> 206 us, step 4.42 -> 4.39 ms;
+                            // sc1 (16): no change; plain (0): the output evicts the weights and tiles from the L2s
+#endif
+
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
                 }
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uintx2u, v), ro,
                                                       (mlane + mo < g.Cb) ? vo : OOB,
-                                                      (mo * HWb + rho * Wb) * 4, 0);
+                                                      (mo * HWb + rho * Wb) * 4, UP2_ST_AUX);
             }
         }
     } else {

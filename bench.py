@@ -186,6 +186,16 @@ def secondary_configs(hp_ae, feed_rates=True):
                              'frac': round(0.3474e9 * BATCH / t5 / 1e12 / FP32_PEAK_TFLOPS, 4),
                              'note': 'encoder forward, algorithmic 0.3474 GFLOP/frame'}})
     del ae
+    # --- the product entry point itself: fit() on the headline workload
+    out.append(fit_throughput(hp_ae))
+    # --- geometries OFF the benchmark's fast paths (their cost was never measured)
+    cfg = os.path.join(REPO, 'behavenet_amd', 'configs', 'ae_jsons')
+    out.append(geometry_step(os.path.join(cfg, 'ae_arch_default.json'), [1, 128, 128],
+                             'shipped configs/ae_jsons/ae_arch_default.json (4 layers 32-64-256-512, '
+                             'k5 s2, last map 8x8) on 1x128x128'))
+    out.append(geometry_step(None, [1, 64, 48],
+                             'default architecture on 1x64x48 frames (the reference\'s '
+                             'tests/integration.py shape)'))
     if feed_rates:
         # --- the headline step fed over PCIe: pinned uint8 trials, one-trial look-ahead
         torch.manual_seed(0)
@@ -202,6 +212,111 @@ def secondary_configs(hp_ae, feed_rates=True):
                     'value': round(BATCH / tp, 1), 'unit': 'frames/s',
                     'ms_per_step': round(tp * 1e3, 3), 'steps': 20})
     return out
+
+
+def fit_throughput(hp_ae, n_epochs=2):
+    """`fit()` (reference training.py:244-461) over 20 resident trials of the headline workload:
+    epoch 0 without optimizer steps, then `n_epochs` epochs of 16 training trials, a validation
+    pass (2 trials) after every epoch, metric rows, best-model snapshot, the final test rows --
+    frames/s over EVERY trial it pushes through the model (train + val + test)."""
+    import contextlib
+    import tempfile
+    from behavenet_amd.fitting.training import fit
+    tmp = tempfile.mkdtemp()
+    hp = dict(hp_ae)
+    hp.update({'max_n_epochs': n_epochs, 'min_n_epochs': n_epochs, 'enable_early_stop': False,
+               'val_check_interval': 1, 'expt_dir': tmp, 'version': 0, 'device': 'cuda',
+               'rng_seed_train': 0, 'export_latents': False, 'early_stop_history': 10,
+               'progress_bar': False})
+    os.makedirs(os.path.join(tmp, 'version_0'), exist_ok=True)
+
+    class Exp(object):
+        version = 0
+
+        def __init__(self):
+            self.rows = []
+
+        def log(self, row):
+            self.rows.append(dict(row))
+
+        def save(self):
+            pass
+
+    def run():
+        torch.manual_seed(0)
+        model = AE(dict(hp)).to('cuda')
+        model.version = 0
+        sess = SyntheticSession(20, BATCH, DIM, seed=100, trial_splits='8;1;1;0')
+        gen = SyntheticSessionsGenerator([sess], device='cuda', placement='device')
+        exp = Exp()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(sys.stderr):
+            fit(hp, model, gen, exp, method='ae')
+        torch.cuda.synchronize()
+        n = gen.n_tot_batches
+        trials = (n_epochs + 1) * (n['train'] + n['val']) + n['test']
+        return time.perf_counter() - t0, trials, len(exp.rows), n
+    run()                                  # (allocator pools, kernel attribute calls)
+    dt, trials, rows, n = run()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {'config': 'configs[1] through the product entry point fit(): epoch 0 + %d epochs over %d '
+                      'train / %d val / %d test trials of 256 frames (resident float32), validation '
+                      'after every epoch, metric rows, best-model snapshot (deepcopy), test rows'
+                      % (n_epochs, n['train'], n['val'], n['test']),
+            'value': round(trials * BATCH / dt, 1), 'unit': 'frames/s (train + val + test trials)',
+            'seconds': round(dt, 4), 'trials_through_the_model': trials, 'metric_rows': rows,
+            'ms_per_trial': round(dt * 1e3 / trials, 3)}
+
+
+def geometry_step(arch_json, dim, label, batch=256):
+    """Training step of an architecture / frame size the specialised kernels were NOT tuned for:
+    ms per step and, layer by layer and role by role, the kernel the dispatch chose."""
+    from tests.golden_utils import base_hparams, make_frames
+    arch = load_handcrafted_arch(list(dim), N_LATENTS, arch_json, check_memory=False)
+    hp = base_hparams(arch, 'ae')
+    hp['device'] = 'cuda'
+    torch.manual_seed(0)
+    m = AE(hp).to('cuda')
+    opt = FlatAdamAMSGrad(m.get_parameters(), lr=1e-4)
+    data = {'images': torch.from_numpy(make_frames(batch, dim, seed=1)).cuda()[None]}
+
+    def step():
+        m.train()
+        opt.zero_grad()
+        m.loss(data, dataset=0, accumulate_grad=True)
+        opt.step()
+    t = _timed(step, 12, 20)
+    kernels = {}
+    for stack, fams in (('encoding', (('fwd', _hip.PROF_CONV_FWD, False), ('bwd_data', _hip.PROF_CONV_BWD_D, True),
+                                      ('bwd_weight', _hip.PROF_CONV_BWD_W, False))),
+                        ('decoding', (('fwd', _hip.PROF_CONVT_FWD, False), ('bwd_data', _hip.PROF_CONVT_BWD_D, True),
+                                      ('bwd_weight', _hip.PROF_CONVT_BWD_W, True)))):
+        for i, layer in enumerate(getattr(m, stack)._plan):
+            for role, fam, swap in fams:
+                if stack == 'encoding' and i == 0 and role == 'bwd_data':
+                    continue
+                # (C, K) as the dispatch reports them: big-side, small-side channels for the
+                # gather-down / weight-gradient launches, the other way round for gather-up
+                big, small = (layer.cin, layer.cout) if layer.kind == 'conv' else (layer.cout, layer.cin)
+                c, k = (small, big) if (layer.kind == 'conv') == swap else (big, small)
+                _hip.prof_select(fam, c, k)
+                step()
+                torch.cuda.synchronize()
+                ms, n, name = _hip.prof_read()
+                _hip.prof_select(_hip.PROF_NONE)
+                key = '%s.%d %s' % ('enc' if stack == 'encoding' else 'dec', i, role)
+                kernels[key] = ('%s %.0f us' % (name, ms * 1e3 / n)) if n else 'not matched'
+    fwd_flop = sum(2.0 * l.cin * l.cout * l.R * l.S * (l.hout * l.wout if l.kind == 'conv' else l.hin * l.win)
+                   for st in ('encoding', 'decoding') for l in getattr(m, st)._plan)
+    tf = 3 * fwd_flop * batch / t / 1e12
+    return {'config': label + ', batch %d, 12 latents: training step' % batch,
+            'value': round(batch / t, 1), 'unit': 'frames/s', 'ms_per_step': round(t * 1e3, 3),
+            'steps': 20, 'roofline': {'bound': 'mfma', 'achieved': round(tf, 2), 'peak': FP32_PEAK_TFLOPS,
+                                      'unit': 'TFLOP/s', 'frac': round(tf / FP32_PEAK_TFLOPS, 4),
+                                      'note': 'whole step, 3 x forward conv FLOPs (zero-padded taps counted)'},
+            'dispatched_kernels': kernels}
 
 
 def profile_kernel(model, opt, gen, family, C, K, steps=2):
