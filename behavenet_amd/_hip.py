@@ -84,6 +84,12 @@ SIGNATURES = {
     'bn_kl_bwd': (_c_int, [_c_void_p] * 4 + [_c_size_t, _c_float, _c_void_p, _c_void_p]),
     'bn_decomposed_kl_fwd': (_c_int, [_c_void_p] * 7 + [_c_int, _c_int, _c_void_p]),
     'bn_decomposed_kl_bwd': (_c_int, [_c_void_p] * 9 + [_c_int, _c_int, _c_void_p]),
+    'bn_psvae_head_fwd': (_c_int, [_c_void_p] * 14 + [_c_int] * 3 + [_c_void_p]),
+    'bn_psvae_head_combine': (
+        _c_int, [_c_void_p] * 4 + [_c_int] + [_c_float] * 3 + [_c_int] + [_c_void_p] * 3),
+    'bn_psvae_head_bwd': (
+        _c_int, [_c_void_p] * 3 + [_c_int] + [_c_void_p] * 10 + [_c_float] + [_c_void_p] * 5 +
+        [_c_int] * 4 + [_c_void_p]),
     'bn_adam_amsgrad_step': (
         _c_int, [_c_void_p] * 5 + [_c_size_t] + [_c_float] * 5 + [_c_int, _c_void_p]),
     'bn_u8_to_unit_float': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_void_p]),
@@ -544,6 +550,55 @@ def decomposed_kl_bwd(z, mu, logvar, log_qz, lse, g3, out=None):
         _ptr(lse, 'lse'), _ptr(g3, 'g3'), _ptr(dz, 'dz'), _ptr(dmu, 'dmu'),
         _ptr(dlogvar, 'dlogvar'), N, D, _stream()), 'bn_decomposed_kl_bwd')
     return dz, dmu, dlogvar
+
+
+def psvae_head_fwd(y, w, logvar, eps, Dw, Db, labels, lmask):
+    """-> (z, z_u, lv_u, yhat, row_sq, row_kl); see include/behavenet_hip.h."""
+    N, L = y.shape
+    U = logvar.shape[1] - L
+    dev = y.device
+    z = torch.empty((N, L + U), dtype=torch.float32, device=dev)
+    z_u = torch.empty((N, U), dtype=torch.float32, device=dev)
+    lv_u = torch.empty((N, U), dtype=torch.float32, device=dev)
+    yhat = torch.empty((N, L), dtype=torch.float32, device=dev)
+    rows = torch.empty((2, N), dtype=torch.float32, device=dev)
+    _check(load().bn_psvae_head_fwd(
+        _ptr(y, 'y'), _ptr(w, 'w', allow_none=True), _ptr(logvar, 'logvar'), _ptr(eps, 'eps'),
+        _ptr(Dw, 'Dw'), _ptr(Db, 'Db', allow_none=True), _ptr(labels, 'labels'),
+        _ptr(lmask, 'lmask', allow_none=True), _ptr(z, 'z'), _ptr(z_u, 'z_u'), _ptr(lv_u, 'lv_u'),
+        _ptr(yhat, 'yhat'), _ptr(rows[0], 'row_sq'), _ptr(rows[1], 'row_kl'), N, L, U, _stream()),
+        'bn_psvae_head_fwd')
+    return z, z_u, lv_u, yhat, rows[0], rows[1]
+
+
+def psvae_head_combine(row_sq, row_kl, dkl3, bounds_dev, n_chunks, alpha, kl, beta, L):
+    """-> (T (n_chunks,), cols5 (n_chunks, 5))."""
+    T = torch.empty((n_chunks,), dtype=torch.float32, device=row_sq.device)
+    cols5 = torch.empty((n_chunks, 5), dtype=torch.float32, device=row_sq.device)
+    _check(load().bn_psvae_head_combine(
+        _ptr(row_sq, 'row_sq'), _ptr(row_kl, 'row_kl'), _ptr(dkl3, 'dkl3'),
+        _ptr(bounds_dev, 'bounds', dtype=torch.int32), int(n_chunks), float(alpha), float(kl),
+        float(beta), int(L), _ptr(T, 'T'), _ptr(cols5, 'cols5'), _stream()), 'bn_psvae_head_combine')
+    return T, cols5
+
+
+def psvae_head_bwd(dz, gT, bounds_dev, n_chunks, y, logvar, eps, yhat, labels, lmask, Dw, gz_u,
+                   gmu_u, glv_u, alpha, dDw, dDb, accumulate):
+    """-> (dy, dw, dlogvar); dDw / dDb are written (or added to) in place."""
+    N, L = y.shape
+    U = logvar.shape[1] - L
+    dy = torch.empty_like(y)
+    dw = torch.empty((N, U), dtype=torch.float32, device=y.device)
+    dlogvar = torch.empty_like(logvar)
+    _check(load().bn_psvae_head_bwd(
+        _ptr(dz, 'dz'), _ptr(gT, 'gT'), _ptr(bounds_dev, 'bounds', dtype=torch.int32),
+        int(n_chunks), _ptr(y, 'y'), _ptr(logvar, 'logvar'), _ptr(eps, 'eps'), _ptr(yhat, 'yhat'),
+        _ptr(labels, 'labels'), _ptr(lmask, 'lmask', allow_none=True), _ptr(Dw, 'Dw'),
+        _ptr(gz_u, 'gz_u'), _ptr(gmu_u, 'gmu_u'), _ptr(glv_u, 'glv_u'), float(alpha),
+        _ptr(dy, 'dy'), _ptr(dw, 'dw'), _ptr(dlogvar, 'dlogvar'),
+        _ptr(dDw, 'dDw', allow_none=True), _ptr(dDb, 'dDb', allow_none=True),
+        int(bool(accumulate)), N, L, U, _stream()), 'bn_psvae_head_bwd')
+    return dy, dw, dlogvar
 
 
 def reparam_bwd(dz, z, mu):

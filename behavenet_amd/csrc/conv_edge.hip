@@ -1189,7 +1189,7 @@ __device__ __forceinline__ void dp_body(
         // byte offset of (strip row j of this wave, half qh) in channel 0
 #define DP_OFF(j, qh) (((n * g.Cs * g.Hs + p0 + wv + DW_WAVES * (j)) * DC_W + 32 * (qh)) * 4)
         floatx16 a0, a1;
-        half(a0, a1, wv, 0, false, 0);
+        half(a0, a0, wv, 0, false, 0);                                  // (no previous half row yet)
         if (u == (int)blockIdx.x) E0_MARK(2);
         half(a1, a0, wv, 1, true, DP_OFF(0, 0));                        // + 16 stores
 #pragma unroll

@@ -1113,3 +1113,92 @@ def combine_chunk_terms(terms, coefs):
 
 def kl_to_std_normal(mu, logvar):
     return KLFn.apply(mu, logvar)
+
+
+_DEVICE_INT_CONSTANTS = {}
+
+
+def device_int_constant(values, device):
+    """int32 counterpart of :func:`device_constant` (chunk bounds handed to kernels)."""
+    key = (tuple(int(v) for v in values), str(device))
+    t = _DEVICE_INT_CONSTANTS.get(key)
+    if t is None:
+        if len(_DEVICE_INT_CONSTANTS) > 256:
+            _DEVICE_INT_CONSTANTS.clear()
+        t = torch.tensor(key[0], dtype=torch.int32, device=device)
+        _DEVICE_INT_CONSTANTS[key] = t
+    return t
+
+
+class PSVAEHeadFn(torch.autograd.Function):
+    """Everything between the PS encoder's heads and the decoder as ONE autograd node (reference
+    vaes.py:571-601 forward, :669-704 loss terms; csrc/psvae_head.hip):
+
+        (y, w, logvar, D.weight, D.bias) -> z (N, L + U), T (n_chunks,), y_hat (N, L), cols5
+
+    with T[c] = -alpha ll_labels + KL(z_s) + kl MI + beta TC + kl DWKL of chunk c (rows
+    ``bounds[c]``; means over the chunk) and cols5 = the five raw terms for the metric table.
+    Forward: 1 + 2 n_chunks + 1 launches (rows, decomposed KL per chunk, combination); backward:
+    1 + 2 n_chunks + 1.  It replaces the reparameterisation, DiagLinear, label log-likelihood, KL,
+    column-split, concatenation and combination nodes (~75 element-wise launches per step)."""
+
+    @staticmethod
+    def forward(ctx, y, w, logvar, Dw, Db, labels, lmask, eps, bounds, alpha, kl, beta):
+        y, w, logvar = y.contiguous(), w.contiguous(), logvar.contiguous()
+        labels, eps = labels.contiguous(), eps.contiguous()
+        lmask = lmask.contiguous() if lmask is not None else None
+        dwv, dbv = Dw.detach(), (Db.detach() if Db is not None else None)
+        L = y.shape[1]
+        z, z_u, lv_u, yhat, row_sq, row_kl = _hip.psvae_head_fwd(y, w, logvar, eps, dwv, dbv, labels,
+                                                                 lmask)
+        n_chunks = len(bounds)
+        dkl3 = torch.empty((n_chunks, 3), dtype=torch.float32, device=y.device)
+        saved = []
+        for c, (b, e) in enumerate(bounds):
+            _, log_qz, lse = _hip.decomposed_kl_fwd(z_u[b:e], w[b:e], lv_u[b:e], out3=dkl3[c])
+            saved += [log_qz, lse]
+        bdev = device_int_constant([v for be in bounds for v in be], y.device)
+        T, cols5 = _hip.psvae_head_combine(row_sq, row_kl, dkl3, bdev, n_chunks, alpha, kl, beta, L)
+        ctx.save_for_backward(y, w, logvar, eps, yhat, labels, lmask, dwv, z_u, lv_u, bdev, *saved)
+        ctx.bounds = list(bounds)
+        ctx.coefs = (float(alpha), float(kl), float(beta))
+        ctx.param_refs = (Dw, Db)
+        ctx.has_bias = Db is not None
+        _note_use((Dw, Db), ctx.needs_input_grad[3])
+        ctx.mark_non_differentiable(yhat, cols5)
+        return z, T, yhat, cols5
+
+    @staticmethod
+    def backward(ctx, dz, gT, _gy, _gc):
+        y, w, logvar, eps, yhat, labels, lmask, dwv, z_u, lv_u, bdev = ctx.saved_tensors[:11]
+        saved = ctx.saved_tensors[11:]
+        alpha, kl, beta = ctx.coefs
+        n_chunks = len(ctx.bounds)
+        dz = dz.contiguous() if dz is not None else torch.zeros_like(logvar)
+        gT = gT.contiguous() if gT is not None else torch.zeros((n_chunks,), device=y.device)
+        g3 = gT[:, None] * device_constant([kl, beta, kl], y.device)[None, :]
+        gz_u, gmu_u, glv_u = torch.empty_like(z_u), torch.empty_like(z_u), torch.empty_like(z_u)
+        for c, (b, e) in enumerate(ctx.bounds):
+            _hip.decomposed_kl_bwd(z_u[b:e], w[b:e], lv_u[b:e], saved[2 * c], saved[2 * c + 1], g3[c],
+                                   out=(gz_u[b:e], gmu_u[b:e], glv_u[b:e]))
+        Dw, Db = ctx.param_refs
+        need_d = ctx.needs_input_grad[3]
+        gw = _grad_buffer(Dw) if need_d else None
+        gb = _grad_buffer(Db) if (need_d and ctx.has_bias) else None
+        direct = need_d and gw is not None and (gb is not None or not ctx.has_bias)
+        if direct:
+            dDw, dDb = gw, gb
+        else:
+            dDw = torch.empty_like(dwv) if need_d else None
+            dDb = torch.empty_like(dwv) if (need_d and ctx.has_bias) else None
+        dy, dw, dlogvar = _hip.psvae_head_bwd(dz, gT, bdev, n_chunks, y, logvar, eps, yhat, labels,
+                                              lmask, dwv, gz_u, gmu_u, glv_u, alpha, dDw, dDb, direct)
+        if direct:
+            _report_ready(ctx.param_refs)
+            dDw = dDb = None
+        return dy, dw, dlogvar, dDw, dDb, None, None, None, None, None, None, None
+
+
+def psvae_head(y, w, logvar, D, labels, lmask, eps, bounds, alpha, kl, beta):
+    """-> (z, T (n_chunks,), y_hat, cols5 (n_chunks, 5)); D = the DiagLinear label map."""
+    return PSVAEHeadFn.apply(y, w, logvar, D.weight, D.bias, labels, lmask, eps, bounds, alpha, kl, beta)

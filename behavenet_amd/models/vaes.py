@@ -12,6 +12,8 @@ reference that are reproduced on purpose:
   log-likelihood by the current chunk size.
 """
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -40,6 +42,19 @@ def set_eps_provider(fn):
     """
     global _eps_provider
     _eps_provider = fn
+
+
+# BN_FUSED_PS_HEAD=0: the PS-VAE's latent head as separate autograd nodes (the first implementation)
+_FUSED_PS_HEAD = os.environ.get('BN_FUSED_PS_HEAD', '1') != '0'
+
+
+def _draw_eps(logvar, bounds):
+    """eps ~ N(0, 1) of the shape of ``logvar``.  With an eps provider (tests): one call per chunk
+    in chunk order with that chunk's shape, as the reference's chunk loop consumes them; else one
+    draw for the whole batch."""
+    if _eps_provider is None or bounds is None:
+        return _eps_provider(logvar) if _eps_provider is not None else torch.randn_like(logvar)
+    return torch.cat([_eps_provider(logvar[b:e]) for b, e in bounds], dim=0)
 
 
 def reparameterize(mu, logvar, eps=None):
@@ -501,6 +516,40 @@ class PSVAE(AE):
         y_hat = self.encoding.D(y)
         return x_hat, z, mu, logvar, y_hat, y, w
 
+    def _loss_terms_unfused(self, xl, yl, ml, nl, sh, bounds, share, dataset, alpha, beta, kl):
+        """Per-chunk total, metric table and y_hat from separate autograd nodes per term: the path
+        of frame-sharded data parallelism (the decomposed KL is evaluated on the gathered chunk)
+        and of BN_FUSED_PS_HEAD=0."""
+        n_labels = self.hparams['n_labels']
+        x_hat, sample, mu, logvar, y_hat, mu_s, mu_u = self._forward_parts(
+            xl, dataset=dataset, use_mean=False, sample_bounds=bounds, sample_shards=sh,
+            pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
+                        'chunk_sizes': sh.sizes})
+        ll_x = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
+                                         const_share=share)
+        ll_y = losses.gaussian_ll_chunks(yl, y_hat, nl, bounds, chunk_sizes=sh.sizes,
+                                         const_share=share)
+        # column blocks once for the whole batch: the means are the encoder's own two heads,
+        # log-variance and sample are split by one node each
+        logvar_s, logvar_u = hf.split_cols(logvar, n_labels)
+        _, sample_u = hf.split_cols(sample, n_labels)
+        zs = sh.kl_terms(mu_s, logvar_s)
+        # batch-coupled: evaluated on the gathered chunk by every rank (see BetaTCVAE)
+        dk = sh.decomposed_kl_terms(sample_u, mu_u, logvar_u)          # (n_chunks, 3)
+        w = sh.share_t(xl.device)
+        if isinstance(w, float):
+            # not sharded: the total and the metric table from one node
+            lossv, terms = hf.combine_chunk_terms(
+                [ll_x, ll_y, zs, dk], [[-1.0], [-float(alpha)], [1.0],
+                                       [float(kl), float(beta), float(kl)]])
+            table = torch.cat([terms, lossv.detach()[:, None]], dim=1)
+        else:
+            kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
+            lossv = -ll_x - float(alpha) * ll_y + zs + kl_terms
+            table = torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk * w[:, None],
+                               (-ll_x - float(alpha) * ll_y + zs + w * kl_terms)[:, None]], dim=1)
+        return lossv, table, y_hat
+
     def loss(self, data, dataset=0, accumulate_grad=True, chunk_size=200):
         """Modified ELBO of the PS-VAE (ref vaes.py:603-729); returns the same 11 keys."""
         x = data['images'][0]
@@ -526,35 +575,25 @@ class PSVAE(AE):
             bounds = sh.bounds_l
             xl, yl, ml, nl = sh.take(x, y, m, n)
             share = sh.share if sh.sharded else None
+            fused_head = not sh.sharded and _FUSED_PS_HEAD and xl.is_cuda
             with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, sample, mu, logvar, y_hat, mu_s, mu_u = self._forward_parts(
-                    xl, dataset=dataset, use_mean=False, sample_bounds=bounds, sample_shards=sh,
-                    pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
-                                'chunk_sizes': sh.sizes})
-                ll_x = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
-                                                 const_share=share)
-                ll_y = losses.gaussian_ll_chunks(yl, y_hat, nl, bounds, chunk_sizes=sh.sizes,
-                                                 const_share=share)
-                # column blocks once for the whole batch: the means are the encoder's own two
-                # heads, log-variance and sample are split by one node each
-                logvar_s, logvar_u = hf.split_cols(logvar, n_labels)
-                _, sample_u = hf.split_cols(sample, n_labels)
-                zs = sh.kl_terms(mu_s, logvar_s)
-                # batch-coupled: evaluated on the gathered chunk by every rank (see BetaTCVAE)
-                dk = sh.decomposed_kl_terms(sample_u, mu_u, logvar_u)          # (n_chunks, 3)
-                w = sh.share_t(x.device)
-                if isinstance(w, float):
-                    # not sharded: the total and the metric table from one node
-                    lossv, terms = hf.combine_chunk_terms(
-                        [ll_x, ll_y, zs, dk], [[-1.0], [-float(alpha)], [1.0],
-                                               [float(kl), float(beta), float(kl)]])
-                    table = torch.cat([terms, lossv.detach()[:, None]], dim=1)
-                else:
-                    kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
-                    lossv = -ll_x - float(alpha) * ll_y + zs + kl_terms
-                    table = torch.cat([ll_x[:, None], ll_y[:, None], zs[:, None], dk * w[:, None],
-                                       (-ll_x - float(alpha) * ll_y + zs + w * kl_terms)[:, None]],
+                if fused_head:
+                    # encoder heads -> ONE node (latents, label head, label / KL / decomposed-KL
+                    # terms of every chunk) -> decoder with the pixel loss in its last kernel
+                    mu_s, mu_u, logvar, pool_idx, outsize = self.encoding(xl, dataset=dataset)
+                    eps = _draw_eps(logvar, bounds)
+                    sample, lat_terms, y_hat, cols5 = hf.psvae_head(
+                        mu_s, mu_u, logvar, self.encoding.D, yl, nl, eps, bounds, alpha, kl, beta)
+                    x_hat = self.decoding(sample, pool_idx, outsize, dataset=dataset,
+                                          pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds,
+                                                      'kind': 'll', 'chunk_sizes': sh.sizes})
+                    ll_x = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes)
+                    lossv = lat_terms - ll_x
+                    table = torch.cat([ll_x.detach()[:, None], cols5, lossv.detach()[:, None]],
                                       dim=1)
+                else:
+                    lossv, table, y_hat = self._loss_terms_unfused(
+                        xl, yl, ml, nl, sh, bounds, share, dataset, alpha, beta, kl)
             # label r^2 over the whole batch: the ranks' rows are gathered (a few KB)
             y_hat_rb = hf.Readback(sh.all_rows(y_hat.detach()))
             y_rb = hf.Readback(sh.all_rows(yl))

@@ -246,6 +246,34 @@ int bn_decomposed_kl_bwd(const float* z, const float* mu, const float* logvar,
                          float* dmu, float* dlogvar, int N, int D, bn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Latent head of the PS-VAE (reference vaes.py:571-601 forward, :669-704 per-chunk loss terms):
+ * everything between the encoder's two heads / the decomposed-KL kernels and the decoder, fused.
+ *   y (N, L) supervised means, w (N, U) unsupervised means, logvar / eps / z (N, L + U), D = the
+ *   diagonal label map (Dw, Db of length L; Db nullable), labels / lmask (N, L; lmask nullable).
+ *   fwd:     z = [y | w] + eps exp(logvar); z_u, lv_u: the unsupervised columns of z / logvar as
+ *            contiguous (N, U) tensors (inputs of bn_decomposed_kl_fwd); yhat = D y;
+ *            row_sq[n] = sum_l (yhat - labels)^2 lmask; row_kl[n] = 0.5 sum_{l<L} (e^lv - lv + y^2 - 1)
+ *   combine: per chunk c = rows [bounds[2c], bounds[2c+1]) (device ints), dkl3 = (n_chunks, 3) from
+ *            bn_decomposed_kl_fwd: cols5[c] = (ll_labels, KL_s, MI, TC, DWKL),
+ *            T[c] = -alpha ll_labels + KL_s + kl MI + beta TC + kl DWKL
+ *   bwd:     gT[c] = dL/dT[c], dz = dL/dz from the decoder, gz_u / gmu_u / glv_u = the outputs of
+ *            bn_decomposed_kl_bwd (called with g3 = gT[c] (kl, beta, kl)) -> dy, dw, dlogvar and the
+ *            gradients of D (written, or added to when accumulate) */
+int bn_psvae_head_fwd(const float* y, const float* w, const float* logvar, const float* eps,
+                      const float* Dw, const float* Db, const float* labels, const float* lmask,
+                      float* z, float* z_u, float* lv_u, float* yhat, float* row_sq,
+                      float* row_kl, int N, int L, int U, bn_stream_t stream);
+int bn_psvae_head_combine(const float* row_sq, const float* row_kl, const float* dkl3,
+                          const int* bounds, int n_chunks, float alpha, float kl, float beta,
+                          int L, float* T, float* cols5, bn_stream_t stream);
+int bn_psvae_head_bwd(const float* dz, const float* gT, const int* bounds, int n_chunks,
+                      const float* y, const float* logvar, const float* eps, const float* yhat,
+                      const float* labels, const float* lmask, const float* Dw, const float* gz_u,
+                      const float* gmu_u, const float* glv_u, float alpha, float* dy, float* dw,
+                      float* dlogvar, float* dDw, float* dDb, int accumulate, int N, int L, int U,
+                      bn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Last decoder layer fused with the pixel loss (replaces, in ONE pass, the ConvTranspose2d + crop
  * + Sigmoid of aes.py:315-330,466-470 and the squared error of losses.py:56-59 / 84-96 together
  * with their derivatives): for every frame n
