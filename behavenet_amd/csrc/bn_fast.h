@@ -58,6 +58,7 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
                          float* db = nullptr, int bias_side = 0, bool* bias_done = nullptr);
 BnFastPlan bn_edge_down_plan(const BnGeom& g);
 const char* bn_edge_down_kernel_name(const BnGeom& g, int act, bool has_dact, bool u8);
+const char* bn_edge_up_kernel_name(const BnGeom& g, bool loss);
 int bn_launch_edge_down(const float* big, const float* w, const float* bias, float* out,
                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                         hipStream_t st, const unsigned char* u8 = nullptr);

@@ -649,7 +649,7 @@ extern "C" int bn_convT2d_fwd_sqerr(const float* x, const float* w, const float*
     if (!bn_geom_ok(g)) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (fused_sqerr_fast(g)) {
-        BnProfScope prof(BN_PROF_CONVT_FWD, g.Cs, g.Cb, "k_up_c1v<8, true>", st);
+        BnProfScope prof(BN_PROF_CONVT_FWD, g.Cs, g.Cb, bn_edge_up_kernel_name(g, true), st);
         return bn_launch_edge_up(x, w, b, xhat, g, act, slope, st, target, mask, dpre, part);
     }
     const size_t need = bn_convT2d_fwd_sqerr_ws_bytes(N, Ci, Hi, Wi, Co, R, S, stride, crop_t,

@@ -1532,6 +1532,10 @@ __global__ __launch_bounds__(ED_THREADS) void k_up_c1(
 //    goes to memory unless asked for (reference aes.py:330 + losses.py:56-59).
 // =============================================================================================
 #define UV_W 64
+#ifndef UP_C1_VARIANT
+#define UP_C1_VARIANT 1                  // 1: k_up_c1m (matrix cores) where its geometry holds (in the
+                                         // training step 41.6 us against 51.0 for k_up_c1v on one box)
+#endif
 
 __device__ __forceinline__ float uv_shift_from_left(float v) {      // lane q <- lane q-1, 0 at q=0
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(
@@ -1703,6 +1707,231 @@ __global__ __launch_bounds__(64) void k_up_c1v(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gather-up with <= 32 small-side channels on the matrix cores (dec.convT4 forward, optionally with
+// the pixel loss): the 32 -> 1 channel reduction is a skinny GEMM
+//     T[tap][pos] = sum_c W[c][tap] * small[c][pos]          (25 taps x 32 channels x positions)
+// and the transposed convolution is then a sum of <= 9 SHIFTED entries of T per output pixel:
+//     out[2P + a][2Q + b] = sum_{(r, dp) in R_a} sum_{(s, dq) in S_b} T[r][s][P + dp][Q + dq],
+//     R_0 = S_0 = {(1, 0), (3, -1)},  R_1 = S_1 = {(0, +1), (2, 0), (4, -1)}        (pt = pl = 1).
+// k_up_c1v does the whole thing on the vector ALU (200 multiply-adds per channel and lane: bound by
+// vector issue at 35 TFLOP/s, 48 us); here the multiply-adds are MFMAs (14 us of matrix time) and
+// the vector ALU only adds the 25 shifted entries (~30 instructions per input row of 64 columns).
+//
+// Workgroup = one frame x one output channel, wave = 8 input rows, 64 lanes = the 64 columns:
+//  * MFMA 32x32x2, rows = taps, columns = 32 positions, reduction = channels (16 steps).  Two column
+//    blocks per input row: A = even columns q = 2 li, B = odd columns q = 2 li + 1 (one 8-byte
+//    load per lane and channel pair feeds both).  The tap rows are ordered so that lane half kk = 0
+//    holds the taps of output column parity b = 0 (s = 1, 3) and half 1 those of b = 1 (s = 2, 4, 0),
+//    register e of both halves having the same column shift: e < 5 none (r = e), 5 <= e < 10 from
+//    q - 1, 10 <= e < 15 from q + 1.  With the even / odd blocks "q - 1" of A is B's lane li - 1 and
+//    of B is A's own lane: per (r, block) two plain adds and ONE v_fmac_f32_dpp (wave shift by one
+//    lane, times a lane mask that clears the value crossing the lane-31 / 32 boundary).
+//  * rows: input row p adds its five kernel rows into a sliding window of output rows
+//    2p - 1 .. 2p + 3; rows 2p - 1 and 2p are complete afterwards.  The first four output rows of a
+//    wave also need the last rows of the wave above: they are kept, every wave leaves its unfinished
+//    window (3 rows) in LDS at the end, one barrier, the wave below adds them and emits.
+//  * emission: two output rows at a time; two v_permlane32_swap give every lane 4 ADJACENT pixels of
+//    one row (lanes 0-31 one row, 32-63 the other): bias, activation, target / mask, squared error,
+//    dL/dpre with 16-byte accesses of full 512-byte rows.
+// ---------------------------------------------------------------------------------------------
+#define UM_R 8                                  // input rows per wave
+typedef unsigned int uintx2m __attribute__((ext_vector_type(2)));
+
+template <bool LOSS>
+__global__ __launch_bounds__(512) void k_up_c1m(
+    const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, const float* __restrict__ target, const float* __restrict__ mask,
+    float* __restrict__ dpre, float* __restrict__ partial, BnGeom g, int act, float slope) {
+    __shared__ float xch[8 * 6 * 64];                // per wave: 3 window rows x 2 blocks x 64 lanes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_waves = g.Hs / UM_R;
+    const int li = lane & 31, kk = lane >> 5;
+    const int n = blockIdx.x, bch = blockIdx.y;
+    const int p0 = wv * UM_R;
+    const int HWs = g.Hs * g.Ws;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)g.N * g.Cs * HWs * 4), 0x00020000);
+    const int obytes = (int)((size_t)g.N * g.Cb * g.Hb * g.Wb * 4);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out ? obytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)target, 0, LOSS ? obytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)mask, 0, (LOSS && mask) ? obytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dpre, 0, LOSS ? obytes : 0, 0x00020000);
+
+    // A operand: lane (li, kk) = row m = li of the tap matrix for channel 2t + kk
+    float wA[16];
+    {
+        const int e = (li & 3) + 4 * (li >> 3), half = (li >> 2) & 1;
+        int r = -1, sx = 0;
+        if (e < 5) { r = e; sx = half ? 2 : 1; }
+        else if (e < 10) { r = e - 5; sx = half ? 4 : 3; }
+        else if (e < 15 && half) { r = e - 10; sx = 0; }
+        // through LDS: the weights of this output channel are read once per workgroup with
+        // coalesced loads (16 gathers per lane and wave kept the CU's one vector-memory pipe busy for
+        // the first microseconds of enc.conv0's first generation)
+        for (int e2 = tid; e2 < 32 * 25; e2 += blockDim.x) {
+            const int c = e2 / 25;
+            xch[e2] = c < g.Cs ? w[(c * g.Cb + bch) * 25 + (e2 - c * 25)] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wA[t] = r >= 0 ? xch[(2 * t + kk) * 25 + r * 5 + sx] : 0.f;
+        __syncthreads();                               // (xch is reused for the window exchange)
+    }
+    // lane masks of the two shifted classes: the wave shift carries lane 31 into lane 32 (and 32
+    // into 31), which are different column blocks' ends
+    const float m_shr = lane == 32 ? 0.f : 1.f;
+    const float m_shl = lane == 31 ? 0.f : 1.f;
+
+    // B operand: small[n, 2t + kk, p, 2 li .. 2 li + 1]
+    const int x_vo = (kk * HWs + 2 * li) * 4;
+    auto load_row = [&](floatx2p (&x)[16], const int p) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const bool ok = 2 * t + kk < g.Cs;
+            x[t] = __builtin_bit_cast(floatx2p, __builtin_amdgcn_raw_buffer_load_b64(
+                rs, ok ? x_vo : ED_OOB, ((n * g.Cs + 2 * t) * g.Hs + p) * g.Ws * 4, 0));
+        }
+    };
+
+    const float bs = bias ? bias[bch] : 0.f;
+    float sq = 0.f;
+    // two complete output rows (h1: registers a1 / b1 of blocks A / B, h2: a2 / b2) -> HBM
+    // byte offset of this lane's four pixels in rows (h1 | h2), out of range for rows outside the frame
+    auto row_vo = [&](const int h1, const int h2) __attribute__((always_inline)) {
+        const int h = kk ? h2 : h1;
+        return (h >= 0 && h < g.Hb) ? (((n * g.Cb + bch) * g.Hb + h) * g.Wb + 4 * li) * 4 : ED_OOB;
+    };
+    // target and mask of a row pair, requested ahead of the multiplications that complete the rows
+    auto load_tm = [&](floatx4e& t4, floatx4e& m4, const int vo) __attribute__((always_inline)) {
+        if (LOSS) {
+            t4 = __builtin_bit_cast(floatx4e, __builtin_amdgcn_raw_buffer_load_b128(rt, vo, 0, 0));
+            if (mask) m4 = __builtin_bit_cast(floatx4e, __builtin_amdgcn_raw_buffer_load_b128(rm, vo, 0, 0));
+        }
+    };
+    auto emit2 = [&](const float a1, const float b1, const float a2, const float b2, const int vo,
+                     const floatx4e t4, const floatx4e m4in) __attribute__((always_inline)) {
+        // v_permlane32_swap x, y: x = [x.lo, y.lo], y = [x.hi, y.hi] (lanes 0-31 | 32-63).  Inline
+        // asm: with two __builtin_amdgcn_permlane32_swap in a row this hipcc re-used the register of
+        // the first one's second result before it was read (tools/lab/swap_probe.hip has the
+        // semantics; the s_nop covers the VALU-write -> permlane hazard the compiler pads itself)
+        float v[4] = {a1, a2, b1, b2};
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[1]));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[2]), "+v"(v[3]));
+        // lanes 0-31: row h1, lanes 32-63: row h2; columns 4 li .. 4 li + 3
+        const bool ok = vo != ED_OOB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] += bs;
+            if (act == BN_ACT_SIGMOID) v[i] = __builtin_amdgcn_rcpf(1.f + __expf(-v[i]));
+            else v[i] = bn_apply_act(v[i], act, slope);
+        }
+        if (out) {
+            const floatx4e o4 = {v[0], v[1], v[2], v[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4e, o4), ro, vo, 0, 0);
+        }
+        if (LOSS) {
+            floatx4e m4 = {1.f, 1.f, 1.f, 1.f};
+            if (mask) m4 = m4in;
+            floatx4e d4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dx = v[i] - t4[i];
+                if (ok) sq = fmaf(dx * dx, m4[i], sq);
+                d4[i] = 2.f * dx * m4[i] * bn_act_grad_from_output(v[i], act, slope);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4e, d4), rd, vo, 0, 0);
+        }
+    };
+
+    // sliding window of output rows 2p - 1 .. 2p + 3 (index = kernel row r), per column block
+    float oa[5], ob[5], ha[4], hb[4];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) oa[r] = ob[r] = 0.f;
+
+    // three register sets of input rows: row p is multiplied while p + 1 and p + 2 are in flight
+    floatx2p x[3][16];
+    load_row(x[0], p0);
+    load_row(x[1], p0 + 1);
+#pragma unroll
+    for (int i = 0; i < UM_R; ++i) {
+        const int p = p0 + i;
+        if (i + 2 < UM_R) load_row(x[(i + 2) % 3], p + 2);
+        floatx4e t4 = {0.f, 0.f, 0.f, 0.f}, m4 = {1.f, 1.f, 1.f, 1.f};
+        const int vo = row_vo(2 * p - 1, 2 * p);
+        if (i >= 2) load_tm(t4, m4, vo);
+        floatx16 accA, accB;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accA[e] = accB[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[t], x[i % 3][t].x, accA, 0, 0, 0);
+            accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[t], x[i % 3][t].y, accB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            // block A (q = 2 li): same q own block; q + 1 = B's lane; q - 1 = B's lane li - 1
+            oa[r] += accA[r] + accB[10 + r];
+            asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                         : "+v"(oa[r]) : "v"(accB[5 + r]), "v"(m_shr));
+            // block B (q = 2 li + 1): q - 1 = A's lane; q + 1 = A's lane li + 1
+            ob[r] += accB[r] + accA[5 + r];
+            asm volatile("v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                         : "+v"(ob[r]) : "v"(accA[10 + r]), "v"(m_shl));
+        }
+        // rows 2p - 1 (index 0) and 2p (index 1) are complete, except in the first two rows of the
+        // wave, whose output rows wait for the wave above
+        if (i < 2) {
+            ha[2 * i] = oa[0]; hb[2 * i] = ob[0];
+            ha[2 * i + 1] = oa[1]; hb[2 * i + 1] = ob[1];
+        } else {
+            emit2(oa[0], ob[0], oa[1], ob[1], vo, t4, m4);
+        }
+        oa[0] = oa[2]; oa[1] = oa[3]; oa[2] = oa[4]; oa[3] = 0.f; oa[4] = 0.f;
+        ob[0] = ob[2]; ob[1] = ob[3]; ob[2] = ob[4]; ob[3] = 0.f; ob[4] = 0.f;
+    }
+    // targets of the rows that waited, requested before the barrier
+    floatx4e th0 = {0.f, 0.f, 0.f, 0.f}, mh0 = {1.f, 1.f, 1.f, 1.f}, th1 = th0, mh1 = mh0, th2 = th0, mh2 = mh0;
+    const int vo_h0 = row_vo(2 * p0 - 1, 2 * p0), vo_h1 = row_vo(2 * p0 + 1, 2 * p0 + 2);
+    const int vo_h2 = row_vo(2 * (p0 + UM_R - 1) + 1, -1);
+    load_tm(th0, mh0, vo_h0);
+    load_tm(th1, mh1, vo_h1);
+    if (wv == n_waves - 1) load_tm(th2, mh2, vo_h2);
+    // unfinished window (rows 2 pe + 1 .. 2 pe + 3) -> the wave below
+    float* slot = xch + wv * (6 * 64);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        slot[(2 * r) * 64 + lane] = oa[r];
+        slot[(2 * r + 1) * 64 + lane] = ob[r];
+    }
+    __syncthreads();
+    if (wv > 0) {
+        const float* up = xch + (wv - 1) * (6 * 64);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            ha[r] += up[(2 * r) * 64 + lane];
+            hb[r] += up[(2 * r + 1) * 64 + lane];
+        }
+    }
+    emit2(ha[0], hb[0], ha[1], hb[1], vo_h0, th0, mh0);
+    emit2(ha[2], hb[2], ha[3], hb[3], vo_h1, th1, mh1);
+    if (wv == n_waves - 1) emit2(oa[0], ob[0], 0.f, 0.f, vo_h2, th2, mh2);          // last row of the frame
+    if (LOSS) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+        if (lane == 0) partial[(n * g.Cb + bch) * n_waves + wv] = sq;
+    }
+}
+
+static bool up_c1m_ok(const BnGeom& g) {
+    // (one workgroup per frame and output channel: small batches keep the finer-grained k_up_c1v)
+    return g.N * g.Cb >= 128 &&
+           g.Cs <= 32 && (g.Hs % UM_R) == 0 && g.Hs / UM_R <= 8 && g.Ws == 64 && g.pt == 1 && g.pl == 1 &&
+           (size_t)g.N * g.Cb * g.Hb * g.Wb * 4 < 0x7fffffffull;
+}
+
 BnFastPlan bn_edge_up_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_up_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb > 4 || g.pt != 1 || g.pl != 1) return p;
@@ -1710,8 +1939,13 @@ BnFastPlan bn_edge_up_plan(const BnGeom& g) {
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
     p.supported = true;
-    p.kernel_name = "k_up_c1v<8, false>";
+    p.kernel_name = bn_edge_up_kernel_name(g, false);
     return p;
+}
+
+const char* bn_edge_up_kernel_name(const BnGeom& g, bool loss) {
+    if (UP_C1_VARIANT == 1 && up_c1m_ok(g)) return loss ? "k_up_c1m<true>" : "k_up_c1m<false>";
+    return loss ? "k_up_c1v<8, true>" : "k_up_c1v<8, false>";
 }
 
 #define UV_R 8          // strip height of the production instantiation
@@ -1740,6 +1974,19 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
         return 0;
     }
 #endif
+    int use_m = UP_C1_VARIANT == 1 && up_c1m_ok(g);
+    if (const char* e = bn_tune_env("BN_UP_C1_M")) use_m = atoi(e) && up_c1m_ok(g);     // (tuning build only)
+    if (use_m) {
+        const dim3 grid_m(g.N, g.Cb), block_m(64 * (g.Hs / UM_R));
+        if (target)
+            hipLaunchKernelGGL((k_up_c1m<true>), grid_m, block_m, 0, st, small, w, bias, out, target, mask,
+                               dpre, partial, g, act, slope);
+        else
+            hipLaunchKernelGGL((k_up_c1m<false>), grid_m, block_m, 0, st, small, w, bias, out, nullptr,
+                               nullptr, nullptr, nullptr, g, act, slope);
+        BN_LAUNCH_CHECK();
+        return 0;
+    }
     const int units = g.N * g.Cb * (g.Hs / UV_R);
     const int grid = units < 256 * 16 ? units : 256 * 16;
     if (target) {

@@ -67,9 +67,9 @@ KERNELS_256 = {
     ('D1', 'bwd_w'): 'k_wgrad4s_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
     ('D3', 'bwd_w'): 'k_wgrad4s_mfma<5>',
     ('E0c2', 'fwd'): 'k_down_c1s<1, false, false, 2, 2>', ('E0c2', 'bwd_w'): 'k_wgrad_c1d',
-    ('D4c2', 'fwd'): 'k_up_c1v<8, false>', ('D4c2', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 2>',
+    ('D4c2', 'fwd'): 'k_up_c1m<false>', ('D4c2', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 2>',
     ('D4c2', 'bwd_w'): 'k_wgrad_c1d',
-    ('D4', 'fwd'): 'k_up_c1v<8, false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 1>', ('D4', 'bwd_w'): 'k_wgrad_c1d',
+    ('D4', 'fwd'): 'k_up_c1m<false>', ('D4', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 1>', ('D4', 'bwd_w'): 'k_wgrad_c1d',
 }
 # the chunked schedules (batch-norm models) launch per chunk: same kernel families at 200 / 56
 # frames, smaller tiles where the grid would not fill the chip
@@ -136,6 +136,9 @@ def dispatched(kind, role, ci, co, fn):
 def check_kernel_name(layer, role, n, name):
     if n == 256:
         assert name == KERNELS_256[(layer, role)], (layer, role, n, name)
+    elif FAMILY[(layer, role)] == 'k_up_c1m' and n < 128:
+        # (one workgroup per frame: batches under 128 frames keep the finer-grained VALU kernel)
+        assert name.split('<')[0] == 'k_up_c1v', (layer, role, n, name)
     else:
         assert name.split('<')[0] == FAMILY[(layer, role)], (layer, role, n, name)
 
@@ -317,7 +320,7 @@ def test_fused_last_layer_loss_at_bench_sizes(n):
         kind, 'fwd', geom[1], geom[4],
         lambda: _hip.convT2d_fwd_sqerr(x.to(DEV), w.to(DEV), b.to(DEV), target.to(DEV), None, geom,
                                        _hip.ACT_SIGMOID, SLOPE, False))
-    assert xh is None and name == 'k_up_c1v<8, true>'
+    assert xh is None and name == ('k_up_c1m<true>' if n >= 128 else 'k_up_c1v<8, true>')
     close(part.sum(dim=1), s32, s64, name='frame sums N=%d' % n)
     close(dpre, d32, d64, name='dpre N=%d' % n)
 
