@@ -413,13 +413,16 @@ class ConcatSessionsGenerator(SyntheticSessionsGenerator):
                  paths_list=None, device='cuda', as_numpy=False, batch_load=True, rng_seed=0,
                  trial_splits=None, train_frac=1.0, placement='host_u8', n_sessions_per_batch=1,
                  keep_in_memory=True):
-        if as_numpy:
-            raise NotImplementedError('as_numpy generators are outside the training path')
         if isinstance(ids_list, dict):
             ids_list = [ids_list]
         n = len(ids_list)
         self.ids = ids_list
         self.as_numpy, self.batch_load = as_numpy, batch_load
+        # host path: trials go through SingleSessionDatasetBatchedLoad.__getitem__ (float32 / 255 on
+        # the host, transforms applied) as in the reference, instead of the pinned-uint8 feed --
+        # for generators that hand out numpy arrays (as_numpy, ref :251-263,625-628) and for
+        # sessions with an image transform
+        self._host_path = bool(as_numpy)
         self.signals = signals_list if signals_list is not None else [['images']] * n
         self.transforms = transforms_list if transforms_list is not None else \
             [[None] * len(sig) for sig in self.signals]
@@ -430,7 +433,9 @@ class ConcatSessionsGenerator(SyntheticSessionsGenerator):
                                                    self.paths):
             if transforms is not None and 'images' in signals and \
                     transforms[list(signals).index('images')] is not None:
-                raise NotImplementedError('image transforms are not supported on the uint8 feed')
+                # a transform works on the float frames (ref :315-317): such sessions -- like
+                # as_numpy generators -- are served through the host path below
+                self._host_path = True
             datasets.append(SingleSessionDatasetBatchedLoad(
                 data_dir, lab=ids['lab'], expt=ids['expt'], animal=ids['animal'],
                 session=ids['session'], signals=signals, transforms=transforms, paths=paths,
@@ -498,6 +503,23 @@ class ConcatSessionsGenerator(SyntheticSessionsGenerator):
     def _extra_signals(self, sample, sess, trial):
         for signal, trials in self._extra[sess].items():
             sample[signal] = trials[trial][None]
+
+    def _sample(self, sess, trial, dtype):
+        if not self._host_path:
+            return super()._sample(sess, trial, dtype)
+        host = self.datasets[sess][int(trial)]          # signals as float32 host tensors
+        sample = OrderedDict()
+        for signal, value in host.items():
+            if signal == 'batch_idx':
+                continue
+            if self.as_numpy:
+                # the reference's form: a list over the loader's batch dimension of 1
+                sample[signal] = [value.cpu().detach().numpy() if torch.is_tensor(value)
+                                  else np.asarray(value)]
+            else:
+                sample[signal] = value[None].to(self.device)
+        sample['batch_idx'] = torch.tensor([trial])
+        return sample
 
     def __str__(self):
         out = 'Generator contains %i SingleSessionDatasetBatchedLoad objects:\n' % self.n_datasets

@@ -81,33 +81,31 @@ class Logger(object):
 
 
 class EarlyStopping(object):
-    """Stop when the validation loss has not improved for `patience` checks (ref :173-241)."""
+    """Patience-based stopping rule behind ``hparams['enable_early_stop']`` (behaviour of reference
+    training.py:173-241, re-stated): a validation check that does not undercut the best loss seen
+    so far by more than ``delta`` is a strike; ``patience`` strikes in a row -- counted only once
+    ``min_epochs`` epochs have passed -- raise ``should_stop``, which ``fit`` polls after every
+    epoch.  The attributes ``fit`` and the reference's callers read keep their names
+    (``best_loss``, ``best_epoch``, ``counter``, ``stopped_epoch``, ``should_stop``)."""
+
+    _REPORT = ('\n== early stopping criteria met; exiting train loop ==\n'
+               'training epochs: %d\nend cost: %04f\nbest epoch: %i\nbest cost: %04f\n')
 
     def __init__(self, patience=10, min_epochs=10, delta=0):
-        self.patience = patience
-        self.min_epochs = min_epochs
-        self.delta = delta
-        self.counter = 0
-        self.best_epoch = 0
-        self.best_loss = np.inf
+        self.patience, self.min_epochs, self.delta = patience, min_epochs, delta
+        self.best_loss, self.best_epoch = np.inf, 0
+        self.counter = 0                 # strikes since the last improvement
         self.stopped_epoch = 0
         self.should_stop = False
 
     def on_val_check(self, epoch, curr_loss):
-        if curr_loss < self.best_loss - self.delta:
-            self.best_loss = curr_loss
-            self.best_epoch = epoch
-            self.counter = 0
-        else:
-            self.counter += 1
-        if epoch > self.min_epochs and self.counter >= self.patience:
-            print('\n== early stopping criteria met; exiting train loop ==')
-            print('training epochs: %d' % epoch)
-            print('end cost: %04f' % curr_loss)
-            print('best epoch: %i' % self.best_epoch)
-            print('best cost: %04f\n' % self.best_loss)
-            self.stopped_epoch = epoch
-            self.should_stop = True
+        improved = curr_loss < self.best_loss - self.delta
+        self.counter = 0 if improved else self.counter + 1
+        if improved:
+            self.best_loss, self.best_epoch = curr_loss, epoch
+        if self.counter >= self.patience and epoch > self.min_epochs:
+            print(self._REPORT % (epoch, curr_loss, self.best_epoch, self.best_loss))
+            self.stopped_epoch, self.should_stop = epoch, True
 
 
 def _snapshot(model, hparams):

@@ -1,6 +1,5 @@
 """Module/model templates; mirror of the reference ``behavenet/models/base.py``."""
 
-import math
 
 import torch
 from torch import nn

@@ -484,7 +484,83 @@ def generator_fixture():
     print('wrote generator.json')
 
 
+def fitting_utils_fixture():
+    """Paths and experiment bookkeeping as the REFERENCE's own behavenet.fitting.utils computes them
+    (not restated known answers): the session tree of tests/test_fitting_utils.py is built with the
+    reference's export_session_info_to_csv, then get_session_dir / get_expt_dir / get_model_params /
+    find_session_dirs / experiment_exists (over meta_tags.pkl files the reference's test-tube
+    logger would have written) are recorded, paths relative to the tree."""
+    import pickle
+    import behavenet.fitting.utils as ru
+    from tests.test_fitting_utils import IDS, MULTI
+    root = tempfile.mkdtemp()
+    for ids in IDS:
+        os.makedirs(os.path.join(root, ids['lab'], ids['expt'], ids['animal'], ids['session']))
+    for rel_, idxs in MULTI.items():
+        ru.export_session_info_to_csv(os.path.join(root, rel_), [IDS[i] for i in idxs])
+
+    def rel(path):
+        return os.path.relpath(path, root)
+
+    def norm_ids(lst):
+        return sorted('/'.join(str(d[k]) for k in ('lab', 'expt', 'animal', 'session')) for d in lst)
+    out = {'session_dir': [], 'expt_dir': [], 'model_params': [], 'find_session_dirs': [],
+           'experiment_exists': []}
+    for lab, expt, animal, session, multi in [
+            ('lab0', 'all', '', '', None), ('lab0', 'expt0', 'all', '', None),
+            ('lab0', 'expt0', 'animal0', 'all', None), ('lab0', 'expt0', 'animal0', 'session-00', None),
+            ('lab1', 'expt0', 'animal0', 'all', None), ('lab0', 'expt0', 'animal0', 'all', 1)]:
+        hp = {'data_dir': root, 'save_dir': root, 'sessions_csv': '', 'lab': lab, 'expt': expt,
+              'animal': animal, 'session': session}
+        if multi is not None:
+            hp['multisession'] = multi
+        d, single = ru.get_session_dir(dict(hp), session_source='save')
+        out['session_dir'].append({'hparams': {k: v for k, v in hp.items() if k not in ('data_dir', 'save_dir')},
+                                   'dir': rel(d), 'sessions': norm_ids(single)})
+    base = {'data_dir': root, 'save_dir': root, 'lab': 'lab0', 'expt': 'expt0', 'animal': 'animal0',
+            'session': 'session-00', 'experiment_name': 'grid', 'model_type': 'conv',
+            'session_dir': os.path.join(root, 'lab0', 'expt0', 'animal0', 'session-00'),
+            'rng_seed_data': 0, 'trial_splits': '8;1;1;0', 'train_frac': 1.0, 'rng_seed_model': 0,
+            'fit_sess_io_layers': False, 'learning_rate': 1e-4, 'l2_reg': 0.0,
+            'conditional_encoder': False, 'msp.alpha': 0.1, 'vae.beta': 2.0,
+            'vae.beta_anneal_epochs': 5, 'beta_tcvae.beta': 3.0, 'beta_tcvae.beta_anneal_epochs': 4,
+            'ps_vae.alpha': 1000, 'ps_vae.beta': 5, 'ps_vae.anneal_epochs': 100,
+            'ps_vae.delta': 50, 'n_background': 3, 'n_sessions_per_batch': 2}
+    for model_class, n_lat in (('ae', 8), ('vae', 10), ('beta-tcvae', 10), ('cond-vae', 8), ('cond-ae', 8),
+                               ('cond-ae-msp', 8), ('ps-vae', 10), ('msps-vae', 11)):
+        hp = dict(base, model_class=model_class, n_ae_latents=n_lat)
+        out['expt_dir'].append({'model_class': model_class, 'n_ae_latents': n_lat,
+                                'dir': rel(ru.get_expt_dir(dict(hp)))})
+        out['model_params'].append({'model_class': model_class, 'n_ae_latents': n_lat,
+                                    'params': jsonable(ru.get_model_params(dict(hp)))})
+    dirs, ids = ru.find_session_dirs(dict(IDS[0], save_dir=root))
+    out['find_session_dirs'] = {'dirs': sorted(rel(d) for d in dirs),
+                                'n_single': sum(i['multisession'] is None for i in ids)}
+    # experiment_exists: three finished grid points on disk, probed with matching / new hparams
+    hp = dict(base, model_class='ae', n_ae_latents=8)
+    expt_dir = ru.get_expt_dir(dict(hp))
+    hp['expt_dir'] = expt_dir
+    grid = [dict(hp, learning_rate=lr, l2_reg=l2) for lr, l2 in ((1e-4, 0.0), (1e-3, 0.0), (1e-4, 1e-5))]
+    for v, g in enumerate(grid):
+        vdir = os.path.join(expt_dir, 'version_%i' % v)
+        os.makedirs(vdir)
+        with open(os.path.join(vdir, 'meta_tags.pkl'), 'wb') as f:
+            pickle.dump(dict(ru.get_model_params(dict(g)), training_completed=(v != 1)), f)
+    for lr, l2 in ((1e-4, 0.0), (1e-3, 0.0), (1e-4, 1e-5), (5e-4, 0.0)):
+        probe = dict(hp, learning_rate=lr, l2_reg=l2)
+        exists, version = ru.experiment_exists(dict(probe), which_version=True)
+        out['experiment_exists'].append({'learning_rate': lr, 'l2_reg': l2, 'exists': bool(exists),
+                                         'version': None if version is None else int(version)})
+    out['base_hparams'] = {k: v for k, v in base.items() if k not in ('data_dir', 'save_dir', 'session_dir')}
+    with open(os.path.join(HERE, 'fitting_utils.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('wrote fitting_utils.json')
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'fitting_utils':
+        fitting_utils_fixture()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'fit':
         fit_fixture()
         sys.exit(0)

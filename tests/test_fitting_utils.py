@@ -292,3 +292,51 @@ def test_make_one_hot_2d():
     assert out[0, 0, 56, 64] == 1 and out[0, 1, 102, 34] == 1
     out = MakeOneHot2D(8, 8)(np.array([[np.nan, 100., -3., 2.4]]))     # nan / clip / round
     assert out[0, 0, 0, 0] == 1 and out[0, 1, 2, 7] == 1
+
+
+def test_paths_and_bookkeeping_match_the_reference_module(tree):
+    """tests/golden/fitting_utils.json holds what the REFERENCE's behavenet.fitting.utils returned
+    (tests/golden/make_golden.py fitting_utils, run against /root/reference) on this same session
+    tree: get_session_dir, get_expt_dir, get_model_params, find_session_dirs and experiment_exists
+    over meta_tags.pkl files -- the functions here must return the same."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden',
+                           'fitting_utils.json')) as f:
+        want = json.load(f)
+
+    def rel(path):
+        return os.path.relpath(path, tree)
+
+    def norm_ids(lst):
+        return sorted('/'.join(str(d[k]) for k in ('lab', 'expt', 'animal', 'session')) for d in lst)
+    for case in want['session_dir']:
+        hp = dict(case['hparams'], data_dir=tree, save_dir=tree)
+        d, single = utils.get_session_dir(hp, session_source='save')
+        assert rel(d) == case['dir'] and norm_ids(single) == case['sessions'], case
+    base = dict(want['base_hparams'], data_dir=tree, save_dir=tree,
+                session_dir=os.path.join(tree, 'lab0', 'expt0', 'animal0', 'session-00'))
+    for e, m in zip(want['expt_dir'], want['model_params']):
+        hp = dict(base, model_class=e['model_class'], n_ae_latents=e['n_ae_latents'])
+        assert rel(utils.get_expt_dir(dict(hp))) == e['dir']
+        got = utils.get_model_params(dict(hp))
+        assert set(got) == set(m['params']), (e['model_class'], set(got) ^ set(m['params']))
+        for k, v in m['params'].items():
+            assert got[k] == v, (e['model_class'], k)
+    dirs, ids = utils.find_session_dirs(dict(IDS[0], save_dir=tree))
+    assert sorted(rel(d) for d in dirs) == want['find_session_dirs']['dirs']
+    assert sum(i['multisession'] is None for i in ids) == want['find_session_dirs']['n_single']
+    # experiment_exists over the same three meta_tags.pkl files
+    hp = dict(base, model_class='ae', n_ae_latents=8)
+    expt_dir = utils.get_expt_dir(dict(hp))
+    hp['expt_dir'] = expt_dir
+    for v, (lr, l2) in enumerate(((1e-4, 0.0), (1e-3, 0.0), (1e-4, 1e-5))):
+        vdir = os.path.join(expt_dir, 'version_%i' % v)
+        os.makedirs(vdir)
+        with open(os.path.join(vdir, 'meta_tags.pkl'), 'wb') as f:
+            pickle.dump(dict(utils.get_model_params(dict(hp, learning_rate=lr, l2_reg=l2)),
+                             training_completed=(v != 1)), f)
+    for case in want['experiment_exists']:
+        probe = dict(hp, learning_rate=case['learning_rate'], l2_reg=case['l2_reg'])
+        exists, version = utils.experiment_exists(dict(probe), which_version=True)
+        assert bool(exists) == case['exists'], case
+        assert (None if version is None else int(version)) == case['version'], case
