@@ -164,6 +164,9 @@ _ws_cache = {}
 
 def _workspace(op, geom, device):
     """(pointer, nbytes) of the grow-only scratch arena of `device` sized for this call."""
+    if torch.device(device).type != 'cuda':
+        raise HipLibraryError(
+            'expected tensors on the GPU, got device %s (the HIP path has no CPU fallback)' % device)
     nbytes = load().bn_conv_ws_bytes(op, *geom)
     if nbytes == 0:
         return None, 0

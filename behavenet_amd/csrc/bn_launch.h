@@ -88,3 +88,14 @@ int bn_launch_dkl_fwd(const float* z, const float* mu, const float* lv, float* o
 int bn_launch_dkl_bwd(const float* z, const float* mu, const float* lv, const float* log_qz,
                       const float* lse, const float* g3, float* dz, float* dmu, float* dlv, int N,
                       int D, hipStream_t st);
+
+// conv_pad.hip: zero-padded copies for geometries off the fast paths, stride-5 1x1 maps as a GEMM
+int bn_launch_pad2d(const float* src, float* dst, size_t planes, int H, int W, int Hp, int Wp,
+                    int oh, int ow, hipStream_t st);
+int bn_launch_crop2d(const float* src, float* dst, size_t planes, int H, int W, int Hp, int Wp,
+                     int oh, int ow, const float* dact_src, int dact, float slope, hipStream_t st);
+bool bn_s5_down_small_ok(const BnGeom& g);
+size_t bn_s5_down_small_ws_bytes(const BnGeom& g);
+int bn_launch_s5_down_small(const float* big, const float* w, const float* bias, float* out,
+                          const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                          void* ws, size_t ws_bytes, hipStream_t st);

@@ -194,6 +194,73 @@ static inline bool ws_ok(const BnFastPlan& p, void* ws, size_t ws_bytes) {
     return p.ws_bytes == 0 || (ws != nullptr && ws_bytes >= p.ws_bytes);
 }
 
+// ---- zero-padded detour for 5x5 stride-2 layers whose small map is no power of two (conv_pad.hip)
+struct PadPlan {
+    bool ok;
+    BnGeom gp;             // the padded geometry the fast kernel runs on
+    BnFastPlan inner;
+    size_t big_bytes, small_bytes, inner_ws;
+    bool edge;             // inner = one of the single-channel edge kernels (own launchers)
+    int oh, ow;            // where the big tensor sits inside its padded copy
+    char name[96];
+};
+static inline int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// role: 0 gather-down, 1 gather-up, 2 weight gradient
+static PadPlan pad_plan(int role, const BnGeom& g) {
+    PadPlan p;
+    p.ok = false;
+    p.edge = false;
+    if (force_generic() || g.R != 5 || g.S != 5 || g.stride != 2) return p;
+    // first tap 1 or 2 pixels outside the frame (TF-"same" padding of 3 or 4 in total); the big
+    // tensor sits (pt - 1, pl - 1) inside its padded copy, which is then a pt = pl = 1 layer
+    if (g.pt < 1 || g.pt > 2 || g.pl < 1 || g.pl > 2) return p;
+    const int oh = g.pt - 1, ow = g.pl - 1;
+    p.oh = oh; p.ow = ow;
+    if (g.Cb <= 2) {
+        // single- / two-channel frames (enc.conv0, dec.convT4): the edge kernels want 64-column
+        // small maps and row counts in multiples of 16
+        if (g.Ws > 64 || g.Cs > 32) return p;
+        const int hs = (g.Hs + 15) / 16 * 16;
+        if (hs == g.Hs && g.Ws == 64 && g.Hb == 2 * g.Hs && g.Wb == 128 && !oh && !ow) return p;
+        if (2 * hs < g.Hb + oh || 128 < g.Wb + ow) return p;
+        p.gp = g;
+        p.gp.Hs = hs; p.gp.Ws = 64; p.gp.Hb = 2 * hs; p.gp.Wb = 128; p.gp.pt = p.gp.pl = 1;
+        p.inner = role == 0 ? bn_edge_down_plan(p.gp) : role == 1 ? bn_edge_up_plan(p.gp)
+                                                                  : bn_edge_wgrad_plan(p.gp);
+        if (!p.inner.supported) return p;
+        p.edge = true;
+    } else {
+        // next power of two; maps the specialised kernels do not take at that size (4x4) once or
+        // twice more (8x8 small maps are the smallest every family covers)
+        int hs = next_pow2(g.Hs), wsm = next_pow2(g.Ws);
+        if (hs == g.Hs && wsm == g.Ws && g.Hb == 2 * g.Hs && g.Wb == 2 * g.Ws && !oh && !ow) { hs *= 2; wsm *= 2; }
+        bool found = false;
+        // as measured first, then square (several families take square maps only), then larger
+        for (int grow = 0; grow < 4 && !found; ++grow) {
+            if (grow == 1) { if (hs == wsm) continue; hs = wsm = (hs > wsm ? hs : wsm); }
+            if (grow >= 2) { hs *= 2; wsm *= 2; }
+            if (2 * hs < g.Hb + oh || 2 * wsm < g.Wb + ow) continue;
+            p.gp = g;
+            p.gp.Hs = hs; p.gp.Ws = wsm; p.gp.Hb = 2 * hs; p.gp.Wb = 2 * wsm; p.gp.pt = p.gp.pl = 1;
+            if ((size_t)g.N * g.Cb * p.gp.Hb * p.gp.Wb * 4 >= 0x7fffffffull) break;
+            if ((size_t)g.N * g.Cs * p.gp.Hs * p.gp.Ws * 4 >= 0x7fffffffull) break;
+            p.inner = role == 0 ? bn_fast_down_plan(p.gp) : role == 1 ? bn_fast_up_plan(p.gp)
+                                                                      : bn_fast_wgrad_plan(p.gp);
+            found = p.inner.supported;
+        }
+        if (!found) return p;
+    }
+    if ((size_t)g.N * g.Cb * p.gp.Hb * p.gp.Wb * 4 >= 0x7fffffffull) return p;
+    p.big_bytes = align256((size_t)g.N * g.Cb * p.gp.Hb * p.gp.Wb * 4);
+    p.small_bytes = align256((size_t)g.N * g.Cs * p.gp.Hs * p.gp.Ws * 4);
+    p.inner_ws = p.inner.ws_bytes;
+    snprintf(p.name, sizeof(p.name), "%s on zero-padded %dx%d", p.inner.kernel_name, p.gp.Hs, p.gp.Ws);
+    p.ok = true;
+    return p;
+}
+static inline size_t pad_ws_bytes(const PadPlan& p) { return p.big_bytes + p.small_bytes + p.inner_ws; }
+
 static int run_down(int family, const float* big, const float* w, const float* bias, float* out,
                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                     void* ws, size_t ws_bytes, hipStream_t st) {
@@ -217,6 +284,29 @@ static int run_down(int family, const float* big, const float* w, const float* b
     }
     BnFastPlan plan = bn_fast_down_plan(g);
     if (generic) plan.supported = false;
+    if (!generic && !plan.supported && bn_s5_down_small_ok(g)) {
+        BnProfScope prof(family, g.Cb, g.Cs, "k_im2col_s5 + k_gemm_mfma", st);
+        return bn_launch_s5_down_small(big, w, bias, out, dact_src, g, act, dact, slope, ws, ws_bytes, st);
+    }
+    if (!generic && !plan.supported) {
+        const PadPlan pp = pad_plan(0, g);
+        // (the edge kernel is instantiated for plain / LeakyReLU epilogues)
+        if (pp.ok && !(pp.edge && act != BN_ACT_NONE && act != BN_ACT_LRELU)) {
+            if (!ws || ws_bytes < pad_ws_bytes(pp)) return BN_E_WORKSPACE;
+            BnProfScope prof(family, g.Cb, g.Cs, pp.name, st);
+            float* bigp = (float*)ws;
+            float* outp = (float*)((char*)ws + pp.big_bytes);
+            void* iws = (char*)ws + pp.big_bytes + pp.small_bytes;
+            int rc = bn_launch_pad2d(big, bigp, (size_t)g.N * g.Cb, g.Hb, g.Wb, pp.gp.Hb, pp.gp.Wb, pp.oh, pp.ow, st);
+            if (rc) return rc;
+            rc = pp.edge ? bn_launch_edge_down(bigp, w, bias, outp, nullptr, pp.gp, act, BN_ACT_NONE, slope, st)
+                         : bn_launch_down_fast(pp.inner, bigp, w, bias, outp, nullptr, pp.gp, act, BN_ACT_NONE,
+                                               slope, iws, st);
+            if (rc) return rc;
+            return bn_launch_crop2d(outp, out, (size_t)g.N * g.Cs, g.Hs, g.Ws, pp.gp.Hs, pp.gp.Ws, 0, 0,
+                                    dact_src, dact, slope, st);
+        }
+    }
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_down_generic", st);
     if (plan.supported) {
         if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
@@ -250,6 +340,24 @@ static int run_up(int family, const float* small, const float* w, const float* b
     }
     BnFastPlan plan = bn_fast_up_plan(g);
     if (generic) plan.supported = false;
+    if (!generic && !plan.supported) {
+        const PadPlan pp = pad_plan(1, g);
+        if (pp.ok) {
+            if (!ws || ws_bytes < pad_ws_bytes(pp)) return BN_E_WORKSPACE;
+            BnProfScope prof(family, g.Cs, g.Cb, pp.name, st);
+            float* outp = (float*)ws;
+            float* smallp = (float*)((char*)ws + pp.big_bytes);
+            void* iws = (char*)ws + pp.big_bytes + pp.small_bytes;
+            int rc = bn_launch_pad2d(small, smallp, (size_t)g.N * g.Cs, g.Hs, g.Ws, pp.gp.Hs, pp.gp.Ws, 0, 0, st);
+            if (rc) return rc;
+            rc = pp.edge ? bn_launch_edge_up(smallp, w, bias, outp, pp.gp, act, slope, st)
+                         : bn_launch_up_fast(pp.inner, smallp, w, bias, outp, nullptr, pp.gp, act, BN_ACT_NONE,
+                                             slope, iws, st);
+            if (rc) return rc;
+            return bn_launch_crop2d(outp, out, (size_t)g.N * g.Cb, g.Hb, g.Wb, pp.gp.Hb, pp.gp.Wb, pp.oh,
+                                    pp.ow, dact_src, dact, slope, st);
+        }
+    }
     BnProfScope prof(family, g.Cs, g.Cb, plan.supported ? plan.kernel_name : "k_up_generic", st);
     if (plan.supported) {
         if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
@@ -285,6 +393,25 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
     }
     BnFastPlan plan = bn_fast_wgrad_plan(g);
     if (generic) plan.supported = false;
+    if (!generic && !plan.supported) {
+        const PadPlan pp = pad_plan(2, g);
+        if (pp.ok) {
+            if (!ws || ws_bytes < pad_ws_bytes(pp)) return BN_E_WORKSPACE;
+            BnProfScope prof(family, g.Cb, g.Cs, pp.name, st);
+            float* bigp = (float*)ws;
+            float* smallp = (float*)((char*)ws + pp.big_bytes);
+            void* iws = (char*)ws + pp.big_bytes + pp.small_bytes;
+            int rc = bn_launch_pad2d(big, bigp, (size_t)g.N * g.Cb, g.Hb, g.Wb, pp.gp.Hb, pp.gp.Wb, pp.oh, pp.ow, st);
+            if (rc) return rc;
+            rc = bn_launch_pad2d(small, smallp, (size_t)g.N * g.Cs, g.Hs, g.Ws, pp.gp.Hs, pp.gp.Ws, 0, 0, st);
+            if (rc) return rc;
+            if (pp.edge)
+                return bn_launch_edge_wgrad(pp.inner, smallp, bigp, dw, pp.gp, accumulate, iws, st, db,
+                                            bias_side, bias_done);
+            return bn_launch_wgrad_fast(pp.inner, smallp, bigp, dw, pp.gp, accumulate, iws, st, db, bias_side,
+                                        bias_done);
+        }
+    }
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_wgrad_generic",
                      st);
     if (plan.supported) {
@@ -326,7 +453,17 @@ extern "C" size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, in
             if (!plan.supported) plan = bn_fast_wgrad_plan(g);
             break;
     }
-    const size_t need = plan.supported ? plan.ws_bytes : 0;
+    size_t need = plan.supported ? plan.ws_bytes : 0;
+    if (!plan.supported) {
+        const int role = (op == BN_OP_CONV_FWD || op == BN_OP_CONVT_BWD_D) ? 0 :
+                         (op == BN_OP_CONV_BWD_D || op == BN_OP_CONVT_FWD) ? 1 : 2;
+        if (role == 0 && bn_s5_down_small_ok(g)) {
+            need = bn_s5_down_small_ws_bytes(g);
+        } else {
+            const PadPlan pp = pad_plan(role, g);
+            if (pp.ok) need = pad_ws_bytes(pp) + (role == 2 ? bias_ws : 0);
+        }
+    }
     return need > bias_ws ? need : bias_ws;
 }
 

@@ -72,7 +72,7 @@ class EpsReplay(object):
         t = self.tensors[self.i]
         self.i += 1
         assert t.shape == like.shape
-        return t
+        return t.to(like.dtype)
 
 
 def eps_list(z, prefix):

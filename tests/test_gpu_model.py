@@ -129,25 +129,27 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
             ora.eps_fn = EpsReplay(eps_list(z, 'loss/eps'))
             hip_vaes.set_eps_provider(EpsReplay(eps_list(z, 'loss/eps'), DEV))
         loss_o = ora.loss(data_c, dataset=DS, accumulate_grad=True)
-        loss_h = hip.loss(data_g, dataset=DS, accumulate_grad=True)
+        with record_branches(hip) as rec:
+            loss_h = hip.loss(data_g, dataset=DS, accumulate_grad=True)
     finally:
         hip_vaes.set_eps_provider(None)
     assert sorted(loss_h.keys()) == sorted(loss_o.keys()) == [str(k) for k in z['loss/keys']]
     for k, want in zip([str(k) for k in z['loss/keys']], z['loss/vals']):
         assert loss_h[k] == pytest.approx(loss_o[k], rel=1e-4, abs=1e-7), k
         assert loss_h[k] == pytest.approx(float(want), rel=1e-4, abs=1e-7), k
-    # batch-norm cases: a float64 run of the oracle measures how well-conditioned the gradients
-    # are (ae_cfg1_bn_b210 normalises 10 values per channel in its second chunk: the fp32
-    # reference is ~1e-3 from the exact answer there)
+    # batch-norm cases (ae_cfg1_bn_b210 normalises 10 values per channel in its second chunk): ONE
+    # LeakyReLU output at a tie (|x| ~ 1e-7 of its layer) on the other branch moves every upstream
+    # gradient by ~1e-3, in float64 as much as in fp32 (tools/diag_bn_cond.py) -- the gradient is a
+    # discontinuous function there, not an ill-conditioned one.  So these cases are compared on the
+    # branch pattern the device took: float64 oracle on that pattern, 2e-5 of each tensor's
+    # maximum, and the pattern may differ from the oracle's own at ties only.
     g64 = None
     if meta['extra_hp'].get('ae_batch_norm') and not variational:
         ora64 = seeded_build(ref_cpu.build_model, case_hparams(meta)).double()
         ora64.train()
-        data64 = {k: v.double() for k, v in data_c.items()}
-        with torch.no_grad():
-            ora64(data64['images'][0][:n_fwd], dataset=DS)
-        ora64.zero_grad()
-        ora64.loss(data64, dataset=DS, accumulate_grad=True)
+        with BranchReplay(rec) as br:
+            ora64.loss({k: v.double() for k, v in data_c.items()}, dataset=DS, accumulate_grad=True)
+        br.assert_only_ties()
         g64 = {k: p.grad for k, p in ora64.named_parameters()}
     names = set(k for k, _ in ora.named_parameters())
     for (k, ph), (_, po) in zip(hip.named_parameters(), ora.named_parameters()):
@@ -160,10 +162,10 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
             assert float(po.grad.abs().max()) <= 1e-4 * wscale, k
             continue
         if g64 is not None:
-            close(ph.grad, po.grad, g64[k], name='%s grad %s' % (name, k), cond=True)
             w64 = g64[k].numpy()
-            e_ref = np.abs(po.grad.double().numpy() - w64).max() / max(np.abs(w64).max(), 1e-30)
-            ctol = max(1e-4, 4 * e_ref)
+            err = np.abs(ph.grad.cpu().double().numpy() - w64).max() / max(np.abs(w64).max(), 1e-30)
+            assert err <= 2e-5, '%s grad %s: normalised max err %.3e on the device branches' % (
+                name, k, err)
         else:
             try:
                 close(ph.grad, po.grad, name='%s grad %s' % (name, k))
@@ -540,7 +542,8 @@ def test_mspsvae_vs_oracle_and_golden():
         np.random.seed(11)
         loss_o = ora.loss(datas_c, dataset=sess, accumulate_grad=True)
         np.random.seed(11)
-        loss_h = hip.loss(datas_g, dataset=sess, accumulate_grad=True)
+        with record_branches(hip) as rec:
+            loss_h = hip.loss(datas_g, dataset=sess, accumulate_grad=True)
         keys = [str(k) for k in z['loss/keys']]
         assert sorted(loss_h.keys()) == sorted(loss_o.keys()) == keys
         for k, want in zip(keys, z['loss/vals']):
@@ -560,9 +563,34 @@ def test_mspsvae_vs_oracle_and_golden():
                 assert float((ph.grad.cpu() - po.grad).abs().max()) <= tol, k
                 assert float(po.grad.abs().max()) <= 100 * tol
                 continue
-            close(ph.grad, po.grad, name='mspsvae grad ' + k)
-            assert checksum_close(checksum(ph.grad.cpu().numpy()), z['grad/' + k + '/checksum'],
-                                  1e-4), k
+            try:
+                close(ph.grad, po.grad, name='mspsvae grad ' + k)
+                assert checksum_close(checksum(ph.grad.cpu().numpy()),
+                                      z['grad/' + k + '/checksum'], 1e-4), k
+            except AssertionError:
+                # a LeakyReLU tie on the other branch (tests/branches.py): accept only if all
+                # gradients agree with the float64 oracle on the device's branch pattern and
+                # that pattern differs from the oracle's own at ties only
+                ora64 = seeded_build(ref_cpu.build_model, case_hparams(meta)).double()
+                ora64.train()
+                ora64.curr_epoch = meta['curr_epoch']
+                ora64.eps_fn = EpsReplay([z['loss/eps0']])
+                np.random.seed(11)
+                with BranchReplay(rec) as br:
+                    ora64.loss([{kk: v.double() for kk, v in d.items()} for d in datas_c],
+                               dataset=sess, accumulate_grad=True)
+                br.assert_only_ties()
+                assert len(br.flips) > 0, 'gradient mismatch without a branch difference'
+                for (k2, p2), (_, p64) in zip(hip.named_parameters(), ora64.named_parameters()):
+                    if p64.grad is None or k2 == 'encoding.C.bias':
+                        continue
+                    w = p64.grad.numpy()
+                    err = np.abs(p2.grad.cpu().double().numpy() - w).max() / max(np.abs(w).max(), 1e-30)
+                    # (1e-4, the stated tolerance, not the 2e-5 of the other same-branch
+                    # comparisons: the triplet term's O(delta) summands cancel in the encoder
+                    # gradients, see encoding.C.bias above -- measured 2.9e-5 at conv0.weight)
+                    assert err <= 1e-4, 'mspsvae grad %s: %.3e on the device branches' % (k2, err)
+                break
 
         # one session (validation): no triplet term, key reported as 0, no gradient side effects
         hip_vaes.set_eps_provider(EpsReplay([z['loss1/eps0']], DEV))

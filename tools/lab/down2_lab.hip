@@ -71,6 +71,17 @@ int main(int argc, char** argv) {
     unsigned long long t0 = ~0ull, r0 = ~0ull, t1 = 0, r1 = 0;
     for (int b = 0; b < nwg; ++b) { auto* p = &tr[(size_t)b * D2_TRACE_SLOTS]; t0 = std::min(t0, p[0]); r0 = std::min(r0, p[1]); t1 = std::max(t1, p[14]); r1 = std::max(r1, p[15]); }
     printf("kernel span: %llu clk, %llu real(100MHz) -> %.3f GHz, %.1f us\n", t1 - t0, r1 - r0, (double)(t1 - t0) / ((double)(r1 - r0) * 10.0), (r1 - r0) / 100.0);
+    {   // shader clock seen by every workgroup that left marks: s_memtime ticks per s_memrealtime tick (100 MHz)
+        std::vector<double> ghz;
+        for (int b = 0; b < 8192; ++b) {
+            auto* q = &tr[(size_t)b * D2_TRACE_SLOTS];
+            if (q[0] && q[14] > q[0] && q[15] > q[1]) ghz.push_back((double)(q[14] - q[0]) / ((double)(q[15] - q[1]) * 10.0));
+        }
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty())
+            printf("shader clock over the lifetime of %zu workgroups (s_memtime / s_memrealtime): min %.3f  median %.3f  max %.3f GHz\n",
+                   ghz.size(), ghz[0], ghz[ghz.size() / 2], ghz.back());
+    }
     for (int b = 0; b < nwg; b += 37) {
         auto* p = &tr[(size_t)b * D2_TRACE_SLOTS];
         printf("wg %3d hwid %08llx start %7llu prologue %6llu", b, p[2], p[0] - t0, p[3] - p[0]);
