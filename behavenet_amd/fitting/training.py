@@ -42,7 +42,14 @@ class Logger(object):
         if n_datasets > 1:
             self.metrics_by_dataset = [{k: {} for k in kinds} for _ in range(n_datasets)]
 
+    def flush(self):
+        """Add up the loss dicts that were handed over unresolved (graph_step.LazyLoss)."""
+        pending, self._pending = getattr(self, '_pending', []), []
+        for dtype, lazy, dataset in pending:
+            self._add(dtype, lazy.resolve(), dataset)
+
     def reset_metrics(self, dtype):
+        self.flush()
         for key in self.metrics[dtype]:
             self.metrics[dtype][key] = 0
         for per in self.metrics_by_dataset:
@@ -50,6 +57,18 @@ class Logger(object):
                 per[dtype][key] = 0
 
     def update_metrics(self, dtype, loss_dict, dataset=None):
+        if hasattr(loss_dict, 'resolve'):
+            # values still on their way from the device: added up, in order, when something
+            # reads the metrics (or a few steps later) -- the host does not wait per step
+            self._pending = getattr(self, '_pending', []) + [(dtype, loss_dict, dataset)]
+            if len(self._pending) > 4:
+                head, self._pending = self._pending[0], self._pending[1:]
+                self._add(head[0], head[1].resolve(), head[2])
+            return
+        self.flush()
+        self._add(dtype, loss_dict, dataset)
+
+    def _add(self, dtype, loss_dict, dataset):
         for key, val in {**loss_dict, 'batches': 1}.items():
             self.metrics[dtype][key] = self.metrics[dtype].get(key, 0) + val
             if isinstance(dataset, int) and self.n_datasets > 1:
@@ -60,6 +79,7 @@ class Logger(object):
             self, dtype, epoch, batch, dataset, trial, best_epoch=None, by_dataset=False):
         if dtype not in _PREFIX:
             raise ValueError("%s is an invalid data type" % dtype)
+        self.flush()
         prefix = _PREFIX[dtype]
         row = {'epoch': epoch, 'batch': batch, 'trial': trial}
         if dtype == 'val':
@@ -77,6 +97,7 @@ class Logger(object):
         return row
 
     def get_loss(self, dtype):
+        self.flush()
         return self.metrics[dtype]['loss'] / self.metrics[dtype]['batches']
 
 
@@ -130,6 +151,7 @@ def _save_checkpoint(model, path, is_main):
 def _merge_rank_metrics(logger, dtype):
     """'trial' mode: every rank logged the trials it trained on; give every rank the totals."""
     import torch.distributed as dist
+    logger.flush()
     mine = [logger.metrics[dtype]] + [per[dtype] for per in logger.metrics_by_dataset]
     everyone = [None] * dist.get_world_size()
     dist.all_gather_object(everyone, mine)
@@ -185,6 +207,15 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
             can_skip = False
         if can_skip and hasattr(data_generator, 'lookahead'):
             data_generator.lookahead = world - 1
+
+    # the step as a HIP graph (fitting/graph_step.py): per input signature, after two eager steps;
+    # opt-in with hparams['hip_graph'] / BN_GRAPH=1 (the step is GPU-bound on an idle host).
+    # Needs the flat gradient arena (the recorded kernels write into fixed addresses).
+    loss_fn = model.loss
+    if flat_g is not None and flat_g.is_cuda:
+        from behavenet_amd.fitting import graph_step
+        if hparams.get('hip_graph', graph_step.enabled_by_default()):
+            loss_fn = graph_step.GraphedLoss(model)
 
     logger = Logger(n_datasets=data_generator.n_datasets)
     early_stop = None
@@ -260,7 +291,7 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
                 stepping = data is not None
                 n_in_step = 1
             if data is not None:
-                loss_dict = model.loss(data, dataset=dataset, accumulate_grad=True)
+                loss_dict = loss_fn(data, dataset=dataset, accumulate_grad=True)
                 logger.update_metrics('train', loss_dict, dataset=dataset)
             if stepping and i_epoch > 0:
                 if flat_g is not None:
@@ -293,7 +324,7 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
                 model.eval()
                 for _ in range(data_generator.n_tot_batches['val']):
                     data, dataset = data_generator.next_batch('val')
-                    loss_dict = model.loss(data, dataset=dataset, accumulate_grad=False)
+                    loss_dict = loss_fn(data, dataset=dataset, accumulate_grad=False)
                     logger.update_metrics('val', loss_dict, dataset=dataset)
 
                 if logger.get_loss('val') < best_val_loss:

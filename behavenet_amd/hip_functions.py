@@ -72,14 +72,16 @@ def reset_grad_ready():
 
 def _note_use(params, needed):
     """Called from Function.forward: `needed` is false under no_grad (no backward will come)."""
-    if _grad_ready_cb is not None and needed:
+    if _grad_ready_cb is not None and needed and not _capturing:
         for p in params:
             if p is not None:
                 _param_uses[id(p)] = _param_uses.get(id(p), 0) + 1
 
 
 def _report_ready(params):
-    if _grad_ready_cb is None or not _single_pass:
+    # (a step recorded into a HIP graph reports nothing: its gradients are exchanged after the
+    # replay, by the reducer's flat path)
+    if _grad_ready_cb is None or not _single_pass or _capturing:
         return
     for p in params:
         if p is None:
@@ -141,6 +143,34 @@ def backward_chunks(chunk_losses, streams=None, single_pass=False):
         _use_side_stream = saved_side
 
 
+# Graph capture (fitting/graph_step.py): while a step is being recorded into a HIP graph nothing
+# may wait on the host.  `Readback` then only remembers its device tensor (whose address is fixed
+# inside the graph's memory pool) and `finish_loss` returns a `DeferredLoss` instead of the loss
+# dict: after every replay the recorded tensors are read back and the same host function turns
+# them into the dict.
+_capturing = False
+
+
+def capturing():
+    return _capturing
+
+
+class DeferredLoss(object):
+    """What ``model.loss`` returns while a step is being captured: the device tensors its
+    read-backs would have copied and the host function that turns their values into the dict."""
+
+    def __init__(self, tensors, fn):
+        self.tensors, self.fn = tensors, fn
+
+
+def finish_loss(readbacks, fn):
+    """``fn(*arrays)`` -> loss dict, with arrays = the values of `readbacks` (None entries stay
+    None).  Eager: waits for the read-backs and calls `fn`; under capture: defers both."""
+    if _capturing:
+        return DeferredLoss([None if rb is None else rb.tensor for rb in readbacks], fn)
+    return fn(*[None if rb is None else rb.numpy() for rb in readbacks])
+
+
 class Readback(object):
     """Asynchronous device -> host copy of a small tensor through a pooled pinned buffer.
 
@@ -154,6 +184,9 @@ class Readback(object):
 
     def __init__(self, t):
         t = t.detach()
+        self.tensor = t
+        if _capturing:
+            return
         self._key = (t.dtype, tuple(t.shape))
         free = Readback._pool.setdefault(self._key, [])
         self._buf = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
@@ -162,6 +195,10 @@ class Readback(object):
         self._event.record()
 
     def numpy(self):
+        if _capturing:
+            raise RuntimeError('a loss value was asked for while the step is being captured '
+                               'into a HIP graph: route the host tail through finish_loss()')
+        self.tensor = None
         self._event.synchronize()
         out = self._buf.numpy().copy()
         Readback._pool[self._key].append(self._buf)

@@ -19,7 +19,8 @@ from behavenet_amd import _hip
 from behavenet_amd.fitting import distributed as bdist
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ChunkScalars, ConvLayerPlan, FusedPixelLoss, Readback, activation, backward_chunks,
+    ChunkScalars, ConvLayerPlan, FusedPixelLoss, Readback, activation, backward_chunks, capturing,
+    finish_loss,
     chunked_sq_err, conv_stack, conv_stack_bn, conv_stack_sq_err, first_layer_forward,
     join_side_streams, linear, begin_chunks, chunk_stream, max_pool, max_unpool,
     pixel_loss_scales, reserve_device_pools)
@@ -531,6 +532,15 @@ class AE(BaseModel):
 
     _whole_batch = True      # loss() implements the single-pass schedule (see _loss_whole_batch)
 
+    # fitting/graph_step.py: ``loss`` can be recorded into a HIP graph on the single-pass path
+    # (its host tail goes through hip_functions.finish_loss); subclasses with their own ``loss``
+    # opt in one by one
+    graph_capturable = True
+    graph_epoch_dependent = False
+
+    def graph_capturable_for(self, x):
+        return self._whole_batch_ok(x)
+
     def __init__(self, hparams):
         super().__init__()
         self.hparams = hparams
@@ -632,7 +642,10 @@ class AE(BaseModel):
                                 'chunk_sizes': sizes},
                     **fwd_kwargs)
                 chunk_losses = losses.mse_chunks(x, x_hat, m, bounds_l, sizes)
-            totals = bdist.all_reduce_(chunk_losses.detach().clone())
+            # (under graph capture the ranks' chunk terms are added on the host instead: no
+            # collective inside the recorded step)
+            totals = chunk_losses.detach() if capturing() else \
+                bdist.all_reduce_(chunk_losses.detach().clone())
         else:       # more ranks than frames: nothing local, but the collectives still line up
             chunk_losses = None
             totals = bdist.all_reduce_(torch.zeros(len(bounds), device=x.device))
@@ -640,8 +653,14 @@ class AE(BaseModel):
         if accumulate_grad and chunk_losses is not None:
             backward_chunks([chunk_losses], single_pass=True)
         join_side_streams()
-        vals = vals.numpy().astype(np.float64)
-        return {'loss': float(np.sum(vals * np.asarray(sizes, dtype=np.float64)) / batch_size)}
+        host_sum = capturing() and local != bounds
+
+        def to_dict(v):
+            v = v.astype(np.float64)
+            if host_sum:
+                v = np.asarray(bdist.all_reduce_scalars(v.tolist()), dtype=np.float64)
+            return {'loss': float(np.sum(v * np.asarray(sizes, dtype=np.float64)) / batch_size)}
+        return finish_loss([vals], to_dict)
 
     def _chunk_streams_ok(self):
         """Chunks may run on two HIP streams unless a layer accumulates outside the weight-
@@ -787,6 +806,8 @@ class AEMSP(AE):
     ``mse(y, y_hat) + mse(z, y_hat P)`` pushes the label information into the row space of P.
     ``model_class = 'cond-ae-msp'``; conv encoder/decoder only.
     """
+
+    graph_capturable = False
 
     def __init__(self, hparams):
         if hparams['model_type'] == 'linear':

@@ -226,6 +226,8 @@ def _stack_scalars(t):
 class VAE(AE):
     """Variational autoencoder / beta-VAE (ref vaes.py:38-208)."""
 
+    graph_capturable = False      # (loss tail not routed through finish_loss yet)
+
     def __init__(self, hparams):
         if hparams['model_type'] == 'linear':
             raise NotImplementedError
@@ -476,6 +478,8 @@ class ConvAEPSEncoder(ConvAEEncoder):
 
 class PSVAE(AE):
     """Partitioned-subspace VAE (ref vaes.py:506-846)."""
+
+    graph_capturable = False      # (loss tail not routed through finish_loss yet)
 
     def __init__(self, hparams):
         if hparams['model_type'] == 'linear':
