@@ -161,7 +161,8 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
 #define WD_BG (WC_IH * WD_RW / 4)                     // 374 groups of the big tile
 #define WD_BGP ((WD_BG + 63) / 64 * 64)               // whole wave rows: 384
 #define WD_BUF (32 * WD_SP + 4 * WD_BGP)              // floats per stage image
-#define WD_LDS (2 * WD_BUF * 4)
+#define WD_ONES 128                                   // floats of 1.0f behind the two images (BIAS)
+#define WD_LDS ((2 * WD_BUF + WD_ONES) * 4)
 
 __device__ __forceinline__ void wd_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
@@ -190,6 +191,13 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
         const int w = e % WD_BUF;
         if (w < 32 * WD_SP && w / WD_SP >= g.Cs) wsm[e] = 0.f;
     }
+    // Conv2d bias gradient = sum over pixels of the small side: tap column 25 of the MFMA is not a
+    // tap, its lanes read 1.0f as their B operand (a constant region behind the images, the same
+    // immediate offsets as the tap lanes), so accumulator column 25 IS the bias partial -- no
+    // vector instruction in the MFMA stream.  (Measured neutral: 34.7 us with either form.  The
+    // 3 us between this variant (enc.conv0: dy fresh from the non-temporal stores of the kernel
+    // before it) and the other (dec.convT4: 31.2 us) is not the bias arithmetic.)
+    if (BIAS) for (int e = tid; e < WD_ONES; e += ED_THREADS) wsm[2 * WD_BUF + e] = 1.f;
     // DMA descriptors: small rows a = wv + 4k, group = lane; big groups e = lane + 64 (wv + 4k)
     const int svo = (wv * PQ + 4 * lane) * 4;
     int bvo[2], bcls = 0;
@@ -223,7 +231,6 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;
-    float bsum = 0.f;
 
     // operand addresses: tap j = li -> (r, s); pixel (row wv, column 2t + kk)
     const int tap = li < 25 ? li : 0;
@@ -231,6 +238,7 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
     int aq_cur = (li * WD_SP + wv * WC_W + kk) * 4;                              // bytes
     int bq_cur = (32 * WD_SP + (2 * wv + tr) * WD_RW + ts + 2 * kk + 3) * 4;     // column wb + 4, pl = 1
     int aq_oth = aq_cur + WD_BUF * 4, bq_oth = bq_cur + WD_BUF * 4;
+    if (do_bias && li >= 25) bq_cur = bq_oth = 2 * WD_BUF * 4;
     const char* sm = reinterpret_cast<const char*>(wsm);
 
     int st = blockIdx.x;
@@ -248,7 +256,6 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
         for (int t = 0; t < WC_W / 2; ++t) {
             const float av = *reinterpret_cast<const float*>(sm + aq_cur + 8 * t);
             const float bv = *reinterpret_cast<const float*>(sm + bq_cur + 16 * t);
-            if (do_bias) bsum += av;
             acc[t & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t & 1], 0, 0, 0);
             if (t >= 2 && t < 12) { if (more) issue_dma(t - 2, cur ^ 1, nx); }
         }
@@ -257,30 +264,24 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
         tmp = bq_cur; bq_cur = bq_oth; bq_oth = tmp;
     }
 
-    // combine the two accumulators, then the four waves (fixed order): partial [a][tap]
+    // combine the two accumulators, then the four waves (fixed order): partial [a][tap]; column 25
+    // of the bias variant holds the channel sums
     __syncthreads();
     float* red = wsm;    // 4 x 16 x 64 floats
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[(wv * 16 + e) * 64 + lane] = acc[0][e] + acc[1][e];
     __syncthreads();
-    if (wv == 0 && li < 25) {
+    if (wv == 0 && (li < 25 || (do_bias && li == 25))) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const float v = (red[e * 64 + lane] + red[(16 + e) * 64 + lane]) +
                             (red[(32 + e) * 64 + lane] + red[(48 + e) * 64 + lane]);
             const int a = (e & 3) + 8 * (e >> 2) + 4 * kk;
-            if (a < g.Cs)
-                part[((size_t)bch * gridDim.x + blockIdx.x) * (g.Cs * 25) + a * 25 + li] = v;
+            if (a < g.Cs) {
+                if (li < 25) part[((size_t)bch * gridDim.x + blockIdx.x) * (g.Cs * 25) + a * 25 + li] = v;
+                else         bias_part[(size_t)blockIdx.x * g.Cs + a] = v;
+            }
         }
-    }
-    if (do_bias) {
-        bsum += __shfl_xor(bsum, 32, 64);
-        __syncthreads();
-        if (lane < 32) red[wv * 32 + lane] = bsum;
-        __syncthreads();
-        if (tid < 32 && tid < g.Cs)
-            bias_part[(size_t)blockIdx.x * g.Cs + tid] =
-                (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
     }
 }
 
