@@ -94,6 +94,17 @@ int bn_launch_pad2d(const float* src, float* dst, size_t planes, int H, int W, i
                     int oh, int ow, hipStream_t st);
 int bn_launch_crop2d(const float* src, float* dst, size_t planes, int H, int W, int Hp, int Wp,
                      int oh, int ow, const float* dact_src, int dact, float slope, hipStream_t st);
+// spatial tiles with halos (maps larger than the specialised kernels take): one axis of the tiling.
+// Tile k holds source coordinates step * k - v0 + i for i in [0, D); its elements [v0, v0 + V) are
+// the ones it OWNS (every source coordinate is owned by exactly one tile: V == step when T > 1).
+struct BnTileAxis { int T, step, v0, V, D; };
+// src (N, C, H, W) -> dst ((N Th Tw), C, Dh, Dw), zeros outside the map; masked: owned elements only
+int bn_launch_tile_gather(const float* src, float* dst, int N, int C, int H, int W, BnTileAxis th,
+                          BnTileAxis tw, int masked, hipStream_t st);
+// dst (N, C, H, W) <- the owning tile's element, times act'(dact_src) when given
+int bn_launch_tile_scatter(const float* src, float* dst, int N, int C, int H, int W, BnTileAxis th,
+                           BnTileAxis tw, const float* dact_src, int dact, float slope,
+                           hipStream_t st);
 bool bn_s5_down_small_ok(const BnGeom& g);
 size_t bn_s5_down_small_ws_bytes(const BnGeom& g);
 int bn_launch_s5_down_small(const float* big, const float* w, const float* bias, float* out,

@@ -261,6 +261,87 @@ static PadPlan pad_plan(int role, const BnGeom& g) {
 }
 static inline size_t pad_ws_bytes(const PadPlan& p) { return p.big_bytes + p.small_bytes + p.inner_ws; }
 
+// ---- spatial tiles with halos for 5x5 stride-2 layers whose maps exceed what the specialised
+// kernels take (conv_pad.hip, k_tile_gather / k_tile_scatter): frames wider than 128 pixels
+struct TilePlan {
+    bool ok;
+    BnTileAxis sh, sw, bh, bw;   // small / big side, rows / columns
+    int T;                       // tiles per frame
+    int nb;                      // frames per pass (the tiled copies stay below 2 GB each)
+    int Dsh, Dsw;                // small-side tile
+    bool edge;
+    size_t big_bytes, small_bytes, inner_ws;
+    char name[96];
+};
+static BnGeom tile_geom(const BnGeom& g, const TilePlan& p, int frames) {
+    BnGeom gp = g;
+    gp.N = frames * p.T;
+    gp.Hs = p.Dsh; gp.Ws = p.Dsw; gp.Hb = 2 * p.Dsh; gp.Wb = 2 * p.Dsw; gp.pt = gp.pl = 1;
+    return gp;
+}
+static BnFastPlan tile_inner(int role, const TilePlan& p, const BnGeom& gp) {
+    if (p.edge)
+        return role == 0 ? bn_edge_down_plan(gp) : role == 1 ? bn_edge_up_plan(gp) : bn_edge_wgrad_plan(gp);
+    return role == 0 ? bn_fast_down_plan(gp) : role == 1 ? bn_fast_up_plan(gp) : bn_fast_wgrad_plan(gp);
+}
+// one axis: small length Ls, big length Lb, first tap pt outside, tile length S (small side)
+static bool tile_axis(int Ls, int Lb, int pt, int S, bool may_fit, BnTileAxis* sm, BnTileAxis* bg) {
+    if (may_fit && Ls <= S && Lb + pt - 1 <= 2 * S) {
+        *sm = BnTileAxis{1, Ls, 0, Ls, S};
+        *bg = BnTileAxis{1, Lb, pt - 1, Lb, 2 * S};
+        return true;
+    }
+    const int V = S - 2, T = (Ls + V - 1) / V;
+    if (Lb > 2 * V * T) return false;
+    *sm = BnTileAxis{T, V, 1, V, S};
+    *bg = BnTileAxis{T, 2 * V, 1 + pt, 2 * V, 2 * S};
+    return true;
+}
+static TilePlan tile_plan(int role, const BnGeom& g) {
+    TilePlan p;
+    p.ok = false;
+    if (force_generic() || g.R != 5 || g.S != 5 || g.stride != 2) return p;
+    if (g.pt < 1 || g.pt > 2 || g.pl < 1 || g.pl > 2) return p;
+    p.edge = g.Cb <= 2;
+    if (p.edge) {
+        if (g.Cs > 32) return p;
+        const int hs16 = (g.Hs + 15) / 16 * 16;
+        const int Sh = hs16 <= 64 ? hs16 : 64;
+        if (!tile_axis(g.Hs, g.Hb, g.pt, Sh, hs16 <= 64, &p.sh, &p.bh)) return p;
+        if (!tile_axis(g.Ws, g.Wb, g.pl, 64, true, &p.sw, &p.bw)) return p;
+    } else {
+        if (!tile_axis(g.Hs, g.Hb, g.pt, 32, true, &p.sh, &p.bh)) return p;
+        if (!tile_axis(g.Ws, g.Wb, g.pl, 32, true, &p.sw, &p.bw)) return p;
+    }
+    p.T = p.sh.T * p.sw.T;
+    if (p.T == 1) return p;                    // fits: the zero-padded embedding serves it
+    p.Dsh = p.sh.D; p.Dsw = p.sw.D;
+    const size_t big_frame = (size_t)p.T * g.Cb * 4 * p.Dsh * p.Dsw * 4;
+    const size_t small_frame = (size_t)p.T * g.Cs * p.Dsh * p.Dsw * 4;
+    const size_t per = big_frame > small_frame ? big_frame : small_frame;
+    size_t nb = 0x7ff00000ull / per;
+    if (nb < 1) return p;
+    if (nb > (size_t)g.N) nb = g.N;
+    p.nb = (int)nb;
+    const BnGeom gp = tile_geom(g, p, p.nb);
+    const BnFastPlan inner = tile_inner(role, p, gp);
+    if (!inner.supported) return p;
+    p.big_bytes = align256(big_frame * nb);
+    p.small_bytes = align256(small_frame * nb);
+    p.inner_ws = inner.ws_bytes;
+    // (a last, shorter pass may pick another tiling of the same family: size for both)
+    if (g.N % p.nb) {
+        const BnFastPlan last = tile_inner(role, p, tile_geom(g, p, g.N % p.nb));
+        if (!last.supported) return p;
+        if (last.ws_bytes > p.inner_ws) p.inner_ws = last.ws_bytes;
+    }
+    snprintf(p.name, sizeof(p.name), "%s on %dx%d tiles of %dx%d", inner.kernel_name, p.sh.T, p.sw.T,
+             p.Dsh, p.Dsw);
+    p.ok = true;
+    return p;
+}
+static inline size_t tile_ws_bytes(const TilePlan& p) { return p.big_bytes + p.small_bytes + p.inner_ws; }
+
 static int run_down(int family, const float* big, const float* w, const float* bias, float* out,
                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                     void* ws, size_t ws_bytes, hipStream_t st) {
@@ -305,6 +386,32 @@ static int run_down(int family, const float* big, const float* w, const float* b
             if (rc) return rc;
             return bn_launch_crop2d(outp, out, (size_t)g.N * g.Cs, g.Hs, g.Ws, pp.gp.Hs, pp.gp.Ws, 0, 0,
                                     dact_src, dact, slope, st);
+        }
+    }
+    if (!generic && !plan.supported) {
+        const TilePlan tp = tile_plan(0, g);
+        if (tp.ok && !(tp.edge && act != BN_ACT_NONE && act != BN_ACT_LRELU)) {
+            if (!ws || ws_bytes < tile_ws_bytes(tp)) return BN_E_WORKSPACE;
+            BnProfScope prof(family, g.Cb, g.Cs, tp.name, st);
+            float* bigp = (float*)ws;
+            float* outp = (float*)((char*)ws + tp.big_bytes);
+            void* iws = (char*)ws + tp.big_bytes + tp.small_bytes;
+            for (int n0 = 0; n0 < g.N; n0 += tp.nb) {
+                const int nf = g.N - n0 < tp.nb ? g.N - n0 : tp.nb;
+                const BnGeom gp = tile_geom(g, tp, nf);
+                const BnFastPlan inner = tile_inner(0, tp, gp);
+                const size_t ob = (size_t)n0 * g.Cb * g.Hb * g.Wb, os = (size_t)n0 * g.Cs * g.Hs * g.Ws;
+                int rc = bn_launch_tile_gather(big + ob, bigp, nf, g.Cb, g.Hb, g.Wb, tp.bh, tp.bw, 0, st);
+                if (rc) return rc;
+                rc = tp.edge ? bn_launch_edge_down(bigp, w, bias, outp, nullptr, gp, act, BN_ACT_NONE, slope, st)
+                             : bn_launch_down_fast(inner, bigp, w, bias, outp, nullptr, gp, act, BN_ACT_NONE,
+                                                   slope, iws, st);
+                if (rc) return rc;
+                rc = bn_launch_tile_scatter(outp, out + os, nf, g.Cs, g.Hs, g.Ws, tp.sh, tp.sw,
+                                            dact_src ? dact_src + os : nullptr, dact, slope, st);
+                if (rc) return rc;
+            }
+            return 0;
         }
     }
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_down_generic", st);
@@ -356,6 +463,32 @@ static int run_up(int family, const float* small, const float* w, const float* b
             if (rc) return rc;
             return bn_launch_crop2d(outp, out, (size_t)g.N * g.Cb, g.Hb, g.Wb, pp.gp.Hb, pp.gp.Wb, pp.oh,
                                     pp.ow, dact_src, dact, slope, st);
+        }
+    }
+    if (!generic && !plan.supported) {
+        const TilePlan tp = tile_plan(1, g);
+        if (tp.ok) {
+            if (!ws || ws_bytes < tile_ws_bytes(tp)) return BN_E_WORKSPACE;
+            BnProfScope prof(family, g.Cs, g.Cb, tp.name, st);
+            float* outp = (float*)ws;
+            float* smallp = (float*)((char*)ws + tp.big_bytes);
+            void* iws = (char*)ws + tp.big_bytes + tp.small_bytes;
+            for (int n0 = 0; n0 < g.N; n0 += tp.nb) {
+                const int nf = g.N - n0 < tp.nb ? g.N - n0 : tp.nb;
+                const BnGeom gp = tile_geom(g, tp, nf);
+                const BnFastPlan inner = tile_inner(1, tp, gp);
+                const size_t ob = (size_t)n0 * g.Cb * g.Hb * g.Wb, os = (size_t)n0 * g.Cs * g.Hs * g.Ws;
+                int rc = bn_launch_tile_gather(small + os, smallp, nf, g.Cs, g.Hs, g.Ws, tp.sh, tp.sw, 0, st);
+                if (rc) return rc;
+                rc = tp.edge ? bn_launch_edge_up(smallp, w, bias, outp, gp, act, slope, st)
+                             : bn_launch_up_fast(inner, smallp, w, bias, outp, nullptr, gp, act, BN_ACT_NONE,
+                                                 slope, iws, st);
+                if (rc) return rc;
+                rc = bn_launch_tile_scatter(outp, out + ob, nf, g.Cb, g.Hb, g.Wb, tp.bh, tp.bw,
+                                            dact_src ? dact_src + ob : nullptr, dact, slope, st);
+                if (rc) return rc;
+            }
+            return 0;
         }
     }
     BnProfScope prof(family, g.Cs, g.Cb, plan.supported ? plan.kernel_name : "k_up_generic", st);
@@ -412,6 +545,43 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
                                         bias_done);
         }
     }
+    if (!generic && !plan.supported) {
+        const TilePlan tp = tile_plan(2, g);
+        if (tp.ok) {
+            if (!ws || ws_bytes < tile_ws_bytes(tp)) return BN_E_WORKSPACE;
+            BnProfScope prof(family, g.Cb, g.Cs, tp.name, st);
+            float* bigp = (float*)ws;
+            float* smallp = (float*)((char*)ws + tp.big_bytes);
+            void* iws = (char*)ws + tp.big_bytes + tp.small_bytes;
+            // the big windows overlap (halos): a bias gradient summed over the big side would count
+            // them twice -- left to the caller's channel sums (bias_done stays false)
+            float* dbt = bias_side == 1 ? db : nullptr;
+            bool done_all = dbt != nullptr;
+            for (int n0 = 0; n0 < g.N; n0 += tp.nb) {
+                const int nf = g.N - n0 < tp.nb ? g.N - n0 : tp.nb;
+                const BnGeom gp = tile_geom(g, tp, nf);
+                const BnFastPlan inner = tile_inner(2, tp, gp);
+                const size_t ob = (size_t)n0 * g.Cb * g.Hb * g.Wb, os = (size_t)n0 * g.Cs * g.Hs * g.Ws;
+                int rc = bn_launch_tile_gather(big + ob, bigp, nf, g.Cb, g.Hb, g.Wb, tp.bh, tp.bw, 0, st);
+                if (rc) return rc;
+                rc = bn_launch_tile_gather(small + os, smallp, nf, g.Cs, g.Hs, g.Ws, tp.sh, tp.sw, 1, st);
+                if (rc) return rc;
+                const int acc = (accumulate || n0 > 0) ? 1 : 0;
+                bool done = false;
+                rc = tp.edge ? bn_launch_edge_wgrad(inner, smallp, bigp, dw, gp, acc, iws, st, dbt, bias_side, &done)
+                             : bn_launch_wgrad_fast(inner, smallp, bigp, dw, gp, acc, iws, st, dbt, bias_side, &done);
+                if (rc) return rc;
+                if (dbt && !done) {
+                    // (a family that leaves the bias to the caller does so for every pass)
+                    if (n0 > 0) return BN_E_BADARG;
+                    dbt = nullptr;
+                    done_all = false;
+                }
+            }
+            if (bias_done && done_all) *bias_done = true;
+            return 0;
+        }
+    }
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_wgrad_generic",
                      st);
     if (plan.supported) {
@@ -461,7 +631,12 @@ extern "C" size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, in
             need = bn_s5_down_small_ws_bytes(g);
         } else {
             const PadPlan pp = pad_plan(role, g);
-            if (pp.ok) need = pad_ws_bytes(pp) + (role == 2 ? bias_ws : 0);
+            if (pp.ok) {
+                need = pad_ws_bytes(pp) + (role == 2 ? bias_ws : 0);
+            } else {
+                const TilePlan tp = tile_plan(role, g);
+                if (tp.ok) need = tile_ws_bytes(tp) + (role == 2 ? bias_ws : 0);
+            }
         }
     }
     return need > bias_ws ? need : bias_ws;

@@ -19,36 +19,52 @@
 // dst (planes, Hp, Wp) <- src (planes, H, W) at row / column offset (oh, ow), zeros elsewhere.
 // (The offset turns a layer whose first tap sits pt = 2 pixels outside the frame into the pt = 1
 // form the specialised kernels are written for: big'[k] = big[k - (pt - 1)].)
+// Every tensor here is below 2 GB (the kernels around these copies address them through buffer
+// descriptors), so all index arithmetic is 32-bit; the padded side moves in 16-byte groups (Wp is
+// a multiple of 4), and so does the cropped side when its rows are.
 __global__ __launch_bounds__(PD_THREADS) void k_pad2d(const float* __restrict__ src,
-                                                       float* __restrict__ dst, size_t planes, int H,
+                                                       float* __restrict__ dst, unsigned planes, int H,
                                                        int W, int Hp, int Wp, int oh, int ow) {
-    const size_t total = planes * Hp * Wp;
-    for (size_t i = (size_t)blockIdx.x * PD_THREADS + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * PD_THREADS) {
-        const int w = (int)(i % Wp) - ow;
-        const size_t t = i / Wp;
-        const int h = (int)(t % Hp) - oh;
-        const size_t pl = t / Hp;
-        dst[i] = (h >= 0 && h < H && w >= 0 && w < W) ? src[(pl * H + h) * W + w] : 0.f;
+    const unsigned wq = Wp >> 2, groups = Hp * wq, total = planes * groups;
+    float4* dp = reinterpret_cast<float4*>(dst);
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned pl = q / groups, e = q - pl * groups;
+        const int hp = e / wq, w0 = 4 * (int)(e - hp * wq) - ow;
+        const int h = hp - oh;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (h >= 0 && h < H) {
+            const float* row = src + (pl * H + h) * W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (w0 + k >= 0 && w0 + k < W) v[k] = row[w0 + k];
+        }
+        dp[q] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
-// dst (planes, H, W) <- src (planes, Hp, Wp) from offset (oh, ow), times act'(dact_src) when given
+// dst (planes, H, W) <- src (planes, Hp, Wp) from offset (oh, ow), times act'(dact_src) when given;
+// VEC = 4: rows of the destination are multiples of four floats
+template <int VEC>
 __global__ __launch_bounds__(PD_THREADS) void k_crop2d(const float* __restrict__ src,
-                                                        float* __restrict__ dst, size_t planes, int H,
+                                                        float* __restrict__ dst, unsigned planes, int H,
                                                         int W, int Hp, int Wp, int oh, int ow,
                                                         const float* __restrict__ dact_src, int dact,
                                                         float slope) {
-    const size_t total = planes * H * W;
-    for (size_t i = (size_t)blockIdx.x * PD_THREADS + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * PD_THREADS) {
-        const int w = (int)(i % W);
-        const size_t t = i / W;
-        const int h = (int)(t % H);
-        const size_t pl = t / H;
-        float v = src[(pl * Hp + h + oh) * Wp + w + ow];
-        if (dact_src) v *= bn_act_grad_from_output(dact_src[i], dact, slope);
-        dst[i] = v;
+    const unsigned wq = W / VEC, groups = H * wq, total = planes * groups;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned pl = q / groups, e = q - pl * groups;
+        const int h = e / wq, w0 = VEC * (int)(e - h * wq);
+        const float* row = src + (pl * Hp + h + oh) * Wp + w0 + ow;
+        float v[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) v[k] = row[k];
+        if (dact_src) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                v[k] *= bn_act_grad_from_output(dact_src[(size_t)q * VEC + k], dact, slope);
+        }
+        if (VEC == 4) reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[VEC - 1]);
+        else dst[q] = v[0];
     }
 }
 
@@ -59,16 +75,122 @@ static int pd_blocks(size_t n) {
 
 int bn_launch_pad2d(const float* src, float* dst, size_t planes, int H, int W, int Hp, int Wp,
                     int oh, int ow, hipStream_t st) {
-    hipLaunchKernelGGL(k_pad2d, dim3(pd_blocks(planes * Hp * Wp)), dim3(PD_THREADS), 0, st, src, dst,
-                       planes, H, W, Hp, Wp, oh, ow);
+    if (Wp & 3) return BN_E_BADARG;
+    hipLaunchKernelGGL(k_pad2d, dim3(pd_blocks(planes * Hp * (Wp >> 2))), dim3(PD_THREADS), 0, st, src,
+                       dst, (unsigned)planes, H, W, Hp, Wp, oh, ow);
     BN_LAUNCH_CHECK();
     return 0;
 }
 
 int bn_launch_crop2d(const float* src, float* dst, size_t planes, int H, int W, int Hp, int Wp,
                      int oh, int ow, const float* dact_src, int dact, float slope, hipStream_t st) {
-    hipLaunchKernelGGL(k_crop2d, dim3(pd_blocks(planes * H * W)), dim3(PD_THREADS), 0, st, src, dst,
-                       planes, H, W, Hp, Wp, oh, ow, dact_src, dact, slope);
+    if ((W & 3) == 0 && ((((uintptr_t)dst) | ((uintptr_t)dact_src)) & 15u) == 0)
+        hipLaunchKernelGGL(k_crop2d<4>, dim3(pd_blocks(planes * H * (W >> 2))), dim3(PD_THREADS), 0, st,
+                           src, dst, (unsigned)planes, H, W, Hp, Wp, oh, ow, dact_src, dact, slope);
+    else
+        hipLaunchKernelGGL(k_crop2d<1>, dim3(pd_blocks(planes * H * W)), dim3(PD_THREADS), 0, st, src,
+                           dst, (unsigned)planes, H, W, Hp, Wp, oh, ow, dact_src, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Maps LARGER than the specialised kernels take (small side wider than 32, or 64 for the
+// single-channel edge layers: frames beyond 128 pixels): spatial tiles with halos, every tile a
+// pseudo-frame of the size the kernels are compiled for.
+//
+// Per axis, tile k of a 32-long small window (S = 32) holds small coordinates 30 k - 1 + p' and the
+// matching 64-long big window holds big coordinates 60 k - 1 - pt + i, which is exactly the
+// correspondence i = 2 p' - 1 + r  <->  b = 2 p - pt + r of the pt = 1 layer the kernels implement.
+//   gather-down: outputs p' in [1, 31) see only rows inside the window -> the tile OWNS 30 outputs;
+//   gather-up:   big rows i in [1 + pt, 61 + pt) get every contribution from inside the window -> the
+//                tile owns 60 big rows;
+//   weight gradient: the small window carries its owned 30 rows only (the rest zero), so every dy
+//                element meets its inputs exactly once over all tiles.
+// Everything outside the map reads as zero (the layer's own padding).  An axis that fits is one
+// tile holding the whole map (the zero-padded embedding above).  Exact, like the padding: only
+// the order of the additions differs from an untiled kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PD_THREADS) void k_tile_gather(const float* __restrict__ src,
+                                                             float* __restrict__ dst, int N, int C,
+                                                             int H, int W, BnTileAxis th,
+                                                             BnTileAxis tw, int masked) {
+    // 16-byte groups of the tiles (D is a multiple of 4), 32-bit indices (tensors below 2 GB)
+    const unsigned T = th.T * tw.T, wq = tw.D >> 2, groups = th.D * wq;
+    const unsigned total = (unsigned)N * T * C * groups;
+    float4* dp = reinterpret_cast<float4*>(dst);
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned pl = q / groups, e = q - pl * groups;
+        const unsigned nt = pl / C, c = pl - nt * C;
+        const unsigned n = nt / T, tix = nt - n * T;
+        const int kh = tix / tw.T, kw = tix - kh * tw.T;
+        const int i = e / wq, j0 = 4 * (int)(e - i * wq);
+        const int y = th.step * kh - th.v0 + i, x0 = tw.step * kw - tw.v0;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && (!masked || (i >= th.v0 && i < th.v0 + th.V))) {
+            const float* row = src + ((n * C + c) * H + y) * W;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + k, x = x0 + j;
+                if (x >= 0 && x < W && (!masked || (j >= tw.v0 && j < tw.v0 + tw.V))) v[k] = row[x];
+            }
+        }
+        dp[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(PD_THREADS) void k_tile_scatter(const float* __restrict__ src,
+                                                              float* __restrict__ dst, int N, int C,
+                                                              int H, int W, BnTileAxis th,
+                                                              BnTileAxis tw,
+                                                              const float* __restrict__ dact_src,
+                                                              int dact, float slope) {
+    const unsigned T = th.T * tw.T, wq = W / VEC, groups = H * wq, DD = th.D * tw.D;
+    const unsigned total = (unsigned)N * C * groups;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned pl = q / groups, e = q - pl * groups;
+        const unsigned n = pl / C, c = pl - n * C;
+        const int y = e / wq, x0 = VEC * (int)(e - y * wq);
+        const int kh = th.T > 1 ? y / th.step : 0;
+        const int i = th.v0 + y - th.step * kh;
+        float v[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int x = x0 + k;
+            const int kw = tw.T > 1 ? x / tw.step : 0;
+            const int j = tw.v0 + x - tw.step * kw;
+            v[k] = src[(((n * T + kh * tw.T + kw) * C + c) * th.D + i) * tw.D + j];
+        }
+        (void)DD;
+        if (dact_src) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                v[k] *= bn_act_grad_from_output(dact_src[(size_t)q * VEC + k], dact, slope);
+        }
+        if (VEC == 4) reinterpret_cast<float4*>(dst)[q] = make_float4(v[0], v[1], v[2], v[VEC - 1]);
+        else dst[q] = v[0];
+    }
+}
+
+int bn_launch_tile_gather(const float* src, float* dst, int N, int C, int H, int W, BnTileAxis th,
+                          BnTileAxis tw, int masked, hipStream_t st) {
+    if (tw.D & 3) return BN_E_BADARG;
+    hipLaunchKernelGGL(k_tile_gather, dim3(pd_blocks((size_t)N * th.T * tw.T * C * th.D * (tw.D >> 2))),
+                       dim3(PD_THREADS), 0, st, src, dst, N, C, H, W, th, tw, masked);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_launch_tile_scatter(const float* src, float* dst, int N, int C, int H, int W, BnTileAxis th,
+                           BnTileAxis tw, const float* dact_src, int dact, float slope,
+                           hipStream_t st) {
+    if ((W & 3) == 0 && ((((uintptr_t)dst) | ((uintptr_t)dact_src)) & 15u) == 0)
+        hipLaunchKernelGGL(k_tile_scatter<4>, dim3(pd_blocks((size_t)N * C * H * (W >> 2))), dim3(PD_THREADS),
+                           0, st, src, dst, N, C, H, W, th, tw, dact_src, dact, slope);
+    else
+        hipLaunchKernelGGL(k_tile_scatter<1>, dim3(pd_blocks((size_t)N * C * H * W)), dim3(PD_THREADS), 0, st,
+                           src, dst, N, C, H, W, th, tw, dact_src, dact, slope);
     BN_LAUNCH_CHECK();
     return 0;
 }

@@ -73,6 +73,14 @@ CONV_CASES = [
     ('pad_E0_64x48', 3, 1, 64, 48, 32, 5, 2, (1, 2), (1, 2)),
     ('s5_2x1', 4, 256, 6, 5, 512, 5, 5, (2, 2), (0, 0)),
     ('s5_1x1', 4, 256, 4, 3, 512, 5, 5, (0, 1), (1, 1)),
+    # maps larger than the specialised kernels take: spatial tiles with halos (conv_pad.hip):
+    # 2x2 tiles of 32x32 (enc.conv1 of a 192x160 frame), 4x1 tiles, an odd-sized map with the
+    # first tap 2 pixels outside, single- and two-channel 192x160 frames on the edge kernels
+    ('tile_48x40', 3, 32, 96, 80, 64, 5, 2, (1, 2), (1, 2)),
+    ('tile_100x24', 2, 32, 200, 48, 64, 5, 2, (1, 2), (1, 2)),
+    ('tile_odd_pl2', 2, 32, 93, 71, 64, 5, 2, (1, 2), (2, 2)),
+    ('tile_E0_96x80', 2, 1, 192, 160, 32, 5, 2, (1, 2), (1, 2)),
+    ('tile_E0c2_80x128', 2, 2, 160, 256, 32, 5, 2, (1, 2), (1, 2)),
 ]
 
 
@@ -152,6 +160,10 @@ CONVT_CASES = [
     ('pad_4x3', 3, 256, 4, 3, 128, 5, 2, 0, (1, 2, 1, 2), 0),
     ('pad_10x8_pl2', 3, 256, 10, 8, 128, 5, 2, 0, (2, 2, 1, 2), 0),
     ('pad_D4_64x48', 3, 32, 32, 24, 1, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('tile_48x40', 3, 64, 48, 40, 32, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('tile_47x36_pt2', 2, 64, 47, 36, 32, 5, 2, 0, (1, 2, 2, 2), 0),
+    ('tile_D4_96x80', 2, 32, 96, 80, 1, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('tile_D4c2_80x128', 2, 32, 80, 128, 2, 5, 2, 0, (1, 2, 1, 2), 0),
 ]
 
 
@@ -602,3 +614,35 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
         assert torch.equal(u.cpu(), u_ref.detach())
         dv = _hip.maxunpool2d_bwd(du.to(DEV), idx)
         assert torch.equal(dv.cpu(), vr.grad)
+
+
+@pytest.mark.parametrize('case_name, want', [
+    ('tile_48x40', 'on zero-padded 64x64'), ('tile_100x24', 'on zero-padded 128x32'),
+    ('tile_E0_96x80', 'on 2x2 tiles of 64x64'), ('pad_24x20', 'on zero-padded 32x32')])
+def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, want):
+    """The dispatch takes the tiled / zero-padded detour (conv_pad.hip), not the direct loops."""
+    case = [c for c in CONV_CASES if c[0] == case_name][0]
+    x, w, b, geom, ref = _conv_setup(case)
+    _hip.prof_select(_hip.PROF_CONV_FWD, 0, 0)
+    try:
+        y = _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE)
+        torch.cuda.synchronize()
+        _, n, name = _hip.prof_read()
+    finally:
+        _hip.prof_select(_hip.PROF_NONE)
+    assert n >= 1 and want in name, name
+    # the other two roles: gather-up and weight gradient (tiles where the padded map is too large
+    # for their families)
+    for prof, fn in ((_hip.PROF_CONV_BWD_D, lambda: _hip.conv2d_bwd_data(
+                          torch.ones_like(y), w.to(DEV), geom, None, _hip.ACT_NONE, SLOPE)),
+                     (_hip.PROF_CONV_BWD_W, lambda: _hip.conv2d_bwd_weight(
+                          x.to(DEV), torch.ones_like(y), torch.empty_like(w, device=DEV),
+                          torch.empty_like(b, device=DEV), geom, False))):
+        _hip.prof_select(prof, 0, 0)
+        try:
+            fn()
+            torch.cuda.synchronize()
+            _, n, name = _hip.prof_read()
+        finally:
+            _hip.prof_select(_hip.PROF_NONE)
+        assert n >= 1 and ('tiles of' in name or 'zero-padded' in name), name
