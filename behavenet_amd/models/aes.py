@@ -598,6 +598,20 @@ class AE(BaseModel):
             not self.hparams.get('ae_batch_norm', False) and \
             os.environ.get('BN_WHOLE_BATCH', '1') != '0'
 
+    def _pass_groups(self, x, chunk_size):
+        """Frame ranges that are run as ONE forward / backward pass each, or None for the
+        chunk-by-chunk pipelines: the whole batch when frames are independent through the
+        model; with batch norm under frame-sharded data parallelism every 200-frame chunk is
+        its own pass (the statistics are per chunk, taken over all ranks' frames:
+        hip_functions.BatchNormActFn), so that the sharding machinery of the single-pass
+        schedule (global chunk means, shared eps, gathered decomposed KL) serves it too."""
+        n = x.shape[0]
+        if self._whole_batch_ok(x):
+            return [(0, n)]
+        if bdist.frames_sharded() and self.model_type == 'conv' and x.is_cuda and self._whole_batch:
+            return [(beg, min(beg + chunk_size, n)) for beg in range(0, n, chunk_size)]
+        return None
+
     @staticmethod
     def _local_frames(local, *tensors):
         """This rank's frames of a frame-sharded batch: the local slice of every chunk, packed
@@ -768,10 +782,20 @@ class ConditionalAE(AE):
             else None
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
-        if self._whole_batch_ok(x):
-            # labels ride along frame by frame: same single-pass schedule as AE.loss
-            return self._loss_whole_batch(x, m, dataset, accumulate_grad, chunk_size,
-                                          labels=y, labels_2d=labels_2d)
+        groups = self._pass_groups(x, chunk_size)
+        if groups is not None:
+            # labels ride along frame by frame: same single-pass schedule as AE.loss (batch norm
+            # under frame sharding: one pass per chunk, see _pass_groups)
+            total = 0.0
+            for gb, ge in groups:
+                part = self._loss_whole_batch(
+                    x[gb:ge], m[gb:ge] if m is not None else None, dataset, accumulate_grad,
+                    chunk_size, labels=y[gb:ge],
+                    labels_2d=labels_2d[gb:ge] if labels_2d is not None else None)
+                if len(groups) == 1:
+                    return part
+                total += part['loss'] * (ge - gb)
+            return {'loss': float(total / batch_size)}
         _no_sharded_chunk_loop(self)
         vals, sizes, deferred = ChunkScalars(), [], []
         self._reserve_pools(x)

@@ -256,27 +256,32 @@ class VAE(AE):
         rbs, sizes, deferred = hf.ChunkScalars(), [], []
         keys = ['loss', 'loss_ll', 'loss_kl']
         self._reserve_pools(x)
-        whole = self._whole_batch_ok(x)
+        groups = self._pass_groups(x, chunk_size)
+        whole = groups is not None
         if whole:
-            # one pass over the whole batch, latents sampled and losses normalised per chunk
-            # (see AE._loss_whole_batch)
-            sh = _FrameShards(batch_size, chunk_size)
-            bounds = sh.bounds_l
-            kw = fwd_kwargs_fn(0, batch_size)
-            xl, ml, *kw_l = sh.take(x, m, *kw.values())
-            kw = dict(zip(kw.keys(), kw_l))
-            with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, _, mu, logvar = self.forward(
-                    xl, dataset=dataset, use_mean=False, sample_bounds=bounds, sample_shards=sh,
-                    pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
-                                'chunk_sizes': sh.sizes}, **kw)
-                ll = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
-                                               const_share=sh.share if sh.sharded else None)
-                klv = sh.kl_terms(mu, logvar)
-                lossv = -ll + float(beta) * klv
-            vals = _finish_whole(torch.stack([lossv, ll, klv], dim=1), lossv,
-                                 accumulate_grad)
-            sizes = sh.sizes
+            # one pass over the whole batch (batch norm under frame sharding: one per chunk),
+            # latents sampled and losses normalised per chunk (see AE._loss_whole_batch)
+            vals, sizes = [], []
+            for gb, ge in groups:
+                sh = _FrameShards(ge - gb, chunk_size)
+                bounds = sh.bounds_l
+                kw = fwd_kwargs_fn(gb, ge)
+                xl, ml, *kw_l = sh.take(x[gb:ge], m[gb:ge] if m is not None else None,
+                                        *kw.values())
+                kw = dict(zip(kw.keys(), kw_l))
+                with torch.set_grad_enabled(bool(accumulate_grad)):
+                    x_hat, _, mu, logvar = self.forward(
+                        xl, dataset=dataset, use_mean=False, sample_bounds=bounds,
+                        sample_shards=sh,
+                        pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
+                                    'chunk_sizes': sh.sizes}, **kw)
+                    ll = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
+                                                   const_share=sh.share if sh.sharded else None)
+                    klv = sh.kl_terms(mu, logvar)
+                    lossv = -ll + float(beta) * klv
+                vals.extend(_finish_whole(torch.stack([lossv, ll, klv], dim=1), lossv,
+                                          accumulate_grad))
+                sizes.extend(sh.sizes)
             n_chunks = 0
         else:
             _no_sharded_chunk_loop(self)
@@ -372,30 +377,34 @@ class BetaTCVAE(VAE):
         rbs, sizes, deferred = hf.ChunkScalars(), [], []
         keys = ['loss', 'loss_ll', 'loss_mi', 'loss_tc', 'loss_dwkl']
         self._reserve_pools(x)
-        whole = self._whole_batch_ok(x)
+        groups = self._pass_groups(x, chunk_size)
+        whole = groups is not None
         if whole:
-            sh = _FrameShards(batch_size, chunk_size)
-            bounds = sh.bounds_l
-            xl, ml = sh.take(x, m)
-            with torch.set_grad_enabled(bool(accumulate_grad)):
-                x_hat, sample, mu, logvar = self.forward(
-                    xl, dataset=dataset, use_mean=False, sample_bounds=bounds, sample_shards=sh,
-                    pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
-                                'chunk_sizes': sh.sizes})
-                ll = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
-                                               const_share=sh.share if sh.sharded else None)
-                # the decomposed KL couples all samples of a chunk: every rank evaluates it on
-                # the gathered chunk (gradients flow through its own rows only)
-                dk = sh.decomposed_kl_terms(sample, mu, logvar)                  # (n_chunks, 3)
-                kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
-                lossv = -ll + kl_terms
-                # what is REPORTED is summed over ranks: the shared terms enter with this rank's
-                # share of the chunk
-                w = sh.share_t(x.device)
-                table = torch.cat([(-ll + w * kl_terms)[:, None], ll[:, None], dk * (w if isinstance(w, float) else w[:, None])],
-                                  dim=1)
-            vals = _finish_whole(table, lossv, accumulate_grad)
-            sizes = sh.sizes
+            vals, sizes = [], []
+            for gb, ge in groups:
+                sh = _FrameShards(ge - gb, chunk_size)
+                bounds = sh.bounds_l
+                xl, ml = sh.take(x[gb:ge], m[gb:ge] if m is not None else None)
+                with torch.set_grad_enabled(bool(accumulate_grad)):
+                    x_hat, sample, mu, logvar = self.forward(
+                        xl, dataset=dataset, use_mean=False, sample_bounds=bounds,
+                        sample_shards=sh,
+                        pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds, 'kind': 'll',
+                                    'chunk_sizes': sh.sizes})
+                    ll = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes,
+                                                   const_share=sh.share if sh.sharded else None)
+                    # the decomposed KL couples all samples of a chunk: every rank evaluates it
+                    # on the gathered chunk (gradients flow through its own rows only)
+                    dk = sh.decomposed_kl_terms(sample, mu, logvar)              # (n_chunks, 3)
+                    kl_terms = float(kl) * dk[:, 0] + float(beta) * dk[:, 1] + float(kl) * dk[:, 2]
+                    lossv = -ll + kl_terms
+                    # what is REPORTED is summed over ranks: the shared terms enter with this
+                    # rank's share of the chunk
+                    w = sh.share_t(x.device)
+                    table = torch.cat([(-ll + w * kl_terms)[:, None], ll[:, None],
+                                       dk * (w if isinstance(w, float) else w[:, None])], dim=1)
+                vals.extend(_finish_whole(table, lossv, accumulate_grad))
+                sizes.extend(sh.sizes)
             n_chunks = 0
         else:
             _no_sharded_chunk_loop(self)
@@ -571,39 +580,48 @@ class PSVAE(AE):
         rbs, sizes, y_hat_all, deferred = hf.ChunkScalars(), [], [], []
         keys = ['loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi', 'loss_zu_tc',
                 'loss_zu_dwkl', 'loss']
-        whole = self._whole_batch_ok(x)
+        groups = self._pass_groups(x, chunk_size)
+        whole = groups is not None
         if whole:
-            # one pass over the whole batch; latents sampled, and every term normalised, per
-            # chunk (see AE._loss_whole_batch)
-            sh = _FrameShards(batch_size, chunk_size)
-            bounds = sh.bounds_l
-            xl, yl, ml, nl = sh.take(x, y, m, n)
-            share = sh.share if sh.sharded else None
-            fused_head = not sh.sharded and _FUSED_PS_HEAD and xl.is_cuda
-            with torch.set_grad_enabled(bool(accumulate_grad)):
-                if fused_head:
-                    # encoder heads -> ONE node (latents, label head, label / KL / decomposed-KL
-                    # terms of every chunk) -> decoder with the pixel loss in its last kernel
-                    mu_s, mu_u, logvar, pool_idx, outsize = self.encoding(xl, dataset=dataset)
-                    eps = _draw_eps(logvar, bounds)
-                    sample, lat_terms, y_hat, cols5 = hf.psvae_head(
-                        mu_s, mu_u, logvar, self.encoding.D, yl, nl, eps, bounds, alpha, kl, beta)
-                    x_hat = self.decoding(sample, pool_idx, outsize, dataset=dataset,
-                                          pixel_loss={'target': xl, 'mask': ml, 'bounds': bounds,
-                                                      'kind': 'll', 'chunk_sizes': sh.sizes})
-                    ll_x = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds, chunk_sizes=sh.sizes)
-                    lossv = lat_terms - ll_x
-                    table = torch.cat([ll_x.detach()[:, None], cols5, lossv.detach()[:, None]],
-                                      dim=1)
-                else:
-                    lossv, table, y_hat = self._loss_terms_unfused(
-                        xl, yl, ml, nl, sh, bounds, share, dataset, alpha, beta, kl)
-            # label r^2 over the whole batch: the ranks' rows are gathered (a few KB)
-            y_hat_rb = hf.Readback(sh.all_rows(y_hat.detach()))
-            y_rb = hf.Readback(sh.all_rows(yl))
-            n_rb = hf.Readback(sh.all_rows(nl)) if n is not None else None
-            vals = _finish_whole(table, lossv, accumulate_grad)
-            sizes = sh.sizes
+            # one pass over the whole batch (batch norm under frame sharding: one per chunk);
+            # latents sampled, and every term normalised, per chunk (see AE._loss_whole_batch)
+            vals, sizes, y_hat_rbs, y_rbs, n_rbs = [], [], [], [], []
+            for gb, ge in groups:
+                sh = _FrameShards(ge - gb, chunk_size)
+                bounds = sh.bounds_l
+                xl, yl, ml, nl = sh.take(x[gb:ge], y[gb:ge], m[gb:ge] if m is not None else None,
+                                         n[gb:ge] if n is not None else None)
+                share = sh.share if sh.sharded else None
+                fused_head = not sh.sharded and _FUSED_PS_HEAD and xl.is_cuda
+                with torch.set_grad_enabled(bool(accumulate_grad)):
+                    if fused_head:
+                        # encoder heads -> ONE node (latents, label head, label / KL /
+                        # decomposed-KL terms of every chunk) -> decoder with the pixel loss in
+                        # its last kernel
+                        mu_s, mu_u, logvar, pool_idx, outsize = self.encoding(xl, dataset=dataset)
+                        eps = _draw_eps(logvar, bounds)
+                        sample, lat_terms, y_hat, cols5 = hf.psvae_head(
+                            mu_s, mu_u, logvar, self.encoding.D, yl, nl, eps, bounds, alpha, kl,
+                            beta)
+                        x_hat = self.decoding(sample, pool_idx, outsize, dataset=dataset,
+                                              pixel_loss={'target': xl, 'mask': ml,
+                                                          'bounds': bounds, 'kind': 'll',
+                                                          'chunk_sizes': sh.sizes})
+                        ll_x = losses.gaussian_ll_chunks(xl, x_hat, ml, bounds,
+                                                         chunk_sizes=sh.sizes)
+                        lossv = lat_terms - ll_x
+                        table = torch.cat([ll_x.detach()[:, None], cols5,
+                                           lossv.detach()[:, None]], dim=1)
+                    else:
+                        lossv, table, y_hat = self._loss_terms_unfused(
+                            xl, yl, ml, nl, sh, bounds, share, dataset, alpha, beta, kl)
+                # label r^2 over the whole batch: the ranks' rows are gathered (a few KB)
+                y_hat_rbs.append(hf.Readback(sh.all_rows(y_hat.detach())))
+                y_rbs.append(hf.Readback(sh.all_rows(yl)))
+                if n is not None:
+                    n_rbs.append(hf.Readback(sh.all_rows(nl)))
+                vals.extend(_finish_whole(table, lossv, accumulate_grad))
+                sizes.extend(sh.sizes)
             n_chunks = 0
         else:
             _no_sharded_chunk_loop(self)
@@ -642,8 +660,13 @@ class PSVAE(AE):
             n_rb = hf.Readback(n) if n is not None else None
             vals = rbs.finish(deferred)
             self._release_first_layer()
-        y_hat_np, y_np = y_hat_rb.numpy(), y_rb.numpy()
-        n_np = n_rb.numpy() if n_rb is not None else None
+        if whole:
+            y_hat_np = np.concatenate([rb.numpy() for rb in y_hat_rbs], axis=0)
+            y_np = np.concatenate([rb.numpy() for rb in y_rbs], axis=0)
+            n_np = np.concatenate([rb.numpy() for rb in n_rbs], axis=0) if n is not None else None
+        else:
+            y_hat_np, y_np = y_hat_rb.numpy(), y_rb.numpy()
+            n_np = n_rb.numpy() if n_rb is not None else None
         order = ['loss', 'loss_data_ll', 'loss_label_ll', 'loss_zs_kl', 'loss_zu_mi',
                  'loss_zu_tc', 'loss_zu_dwkl']
         out = {k: 0.0 for k in order}

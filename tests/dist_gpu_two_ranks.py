@@ -17,7 +17,7 @@ from behavenet_amd.data.data_generator import SyntheticSession, SyntheticSession
 from behavenet_amd.fitting import distributed as bdist  # noqa: E402
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad  # noqa: E402
 from behavenet_amd.fitting.training import fit  # noqa: E402
-from behavenet_amd.models import AE, BetaTCVAE, PSVAE  # noqa: E402
+from behavenet_amd.models import AE, BetaTCVAE, PSVAE, VAE  # noqa: E402
 from behavenet_amd.models import vaes as hip_vaes  # noqa: E402
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch  # noqa: E402
 from tests.golden_utils import base_hparams, make_frames, make_labels  # noqa: E402
@@ -48,9 +48,14 @@ def build_case(case):
     np.random.seed(0)
     if case == 'ae_bn':
         model = AE(base_hparams(arch, 'ae', {'ae_batch_norm': True}))
-    elif case == 'psvae':
+    elif case == 'vae_bn':
+        model = VAE(base_hparams(arch, 'vae', {'ae_batch_norm': True, 'vae.beta': 2.0,
+                                               'vae.beta_anneal_epochs': 0, 'max_n_epochs': 10}))
+        hip_vaes.set_eps_provider(_Eps())
+    elif case in ('psvae', 'psvae_bn'):
         hp = base_hparams(arch, 'ps-vae', {'ps_vae.alpha': 10.0, 'ps_vae.beta': 3.0,
-                                           'ps_vae.anneal_epochs': 0, 'max_n_epochs': 10})
+                                           'ps_vae.anneal_epochs': 0, 'max_n_epochs': 10,
+                                           'ae_batch_norm': case == 'psvae_bn'})
         hp['n_labels'] = 2
         model = PSVAE(hp)
         data['labels'] = torch.from_numpy(make_labels(44, 2, seed=2)).to(DEV)[None]
@@ -78,9 +83,15 @@ def build_oracle(case, dtype=torch.float64):
     np.random.seed(0)
     if case == 'ae_bn':
         model = ref_cpu.AE(base_hparams(arch, 'ae', {'ae_batch_norm': True}))
-    elif case == 'psvae':
+    elif case == 'vae_bn':
+        model = ref_cpu.VAE(base_hparams(arch, 'vae', {'ae_batch_norm': True, 'vae.beta': 2.0,
+                                                       'vae.beta_anneal_epochs': 0,
+                                                       'max_n_epochs': 10}))
+        model.eps_fn = _Eps()
+    elif case in ('psvae', 'psvae_bn'):
         hp = base_hparams(arch, 'ps-vae', {'ps_vae.alpha': 10.0, 'ps_vae.beta': 3.0,
-                                           'ps_vae.anneal_epochs': 0, 'max_n_epochs': 10})
+                                           'ps_vae.anneal_epochs': 0, 'max_n_epochs': 10,
+                                           'ae_batch_norm': case == 'psvae_bn'})
         hp['n_labels'] = 2
         model = ref_cpu.PSVAE(hp)
         data['labels'] = torch.from_numpy(make_labels(44, 2, seed=2)).to(dtype)[None]

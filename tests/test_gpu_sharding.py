@@ -194,7 +194,7 @@ def _run_two_ranks(tmp_path, case):
         return json.load(f)
 
 
-@pytest.mark.parametrize('case', ['ae_bn', 'psvae', 'betatc'])
+@pytest.mark.parametrize('case', ['ae_bn', 'psvae', 'betatc', 'vae_bn', 'psvae_bn'])
 def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, case):
     """Real collectives (gloo, host-staged) between two processes sharing the GPU: the terms
     emulation cannot provide (SyncBN statistics, the decomposed KL on the all-gathered chunk).
@@ -230,7 +230,7 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, case):
     for k, v in l64.items():
         assert got['loss'][k] == pytest.approx(v, rel=1e-4, abs=1e-6), ('float64 oracle', k)
     assert sum(w.size for _, w in g64) == g.size
-    g32 = oracle_grads(torch.float32)[1] if case == 'ae_bn' else None
+    g32 = oracle_grads(torch.float32)[1] if case.endswith('_bn') else None
     names = {k for k, _ in g64}
     off = 0
     for i, (k, w) in enumerate(g64):
