@@ -105,6 +105,25 @@ int bn_launch_tile_gather(const float* src, float* dst, int N, int C, int H, int
 int bn_launch_tile_scatter(const float* src, float* dst, int N, int C, int H, int W, BnTileAxis th,
                            BnTileAxis tw, const float* dact_src, int dact, float slope,
                            hipStream_t st);
+// dst[n][c0d + c][i] <- src[n][c0s + c][i], c < Cg, i < HW (a multiple of 4); optional act' mask
+int bn_launch_chan_copy(const float* src, float* dst, int N, int Csrc, int c0s, int Cdst, int c0d,
+                        int Cg, int HW, const float* dact_src, int dact, float slope, hipStream_t st);
+// im2col + GEMM for whatever no specialised kernel (or detour onto one) serves
+bool bn_col_ok(const BnGeom& g);
+size_t bn_col_ws_bytes(const BnGeom& g);
+int bn_launch_col_down(const float* big, const float* w, const float* bias, float* out,
+                       const float* dact_src, const BnGeom& g, int act, int dact, float slope, void* ws,
+                       size_t ws_bytes, hipStream_t st);
+int bn_launch_col_up(const float* small, const float* w, const float* bias, float* out,
+                     const float* dact_src, const BnGeom& g, int act, int dact, float slope, void* ws,
+                     size_t ws_bytes, hipStream_t st);
+int bn_launch_col_wgrad(const float* small, const float* big, float* dw, const BnGeom& g, int accumulate,
+                        void* ws, size_t ws_bytes, hipStream_t st, float* db, int bias_side,
+                        bool* bias_done);
+// kernels smaller than 5x5 embedded in 5x5 taps (weights [pairs][R][S] <-> [pairs][5][5])
+int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hipStream_t st);
+int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S, int accumulate,
+                        hipStream_t st);
 bool bn_s5_down_small_ok(const BnGeom& g);
 size_t bn_s5_down_small_ws_bytes(const BnGeom& g);
 int bn_launch_s5_down_small(const float* big, const float* w, const float* bias, float* out,

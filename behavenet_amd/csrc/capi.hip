@@ -342,10 +342,68 @@ static TilePlan tile_plan(int role, const BnGeom& g) {
 }
 static inline size_t tile_ws_bytes(const TilePlan& p) { return p.big_bytes + p.small_bytes + p.inner_ws; }
 
+// ---- kernels smaller than 5x5 with stride 2 (ae_arch_2.json: 4x4): 5x5 taps, the added ones zero
+static size_t role_ws_need(int role, const BnGeom& g);
+static bool served_fast(int role, const BnGeom& g);
+// ---- single- / two-channel edge layers with more than 32 channels on the other side (1 -> 64):
+// groups of 32 small-side channels on contiguous copies (gather-down, weight gradient)
+static bool chan_plan(int role, const BnGeom& g, BnGeom* gg) {
+    if (force_generic() || role == 1 || g.Cb > 2 || g.Cs <= 32 || (g.Cs & 31)) return false;
+    if (g.R != 5 || g.S != 5 || g.stride != 2 || ((g.Hs * g.Ws) & 3)) return false;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    *gg = g;
+    gg->Cs = 32;
+    return served_fast(role, *gg);
+}
+static inline size_t chan_bytes(const BnGeom& g) { return align256((size_t)g.N * 32 * g.Hs * g.Ws * 4); }
+static bool served_fast(int role, const BnGeom& g) {
+    BnGeom gg;
+    if (chan_plan(role, g, &gg)) return true;
+    if (g.Cb <= 4) {
+        const BnFastPlan ed = role == 0 ? bn_edge_down_plan(g) : role == 1 ? bn_edge_up_plan(g)
+                                                                          : bn_edge_wgrad_plan(g);
+        if (ed.supported) return true;
+    }
+    const BnFastPlan pl = role == 0 ? bn_fast_down_plan(g) : role == 1 ? bn_fast_up_plan(g)
+                                                                      : bn_fast_wgrad_plan(g);
+    if (pl.supported) return true;
+    return pad_plan(role, g).ok || tile_plan(role, g).ok;
+}
+static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
+    if (force_generic() || g.stride != 2 || g.R > 5 || g.S > 5 || (g.R == 5 && g.S == 5)) return false;
+    if (g.R < 2 || g.S < 2) return false;
+    *g5 = g;
+    g5->R = g5->S = 5;
+    return served_fast(role, *g5);
+}
+static inline size_t taps_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * 25 * sizeof(float)); }
+
 static int run_down(int family, const float* big, const float* w, const float* bias, float* out,
                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                     void* ws, size_t ws_bytes, hipStream_t st) {
     const bool generic = force_generic() || !aligned16_all(big, w, out, dact_src);
+    BnGeom g5;
+    if (!generic && taps_plan(0, g, &g5)) {
+        const size_t wb = taps_bytes(g);
+        if (!ws || ws_bytes < wb + role_ws_need(0, g5)) return BN_E_WORKSPACE;
+        const int rc = bn_launch_pad_taps(w, (float*)ws, (size_t)g.Cs * g.Cb, g.R, g.S, st);
+        if (rc) return rc;
+        return run_down(family, big, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
+                        (char*)ws + wb, ws_bytes - wb, st);
+    }
+    if (!generic && chan_plan(0, g, &g5)) {
+        const size_t cb = chan_bytes(g);
+        if (!ws || ws_bytes < cb + role_ws_need(0, g5)) return BN_E_WORKSPACE;
+        const int PQ = g.Hs * g.Ws;
+        for (int c0 = 0; c0 < g.Cs; c0 += 32) {
+            int rc = run_down(family, big, w + (size_t)c0 * g.Cb * 25, bias ? bias + c0 : nullptr, (float*)ws,
+                              nullptr, g5, act, BN_ACT_NONE, slope, (char*)ws + cb, ws_bytes - cb, st);
+            if (rc) return rc;
+            rc = bn_launch_chan_copy((const float*)ws, out, g.N, 32, 0, g.Cs, c0, 32, PQ, dact_src, dact, slope, st);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if (!generic) {
         const BnFastPlan ed = bn_edge_down_plan(g);
         // epilogues the edge kernel is instantiated for: plain / LeakyReLU forward, or a data
@@ -414,6 +472,10 @@ static int run_down(int family, const float* big, const float* w, const float* b
             return 0;
         }
     }
+    if (!generic && !plan.supported && bn_col_ok(g)) {
+        BnProfScope prof(family, g.Cb, g.Cs, "k_im2col + k_gemm_mfma", st);
+        return bn_launch_col_down(big, w, bias, out, dact_src, g, act, dact, slope, ws, ws_bytes, st);
+    }
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_down_generic", st);
     if (plan.supported) {
         if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
@@ -426,6 +488,15 @@ static int run_up(int family, const float* small, const float* w, const float* b
                   const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                   void* ws, size_t ws_bytes, hipStream_t st) {
     const bool generic = force_generic() || !aligned16_all(small, w, out, dact_src);
+    BnGeom g5;
+    if (!generic && taps_plan(1, g, &g5)) {
+        const size_t wb = taps_bytes(g);
+        if (!ws || ws_bytes < wb + role_ws_need(1, g5)) return BN_E_WORKSPACE;
+        const int rc = bn_launch_pad_taps(w, (float*)ws, (size_t)g.Cs * g.Cb, g.R, g.S, st);
+        if (rc) return rc;
+        return run_up(family, small, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
+                      (char*)ws + wb, ws_bytes - wb, st);
+    }
     if (!generic && bn_qgemm_supported(g)) {
         if (bn_qgemm_ws_bytes(1, g) && (!ws || ws_bytes < bn_qgemm_ws_bytes(1, g))) return BN_E_WORKSPACE;
         BnProfScope prof(family, g.Cs, g.Cb, "k_qgemm<1>", st);
@@ -491,6 +562,10 @@ static int run_up(int family, const float* small, const float* w, const float* b
             return 0;
         }
     }
+    if (!generic && !plan.supported && bn_col_ok(g)) {
+        BnProfScope prof(family, g.Cs, g.Cb, "k_gemm_mfma + k_col2im", st);
+        return bn_launch_col_up(small, w, bias, out, dact_src, g, act, dact, slope, ws, ws_bytes, st);
+    }
     BnProfScope prof(family, g.Cs, g.Cb, plan.supported ? plan.kernel_name : "k_up_generic", st);
     if (plan.supported) {
         if (!ws_ok(plan, ws, ws_bytes)) return BN_E_WORKSPACE;
@@ -503,6 +578,40 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
                      const BnGeom& g, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
                      float* db, int bias_side, bool* bias_done) {
     const bool generic = force_generic() || !aligned16_all(small, big, dw);
+    BnGeom g5;
+    if (!generic && taps_plan(2, g, &g5)) {
+        const size_t wb = taps_bytes(g);
+        if (!ws || ws_bytes < wb + role_ws_need(2, g5)) return BN_E_WORKSPACE;
+        // (dw5 is written, not accumulated; a bias gradient that has to be accumulated is left to
+        // the caller's channel sums)
+        int rc = run_wgrad(family, small, big, (float*)ws, g5, 0, (char*)ws + wb, ws_bytes - wb, st,
+                           accumulate ? nullptr : db, bias_side, bias_done);
+        if (rc) return rc;
+        return bn_launch_crop_taps((const float*)ws, dw, (size_t)g.Cs * g.Cb, g.R, g.S, accumulate, st);
+    }
+    if (!generic && chan_plan(2, g, &g5)) {
+        const size_t cb = chan_bytes(g);
+        if (!ws || ws_bytes < cb + role_ws_need(2, g5)) return BN_E_WORKSPACE;
+        const int PQ = g.Hs * g.Ws;
+        bool all_done = db && bias_side == 1;
+        for (int c0 = 0; c0 < g.Cs; c0 += 32) {
+            int rc = bn_launch_chan_copy(small, (float*)ws, g.N, g.Cs, c0, 32, 0, 32, PQ, nullptr, 0, 0.f, st);
+            if (rc) return rc;
+            bool done = false;
+            // (a bias gradient over the big side would be the same sum once per group)
+            rc = run_wgrad(family, (const float*)ws, big, dw + (size_t)c0 * g.Cb * 25, g5, accumulate,
+                           (char*)ws + cb, ws_bytes - cb, st, (db && bias_side == 1) ? db + c0 : nullptr,
+                           bias_side, &done);
+            if (rc) return rc;
+            if (db && bias_side == 1 && !done) {
+                if (c0 > 0) return BN_E_BADARG;
+                all_done = false;
+                db = nullptr;
+            }
+        }
+        if (bias_done && all_done) *bias_done = true;
+        return 0;
+    }
     if (!generic && bn_qgemm_supported(g)) {
         if (!ws || ws_bytes < bn_qgemm_ws_bytes(2, g)) return BN_E_WORKSPACE;
         BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<2>", st);
@@ -582,6 +691,10 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
             return 0;
         }
     }
+    if (!generic && !plan.supported && bn_col_ok(g)) {
+        BnProfScope prof(family, g.Cb, g.Cs, "k_im2col + k_gemm_mfma (dW)", st);
+        return bn_launch_col_wgrad(small, big, dw, g, accumulate, ws, ws_bytes, st, db, bias_side, bias_done);
+    }
     BnProfScope prof(family, g.Cb, g.Cs, plan.supported ? plan.kernel_name : "k_wgrad_generic",
                      st);
     if (plan.supported) {
@@ -590,6 +703,29 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
                                     bias_done);
     }
     return bn_launch_wgrad_generic(small, big, dw, g, accumulate, st);
+}
+
+// scratch of one role on geometry g (without the bias gradient's)
+static size_t role_ws_need(int role, const BnGeom& g) {
+    BnGeom g5;
+    if (taps_plan(role, g, &g5)) return taps_bytes(g) + role_ws_need(role, g5);
+    if (chan_plan(role, g, &g5)) return chan_bytes(g) + role_ws_need(role, g5);
+    if (bn_qgemm_supported(g)) return bn_qgemm_ws_bytes(role, g);
+    BnFastPlan plan;
+    if (role == 0) plan = bn_fast_down_plan(g);
+    else if (role == 1) plan = bn_fast_up_plan(g);
+    else {
+        plan = bn_edge_wgrad_plan(g);
+        if (!plan.supported) plan = bn_fast_wgrad_plan(g);
+    }
+    if (plan.supported) return plan.ws_bytes;
+    if (role == 0 && bn_s5_down_small_ok(g)) return bn_s5_down_small_ws_bytes(g);
+    const PadPlan pp = pad_plan(role, g);
+    if (pp.ok) return pad_ws_bytes(pp);
+    const TilePlan tp = tile_plan(role, g);
+    if (tp.ok) return tile_ws_bytes(tp);
+    if (bn_col_ok(g)) return bn_col_ws_bytes(g);
+    return 0;
 }
 
 extern "C" size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, int R, int S,
@@ -608,37 +744,9 @@ extern "C" size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, in
     if (op == BN_OP_CONV_BWD_W) bias_ws = bn_channel_sum_ws_bytes(N, K, P * Q);
     if (op == BN_OP_CONVT_BWD_W) bias_ws = bn_channel_sum_ws_bytes(N, K, P * Q);
     if (force_generic()) return bias_ws;
-    if (bn_qgemm_supported(g)) {
-        const int role = (op == BN_OP_CONV_FWD || op == BN_OP_CONVT_BWD_D) ? 0 :
-                         (op == BN_OP_CONV_BWD_D || op == BN_OP_CONVT_FWD) ? 1 : 2;
-        const size_t need = bn_qgemm_ws_bytes(role, g);
-        return need > bias_ws ? need : bias_ws;
-    }
-    BnFastPlan plan;
-    switch (op) {
-        case BN_OP_CONV_FWD: case BN_OP_CONVT_BWD_D: plan = bn_fast_down_plan(g); break;
-        case BN_OP_CONV_BWD_D: case BN_OP_CONVT_FWD: plan = bn_fast_up_plan(g); break;
-        default:
-            plan = bn_edge_wgrad_plan(g);
-            if (!plan.supported) plan = bn_fast_wgrad_plan(g);
-            break;
-    }
-    size_t need = plan.supported ? plan.ws_bytes : 0;
-    if (!plan.supported) {
-        const int role = (op == BN_OP_CONV_FWD || op == BN_OP_CONVT_BWD_D) ? 0 :
-                         (op == BN_OP_CONV_BWD_D || op == BN_OP_CONVT_FWD) ? 1 : 2;
-        if (role == 0 && bn_s5_down_small_ok(g)) {
-            need = bn_s5_down_small_ws_bytes(g);
-        } else {
-            const PadPlan pp = pad_plan(role, g);
-            if (pp.ok) {
-                need = pad_ws_bytes(pp) + (role == 2 ? bias_ws : 0);
-            } else {
-                const TilePlan tp = tile_plan(role, g);
-                if (tp.ok) need = tile_ws_bytes(tp) + (role == 2 ? bias_ws : 0);
-            }
-        }
-    }
+    const int role = (op == BN_OP_CONV_FWD || op == BN_OP_CONVT_BWD_D) ? 0 :
+                     (op == BN_OP_CONV_BWD_D || op == BN_OP_CONVT_FWD) ? 1 : 2;
+    const size_t need = role_ws_need(role, g) + (role == 2 ? bias_ws : 0);
     return need > bias_ws ? need : bias_ws;
 }
 

@@ -95,6 +95,89 @@ int bn_launch_crop2d(const float* src, float* dst, size_t planes, int H, int W, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernels smaller than 5x5 (ae_arch_2.json: 4x4) on the 5x5 stride-2 families: the weights are
+// embedded top-left in 5x5 taps, the added taps are zero.  Same index relation (small pixel p meets
+// big row 2p - pt + r), so every role is exact; the weight gradient of the added taps is dropped.
+// ---------------------------------------------------------------------------------------------
+// w5[pair][5][5] <- w[pair][R][S]
+__global__ __launch_bounds__(PD_THREADS) void k_pad_taps(const float* __restrict__ w,
+                                                          float* __restrict__ w5, unsigned pairs,
+                                                          int R, int S) {
+    const unsigned total = pairs * 25;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned pr = q / 25, t = q - pr * 25;
+        const int r = t / 5, c = t - 5 * r;
+        w5[q] = (r < R && c < S) ? w[pr * (R * S) + r * S + c] : 0.f;
+    }
+}
+// dw[pair][R][S] (+)= dw5[pair][5][5]
+__global__ __launch_bounds__(PD_THREADS) void k_crop_taps(const float* __restrict__ dw5,
+                                                           float* __restrict__ dw, unsigned pairs,
+                                                           int R, int S, int accumulate) {
+    const unsigned total = pairs * R * S;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned pr = q / (R * S), t = q - pr * (R * S);
+        const int r = t / S, c = t - S * r;
+        const float v = dw5[pr * 25 + r * 5 + c];
+        dw[q] = accumulate ? dw[q] + v : v;
+    }
+}
+int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hipStream_t st) {
+    hipLaunchKernelGGL(k_pad_taps, dim3(pd_blocks(pairs * 25)), dim3(PD_THREADS), 0, st, w, w5,
+                       (unsigned)pairs, R, S);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S, int accumulate,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_crop_taps, dim3(pd_blocks(pairs * R * S)), dim3(PD_THREADS), 0, st, dw5, dw,
+                       (unsigned)pairs, R, S, accumulate);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Channel groups: the single-channel edge kernels take up to 32 channels on their many-channel
+// side; a layer with more (ae_arch_2.json: 1 -> 64) is run group by group on contiguous copies
+// (gather-down and weight gradient are independent per small-side channel).
+//   dst[n][c0d + c][i] <- src[n][c0s + c][i] (times act'(dact_src at dst) when given), c < Cg
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PD_THREADS) void k_chan_copy(const float* __restrict__ src,
+                                                           float* __restrict__ dst, unsigned N,
+                                                           unsigned Csrc, unsigned c0s, unsigned Cdst,
+                                                           unsigned c0d, unsigned Cg, unsigned HW4,
+                                                           const float* __restrict__ dact_src, int dact,
+                                                           float slope) {
+    const unsigned total = N * Cg * HW4;                    // 16-byte groups (HW is a multiple of 4)
+    const float4* sp = reinterpret_cast<const float4*>(src);
+    const float4* ap = reinterpret_cast<const float4*>(dact_src);
+    float4* dp = reinterpret_cast<float4*>(dst);
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned i = q % HW4, t = q / HW4;
+        const unsigned c = t % Cg, n = t / Cg;
+        float4 v = sp[(n * Csrc + c0s + c) * HW4 + i];
+        const unsigned o = (n * Cdst + c0d + c) * HW4 + i;
+        if (ap) {
+            const float4 a = ap[o];
+            v.x *= bn_act_grad_from_output(a.x, dact, slope);
+            v.y *= bn_act_grad_from_output(a.y, dact, slope);
+            v.z *= bn_act_grad_from_output(a.z, dact, slope);
+            v.w *= bn_act_grad_from_output(a.w, dact, slope);
+        }
+        dp[o] = v;
+    }
+}
+int bn_launch_chan_copy(const float* src, float* dst, int N, int Csrc, int c0s, int Cdst, int c0d,
+                        int Cg, int HW, const float* dact_src, int dact, float slope, hipStream_t st) {
+    if (HW & 3) return BN_E_BADARG;
+    hipLaunchKernelGGL(k_chan_copy, dim3(pd_blocks((size_t)N * Cg * (HW >> 2))), dim3(PD_THREADS), 0, st,
+                       src, dst, (unsigned)N, (unsigned)Csrc, (unsigned)c0s, (unsigned)Cdst, (unsigned)c0d,
+                       (unsigned)Cg, (unsigned)(HW >> 2), dact_src, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Maps LARGER than the specialised kernels take (small side wider than 32, or 64 for the
 // single-channel edge layers: frames beyond 128 pixels): spatial tiles with halos, every tile a
 // pseudo-frame of the size the kernels are compiled for.
@@ -273,6 +356,199 @@ int bn_launch_s5_down_small(const float* big, const float* w, const float* bias,
     if (rc) return rc;
     hipLaunchKernelGGL(k_s5_rows_to_nchw, dim3(pd_blocks((size_t)rows * g.Cs)), dim3(PD_THREADS), 0, st, tmp,
                        out, dact_src, g.N, g.Cs, PQ, act, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Everything else (kernel sizes up to 9, stride 1, odd channel counts -- what the reference's
+// architecture search draws, ae_arch_2.json's last 4x4 stride-1 layer): im2col + the MFMA GEMM,
+// a few dozen frames per pass so that the column matrix stays below 512 MB.  40 TFLOP/s class
+// against ~1 TFLOP/s for the direct loops of conv_generic.hip.
+//   rows = (n, p, q) of the small side, columns = (c, r, s) of the big side:
+//   down:   out_rows = col W^T               (+ bias, activation, act' mask on the way to NCHW)
+//   wgrad:  dW = small_rows^T col            (reduction over the rows, accumulated over passes)
+//   up:     colg = small_rows W, then every big pixel gathers its <= ceil(R/s) ceil(S/s) terms
+// ---------------------------------------------------------------------------------------------
+#define COL_MAX_BYTES ((size_t)512 << 20)
+
+__global__ __launch_bounds__(PD_THREADS) void k_im2col(const float* __restrict__ big,
+                                                        float* __restrict__ col, BnGeom g, int n0,
+                                                        int nf) {
+    const unsigned PQ = g.Hs * g.Ws, RS = g.R * g.S, K = g.Cb * RS;
+    const unsigned total = (unsigned)nf * PQ * K;
+    for (unsigned i = blockIdx.x * PD_THREADS + threadIdx.x; i < total; i += gridDim.x * PD_THREADS) {
+        const unsigned tap = i % RS;
+        unsigned t = i / RS;
+        const unsigned c = t % g.Cb;
+        t /= g.Cb;
+        const unsigned pq = t % PQ, n = t / PQ;
+        const int p = pq / g.Ws, q = pq - p * g.Ws;
+        const int r = tap / g.S, sx = tap - r * g.S;
+        const int h = g.stride * p + r - g.pt, w = g.stride * q + sx - g.pl;
+        col[i] = (h >= 0 && h < g.Hb && w >= 0 && w < g.Wb)
+            ? big[(((size_t)(n0 + n) * g.Cb + c) * g.Hb + h) * g.Wb + w] : 0.f;
+    }
+}
+
+// rows[(n, pq)][m] <- small[n0 + n][m][pq]
+__global__ __launch_bounds__(PD_THREADS) void k_nchw_to_rows(const float* __restrict__ small,
+                                                              float* __restrict__ rows, int n0, int nf,
+                                                              int M, int PQ) {
+    const unsigned total = (unsigned)nf * M * PQ;
+    for (unsigned i = blockIdx.x * PD_THREADS + threadIdx.x; i < total; i += gridDim.x * PD_THREADS) {
+        const unsigned m = i % M, t = i / M;
+        const unsigned pq = t % PQ, n = t / PQ;
+        rows[i] = small[((size_t)(n0 + n) * M + m) * PQ + pq];
+    }
+}
+
+// out[n0 + n][cb][y][x] = act(bias[cb] + sum over the taps that reach (y, x)) * act'(dact_src)
+__global__ __launch_bounds__(PD_THREADS) void k_col2im(const float* __restrict__ colg,
+                                                        float* __restrict__ out,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ dact_src, BnGeom g,
+                                                        int n0, int nf, int act, int dact,
+                                                        float slope) {
+    const unsigned HW = g.Hb * g.Wb, RS = g.R * g.S, K = g.Cb * RS, PQ = g.Hs * g.Ws;
+    const unsigned total = (unsigned)nf * g.Cb * HW;
+    for (unsigned i = blockIdx.x * PD_THREADS + threadIdx.x; i < total; i += gridDim.x * PD_THREADS) {
+        const unsigned yx = i % HW, t = i / HW;
+        const unsigned cb = t % g.Cb, n = t / g.Cb;
+        const int y = yx / g.Wb, x = yx - y * g.Wb;
+        float v = bias ? bias[cb] : 0.f;
+        for (int r = 0; r < g.R; ++r) {
+            const int pn = y + g.pt - r;
+            if (pn < 0 || pn % g.stride) continue;
+            const int p = pn / g.stride;
+            if (p >= g.Hs) continue;
+            for (int sx = 0; sx < g.S; ++sx) {
+                const int qn = x + g.pl - sx;
+                if (qn < 0 || qn % g.stride) continue;
+                const int q = qn / g.stride;
+                if (q >= g.Ws) continue;
+                v += colg[((size_t)n * PQ + p * g.Ws + q) * K + cb * RS + r * g.S + sx];
+            }
+        }
+        v = bn_apply_act(v, act, slope);
+        const size_t o = (size_t)(n0 + n) * g.Cb * HW + (size_t)cb * HW + yx;
+        if (dact_src) v *= bn_act_grad_from_output(dact_src[o], dact, slope);
+        out[o] = v;
+    }
+}
+
+static int col_frames(const BnGeom& g) {
+    const size_t per = (size_t)g.Hs * g.Ws * g.Cb * g.R * g.S * 4;
+    size_t nb = COL_MAX_BYTES / (per ? per : 1);
+    const size_t rows_cap = ((size_t)1 << 21) / ((size_t)g.Hs * g.Ws);     // GEMM grid: rows / 32 < 65536
+    if (nb > rows_cap) nb = rows_cap;
+    if (nb > (size_t)g.N) nb = g.N;
+    return (int)nb;
+}
+bool bn_col_ok(const BnGeom& g) {
+    if (g.R > 9 || g.S > 9 || g.stride < 1) return false;
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    return col_frames(g) >= 1;
+}
+static size_t col_col_bytes(const BnGeom& g) {
+    return ((size_t)col_frames(g) * g.Hs * g.Ws * g.Cb * g.R * g.S * 4 + 255) & ~(size_t)255;
+}
+static size_t col_rows_bytes(const BnGeom& g) {
+    return ((size_t)col_frames(g) * g.Hs * g.Ws * g.Cs * 4 + 255) & ~(size_t)255;
+}
+size_t bn_col_ws_bytes(const BnGeom& g) {
+    const int rows = col_frames(g) * g.Hs * g.Ws, K = g.Cb * g.R * g.S;
+    size_t gw = bn_gemm_ws_bytes(rows, g.Cs, K);
+    const size_t g2 = bn_gemm_ws_bytes(g.Cs, K, rows), g3 = bn_gemm_ws_bytes(rows, K, g.Cs);
+    if (g2 > gw) gw = g2;
+    if (g3 > gw) gw = g3;
+    return col_col_bytes(g) + col_rows_bytes(g) + gw;
+}
+
+int bn_launch_col_down(const float* big, const float* w, const float* bias, float* out,
+                       const float* dact_src, const BnGeom& g, int act, int dact, float slope, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+    if (!ws || ws_bytes < bn_col_ws_bytes(g)) return BN_E_WORKSPACE;
+    const int PQ = g.Hs * g.Ws, K = g.Cb * g.R * g.S, nb = col_frames(g);
+    float* col = (float*)ws;
+    float* tmp = (float*)((char*)ws + col_col_bytes(g));
+    const size_t used = col_col_bytes(g) + col_rows_bytes(g);
+    for (int n0 = 0; n0 < g.N; n0 += nb) {
+        const int nf = g.N - n0 < nb ? g.N - n0 : nb, rows = nf * PQ;
+        hipLaunchKernelGGL(k_im2col, dim3(pd_blocks((size_t)rows * K)), dim3(PD_THREADS), 0, st, big, col, g, n0, nf);
+        GemmArgs a;                               // tmp[i, m] = b[m] + sum_k col[i, k] W[m, k]
+        a.A = col; a.sai = K; a.sak = 1;
+        a.B = w; a.sbk = 1; a.sbj = K;
+        a.C = tmp; a.sci = g.Cs; a.scj = 1;
+        a.M = rows; a.N = g.Cs; a.K = K;
+        a.bias_j = bias; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = slope; a.accumulate = 0;
+        const int rc = bn_launch_gemm(a, st, (char*)ws + used, ws_bytes - used);
+        if (rc) return rc;
+        const size_t os = (size_t)n0 * g.Cs * PQ;
+        hipLaunchKernelGGL(k_s5_rows_to_nchw, dim3(pd_blocks((size_t)rows * g.Cs)), dim3(PD_THREADS), 0, st, tmp,
+                           out + os, dact_src ? dact_src + os : nullptr, nf, g.Cs, PQ, act, dact, slope);
+    }
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_launch_col_wgrad(const float* small, const float* big, float* dw, const BnGeom& g, int accumulate,
+                        void* ws, size_t ws_bytes, hipStream_t st, float* db, int bias_side,
+                        bool* bias_done) {
+    if (!ws || ws_bytes < bn_col_ws_bytes(g)) return BN_E_WORKSPACE;
+    const int PQ = g.Hs * g.Ws, K = g.Cb * g.R * g.S, nb = col_frames(g);
+    float* col = (float*)ws;
+    float* srows = (float*)((char*)ws + col_col_bytes(g));
+    const size_t used = col_col_bytes(g) + col_rows_bytes(g);
+    for (int n0 = 0; n0 < g.N; n0 += nb) {
+        const int nf = g.N - n0 < nb ? g.N - n0 : nb, rows = nf * PQ;
+        const int acc = (accumulate || n0 > 0) ? 1 : 0;
+        hipLaunchKernelGGL(k_im2col, dim3(pd_blocks((size_t)rows * K)), dim3(PD_THREADS), 0, st, big, col, g, n0, nf);
+        hipLaunchKernelGGL(k_nchw_to_rows, dim3(pd_blocks((size_t)rows * g.Cs)), dim3(PD_THREADS), 0, st, small,
+                           srows, n0, nf, g.Cs, PQ);
+        GemmArgs a;                               // dW[m, k] (+)= sum_i srows[i, m] col[i, k]
+        a.A = srows; a.sai = 1; a.sak = g.Cs;
+        a.B = col; a.sbk = K; a.sbj = 1;
+        a.C = dw; a.sci = K; a.scj = 1;
+        a.M = g.Cs; a.N = K; a.K = rows;
+        a.bias_j = nullptr; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f; a.accumulate = acc;
+        int rc = bn_launch_gemm(a, st, (char*)ws + used, ws_bytes - used);
+        if (rc) return rc;
+        if (db && bias_side == 1) {
+            rc = bn_launch_col_sum(srows, db, rows, g.Cs, acc, st);
+            if (rc) return rc;
+        }
+    }
+    if (db && bias_side == 1 && bias_done) *bias_done = true;
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_launch_col_up(const float* small, const float* w, const float* bias, float* out,
+                     const float* dact_src, const BnGeom& g, int act, int dact, float slope, void* ws,
+                     size_t ws_bytes, hipStream_t st) {
+    if (!ws || ws_bytes < bn_col_ws_bytes(g)) return BN_E_WORKSPACE;
+    const int PQ = g.Hs * g.Ws, K = g.Cb * g.R * g.S, nb = col_frames(g);
+    float* colg = (float*)ws;
+    float* srows = (float*)((char*)ws + col_col_bytes(g));
+    const size_t used = col_col_bytes(g) + col_rows_bytes(g);
+    for (int n0 = 0; n0 < g.N; n0 += nb) {
+        const int nf = g.N - n0 < nb ? g.N - n0 : nb, rows = nf * PQ;
+        hipLaunchKernelGGL(k_nchw_to_rows, dim3(pd_blocks((size_t)rows * g.Cs)), dim3(PD_THREADS), 0, st, small,
+                           srows, n0, nf, g.Cs, PQ);
+        GemmArgs a;                               // colg[i, k] = sum_m srows[i, m] W[m, k]
+        a.A = srows; a.sai = g.Cs; a.sak = 1;
+        a.B = w; a.sbk = K; a.sbj = 1;
+        a.C = colg; a.sci = K; a.scj = 1;
+        a.M = rows; a.N = K; a.K = g.Cs;
+        a.bias_j = nullptr; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f; a.accumulate = 0;
+        const int rc = bn_launch_gemm(a, st, (char*)ws + used, ws_bytes - used);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_col2im, dim3(pd_blocks((size_t)nf * g.Cb * g.Hb * g.Wb)), dim3(PD_THREADS), 0, st,
+                           colg, out, bias, dact_src, g, n0, nf, act, dact, slope);
+    }
     BN_LAUNCH_CHECK();
     return 0;
 }

@@ -196,6 +196,12 @@ def secondary_configs(hp_ae, feed_rates=True):
     out.append(geometry_step(None, [1, 64, 48],
                              'default architecture on 1x64x48 frames (the reference\'s '
                              'tests/integration.py shape)'))
+    out.append(geometry_step(os.path.join(cfg, 'ae_arch_2.json'), [1, 128, 128],
+                             'shipped configs/ae_jsons/ae_arch_2.json (5 layers of 64 channels, k4, '
+                             'strides 2,2,2,2,1) on 1x128x128', names=False))
+    out.append(geometry_step(None, [2, 192, 160],
+                             'default architecture on 2x192x160 frames (maps beyond the tiles of '
+                             'the specialised kernels: spatial tiles with halos)', names=False))
     if feed_rates:
         # --- the headline step fed over PCIe: pinned uint8 trials, one-trial look-ahead
         torch.manual_seed(0)
@@ -270,7 +276,7 @@ def fit_throughput(hp_ae, n_epochs=2):
             'ms_per_trial': round(dt * 1e3 / trials, 3)}
 
 
-def geometry_step(arch_json, dim, label, batch=256):
+def geometry_step(arch_json, dim, label, batch=256, names=True):
     """Training step of an architecture / frame size the specialised kernels were NOT tuned for:
     ms per step and, layer by layer and role by role, the kernel the dispatch chose."""
     from tests.golden_utils import base_hparams, make_frames
@@ -289,7 +295,8 @@ def geometry_step(arch_json, dim, label, batch=256):
         opt.step()
     t = _timed(step, 12, 20)
     kernels = {}
-    for stack, fams in (('encoding', (('fwd', _hip.PROF_CONV_FWD, False), ('bwd_data', _hip.PROF_CONV_BWD_D, True),
+    # (names=False: several layers share a channel pair, the per-layer readout would mix them)
+    for stack, fams in () if not names else (('encoding', (('fwd', _hip.PROF_CONV_FWD, False), ('bwd_data', _hip.PROF_CONV_BWD_D, True),
                                       ('bwd_weight', _hip.PROF_CONV_BWD_W, False))),
                         ('decoding', (('fwd', _hip.PROF_CONVT_FWD, False), ('bwd_data', _hip.PROF_CONVT_BWD_D, True),
                                       ('bwd_weight', _hip.PROF_CONVT_BWD_W, True)))):

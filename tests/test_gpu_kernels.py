@@ -81,6 +81,14 @@ CONV_CASES = [
     ('tile_odd_pl2', 2, 32, 93, 71, 64, 5, 2, (1, 2), (2, 2)),
     ('tile_E0_96x80', 2, 1, 192, 160, 32, 5, 2, (1, 2), (1, 2)),
     ('tile_E0c2_80x128', 2, 2, 160, 256, 32, 5, 2, (1, 2), (1, 2)),
+    # kernels smaller than 5x5 on the 5x5 families (zero taps added): ae_arch_2.json's 4x4 layers
+    ('k4_64ch_32x32', 3, 64, 64, 64, 64, 4, 2, (1, 1), (1, 1)),
+    ('k4_64ch_8x8', 3, 64, 16, 16, 64, 4, 2, (1, 1), (1, 1)),
+    ('k3_16x16', 2, 32, 32, 32, 64, 3, 2, (1, 1), (1, 1)),
+    ('k4x3_24x20', 2, 32, 48, 40, 64, 4, 2, (1, 1), (1, 1)),
+    # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
+    ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
+    ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
 ]
 
 
@@ -164,6 +172,10 @@ CONVT_CASES = [
     ('tile_47x36_pt2', 2, 64, 47, 36, 32, 5, 2, 0, (1, 2, 2, 2), 0),
     ('tile_D4_96x80', 2, 32, 96, 80, 1, 5, 2, 0, (1, 2, 1, 2), 0),
     ('tile_D4c2_80x128', 2, 32, 80, 128, 2, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('k4_64ch_16x16', 3, 64, 16, 16, 64, 4, 2, 0, (1, 1, 1, 1), 0),
+    ('k3_8x8', 2, 128, 8, 8, 64, 3, 2, 0, (1, 0, 1, 0), 0),
+    ('D4_64ch', 2, 64, 64, 64, 1, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('D4_k4_64ch', 2, 64, 64, 64, 1, 4, 2, 0, (1, 1, 1, 1), 0),
 ]
 
 
@@ -618,7 +630,8 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
 
 @pytest.mark.parametrize('case_name, want', [
     ('tile_48x40', 'on zero-padded 64x64'), ('tile_100x24', 'on zero-padded 128x32'),
-    ('tile_E0_96x80', 'on 2x2 tiles of 64x64'), ('pad_24x20', 'on zero-padded 32x32')])
+    ('tile_E0_96x80', 'on 2x2 tiles of 64x64'), ('pad_24x20', 'on zero-padded 32x32'),
+    ('k4_64ch_32x32', 'mfma'), ('k4x3_24x20', 'on zero-padded 32x32')])
 def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, want):
     """The dispatch takes the tiled / zero-padded detour (conv_pad.hip), not the direct loops."""
     case = [c for c in CONV_CASES if c[0] == case_name][0]
@@ -645,4 +658,4 @@ def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, wan
             _, n, name = _hip.prof_read()
         finally:
             _hip.prof_select(_hip.PROF_NONE)
-        assert n >= 1 and ('tiles of' in name or 'zero-padded' in name), name
+        assert n >= 1 and ('tiles of' in name or 'zero-padded' in name or 'mfma' in name), name
