@@ -276,6 +276,49 @@ def fit_throughput(hp_ae, n_epochs=2):
             'ms_per_trial': round(dt * 1e3 / trials, 3)}
 
 
+def live_hbm_traffic(kernel_substr='k_down_c1p', timeout_s=150):
+    """HBM bytes per launch of the roofline kernel from the PMC counters, collected NOW: two separate
+    `rocprofv3 --kernel-trace --pmc` passes (FETCH_SIZE, WRITE_SIZE; MI355X_MICROARCH.md: KB units,
+    FETCH_SIZE doubled on gfx950) over tools/run_layer.py (enc.conv0 forward, 256 frames per launch),
+    as child processes -- counters cannot be collected from inside this process.
+    -> (bytes or None, {'FETCH_SIZE_KB', 'WRITE_SIZE_KB', 'launches'} or the reason it failed)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    got = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='bn_pmc_', dir='/tmp')
+        cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'run',
+               '--', sys.executable, os.path.join(REPO, 'tools', 'run_layer.py'), '--layer', 'E0',
+               '--op', 'fwd', '--n', str(BATCH), '--iters', '6']
+        try:
+            subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+            files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            vals = []
+            for f in files:
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r.get('Counter_Name') == counter and kernel_substr in r.get('Kernel_Name', ''):
+                            vals.append(float(r['Counter_Value']))
+        except Exception as err:                                    # noqa: BLE001
+            return None, '%s pass failed: %s' % (counter, err)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        if len(vals) < 3:
+            return None, '%s pass: %d launches of %s found' % (counter, len(vals), kernel_substr)
+        got[counter] = sum(vals[1:]) / len(vals[1:])            # (first launch: cold caches)
+        got['launches'] = len(vals)
+    info = {'FETCH_SIZE_KB': round(got['FETCH_SIZE'], 1), 'WRITE_SIZE_KB': round(got['WRITE_SIZE'], 1),
+            'launches': got['launches']}
+    return (2.0 * got['FETCH_SIZE'] + got['WRITE_SIZE']) * 1024.0, info
+
+
 def geometry_step(arch_json, dim, label, batch=256, names=True):
     """Training step of an architecture / frame size the specialised kernels were NOT tuned for:
     ms per step and, layer by layer and role by role, the kernel the dispatch chose."""
@@ -388,6 +431,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true',
+                    help='skip the live rocprofv3 --pmc passes behind roofline.traffic')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the secondary configs (PS-VAE, encode-only, PCIe-fed)')
     ap.add_argument('--feed', default='device', choices=['device', 'device_u8', 'host_u8', 'host'],
@@ -535,10 +580,26 @@ def main():
     conv0_bytes = CONV0_BYTES_PER_FRAME * conv0_frames * args.steps
     achieved = conv0_bytes / (conv0_ms * 1e-3) / 1e9 if conv0_ms > 0 else 0.0
     traffic = None
-    tr_path = os.path.join(REPO, 'profiles', 'conv0_hbm_traffic.json')
-    if os.path.exists(tr_path):
-        with open(tr_path) as f:
-            traffic = json.load(f).get('hbm_bytes_per_launch_avg')
+    traffic_source = None
+    # (not in the reduced runs of the tools / tests, which may themselves sit under rocprofv3)
+    if rank == 0 and world == 1 and not args.no_pmc and not args.no_secondary:
+        traffic, info = live_hbm_traffic()
+        if traffic is not None:
+            traffic_source = ('measured in this run: two child processes `rocprofv3 --kernel-trace --pmc '
+                              'FETCH_SIZE` / `--pmc WRITE_SIZE` over tools/run_layer.py (enc.conv0 forward, '
+                              '%d frames per launch, mean of %d launches after the first): 2 x %.1f KB + '
+                              '%.1f KB' % (BATCH, info['launches'] - 1, info['FETCH_SIZE_KB'],
+                                           info['WRITE_SIZE_KB']))
+        else:
+            traffic_source = 'live PMC pass unavailable (%s); ' % info
+    if traffic is None:
+        tr_path = os.path.join(REPO, 'profiles', 'conv0_hbm_traffic.json')
+        if os.path.exists(tr_path):
+            with open(tr_path) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch_avg')
+        traffic_source = (traffic_source or '') + (
+            'profiles/conv0_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over '
+            'tools/run_layer.py (tools/pmc_hbm.sh), same kernel, 256 frames per launch')
     roofline = {
         'bound': 'hbm', 'kernel': conv0_name, 'layer': 'enc.conv0 fwd (1->32, k5 s2, +bias+lrelu)',
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -546,9 +607,7 @@ def main():
         'launches': conv0_n, 'avg_launch_us': round(conv0_ms * 1e3 / max(conv0_n, 1), 2),
         'algorithmic_bytes_per_launch_avg': int(conv0_bytes // max(conv0_n, 1)),
         'traffic': traffic,
-        'traffic_source': 'profiles/conv0_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes '
-                          'over tools/run_layer.py (tools/pmc_hbm.sh), same kernel, 256 frames per launch; '
-                          'counters cannot be collected from inside this process',
+        'traffic_source': traffic_source,
         # what the same dispatch-attached events read around an EMPTY kernel: avg_launch_us is the
         # raw interval (not corrected); rocprofv3's kernel timestamps come out ~1.5-2 us lower
         'event_interval_of_empty_kernel_us': round(float(_hip.load().bn_prof_dispatch_overhead_us(
