@@ -587,6 +587,14 @@ if __name__ == '__main__':
         model_case('ae_valid_1x30x26', RefAE, [1, 30, 26], 6, 12, 'ae', arch_json='arch_valid.json')
         model_case('ae_maxpool', RefAE, [1, 32, 32], 8, 12, 'ae', arch_json='arch_maxpool.json')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'arch2':
+        # the second shipped architecture (configs/ae_jsons/ae_arch_2.json: five 64-channel layers of
+        # 4x4 kernels, strides 2,2,2,2,1) on 1x128x128 frames
+        model_case('ae_arch2_1x128x128', RefAE, [1, 128, 128], 12, 6, 'ae',
+                   arch_json='../../behavenet_amd/configs/ae_jsons/ae_arch_2.json')
+        # two-camera frames larger than the tiles of the specialised kernels (default architecture)
+        model_case('ae_2x192x160', RefAE, [2, 192, 160], 12, 4, 'ae')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'maxpool_valid':
         # MaxPool2d(ceil_mode=False) / odd pre-pool sizes (aes.py:173-178): 30x26 -> 26x22 -> 13x11
         # -> 9x7 -> 4x3 (the pools drop the last row / column)

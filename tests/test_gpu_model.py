@@ -88,7 +88,7 @@ def _assert_grads_on_device_branches(hip, meta, data_c, data_g, dataset, name):
 
 CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc_cfg1',
          'condvae_cfg1', 'psvae_cfg4', 'ae_cfg1_bn', 'ae_cfg1_bn_b210', 'vae_1x64x48_bn', 'ae_cfg1_lastff', 'aemsp_cfg1',
-         'condae_cfg1', 'condae_enc_cfg1', 'ae_sessio_masks', 'ae_linear', 'ae_valid_1x30x26', 'ae_maxpool',
+         'condae_cfg1', 'condae_enc_cfg1', 'ae_sessio_masks', 'ae_linear', 'ae_valid_1x30x26', 'ae_arch2_1x128x128', 'ae_2x192x160', 'ae_maxpool',
          'ae_maxpool_valid']
 
 
