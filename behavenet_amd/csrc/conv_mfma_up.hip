@@ -566,7 +566,10 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
     p.c = cc;
     p.kernel_name = p.a == 2 ? (cc == 8 ? "k_up_mfma<2, 8>" : "k_up_mfma<2, 4>")
                              : (cc == 8 ? "k_up_mfma<1, 8>" : "k_up_mfma<1, 4>");
-    if (p.a == 1 && up2_ok(g, &p.c)) {
+    // the streamlined kernel wherever it applies (round 3: 64-channel big sides used to take the
+    // two-block first-generation kernel once the grid was large: 530 against 2 x 206 us)
+    if ((p.a == 1 || (ok1 && env_mr != 2)) && up2_ok(g, &p.c)) {
+        p.a = 1;
         p.variant = 2;
         const int lgw = ilog2_exact_up(g.Ws);
         static const char* const n4[6] = {"", "", "", "k_up2_mfma<3, 4>", "k_up2_mfma<4, 4>", "k_up2_mfma<5, 4>"};
