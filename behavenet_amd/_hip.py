@@ -52,6 +52,12 @@ SIGNATURES = {
     'bn_batchnorm_stats': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
     'bn_batchnorm_finalize': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_float] * 3 + [_c_void_p]),
     'bn_batchnorm_act_fwd': (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_float, _c_void_p]),
+    'bn_batchnorm_train_fwd_chunks': (
+        _c_int, [_c_void_p] * 10 + [_c_int] * 3 + [_c_float, _c_int, _c_float, _c_void_p, _c_size_t,
+                                                  _c_void_p]),
+    'bn_batchnorm_act_bwd_chunks': (
+        _c_int, [_c_void_p] * 9 + [_c_int, _c_void_p] + [_c_int] * 4 + [_c_float, _c_void_p, _c_size_t,
+                                                                       _c_void_p]),
     'bn_batchnorm_act_bwd': (
         _c_int, [_c_void_p] * 9 + [_c_int] * 6 + [_c_float, _c_void_p, _c_size_t, _c_void_p]),
     'bn_batchnorm_moment': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
@@ -273,8 +279,9 @@ def _bn_ws(n, c, device):
     return buf.data_ptr(), nbytes
 
 
-def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope):
-    """-> (y, mean, invstd); updates the running statistics in place (train mode)."""
+def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, y=None):
+    """-> (y, mean, invstd); updates the running statistics in place (train mode).  ``y``: where to
+    write the result (a contiguous slice of a larger batch)."""
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
     mean = torch.empty((c,), dtype=torch.float32, device=x.device)
@@ -290,12 +297,54 @@ def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps
         _ptr(running_mean, 'running_mean', allow_none=True),
         _ptr(running_var, 'running_var', allow_none=True), c, eps, momentum, unbias, _stream()),
         'bn_batchnorm_finalize')
-    y = torch.empty_like(x)
+    if y is None:
+        y = torch.empty_like(x)
     _check(load().bn_batchnorm_act_fwd(
         _ptr(x, 'x'), _ptr(mean, 'mean'), _ptr(invstd, 'invstd'),
         _ptr(gamma, 'gamma', allow_none=True), _ptr(beta, 'beta', allow_none=True), _ptr(y, 'y'),
         n, c, hw, act, slope, _stream()), 'bn_batchnorm_act_fwd')
     return y, mean, invstd
+
+
+def batchnorm_train_fwd_chunks(x, gamma, beta, running_mean, running_var, factors, eps, act, slope,
+                               bounds):
+    """Train-mode batch norm with statistics per chunk of frames (``bounds``: [(beg, end)] in order,
+    ``factors``: the running-estimate factor of every chunk's update).  One library call.
+    -> (y, mean (n_chunks, C), invstd (n_chunks, C))."""
+    import ctypes
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    k = len(bounds)
+    mean = torch.empty((k, c), dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    y = torch.empty_like(x)
+    ws, nb = _bn_ws(max(e - b for b, e in bounds), c, x.device)
+    flat = (ctypes.c_int * (2 * k))(*[v for be in bounds for v in be])
+    fac = (ctypes.c_float * k)(*[float(f) for f in factors])
+    _check(load().bn_batchnorm_train_fwd_chunks(
+        _ptr(x, 'x'), _ptr(gamma, 'gamma', allow_none=True), _ptr(beta, 'beta', allow_none=True),
+        _ptr(running_mean, 'running_mean', allow_none=True),
+        _ptr(running_var, 'running_var', allow_none=True), _ptr(y, 'y'), _ptr(mean, 'mean'),
+        _ptr(invstd, 'invstd'), ctypes.cast(flat, ctypes.c_void_p), ctypes.cast(fac, ctypes.c_void_p),
+        k, c, hw, eps, act, slope, ws, nb, _stream()), 'bn_batchnorm_train_fwd_chunks')
+    return y, mean, invstd
+
+
+def batchnorm_bwd_chunks(x, y, dy, mean, invstd, gamma, dgamma, dbeta, accumulate, act, slope, bounds):
+    import ctypes
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    k = len(bounds)
+    dx = torch.empty_like(x)
+    ws, nb = _bn_ws(max(e - b for b, e in bounds), c, x.device)
+    flat = (ctypes.c_int * (2 * k))(*[v for be in bounds for v in be])
+    _check(load().bn_batchnorm_act_bwd_chunks(
+        _ptr(x, 'x'), _ptr(y, 'y'), _ptr(dy, 'dy'), _ptr(mean, 'mean'), _ptr(invstd, 'invstd'),
+        _ptr(gamma, 'gamma', allow_none=True), _ptr(dx, 'dx'),
+        _ptr(dgamma, 'dgamma', allow_none=True), _ptr(dbeta, 'dbeta', allow_none=True),
+        int(accumulate), ctypes.cast(flat, ctypes.c_void_p), k, c, hw, act, slope, ws, nb, _stream()),
+        'bn_batchnorm_act_bwd_chunks')
+    return dx
 
 
 def batchnorm_eval_fwd(x, gamma, beta, running_mean, running_var, eps, act, slope):
@@ -314,10 +363,11 @@ def batchnorm_eval_fwd(x, gamma, beta, running_mean, running_var, eps, act, slop
 
 
 def batchnorm_bwd(x, y, dy, mean, invstd, gamma, dgamma, dbeta, accumulate, batch_stats, act,
-                  slope):
+                  slope, dx=None):
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
-    dx = torch.empty_like(x)
+    if dx is None:
+        dx = torch.empty_like(x)
     ws, nb = _bn_ws(n, c, x.device)
     _check(load().bn_batchnorm_act_bwd(
         _ptr(x, 'x'), _ptr(y, 'y'), _ptr(dy, 'dy'), _ptr(mean, 'mean'), _ptr(invstd, 'invstd'),

@@ -20,7 +20,10 @@ __device__ __forceinline__ float bnk_block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// part[c][sp] = sum over frames [n_beg, n_end) and pixels of (x - shift[c])^p   (p = 1 or 2)
+// part[c][sp] = sum over frames [n_beg, n_end) and pixels of (x - shift[c])^p   (p = 1 or 2).
+// The (frame, pixel) pairs of a slice are walked as ONE index range: with a loop over frames
+// around a loop over pixels the 2x2 maps of the deepest layer kept 4 of 256 threads busy for 100
+// dependent iterations (80-100 us for 400 KB; round 3).
 template <int POW>
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_moment_part(
     const float* __restrict__ x, const float* __restrict__ shift, float* __restrict__ part, int N,
@@ -29,26 +32,38 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_moment_part(
     const int c = blockIdx.x, sp = blockIdx.y;
     const int n_beg = (int)((long)sp * N / S), n_end = (int)((long)(sp + 1) * N / S);
     const float sh = shift ? shift[c] : 0.f;
-    float acc = 0.f;
+    float acc = 0.f, acc2 = 0.f;
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);
-    for (int n = n_beg; n < n_end; ++n) {
-        const float* xp = x + ((size_t)n * C + c) * HW;
-        if (vec) {
-            const float4* x4 = reinterpret_cast<const float4*>(xp);
-            for (int i = threadIdx.x; i < (HW >> 2); i += BNK_THREADS) {
-                float4 v = x4[i];
-                v.x -= sh; v.y -= sh; v.z -= sh; v.w -= sh;
-                if (POW == 2) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
-                acc += (v.x + v.y) + (v.z + v.w);
+    if (vec) {
+        const unsigned hw4 = HW >> 2, cnt = (unsigned)(n_end - n_beg) * hw4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (unsigned e = threadIdx.x; e < cnt; e += 2 * BNK_THREADS) {
+            const unsigned e2 = e + BNK_THREADS;
+            const unsigned n = e / hw4, i = e - n * hw4;
+            float4 v = x4[((size_t)(n_beg + n) * C + c) * hw4 + i];
+            float4 w = make_float4(sh, sh, sh, sh);
+            if (e2 < cnt) {
+                const unsigned n2 = e2 / hw4, i2 = e2 - n2 * hw4;
+                w = x4[((size_t)(n_beg + n2) * C + c) * hw4 + i2];
             }
-        } else {
-            for (int i = threadIdx.x; i < HW; i += BNK_THREADS) {
-                float v = xp[i] - sh;
-                acc += POW == 2 ? v * v : v;
+            v.x -= sh; v.y -= sh; v.z -= sh; v.w -= sh;
+            w.x -= sh; w.y -= sh; w.z -= sh; w.w -= sh;
+            if (POW == 2) {
+                v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w;
+                w.x *= w.x; w.y *= w.y; w.z *= w.z; w.w *= w.w;
             }
+            acc += (v.x + v.y) + (v.z + v.w);
+            acc2 += (w.x + w.y) + (w.z + w.w);
+        }
+    } else {
+        const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
+        for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
+            const unsigned n = e / HW, i = e - n * HW;
+            const float v = x[((size_t)(n_beg + n) * C + c) * HW + i] - sh;
+            acc += POW == 2 ? v * v : v;
         }
     }
-    const float s = bnk_block_sum(acc, red);
+    const float s = bnk_block_sum(acc + acc2, red);
     if (threadIdx.x == 0) part[(size_t)c * S + sp] = s;
 }
 
@@ -77,37 +92,39 @@ __global__ void k_bn_finalize(const float* __restrict__ mean, const float* __res
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * unbias;
 }
 
-// y = act( (x - mean) * invstd * gamma + beta )
+static int bnk_flat_blocks(size_t n) {
+    const size_t b = (n + BNK_THREADS - 1) / BNK_THREADS;
+    return (int)(b < 16384 ? (b ? b : 1) : 16384);
+}
+
+// y = act( (x - mean) * invstd * gamma + beta ), flat over all (frame, channel, pixel group)s: a
+// workgroup per (frame, channel) left 252 of 256 threads idle on the 2x2 maps
+template <int VEC>
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int C,
-    int HW, int act, float slope) {
-    const int nc = blockIdx.x;           // n * C + c
-    const int c = nc % C;
-    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
-    const float* xp = x + (size_t)nc * HW;
-    float* yp = y + (size_t)nc * HW;
-    if ((HW & 3) == 0 && (((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0)) {
-        const float4* x4 = reinterpret_cast<const float4*>(xp);
-        float4* y4 = reinterpret_cast<float4*>(yp);
-        for (int i = threadIdx.x; i < (HW >> 2); i += BNK_THREADS) {
-            const float4 v = x4[i];
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+    unsigned NC, int C, int HW, int act, float slope) {
+    const unsigned hwv = HW / VEC, total = NC * hwv;
+    for (unsigned e = blockIdx.x * BNK_THREADS + threadIdx.x; e < total; e += gridDim.x * BNK_THREADS) {
+        const int c = (e / hwv) % C;
+        const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+        const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+        if (VEC == 4) {
+            const float4 v = reinterpret_cast<const float4*>(x)[e];
             float4 o;
             o.x = bn_apply_act(fmaf(v.x, sc, sh), act, slope);
             o.y = bn_apply_act(fmaf(v.y, sc, sh), act, slope);
             o.z = bn_apply_act(fmaf(v.z, sc, sh), act, slope);
             o.w = bn_apply_act(fmaf(v.w, sc, sh), act, slope);
-            y4[i] = o;
+            reinterpret_cast<float4*>(y)[e] = o;
+        } else {
+            y[e] = bn_apply_act(fmaf(x[e], sc, sh), act, slope);
         }
-    } else {
-        for (int i = threadIdx.x; i < HW; i += BNK_THREADS)
-            yp[i] = bn_apply_act(fmaf(xp[i], sc, sh), act, slope);
     }
 }
 
 // backward reductions: part0[c][sp] = sum dz, part1[c][sp] = sum dz * xhat,
-// dz = dy * act'(y), xhat = (x - mean) * invstd
+// dz = dy * act'(y), xhat = (x - mean) * invstd   (one index range per slice, see above)
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ part0,
@@ -117,12 +134,33 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     const int n_beg = (int)((long)sp * N / S), n_end = (int)((long)(sp + 1) * N / S);
     const float m = mean[c], is = invstd[c];
     float a0 = 0.f, a1 = 0.f;
-    for (int n = n_beg; n < n_end; ++n) {
-        const size_t base = ((size_t)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += BNK_THREADS) {
-            const float dz = dy[base + i] * bn_act_grad_from_output(y[base + i], act, slope);
+    const bool vec = (HW & 3) == 0 &&
+                     (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy)) & 15u) == 0);
+    if (vec) {
+        const unsigned hw4 = HW >> 2, cnt = (unsigned)(n_end - n_beg) * hw4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const float4* y4 = reinterpret_cast<const float4*>(y);
+        const float4* d4 = reinterpret_cast<const float4*>(dy);
+        for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
+            const unsigned n = e / hw4, i = e - n * hw4;
+            const size_t o = ((size_t)(n_beg + n) * C + c) * hw4 + i;
+            const float4 xv = x4[o], yv = y4[o], dv = d4[o];
+            const float z0 = dv.x * bn_act_grad_from_output(yv.x, act, slope);
+            const float z1 = dv.y * bn_act_grad_from_output(yv.y, act, slope);
+            const float z2 = dv.z * bn_act_grad_from_output(yv.z, act, slope);
+            const float z3 = dv.w * bn_act_grad_from_output(yv.w, act, slope);
+            a0 += (z0 + z1) + (z2 + z3);
+            a1 += (z0 * ((xv.x - m) * is) + z1 * ((xv.y - m) * is)) +
+                  (z2 * ((xv.z - m) * is) + z3 * ((xv.w - m) * is));
+        }
+    } else {
+        const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
+        for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
+            const unsigned n = e / HW, i = e - n * HW;
+            const size_t o = ((size_t)(n_beg + n) * C + c) * HW + i;
+            const float dz = dy[o] * bn_act_grad_from_output(y[o], act, slope);
             a0 += dz;
-            a1 += dz * ((x[base + i] - m) * is);
+            a1 += dz * ((x[o] - m) * is);
         }
     }
     const float s0 = bnk_block_sum(a0, red);
@@ -133,33 +171,54 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     }
 }
 
-// dx = gamma * invstd * (dz - dbeta/n - xhat * dgamma/n);  dgamma/dbeta (+)= the sums
+// both sums of the backward pass and the parameter gradients in one launch (they were three)
+__global__ void k_bn_bwd_combine(const float* __restrict__ part0, const float* __restrict__ part1,
+                                 float* __restrict__ sum0, float* __restrict__ sum1,
+                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int S,
+                                 int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) {
+        v0 += part0[(size_t)c * S + s];
+        v1 += part1[(size_t)c * S + s];
+    }
+    sum0[c] = v0;
+    sum1[c] = v1;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + v1 : v1;
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + v0 : v0;
+}
+
+// dx = gamma * invstd * (dz - dbeta/n - xhat * dgamma/n), flat like the forward
+template <int VEC>
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ sum_dz,
-    const float* __restrict__ sum_dzx, float* __restrict__ dx, int C, int HW, float inv_n, int act,
-    float slope) {
-    const int nc = blockIdx.x;
-    const int c = nc % C;
-    const float m = mean[c], is = invstd[c];
-    const float g = (gamma ? gamma[c] : 1.f) * is;
-    const float k0 = sum_dz[c] * inv_n, k1 = sum_dzx[c] * inv_n;
-    const size_t base = (size_t)nc * HW;
-    for (int i = threadIdx.x; i < HW; i += BNK_THREADS) {
-        const float dz = dy[base + i] * bn_act_grad_from_output(y[base + i], act, slope);
-        const float xh = (x[base + i] - m) * is;
-        dx[base + i] = g * (dz - k0 - xh * k1);
+    const float* __restrict__ sum_dzx, float* __restrict__ dx, unsigned NC, int C, int HW,
+    float inv_n, int act, float slope) {
+    const unsigned hwv = HW / VEC, total = NC * hwv;
+    for (unsigned e = blockIdx.x * BNK_THREADS + threadIdx.x; e < total; e += gridDim.x * BNK_THREADS) {
+        const int c = (e / hwv) % C;
+        const float m = mean[c], is = invstd[c];
+        const float g = (gamma ? gamma[c] : 1.f) * is;
+        const float k0 = sum_dz[c] * inv_n, k1 = sum_dzx[c] * inv_n;
+        if (VEC == 4) {
+            const float4 xv = reinterpret_cast<const float4*>(x)[e];
+            const float4 yv = reinterpret_cast<const float4*>(y)[e];
+            const float4 dv = reinterpret_cast<const float4*>(dy)[e];
+            float4 o;
+            o.x = g * (dv.x * bn_act_grad_from_output(yv.x, act, slope) - k0 - ((xv.x - m) * is) * k1);
+            o.y = g * (dv.y * bn_act_grad_from_output(yv.y, act, slope) - k0 - ((xv.y - m) * is) * k1);
+            o.z = g * (dv.z * bn_act_grad_from_output(yv.z, act, slope) - k0 - ((xv.z - m) * is) * k1);
+            o.w = g * (dv.w * bn_act_grad_from_output(yv.w, act, slope) - k0 - ((xv.w - m) * is) * k1);
+            reinterpret_cast<float4*>(dx)[e] = o;
+        } else {
+            const float dz = dy[e] * bn_act_grad_from_output(y[e], act, slope);
+            dx[e] = g * (dz - k0 - ((x[e] - m) * is) * k1);
+        }
     }
-}
-
-__global__ void k_bn_param_grads(const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx,
-                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int C,
-                                 int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + sum_dzx[c] : sum_dzx[c];
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + sum_dz[c] : sum_dz[c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,8 +261,13 @@ int bn_launch_bn_finalize(const float* mean, const float* var, float* invstd, fl
 int bn_launch_bn_act_fwd(const float* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, float* y, int N, int C, int HW,
                          int act, float slope, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_act_fwd, dim3(N * C), dim3(BNK_THREADS), 0, st, x, mean, invstd, gamma,
-                       beta, y, C, HW, act, slope);
+    if ((size_t)N * C * HW >= 0xffffffffull) return BN_E_SHAPE;
+    if ((HW & 3) == 0 && (((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0))
+        hipLaunchKernelGGL(k_bn_act_fwd<4>, dim3(bnk_flat_blocks((size_t)N * C * (HW >> 2))), dim3(BNK_THREADS),
+                           0, st, x, mean, invstd, gamma, beta, y, (unsigned)(N * C), C, HW, act, slope);
+    else
+        hipLaunchKernelGGL(k_bn_act_fwd<1>, dim3(bnk_flat_blocks((size_t)N * C * HW)), dim3(BNK_THREADS), 0,
+                           st, x, mean, invstd, gamma, beta, y, (unsigned)(N * C), C, HW, act, slope);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -219,15 +283,11 @@ int bn_launch_bn_act_bwd(const float* x, const float* y, const float* dy, const 
     float* sum1 = sum0 + C;
     hipLaunchKernelGGL(k_bn_bwd_part, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
                        part0, part1, N, C, HW, S, act, slope);
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, sum0, C, S, 1.0f);
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part1, sum1, C, S, 1.0f);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(N * C), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
-                       gamma, sum0, sum1, dx, C, HW,
-                       batch_stats ? 1.0f / ((float)N * (float)HW) : 0.0f, act, slope);
-    hipLaunchKernelGGL(k_bn_param_grads, dim3((C + 63) / 64), dim3(64), 0, st, sum0, sum1, dgamma,
-                       dbeta, C, accumulate);
+    hipLaunchKernelGGL(k_bn_bwd_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, part1, sum0, sum1,
+                       dgamma, dbeta, C, S, accumulate);
     BN_LAUNCH_CHECK();
-    return 0;
+    return bn_launch_bn_bwd_apply(x, y, dy, mean, invstd, gamma, sum0, sum1, dx, N, C, HW,
+                                  batch_stats ? 1.0f / ((float)N * (float)HW) : 0.0f, act, slope, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -271,8 +331,16 @@ int bn_launch_bn_bwd_apply(const float* x, const float* y, const float* dy, cons
                            const float* invstd, const float* gamma, const float* sum_dz,
                            const float* sum_dzx, float* dx, int N, int C, int HW, float inv_count,
                            int act, float slope, hipStream_t st) {
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(N * C), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
-                       gamma, sum_dz, sum_dzx, dx, C, HW, inv_count, act, slope);
+    if ((size_t)N * C * HW >= 0xffffffffull) return BN_E_SHAPE;
+    if ((HW & 3) == 0 &&
+        (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15u) == 0))
+        hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3(bnk_flat_blocks((size_t)N * C * (HW >> 2))),
+                           dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx,
+                           (unsigned)(N * C), C, HW, inv_count, act, slope);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3(bnk_flat_blocks((size_t)N * C * HW)), dim3(BNK_THREADS),
+                           0, st, x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx, (unsigned)(N * C), C,
+                           HW, inv_count, act, slope);
     BN_LAUNCH_CHECK();
     return 0;
 }

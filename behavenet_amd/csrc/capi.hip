@@ -925,6 +925,62 @@ extern "C" int bn_batchnorm_act_bwd(const float* x, const float* y, const float*
                                 batch_stats, N, C, HW, act, slope, ws, (hipStream_t)stream);
 }
 
+// Train-mode BatchNorm2d + activation over a batch whose statistics are taken PER CHUNK of frames
+// (rows [bounds[2i], bounds[2i+1]) of x, in order; the running estimates see one update per chunk
+// with factors[i]): one call per layer instead of three per chunk.  mean / invstd: [n_chunks][C].
+extern "C" int bn_batchnorm_train_fwd_chunks(const float* x, const float* gamma, const float* beta,
+                                             float* running_mean, float* running_var, float* y,
+                                             float* mean, float* invstd, const int* bounds,
+                                             const float* factors, int n_chunks, int C, int HW,
+                                             float eps, int act, float slope, void* ws,
+                                             size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !y || !mean || !invstd || !bounds || n_chunks <= 0 || C <= 0 || HW <= 0) return BN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n_chunks; ++i) {
+        const int b = bounds[2 * i], n = bounds[2 * i + 1] - b;
+        if (n <= 0 || b < 0) return BN_E_BADARG;
+        // var: the tail of the scratch (behind the two partial arrays, where the backward pass keeps its sums)
+        if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(n, C)) return BN_E_WORKSPACE;
+        float* var = (float*)((char*)ws + bn_batchnorm_ws_bytes_impl(n, C)) - 2 * C;
+        const float* xc = x + (size_t)b * C * HW;
+        int rc = bn_launch_bn_stats(xc, mean + (size_t)i * C, var, n, C, HW, ws, st);
+        if (rc) return rc;
+        const double cnt = (double)n * HW;
+        rc = bn_launch_bn_finalize(mean + (size_t)i * C, var, invstd + (size_t)i * C, running_mean, running_var,
+                                   C, eps, factors ? factors[i] : 0.f,
+                                   cnt > 1 ? (float)(cnt / (cnt - 1.0)) : 1.f, st);
+        if (rc) return rc;
+        rc = bn_launch_bn_act_fwd(xc, mean + (size_t)i * C, invstd + (size_t)i * C, gamma, beta,
+                                  y + (size_t)b * C * HW, n, C, HW, act, slope, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// the backward pass of the same: dgamma / dbeta are accumulated over the chunks (accumulate = 0:
+// they are overwritten by the first chunk)
+extern "C" int bn_batchnorm_act_bwd_chunks(const float* x, const float* y, const float* dy,
+                                           const float* mean, const float* invstd,
+                                           const float* gamma, float* dx, float* dgamma,
+                                           float* dbeta, int accumulate, const int* bounds,
+                                           int n_chunks, int C, int HW, int act, float slope,
+                                           void* ws, size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !y || !dy || !mean || !invstd || !dx || !bounds || n_chunks <= 0 || C <= 0 || HW <= 0)
+        return BN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < n_chunks; ++i) {
+        const int b = bounds[2 * i], n = bounds[2 * i + 1] - b;
+        if (n <= 0 || b < 0) return BN_E_BADARG;
+        if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(n, C)) return BN_E_WORKSPACE;
+        const size_t o = (size_t)b * C * HW;
+        const int rc = bn_launch_bn_act_bwd(x + o, y + o, dy + o, mean + (size_t)i * C, invstd + (size_t)i * C,
+                                            gamma, dx + o, dgamma, dbeta, (accumulate || i > 0) ? 1 : 0, 1, n,
+                                            C, HW, act, slope, ws, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int bn_batchnorm_moment(const float* x, const float* center, float* sums, int N, int C,
                                    int HW, void* ws, size_t ws_bytes, bn_stream_t stream) {
     if (!x || !sums || N <= 0 || C <= 0 || HW <= 0) return BN_E_BADARG;

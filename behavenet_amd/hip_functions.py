@@ -659,6 +659,29 @@ def pixel_loss_scales(kind, bounds, per_frame, chunk_sizes=None):
     raise ValueError('unknown pixel loss kind "%s"' % kind)
 
 
+# Batch-norm statistics are per 200-frame chunk (the reference runs its chunks one after another
+# through the whole network); everything else in the network is per frame.  Inside ``bn_chunks``
+# the batch-norm nodes take their statistics -- and fold them into the running estimates -- chunk
+# by chunk over the given row ranges of ONE pass over the whole batch, so that every convolution
+# sees all frames at once (AE + batch norm at 256 frames: 8.2 -> see DESIGN.md ms/step).
+_bn_bounds = None
+
+
+class bn_chunks(object):
+    def __init__(self, bounds):
+        self.bounds = [(int(b), int(e)) for b, e in bounds if e > b]
+
+    def __enter__(self):
+        global _bn_bounds
+        self._prev, _bn_bounds = _bn_bounds, (self.bounds if len(self.bounds) > 1 else None)
+        return self
+
+    def __exit__(self, *exc):
+        global _bn_bounds
+        _bn_bounds = self._prev
+        return False
+
+
 class BatchNormActFn(torch.autograd.Function):
     """y = act(BatchNorm2d(x)) with nn.BatchNorm2d's train / eval semantics (aes.py:90-97,113).
 
@@ -686,6 +709,7 @@ class BatchNormActFn(torch.autograd.Function):
                 rm = rv = None
             from behavenet_amd.fitting import distributed as bdist
             ctx.sync_count = None
+            ctx.chunks = None
             if bdist.frames_sharded():
                 # the chunk's frames are spread over the ranks: statistics over all of them
                 # (per-channel sums all-reduced), as the single device sees them
@@ -695,11 +719,26 @@ class BatchNormActFn(torch.autograd.Function):
                 y, mean, invstd, ctx.sync_count = _hip.batchnorm_sync_train_fwd(
                     x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE,
                     bdist.all_reduce_)
+            elif _bn_bounds is not None and x.shape[0] == _bn_bounds[-1][1]:
+                # one pass over the whole batch, statistics per chunk (in chunk order: the
+                # running estimates see the same sequence of updates as in the reference)
+                k = len(_bn_bounds)
+                factors = [factor] * k
+                if rm is not None and k > 1:
+                    # (the first chunk's count was added above)
+                    if module.momentum is None:
+                        first = 1.0 / factor
+                        factors = [1.0 / (first + i) for i in range(k)]
+                    module.num_batches_tracked.add_(k - 1)
+                y, mean, invstd = _hip.batchnorm_train_fwd_chunks(
+                    x, g, b, rm, rv, factors, float(module.eps), act, LRELU_SLOPE, _bn_bounds)
+                ctx.chunks = list(_bn_bounds)
             else:
                 y, mean, invstd = _hip.batchnorm_train_fwd(
                     x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE)
         else:
             ctx.sync_count = None
+            ctx.chunks = None
             mean = rm
             y, invstd = _hip.batchnorm_eval_fwd(x, g, b, rm, rv, float(module.eps), act,
                                                 LRELU_SLOPE)
@@ -733,6 +772,19 @@ class BatchNormActFn(torch.autograd.Function):
                 return (dx if ctx.needs_input_grad[0] else None), None, None, None, None
             return (dx if ctx.needs_input_grad[0] else None), \
                 (sum_dzx if need_g else None), (sum_dz if need_b else None), None, None
+        chunks = getattr(ctx, 'chunks', None)
+        if chunks is not None:
+            dy = dy.contiguous()
+            if direct:
+                dgamma, dbeta = gg, gb
+            else:
+                dgamma = torch.zeros_like(mean[0]) if need_g else None
+                dbeta = torch.zeros_like(mean[0]) if need_b else None
+            dx = _hip.batchnorm_bwd_chunks(x, y, dy, mean, invstd, g, dgamma, dbeta, True, ctx.act,
+                                           LRELU_SLOPE, chunks)
+            if direct:
+                dgamma = dbeta = None
+            return (dx if ctx.needs_input_grad[0] else None), dgamma, dbeta, None, None
         if direct:
             dgamma, dbeta = gg, gb
         else:

@@ -19,8 +19,8 @@ from behavenet_amd import _hip
 from behavenet_amd.fitting import distributed as bdist
 from behavenet_amd.models.base import BaseModule, BaseModel
 from behavenet_amd.hip_functions import (
-    ChunkScalars, ConvLayerPlan, FusedPixelLoss, Readback, activation, backward_chunks, capturing,
-    finish_loss,
+    ChunkScalars, ConvLayerPlan, FusedPixelLoss, Readback, activation, backward_chunks, bn_chunks,
+    capturing, finish_loss,
     chunked_sq_err, conv_stack, conv_stack_bn, conv_stack_sq_err, first_layer_forward,
     join_side_streams, linear, begin_chunks, chunk_stream, max_pool, max_unpool,
     pixel_loss_scales, reserve_device_pools)
@@ -539,7 +539,7 @@ class AE(BaseModel):
     graph_epoch_dependent = False
 
     def graph_capturable_for(self, x):
-        return self._whole_batch_ok(x)
+        return self._whole_batch_ok(x) and not self.hparams.get('ae_batch_norm', False)
 
     def __init__(self, hparams):
         super().__init__()
@@ -594,8 +594,10 @@ class AE(BaseModel):
     def _whole_batch_ok(self, x):
         """Frames are independent through this model (no batch norm): the chunks of the reference
         only bound ITS memory use, and only the loss normalisation depends on them."""
+        # (batch norm: its statistics are per chunk -- hip_functions.bn_chunks takes them chunk by
+        # chunk inside the one pass; under frame sharding they also span ranks: _pass_groups)
         return self.model_type == 'conv' and x.is_cuda and self._whole_batch and \
-            not self.hparams.get('ae_batch_norm', False) and \
+            not (self.hparams.get('ae_batch_norm', False) and bdist.frames_sharded()) and \
             os.environ.get('BN_WHOLE_BATCH', '1') != '0'
 
     def _pass_groups(self, x, chunk_size):
@@ -650,11 +652,12 @@ class AE(BaseModel):
         if x.shape[0] > 0:
             with torch.set_grad_enabled(bool(accumulate_grad)):
                 # the pixel loss rides in the epilogue of the last decoder layer
-                x_hat, _ = self.forward(
-                    x, dataset=dataset,
-                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds_l, 'kind': 'mse',
-                                'chunk_sizes': sizes},
-                    **fwd_kwargs)
+                with bn_chunks(bounds_l):
+                    x_hat, _ = self.forward(
+                        x, dataset=dataset,
+                        pixel_loss={'target': x, 'mask': m, 'bounds': bounds_l, 'kind': 'mse',
+                                    'chunk_sizes': sizes},
+                        **fwd_kwargs)
                 chunk_losses = losses.mse_chunks(x, x_hat, m, bounds_l, sizes)
             # (under graph capture the ranks' chunk terms are added on the host instead: no
             # collective inside the recorded step)
@@ -888,7 +891,7 @@ class AEMSP(AE):
             # terms are means over a chunk's rows like the pixel term
             bounds = [(beg, min(beg + chunk_size, batch_size))
                       for beg in range(0, batch_size, chunk_size)]
-            with torch.set_grad_enabled(bool(accumulate_grad)):
+            with torch.set_grad_enabled(bool(accumulate_grad)), bn_chunks(bounds):
                 P = self._P()
                 z, pool_idx, outsize = self.encoding(x, dataset=dataset)
                 y_hat = linear(z, P, None)

@@ -269,7 +269,7 @@ class VAE(AE):
                 xl, ml, *kw_l = sh.take(x[gb:ge], m[gb:ge] if m is not None else None,
                                         *kw.values())
                 kw = dict(zip(kw.keys(), kw_l))
-                with torch.set_grad_enabled(bool(accumulate_grad)):
+                with torch.set_grad_enabled(bool(accumulate_grad)), hf.bn_chunks(bounds):
                     x_hat, _, mu, logvar = self.forward(
                         xl, dataset=dataset, use_mean=False, sample_bounds=bounds,
                         sample_shards=sh,
@@ -385,7 +385,7 @@ class BetaTCVAE(VAE):
                 sh = _FrameShards(ge - gb, chunk_size)
                 bounds = sh.bounds_l
                 xl, ml = sh.take(x[gb:ge], m[gb:ge] if m is not None else None)
-                with torch.set_grad_enabled(bool(accumulate_grad)):
+                with torch.set_grad_enabled(bool(accumulate_grad)), hf.bn_chunks(bounds):
                     x_hat, sample, mu, logvar = self.forward(
                         xl, dataset=dataset, use_mean=False, sample_bounds=bounds,
                         sample_shards=sh,
@@ -593,7 +593,7 @@ class PSVAE(AE):
                                          n[gb:ge] if n is not None else None)
                 share = sh.share if sh.sharded else None
                 fused_head = not sh.sharded and _FUSED_PS_HEAD and xl.is_cuda
-                with torch.set_grad_enabled(bool(accumulate_grad)):
+                with torch.set_grad_enabled(bool(accumulate_grad)), hf.bn_chunks(bounds):
                     if fused_head:
                         # encoder heads -> ONE node (latents, label head, label / KL /
                         # decomposed-KL terms of every chunk) -> decoder with the pixel loss in
