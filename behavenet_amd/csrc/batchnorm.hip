@@ -10,6 +10,30 @@
 #include "bn_launch.h"
 
 #define BNK_THREADS 256
+#define BNK_MAX_CHUNKS 4
+
+// Row ranges whose statistics are separate (the reference's 200-frame chunks inside one pass over
+// the batch): blockIdx.z / a frame's range selects the chunk, statistics are laid out [chunk][C].
+struct BnChunks {
+    int n;
+    int beg[BNK_MAX_CHUNKS], end[BNK_MAX_CHUNKS];
+    float scale[BNK_MAX_CHUNKS];          // per-chunk factor (1 / count, running-estimate factor, ...)
+    float aux[BNK_MAX_CHUNKS];            // second per-chunk factor (unbiasing)
+};
+static BnChunks bnk_one_chunk(int N, float scale = 1.f, float aux = 1.f) {
+    BnChunks ch;
+    ch.n = 1;
+    for (int i = 0; i < BNK_MAX_CHUNKS; ++i) { ch.beg[i] = 0; ch.end[i] = 0; ch.scale[i] = scale; ch.aux[i] = aux; }
+    ch.end[0] = N;
+    return ch;
+}
+__device__ __forceinline__ int bnk_chunk_of(const BnChunks& ch, int n) {
+    int z = 0;
+#pragma unroll
+    for (int i = 1; i < BNK_MAX_CHUNKS; ++i)
+        if (i < ch.n && n >= ch.beg[i]) z = i;
+    return z;
+}
 
 __device__ __forceinline__ float bnk_block_sum(float v, float* red) {
 #pragma unroll
@@ -26,12 +50,13 @@ __device__ __forceinline__ float bnk_block_sum(float v, float* red) {
 // dependent iterations (80-100 us for 400 KB; round 3).
 template <int POW>
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_moment_part(
-    const float* __restrict__ x, const float* __restrict__ shift, float* __restrict__ part, int N,
-    int C, int HW, int S) {
+    const float* __restrict__ x, const float* __restrict__ shift, float* __restrict__ part,
+    BnChunks ch, int C, int HW, int S) {
     __shared__ float red[4];
-    const int c = blockIdx.x, sp = blockIdx.y;
-    const int n_beg = (int)((long)sp * N / S), n_end = (int)((long)(sp + 1) * N / S);
-    const float sh = shift ? shift[c] : 0.f;
+    const int c = blockIdx.x, sp = blockIdx.y, z = blockIdx.z;
+    const int N = ch.end[z] - ch.beg[z];
+    const int n_beg = ch.beg[z] + (int)((long)sp * N / S), n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
+    const float sh = shift ? shift[z * C + c] : 0.f;
     float acc = 0.f, acc2 = 0.f;
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);
     if (vec) {
@@ -64,32 +89,34 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_moment_part(
         }
     }
     const float s = bnk_block_sum(acc + acc2, red);
-    if (threadIdx.x == 0) part[(size_t)c * S + sp] = s;
+    if (threadIdx.x == 0) part[((size_t)z * C + c) * S + sp] = s;
 }
 
-// out[c] = scale * sum_s part[c][s]
+// out[z][c] = scale[z] * sum_s part[z][c][s]
 __global__ void k_bn_combine(const float* __restrict__ part, float* __restrict__ out, int C, int S,
-                             float scale) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+                             BnChunks ch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * ch.n) return;
     float v = 0.f;
 #pragma unroll 8
-    for (int s = 0; s < S; ++s) v += part[(size_t)c * S + s];
-    out[c] = v * scale;
+    for (int s = 0; s < S; ++s) v += part[(size_t)i * S + s];
+    out[i] = v * ch.scale[i / C];
 }
 
 // invstd = 1/sqrt(var + eps); running stats (momentum < 0: the caller passes the cumulative
 // average factor 1/num_batches_tracked instead, as nn.BatchNorm2d(momentum=None) does)
+// (chunks in order: the running estimates see one update per chunk, factor scale[z], unbiasing aux[z])
 __global__ void k_bn_finalize(const float* __restrict__ mean, const float* __restrict__ var,
                               float* __restrict__ invstd, float* __restrict__ running_mean,
-                              float* __restrict__ running_var, int C, float eps, float momentum,
-                              float unbias) {
+                              float* __restrict__ running_var, int C, float eps, BnChunks ch) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float m = mean[c], v = var[c];
-    invstd[c] = 1.0f / sqrtf(v + eps);
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * unbias;
+    for (int z = 0; z < ch.n; ++z) {
+        const float m = mean[z * C + c], v = var[z * C + c], momentum = ch.scale[z];
+        invstd[z * C + c] = 1.0f / sqrtf(v + eps);
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * ch.aux[z];
+    }
 }
 
 static int bnk_flat_blocks(size_t n) {
@@ -103,12 +130,13 @@ template <int VEC>
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd(
     const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-    unsigned NC, int C, int HW, int act, float slope) {
+    unsigned NC, int C, int HW, int act, float slope, BnChunks ch) {
     const unsigned hwv = HW / VEC, total = NC * hwv;
     for (unsigned e = blockIdx.x * BNK_THREADS + threadIdx.x; e < total; e += gridDim.x * BNK_THREADS) {
-        const int c = (e / hwv) % C;
-        const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-        const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+        const unsigned nc = e / hwv;
+        const int c = nc % C, zc = bnk_chunk_of(ch, nc / C) * C + c;
+        const float sc = invstd[zc] * (gamma ? gamma[c] : 1.f);
+        const float sh = (beta ? beta[c] : 0.f) - mean[zc] * sc;
         if (VEC == 4) {
             const float4 v = reinterpret_cast<const float4*>(x)[e];
             float4 o;
@@ -128,11 +156,12 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd(
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ part0,
-    float* __restrict__ part1, int N, int C, int HW, int S, int act, float slope) {
+    float* __restrict__ part1, BnChunks ch, int C, int HW, int S, int act, float slope) {
     __shared__ float red[4];
-    const int c = blockIdx.x, sp = blockIdx.y;
-    const int n_beg = (int)((long)sp * N / S), n_end = (int)((long)(sp + 1) * N / S);
-    const float m = mean[c], is = invstd[c];
+    const int c = blockIdx.x, sp = blockIdx.y, z = blockIdx.z;
+    const int N = ch.end[z] - ch.beg[z];
+    const int n_beg = ch.beg[z] + (int)((long)sp * N / S), n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
+    const float m = mean[z * C + c], is = invstd[z * C + c];
     float a0 = 0.f, a1 = 0.f;
     const bool vec = (HW & 3) == 0 &&
                      (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy)) & 15u) == 0);
@@ -166,8 +195,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     const float s0 = bnk_block_sum(a0, red);
     const float s1 = bnk_block_sum(a1, red);
     if (threadIdx.x == 0) {
-        part0[(size_t)c * S + sp] = s0;
-        part1[(size_t)c * S + sp] = s1;
+        part0[((size_t)z * C + c) * S + sp] = s0;
+        part1[((size_t)z * C + c) * S + sp] = s1;
     }
 }
 
@@ -175,19 +204,24 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
 __global__ void k_bn_bwd_combine(const float* __restrict__ part0, const float* __restrict__ part1,
                                  float* __restrict__ sum0, float* __restrict__ sum1,
                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int S,
-                                 int accumulate) {
+                                 int accumulate, int n_chunks) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float v0 = 0.f, v1 = 0.f;
+    float g = (accumulate && dgamma) ? dgamma[c] : 0.f, b = (accumulate && dbeta) ? dbeta[c] : 0.f;
+    for (int z = 0; z < n_chunks; ++z) {          // chunk order, as separate backward passes would add
+        float v0 = 0.f, v1 = 0.f;
 #pragma unroll 8
-    for (int s = 0; s < S; ++s) {
-        v0 += part0[(size_t)c * S + s];
-        v1 += part1[(size_t)c * S + s];
+        for (int s = 0; s < S; ++s) {
+            v0 += part0[((size_t)z * C + c) * S + s];
+            v1 += part1[((size_t)z * C + c) * S + s];
+        }
+        sum0[z * C + c] = v0;
+        sum1[z * C + c] = v1;
+        g += v1;
+        b += v0;
     }
-    sum0[c] = v0;
-    sum1[c] = v1;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + v1 : v1;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + v0 : v0;
+    if (dgamma) dgamma[c] = g;
+    if (dbeta) dbeta[c] = b;
 }
 
 // dx = gamma * invstd * (dz - dbeta/n - xhat * dgamma/n), flat like the forward
@@ -197,13 +231,14 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ sum_dz,
     const float* __restrict__ sum_dzx, float* __restrict__ dx, unsigned NC, int C, int HW,
-    float inv_n, int act, float slope) {
+    int act, float slope, BnChunks ch) {
     const unsigned hwv = HW / VEC, total = NC * hwv;
     for (unsigned e = blockIdx.x * BNK_THREADS + threadIdx.x; e < total; e += gridDim.x * BNK_THREADS) {
-        const int c = (e / hwv) % C;
-        const float m = mean[c], is = invstd[c];
+        const unsigned nc = e / hwv;
+        const int c = nc % C, z = bnk_chunk_of(ch, nc / C), zc = z * C + c;
+        const float m = mean[zc], is = invstd[zc], inv_n = ch.scale[z];
         const float g = (gamma ? gamma[c] : 1.f) * is;
-        const float k0 = sum_dz[c] * inv_n, k1 = sum_dzx[c] * inv_n;
+        const float k0 = sum_dz[zc] * inv_n, k1 = sum_dzx[zc] * inv_n;
         if (VEC == 4) {
             const float4 xv = reinterpret_cast<const float4*>(x)[e];
             const float4 yv = reinterpret_cast<const float4*>(y)[e];
@@ -230,30 +265,57 @@ static int bn_splits(int N, int C) {
 }
 
 size_t bn_batchnorm_ws_bytes_impl(int N, int C) {
-    // two partial arrays [C][S] + two combined vectors [C]
-    return ((size_t)2 * C * bn_splits(N, C) + 2 * C) * sizeof(float);
+    // per chunk (up to BNK_MAX_CHUNKS): two partial arrays [C][S] + two combined vectors [C]
+    return (size_t)BNK_MAX_CHUNKS * ((size_t)2 * C * bn_splits(N, C) + 2 * C) * sizeof(float);
+}
+
+static int bnk_max_len(const BnChunks& ch) {
+    int m = 0;
+    for (int z = 0; z < ch.n; ++z) m = ch.end[z] - ch.beg[z] > m ? ch.end[z] - ch.beg[z] : m;
+    return m;
+}
+
+// mean / var of every chunk: [ch.n][C]
+static int bn_launch_stats_chunks(const float* x, float* mean, float* var, BnChunks ch, int C, int HW,
+                                  void* ws, hipStream_t st) {
+    const int S = bn_splits(bnk_max_len(ch), C);
+    float* part = (float*)ws;
+    for (int z = 0; z < ch.n; ++z) ch.scale[z] = 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW);
+    const dim3 cgrid((C * ch.n + 63) / 64);
+    hipLaunchKernelGGL(k_bn_moment_part<1>, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x,
+                       (const float*)nullptr, part, ch, C, HW, S);
+    hipLaunchKernelGGL(k_bn_combine, cgrid, dim3(64), 0, st, part, mean, C, S, ch);
+    hipLaunchKernelGGL(k_bn_moment_part<2>, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x,
+                       (const float*)mean, part, ch, C, HW, S);
+    hipLaunchKernelGGL(k_bn_combine, cgrid, dim3(64), 0, st, part, var, C, S, ch);
+    BN_LAUNCH_CHECK();
+    return 0;
 }
 
 int bn_launch_bn_stats(const float* x, float* mean, float* var, int N, int C, int HW, void* ws,
                        hipStream_t st) {
-    const int S = bn_splits(N, C);
-    float* part = (float*)ws;
-    const float inv_n = 1.0f / ((float)N * (float)HW);
-    hipLaunchKernelGGL(k_bn_moment_part<1>, dim3(C, S), dim3(BNK_THREADS), 0, st, x,
-                       (const float*)nullptr, part, N, C, HW, S);
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part, mean, C, S, inv_n);
-    hipLaunchKernelGGL(k_bn_moment_part<2>, dim3(C, S), dim3(BNK_THREADS), 0, st, x,
-                       (const float*)mean, part, N, C, HW, S);
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part, var, C, S, inv_n);
-    BN_LAUNCH_CHECK();
-    return 0;
+    return bn_launch_stats_chunks(x, mean, var, bnk_one_chunk(N), C, HW, ws, st);
 }
 
 int bn_launch_bn_finalize(const float* mean, const float* var, float* invstd, float* running_mean,
                           float* running_var, int C, float eps, float momentum, float unbias,
                           hipStream_t st) {
     hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, st, mean, var, invstd,
-                       running_mean, running_var, C, eps, momentum, unbias);
+                       running_mean, running_var, C, eps, bnk_one_chunk(0, momentum, unbias));
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int bn_launch_act_fwd_chunks(const float* x, const float* mean, const float* invstd,
+                                    const float* gamma, const float* beta, float* y, int N, int C, int HW,
+                                    int act, float slope, const BnChunks& ch, hipStream_t st) {
+    if ((size_t)N * C * HW >= 0xffffffffull) return BN_E_SHAPE;
+    if ((HW & 3) == 0 && (((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0))
+        hipLaunchKernelGGL(k_bn_act_fwd<4>, dim3(bnk_flat_blocks((size_t)N * C * (HW >> 2))), dim3(BNK_THREADS),
+                           0, st, x, mean, invstd, gamma, beta, y, (unsigned)(N * C), C, HW, act, slope, ch);
+    else
+        hipLaunchKernelGGL(k_bn_act_fwd<1>, dim3(bnk_flat_blocks((size_t)N * C * HW)), dim3(BNK_THREADS), 0,
+                           st, x, mean, invstd, gamma, beta, y, (unsigned)(N * C), C, HW, act, slope, ch);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -261,33 +323,103 @@ int bn_launch_bn_finalize(const float* mean, const float* var, float* invstd, fl
 int bn_launch_bn_act_fwd(const float* x, const float* mean, const float* invstd,
                          const float* gamma, const float* beta, float* y, int N, int C, int HW,
                          int act, float slope, hipStream_t st) {
+    return bn_launch_act_fwd_chunks(x, mean, invstd, gamma, beta, y, N, C, HW, act, slope, bnk_one_chunk(N), st);
+}
+
+static int bn_launch_bwd_apply_chunks(const float* x, const float* y, const float* dy, const float* mean,
+                                      const float* invstd, const float* gamma, const float* sum_dz,
+                                      const float* sum_dzx, float* dx, int N, int C, int HW, int act,
+                                      float slope, const BnChunks& ch, hipStream_t st) {
     if ((size_t)N * C * HW >= 0xffffffffull) return BN_E_SHAPE;
-    if ((HW & 3) == 0 && (((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0))
-        hipLaunchKernelGGL(k_bn_act_fwd<4>, dim3(bnk_flat_blocks((size_t)N * C * (HW >> 2))), dim3(BNK_THREADS),
-                           0, st, x, mean, invstd, gamma, beta, y, (unsigned)(N * C), C, HW, act, slope);
+    if ((HW & 3) == 0 &&
+        (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15u) == 0))
+        hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3(bnk_flat_blocks((size_t)N * C * (HW >> 2))),
+                           dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx,
+                           (unsigned)(N * C), C, HW, act, slope, ch);
     else
-        hipLaunchKernelGGL(k_bn_act_fwd<1>, dim3(bnk_flat_blocks((size_t)N * C * HW)), dim3(BNK_THREADS), 0,
-                           st, x, mean, invstd, gamma, beta, y, (unsigned)(N * C), C, HW, act, slope);
+        hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3(bnk_flat_blocks((size_t)N * C * HW)), dim3(BNK_THREADS),
+                           0, st, x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx, (unsigned)(N * C), C,
+                           HW, act, slope, ch);
     BN_LAUNCH_CHECK();
     return 0;
+}
+
+// backward of all chunks (statistics [ch.n][C]); x / y / dy / dx hold N frames in total
+static int bn_launch_act_bwd_chunks(const float* x, const float* y, const float* dy, const float* mean,
+                                    const float* invstd, const float* gamma, float* dx, float* dgamma,
+                                    float* dbeta, int accumulate, int batch_stats, int N, BnChunks ch,
+                                    int C, int HW, int act, float slope, void* ws, hipStream_t st) {
+    const int S = bn_splits(bnk_max_len(ch), C);
+    float* part0 = (float*)ws;
+    float* part1 = part0 + (size_t)ch.n * C * S;
+    float* sum0 = part1 + (size_t)ch.n * C * S;
+    float* sum1 = sum0 + (size_t)ch.n * C;
+    hipLaunchKernelGGL(k_bn_bwd_part, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
+                       part0, part1, ch, C, HW, S, act, slope);
+    hipLaunchKernelGGL(k_bn_bwd_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, part1, sum0, sum1,
+                       dgamma, dbeta, C, S, accumulate, ch.n);
+    BN_LAUNCH_CHECK();
+    for (int z = 0; z < ch.n; ++z)
+        ch.scale[z] = batch_stats ? 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW) : 0.0f;
+    return bn_launch_bwd_apply_chunks(x, y, dy, mean, invstd, gamma, sum0, sum1, dx, N, C, HW, act, slope,
+                                      ch, st);
 }
 
 int bn_launch_bn_act_bwd(const float* x, const float* y, const float* dy, const float* mean,
                          const float* invstd, const float* gamma, float* dx, float* dgamma,
                          float* dbeta, int accumulate, int batch_stats, int N, int C, int HW,
                          int act, float slope, void* ws, hipStream_t st) {
-    const int S = bn_splits(N, C);
-    float* part0 = (float*)ws;
-    float* part1 = part0 + (size_t)C * S;
-    float* sum0 = part1 + (size_t)C * S;
-    float* sum1 = sum0 + C;
-    hipLaunchKernelGGL(k_bn_bwd_part, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
-                       part0, part1, N, C, HW, S, act, slope);
-    hipLaunchKernelGGL(k_bn_bwd_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, part1, sum0, sum1,
-                       dgamma, dbeta, C, S, accumulate);
+    return bn_launch_act_bwd_chunks(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, accumulate,
+                                    batch_stats, N, bnk_one_chunk(N), C, HW, act, slope, ws, st);
+}
+
+// ---- up to BNK_MAX_CHUNKS chunks of one batch in the launches of one (the chunked entry points) ----
+static bool bnk_make_chunks(const int* bounds, int n_chunks, BnChunks* ch, int* N) {
+    if (n_chunks < 1 || n_chunks > BNK_MAX_CHUNKS) return false;
+    *ch = bnk_one_chunk(0);
+    ch->n = n_chunks;
+    int pos = 0;
+    for (int i = 0; i < n_chunks; ++i) {
+        if (bounds[2 * i] != pos || bounds[2 * i + 1] <= pos) return false;     // contiguous, in order
+        ch->beg[i] = bounds[2 * i];
+        ch->end[i] = pos = bounds[2 * i + 1];
+    }
+    *N = pos;
+    return true;
+}
+
+int bn_launch_bn_train_fwd_chunks(const float* x, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float* y, float* mean,
+                                  float* invstd, const int* bounds, const float* factors, int n_chunks,
+                                  int C, int HW, float eps, int act, float slope, void* ws,
+                                  hipStream_t st) {
+    BnChunks ch;
+    int N = 0;
+    if (!bnk_make_chunks(bounds, n_chunks, &ch, &N)) return BN_E_SHAPE;
+    const int S = bn_splits(bnk_max_len(ch), C);
+    float* var = (float*)ws + (size_t)2 * ch.n * C * S;          // behind the partial arrays
+    int rc = bn_launch_stats_chunks(x, mean, var, ch, C, HW, ws, st);
+    if (rc) return rc;
+    for (int z = 0; z < ch.n; ++z) {
+        const double cnt = (double)(ch.end[z] - ch.beg[z]) * HW;
+        ch.scale[z] = factors ? factors[z] : 0.f;
+        ch.aux[z] = cnt > 1 ? (float)(cnt / (cnt - 1.0)) : 1.f;
+    }
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)mean, (const float*)var,
+                       invstd, running_mean, running_var, C, eps, ch);
     BN_LAUNCH_CHECK();
-    return bn_launch_bn_bwd_apply(x, y, dy, mean, invstd, gamma, sum0, sum1, dx, N, C, HW,
-                                  batch_stats ? 1.0f / ((float)N * (float)HW) : 0.0f, act, slope, st);
+    return bn_launch_act_fwd_chunks(x, mean, invstd, gamma, beta, y, N, C, HW, act, slope, ch, st);
+}
+
+int bn_launch_bn_act_bwd_chunks(const float* x, const float* y, const float* dy, const float* mean,
+                                const float* invstd, const float* gamma, float* dx, float* dgamma,
+                                float* dbeta, int accumulate, const int* bounds, int n_chunks, int C,
+                                int HW, int act, float slope, void* ws, hipStream_t st) {
+    BnChunks ch;
+    int N = 0;
+    if (!bnk_make_chunks(bounds, n_chunks, &ch, &N)) return BN_E_SHAPE;
+    return bn_launch_act_bwd_chunks(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, accumulate, 1, N, ch,
+                                    C, HW, act, slope, ws, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,13 +431,14 @@ int bn_launch_bn_moment(const float* x, const float* center, float* sums, int N,
                         void* ws, hipStream_t st) {
     const int S = bn_splits(N, C);
     float* part = (float*)ws;
+    const BnChunks ch = bnk_one_chunk(N);
     if (center)
         hipLaunchKernelGGL(k_bn_moment_part<2>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, center,
-                           part, N, C, HW, S);
+                           part, ch, C, HW, S);
     else
         hipLaunchKernelGGL(k_bn_moment_part<1>, dim3(C, S), dim3(BNK_THREADS), 0, st, x,
-                           (const float*)nullptr, part, N, C, HW, S);
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part, sums, C, S, 1.0f);
+                           (const float*)nullptr, part, ch, C, HW, S);
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part, sums, C, S, ch);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -317,11 +450,11 @@ int bn_launch_bn_bwd_reduce(const float* x, const float* y, const float* dy, con
     const int S = bn_splits(N, C);
     float* part0 = (float*)ws;
     float* part1 = part0 + (size_t)C * S;
+    const BnChunks ch = bnk_one_chunk(N);
     hipLaunchKernelGGL(k_bn_bwd_part, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
-                       part0, part1, N, C, HW, S, act, slope);
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, sum_dz, C, S, 1.0f);
-    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part1, sum_dzx, C, S,
-                       1.0f);
+                       part0, part1, ch, C, HW, S, act, slope);
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, sum_dz, C, S, ch);
+    hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part1, sum_dzx, C, S, ch);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -331,16 +464,6 @@ int bn_launch_bn_bwd_apply(const float* x, const float* y, const float* dy, cons
                            const float* invstd, const float* gamma, const float* sum_dz,
                            const float* sum_dzx, float* dx, int N, int C, int HW, float inv_count,
                            int act, float slope, hipStream_t st) {
-    if ((size_t)N * C * HW >= 0xffffffffull) return BN_E_SHAPE;
-    if ((HW & 3) == 0 &&
-        (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15u) == 0))
-        hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3(bnk_flat_blocks((size_t)N * C * (HW >> 2))),
-                           dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx,
-                           (unsigned)(N * C), C, HW, inv_count, act, slope);
-    else
-        hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3(bnk_flat_blocks((size_t)N * C * HW)), dim3(BNK_THREADS),
-                           0, st, x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx, (unsigned)(N * C), C,
-                           HW, inv_count, act, slope);
-    BN_LAUNCH_CHECK();
-    return 0;
+    return bn_launch_bwd_apply_chunks(x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx, N, C, HW, act, slope,
+                                      bnk_one_chunk(N, inv_count), st);
 }

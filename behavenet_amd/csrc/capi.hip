@@ -936,6 +936,16 @@ extern "C" int bn_batchnorm_train_fwd_chunks(const float* x, const float* gamma,
                                              size_t ws_bytes, bn_stream_t stream) {
     if (!x || !y || !mean || !invstd || !bounds || n_chunks <= 0 || C <= 0 || HW <= 0) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    {   // all chunks in the launches of one (up to four contiguous chunks)
+        int nmax = 0;
+        for (int i = 0; i < n_chunks; ++i) nmax = bounds[2 * i + 1] - bounds[2 * i] > nmax ? bounds[2 * i + 1] - bounds[2 * i] : nmax;
+        if (nmax > 0 && ws && ws_bytes >= bn_batchnorm_ws_bytes_impl(nmax, C)) {
+            const int rc = bn_launch_bn_train_fwd_chunks(x, gamma, beta, running_mean, running_var, y, mean,
+                                                         invstd, bounds, factors, n_chunks, C, HW, eps, act,
+                                                         slope, ws, st);
+            if (rc != BN_E_SHAPE) return rc;
+        }
+    }
     for (int i = 0; i < n_chunks; ++i) {
         const int b = bounds[2 * i], n = bounds[2 * i + 1] - b;
         if (n <= 0 || b < 0) return BN_E_BADARG;
@@ -968,6 +978,15 @@ extern "C" int bn_batchnorm_act_bwd_chunks(const float* x, const float* y, const
     if (!x || !y || !dy || !mean || !invstd || !dx || !bounds || n_chunks <= 0 || C <= 0 || HW <= 0)
         return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
+    {
+        int nmax = 0;
+        for (int i = 0; i < n_chunks; ++i) nmax = bounds[2 * i + 1] - bounds[2 * i] > nmax ? bounds[2 * i + 1] - bounds[2 * i] : nmax;
+        if (nmax > 0 && ws && ws_bytes >= bn_batchnorm_ws_bytes_impl(nmax, C)) {
+            const int rc = bn_launch_bn_act_bwd_chunks(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta,
+                                                       accumulate, bounds, n_chunks, C, HW, act, slope, ws, st);
+            if (rc != BN_E_SHAPE) return rc;
+        }
+    }
     for (int i = 0; i < n_chunks; ++i) {
         const int b = bounds[2 * i], n = bounds[2 * i + 1] - b;
         if (n <= 0 || b < 0) return BN_E_BADARG;
