@@ -682,6 +682,22 @@ class bn_chunks(object):
         return False
 
 
+def _batches_tracked(module, added=1):
+    """``int(module.num_batches_tracked)`` after this node's in-place add, without reading the
+    device counter back every step (momentum=None, the reference's default: the cumulative-average
+    factor is 1 / count -- nine host synchronisations per training step otherwise).  A host
+    mirror follows the counter; it is re-read from the device whenever something else has touched
+    the tensor (load_state_dict, a new tensor, a reset)."""
+    t = module.num_batches_tracked
+    mirror = getattr(module, '_bn_count_mirror', None)
+    if mirror is not None and mirror[0] is t and mirror[1] == t._version - 1:
+        value = mirror[2] + added
+    else:
+        value = int(t.item())
+    module._bn_count_mirror = (t, t._version, value)
+    return value
+
+
 class BatchNormActFn(torch.autograd.Function):
     """y = act(BatchNorm2d(x)) with nn.BatchNorm2d's train / eval semantics (aes.py:90-97,113).
 
@@ -702,7 +718,7 @@ class BatchNormActFn(torch.autograd.Function):
             if module.training and module.track_running_stats and rm is not None:
                 module.num_batches_tracked.add_(1)
                 if module.momentum is None:
-                    factor = 1.0 / float(module.num_batches_tracked.item())
+                    factor = 1.0 / float(_batches_tracked(module))
                 else:
                     factor = float(module.momentum)
             else:
@@ -730,6 +746,8 @@ class BatchNormActFn(torch.autograd.Function):
                         first = 1.0 / factor
                         factors = [1.0 / (first + i) for i in range(k)]
                     module.num_batches_tracked.add_(k - 1)
+                    if module.momentum is None:
+                        _batches_tracked(module, k - 1)
                 y, mean, invstd = _hip.batchnorm_train_fwd_chunks(
                     x, g, b, rm, rv, factors, float(module.eps), act, LRELU_SLOPE, _bn_bounds)
                 ctx.chunks = list(_bn_bounds)

@@ -539,7 +539,11 @@ class AE(BaseModel):
     graph_epoch_dependent = False
 
     def graph_capturable_for(self, x):
-        return self._whole_batch_ok(x) and not self.hparams.get('ae_batch_norm', False)
+        # (batch norm with momentum=None reads its batch counter on the host for the cumulative
+        # average factor: not recordable)
+        return self._whole_batch_ok(x) and not (
+            self.hparams.get('ae_batch_norm', False) and
+            self.hparams.get('ae_batch_norm_momentum', 0.1) is None)
 
     def __init__(self, hparams):
         super().__init__()

@@ -64,6 +64,37 @@ def test_graphed_step_is_bit_identical_to_eager(dim, batch):
     assert torch.equal(p_e, p_g)
 
 
+def test_graphed_step_with_batch_norm_statistics_per_chunk():
+    """Batch norm inside the recorded step: statistics per 200-frame chunk, the running estimates
+    and the batch counter advance with every replay exactly as on eager launches."""
+    dim = (1, 64, 48)
+    hp = _hparams(dim, 'ae', {'ae_batch_norm': True, 'ae_batch_norm_momentum': 0.1})
+    batches = [{'images': [torch.from_numpy(make_frames(210, list(dim), seed=50 + i)).to(DEV)]}
+               for i in range(5)]
+
+    def run(graphed):
+        np.random.seed(0)
+        torch.manual_seed(0)
+        model = AE(hp).to(DEV)
+        opt = FlatAdamAMSGrad(model.get_parameters(), lr=1e-3)
+        fn = GraphedLoss(model, warmup=1) if graphed else model.loss
+        losses = []
+        for data in batches:
+            model.train()
+            opt.zero_grad()
+            losses.append(dict(fn(data, dataset=0, accumulate_grad=True)))
+            opt.step()
+        bufs = {k: v.clone() for k, v in model.named_buffers()}
+        return losses, opt.flat_p.clone(), bufs, fn
+    l_e, p_e, b_e, _ = run(False)
+    l_g, p_g, b_g, fn = run(True)
+    assert fn.n_replays == 4 and fn.n_eager == 1
+    assert l_e == l_g
+    assert torch.equal(p_e, p_g)
+    for k in b_e:
+        assert torch.equal(b_e[k], b_g[k]), k
+
+
 def test_graphed_step_conditional_ae_with_labels():
     dim = (1, 64, 48)
     hp = _hparams(dim, 'cond-ae', {'n_labels': 3, 'conditional_encoder': False})

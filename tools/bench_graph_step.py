@@ -17,9 +17,9 @@ from tests.golden_utils import base_hparams, make_frames
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 
 
-def run(label, dim, batch, shard=None):
+def run(label, dim, batch, shard=None, extra=None):
     arch = load_handcrafted_arch(list(dim), 12, None, check_memory=False)
-    hp = base_hparams(arch, 'ae', {})
+    hp = base_hparams(arch, 'ae', extra or {})
     hp['device'] = 'cuda'
     out = []
     for graphed in (False, True):
@@ -57,6 +57,7 @@ def run(label, dim, batch, shard=None):
 
 
 run('1x128x128, 256 frames (headline)', (1, 128, 128), 256)
+run('1x128x128, 256 frames, batch norm', (1, 128, 128), 256, extra={'ae_batch_norm': True})
 run('1x64x48, 256 frames', (1, 64, 48), 256)
 run('1x128x128, 32 frames', (1, 128, 128), 32)
 run('1x32x32, 32 frames (configs[0])', (1, 32, 32), 32)
