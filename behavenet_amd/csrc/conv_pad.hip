@@ -514,14 +514,12 @@ int bn_launch_col_wgrad(const float* small, const float* big, float* dw, const B
         a.C = dw; a.sci = K; a.scj = 1;
         a.M = g.Cs; a.N = K; a.K = rows;
         a.bias_j = nullptr; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f; a.accumulate = acc;
-        int rc = bn_launch_gemm(a, st, (char*)ws + used, ws_bytes - used);
+        const int rc = bn_launch_gemm(a, st, (char*)ws + used, ws_bytes - used);
         if (rc) return rc;
-        if (db && bias_side == 1) {
-            rc = bn_launch_col_sum(srows, db, rows, g.Cs, acc, st);
-            if (rc) return rc;
-        }
     }
-    if (db && bias_side == 1 && bias_done) *bias_done = true;
+    // (the bias gradient is left to the caller's channel sums over the NCHW tensor: a column sum
+    // over millions of rows with one wave per column took 3.5 ms per call)
+    (void)db; (void)bias_side; (void)bias_done;
     BN_LAUNCH_CHECK();
     return 0;
 }
