@@ -370,7 +370,11 @@ static bool served_fast(int role, const BnGeom& g) {
     return pad_plan(role, g).ok || tile_plan(role, g).ok;
 }
 static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
-    if (force_generic() || g.stride != 2 || g.R > 5 || g.S > 5 || (g.R == 5 && g.S == 5)) return false;
+    // (stride 1 too: the index relation p * stride - pt + r does not care, and the stride-1 gather-down
+    // kernel is instantiated for 3x3 and 5x5 -- a 4x4 layer becomes a 5x5 one where that kernel serves it)
+    if (force_generic() || (g.stride != 2 && g.stride != 1) || g.R > 5 || g.S > 5 || (g.R == 5 && g.S == 5))
+        return false;
+    if (g.stride == 1 && g.R == 3 && g.S == 3) return false;      // served as it is
     if (g.R < 2 || g.S < 2) return false;
     *g5 = g;
     g5->R = g5->S = 5;

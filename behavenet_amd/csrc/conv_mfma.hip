@@ -281,7 +281,7 @@ static bool down_tile(const BnGeom& g, int MR, int NR, int CC, DownTile* t, int*
     t->xl_floats = (CC * t->CHS + 3) & ~3;
     const size_t lds = ((size_t)t->xl_floats + (size_t)CC * g.R * g.S * t->TMP) * 4;
     if (lds > MF_MAX_LDS) return false;
-    if (t->CHS > MF_THREADS * (g.stride == 2 ? 6 : 13)) return false;   // KIN register budget
+    if (t->CHS > MF_THREADS * (g.stride == 1 ? 3 : g.stride == 2 ? 6 : 13)) return false;   // KIN register budget
     const int groups = (g.N + t->F - 1) / t->F;
     *n_wg_xy = groups * t->tiles_per_frame * ((g.Cs + 32 * MR - 1) / (32 * MR));
     t->splits = 1;
@@ -291,8 +291,13 @@ static bool down_tile(const BnGeom& g, int MR, int NR, int CC, DownTile* t, int*
 
 BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_down_generic", 0, 0, 0, 0, 0, 0};
-    if (g.R != 5 || g.S != 5) return p;
-    if (g.stride != 2 && g.stride != 5) return p;
+    // stride 1 (round 3): the first-generation kernel has no stride-specific assumption in its body;
+    // 3x3 and 5x5 kernels are instantiated (max-pooling architectures, ae_arch_2.json's last layer
+    // through zero-extended taps).  Forward and -- through flipped weights, capi.hip -- data gradient;
+    // the weight gradient of these layers stays on im2col + GEMM.
+    const bool s1 = g.stride == 1 && g.R == g.S && (g.R == 3 || g.R == 5);
+    if (!s1 && (g.R != 5 || g.S != 5)) return p;
+    if (!s1 && g.stride != 2 && g.stride != 5) return p;
     if (g.Cb < 2) return p;            // single-channel inputs: conv_edge.hip
     if (g.Cs < 16) return p;
     const int CC = (g.stride == 5) ? 2 : 4;
@@ -300,7 +305,7 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     // (bench.py, other streams' kernels fill the machine) they beat both the larger 64x256 tiles
     // and the 32x128 tiles with more workgroups; stride 5: 64x128 tiles, the reduction split
     static const int cand[3][2] = {{2, 1}, {2, 2}, {1, 1}};
-    const int want = g.stride == 2 ? 96 : 1;   // stride 5 (K = 6400): the 64x128 tile + split-K
+    const int want = g.stride <= 2 ? 96 : 1;   // stride 5 (K = 6400): the 64x128 tile + split-K
     int best = -1, best_wg = 0;
     DownTile t;
     // whole-batch launches (256 frames) of the layers with 16-pixel or wider small maps: the
@@ -345,7 +350,7 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     // (stride 2: the second-generation kernel without split is preferred down to ~100
     // workgroups -- the other chunk's and the weight-gradient stream's kernels fill the machine)
     int splits = 1;
-    if (best_wg < (g.stride == 2 ? want : 384)) {
+    if (best_wg < (g.stride <= 2 ? want : 384)) {
         const int max_splits = g.Cb / (4 * CC) > 0 ? g.Cb / (4 * CC) : 1;
         splits = 512 / best_wg;            // all workgroups resident at once (2 per CU)
         if (splits > max_splits) splits = max_splits;
@@ -364,7 +369,10 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
         {"k_down_mfma<2, 1, 2, 5>", "k_down_mfma<2, 2, 2, 5>", "k_down_mfma<1, 1, 2, 5>"}};
     static const char* const names2[3] = {"k_down2_mfma<2, 1>", "k_down2_mfma<2, 2>",
                                           "k_down2_mfma<1, 1>"};
-    p.kernel_name = names1[g.stride == 2 ? 0 : 1][best];
+    static const char* const names_s1[2][3] = {
+        {"k_down_mfma<2, 1, 4, 1, 3, 3>", "k_down_mfma<2, 2, 4, 1, 3, 3>", "k_down_mfma<1, 1, 4, 1, 3, 3>"},
+        {"k_down_mfma<2, 1, 4, 1, 5, 5>", "k_down_mfma<2, 2, 4, 1, 5, 5>", "k_down_mfma<1, 1, 4, 1, 5, 5>"}};
+    p.kernel_name = g.stride == 1 ? names_s1[g.R == 5 ? 1 : 0][best] : names1[g.stride == 2 ? 0 : 1][best];
     if (g.stride == 2 && splits == 1 && CC == 4 && bn_down2_supported(g, p.a, p.b)) {
         p.variant = 2;
         p.kernel_name = names2[best];
@@ -379,6 +387,16 @@ static int launch_down(const DownTile& t, dim3 grid, size_t lds, const float* bi
     hipLaunchKernelGGL((k_down_mfma<MR, NR, CC, ST, 5, 5, (ST == 2 ? 6 : 13)>), grid,
                        dim3(MF_THREADS), lds, st, big, w, bias, out, dact_src, g, t, act, dact,
                        slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MR, int NR, int R>
+static int launch_down_s1(const DownTile& t, dim3 grid, size_t lds, const float* big, const float* w,
+                          const float* bias, float* out, const float* dact_src, const BnGeom& g,
+                          int act, int dact, float slope, hipStream_t st) {
+    hipLaunchKernelGGL((k_down_mfma<MR, NR, 4, 1, R, R, 3>), grid, dim3(MF_THREADS), lds, st, big, w,
+                       bias, out, dact_src, g, t, act, dact, slope);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -403,7 +421,7 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
     }
     const int groups = (g.N + t.F - 1) / t.F;
     dim3 grid(groups * t.tiles_per_frame, (g.Cs + 32 * MR - 1) / (32 * MR), splits);
-    const size_t lds = ((size_t)t.xl_floats + (size_t)CC * 25 * t.TMP) * 4;
+    const size_t lds = ((size_t)t.xl_floats + (size_t)CC * g.R * g.S * t.TMP) * 4;
     float* dst = splits > 1 ? (float*)ws : out;
     int rc = BN_E_SHAPE;
 #define DOWN_CASE(mr, nr, cc, s)                                                                 \
@@ -413,6 +431,12 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
     DOWN_CASE(2, 2, 4, 2) DOWN_CASE(2, 1, 4, 2) DOWN_CASE(1, 1, 4, 2)
     DOWN_CASE(2, 2, 2, 5) DOWN_CASE(2, 1, 2, 5) DOWN_CASE(1, 1, 2, 5)
 #undef DOWN_CASE
+#define DOWN_S1(mr, nr, r)                                                                       \
+    if (g.stride == 1 && CC == 4 && MR == mr && NR == nr && g.R == r)                            \
+        rc = launch_down_s1<mr, nr, r>(t, grid, lds, big, w, bias, dst, dact_src, g, act, dact, slope, st);
+    DOWN_S1(2, 2, 3) DOWN_S1(2, 1, 3) DOWN_S1(1, 1, 3)
+    DOWN_S1(2, 2, 5) DOWN_S1(2, 1, 5) DOWN_S1(1, 1, 5)
+#undef DOWN_S1
     if (rc) return rc;
     if (splits > 1) {
         const size_t total = (size_t)g.N * g.Cs * g.Hs * g.Ws;

@@ -89,6 +89,10 @@ CONV_CASES = [
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
+    # stride 1 on the first-generation gather-down kernel (3x3, 5x5; 4x4 through zero-extended taps)
+    ('s1_k5_64x64', 2, 16, 64, 64, 32, 5, 1, (2, 2), (2, 2)),
+    ('s1_k3_32x32', 3, 32, 32, 32, 64, 3, 1, (1, 1), (1, 1)),
+    ('s1_k4_8x8', 3, 64, 8, 8, 64, 4, 1, (1, 2), (1, 2)),
 ]
 
 
@@ -631,7 +635,8 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
 @pytest.mark.parametrize('case_name, want', [
     ('tile_48x40', 'on zero-padded 64x64'), ('tile_100x24', 'on zero-padded 128x32'),
     ('tile_E0_96x80', 'on 2x2 tiles of 64x64'), ('pad_24x20', 'on zero-padded 32x32'),
-    ('k4_64ch_32x32', 'mfma'), ('k4x3_24x20', 'on zero-padded 32x32')])
+    ('k4_64ch_32x32', 'mfma'), ('k4x3_24x20', 'on zero-padded 32x32'),
+    ('s1_k5_64x64', 'k_down_mfma<'), ('s1_k4_8x8', 'k_down_mfma<')])
 def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, want):
     """The dispatch takes the tiled / zero-padded detour (conv_pad.hip), not the direct loops."""
     case = [c for c in CONV_CASES if c[0] == case_name][0]
