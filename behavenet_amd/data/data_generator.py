@@ -276,7 +276,9 @@ class SyntheticSessionsGenerator(object):
         # data-parallel 'trial' mode the one `lookahead` = world - 1 places further down (the
         # trials in between go to the other ranks, `next_batch(skip=True)`)
         queue = self._queues[sess][dtype]      # (None: the session's order is not drawn yet)
-        ahead = int(getattr(self, 'lookahead', 0))
+        # (only the TRAINING loop deals trials out to the ranks; validation and test loops consume
+        # every trial on every rank, their next request is the head of the queue)
+        ahead = int(getattr(self, 'lookahead', 0)) if dtype == 'train' else 0
         if queue and len(queue) > ahead:
             nxt = queue[ahead]
             host = self._store[sess][0][nxt]

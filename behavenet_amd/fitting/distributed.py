@@ -42,8 +42,19 @@ def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun env)."""
+def _loopback(addr):
+    return addr in ('127.0.0.1', 'localhost', '::1')
+
+
+def init_from_env(backend=None, timeout_s=None):
+    """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun env).
+
+    ``timeout_s`` (or env BN_DIST_TIMEOUT_S; default 600): how long the rendezvous and any later
+    collective may wait for a missing rank before it raises -- torch's default of 30 minutes turns
+    a rank that died into a job that hangs.  When the rendezvous address is the loopback interface
+    (one node: what ``torchrun --master-addr 127.0.0.1`` and bench.py use) gloo and the RCCL
+    bootstrap are pinned to ``lo`` unless the user chose an interface: both otherwise pick theirs
+    from the HOST NAME, which on a container need not resolve to anything reachable."""
     if dist.is_initialized():
         return rank(), world_size()
     ws = int(os.environ.get('WORLD_SIZE', '1'))
@@ -52,13 +63,20 @@ def init_from_env(backend=None):
     os.environ.setdefault('RANK', '0')
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
+    if _loopback(os.environ['MASTER_ADDR']):
+        os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
+        os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
     if backend is None:
         # BN_DIST_BACKEND=gloo: several ranks on ONE GPU (tests; RCCL refuses two ranks per device)
         backend = os.environ.get('BN_DIST_BACKEND') or (
             'nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
+    if timeout_s is None:
+        timeout_s = float(os.environ.get('BN_DIST_TIMEOUT_S', '600'))
+    import datetime
+    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws,
+                            timeout=datetime.timedelta(seconds=float(timeout_s)))
     return rank(), world_size()
 
 

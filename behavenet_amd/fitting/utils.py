@@ -316,6 +316,8 @@ def experiment_exists(hparams, which_version=False):
 
 def export_hparams(hparams, exp):
     """``meta_tags.pkl`` (pickled dict) + ``meta_tags.csv`` (through ``exp.tag``) of a version."""
+    if getattr(exp, 'debug', False):
+        return          # a non-main rank of a data-parallel fit: rank 0 writes the version's files
     meta_file = os.path.join(hparams['expt_dir'], 'version_%i' % exp.version, 'meta_tags.pkl')
     with open(meta_file, 'wb') as f:
         pickle.dump(hparams, f)
@@ -331,18 +333,34 @@ def create_experiment(hparams):
     test-tube's layout).
     """
     from behavenet_amd.fitting.experiment import Experiment
+    from behavenet_amd.fitting import distributed as bdist
+    # The ranks of ONE data-parallel fit (a process group is up) share one version: rank 0 decides
+    # whether the grid point exists, claims version_K and tells the others, which log into a
+    # file-less Experiment of the same K (rank 0 writes metrics and checkpoints, `fit`).  Ranks of
+    # a grid search (one grid point per rank, no process group: `run_grid`) each claim their own.
+    dp = bdist.is_active() and bdist.world_size() > 1
+    main = (not dp) or bdist.rank() == 0
     hparams['session_dir'], sess_ids = get_session_dir(
         hparams, session_source=hparams.get('all_source', 'save'))
-    if not os.path.isdir(hparams['session_dir']):
-        os.makedirs(hparams['session_dir'])
-        export_session_info_to_csv(hparams['session_dir'], sess_ids)
     hparams['expt_dir'] = get_expt_dir(hparams)
-    os.makedirs(hparams['expt_dir'], exist_ok=True)
-    if experiment_exists(hparams):
+    version = None
+    if main:
+        if not os.path.isdir(hparams['session_dir']):
+            os.makedirs(hparams['session_dir'])
+            export_session_info_to_csv(hparams['session_dir'], sess_ids)
+        os.makedirs(hparams['expt_dir'], exist_ok=True)
+        if not experiment_exists(hparams):
+            exp = Experiment(name=hparams['experiment_name'], debug=False,
+                             save_dir=os.path.dirname(hparams['expt_dir']))
+            exp.save()
+            version = exp.version
+    if dp:
+        version = bdist.broadcast_object(version, src=0)
+        if version is not None and not main:
+            exp = Experiment(name=hparams['experiment_name'], debug=True, version=version,
+                             save_dir=os.path.dirname(hparams['expt_dir']))
+    if version is None:
         return None, None, None
-    exp = Experiment(name=hparams['experiment_name'], debug=False,
-                     save_dir=os.path.dirname(hparams['expt_dir']))
-    exp.save()
     hparams['version'] = exp.version
     return hparams, sess_ids, exp
 

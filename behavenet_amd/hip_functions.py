@@ -735,7 +735,13 @@ class BatchNormActFn(torch.autograd.Function):
                 y, mean, invstd, ctx.sync_count = _hip.batchnorm_sync_train_fwd(
                     x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE,
                     bdist.all_reduce_)
-            elif _bn_bounds is not None and x.shape[0] == _bn_bounds[-1][1]:
+            elif _bn_bounds is not None:
+                if x.shape[0] != _bn_bounds[-1][1]:
+                    # whole-batch statistics here would silently differ from the reference's
+                    # per-chunk ones (and advance num_batches_tracked by 1 instead of n_chunks)
+                    raise RuntimeError(
+                        'batch norm inside bn_chunks(%s): the input has %d frames, the chunk '
+                        'bounds cover %d' % (_bn_bounds, x.shape[0], _bn_bounds[-1][1]))
                 # one pass over the whole batch, statistics per chunk (in chunk order: the
                 # running estimates see the same sequence of updates as in the reference)
                 k = len(_bn_bounds)

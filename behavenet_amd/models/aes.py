@@ -540,7 +540,13 @@ class AE(BaseModel):
 
     def graph_capturable_for(self, x):
         # (batch norm with momentum=None reads its batch counter on the host for the cumulative
-        # average factor: not recordable)
+        # average factor: not recordable; a frame-sharded step of REAL ranks issues collectives from
+        # inside `loss` -- the per-chunk loss table, and a rank with an empty shard takes another
+        # branch than the ones that record -- so it runs eagerly: every rank then issues the same
+        # sequence at the same points)
+        from behavenet_amd.fitting import distributed as bdist
+        if bdist.frames_sharded() and bdist._emulated is None:
+            return False
         return self._whole_batch_ok(x) and not (
             self.hparams.get('ae_batch_norm', False) and
             self.hparams.get('ae_batch_norm_momentum', 0.1) is None)

@@ -94,6 +94,11 @@ def cpu_baseline(hp_template, budget_s=20.0):
     """Time the CPU oracle on the same workload (bounded sample) on this host's cores."""
     from oracle import ref_cpu
     from tests.golden_utils import make_frames
+    from behavenet_amd.hostinfo import limit_host_threads, usable_cpus
+    # threads = the CPUs this container may use (cgroup quota), not the machine's core count:
+    # torch's default of 128 threads on a 16-CPU quota ran this baseline ~4 x slower (round 3's
+    # 54.7 frames/s "on 128 cores"); `cores` below is what is actually used
+    threads = limit_host_threads()
     hp = dict(hp_template)
     hp['device'] = 'cpu'
     torch.manual_seed(0)
@@ -109,11 +114,12 @@ def cpu_baseline(hp_template, budget_s=20.0):
         el = time.perf_counter() - t0
         if el >= budget_s or steps >= 5 or (steps >= 1 and el + el / steps > 1.5 * budget_s):
             break
-    return {'value': BATCH * steps / el, 'unit': 'frames/s', 'cores': torch.get_num_threads(),
+    return {'value': BATCH * steps / el, 'unit': 'frames/s', 'cores': threads,
             'kind': 'port',
             'sample': '%d full training step(s) of the same workload (batch %d, chunks 200+56, '
-                      'fwd+bwd+Adam) in %.1f s, torch %s CPU' % (steps, BATCH, el,
-                                                                torch.__version__)}
+                      'fwd+bwd+Adam) in %.1f s, torch %s CPU, %d threads = the container\'s CPU '
+                      'quota (the machine shows %d hardware threads)' % (
+                          steps, BATCH, el, torch.__version__, usable_cpus(), os.cpu_count() or 0)}
 
 
 def _timed(fn, warm, steps):
@@ -389,7 +395,8 @@ def self_launch(n_gpus):
         port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL between processes)
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    from behavenet_amd.hostinfo import usable_cpus
+    env.setdefault('OMP_NUM_THREADS', str(max(1, usable_cpus() // n_gpus)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node',
            str(n_gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.abspath(__file__)] + sys.argv[1:]

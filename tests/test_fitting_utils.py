@@ -264,6 +264,51 @@ def test_experiment_versions_are_claimed_atomically(tmp_path):
     assert sorted(versions) == list(range(8))
 
 
+def _dp_create(rank, world, port, tree, out):
+    import torch
+    from behavenet_amd.fitting import distributed as bdist
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world)})
+    torch.set_num_threads(1)
+    bdist.init_from_env(backend='gloo', timeout_s=60)
+    hp, _, exp = utils.create_experiment(_hparams(tree))
+    hp['training_completed'] = True
+    utils.export_hparams(hp, exp)
+    exp.log({'epoch': 0, 'val_loss': 0.5 + rank, 'dataset': -1})
+    exp.save()
+    torch.distributed.barrier()
+    again = utils.create_experiment(_hparams(tree))
+    out.put((rank, exp.version, hp['version'], bool(exp.debug), again == (None, None, None)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_ranks_of_one_data_parallel_fit_share_one_version(tree):
+    """Two ranks of ONE fit (process group up) call create_experiment: rank 0 claims version_0 and
+    writes its files, rank 1 logs into a file-less experiment of the same version -- no second
+    version_K with a finished meta_tags and no model in it, and both ranks agree that
+    the grid point exists afterwards."""
+    import pandas as pd
+    import torch.multiprocessing as mp
+    from tests.test_distributed_cpu import _free_port
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_create, args=(r, 2, port, tree, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, 0, 0, False, True), (1, 0, 0, True, True)]
+    expt_dir = os.path.join(tree, 'lab0', 'expt0', 'animal0', 'session-00', 'ae', 'conv',
+                            '08_latents', 'grid')
+    assert sorted(os.listdir(expt_dir)) == ['version_0']
+    df = pd.read_csv(os.path.join(expt_dir, 'version_0', 'metrics.csv'))
+    assert list(df['val_loss']) == [0.5]                    # rank 0's row only
+
+
 def test_data_generator_inputs():
     from behavenet_amd.data.utils import get_data_generator_inputs
     from behavenet_amd.data.transforms import MakeOneHot2D

@@ -92,8 +92,16 @@ CASES = ['ae_cfg1', 'ae_cfg1_b210', 'ae_cfg2', 'ae_1x64x48', 'vae_cfg1', 'betatc
          'ae_maxpool_valid']
 
 
+# which cases took the tie fallback of the test below in this run, and which are known to
+TIE_FALLBACK_TAKEN = []
+TIE_FALLBACK_KNOWN = {'condae_cfg1'}     # one flip in dec.convT1 on the current tilings (round 4)
+TIE_FALLBACK_SEEN_ALL = []
+
+
 @pytest.mark.parametrize('name', CASES)
 def test_forward_loss_grads_vs_oracle_and_golden(name):
+    if name == CASES[-1]:
+        TIE_FALLBACK_SEEN_ALL.append(True)
     z, meta = load_case(name)
     DS = meta.get('dataset', 0)
     hip, ora, hp = _pair(meta)
@@ -179,11 +187,23 @@ def test_forward_loss_grads_vs_oracle_and_golden(name):
                 if variational or meta['extra_hp'].get('ae_batch_norm'):
                     raise
                 _assert_grads_on_device_branches(hip, meta, data_c, data_g, DS, name)
+                TIE_FALLBACK_TAKEN.append(name)
                 break
     # batch-norm running statistics after the same call sequence (one forward, one loss call)
     for (k, bh), (_, bo) in zip(hip.named_buffers(), ora.named_buffers()):
         if 'running_' in k or 'num_batches' in k:
             close(bh.float(), bo.float(), name='%s buffer %s' % (name, k))
+
+
+def test_tie_fallback_was_taken_by_the_known_cases_only():
+    """The escape hatch above (direct comparison fails -> compare on the device's LeakyReLU
+    branches) is for the cases KNOWN to have a pre-activation at a tie on this library's tilings.
+    A regression that turned other cases into "tie" cases must fail here, not print dots."""
+    if not TIE_FALLBACK_SEEN_ALL:
+        pytest.skip('needs the whole of test_forward_loss_grads_vs_oracle_and_golden in this run')
+    print('tie fallback taken by: %s' % sorted(TIE_FALLBACK_TAKEN))
+    extra = set(TIE_FALLBACK_TAKEN) - TIE_FALLBACK_KNOWN
+    assert not extra, 'cases that newly need the tie fallback: %s' % sorted(extra)
 
 
 @pytest.mark.parametrize('name', ['ae_cfg1', 'ae_cfg2', 'vae_cfg1', 'ae_cfg1_bn'])

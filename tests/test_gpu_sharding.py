@@ -177,31 +177,113 @@ def test_batch_coupled_terms_refuse_emulation():
             model.loss(data, dataset=0, accumulate_grad=True)
 
 
-def _run_two_ranks(tmp_path, case):
-    port = 29500 + (os.getpid() % 2000)
-    procs = []
+def _free_port():
+    """A TCP port nobody listens on (bound to 0 and released): two runs never share a rendezvous."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _child_env(**extra):
+    """Environment of a child rank: loopback rendezvous on the loopback INTERFACE (gloo otherwise
+    picks its interface from the host name, which need not resolve on a fresh box), a fresh port,
+    a 60 s ceiling on the rendezvous and every collective, no rank variables inherited."""
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(MASTER_ADDR='127.0.0.1', GLOO_SOCKET_IFNAME='lo', NCCL_SOCKET_IFNAME='lo',
+               BN_DIST_TIMEOUT_S='60', PYTHONFAULTHANDLER='1')
+    env['PYTHONPATH'] = REPO + (os.pathsep + env['PYTHONPATH'] if env.get('PYTHONPATH') else '')
+    # two ranks + this process share the container's CPU quota (behavenet_amd/hostinfo.py)
+    from behavenet_amd.hostinfo import usable_cpus
+    env['OMP_NUM_THREADS'] = env['MKL_NUM_THREADS'] = str(max(1, usable_cpus() // 4))
+    env.update(extra)
+    return env
+
+
+def _wait_all(procs, logs, limit_s, what):
+    """Wait for the child processes (their output goes to FILES: no pipe can fill up and block a
+    rank inside a collective); when the limit expires or one fails, kill every one of them --
+    whole process groups -- and fail with the tail of every log, so that a stall names its cause
+    instead of eating the suite's time limit."""
+    import signal
+    import time
+    t_end = time.time() + limit_s
+    failed = None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                failed = 'exit codes %s' % codes
+                break
+            if all(c == 0 for c in codes):
+                return
+            if time.time() > t_end:
+                failed = 'no exit after %d s (codes %s)' % (limit_s, codes)
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+    tails = []
+    for path in logs:
+        with open(path, errors='replace') as f:
+            tails.append('---- %s ----\n%s' % (os.path.basename(path), f.read()[-3000:]))
+    pytest.fail('%s: %s\n%s' % (what, failed, '\n'.join(tails)), pytrace=False)
+
+
+TWO_RANK_CASES = ['ae_bn', 'psvae', 'betatc', 'vae_bn', 'psvae_bn', 'fit']
+
+
+def _run_two_ranks(tmp, cases, limit_s=240):
+    port = _free_port()
+    procs, logs = [], []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0',
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), BN_DP_SHARD='frames',
-                   PYTHONPATH=REPO)
-        procs.append(subprocess.Popen(
-            [sys.executable, os.path.join(REPO, 'tests', 'dist_gpu_two_ranks.py'), case,
-             str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
-    for p, o in zip(procs, outs):
-        assert p.returncode == 0, o[-3000:]
-    with open(os.path.join(str(tmp_path), case + '_rank0.json')) as f:
+        env = _child_env(RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_PORT=str(port),
+                         BN_DP_SHARD='frames')
+        logs.append(os.path.join(tmp, 'two_ranks_rank%d.log' % r))
+        with open(logs[-1], 'wb') as log:
+            procs.append(subprocess.Popen(
+                [sys.executable, os.path.join(REPO, 'tests', 'dist_gpu_two_ranks.py'),
+                 ','.join(cases), tmp], env=env, stdout=log, stderr=subprocess.STDOUT,
+                stdin=subprocess.DEVNULL, start_new_session=True))
+    _wait_all(procs, logs, limit_s, 'two ranks, cases %s' % ','.join(cases))
+
+
+@pytest.fixture(scope='module')
+def two_rank_dir(tmp_path_factory):
+    """ONE pair of rank processes (one rendezvous, one HIP context each) runs all two-rank cases
+    and leaves their results here; round 3 started a pair per case (25 s for the first)."""
+    tmp = str(tmp_path_factory.mktemp('two_ranks'))
+    _run_two_ranks(tmp, TWO_RANK_CASES)
+    return tmp
+
+
+def _two_rank_result(tmp, case):
+    assert os.path.exists(os.path.join(tmp, case + '.done')), 'case %s did not complete' % case
+    with open(os.path.join(tmp, case + '_rank0.json')) as f:
         return json.load(f)
 
 
-@pytest.mark.parametrize('case', ['ae_bn', 'psvae', 'betatc', 'vae_bn', 'psvae_bn'])
-def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, case):
+@pytest.mark.parametrize('case', TWO_RANK_CASES[:-1])
+def test_two_ranks_on_one_gpu_match_the_single_process_step(two_rank_dir, case):
     """Real collectives (gloo, host-staged) between two processes sharing the GPU: the terms
     emulation cannot provide (SyncBN statistics, the decomposed KL on the all-gathered chunk).
     Loss dict and running statistics against the single-process HIP step; the all-reduced
     gradient -- ALL of it -- against the float64 oracle run on the LeakyReLU branch pattern
     assembled from the two ranks' passes, at the 2e-5 of the unsharded tests."""
-    got = _run_two_ranks(tmp_path, case)
+    tmp_path = two_rank_dir
+    got = _two_rank_result(tmp_path, case)
     from tests.dist_gpu_two_ranks import build_case, build_oracle
     model, data, kw = build_case(case)
     model.zero_grad(set_to_none=True)
@@ -250,8 +332,8 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step(tmp_path, case):
         assert err <= tol, '%s grad %s: normalised max err %.3e (tol %.1e)' % (case, k, err, tol)
 
 
-def test_fit_in_frames_mode_matches_single_process(tmp_path):
-    got = _run_two_ranks(tmp_path, 'fit')
+def test_fit_in_frames_mode_matches_single_process(two_rank_dir, tmp_path):
+    got = _two_rank_result(two_rank_dir, 'fit')
     from tests.dist_gpu_two_ranks import run_fit
     want = run_fit(os.path.join(str(tmp_path), 'single'))
     assert len(got['rows']) == len(want['rows'])
@@ -272,33 +354,36 @@ def test_fit_in_frames_mode_matches_single_process(tmp_path):
     assert np.mean(diff > 0.02 * travel + 1e-3 * np.abs(want['param_sample'])) <= 0.02
 
 
-def _bench_line(cmd, env):
-    out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                         timeout=900).stdout.decode()
+def _bench_line(cmd, env, tmp_path, limit_s=240):
+    log = os.path.join(str(tmp_path), 'bench_%d.log' % len(os.listdir(str(tmp_path))))
+    with open(log, 'wb') as f:
+        proc = subprocess.Popen(cmd, env=env, cwd=REPO, stdout=f, stderr=subprocess.STDOUT,
+                                stdin=subprocess.DEVNULL, start_new_session=True)
+    _wait_all([proc], [log], limit_s, ' '.join(cmd[-8:]))
+    with open(log, errors='replace') as f:
+        out = f.read()
     lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, out[-3000:]
     return json.loads(lines[0])
 
 
 @pytest.mark.parametrize('launcher', ['torchrun', 'self'])
-def test_bench_two_ranks_control_flow(launcher):
+def test_bench_two_ranks_control_flow(launcher, tmp_path):
     """`bench.py --gpus 2` both ways -- as the driver launches it (torch.distributed.run, one
     process per rank) and PLAINLY (`python bench.py --gpus 2`: the script starts its own ranks, as
     the reference's entry point forks its per-GPU processes, ae_grid_search.py:173-181) -- with both
     ranks on the one GPU over gloo: parameter broadcast, per-step gradient all-reduce (mean over
     the ranks' trials), barrier-bracketed timing, max over ranks, one JSON line from rank 0 with
     the whole-job value and what the collective library saw."""
-    env = dict(os.environ, BN_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
-    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
-        env.pop(k, None)
+    env = _child_env(BN_DIST_BACKEND='gloo')
     tail = [os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
             '--no-cpu-baseline', '--no-secondary']
     if launcher == 'torchrun':
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-               '--master-addr', '127.0.0.1', '--master-port', '29517'] + tail
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + tail
     else:
         cmd = [sys.executable] + tail
-    d = _bench_line(cmd, env)
+    d = _bench_line(cmd, env, tmp_path)
     assert d['n_gpus'] == 2 and d['steps'] == 4 and d['scaling'] == 'weak'
     assert d['config']['global_frames_per_step'] == 512
     assert abs(d['value'] - 512 * 1e3 / d['ms_per_step']) <= 0.01 * d['value']
@@ -311,17 +396,16 @@ def test_bench_two_ranks_control_flow(launcher):
     assert ar['allreduce_alone_ms'] > 0
 
 
-def test_bench_two_ranks_frame_sharded():
+def test_bench_two_ranks_frame_sharded(tmp_path):
     """`python bench.py --gpus 2 --shard frames`: the strong-scaling (parity-exact) reading of
     BASELINE configs[2] -- one 256-frame trial per step, 128 frames per rank, summed gradients;
     the loss it reports is the single-device loss of the same trajectory."""
-    env = dict(os.environ, BN_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
-    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
-        env.pop(k, None)
+    env = _child_env(BN_DIST_BACKEND='gloo')
     tail = ['--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary']
     d2 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--shard',
-                      'frames'] + tail, env)
-    d1 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1'] + tail, env)
+                      'frames'] + tail, env, tmp_path)
+    d1 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1'] + tail, env,
+                     tmp_path)
     assert d2['n_gpus'] == 2 and d2['scaling'] == 'strong'
     assert d2['config']['global_frames_per_step'] == 256
     assert d2['config']['frames_per_step_per_gpu'] == 128
