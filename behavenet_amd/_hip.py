@@ -101,6 +101,8 @@ SIGNATURES = {
     'bn_u8_to_unit_float': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_void_p]),
     'bn_prof_select': (_c_int, [_c_int] * 3),
     'bn_prof_read': (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
+    'bn_prof_read_main': (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
+    'bn_prof_set_bracket': (_c_int, [_c_int]),
     'bn_prof_kernel_name': (ctypes.c_char_p, []),
     'bn_prof_dispatch_overhead_us': (ctypes.c_double, [_c_int, _c_void_p]),
 }
@@ -694,6 +696,17 @@ def prof_read():
     _check(load().bn_prof_read(ctypes.byref(ms), ctypes.byref(n)), 'bn_prof_read')
     name = load().bn_prof_kernel_name()
     return ms.value, n.value, (name.decode() if name else '')
+
+
+def prof_set_bracket(on):
+    return load().bn_prof_set_bracket(1 if on else 0)
+
+
+def prof_read_main():
+    """(ms, launches) of the main kernels of the profiled calls (dispatch-attached events)."""
+    ms, n = ctypes.c_double(0.0), ctypes.c_long(0)
+    _check(load().bn_prof_read_main(ctypes.byref(ms), ctypes.byref(n)), 'bn_prof_read_main')
+    return ms.value, n.value
 
 
 # ------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // Shared host/device helpers for libbehavenet_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 #include "../../include/behavenet_hip.h"
@@ -60,18 +61,28 @@ __device__ __forceinline__ float bn_act_grad_from_output(float y, int act, float
 // profiling hook (bn_prof_*): brackets launches of one kernel family with hipEvents
 // ---------------------------------------------------------------------------------------------
 struct BnProfScope {
-    bool active, on_dispatch;
+    bool active;
     hipStream_t stream;
-    hipEvent_t e0, e1;
-    // on_dispatch: the op is ONE kernel whose launcher attaches the events to the dispatch
-    // itself (hipExtLaunchKernelGGL start/stop events = the kernel's own begin/end timestamps,
-    // what rocprofv3 reports) instead of bracketing it with two event records on the stream
-    BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s,
-                bool on_dispatch = false);
+    int slot;
+    // brackets everything the op launches with two event records on the stream AND offers a
+    // second event pair to the launcher of the op's main kernel (BN_LAUNCH_MAIN), which attaches
+    // it to that dispatch (hipExtLaunchKernelGGL start / stop events = the kernel's own begin /
+    // end timestamps, what rocprofv3 reports): bn_prof_read = the op, bn_prof_read_main = the kernel
+    BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s);
     ~BnProfScope();
 };
-// launcher side of on_dispatch: true (and the pair) if a profiling scope is waiting for it
+// launcher side: true (and the pair) if a profiling scope is waiting for its main kernel
 bool bn_prof_take_dispatch_events(hipEvent_t* e0, hipEvent_t* e1);
+
+// launch of an op's MAIN kernel: with bench.py's hook armed the dispatch carries the events
+#define BN_LAUNCH_MAIN(kernel, grid, block, lds, st, ...)                                        \
+    do {                                                                                         \
+        hipEvent_t _e0 = nullptr, _e1 = nullptr;                                                 \
+        if (bn_prof_take_dispatch_events(&_e0, &_e1))                                            \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, st, _e0, _e1, 0, __VA_ARGS__);       \
+        else                                                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                       \
+    } while (0)
 
 #define BN_LAUNCH_CHECK()                                   \
     do {                                                    \

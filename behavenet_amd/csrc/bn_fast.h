@@ -81,3 +81,14 @@ int bn_launch_qgemm_up(const float* small, const float* w, const float* bias, fl
                        void* ws, hipStream_t st);
 int bn_launch_qgemm_wgrad(const float* small, const float* big, float* dw, const BnGeom& g,
                           int accumulate, void* ws, hipStream_t st);
+
+// conv_qgemm2.hip: second generation of the gather-up role and the weight gradient of the same
+// layers (a workgroup walks all four quadrants; operands by LDS-DMA as they lie in memory; the weight
+// gradient adds the quadrants that share a tap itself and yields the bias gradient of either side)
+bool bn_qg2_up_supported(const BnGeom& g, int act, int dact);
+int bn_launch_qg2_up(const float* small, const float* w, const float* bias, float* out,
+                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                     hipStream_t st);
+bool bn_qg2_wgrad_supported(const BnGeom& g);
+int bn_launch_qg2_wgrad(const float* small, const float* big, float* dw, const BnGeom& g,
+                        int accumulate, float* db, int bias_side, hipStream_t st);

@@ -14,81 +14,83 @@
 // profiling hook
 // ------------------------------------------------------------------------------------------
 namespace {
+// One slot per profiled op: a BRACKET pair (hipEventRecord before / after everything the op
+// launches: the whole op, event overhead and launch gaps included) and a DISPATCH pair that the
+// launcher of the op's main kernel attaches to that one dispatch (hipExtLaunchKernelGGL start /
+// stop events = the kernel's own begin / end timestamps, what rocprofv3 reports).
 struct ProfState {
     int family = BN_PROF_NONE;
     int C = 0, K = 0;
-    static const int kMaxPairs = 4096;
-    hipEvent_t ev[2 * kMaxPairs];
-    int created = 0;
-    int used = 0;          // pairs recorded since the last read/reset
-    double total_ms = 0.0;
-    long launches = 0;
+    static const int kMaxSlots = 2048;
+    hipEvent_t ev[4 * kMaxSlots];
+    bool taken[kMaxSlots], bracketed[kMaxSlots];
+    int created = 0;       // slots whose four events exist
+    int used = 0;          // slots recorded since the last read/reset
+    double total_ms = 0.0, main_ms = 0.0;
+    long launches = 0, main_launches = 0;
+    bool bracket = true;   // bn_prof_set_bracket(0): dispatch pair only (nothing extra on the stream)
     char kernel_name[96] = "";
 } g_prof;
 
 void prof_drain() {
     for (int i = 0; i < g_prof.used; ++i) {
         float ms = 0.f;
-        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) == hipSuccess &&
-            hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) == hipSuccess) {
+        if (g_prof.bracketed[i] && hipEventSynchronize(g_prof.ev[4 * i + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, g_prof.ev[4 * i], g_prof.ev[4 * i + 1]) == hipSuccess) {
             g_prof.total_ms += ms;
             g_prof.launches += 1;
+        }
+        if (g_prof.taken[i] && hipEventSynchronize(g_prof.ev[4 * i + 3]) == hipSuccess &&
+            hipEventElapsedTime(&ms, g_prof.ev[4 * i + 2], g_prof.ev[4 * i + 3]) == hipSuccess) {
+            g_prof.main_ms += ms;
+            g_prof.main_launches += 1;
         }
     }
     g_prof.used = 0;
 }
 }  // namespace
 
-static hipEvent_t g_dispatch_e0 = nullptr, g_dispatch_e1 = nullptr;
-static bool g_dispatch_pending = false, g_dispatch_taken = false;
+static int g_dispatch_slot = -1;            // slot whose dispatch pair waits for a launcher
 
 bool bn_prof_take_dispatch_events(hipEvent_t* e0, hipEvent_t* e1) {
-    if (!g_dispatch_pending) return false;
-    *e0 = g_dispatch_e0;
-    *e1 = g_dispatch_e1;
-    g_dispatch_pending = false;
-    g_dispatch_taken = true;
+    if (g_dispatch_slot < 0) return false;
+    *e0 = g_prof.ev[4 * g_dispatch_slot + 2];
+    *e1 = g_prof.ev[4 * g_dispatch_slot + 3];
+    g_prof.taken[g_dispatch_slot] = true;
+    g_dispatch_slot = -1;
     return true;
 }
 
-BnProfScope::BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s,
-                         bool on_dispatch_)
-    : active(false), on_dispatch(on_dispatch_), stream(s), e0(nullptr), e1(nullptr) {
+BnProfScope::BnProfScope(int family, int C, int K, const char* kernel_name, hipStream_t s)
+    : active(false), stream(s), slot(-1) {
     if (g_prof.family == BN_PROF_NONE || g_prof.family != family) return;
     if (g_prof.C > 0 && g_prof.C != C) return;
     if (g_prof.K > 0 && g_prof.K != K) return;
-    if (g_prof.used >= ProfState::kMaxPairs) prof_drain();
+    if (g_dispatch_slot >= 0) return;                 // nested scope (a detour re-entering run_*)
+    if (g_prof.used >= ProfState::kMaxSlots) prof_drain();
     const int i = g_prof.used;
-    while (g_prof.created <= 2 * i + 1) {
-        if (hipEventCreate(&g_prof.ev[g_prof.created]) != hipSuccess) return;
+    while (g_prof.created <= i) {
+        for (int e = 0; e < 4; ++e)
+            if (hipEventCreate(&g_prof.ev[4 * g_prof.created + e]) != hipSuccess) return;
         g_prof.created++;
     }
-    e0 = g_prof.ev[2 * i];
-    e1 = g_prof.ev[2 * i + 1];
     if (kernel_name) {
         strncpy(g_prof.kernel_name, kernel_name, sizeof(g_prof.kernel_name) - 1);
         g_prof.kernel_name[sizeof(g_prof.kernel_name) - 1] = 0;
     }
-    if (on_dispatch) {
-        g_dispatch_e0 = e0;
-        g_dispatch_e1 = e1;
-        g_dispatch_pending = true;
-        g_dispatch_taken = false;
-        active = true;
-        return;
-    }
-    if (hipEventRecord(e0, stream) != hipSuccess) return;
+    g_prof.taken[i] = false;
+    g_prof.bracketed[i] = g_prof.bracket;
+    if (g_prof.bracket && hipEventRecord(g_prof.ev[4 * i], stream) != hipSuccess) return;
+    slot = i;
+    g_dispatch_slot = i;
     active = true;
 }
 
 BnProfScope::~BnProfScope() {
     if (!active) return;
-    if (on_dispatch) {
-        if (g_dispatch_taken) g_prof.used++;
-        g_dispatch_pending = g_dispatch_taken = false;
-        return;
-    }
-    if (hipEventRecord(e1, stream) == hipSuccess) g_prof.used++;
+    g_dispatch_slot = -1;
+    if (!g_prof.bracketed[slot]) { if (g_prof.taken[slot]) g_prof.used++; return; }
+    if (hipEventRecord(g_prof.ev[4 * slot + 1], stream) == hipSuccess) g_prof.used++;
 }
 
 extern "C" int bn_prof_select(int family, int C, int K) {
@@ -97,9 +99,10 @@ extern "C" int bn_prof_select(int family, int C, int K) {
     g_prof.C = C;
     g_prof.K = K;
     g_prof.used = 0;
-    g_prof.total_ms = 0.0;
-    g_prof.launches = 0;
+    g_prof.total_ms = g_prof.main_ms = 0.0;
+    g_prof.launches = g_prof.main_launches = 0;
     g_prof.kernel_name[0] = 0;
+    g_dispatch_slot = -1;
     return 0;
 }
 
@@ -108,6 +111,20 @@ extern "C" int bn_prof_read(double* total_ms, long* launches) {
     prof_drain();
     *total_ms = g_prof.total_ms;
     *launches = g_prof.launches;
+    return 0;
+}
+
+extern "C" int bn_prof_set_bracket(int on) {
+    const int prev = g_prof.bracket ? 1 : 0;
+    g_prof.bracket = on != 0;
+    return prev;
+}
+
+extern "C" int bn_prof_read_main(double* total_ms, long* launches) {
+    if (!total_ms || !launches) return BN_E_BADARG;
+    prof_drain();
+    *total_ms = g_prof.main_ms;
+    *launches = g_prof.main_launches;
     return 0;
 }
 
@@ -416,7 +433,7 @@ static int run_down(int family, const float* big, const float* w, const float* b
                                      : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
         if (ed.supported && epi_ok) {
             const char* name = bn_edge_down_kernel_name(g, act, dact_src != nullptr, false);
-            BnProfScope prof(family, g.Cb, g.Cs, name, st, /*on_dispatch=*/true);
+            BnProfScope prof(family, g.Cb, g.Cs, name, st);
             return bn_launch_edge_down(big, w, bias, out, dact_src, g, act, dact, slope, st);
         }
     }
@@ -500,6 +517,10 @@ static int run_up(int family, const float* small, const float* w, const float* b
         if (rc) return rc;
         return run_up(family, small, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
                       (char*)ws + wb, ws_bytes - wb, st);
+    }
+    if (!generic && bn_qg2_up_supported(g, act, dact_src ? dact : BN_ACT_NONE)) {
+        BnProfScope prof(family, g.Cs, g.Cb, "k_qg2_up", st);
+        return bn_launch_qg2_up(small, w, bias, out, dact_src, g, act, dact, slope, st);
     }
     if (!generic && bn_qgemm_supported(g)) {
         if (bn_qgemm_ws_bytes(1, g) && (!ws || ws_bytes < bn_qgemm_ws_bytes(1, g))) return BN_E_WORKSPACE;
@@ -615,6 +636,13 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         }
         if (bias_done && all_done) *bias_done = true;
         return 0;
+    }
+    if (!generic && bn_qg2_wgrad_supported(g)) {
+        BnProfScope prof(family, g.Cb, g.Cs, "k_qg2_wgrad", st);
+        // the bias gradient of either side is a by-product (the operand tiles pass through LDS)
+        const int rc = bn_launch_qg2_wgrad(small, big, dw, g, accumulate, db, db ? bias_side : 0, st);
+        if (rc == 0 && db && (bias_side == 1 || bias_side == 2) && bias_done) *bias_done = true;
+        return rc;
     }
     if (!generic && bn_qgemm_supported(g)) {
         if (!ws || ws_bytes < bn_qgemm_ws_bytes(2, g)) return BN_E_WORKSPACE;
@@ -790,8 +818,7 @@ extern "C" int bn_conv2d_fwd_u8(const unsigned char* x, const float* w, const fl
     if (!bn_geom_ok(g)) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (u8_fast(g, act)) {
-        BnProfScope prof(BN_PROF_CONV_FWD, g.Cb, g.Cs, bn_edge_down_kernel_name(g, act, false, true), st,
-                         true);
+        BnProfScope prof(BN_PROF_CONV_FWD, g.Cb, g.Cs, bn_edge_down_kernel_name(g, act, false, true), st);
         return bn_launch_edge_down(nullptr, w, b, y, nullptr, g, act, BN_ACT_NONE, slope, st, x);
     }
     const size_t need =

@@ -325,13 +325,13 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
             attr_set = true;
         }
         if (bias_part)
-            hipLaunchKernelGGL(k_wgrad_c1d<true>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
+            BN_LAUNCH_MAIN(k_wgrad_c1d<true>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
                                big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
         else
-            hipLaunchKernelGGL(k_wgrad_c1d<false>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
+            BN_LAUNCH_MAIN(k_wgrad_c1d<false>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
                                big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
     } else {
-        hipLaunchKernelGGL(k_wgrad_c1, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
+        BN_LAUNCH_MAIN(k_wgrad_c1, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
                            (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
     }
     BN_LAUNCH_CHECK();
@@ -1969,7 +1969,7 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_up_c1, dim3(g.N * (g.Hs / UC_TH), g.Cb), dim3(ED_THREADS), UC_LDS, st,
+        BN_LAUNCH_MAIN(k_up_c1, dim3(g.N * (g.Hs / UC_TH), g.Cb), dim3(ED_THREADS), UC_LDS, st,
                            small, w, bias, out, g, act, slope);
         BN_LAUNCH_CHECK();
         return 0;
@@ -1980,10 +1980,10 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
     if (use_m) {
         const dim3 grid_m(g.N, g.Cb), block_m(64 * (g.Hs / UM_R));
         if (target)
-            hipLaunchKernelGGL((k_up_c1m<true>), grid_m, block_m, 0, st, small, w, bias, out, target, mask,
+            BN_LAUNCH_MAIN((k_up_c1m<true>), grid_m, block_m, 0, st, small, w, bias, out, target, mask,
                                dpre, partial, g, act, slope);
         else
-            hipLaunchKernelGGL((k_up_c1m<false>), grid_m, block_m, 0, st, small, w, bias, out, nullptr,
+            BN_LAUNCH_MAIN((k_up_c1m<false>), grid_m, block_m, 0, st, small, w, bias, out, nullptr,
                                nullptr, nullptr, nullptr, g, act, slope);
         BN_LAUNCH_CHECK();
         return 0;
@@ -1991,7 +1991,7 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
     const int units = g.N * g.Cb * (g.Hs / UV_R);
     const int grid = units < 256 * 16 ? units : 256 * 16;
     if (target) {
-        hipLaunchKernelGGL((k_up_c1v<UV_R, true>), dim3(grid), dim3(64), 0, st, small, w, bias, out,
+        BN_LAUNCH_MAIN((k_up_c1v<UV_R, true>), dim3(grid), dim3(64), 0, st, small, w, bias, out,
                            target, mask, dpre, partial, g, act, slope, units);
     } else {
 #ifdef BN_TUNING
@@ -1999,7 +1999,7 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
         if (r4 < 0) { const char* e = bn_tune_env("BN_UP_C1_R4"); r4 = e ? atoi(e) : 0; }
         if (r4 == 1) {
             const int units4 = g.N * g.Cb * (g.Hs / 4);
-            hipLaunchKernelGGL((k_up_c1v<4, false>), dim3(units4 < 256 * 24 ? units4 : 256 * 24),
+            BN_LAUNCH_MAIN((k_up_c1v<4, false>), dim3(units4 < 256 * 24 ? units4 : 256 * 24),
                                dim3(64), 0, st, small, w, bias, out, nullptr, nullptr, nullptr,
                                nullptr, g, act, slope, units4);
             BN_LAUNCH_CHECK();
@@ -2007,13 +2007,13 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
         }
         if (r4 == 16) {
             const int units16 = g.N * g.Cb * (g.Hs / 16);
-            hipLaunchKernelGGL((k_up_c1v<16, false>), dim3(units16), dim3(64), 0, st, small, w, bias,
+            BN_LAUNCH_MAIN((k_up_c1v<16, false>), dim3(units16), dim3(64), 0, st, small, w, bias,
                                out, nullptr, nullptr, nullptr, nullptr, g, act, slope, units16);
             BN_LAUNCH_CHECK();
             return 0;
         }
 #endif
-        hipLaunchKernelGGL((k_up_c1v<UV_R, false>), dim3(grid), dim3(64), 0, st, small, w, bias, out,
+        BN_LAUNCH_MAIN((k_up_c1v<UV_R, false>), dim3(grid), dim3(64), 0, st, small, w, bias, out,
                            nullptr, nullptr, nullptr, nullptr, g, act, slope, units);
     }
     BN_LAUNCH_CHECK();

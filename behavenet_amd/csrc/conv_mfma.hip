@@ -384,7 +384,7 @@ template <int MR, int NR, int CC, int ST>
 static int launch_down(const DownTile& t, dim3 grid, size_t lds, const float* big, const float* w,
                        const float* bias, float* out, const float* dact_src, const BnGeom& g,
                        int act, int dact, float slope, hipStream_t st) {
-    hipLaunchKernelGGL((k_down_mfma<MR, NR, CC, ST, 5, 5, (ST == 2 ? 6 : 13)>), grid,
+    BN_LAUNCH_MAIN((k_down_mfma<MR, NR, CC, ST, 5, 5, (ST == 2 ? 6 : 13)>), grid,
                        dim3(MF_THREADS), lds, st, big, w, bias, out, dact_src, g, t, act, dact,
                        slope);
     BN_LAUNCH_CHECK();
@@ -395,7 +395,7 @@ template <int MR, int NR, int R>
 static int launch_down_s1(const DownTile& t, dim3 grid, size_t lds, const float* big, const float* w,
                           const float* bias, float* out, const float* dact_src, const BnGeom& g,
                           int act, int dact, float slope, hipStream_t st) {
-    hipLaunchKernelGGL((k_down_mfma<MR, NR, 4, 1, R, R, 3>), grid, dim3(MF_THREADS), lds, st, big, w,
+    BN_LAUNCH_MAIN((k_down_mfma<MR, NR, 4, 1, R, R, 3>), grid, dim3(MF_THREADS), lds, st, big, w,
                        bias, out, dact_src, g, t, act, dact, slope);
     BN_LAUNCH_CHECK();
     return 0;

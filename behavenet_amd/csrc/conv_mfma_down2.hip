@@ -444,7 +444,7 @@ static int launch_down2(const Down2Tile& t, dim3 grid, size_t lds, const float* 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_down2_mfma<MR, NR>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
+    BN_LAUNCH_MAIN((k_down2_mfma<MR, NR>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
                        dact_src, g, t, act, dact, slope);
     BN_LAUNCH_CHECK();
     return 0;

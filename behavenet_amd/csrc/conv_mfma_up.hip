@@ -540,7 +540,7 @@ static int launch_up2(const float* small, const float* w, const float* bias, flo
     }
     const int groups = (g.N + T::F - 1) / T::F;
     dim3 grid(groups * T::TPF, (g.Cb + 31) / 32);
-    hipLaunchKernelGGL((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+    BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                        dact_src, g, act, dact, slope);
     BN_LAUNCH_CHECK();
     return 0;
@@ -603,16 +603,16 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
     dim3 grid(groups * t.tiles_per_frame, (g.Cb + 32 * MR - 1) / (32 * MR));
     const size_t lds = up_lds_bytes(t.xl_floats, MR, CC);
     if (MR == 2 && CC == 8) {
-        hipLaunchKernelGGL((k_up_mfma<2, 8>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+        BN_LAUNCH_MAIN((k_up_mfma<2, 8>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                            dact_src, g, t, act, dact, slope);
     } else if (MR == 2) {
-        hipLaunchKernelGGL((k_up_mfma<2, 4>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+        BN_LAUNCH_MAIN((k_up_mfma<2, 4>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                            dact_src, g, t, act, dact, slope);
     } else if (CC == 8) {
-        hipLaunchKernelGGL((k_up_mfma<1, 8>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+        BN_LAUNCH_MAIN((k_up_mfma<1, 8>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                            dact_src, g, t, act, dact, slope);
     } else {
-        hipLaunchKernelGGL((k_up_mfma<1, 4>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+        BN_LAUNCH_MAIN((k_up_mfma<1, 4>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                            dact_src, g, t, act, dact, slope);
     }
     BN_LAUNCH_CHECK();

@@ -522,7 +522,7 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_wgrad4_mfma<LGQ>, grid, dim3(W4_THREADS), lds, st, small, big, part,
+    BN_LAUNCH_MAIN(k_wgrad4_mfma<LGQ>, grid, dim3(W4_THREADS), lds, st, small, big, part,
                        bias_part, g, t);
     BN_LAUNCH_CHECK();
     return 0;
@@ -539,7 +539,7 @@ static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const f
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_wgrad4s_mfma<LGQ, BIAS>), grid, dim3(W4_THREADS),
+    BN_LAUNCH_MAIN((k_wgrad4s_mfma<LGQ, BIAS>), grid, dim3(W4_THREADS),
                        (size_t)2 * W4S<LGQ>::BUFW * 4, st, small, big, part, bias_part, g, n_stages,
                        splits, lg_tpf, nbias);
     BN_LAUNCH_CHECK();

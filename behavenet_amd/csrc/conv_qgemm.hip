@@ -397,7 +397,7 @@ int bn_launch_qgemm_down(const float* big, const float* w, const float* bias, fl
                 nullptr, nullptr, nullptr, 0, 0, 0.f};
     a.kper = ((a.K / splits + QG_KS - 1) / QG_KS) * QG_KS;
     const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4 * splits);
-    hipLaunchKernelGGL(k_qgemm<QG_DOWN>, grid, dim3(256), 0, st, a);
+    BN_LAUNCH_MAIN(k_qgemm<QG_DOWN>, grid, dim3(256), 0, st, a);
     BN_LAUNCH_CHECK();
     const size_t total = (size_t)g.N * g.Cs * 4;
     hipLaunchKernelGGL(k_qg_finish_down, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
@@ -418,7 +418,7 @@ int bn_launch_qgemm_up(const float* small, const float* w, const float* bias, fl
                 out, bias, dact_src, act, dact, slope};
     a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
     const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4);
-    hipLaunchKernelGGL(k_qgemm<QG_UP>, grid, dim3(256), 0, st, a);
+    BN_LAUNCH_MAIN(k_qgemm<QG_UP>, grid, dim3(256), 0, st, a);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -429,7 +429,7 @@ int bn_launch_qgemm_wgrad(const float* small, const float* big, float* dw, const
                 nullptr, nullptr, nullptr, 0, 0, 0.f};
     a.kper = ((a.K + QG_KS - 1) / QG_KS) * QG_KS;
     const dim3 grid(a.Nc / (QG_NB * QG_T), (a.M + QG_T - 1) / QG_T, 4);
-    hipLaunchKernelGGL(k_qgemm<QG_WGRAD>, grid, dim3(256), 0, st, a);
+    BN_LAUNCH_MAIN(k_qgemm<QG_WGRAD>, grid, dim3(256), 0, st, a);
     BN_LAUNCH_CHECK();
     const size_t npair = (size_t)g.Cs * g.Cb;
     hipLaunchKernelGGL(k_qg_finish_wgrad, dim3((unsigned)((npair + 255) / 256)), dim3(256), 0, st,

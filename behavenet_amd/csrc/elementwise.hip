@@ -385,7 +385,7 @@ int bn_launch_adam(float* p, const float* g, float* m, float* v, float* vmax, si
         const char* e = bn_tune_env("BN_ADAM_WT");
         if (e && e[0] == '0') vec = 1;
     }
-    hipLaunchKernelGGL(k_adam_amsgrad, dim3(ew_blocks(vec ? n / 4 + 1 : n)), dim3(EW_THREADS), 0,
+    BN_LAUNCH_MAIN(k_adam_amsgrad, dim3(ew_blocks(vec ? n / 4 + 1 : n)), dim3(EW_THREADS), 0,
                        st, p, g, m, v, vmax, n, step_size, b1, b2, bc2_sqrt, eps, wd, vec);
     BN_LAUNCH_CHECK();
     return 0;

@@ -376,14 +376,17 @@ def geometry_step(arch_json, dim, label, batch=256, names=True):
 
 
 def profile_kernel(model, opt, gen, family, C, K, steps=2):
-    """HIP-event time per launch of one kernel family/geometry over a few extra steps."""
+    """HIP-event time of one kernel family/geometry over a few extra steps: per call (everything it
+    launches, bracketed on the stream) and of its main kernel alone (events attached to the dispatch
+    = the kernel's own begin / end timestamps, what rocprofv3 reports)."""
     _hip.prof_select(family, C, K)
     for _ in range(steps):
         one_step(model, opt, gen)
     torch.cuda.synchronize()
     ms, n, name = _hip.prof_read()
+    main_ms, main_n = _hip.prof_read_main()
     _hip.prof_select(_hip.PROF_NONE)
-    return ms, n, name
+    return ms, n, name, main_ms, main_n
 
 
 def self_launch(n_gpus):
@@ -543,6 +546,7 @@ def main():
         one_step(model, opt, gen)
 
     if os.environ.get('BN_BENCH_NOHOOK') != '1':
+        _hip.prof_set_bracket(False)                    # dispatch-attached events only
         _hip.prof_select(_hip.PROF_CONV_FWD, 1, 32)     # enc.conv0 launches inside the timed region
     barrier()
     t0 = time.perf_counter()
@@ -568,8 +572,10 @@ def main():
         worst = max(range(len(_PARTS)), key=lambda i: sum(_PARTS[i]))
         print('slowest step %d: zero_grad %.2f next_batch %.2f loss %.2f allreduce+step %.2f' % (
             (worst,) + tuple(_PARTS[worst])), file=sys.stderr)
-    conv0_ms, conv0_n, conv0_name = _hip.prof_read()
+    _, _, conv0_name = _hip.prof_read()
+    conv0_ms, conv0_n = _hip.prof_read_main()
     _hip.prof_select(_hip.PROF_NONE)
+    _hip.prof_set_bracket(True)
 
     if bdist.is_active():
         t = torch.tensor([elapsed], dtype=torch.float64,
@@ -680,13 +686,17 @@ def main():
                  4.0 * 2048 * N_LATENTS),
                 ('dec.FF bwd (dx + dW + db)', _hip.PROF_LINEAR_BWD, N_LATENTS, 2048,
                  4.0 * 2048 * N_LATENTS)]:
-            ms, n, name = profile_kernel(model, opt, gen, fam, C, K)
+            ms, n, name, kms, kn = profile_kernel(model, opt, gen, fam, C, K, steps=4)
             if n:
-                tf = flop_per_frame * BATCH * n / (ms * 1e-3) / 1e12
+                # the main kernel alone when its launcher attaches the events, else the whole call
+                t_ms, t_n = (kms, kn) if kn else (ms, n)
+                tf = flop_per_frame * BATCH * t_n / (t_ms * 1e-3) / 1e12
                 extra.append({'layer': label, 'kernel': name, 'bound': 'mfma',
                               'achieved': round(tf, 3), 'peak': FP32_PEAK_TFLOPS,
                               'unit': 'TFLOP/s', 'frac': round(tf / FP32_PEAK_TFLOPS, 5),
-                              'launches': n, 'avg_launch_us': round(ms * 1e3 / n, 1)})
+                              'launches': t_n, 'avg_launch_us': round(t_ms * 1e3 / t_n, 1),
+                              'timed': 'main kernel (dispatch events)' if kn else 'whole call (stream events)',
+                              'whole_call_us': round(ms * 1e3 / n, 1)})
             else:
                 extra.append({'layer': label, 'error': 'no launch matched (%d, %d, %d)' % (fam, C, K)})
         # the two other HBM-bound edge kernels of the step, same event method as `roofline`
@@ -697,13 +707,16 @@ def main():
                 ('enc.conv0 bwd-weight', _hip.PROF_CONV_BWD_W, 1, 32, CONV0_BYTES_PER_FRAME),
                 ('dec.convT4 bwd-weight', _hip.PROF_CONVT_BWD_W, 1, 32, CONV0_BYTES_PER_FRAME),
                 ('dec.convT4 bwd-data', _hip.PROF_CONVT_BWD_D, 1, 32, 65536 + 2 * 524288)]:
-            ms, n, name = profile_kernel(model, opt, gen, fam, C, K)
+            ms, n, name, kms, kn = profile_kernel(model, opt, gen, fam, C, K, steps=4)
             if n:
-                gbs = bytes_per_frame * BATCH * n / (ms * 1e-3) / 1e9
+                t_ms, t_n = (kms, kn) if kn else (ms, n)
+                gbs = bytes_per_frame * BATCH * t_n / (t_ms * 1e-3) / 1e9
                 extra.append({'layer': label, 'kernel': name, 'bound': 'hbm',
                               'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                              'frac': round(gbs / HBM_PEAK_GBS, 4), 'launches': n,
-                              'avg_launch_us': round(ms * 1e3 / n, 1)})
+                              'frac': round(gbs / HBM_PEAK_GBS, 4), 'launches': t_n,
+                              'avg_launch_us': round(t_ms * 1e3 / t_n, 1),
+                              'timed': 'main kernel (dispatch events)' if kn else 'whole call (stream events)',
+                              'whole_call_us': round(ms * 1e3 / n, 1)})
             else:
                 extra.append({'layer': label, 'error': 'no launch matched (%d, %d, %d)' % (fam, C, K)})
         out['roofline_other_kernels'] = extra

@@ -18,6 +18,15 @@
  *     BN_E_* code for an argument/shape error.  No entry point throws or exits.
  *   - "accumulate != 0" means the gradient outputs are added to (+=) instead of overwritten,
  *     which is how the reference accumulates over its 200-frame chunks (aes.py:751-771).
+ *
+ * Deliberately NOT in this ABI: collectives.  SURVEY.md section 8(b) sketched
+ * bn_comm_init / bn_allreduce_grads / bn_comm_destroy; they do not exist.  The gradient
+ * exchange of the data-parallel path (one flat gradient arena, bucketed, overlapped with the
+ * backward pass) is issued from Python through torch.distributed (backend "nccl" = RCCL over
+ * xGMI; behavenet_amd/fitting/distributed.py), which already owns the communicator, its
+ * streams and the rendezvous.  A second RCCL communicator behind this library would duplicate
+ * that state for no kernel of this path: the library only ever sees device pointers, and the
+ * all-reduce operates in place on the same arena the backward kernels accumulate into.
  */
 #ifndef BEHAVENET_HIP_H
 #define BEHAVENET_HIP_H
@@ -344,8 +353,9 @@ int bn_conv2d_fwd_u8(const unsigned char* x, const float* w, const float* b, flo
 int bn_u8_to_unit_float(const unsigned char* in, float* out, size_t n, bn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * In-library kernel timing used by bench.py's roofline line: when enabled, every launch of the
- * selected kernel family is bracketed by hipEvents on its own stream.
+ * In-library kernel timing used by bench.py's roofline line: when enabled, every call of the
+ * selected kernel family is bracketed by hipEvents on its own stream, and the dispatch of its
+ * main kernel carries a second pair.
  * ------------------------------------------------------------------------------------------ */
 #define BN_PROF_NONE        0
 #define BN_PROF_CONV_FWD    1
@@ -359,8 +369,15 @@ int bn_u8_to_unit_float(const unsigned char* in, float* out, size_t n, bn_stream
 #define BN_PROF_LINEAR_BWD  9   /* nn.Linear backward: all launches of one bn_linear_bwd call */
 /* select family + optional geometry filter (C<=0 / K<=0 = any).  Resets the accumulators. */
 int bn_prof_select(int family, int C, int K);
-/* host-synchronising: total milliseconds and launch count since bn_prof_select */
+/* host-synchronising: total milliseconds and call count since bn_prof_select, everything a
+ * call launched (its combine / finish kernels, the two event records and the gaps included) */
 int bn_prof_read(double* total_ms, long* launches);
+/* the same calls, the MAIN kernel of each alone: interval of the events attached to its dispatch
+ * (launches = 0 when the path that served the call does not attach them) */
+int bn_prof_read_main(double* total_ms, long* launches);
+/* on == 0: no bracketing event records (only the dispatch pair; nothing extra goes on the stream
+ * inside a timed region).  Returns the previous setting; default on. */
+int bn_prof_set_bracket(int on);
 /* name of the device kernel that served the most recent launch of the selected family */
 const char* bn_prof_kernel_name(void);
 /* constant part of a dispatch-attached event interval (empty kernel, minimum over iters), us */

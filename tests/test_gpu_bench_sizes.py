@@ -58,8 +58,8 @@ KERNELS_256 = {
     ('E3', 'bwd_d'): 'k_up2_mfma<3, 4>',
     ('E1', 'bwd_w'): 'k_wgrad4s_mfma<5>', ('E2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
     ('E3', 'bwd_w'): 'k_wgrad4s_mfma<3>',
-    ('E4', 'fwd'): 'k_qgemm<0>', ('E4', 'bwd_d'): 'k_qgemm<1>', ('E4', 'bwd_w'): 'k_qgemm<2>',
-    ('D0', 'fwd'): 'k_qgemm<1>', ('D0', 'bwd_d'): 'k_qgemm<0>', ('D0', 'bwd_w'): 'k_qgemm<2>',
+    ('E4', 'fwd'): 'k_qgemm<0>', ('E4', 'bwd_d'): 'k_qg2_up', ('E4', 'bwd_w'): 'k_qg2_wgrad',
+    ('D0', 'fwd'): 'k_qg2_up', ('D0', 'bwd_d'): 'k_qgemm<0>', ('D0', 'bwd_w'): 'k_qg2_wgrad',
     ('D1', 'fwd'): 'k_up2_mfma<3, 4>', ('D2', 'fwd'): 'k_up2_mfma<4, 4>',
     ('D3', 'fwd'): 'k_up2_mfma<5, 4>',
     ('D1', 'bwd_d'): 'k_down2_mfma<2, 1>', ('D2', 'bwd_d'): 'k_down2_mfma<2, 2>',
