@@ -33,6 +33,11 @@ int bn_launch_channel_sum(const float* t, float* db, int N, int C, int npix, int
 int bn_launch_gemm(const GemmArgs& a, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
 size_t bn_gemm_ws_bytes(int M, int N, int K);
 int bn_launch_col_sum(const float* dy, float* db, int M, int N, int accumulate, hipStream_t st);
+// nn.Linear in one launch: up to two products (nullable) and the column sums of dy (M x N) into db
+// (nullable), side by side in one grid
+int bn_launch_linear_jobs(const GemmArgs* g0, const GemmArgs* g1, const float* dy, float* db, int M,
+                          int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+size_t bn_linear_jobs_ws_bytes(int M, int N, int K);
 
 // elementwise.hip
 int bn_launch_act_fwd(const float* x, float* y, size_t n, int act, float slope, hipStream_t st);

@@ -1080,8 +1080,8 @@ extern "C" int bn_linear_fwd(const float* x, const float* w, const float* b, flo
     a.C = y; a.sci = N; a.scj = 1;
     a.M = M; a.N = N; a.K = K;
     a.bias_j = b; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f; a.accumulate = 0;
-    BnProfScope prof(BN_PROF_LINEAR_FWD, K, N, "k_gemm_mfma", (hipStream_t)stream);
-    return bn_launch_gemm(a, (hipStream_t)stream, ws, ws_bytes);
+    BnProfScope prof(BN_PROF_LINEAR_FWD, K, N, "k_linear_jobs", (hipStream_t)stream);
+    return bn_launch_linear_jobs(&a, nullptr, nullptr, nullptr, 0, 0, 0, ws, ws_bytes, (hipStream_t)stream);
 }
 
 extern "C" int bn_linear_bwd(const float* x, const float* w, const float* dy, float* dx,
@@ -1090,35 +1090,31 @@ extern "C" int bn_linear_bwd(const float* x, const float* w, const float* dy, fl
                              bn_stream_t stream) {
     if (!dy || M <= 0 || K <= 0 || N <= 0) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
-    int rc = 0;
-    // (one scope over the data-gradient GEMM, the weight-gradient GEMM and the bias column sum)
-    BnProfScope prof(BN_PROF_LINEAR_BWD, K, N, "k_gemm_mfma (dx) + k_gemm_mfma (dw) + k_col_sum", st);
+    // one launch: data gradient, weight gradient and bias column sums side by side
+    BnProfScope prof(BN_PROF_LINEAR_BWD, K, N, "k_linear_jobs (dx, dW, db)", st);
+    GemmArgs gx, gw;
     if (dx) {
         if (!w) return BN_E_BADARG;
-        GemmArgs a;                       // dx[m,k] = sum_n dy[m,n] w[n,k]
+        GemmArgs& a = gx;                 // dx[m,k] = sum_n dy[m,n] w[n,k]
         a.A = dy; a.sai = N; a.sak = 1;
         a.B = w; a.sbk = K; a.sbj = 1;
         a.C = dx; a.sci = K; a.scj = 1;
         a.M = M; a.N = K; a.K = N;
         a.bias_j = nullptr; a.dact_src = dact_src; a.dact = dact; a.slope = slope;
-        a.accumulate = 0;
-        rc = bn_launch_gemm(a, st, ws, ws_bytes);
-        if (rc) return rc;
+        a.accumulate = 0; a.part = nullptr; a.kslice = 0;
     }
     if (dw) {
         if (!x) return BN_E_BADARG;
-        GemmArgs a;                       // dw[n,k] = sum_m dy[m,n] x[m,k]
+        GemmArgs& a = gw;                 // dw[n,k] = sum_m dy[m,n] x[m,k]
         a.A = dy; a.sai = 1; a.sak = N;
         a.B = x; a.sbk = K; a.sbj = 1;
         a.C = dw; a.sci = K; a.scj = 1;
         a.M = N; a.N = K; a.K = M;
         a.bias_j = nullptr; a.dact_src = nullptr; a.dact = BN_ACT_NONE; a.slope = 0.f;
-        a.accumulate = accumulate;
-        rc = bn_launch_gemm(a, st);
-        if (rc) return rc;
+        a.accumulate = accumulate; a.part = nullptr; a.kslice = 0;
     }
-    if (db) rc = bn_launch_col_sum(dy, db, M, N, accumulate, st);
-    return rc;
+    return bn_launch_linear_jobs(dx ? &gx : nullptr, dw ? &gw : nullptr, dy, db, M, N, accumulate, ws,
+                                 ws_bytes, st);
 }
 
 // ------------------------------------------------------------------------------------------

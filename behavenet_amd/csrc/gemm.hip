@@ -6,25 +6,27 @@
 // B[k=l>>5][j=l&31]; accumulator register t of lane l is C[(t&3)+8*(t>>2)+4*(l>>5)][l&31].
 // The latent GEMMs are skinny (N=12..64 or K=12..64), so a workgroup owns one 32x32 output tile
 // and its SPLITK waves split the reduction dimension, combined in fixed order through LDS.
+#include <string.h>
 #include "bn_common.h"
 #include "bn_launch.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 
-template <int SPLITK>
-__global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
-    __shared__ float red[SPLITK > 1 ? SPLITK * 16 * 64 : 1];
+// One 32x32 tile of C at tile coordinates (bx, by), reduction slice bz of a.kslice, shared by `nw`
+// waves (wave `ws` of them; combined through `red` = nw * 1024 floats in the fixed order of the wave
+// index).  Every wave of the tile must call it; the caller's block may hold other tiles.
+__device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const int by, const int bz,
+                                          const int nw, const int ws, float* red) {
     const int lane = threadIdx.x & 63;
-    const int ws = threadIdx.x >> 6;
-    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int i0 = by * 32, j0 = bx * 32;
     const int li = lane & 31, lk = lane >> 5;
 
-    // this workgroup's slice (gridDim.z slices of a.kslice, a multiple of 16) and this wave's
-    // part of it (even length so k pairs stay aligned)
-    const int zbeg = blockIdx.z * a.kslice;
+    // this tile's slice (slices of a.kslice, a multiple of 16) and this wave's part of it (even
+    // length so k pairs stay aligned)
+    const int zbeg = bz * a.kslice;
     const int zend = min(a.K, zbeg + a.kslice);
-    int kper = (zend - zbeg + SPLITK - 1) / SPLITK;
+    int kper = (zend - zbeg + nw - 1) / nw;
     kper = (kper + 7) & ~7;
     const int kbeg = zbeg + ws * kper;
     const int kend = min(zend, kbeg + kper);
@@ -42,51 +44,82 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
     // operand and feeds 4 MFMA steps from them -- step u pairs k = base+u (lane half 0) with
     // k = base+4+u (lane half 1).  A per-lane 4-byte gather would touch 64 cache lines per
     // instruction for 2 useful floats each; this touches them once per 8 k.
+    // These skinny products are bound by memory LATENCY: a trip requests 32 k of both operands
+    // (8 independent 16-byte loads) before its first MFMA, and the trips of a wave are few.
     const bool vec = (a.sak == 1) && (a.sbk == 1) && ((kbeg & 7) == 0) && ((kend & 7) == 0) &&
                      ((a.sai & 3) == 0) && ((a.sbj & 3) == 0) &&
                      ((((uintptr_t)a.A) | ((uintptr_t)a.B)) & 15u) == 0;
     if (vec) {
-        for (int k0 = kbeg; k0 < kend; k0 += 16) {      // 2 float4 per operand per trip
-            float4 av4[2], bv4[2];
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {      // 4 float4 per operand per trip
+            float4 av4[4], bv4[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 4; ++h) {
                 const int k = min(k0 + 8 * h + 4 * lk, kend - 4);
                 av4[h] = *reinterpret_cast<const float4*>(ap + k);
                 bv4[h] = *reinterpret_cast<const float4*>(bp + k);
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < 4; ++h) {
                 const bool ok = (k0 + 8 * h) < kend;
                 const float ax[4] = {av4[h].x, av4[h].y, av4[h].z, av4[h].w};
-                const float bx[4] = {bv4[h].x, bv4[h].y, bv4[h].z, bv4[h].w};
+                const float bx4[4] = {bv4[h].x, bv4[h].y, bv4[h].z, bv4[h].w};
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_ok && ok) ? ax[u] : 0.f,
-                                                               (b_ok && ok) ? bx[u] : 0.f, acc, 0,
+                                                               (b_ok && ok) ? bx4[u] : 0.f, acc, 0,
                                                                0, 0);
             }
         }
     }
-    // 8 reduction steps per trip: 16 independent (clamped, unconditional) loads are in flight
-    // before the first MFMA needs one -- these skinny GEMMs are latency-, not bandwidth-bound
-    const int klast = max(kend - 1, kbeg);
-    for (int k0 = kbeg + lk; k0 < (vec ? 0 : kend + lk); k0 += 16) {
-        float av[8], bv[8];
+    // A alone unit-stride (the data gradient of a wide layer: A = dy (M x 2048) in rows of 8 KB,
+    // B = the 12-column weight): A by 16-byte loads as above -- a 4-byte gather along a row-strided
+    // operand touches 64 cache lines per instruction, and the CU's line rate, not bytes, sets the
+    // pace -- B by four 4-byte loads from its small, cache-resident matrix
+    const bool veca = !vec && (a.sak == 1) && ((kbeg & 7) == 0) && ((kend & 7) == 0) &&
+                      ((a.sai & 3) == 0) && (((uintptr_t)a.A) & 15u) == 0;
+    if (veca) {
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            float4 av4[4];
+            float bs[4][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+            for (int h = 0; h < 4; ++h) {
+                const int k = min(k0 + 8 * h + 4 * lk, kend - 4);
+                av4[h] = *reinterpret_cast<const float4*>(ap + k);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bs[h][u] = bp[(long)(k + u) * a.sbk];
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const bool ok = (k0 + 8 * h) < kend;
+                const float ax[4] = {av4[h].x, av4[h].y, av4[h].z, av4[h].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_ok && ok) ? ax[u] : 0.f,
+                                                               (b_ok && ok) ? bs[h][u] : 0.f, acc, 0,
+                                                               0, 0);
+            }
+        }
+    }
+    // 16 reduction steps per trip: 32 independent (clamped, unconditional) loads are in flight
+    // before the first MFMA needs one
+    const int klast = max(kend - 1, kbeg);
+    for (int k0 = kbeg + lk; k0 < ((vec || veca) ? 0 : kend + lk); k0 += 32) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
             const int k = min(k0 + 2 * u, klast);
             av[u] = ap[(long)k * a.sak];
             bv[u] = bp[(long)k * a.sbk];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const bool ok = (k0 + 2 * u) < kend;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a_ok && ok) ? av[u] : 0.f,
                                                        (b_ok && ok) ? bv[u] : 0.f, acc, 0, 0, 0);
         }
     }
 
-    if (SPLITK > 1) {
+    if (nw > 1) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) red[(ws * 16 + t) * 64 + lane] = acc[t];
         __syncthreads();
@@ -94,7 +127,7 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             float s = red[t * 64 + lane];
-            for (int w2 = 1; w2 < SPLITK; ++w2) s += red[(w2 * 16 + t) * 64 + lane];
+            for (int w2 = 1; w2 < nw; ++w2) s += red[(w2 * 16 + t) * 64 + lane];
             acc[t] = s;
         }
     }
@@ -105,7 +138,7 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int i = i0 + (t & 3) + 8 * (t >> 2) + 4 * (lane >> 5);
-            if (i < a.M) a.part[((size_t)blockIdx.z * a.M + i) * a.N + j] = acc[t];
+            if (i < a.M) a.part[((size_t)bz * a.M + i) * a.N + j] = acc[t];
         }
         return;
     }
@@ -119,6 +152,137 @@ __global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
         if (a.dact_src) v *= bn_act_grad_from_output(a.dact_src[off], a.dact, a.slope);
         a.C[off] = a.accumulate ? a.C[off] + v : v;
     }
+}
+
+template <int SPLITK>
+__global__ __launch_bounds__(64 * SPLITK) void k_gemm_mfma(GemmArgs a) {
+    __shared__ float red[SPLITK > 1 ? SPLITK * 16 * 64 : 1];
+    gemm_tile(a, blockIdx.x, blockIdx.y, blockIdx.z, SPLITK, threadIdx.x >> 6, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// nn.Linear: the jobs of a direction side by side in ONE grid.  A workgroup of four waves serves
+// 4 / nw units (a unit = one 32x32 tile x one reduction slice), nw waves sharing a unit's reduction
+// (nw = 4 for the deep products, 1 for the 12-deep ones, whose units then share a workgroup); the
+// backward pass runs its three jobs -- data gradient, weight gradient, bias column sums -- in the same
+// launch (they read the same two operands and depend on nothing else).  A 2048-deep product onto a
+// handful of tiles is still split over workgroups (its row-strided operand reads are bound by the
+// CU's cache-line rate: 8 workgroups took 25 us, 128 take 6) and combined in fixed order by
+// k_gemm_combine.  The backward pass used to be three or four launches of 5-11 us for 12.6 MFLOP.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gemm_combine(GemmArgs a, int slices);
+#define GJ_WAVES 4
+struct GemmJob { GemmArgs a; int tiles_x, tiles, slices, nw, blocks; };
+struct LinearJobs {
+    GemmJob g[2];
+    const float* dy; float* db; int M, N, accumulate, db_blocks;     // bias column sums (db nullable)
+};
+
+__global__ __launch_bounds__(64 * GJ_WAVES) void k_linear_jobs(LinearJobs p) {
+    __shared__ float red[GJ_WAVES * 16 * 64];
+    int b = blockIdx.x;
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const GemmJob& job = p.g[q];
+        if (b < job.blocks) {
+            const int upb = GJ_WAVES / job.nw;
+            const int unit = b * upb + wave / job.nw;
+            if (unit >= job.tiles * job.slices) return;
+            const int tile = unit / job.slices, slice = unit - tile * job.slices;
+            gemm_tile(job.a, tile % job.tiles_x, tile / job.tiles_x, slice, job.nw, wave % job.nw,
+                      red + (wave / job.nw) * job.nw * 1024);
+            return;
+        }
+        b -= job.blocks;
+    }
+    // db[n] (+)= sum_m dy[m][n]: 64 columns per workgroup, the rows dealt to the four waves and added
+    // up in the fixed order of the wave index
+    const int col = b * 64 + (threadIdx.x & 63);
+    float acc = 0.f;
+    if (col < p.N) {
+        // sixteen loads in flight, added in row order (one load per trip was a chain of M / 4
+        // memory latencies: 20 us for 256 rows)
+        for (int m0 = wave; m0 < p.M; m0 += 16 * GJ_WAVES) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int m = m0 + u * GJ_WAVES;
+                v[u] = p.dy[(size_t)(m < p.M ? m : wave) * p.N + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (m0 + u * GJ_WAVES < p.M) acc += v[u];
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (wave == 0 && col < p.N) {
+        float v = red[threadIdx.x];
+        for (int w2 = 1; w2 < GJ_WAVES; ++w2) v += red[w2 * 64 + threadIdx.x];
+        p.db[col] = p.accumulate ? p.db[col] + v : v;
+    }
+}
+
+// a long reduction feeding only a handful of output tiles (the 2048 -> n_latents projections:
+// 8 tiles) is split over workgroups, so that it does not run on 8 of the 256 CUs
+static int gemm_slices(int M, int N, int K) {
+    const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
+    if (K < 1024 || tiles > 32) return 1;
+    int s = K / 128;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+static void gemm_job(GemmJob* j, const GemmArgs& a, float* part) {
+    j->a = a;
+    j->tiles_x = (a.N + 31) / 32;
+    j->tiles = j->tiles_x * ((a.M + 31) / 32);
+    j->slices = part ? gemm_slices(a.M, a.N, a.K) : 1;
+    j->a.part = j->slices > 1 ? part : nullptr;
+    j->a.kslice = ((a.K + j->slices - 1) / j->slices + 15) & ~15;
+    const int kw = j->a.kslice / 32;        // >= 32 reduction steps per wave
+    j->nw = kw >= 4 ? 4 : kw >= 2 ? 2 : 1;
+    const int upb = GJ_WAVES / j->nw, units = j->tiles * j->slices;
+    j->blocks = (units + upb - 1) / upb;
+}
+
+size_t bn_linear_jobs_ws_bytes(int M, int N, int K) {
+    const int s = gemm_slices(M, N, K);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
+// up to two products and the column sums of `dy` (M x N, nullable with db) in one launch; a product
+// that is split over workgroups takes its partial tiles through `ws` (g0 first) and is finished by
+// k_gemm_combine
+int bn_launch_linear_jobs(const GemmArgs* g0, const GemmArgs* g1, const float* dy, float* db, int M,
+                          int N, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    LinearJobs p;
+    memset(&p, 0, sizeof(p));
+    int blocks = 0;
+    const GemmArgs* gs[2] = {g0, g1};
+    char* wp = (char*)ws;
+    for (int q = 0; q < 2; ++q)
+        if (gs[q]) {
+            const size_t need = bn_linear_jobs_ws_bytes(gs[q]->M, gs[q]->N, gs[q]->K);
+            float* part = nullptr;
+            if (need && wp && ws_bytes >= need) { part = (float*)wp; wp += need; ws_bytes -= need; }
+            gemm_job(&p.g[q], *gs[q], part);
+            blocks += p.g[q].blocks;
+        }
+    if (db) {
+        p.dy = dy; p.db = db; p.M = M; p.N = N; p.accumulate = accumulate;
+        p.db_blocks = (N + 63) / 64;
+        blocks += p.db_blocks;
+    }
+    if (blocks == 0) return 0;
+    BN_LAUNCH_MAIN(k_linear_jobs, dim3(blocks), dim3(64 * GJ_WAVES), 0, st, p);
+    for (int q = 0; q < 2; ++q)
+        if (gs[q] && p.g[q].slices > 1)
+            hipLaunchKernelGGL(k_gemm_combine, dim3((gs[q]->M * gs[q]->N + 255) / 256), dim3(256), 0, st,
+                               p.g[q].a, p.g[q].slices);
+    BN_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -264,16 +428,6 @@ __global__ __launch_bounds__(64) void k_col_sum(const float* __restrict__ dy,
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (threadIdx.x == 0) db[n] = accumulate ? db[n] + acc : acc;
-}
-
-// a long reduction feeding only a handful of output tiles (the 2048 -> n_latents projections:
-// 7 tiles) is split over workgroups as well, so that it does not run on 7 of the 256 CUs
-static int gemm_slices(int M, int N, int K) {
-    const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
-    if (K < 1024 || tiles > 32) return 1;
-    int s = K / 128;
-    if (s > 16) s = 16;
-    return s < 1 ? 1 : s;
 }
 
 // split of the reduction over workgroups: as many slices as fill the chip twice, 128-deep at least
