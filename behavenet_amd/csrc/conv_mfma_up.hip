@@ -17,6 +17,10 @@
                             // training step dec.convT3 fwd (134 MB of output) 224 -> 206 us, step 4.42 -> 4.39 ms;
                             // sc1 (16): no change; plain (0): the output evicts the weights and tiles from the L2s
 #endif
+#ifndef UP2_ST_AUX_D
+#define UP2_ST_AUX_D UP2_ST_AUX   // the same for the data-gradient epilogue (dact_src given), whose output
+                                  // is read back by the very next kernel (the layer's weight gradient)
+#endif
 
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -441,9 +445,14 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
                     v.x *= d[e].x > 0.f ? 1.f : ds;
                     v.y *= d[e].y > 0.f ? 1.f : ds;
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uintx2u, v), ro,
-                                                      (mlane + mo < g.Cb) ? vo : OOB,
-                                                      (mo * HWb + rho * Wb) * 4, UP2_ST_AUX);
+                if (UP2_ST_AUX_D != UP2_ST_AUX && dact_src)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uintx2u, v), ro,
+                                                          (mlane + mo < g.Cb) ? vo : OOB,
+                                                          (mo * HWb + rho * Wb) * 4, UP2_ST_AUX_D);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(uintx2u, v), ro,
+                                                          (mlane + mo < g.Cb) ? vo : OOB,
+                                                          (mo * HWb + rho * Wb) * 4, UP2_ST_AUX);
             }
         }
     } else {

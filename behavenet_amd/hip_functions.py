@@ -451,6 +451,9 @@ class ConvStackFn(torch.autograd.Function):
         return (None, dx, None) + tuple(grads)
 
 
+_DGRAD_FIRST = os.environ.get('BN_DGRAD_FIRST', '0') == '1'
+
+
 def _stack_backward(ctx, dpre, first_param):
     """Backward pass of a fused conv stack from ``dpre`` = dL/d(pre-activation of the top layer):
     per layer the weight (+bias) gradient, then the data gradient with the activation derivative
@@ -475,6 +478,17 @@ def _stack_backward(ctx, dpre, first_param):
                 if ctx.needs_input_grad[first_param + 2 * i] else None
         need_w = ctx.needs_input_grad[first_param + 2 * i]
         need_b = ctx.needs_input_grad[first_param + 1 + 2 * i]
+        # BN_DGRAD_FIRST=1: data gradient FIRST when the layer below is a single-channel edge layer,
+        # so that this layer's matrix-bound weight gradient runs between the 134 MB of (non-temporal)
+        # data-gradient writes and the HBM-bound weight gradient that reads them back.  Measured
+        # (round 4, one box): no difference (35.2 against 35.1 us for enc.conv0's weight gradient,
+        # step 4.330 against 4.337 ms); that kernel takes 35 us on some boxes and 41 on others in
+        # either order.  Off by default.
+        dpre_below = None
+        if i > 0 and min(plan[i - 1].cin, plan[i - 1].cout) <= 4 and _DGRAD_FIRST:
+            dact_src, dact = acts[i], plan[i - 1].act
+            bwd_data = _hip.conv2d_bwd_data if layer.kind == 'conv' else _hip.convT2d_bwd_data
+            dpre_below = bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
         if need_w:
             gw = _grad_buffer(ctx.param_refs[2 * i])
             gb = _grad_buffer(ctx.param_refs[2 * i + 1]) if need_b else None
@@ -509,7 +523,9 @@ def _stack_backward(ctx, dpre, first_param):
                     _report_ready(ctx.param_refs[2 * i:2 * i + 2])
             if not direct:
                 grads[2 * i], grads[2 * i + 1] = dw, db
-        if i > 0 or ctx.need_dx:
+        if dpre_below is not None:
+            dpre = dpre_below
+        elif i > 0 or ctx.need_dx:
             # fuse the derivative of the layer below into this kernel's epilogue
             dact_src = acts[i] if i > 0 else None
             dact = plan[i - 1].act if i > 0 else _hip.ACT_NONE
