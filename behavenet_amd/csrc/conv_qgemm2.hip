@@ -208,6 +208,9 @@ bool bn_qg2_up_supported(const BnGeom& g, int act, int dact) {
     if (!bn_qgemm_supported(g)) return false;
     if (act == BN_ACT_SIGMOID || dact == BN_ACT_SIGMOID) return false;
     if ((g.Cs % Q2U_KS) != 0 || (g.Cb & 7) != 0) return false;
+    // one workgroup per 32 frames x 8 channels, each as long as the whole launch: below ~128 of them
+    // (a 32-frame shard of a trial: 32) the first generation's finer grid is faster (24 against 40 us)
+    if (((g.N + 31) / 32) * (g.Cb / 8) < 128) return false;
     return true;
 }
 

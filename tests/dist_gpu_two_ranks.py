@@ -146,8 +146,44 @@ def run_fit(tmp):
     return {'rows': rows, 'param_sample': flat[idx.to(flat.device)].cpu().tolist()}
 
 
+def run_refusals():
+    """AEMSP and MSPSVAE under frame sharding: EVERY rank must raise before it issues a kernel or
+    a collective (a rank that went on alone would hang the others in their next collective).  ->
+    {class name: message} of what this rank raised."""
+    from behavenet_amd.models import AEMSP
+    from tests.test_gpu_model import _pair
+    from tests.test_oracle_golden import _msps_case
+    got = {}
+    arch = load_handcrafted_arch(list(DIM), 8, None, check_memory=False)
+    hp = base_hparams(arch, 'cond-ae-msp', {'msp.alpha': 0.05, 'conditional_encoder': False})
+    hp['n_labels'] = 4
+    torch.manual_seed(0)
+    model = AEMSP(hp).to(DEV)
+    data = {'images': torch.from_numpy(make_frames(44, DIM, seed=8)).to(DEV)[None],
+            'labels': torch.from_numpy(make_labels(44, 4, seed=2)).to(DEV)[None]}
+    try:
+        model.loss(data, dataset=0, accumulate_grad=True, chunk_size=30)
+        got['AEMSP'] = None
+    except NotImplementedError as err:
+        got['AEMSP'] = str(err)
+    _, meta, datas_c = _msps_case()
+    msps, _, _ = _pair(meta)
+    datas_g = [{k: v.to(DEV) for k, v in d.items()} for d in datas_c]
+    try:
+        msps.loss(datas_g[0], dataset=meta['sess'][0] if isinstance(meta.get('sess'), list) else 0,
+                  accumulate_grad=True)
+        got['MSPSVAE'] = None
+    except NotImplementedError as err:
+        got['MSPSVAE'] = str(err)
+    return got
+
+
 def run_case(case, tmp, rank):
-    if case == 'fit':
+    if case == 'refuse':
+        out = run_refusals()
+        with open(os.path.join(tmp, 'refuse_rank%d.json' % rank), 'w') as f:
+            json.dump(out, f)
+    elif case == 'fit':
         out = run_fit(os.path.join(tmp, 'rank%d' % rank))
     else:
         from tests.branches import record_branches

@@ -139,6 +139,9 @@ def check_kernel_name(layer, role, n, name):
     elif FAMILY[(layer, role)] == 'k_up_c1m' and n < 128:
         # (one workgroup per frame: batches under 128 frames keep the finer-grained VALU kernel)
         assert name.split('<')[0] == 'k_up_c1v', (layer, role, n, name)
+    elif FAMILY[(layer, role)] == 'k_qg2_up' and n < 128:
+        # (one workgroup per 32 frames x 8 channels: small batches keep the first generation's finer grid)
+        assert name.split('<')[0] == 'k_qgemm', (layer, role, n, name)
     else:
         assert name.split('<')[0] == FAMILY[(layer, role)], (layer, role, n, name)
 
