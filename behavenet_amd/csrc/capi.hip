@@ -605,14 +605,20 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
     const bool generic = force_generic() || !aligned16_all(small, big, dw);
     BnGeom g5;
     if (!generic && taps_plan(2, g, &g5)) {
-        const size_t wb = taps_bytes(g);
+        // dw5 and (when the inner kernel yields it) the bias gradient are WRITTEN into scratch; the
+        // crop kernel adds both to the caller's tensors (the bias row sits behind dw5, inside the
+        // 256-byte rounding of taps_bytes or in the 4 KB the plan adds for it)
+        const size_t wb = taps_bytes(g) + 4096;
         if (!ws || ws_bytes < wb + role_ws_need(2, g5)) return BN_E_WORKSPACE;
-        // (dw5 is written, not accumulated; a bias gradient that has to be accumulated is left to
-        // the caller's channel sums)
+        const int nb = bias_side == 1 ? g.Cs : g.Cb;
+        float* db5 = (db && nb <= 1024) ? (float*)((char*)ws + taps_bytes(g)) : nullptr;
+        bool done = false;
         int rc = run_wgrad(family, small, big, (float*)ws, g5, 0, (char*)ws + wb, ws_bytes - wb, st,
-                           accumulate ? nullptr : db, bias_side, bias_done);
+                           db5, bias_side, &done);
         if (rc) return rc;
-        return bn_launch_crop_taps((const float*)ws, dw, (size_t)g.Cs * g.Cb, g.R, g.S, accumulate, st);
+        if (done && bias_done) *bias_done = true;
+        return bn_launch_crop_taps((const float*)ws, dw, (size_t)g.Cs * g.Cb, g.R, g.S, accumulate, st,
+                                   done ? db5 : nullptr, db, nb);
     }
     if (!generic && chan_plan(2, g, &g5)) {
         const size_t cb = chan_bytes(g);
@@ -740,7 +746,7 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
 // scratch of one role on geometry g (without the bias gradient's)
 static size_t role_ws_need(int role, const BnGeom& g) {
     BnGeom g5;
-    if (taps_plan(role, g, &g5)) return taps_bytes(g) + role_ws_need(role, g5);
+    if (taps_plan(role, g, &g5)) return taps_bytes(g) + (role == 2 ? 4096 : 0) + role_ws_need(role, g5);
     if (chan_plan(role, g, &g5)) return chan_bytes(g) + role_ws_need(role, g5);
     if (bn_qgemm_supported(g)) return bn_qgemm_ws_bytes(role, g);
     BnFastPlan plan;

@@ -110,11 +110,16 @@ __global__ __launch_bounds__(PD_THREADS) void k_pad_taps(const float* __restrict
         w5[q] = (r < R && c < S) ? w[pr * (R * S) + r * S + c] : 0.f;
     }
 }
-// dw[pair][R][S] (+)= dw5[pair][5][5]
+// dw[pair][R][S] (+)= dw5[pair][5][5];  db[i] (+)= db5[i] (the bias gradient the inner kernel left in
+// scratch: it writes, the caller accumulates)
 __global__ __launch_bounds__(PD_THREADS) void k_crop_taps(const float* __restrict__ dw5,
                                                            float* __restrict__ dw, unsigned pairs,
-                                                           int R, int S, int accumulate) {
+                                                           int R, int S, int accumulate,
+                                                           const float* __restrict__ db5,
+                                                           float* __restrict__ db, unsigned nb) {
     const unsigned total = pairs * R * S;
+    if (db5 && blockIdx.x == 0)
+        for (unsigned i = threadIdx.x; i < nb; i += PD_THREADS) db[i] = accumulate ? db[i] + db5[i] : db5[i];
     for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
         const unsigned pr = q / (R * S), t = q - pr * (R * S);
         const int r = t / S, c = t - S * r;
@@ -129,9 +134,9 @@ int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hi
     return 0;
 }
 int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S, int accumulate,
-                        hipStream_t st) {
+                        hipStream_t st, const float* db5, float* db, int nb) {
     hipLaunchKernelGGL(k_crop_taps, dim3(pd_blocks(pairs * R * S)), dim3(PD_THREADS), 0, st, dw5, dw,
-                       (unsigned)pairs, R, S, accumulate);
+                       (unsigned)pairs, R, S, accumulate, db5, db, (unsigned)nb);
     BN_LAUNCH_CHECK();
     return 0;
 }

@@ -372,6 +372,62 @@ def reduce_gradients(optimizer, average=False):
         all_reduce_flat_(optimizer.flat_g, average=average)
 
 
+def sharded_step(optimizer, average=False, divide_by=None):
+    """The optimizer step of SURVEY.md section 8e's alternative: reduce-scatter of the flat gradient
+    arena -> Adam on THIS rank's 1/R shard -> all-gather of the parameter arena, instead of
+    all-reduce + R identical full steps.  Same bytes on the links (an all-reduce is a
+    reduce-scatter and an all-gather), 1/R of the optimizer's 9 x 4 bytes per parameter of HBM
+    traffic per rank; but the all-gather sits BEHIND the step where nothing is left to overlap it,
+    while the bucketed all-reduce rides under the backward pass -- which is why it is an option
+    (``hparams['shard_optimizer']``, ``BN_SHARD_OPTIMIZER=1``) and not the default.
+
+    The update is element-wise, so the parameters come out as after the replicated step wherever
+    the two reductions add the ranks' terms in the same order (two ranks: always).  Needs an
+    optimizer built with ``shard_over == world_size()``; the moments of the other ranks' shards
+    are never touched on this rank."""
+    if not is_active() or world_size() == 1 or _emulated is not None:
+        reduce_gradients(optimizer, average=average)
+        if divide_by is not None:
+            optimizer.flat_g.div_(float(divide_by))
+        optimizer.step()
+        return
+    W, r = world_size(), rank()
+    if getattr(optimizer, 'shard_over', 1) != W:
+        raise ValueError('sharded_step: the optimizer was built for %d shards, the group has %d '
+                         'ranks' % (getattr(optimizer, 'shard_over', 1), W))
+    flat_g, flat_p = optimizer.flat_g, optimizer.flat_p
+    if flat_g.is_cuda:
+        from behavenet_amd.hip_functions import join_side_streams
+        join_side_streams()
+    lo, hi = optimizer.shard_range(r)
+    staged = _backend() == 'gloo' and flat_g.is_cuda
+    if _backend() == 'nccl':
+        dist.reduce_scatter_tensor(flat_g[lo:hi], flat_g, op=dist.ReduceOp.SUM)
+    else:
+        # gloo has no reduce-scatter: one reduce per shard to its owner (the same sums)
+        src = flat_g.detach().cpu() if staged else flat_g
+        for q in range(W):
+            qlo, qhi = optimizer.shard_range(q)
+            dist.reduce(src[qlo:qhi], dst=q, op=dist.ReduceOp.SUM)
+        if staged:
+            flat_g[lo:hi].copy_(src[lo:hi])
+    if average:
+        flat_g[lo:hi].div_(W)
+    if divide_by is not None:
+        flat_g[lo:hi].div_(float(divide_by))
+    optimizer.step_range(lo, hi)
+    if _backend() == 'nccl':
+        dist.all_gather_into_tensor(flat_p, flat_p[lo:hi].clone())
+    else:
+        mine = flat_p[lo:hi].detach().cpu() if staged else flat_p[lo:hi].detach().clone()
+        parts = [torch.empty_like(mine) for _ in range(W)]
+        dist.all_gather(parts, mine)
+        with torch.no_grad():
+            for q, part in enumerate(parts):
+                qlo, qhi = optimizer.shard_range(q)
+                flat_p[qlo:qhi].copy_(part)
+
+
 def all_reduce_scalars(values):
     """Sum a short list of python floats over ranks (loss bookkeeping)."""
     if not is_active() or _emulated is not None:

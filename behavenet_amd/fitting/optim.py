@@ -23,7 +23,11 @@ _ALIGN = 4  # floats (16 bytes)
 
 class FlatAdamAMSGrad(object):
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 shard_over=1):
+        """``shard_over`` = R > 1: the arenas are padded to R equal 16-byte aligned shards, so that
+        ``fitting.distributed.sharded_step`` can reduce-scatter the gradients, step shard r on rank r
+        (``step_range``) and all-gather the parameters."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('optimizer got an empty parameter list')
@@ -39,6 +43,11 @@ class FlatAdamAMSGrad(object):
             self.offsets.append(total)
             total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.numel = total
+        self.shard_over = max(1, int(shard_over))
+        if self.shard_over > 1:
+            per = (total + self.shard_over - 1) // self.shard_over
+            per = (per + _ALIGN - 1) // _ALIGN * _ALIGN
+            total = per * self.shard_over
         self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -70,12 +79,26 @@ class FlatAdamAMSGrad(object):
         self.flat_g.zero_()
 
     def step(self):
+        self.step_range(0, self.flat_p.numel())
+
+    def shard_range(self, r):
+        """[lo, hi) of shard ``r`` of ``shard_over`` in the arenas."""
+        per = self.flat_p.numel() // self.shard_over
+        return r * per, (r + 1) * per
+
+    def step_range(self, lo, hi):
+        """One Adam(amsgrad) step of the arena elements [lo, hi) only (the update is element-wise: a
+        range stepped alone gets bit for bit what a step of the whole arena gives it).  ``lo`` and
+        ``hi`` must be multiples of 4 (16-byte groups)."""
         join_side_streams()   # weight gradients queued on the side stream are complete
         self._grads_in_arena()
         self.step_count += 1
+        if lo % _ALIGN or hi % _ALIGN:
+            raise ValueError('step_range: [%d, %d) is not 16-byte aligned' % (lo, hi))
         if self.flat_p.is_cuda:
             _hip.adam_amsgrad_step(
-                self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.max_exp_avg_sq,
+                self.flat_p[lo:hi], self.flat_g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                self.max_exp_avg_sq[lo:hi],
                 self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                 self.step_count)
         else:

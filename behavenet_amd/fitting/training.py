@@ -181,11 +181,18 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
     ``optimizer`` (optional) injects an object with ``zero_grad()``/``step()``; by default a
     :class:`FlatAdamAMSGrad` over ``model.get_parameters()`` is built.
     """
+    # hparams['shard_optimizer'] (BN_SHARD_OPTIMIZER=1): reduce-scatter -> Adam on this rank's 1/R
+    # shard of the arena -> all-gather, instead of all-reduce + R identical steps
+    # (fitting/distributed.py sharded_step; off by default)
+    shard_opt = bool(hparams.get('shard_optimizer', os.environ.get('BN_SHARD_OPTIMIZER') == '1')) \
+        and bdist.is_active() and bdist.world_size() > 1
     if optimizer is None:
         from behavenet_amd.fitting.optim import FlatAdamAMSGrad
         optimizer = FlatAdamAMSGrad(
             model.get_parameters(), lr=hparams['learning_rate'],
-            weight_decay=hparams.get('l2_reg', 0))
+            weight_decay=hparams.get('l2_reg', 0),
+            shard_over=bdist.world_size() if shard_opt else 1)
+    shard_opt = shard_opt and getattr(optimizer, 'shard_over', 1) == bdist.world_size()
     flat_g = getattr(optimizer, 'flat_g', None)
     if hparams.get('dp_shard') is not None:
         bdist.set_shard_mode(hparams['dp_shard'])
@@ -194,7 +201,8 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
     trial_mode = world > 1 and bdist.shard_mode() == 'trial'
     if bdist.is_active() and getattr(optimizer, 'flat_p', None) is not None:
         bdist.broadcast_parameters_(optimizer.flat_p)
-        bdist.attach_reducer(optimizer)
+        if not shard_opt:
+            bdist.attach_reducer(optimizer)
 
     reducer = getattr(optimizer, 'reducer', None)
     overlap_pref = reducer.overlap if reducer is not None else False
@@ -294,14 +302,17 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
                 loss_dict = loss_fn(data, dataset=dataset, accumulate_grad=True)
                 logger.update_metrics('train', loss_dict, dataset=dataset)
             if stepping and i_epoch > 0:
-                if flat_g is not None:
-                    if trial_mode:
-                        # mean over the trials of this step (a rank without one adds zeros)
-                        bdist.reduce_gradients(optimizer)
-                        optimizer.flat_g.div_(float(n_in_step))
-                    else:
-                        bdist.reduce_gradients(optimizer)
-                optimizer.step()
+                if flat_g is not None and shard_opt:
+                    bdist.sharded_step(optimizer, divide_by=n_in_step if trial_mode else None)
+                else:
+                    if flat_g is not None:
+                        if trial_mode:
+                            # mean over the trials of this step (a rank without one adds zeros)
+                            bdist.reduce_gradients(optimizer)
+                            optimizer.flat_g.div_(float(n_in_step))
+                        else:
+                            bdist.reduce_gradients(optimizer)
+                    optimizer.step()
 
             if (i_train + 1) % n_train == 0:
                 if trial_mode:

@@ -82,8 +82,11 @@ def one_step(model, opt, gen):
     if t: t.append(time.perf_counter())
     loss = model.loss(data, dataset=dataset, accumulate_grad=True)
     if t: t.append(time.perf_counter())
-    bdist.reduce_gradients(opt, average=_AVERAGE)
-    opt.step()
+    if getattr(opt, 'shard_over', 1) > 1:
+        bdist.sharded_step(opt, average=_AVERAGE)      # --shard-optimizer
+    else:
+        bdist.reduce_gradients(opt, average=_AVERAGE)
+        opt.step()
     if t:
         t.append(time.perf_counter())
         _PARTS.append([(b - a) * 1e3 for a, b in zip(t[:-1], t[1:])])
@@ -449,6 +452,9 @@ def main():
                     help="where the trials live (default 'device': resident float32, the headline "
                          "metric; 'host_u8' = pinned uint8 + prefetch, the PCIe-inclusive rate)")
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--shard-optimizer', action='store_true',
+                    help='N > 1: reduce-scatter -> Adam on 1/N of the arena per rank -> all-gather, instead '
+                         'of the overlapped bucketed all-reduce + N identical steps')
     ap.add_argument('--shard', default='trial', choices=['trial', 'frames'],
                     help="N > 1: 'trial' = one 256-frame trial per rank per step (weak scaling), "
                          "'frames' = the ranks share ONE trial, each takes its slice of every "
@@ -476,10 +482,12 @@ def main():
     hp = build_hparams()
     torch.manual_seed(hp['rng_seed_model'])
     model = AE(hp).to('cuda')
+    shard_opt = args.shard_optimizer and world > 1
     opt = FlatAdamAMSGrad(model.get_parameters(), lr=hp['learning_rate'],
-                          weight_decay=hp['l2_reg'])
+                          weight_decay=hp['l2_reg'], shard_over=world if shard_opt else 1)
     bdist.broadcast_parameters_(opt.flat_p)
-    bdist.attach_reducer(opt)
+    if not shard_opt:
+        bdist.attach_reducer(opt)
 
     # 20 trials x 256 frames per rank, trial_splits 8;1;1;0 -> 16 train trials
     # ('frames': every rank holds the same trials and walks them in the same order)

@@ -178,8 +178,34 @@ def run_refusals():
     return got
 
 
+def run_sharded_optimizer():
+    """Three optimizer steps of an AE on this rank's frames: reduce-scatter -> Adam on this rank's
+    half of the arena -> all-gather (`bdist.sharded_step`) against all-reduce + the full step, on the
+    device kernel.  -> max |difference| of the parameters (two ranks: must be 0)."""
+    import copy
+    model, data, kw = build_case('ae_bn')
+    twin = copy.deepcopy(model)
+    opt_s = FlatAdamAMSGrad(model.get_parameters(), lr=1e-3, shard_over=2)
+    opt_r = FlatAdamAMSGrad(twin.get_parameters(), lr=1e-3)
+    for _ in range(3):
+        for m, opt in ((model, opt_s), (twin, opt_r)):
+            opt.zero_grad()
+            m.loss(data, dataset=0, accumulate_grad=True, **kw)
+        bdist.sharded_step(opt_s)
+        bdist.reduce_gradients(opt_r)
+        opt_r.step()
+    n = opt_r.flat_p.numel()
+    diff = float((opt_s.flat_p[:n] - opt_r.flat_p).abs().max().item())
+    return {'max_abs_diff': diff, 'params_finite': bool(torch.isfinite(opt_s.flat_p).all().item()),
+            'steps': opt_s.step_count}
+
+
 def run_case(case, tmp, rank):
-    if case == 'refuse':
+    if case == 'shardopt':
+        out = run_sharded_optimizer()
+        with open(os.path.join(tmp, 'shardopt_rank%d.json' % rank), 'w') as f:
+            json.dump(out, f)
+    elif case == 'refuse':
         out = run_refusals()
         with open(os.path.join(tmp, 'refuse_rank%d.json' % rank), 'w') as f:
             json.dump(out, f)

@@ -163,3 +163,85 @@ def test_bucketed_reducer_equals_flat_all_reduce():
     assert results[0][1] == max(results[0][2]) >= 3     # every bucket went out before finish()
     assert 0 < results[1][1] < results[0][1]     # a missing parameter holds its bucket and later ones
     assert results[2][1] == 0
+
+
+class _CpuShardedAdam(object):
+    """FlatAdamAMSGrad's sharding interface (flat_p, flat_g, shard_over, shard_range, step,
+    step_range) on the CPU, with the element-wise Adam(amsgrad) update written out."""
+
+    def __init__(self, n, shard_over, lr=1e-2):
+        per = ((n + shard_over - 1) // shard_over + 3) // 4 * 4
+        total = per * shard_over
+        self.shard_over, self.lr, self.t = shard_over, lr, 0
+        g = torch.Generator().manual_seed(5)
+        self.flat_p = torch.randn(total, generator=g)
+        self.flat_g = torch.zeros(total)
+        self.m, self.v, self.vmax = torch.zeros(total), torch.zeros(total), torch.zeros(total)
+
+    def shard_range(self, r):
+        per = self.flat_p.numel() // self.shard_over
+        return r * per, (r + 1) * per
+
+    def step(self):
+        self.step_range(0, self.flat_p.numel())
+
+    def step_range(self, lo, hi):
+        self.t += 1
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        g = self.flat_g[lo:hi]
+        self.m[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
+        self.v[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
+        torch.maximum(self.vmax[lo:hi], self.v[lo:hi], out=self.vmax[lo:hi])
+        denom = (self.vmax[lo:hi].sqrt() / (1 - b2 ** self.t) ** 0.5).add_(eps)
+        self.flat_p[lo:hi].addcdiv_(self.m[lo:hi], denom, value=-self.lr / (1 - b1 ** self.t))
+
+
+def _sharded_step_worker(rank, world, port, out):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port),
+                       'RANK': str(rank), 'WORLD_SIZE': str(world)})
+    torch.set_num_threads(1)
+    bdist.init_from_env(backend='gloo')
+    n = 10007                                     # not a multiple of anything
+    sharded, replicated = _CpuShardedAdam(n, world), _CpuShardedAdam(n, world)
+    for step in range(3):
+        g = torch.randn(sharded.flat_g.shape, generator=torch.Generator().manual_seed(100 * step + rank))
+        sharded.flat_g.copy_(g)
+        replicated.flat_g.copy_(g)
+        bdist.sharded_step(sharded, average=(step == 1), divide_by=3.0 if step == 2 else None)
+        # the replicated step: all-reduce, the same scalings, a full step on every rank
+        bdist.all_reduce_flat_(replicated.flat_g, average=(step == 1))
+        if step == 2:
+            replicated.flat_g.div_(3.0)
+        replicated.step()
+    lo, hi = sharded.shard_range(rank)
+    others_untouched = bool((sharded.m[:lo] == 0).all() and (sharded.m[hi:] == 0).all())
+    out.put((rank, sharded.flat_p.numpy().copy(), replicated.flat_p.numpy().copy(), others_untouched))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_optimizer_step_equals_the_replicated_step(world):
+    """reduce-scatter -> Adam on this rank's shard -> all-gather (fitting/distributed.py
+    sharded_step) against all-reduce + identical full steps: the same
+    parameters on every rank -- bit for bit with two ranks (a + b in either form), to rounding
+    with three (the two reductions may add the ranks' terms in different orders) -- and the
+    moments of the other ranks' shards never touched."""
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_step_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = results[0][1]
+    for rank, got, want, untouched in results:
+        assert untouched, rank
+        np.testing.assert_array_equal(got, ref)            # every rank holds the same parameters
+        if world == 2:
+            np.testing.assert_array_equal(got, want)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)

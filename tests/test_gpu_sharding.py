@@ -242,7 +242,7 @@ def _wait_all(procs, logs, limit_s, what):
     pytest.fail('%s: %s\n%s' % (what, failed, '\n'.join(tails)), pytrace=False)
 
 
-TWO_RANK_CASES = ['ae_bn', 'psvae', 'betatc', 'vae_bn', 'psvae_bn', 'refuse', 'fit']
+TWO_RANK_CASES = ['ae_bn', 'psvae', 'betatc', 'vae_bn', 'psvae_bn', 'refuse', 'shardopt', 'fit']
 
 
 def _run_two_ranks(tmp, cases, limit_s=240):
@@ -275,6 +275,18 @@ def _two_rank_result(tmp, case):
         return json.load(f)
 
 
+def test_sharded_optimizer_step_on_two_ranks_equals_the_replicated_step(two_rank_dir):
+    """`bdist.sharded_step` with the device kernel (`FlatAdamAMSGrad.step_range` on this rank's half
+    of the arena) against all-reduce + the full step, three steps of a frame-sharded AE with batch
+    norm: bit-identical parameters on both ranks."""
+    assert os.path.exists(os.path.join(two_rank_dir, 'shardopt.done'))
+    for r in range(2):
+        with open(os.path.join(two_rank_dir, 'shardopt_rank%d.json' % r)) as f:
+            got = json.load(f)
+        assert got['params_finite'] and got['steps'] == 3, got
+        assert got['max_abs_diff'] == 0.0, (r, got)
+
+
 def test_frame_sharding_is_refused_on_every_rank_for_the_session_coupled_models(two_rank_dir):
     """`AEMSP` and `MSPSVAE` are not served by frame sharding (their projection / triplet terms are
     not sharded here; reference terms vaes.py:1040-1048, aes.py:1062-1065): BOTH ranks must raise
@@ -288,7 +300,7 @@ def test_frame_sharding_is_refused_on_every_rank_for_the_session_coupled_models(
             assert got[cls] is not None and 'frame' in got[cls].lower(), (r, cls, got[cls])
 
 
-@pytest.mark.parametrize('case', TWO_RANK_CASES[:-2])
+@pytest.mark.parametrize('case', TWO_RANK_CASES[:-3])
 def test_two_ranks_on_one_gpu_match_the_single_process_step(two_rank_dir, case):
     """Real collectives (gloo, host-staged) between two processes sharing the GPU: the terms
     emulation cannot provide (SyncBN statistics, the decomposed KL on the all-gathered chunk).
