@@ -37,7 +37,12 @@ struct BnGeom {
     int Cb, Hb, Wb;   // big side
     int R, S, stride;
     int pt, pl;       // offset of tap (0,0) of small pixel (0,0) in big coordinates is (-pt,-pl)
+    int CsS;          // channels per FRAME of the small tensor in memory when it is a channel window of
+                      // a wider tensor (0 = Cs: contiguous).  Honoured by the single-channel edge kernels
+                      // that serve channel groups in place (k_down_c1p, k_down_c1s, k_wgrad_c1d); every
+                      // other kernel requires 0.
 };
+static inline __host__ __device__ int bn_cs_stride(const BnGeom& g) { return g.CsS > 0 ? g.CsS : g.Cs; }
 
 static inline int bn_geom_ok(const BnGeom& g) {
     return g.N > 0 && g.Cs > 0 && g.Hs > 0 && g.Ws > 0 && g.Cb > 0 && g.Hb > 0 && g.Wb > 0 &&

@@ -174,14 +174,14 @@ static inline BnGeom conv_geom(int N, int C, int H, int W, int K, int R, int S, 
                                int pad_t, int pad_l, int P, int Q) {
     BnGeom g;
     g.N = N; g.Cs = K; g.Hs = P; g.Ws = Q; g.Cb = C; g.Hb = H; g.Wb = W;
-    g.R = R; g.S = S; g.stride = stride; g.pt = pad_t; g.pl = pad_l;
+    g.R = R; g.S = S; g.stride = stride; g.pt = pad_t; g.pl = pad_l; g.CsS = 0;
     return g;
 }
 static inline BnGeom convT_geom(int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                                 int crop_t, int crop_l, int Ho, int Wo) {
     BnGeom g;
     g.N = N; g.Cs = Ci; g.Hs = Hi; g.Ws = Wi; g.Cb = Co; g.Hb = Ho; g.Wb = Wo;
-    g.R = R; g.S = S; g.stride = stride; g.pt = crop_t; g.pl = crop_l;
+    g.R = R; g.S = S; g.stride = stride; g.pt = crop_t; g.pl = crop_l; g.CsS = 0;
     return g;
 }
 
@@ -416,6 +416,23 @@ static int run_down(int family, const float* big, const float* w, const float* b
         const size_t cb = chan_bytes(g);
         if (!ws || ws_bytes < cb + role_ws_need(0, g5)) return BN_E_WORKSPACE;
         const int PQ = g.Hs * g.Ws;
+        // the edge kernels write a group straight into its channel window of the output (frames of
+        // Cs channels, BnGeom::CsS) and read the mask there: no contiguous copy, no k_chan_copy
+        const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
+                                     : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
+        if (g.Cb == 1 && bn_edge_down_plan(g5).supported && epi_ok) {
+            BnGeom gw = g5;
+            gw.CsS = g.Cs;
+            for (int c0 = 0; c0 < g.Cs; c0 += 32) {
+                BnProfScope prof(family, g.Cb, g.Cs, bn_edge_down_kernel_name(g5, act, dact_src != nullptr, false), st);
+                const int rc = bn_launch_edge_down(big, w + (size_t)c0 * g.Cb * 25, bias ? bias + c0 : nullptr,
+                                                   out + (size_t)c0 * PQ,
+                                                   dact_src ? dact_src + (size_t)c0 * PQ : nullptr, gw, act,
+                                                   dact, slope, st);
+                if (rc) return rc;
+            }
+            return 0;
+        }
         for (int c0 = 0; c0 < g.Cs; c0 += 32) {
             int rc = run_down(family, big, w + (size_t)c0 * g.Cb * 25, bias ? bias + c0 : nullptr, (float*)ws,
                               nullptr, g5, act, BN_ACT_NONE, slope, (char*)ws + cb, ws_bytes - cb, st);
@@ -625,6 +642,28 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         if (!ws || ws_bytes < cb + role_ws_need(2, g5)) return BN_E_WORKSPACE;
         const int PQ = g.Hs * g.Ws;
         bool all_done = db && bias_side == 1;
+        // k_wgrad_c1d reads a group from its channel window of the small tensor (BnGeom::CsS)
+        const BnFastPlan edw = bn_edge_wgrad_plan(g5);
+        if (g.Cb == 1 && edw.supported && g5.pt == 1 && g5.pl == 1) {
+            BnGeom gw = g5;
+            gw.CsS = g.Cs;
+            if (!ws_ok(edw, (char*)ws + cb, ws_bytes - cb)) return BN_E_WORKSPACE;
+            for (int c0 = 0; c0 < g.Cs; c0 += 32) {
+                BnProfScope prof(family, g.Cb, g.Cs, edw.kernel_name, st);
+                bool done = false;
+                const int rc = bn_launch_edge_wgrad(edw, small + (size_t)c0 * PQ, big, dw + (size_t)c0 * g.Cb * 25,
+                                                    gw, accumulate, (char*)ws + cb, st,
+                                                    (db && bias_side == 1) ? db + c0 : nullptr, bias_side, &done);
+                if (rc) return rc;
+                if (db && bias_side == 1 && !done) {
+                    if (c0 > 0) return BN_E_BADARG;
+                    all_done = false;
+                    db = nullptr;
+                }
+            }
+            if (bias_done && all_done) *bias_done = true;
+            return 0;
+        }
         for (int c0 = 0; c0 < g.Cs; c0 += 32) {
             int rc = bn_launch_chan_copy(small, (float*)ws, g.N, g.Cs, c0, 32, 0, 32, PQ, nullptr, 0, 0.f, st);
             if (rc) return rc;

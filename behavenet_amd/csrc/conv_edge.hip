@@ -179,9 +179,12 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
     const int PQ = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
     const int bch = blockIdx.y;
     const bool do_bias = BIAS && bch == 0;
+    // (the small side may be a window of Cs channels in frames of css: the last frame's window ends
+    // the buffer range)
+    const int css = bn_cs_stride(g);
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+        (void*)small, 0, (int)((((size_t)g.N - 1) * css + g.Cs) * PQ * 4), 0x00020000);
     // the big image is addressed from one row above its start (patch row y = image row 2 p0 - 1 + y)
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(big - g.Wb), 0, (int)(((size_t)g.N * g.Cb * HWb + g.Wb) * 4), 0x00020000);
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
         float* img = wsm + buf * WD_BUF;
         if (d < 8) {
             if (wv + 4 * d < g.Cs)                                   // wave-uniform
-                wd_dma16(rs, img + (wv + 4 * d) * WD_SP, svo, ((n * g.Cs + 4 * d) * g.Hs + p0) * g.Ws * 4);
+                wd_dma16(rs, img + (wv + 4 * d) * WD_SP, svo, ((n * css + 4 * d) * g.Hs + p0) * g.Ws * 4);
         } else {
             const int k = d - 8;
             if (64 * (wv + 4 * k) < WD_BGP) {                        // wave-uniform
@@ -313,6 +316,7 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
     // Conv2d bias gradient (sum of the small side) as a by-product
     float* bias_part = (db && bias_side == 1)
         ? (float*)ws + (size_t)g.Cb * plan.d * g.Cs * 25 : nullptr;
+    if (g.CsS > 0 && g.CsS != g.Cs && !(g.pt == 1 && g.pl == 1)) return BN_E_SHAPE;   // k_wgrad_c1d only
     if (g.pt == 1 && g.pl == 1) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -655,10 +659,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 
 
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)big_, 0, (int)((size_t)g.N * CB * HWb * (U8 ? 1 : 4)), 0x00020000);
+    const int css = bn_cs_stride(g);         // output (and mask): a window of Cs channels in frames of css
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)out, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+        (void*)out, 0, (int)((((size_t)g.N - 1) * css + g.Cs) * PQ * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(MASK ? dact_src : out), 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+        (void*)(MASK ? dact_src : out), 0, (int)((((size_t)g.N - 1) * css + g.Cs) * PQ * 4), 0x00020000);
 
     // the zero columns left and right of the image never change: written once
     for (int e = lane; e < CB * IH * 8; e += 64) {
@@ -782,7 +787,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 
                                                                    acc[qh], 0, 0, 0);
             }
             // 16 x 2 dword stores: lanes 0-31 one 128-byte line of channel ch, lanes 32-63 of ch+4
-            const int row_off = ((n * g.Cs * g.Hs + (p0 + pr)) * DC_W) * 4;
+            const int row_off = ((n * css * g.Hs + (p0 + pr)) * DC_W) * 4;
 #pragma unroll
             for (int qh = 0; qh < 2; ++qh) {
                 float d[16];
@@ -1066,8 +1071,9 @@ __device__ __forceinline__ void dp_body(
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 800 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbi = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(bias ? bias : w), 0, bias ? 32 * 4 : 0, 0x00020000);          // no bias: reads 0
+    const int css = bn_cs_stride(g);         // output: a window of Cs channels in frames of css
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)out, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+        (void*)out, 0, (int)((((size_t)g.N - 1) * css + g.Cs) * PQ * 4), 0x00020000);
 
     // first instructions: weights (wave wv copies groups 64 wv ..), bias (wave 3's free lanes), image
     {
@@ -1188,7 +1194,7 @@ __device__ __forceinline__ void dp_body(
         const int n = u / spf;
         const int p0 = STRIP * (u - n * spf);
         // byte offset of (strip row j of this wave, half qh) in channel 0
-#define DP_OFF(j, qh) (((n * g.Cs * g.Hs + p0 + wv + DW_WAVES * (j)) * DC_W + 32 * (qh)) * 4)
+#define DP_OFF(j, qh) (((n * css * g.Hs + p0 + wv + DW_WAVES * (j)) * DC_W + 32 * (qh)) * 4)
         floatx16 a0, a1;
         half(a0, a0, wv, 0, false, 0);                                  // (no previous half row yet)
         if (u == (int)blockIdx.x) E0_MARK(2);
@@ -1383,6 +1389,9 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
             : launch_down_c1p<BN_ACT_NONE, 16>(big, w, bias, out, g, slope, st, e0, e1);
     }
     if (variant == 4 || variant == 5) variant = 3;
+    // (a channel window in wider frames, BnGeom::CsS: only k_down_c1p and k_down_c1s address it)
+    const bool windowed = g.CsS > 0 && g.CsS != g.Cs;
+    if (windowed && variant != 1 && variant != 2) variant = 1;
     if (variant == 3 && !dact_src && down_c1w_ok(g))
         return act == BN_ACT_LRELU
             ? launch_down_c1w<BN_ACT_LRELU>(big, w, bias, out, g, slope, st, e0, e1)

@@ -20,7 +20,7 @@ int main(int argc, char** argv) {
     const char* layer = argc > 1 ? argv[1] : "E2";
     const int N = argc > 2 ? atoi(argv[2]) : 256;
     int MR = argc > 3 ? atoi(argv[3]) : 2, NR = argc > 4 ? atoi(argv[4]) : 2;
-    BnGeom g;
+    BnGeom g; g.CsS = 0;
     g.N = N; g.R = g.S = 5; g.stride = 2; g.pt = 1; g.pl = 1;
     if (!strcmp(layer, "E1")) { g.Cb = 32; g.Hb = g.Wb = 64; g.Cs = 64; }
     else if (!strcmp(layer, "E2")) { g.Cb = 64; g.Hb = g.Wb = 32; g.Cs = 128; }

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_heat(float* sink, int iters, float seed
 
 int main(int argc, char** argv) {
     const int N = 256;
-    BnGeom g;
+    BnGeom g; g.CsS = 0;
     g.N = N; g.R = g.S = 5; g.stride = 2; g.pt = 1; g.pl = 1;
     g.Cs = 32; g.Hs = g.Ws = 64; g.Cb = 1; g.Hb = g.Wb = 128;
     const size_t nb = (size_t)N * 128 * 128, ns = (size_t)N * 32 * 64 * 64;

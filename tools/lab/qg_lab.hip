@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
     const char* role = argc > 1 ? argv[1] : "up";
     const int N = argc > 2 ? atoi(argv[2]) : 256;
     const int iters = argc > 3 ? atoi(argv[3]) : 30;
-    BnGeom g; g.N = N; g.Cs = 512; g.Hs = g.Ws = 2; g.Cb = 256; g.Hb = g.Wb = 8; g.R = g.S = 5; g.stride = 5; g.pt = g.pl = 1;
+    BnGeom g; g.CsS = 0; g.N = N; g.Cs = 512; g.Hs = g.Ws = 2; g.Cb = 256; g.Hb = g.Wb = 8; g.R = g.S = 5; g.stride = 5; g.pt = g.pl = 1;
     srand(3);
     const size_t n_small = (size_t)N * g.Cs * 4, n_big = (size_t)N * g.Cb * 64, n_w = (size_t)g.Cs * g.Cb * 25;
     float* small = dev(rnd(n_small, 1.f)); float* big = dev(rnd(n_big, 1.f)); float* w = dev(rnd(n_w, 0.05f));

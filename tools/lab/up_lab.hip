@@ -14,7 +14,7 @@ int main(int argc, char** argv) {
     const int N = argc > 2 ? atoi(argv[2]) : 256;
     const int cc = argc > 3 ? atoi(argv[3]) : 4;
     const int use_dact = argc > 4 ? atoi(argv[4]) : 0;
-    BnGeom g;
+    BnGeom g; g.CsS = 0;
     g.N = N; g.R = g.S = 5; g.stride = 2; g.pt = 1; g.pl = 1;
     if (!strcmp(layer, "D1")) { g.Cs = 256; g.Hs = g.Ws = 8; g.Cb = 128; }
     else if (!strcmp(layer, "D2")) { g.Cs = 128; g.Hs = g.Ws = 16; g.Cb = 64; }
