@@ -100,6 +100,7 @@ SIGNATURES = {
         _c_int, [_c_void_p] * 5 + [_c_size_t] + [_c_float] * 5 + [_c_int, _c_void_p]),
     'bn_u8_to_unit_float': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_void_p]),
     'bn_prof_select': (_c_int, [_c_int] * 3),
+    'bn_prof_select_nth': (_c_int, [_c_int] * 4),
     'bn_prof_read': (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
     'bn_prof_read_main': (_c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]),
     'bn_prof_set_bracket': (_c_int, [_c_int]),
@@ -687,8 +688,12 @@ def u8_to_unit_float(u8):
     return out
 
 
-def prof_select(family, C=0, K=0):
-    _check(load().bn_prof_select(family, C, K), 'bn_prof_select')
+def prof_select(family, C=0, K=0, nth=None):
+    """Time the calls of one family (and channel pair); ``nth``: only the nth matching call."""
+    if nth is None:
+        _check(load().bn_prof_select(family, C, K), 'bn_prof_select')
+    else:
+        _check(load().bn_prof_select_nth(family, C, K, int(nth)), 'bn_prof_select_nth')
 
 
 def prof_read():

@@ -29,6 +29,7 @@ struct ProfState {
     double total_ms = 0.0, main_ms = 0.0;
     long launches = 0, main_launches = 0;
     bool bracket = true;   // bn_prof_set_bracket(0): dispatch pair only (nothing extra on the stream)
+    int nth = -1, seen = 0;   // bn_prof_select_nth: only the nth matching call since the selection
     char kernel_name[96] = "";
 } g_prof;
 
@@ -67,6 +68,7 @@ BnProfScope::BnProfScope(int family, int C, int K, const char* kernel_name, hipS
     if (g_prof.C > 0 && g_prof.C != C) return;
     if (g_prof.K > 0 && g_prof.K != K) return;
     if (g_dispatch_slot >= 0) return;                 // nested scope (a detour re-entering run_*)
+    if (g_prof.nth >= 0 && g_prof.seen++ != g_prof.nth) return;
     if (g_prof.used >= ProfState::kMaxSlots) prof_drain();
     const int i = g_prof.used;
     while (g_prof.created <= i) {
@@ -102,8 +104,16 @@ extern "C" int bn_prof_select(int family, int C, int K) {
     g_prof.total_ms = g_prof.main_ms = 0.0;
     g_prof.launches = g_prof.main_launches = 0;
     g_prof.kernel_name[0] = 0;
+    g_prof.nth = -1;
+    g_prof.seen = 0;
     g_dispatch_slot = -1;
     return 0;
+}
+
+extern "C" int bn_prof_select_nth(int family, int C, int K, int nth) {
+    const int rc = bn_prof_select(family, C, K);
+    if (rc == 0) g_prof.nth = nth;
+    return rc;
 }
 
 extern "C" int bn_prof_read(double* total_ms, long* launches) {
@@ -423,8 +433,8 @@ static int run_down(int family, const float* big, const float* w, const float* b
         if (g.Cb == 1 && bn_edge_down_plan(g5).supported && epi_ok) {
             BnGeom gw = g5;
             gw.CsS = g.Cs;
+            BnProfScope prof(family, g.Cb, g.Cs, bn_edge_down_kernel_name(g5, act, dact_src != nullptr, false), st);
             for (int c0 = 0; c0 < g.Cs; c0 += 32) {
-                BnProfScope prof(family, g.Cb, g.Cs, bn_edge_down_kernel_name(g5, act, dact_src != nullptr, false), st);
                 const int rc = bn_launch_edge_down(big, w + (size_t)c0 * g.Cb * 25, bias ? bias + c0 : nullptr,
                                                    out + (size_t)c0 * PQ,
                                                    dact_src ? dact_src + (size_t)c0 * PQ : nullptr, gw, act,
@@ -648,8 +658,8 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
             BnGeom gw = g5;
             gw.CsS = g.Cs;
             if (!ws_ok(edw, (char*)ws + cb, ws_bytes - cb)) return BN_E_WORKSPACE;
+            BnProfScope prof(family, g.Cb, g.Cs, edw.kernel_name, st);
             for (int c0 = 0; c0 < g.Cs; c0 += 32) {
-                BnProfScope prof(family, g.Cb, g.Cs, edw.kernel_name, st);
                 bool done = false;
                 const int rc = bn_launch_edge_wgrad(edw, small + (size_t)c0 * PQ, big, dw + (size_t)c0 * g.Cb * 25,
                                                     gw, accumulate, (char*)ws + cb, st,

@@ -207,10 +207,10 @@ def secondary_configs(hp_ae, feed_rates=True):
                              'tests/integration.py shape)'))
     out.append(geometry_step(os.path.join(cfg, 'ae_arch_2.json'), [1, 128, 128],
                              'shipped configs/ae_jsons/ae_arch_2.json (5 layers of 64 channels, k4, '
-                             'strides 2,2,2,2,1) on 1x128x128', names=False))
+                             'strides 2,2,2,2,1) on 1x128x128'))
     out.append(geometry_step(None, [2, 192, 160],
                              'default architecture on 2x192x160 frames (maps beyond the tiles of '
-                             'the specialised kernels: spatial tiles with halos)', names=False))
+                             'the specialised kernels: spatial tiles with halos)'))
     if feed_rates:
         # --- the headline step fed over PCIe: pinned uint8 trials, one-trial look-ahead
         torch.manual_seed(0)
@@ -347,26 +347,36 @@ def geometry_step(arch_json, dim, label, batch=256, names=True):
         opt.step()
     t = _timed(step, 12, 20)
     kernels = {}
-    # (names=False: several layers share a channel pair, the per-layer readout would mix them)
+    # layer by layer and role by role: one extra step each with the hook on the nth matching call
+    # (layers may share a family and a channel pair: the forward pass visits them bottom-up, the
+    # backward pass top-down)
     for stack, fams in () if not names else (('encoding', (('fwd', _hip.PROF_CONV_FWD, False), ('bwd_data', _hip.PROF_CONV_BWD_D, True),
                                       ('bwd_weight', _hip.PROF_CONV_BWD_W, False))),
                         ('decoding', (('fwd', _hip.PROF_CONVT_FWD, False), ('bwd_data', _hip.PROF_CONVT_BWD_D, True),
                                       ('bwd_weight', _hip.PROF_CONVT_BWD_W, True)))):
-        for i, layer in enumerate(getattr(m, stack)._plan):
+        plan = getattr(m, stack)._plan
+
+        def ck(layer, swap):
+            # (C, K) as the dispatch reports them: big-side, small-side channels for the
+            # gather-down / weight-gradient launches, the other way round for gather-up
+            big, small = (layer.cin, layer.cout) if layer.kind == 'conv' else (layer.cout, layer.cin)
+            return (small, big) if (layer.kind == 'conv') == swap else (big, small)
+        for i, layer in enumerate(plan):
             for role, fam, swap in fams:
                 if stack == 'encoding' and i == 0 and role == 'bwd_data':
                     continue
-                # (C, K) as the dispatch reports them: big-side, small-side channels for the
-                # gather-down / weight-gradient launches, the other way round for gather-up
-                big, small = (layer.cin, layer.cout) if layer.kind == 'conv' else (layer.cout, layer.cin)
-                c, k = (small, big) if (layer.kind == 'conv') == swap else (big, small)
-                _hip.prof_select(fam, c, k)
+                c, k = ck(layer, swap)
+                same = [j for j, other in enumerate(plan) if ck(other, swap) == (c, k)
+                        and not (stack == 'encoding' and j == 0 and role == 'bwd_data')]
+                nth = same.index(i) if role == 'fwd' else same[::-1].index(i)
+                _hip.prof_select(fam, c, k, nth=nth)
                 step()
                 torch.cuda.synchronize()
                 ms, n, name = _hip.prof_read()
+                kms, kn = _hip.prof_read_main()
                 _hip.prof_select(_hip.PROF_NONE)
                 key = '%s.%d %s' % ('enc' if stack == 'encoding' else 'dec', i, role)
-                kernels[key] = ('%s %.0f us' % (name, ms * 1e3 / n)) if n else 'not matched'
+                kernels[key] = ('%s %.0f us' % (name, (kms / kn if kn else ms / n) * 1e3)) if n else 'not matched'
     fwd_flop = sum(2.0 * l.cin * l.cout * l.R * l.S * (l.hout * l.wout if l.kind == 'conv' else l.hin * l.win)
                    for st in ('encoding', 'decoding') for l in getattr(m, st)._plan)
     tf = 3 * fwd_flop * batch / t / 1e12

@@ -369,6 +369,9 @@ int bn_u8_to_unit_float(const unsigned char* in, float* out, size_t n, bn_stream
 #define BN_PROF_LINEAR_BWD  9   /* nn.Linear backward: all launches of one bn_linear_bwd call */
 /* select family + optional geometry filter (C<=0 / K<=0 = any).  Resets the accumulators. */
 int bn_prof_select(int family, int C, int K);
+/* the same, but only the nth (0-based) matching call after the selection is timed: tells layers
+ * apart that share a family and a channel pair (ae_arch_2.json: four 64 -> 64 layers) */
+int bn_prof_select_nth(int family, int C, int K, int nth);
 /* host-synchronising: total milliseconds and call count since bn_prof_select, everything a
  * call launched (its combine / finish kernels, the two event records and the gaps included) */
 int bn_prof_read(double* total_ms, long* launches);
