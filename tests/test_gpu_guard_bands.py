@@ -53,12 +53,15 @@ CONV = [  # (name, C, H, W, K, P, Q, stride, pad_t, pad_l)
     ('E2', 64, 8, 8, 128, 4, 4, 2, 1, 1), ('E3', 128, 4, 4, 256, 2, 2, 2, 1, 1),
     ('E4', 256, 2, 2, 512, 1, 1, 5, 1, 1), ('E0_128', 1, 128, 128, 32, 64, 64, 2, 1, 1),
     ('E1_128', 32, 64, 64, 64, 32, 32, 2, 1, 1), ('E4_128', 256, 8, 8, 512, 2, 2, 5, 1, 1),
+    # 1 -> 64: two groups of 32 channels served in place through channel windows (BnGeom::CsS)
+    ('E0_64ch', 1, 128, 128, 64, 64, 64, 2, 1, 1),
 ]
 CONVT = [  # (name, Ci, Hi, Wi, Co, Ho, Wo, stride, crop_t, crop_l)
     ('D0', 512, 1, 1, 256, 2, 2, 5, 1, 1), ('D1', 256, 2, 2, 128, 4, 4, 2, 1, 1),
     ('D2', 128, 4, 4, 64, 8, 8, 2, 1, 1), ('D3', 64, 8, 8, 32, 16, 16, 2, 1, 1),
     ('D4', 32, 16, 16, 1, 32, 32, 2, 1, 1), ('D4_128', 32, 64, 64, 1, 128, 128, 2, 1, 1),
     ('D3_128', 64, 32, 32, 32, 64, 64, 2, 1, 1), ('D0_128', 512, 2, 2, 256, 8, 8, 5, 1, 1),
+    ('D4_64ch', 64, 64, 64, 1, 128, 128, 2, 1, 1),
 ]
 
 
@@ -105,6 +108,31 @@ def test_convT_roles_do_not_read_outside_their_operands(case, n):
     finite(xh, name + ' fused xhat')
     finite(dpre, name + ' fused dpre')
     finite(part, name + ' fused partial sums')
+
+
+@pytest.mark.parametrize('n', [130, 160])
+def test_stride5_second_generation_does_not_read_outside_its_operands(n):
+    """The gather-up kernel of the stride-5 layers (k_qg2_up) only serves batches of >= 128 frames:
+    130 frames = four full 32-frame tiles and a ragged one, under guard bands, in both of its roles
+    (conv data gradient with and without the LeakyReLU' mask, convT forward), and the weight gradient
+    with either bias side next to it."""
+    geom = (n, 256, 8, 8, 512, 5, 5, 5, 1, 1, 2, 2)
+    x, w = guarded(_rand(n, 256, 8, 8)), guarded(_rand(512, 256, 5, 5) * 0.05)
+    dy = guarded(_rand(n, 512, 2, 2, seed=1))
+    finite(_hip.conv2d_bwd_data(dy, w, geom, x, _hip.ACT_LRELU, SLOPE), 'E4 bwd-data')
+    finite(_hip.conv2d_bwd_data(dy, w, geom, None, _hip.ACT_NONE, SLOPE), 'E4 bwd-data plain')
+    dw, db = guarded(torch.zeros(512, 256, 5, 5)), guarded(torch.zeros(512))
+    _hip.conv2d_bwd_weight(x, dy, dw, db, geom, False)
+    finite(dw, 'E4 dw')
+    finite(db, 'E4 db')
+    geom_t = (n, 512, 2, 2, 256, 5, 5, 5, 1, 1, 8, 8)
+    xt, wt, bt = guarded(_rand(n, 512, 2, 2)), guarded(_rand(512, 256, 5, 5) * 0.05), guarded(_rand(256))
+    dyt = guarded(_rand(n, 256, 8, 8, seed=2))
+    finite(_hip.convT2d_fwd(xt, wt, bt, geom_t, _hip.ACT_LRELU, SLOPE), 'D0 fwd')
+    dwt, dbt = guarded(torch.zeros(512, 256, 5, 5)), guarded(torch.zeros(256))
+    _hip.convT2d_bwd_weight(xt, dyt, dwt, dbt, geom_t, True)
+    finite(dwt, 'D0 dw')
+    finite(dbt, 'D0 db')
 
 
 @pytest.mark.parametrize('M,K,N', [(5, 512, 4), (6, 512, 8), (7, 2048, 12), (5, 12, 2048),
