@@ -549,8 +549,9 @@ def main():
                           'ms_per_step_behind': round(timing[False] * 1e3, 3)}
     if bdist.is_active():
         # what the collective library saw, and the exchange timed on its own
-        allreduce_mode = dict(allreduce_mode or {'chosen': 'one flat all-reduce behind the '
-                                                           'backward pass'})
+        allreduce_mode = dict(allreduce_mode or {'chosen': (
+            'sharded optimizer: reduce-scatter -> Adam on 1/N of the arena -> all-gather, behind the '
+            'backward pass' if shard_opt else 'one flat all-reduce behind the backward pass')})
         allreduce_mode.update({
             'world_size': torch.distributed.get_world_size(),
             'backend': torch.distributed.get_backend() + (

@@ -167,6 +167,93 @@ def test_fit_trial_mode_two_ranks(tmp_path):
     np.testing.assert_allclose([r['tr_loss'] for r in rows0], tr_rows, rtol=1e-6)
 
 
+class _CpuShardedFlatAdam(_CpuFlatAdam):
+    """_CpuFlatAdam with FlatAdamAMSGrad's sharding interface (shard_over, shard_range, step_range):
+    the element-wise Adam(amsgrad) update written out, arenas padded to equal 16-byte shards."""
+
+    def __init__(self, params, lr, weight_decay=0.0, shard_over=1):
+        self.params = [p for p in params if p.requires_grad]
+        self.offsets, total = [], 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += p.numel()
+        self.numel = total
+        per = ((total + shard_over - 1) // shard_over + 3) // 4 * 4
+        total = per * shard_over
+        self.shard_over, self.lr, self.wd, self.t = shard_over, lr, weight_decay, 0
+        self.flat_p, self.flat_g = torch.zeros(total), torch.zeros(total)
+        self.m, self.v, self.vmax = torch.zeros(total), torch.zeros(total), torch.zeros(total)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.flat_p[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[off:off + p.numel()].view_as(p)
+
+    def shard_range(self, r):
+        per = self.flat_p.numel() // self.shard_over
+        return r * per, (r + 1) * per
+
+    def step(self):
+        self.step_range(0, self.flat_p.numel())
+
+    def step_range(self, lo, hi):
+        self.t += 1
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        g = self.flat_g[lo:hi] + self.wd * self.flat_p[lo:hi]
+        self.m[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
+        self.v[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
+        torch.maximum(self.vmax[lo:hi], self.v[lo:hi], out=self.vmax[lo:hi])
+        denom = (self.vmax[lo:hi].sqrt() / (1 - b2 ** self.t) ** 0.5).add_(eps)
+        self.flat_p[lo:hi].addcdiv_(self.m[lo:hi], denom, value=-self.lr / (1 - b1 ** self.t))
+
+
+def _fit_worker_sharded(rank, world, port, tmp, out, shard):
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world)})
+    torch.set_num_threads(2)
+    bdist.init_from_env(backend='gloo')
+    hp, gen, model = _setup(os.path.join(tmp, 's%d_r%d' % (int(shard), rank)))
+    hp['dp_shard'] = 'trial'
+    hp['shard_optimizer'] = shard
+    opt = _CpuShardedFlatAdam(model.get_parameters(), hp['learning_rate'], hp['l2_reg'],
+                              shard_over=world if shard else 1)
+    exp = _Exp()
+    fit(hp, model, gen, exp, method='ae', optimizer=opt)
+    out.put((rank, opt.flat_p[:opt.numel].clone().numpy(), [r for r in exp.rows if 'tr_loss' in r],
+             getattr(opt, 'reducer', None) is not None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_with_sharded_optimizer_equals_the_replicated_fit(tmp_path):
+    """`fit()` with hparams['shard_optimizer'] on two ranks (reduce-scatter -> Adam on this rank's
+    half of the arena -> all-gather per step, no bucketed reducer) against the same fit with the
+    all-reduce + full step: the same parameters on both ranks, bit for bit, and the same metric
+    rows."""
+    world = 2
+    results = {}
+    for shard in (True, False):
+        ctx = mp.get_context('spawn')
+        out = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_fit_worker_sharded, args=(r, world, port, str(tmp_path), out, shard))
+                 for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([out.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        results[shard] = res
+    (_, ps0, rows_s0, red_s0), (_, ps1, rows_s1, _) = results[True]
+    (_, pr0, rows_r0, red_r0), _ = results[False]
+    assert not red_s0 and red_r0           # the sharded fit runs without the overlapped reducer
+    np.testing.assert_array_equal(ps0, ps1)
+    np.testing.assert_array_equal(ps0, pr0)
+    assert rows_s0 == rows_s1 == rows_r0 and len(rows_s0) == 3
+
+
 def _fit_worker_hooks(rank, world, port, tmp, out):
     """As _fit_worker, with what the HIP autograd nodes do on the device: every parameter is
     reported to the bucketed reducer as soon as its gradient is complete, so buckets go out

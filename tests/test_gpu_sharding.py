@@ -421,6 +421,20 @@ def test_bench_two_ranks_control_flow(launcher, tmp_path):
     assert ar['allreduce_alone_ms'] > 0
 
 
+def test_bench_two_ranks_sharded_optimizer(tmp_path):
+    """`python bench.py --gpus 2 --shard-optimizer`: the step is reduce-scatter -> Adam on half of
+    the arena -> all-gather; the same trajectory as the replicated step (same seeds, same trials:
+    the reported loss agrees to rounding)."""
+    env = _child_env(BN_DIST_BACKEND='gloo')
+    tail = ['--gpus', '2', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary']
+    ds = _bench_line([sys.executable, os.path.join(REPO, 'bench.py')] + tail + ['--shard-optimizer'],
+                     env, tmp_path)
+    dr = _bench_line([sys.executable, os.path.join(REPO, 'bench.py')] + tail, env, tmp_path)
+    assert ds['n_gpus'] == 2 and ds['allreduce']['chosen'].startswith('sharded optimizer')
+    assert ds['allreduce']['gradient_bytes'] % (2 * 16) == 0          # two equal 16-byte aligned shards
+    assert ds['final_loss'] == pytest.approx(dr['final_loss'], rel=1e-5)
+
+
 def test_bench_two_ranks_frame_sharded(tmp_path):
     """`python bench.py --gpus 2 --shard frames`: the strong-scaling (parity-exact) reading of
     BASELINE configs[2] -- one 256-frame trial per step, 128 frames per rank, summed gradients;
