@@ -31,9 +31,10 @@ int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float
 // conv_mfma_down2.hip: 16-byte-DMA generation of the stride-2 gather-down kernel (chosen by
 // bn_fast_down_plan when the geometry fits and no split-K is needed; plan.variant == 2)
 bool bn_down2_supported(const BnGeom& g, int MR, int NR);
+int bn_down2_splits(const BnGeom& g, int MR, int NR);
 int bn_launch_down2(int MR, int NR, const float* big, const float* w, const float* bias,
                     float* out, const float* dact_src, const BnGeom& g, int act, int dact,
-                    float slope, hipStream_t st);
+                    float slope, hipStream_t st, int splits = 1, void* ws = nullptr);
 
 // conv_mfma_wgrad4.hip: 16-byte-DMA generation of the stride-2 weight gradient (tried first by
 // bn_fast_wgrad_plan; plan.variant == 4)
@@ -92,3 +93,9 @@ int bn_launch_qg2_up(const float* small, const float* w, const float* bias, floa
 bool bn_qg2_wgrad_supported(const BnGeom& g);
 int bn_launch_qg2_wgrad(const float* small, const float* big, float* dw, const BnGeom& g,
                         int accumulate, float* db, int bias_side, hipStream_t st);
+
+// conv_mfma.hip: out = epilogue(sum_z part[z]) of a reduction split over workgroups (NCHW, C channels
+// of npix pixels; fixed summation order)
+int bn_launch_split_epilogue(const float* part, const float* bias, float* out, const float* dact_src,
+                             size_t total, int splits, int C, int npix, int act, int dact, float slope,
+                             hipStream_t st);

@@ -252,6 +252,17 @@ __global__ __launch_bounds__(256) void k_split_epilogue(
     }
 }
 
+int bn_launch_split_epilogue(const float* part, const float* bias, float* out, const float* dact_src,
+                             size_t total, int splits, int C, int npix, int act, int dact, float slope,
+                             hipStream_t st) {
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_split_epilogue, dim3(blocks), dim3(256), 0, st, part, bias, out, dact_src, total,
+                       splits, C, npix, act, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // planning: plan.variant = (MR<<8)|(NR<<4)|CC... kept explicit in a,b,c,d
 //   a = MR, b = NR, c = CC, d = splits
@@ -377,6 +388,23 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
         p.variant = 2;
         p.kernel_name = names2[best];
     }
+    // small batches: the streamlined kernel on the LARGEST tile that fits, its reduction split over
+    // workgroups (round 4; the first generation's split path is 20 % slower per FLOP, and the
+    // unsplit 32-channel tile ran 128 workgroups of 54 us for a 32-frame shard)
+    if (g.stride == 2 && CC == 4 && !bn_tune_env("BN_DOWN_SPLITS") && !bn_tune_env("BN_DOWN_TILE")) {
+        for (int i = 0; i < 3; ++i) {
+            const int mr = cand[i][0], nr = cand[i][1];
+            if (mr == 2 && g.Cs < 64) continue;
+            if (!bn_down2_supported(g, mr, nr)) continue;
+            const int s2 = bn_down2_splits(g, mr, nr);
+            if (s2 > 1) {
+                p.a = mr; p.b = nr; p.d = s2; p.variant = 2;
+                p.kernel_name = names2[i];
+                p.ws_bytes = (size_t)s2 * g.N * g.Cs * g.Hs * g.Ws * sizeof(float);
+            }
+            break;          // only the first (preferred) tile shape that the kernel serves
+        }
+    }
     return p;
 }
 
@@ -406,7 +434,7 @@ int bn_launch_down_fast(const BnFastPlan& plan, const float* big, const float* w
                         int act, int dact, float slope, void* ws, hipStream_t st) {
     const int MR = plan.a, NR = plan.b, CC = plan.c, splits = plan.d;
     if (plan.variant == 2)
-        return bn_launch_down2(MR, NR, big, w, bias, out, dact_src, g, act, dact, slope, st);
+        return bn_launch_down2(MR, NR, big, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws);
     DownTile t;
     int nwg = 0;
     if (!down_tile(g, MR, NR, CC, &t, &nwg)) return BN_E_SHAPE;

@@ -68,8 +68,13 @@ template <int MR, int NR>
 __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, Down2Tile t, int act,
-    int dact, float slope) {
+    int dact, float slope, int cper, size_t zstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // reduction split over workgroups (small batches: gridDim.z slices of cper input channels, raw
+    // sums into slab blockIdx.z of the scratch, finished by k_split_epilogue); gridDim.z == 1: all
+    const int c_beg = blockIdx.z * cper;
+    const int c_end = min(g.Cb, c_beg + cper);
+    out += blockIdx.z * zstride;
 #ifdef D2_TRACE
     unsigned long long* trc = d2_trace + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * D2_TRACE_SLOTS;
 #define D2_MARK(slot) do { if (threadIdx.x == 0) trc[slot] = __builtin_readcyclecounter(); } while (0)
@@ -262,8 +267,8 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
                 }
                 // the next chunk's loads ride in this stream, one instruction per slot
                 const int sl = it * NM + j;
-                if (sl >= 1 && sl < 1 + D2_XK) { if (c0 + CC < g.Cb) issue_image(sl - 1, c0 + CC, BUF ^ 1); }
-                if (sl >= 1 + D2_XK && sl < 1 + D2_XK + WK) { if (c0 + CC < g.Cb) load_weights(sl - 1 - D2_XK, c0 + CC); }
+                if (sl >= 1 && sl < 1 + D2_XK) { if (c0 + CC < c_end) issue_image(sl - 1, c0 + CC, BUF ^ 1); }
+                if (sl >= 1 + D2_XK && sl < 1 + D2_XK + WK) { if (c0 + CC < c_end) load_weights(sl - 1 - D2_XK, c0 + CC); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -284,15 +289,15 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
 
     D2_MARK(3);
 #pragma unroll
-    for (int k = 0; k < D2_XK; ++k) issue_image(k, 0, 0);
+    for (int k = 0; k < D2_XK; ++k) issue_image(k, c_beg, 0);
 #pragma unroll
-    for (int k = 0; k < WK; ++k) load_weights(k, 0);
-    for (int c0 = 0; c0 < g.Cb; c0 += 2 * CC) {
+    for (int k = 0; k < WK; ++k) load_weights(k, c_beg);
+    for (int c0 = c_beg; c0 < c_end; c0 += 2 * CC) {
         if (c0 < 6 * CC) D2_MARK(4 + 2 * (c0 / CC));
         boundary(c0);
         if (c0 < 6 * CC) D2_MARK(5 + 2 * (c0 / CC));
         chunk_rows(0, c0);
-        if (c0 + CC < g.Cb) {
+        if (c0 + CC < c_end) {
             if (c0 < 4 * CC) D2_MARK(6 + 2 * (c0 / CC));
             boundary(c0 + CC);
             if (c0 < 4 * CC) D2_MARK(7 + 2 * (c0 / CC));
@@ -436,7 +441,7 @@ bool bn_down2_supported(const BnGeom& g, int MR, int NR) {
 template <int MR, int NR>
 static int launch_down2(const Down2Tile& t, dim3 grid, size_t lds, const float* big, const float* w,
                         const float* bias, float* out, const float* dact_src, const BnGeom& g,
-                        int act, int dact, float slope, hipStream_t st) {
+                        int act, int dact, float slope, hipStream_t st, int cper, size_t zstride) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_down2_mfma<MR, NR>,
@@ -445,24 +450,51 @@ static int launch_down2(const Down2Tile& t, dim3 grid, size_t lds, const float* 
         attr_set = true;
     }
     BN_LAUNCH_MAIN((k_down2_mfma<MR, NR>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
-                       dact_src, g, t, act, dact, slope);
+                       dact_src, g, t, act, dact, slope, cper, zstride);
     BN_LAUNCH_CHECK();
     return 0;
 }
 
+// reduction splits: a grid that fills less than a quarter of the chip's 512 workgroup slots (a
+// 32-frame shard of a trial) is cut over the input channels into up to 8 slices of >= 16 channels
+int bn_down2_splits(const BnGeom& g, int MR, int NR) {
+    Down2Tile t;
+    size_t lds = 0;
+    if (!down2_tile(g, MR, NR, &t, &lds)) return 1;
+    const int wgs = ((g.N + t.F - 1) / t.F) * t.tiles_per_frame * ((g.Cs + 32 * MR - 1) / (32 * MR));
+    if (wgs > 160) return 1;
+    int s = 512 / wgs;
+    if (s > 8) s = 8;
+    while (s > 1 && (g.Cb % (s * 2 * D2_CC) != 0 || g.Cb / s < 16)) --s;
+    return s < 1 ? 1 : s;
+}
+
 int bn_launch_down2(int MR, int NR, const float* big, const float* w, const float* bias,
                     float* out, const float* dact_src, const BnGeom& g, int act, int dact,
-                    float slope, hipStream_t st) {
+                    float slope, hipStream_t st, int splits, void* ws) {
     Down2Tile t;
     size_t lds = 0;
     if (!down2_tile(g, MR, NR, &t, &lds)) return BN_E_SHAPE;
     const int groups = (g.N + t.F - 1) / t.F;
-    dim3 grid(groups * t.tiles_per_frame, (g.Cs + 32 * MR - 1) / (32 * MR));
+    if (splits < 1) splits = 1;
+    dim3 grid(groups * t.tiles_per_frame, (g.Cs + 32 * MR - 1) / (32 * MR), splits);
+    const size_t total = (size_t)g.N * g.Cs * g.Hs * g.Ws;
+    if (splits > 1 && !ws) return BN_E_WORKSPACE;
+    // (split: raw sums into the slabs, no bias / activation / mask in the kernel)
+    const float* kb = splits > 1 ? nullptr : bias;
+    const float* kd = splits > 1 ? nullptr : dact_src;
+    float* ko = splits > 1 ? (float*)ws : out;
+    const int ka = splits > 1 ? BN_ACT_NONE : act, kda = splits > 1 ? BN_ACT_NONE : dact;
+    const int cper = g.Cb / splits;
+    const size_t zs = splits > 1 ? total : 0;
+    int rc = BN_E_SHAPE;
     if (MR == 2 && NR == 2)
-        return launch_down2<2, 2>(t, grid, lds, big, w, bias, out, dact_src, g, act, dact, slope, st);
-    if (MR == 2 && NR == 1)
-        return launch_down2<2, 1>(t, grid, lds, big, w, bias, out, dact_src, g, act, dact, slope, st);
-    if (MR == 1 && NR == 1)
-        return launch_down2<1, 1>(t, grid, lds, big, w, bias, out, dact_src, g, act, dact, slope, st);
-    return BN_E_SHAPE;
+        rc = launch_down2<2, 2>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
+    else if (MR == 2 && NR == 1)
+        rc = launch_down2<2, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
+    else if (MR == 1 && NR == 1)
+        rc = launch_down2<1, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
+    if (rc || splits == 1) return rc;
+    return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cs,
+                                    g.Hs * g.Ws, act, dact, slope, st);
 }

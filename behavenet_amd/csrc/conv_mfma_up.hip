@@ -252,9 +252,14 @@ template <int LGW, int CC>
 __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, int act, int dact,
-    float slope) {
+    float slope, int cper, size_t zstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using T = UP2<LGW>;
+    // reduction split over workgroups (small batches: gridDim.z slices of cper input channels, raw
+    // sums into slab blockIdx.z of the scratch, finished by k_split_epilogue); gridDim.z == 1: all
+    const int c_beg = blockIdx.z * cper;
+    const int c_end = min(g.Cs, c_beg + cper);
+    out += blockIdx.z * zstride;
     constexpr int RS = 25, TM = 32, Ws = T::Ws, HWs = T::HW, SWp = T::SWp;
     constexpr int XBUF = CC * T::CHSP;                    // floats per input image
     constexpr int WCH = TM * RS;                          // weight floats per channel
@@ -387,14 +392,14 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
 
     static_assert(NDMA + 2 <= (CC / 2) * 25, "DMA slots");
 #pragma unroll
-    for (int d = 0; d < NDMA; ++d) issue_dma(d, 0, 0);
+    for (int d = 0; d < NDMA; ++d) issue_dma(d, 0, c_beg);
     int cur = 0;
-    for (int c0 = 0; c0 < g.Cs; c0 += CC) {
+    for (int c0 = c_beg; c0 < c_end; c0 += CC) {
         // own DMA of this chunk landed; after the barrier everyone's has, and every wave is done
         // reading the other image pair
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        chunk_body(xb_cur, wa_cur, cur ^ 1, c0 + CC < g.Cs, c0 + CC);
+        chunk_body(xb_cur, wa_cur, cur ^ 1, c0 + CC < c_end, c0 + CC);
         cur ^= 1;
         int tmp = xb_cur; xb_cur = xb_oth; xb_oth = tmp;
         tmp = wa_cur; wa_cur = wa_oth; wa_oth = tmp;
@@ -533,10 +538,23 @@ static bool up2_ok(const BnGeom& g, int* cc_out) {
     return true;
 }
 
+// reduction splits of the streamlined gather-up kernel: a grid that fills less than half of the chip
+// (a 32-frame shard of a trial: 64 workgroups of 105 us each) is cut over the input channels into
+// up to 8 slices of >= 32 channels, raw sums through scratch, finished by k_split_epilogue
+static int up2_splits(const BnGeom& g, int lgw, int cc) {
+    const int F = (1 << (2 * lgw)) >= 128 ? 1 : 128 >> (2 * lgw);
+    const int tpf = (1 << (2 * lgw)) >= 128 ? (1 << (2 * lgw)) / 128 : 1;
+    const int wgs = ((g.N + F - 1) / F) * tpf * ((g.Cb + 31) / 32);
+    if (wgs > 128) return 1;
+    int s = 256 / wgs;
+    while (s > 1 && (g.Cs % (s * cc) != 0 || g.Cs / s < 32)) --s;
+    return s > 8 ? 8 : (s < 1 ? 1 : s);
+}
+
 template <int LGW, int CC>
 static int launch_up2(const float* small, const float* w, const float* bias, float* out,
                       const float* dact_src, const BnGeom& g, int act, int dact, float slope,
-                      hipStream_t st) {
+                      hipStream_t st, int splits, void* ws) {
     using T = UP2<LGW>;
     constexpr int WDMA = (CC * 32 * 25 / 4 + MF_THREADS - 1) / MF_THREADS;
     constexpr size_t lds = ((size_t)2 * CC * T::CHSP + (size_t)2 * WDMA * MF_THREADS * 4) * 4;
@@ -548,9 +566,19 @@ static int launch_up2(const float* small, const float* w, const float* bias, flo
         attr_set = true;
     }
     const int groups = (g.N + T::F - 1) / T::F;
-    dim3 grid(groups * T::TPF, (g.Cb + 31) / 32);
+    dim3 grid(groups * T::TPF, (g.Cb + 31) / 32, splits);
+    if (splits > 1) {
+        if (!ws) return BN_E_WORKSPACE;
+        const size_t total = (size_t)g.N * g.Cb * g.Hb * g.Wb;
+        BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w,
+                       (const float*)nullptr, (float*)ws, (const float*)nullptr, g, BN_ACT_NONE,
+                       BN_ACT_NONE, slope, g.Cs / splits, total);
+        BN_LAUNCH_CHECK();
+        return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cb,
+                                        g.Hb * g.Wb, act, dact, slope, st);
+    }
     BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
-                       dact_src, g, act, dact, slope);
+                       dact_src, g, act, dact, slope, g.Cs, (size_t)0);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -584,6 +612,8 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
         static const char* const n4[6] = {"", "", "", "k_up2_mfma<3, 4>", "k_up2_mfma<4, 4>", "k_up2_mfma<5, 4>"};
         static const char* const n8[6] = {"", "", "", "k_up2_mfma<3, 8>", "k_up2_mfma<4, 8>", "k_up2_mfma<5, 8>"};
         p.kernel_name = p.c == 8 ? n8[lgw] : n4[lgw];
+        p.d = up2_splits(g, lgw, p.c);
+        p.ws_bytes = p.d > 1 ? (size_t)p.d * g.N * g.Cb * g.Hb * g.Wb * sizeof(float) : 0;
     }
     return p;
 }
@@ -591,13 +621,13 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
 int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w,
                       const float* bias, float* out, const float* dact_src, const BnGeom& g,
                       int act, int dact, float slope, void* ws, hipStream_t st) {
-    (void)ws;
     const int MR = plan.a, CC = plan.c;
     if (plan.variant == 2) {
         const int lgw = ilog2_exact_up(g.Ws);
+        const int splits = plan.d > 1 ? plan.d : 1;
 #define UP2_CASE(L, C)                                                                          \
     if (lgw == L && CC == C)                                                                    \
-        return launch_up2<L, C>(small, w, bias, out, dact_src, g, act, dact, slope, st);
+        return launch_up2<L, C>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws);
         UP2_CASE(3, 4) UP2_CASE(4, 4) UP2_CASE(5, 4) UP2_CASE(3, 8) UP2_CASE(4, 8) UP2_CASE(5, 8)
 #undef UP2_CASE
         return BN_E_SHAPE;

@@ -380,7 +380,16 @@ static int qg_down_splits(const BnGeom& g) {
     if (env < 0) { const char* e = bn_tune_env("BN_QG_SPLITS"); env = e ? atoi(e) : 0; }
     if (env > 0) return env;
     if ((g.Cs / QG_T) * 4 >= 64) return 1;
-    return g.Cb * 16 >= 4096 ? 4 : (g.Cb * 16 >= 2048 ? 2 : 1);
+    int s = g.Cb * 16 >= 4096 ? 4 : (g.Cb * 16 >= 2048 ? 2 : 1);
+    // small batches (round 4; a 32-frame shard of a trial ran 64 workgroups of 40 us): more slices
+    // until ~256 workgroups, 256 reduction elements per slice at least.  Batches of more than 64
+    // frames keep the channel-count rule, so the 200 / 56 / 256-frame passes of the benchmark
+    // are unaffected beyond the 56-frame chunk.
+    if (g.N <= 64) {
+        const int tiles = (g.Cs / (QG_NB * QG_T)) * ((g.N + QG_T - 1) / QG_T) * 4;
+        while (tiles * s < 256 && s < 16 && (g.Cb * 16) / (2 * s) >= 256) s *= 2;
+    }
+    return s;
 }
 
 size_t bn_qgemm_ws_bytes(int role, const BnGeom& g) {
