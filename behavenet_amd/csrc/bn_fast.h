@@ -32,6 +32,7 @@ int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float
 // bn_fast_down_plan when the geometry fits and no split-K is needed; plan.variant == 2)
 bool bn_down2_supported(const BnGeom& g, int MR, int NR);
 int bn_down2_splits(const BnGeom& g, int MR, int NR);
+float bn_down2_fill(const BnGeom& g, int MR, int NR);
 int bn_launch_down2(int MR, int NR, const float* big, const float* w, const float* bias,
                     float* out, const float* dact_src, const BnGeom& g, int act, int dact,
                     float slope, hipStream_t st, int splits = 1, void* ws = nullptr);

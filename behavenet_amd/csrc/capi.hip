@@ -263,6 +263,22 @@ static PadPlan pad_plan(int role, const BnGeom& g) {
         int hs = next_pow2(g.Hs), wsm = next_pow2(g.Ws);
         if (hs == g.Hs && wsm == g.Ws && g.Hb == 2 * g.Hs && g.Wb == 2 * g.Ws && !oh && !ow) { hs *= 2; wsm *= 2; }
         bool found = false;
+        // round 4: the fast families take any height and many widths that are no powers of two -- the
+        // narrowest zero-padded copy one of them serves, rows only as far as the shifted big map needs
+        {
+            const int hmin = 2 * g.Hs >= g.Hb + oh ? g.Hs : (g.Hb + oh + 1) / 2;
+            int w0 = 2 * g.Ws >= g.Wb + ow ? g.Ws : (g.Wb + ow + 1) / 2;
+            for (int wq = w0; wq <= wsm && wq <= w0 + 8 && !found; ++wq) {
+                if (wq == g.Ws && hmin == g.Hs && g.Hb == 2 * g.Hs && g.Wb == 2 * g.Ws && !oh && !ow) continue;
+                p.gp = g;
+                p.gp.Hs = hmin; p.gp.Ws = wq; p.gp.Hb = 2 * hmin; p.gp.Wb = 2 * wq; p.gp.pt = p.gp.pl = 1;
+                if ((size_t)g.N * g.Cb * p.gp.Hb * p.gp.Wb * 4 >= 0x7fffffffull) break;
+                if ((size_t)g.N * g.Cs * p.gp.Hs * p.gp.Ws * 4 >= 0x7fffffffull) break;
+                p.inner = role == 0 ? bn_fast_down_plan(p.gp) : role == 1 ? bn_fast_up_plan(p.gp)
+                                                                          : bn_fast_wgrad_plan(p.gp);
+                found = p.inner.supported;
+            }
+        }
         // as measured first, then square (several families take square maps only), then larger
         for (int grow = 0; grow < 4 && !found; ++grow) {
             if (grow == 1) { if (hs == wsm) continue; hs = wsm = (hs > wsm ? hs : wsm); }

@@ -352,6 +352,27 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
             best_wg = nwg;
         }
     }
+    if (best < 0 && g.stride == 2 && g.R == 5 && g.S == 5) {
+        // maps whose sizes are no powers of two (64x48 or 192x160 frames): the second-generation kernel
+        // takes any even width and any height; the tile shape that wastes the fewest pixels
+        float fill = 0.f;
+        for (int i = 0; i < 3; ++i) {
+            if (cand[i][0] == 2 && g.Cs < 64) continue;
+            const float f = bn_down2_fill(g, cand[i][0], cand[i][1]);
+            if (f > fill + 0.02f) { fill = f; best = i; }
+        }
+        if (best < 0) return p;
+        static const char* const names2n[3] = {"k_down2_mfma<2, 1>", "k_down2_mfma<2, 2>", "k_down2_mfma<1, 1>"};
+        p.supported = true;
+        p.a = cand[best][0]; p.b = cand[best][1]; p.c = CC; p.d = 1; p.variant = 2;
+        p.kernel_name = names2n[best];
+        const int s2 = bn_down2_splits(g, p.a, p.b);
+        if (s2 > 1) {
+            p.d = s2;
+            p.ws_bytes = (size_t)s2 * g.N * g.Cs * g.Hs * g.Ws * sizeof(float);
+        }
+        return p;
+    }
     if (best < 0) return p;
     p.supported = true;
     p.a = cand[best][0];

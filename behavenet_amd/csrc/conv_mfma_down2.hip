@@ -56,7 +56,7 @@ __device__ __forceinline__ void d2_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 }
 
 struct Down2Tile {
-    int F, PT_H, lgQ, lgPTQ;
+    int F, PT_H, PTQ;             // frames / small-map rows of a workgroup tile, PT_H * Ws
     int IH, RW, FS, CHS;          // patch rows per frame, row stride, per-frame / per-channel floats
     int tiles_per_frame;
     int groups;                   // 16-byte groups of one chunk image (D2_CC * CHS / 4)
@@ -109,13 +109,18 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     bool pvalid[NR];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
-        const int pix = 32 * (wv * NR + nr) + li;
-        const int f = pix >> t.lgPTQ;
-        const int rem = pix & ((1 << t.lgPTQ) - 1);
-        const int pj = rem >> t.lgQ, qj = rem & (Q - 1);
+        // pixel -> (frame, row, column) of the tile; maps whose sizes are no powers of two leave the
+        // last pixels of a tile (and the rows of a frame's last tile below the map) without an
+        // output: those lanes multiply the tile's first pixel and store nothing
+        int pix = 32 * (wv * NR + nr) + li;
+        const bool inside = pix < t.F * t.PTQ;
+        if (!inside) pix = 0;
+        const int f = pix / t.PTQ;
+        const int rem = pix - f * t.PTQ;
+        const int pj = rem / Q, qj = rem - pj * Q;
         // pair 0 = columns (2q-2, 2q-1) of the image = LDS columns 2q+2, 2q+3
         base[nr] = f * t.FS + (2 * pj) * t.RW + 2 * qj + (D2_X0 - 2) + kk * t.CHS;
-        pvalid[nr] = (n0 + f) < g.N;
+        pvalid[nr] = inside && (n0 + f) < g.N && (p0 + pj) < g.Hs;
         opix[nr] = (size_t)(n0 + f) * g.Cs * PQ + (size_t)(p0 + pj) * Q + qj;
     }
 
@@ -396,35 +401,44 @@ static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* ld
     if (g.R != 5 || g.S != 5 || g.stride != 2 || g.pl != 1 || g.pt < 0) return false;
     if ((g.Cb % D2_CC) != 0 || (g.Wb & 3) != 0) return false;
     const int TP = 128 * NR;
-    const int lgQ = ilog2_exact_d2(g.Ws), lgP = ilog2_exact_d2(g.Hs);
-    if (lgQ < 2 || lgP < 0 || g.Ws > TP) return false;
+    // any even map width (16-byte rows of the big map), any height: a tile is F whole frames or PT_H
+    // rows of one (the rows of a frame spread evenly over its tiles); powers of two fill it exactly
+    if (g.Ws < 4 || (g.Ws & 1) || g.Ws > TP || g.Hs < 1) return false;
+    const bool pow2 = ilog2_exact_d2(g.Ws) >= 0 && ilog2_exact_d2(g.Hs) >= 0;
     const int PQ = g.Hs * g.Ws;
-    if (PQ >= TP) {
-        t->F = 1;
-        t->PT_H = TP / g.Ws;
-    } else {
-        t->F = TP / PQ;
-        t->PT_H = g.Hs;
-    }
-    t->lgQ = lgQ;
-    t->lgPTQ = ilog2_exact_d2(t->PT_H * g.Ws);
-    t->IH = 2 * (t->PT_H - 1) + 5;
     int rw = 2 * g.Ws + 8;
-    if (g.Ws < 32)
-        while ((rw & 31) != (g.Ws & 31)) rw += 4;        // half-wave rows cover the 64 banks once
-    t->RW = rw;
-    t->FS = t->IH * rw;
-    t->CHS = t->F * t->FS;
-    t->tiles_per_frame = (t->F == 1) ? g.Hs / t->PT_H : 1;
-    t->groups = D2_CC * t->CHS / 4;
-    if (t->groups > D2_THREADS * D2_XK) return false;
-    t->xbuf_floats = 4 * ((t->groups + 63) & ~63);
+    // the 32 pixels of a half wave (several image rows when Ws < 32 or no power of two) cover the 64
+    // banks once with their 8-byte reads if the row stride == Ws (mod 32)
+    if ((g.Ws < 32 || !pow2) && (g.Ws & 3) == 0)
+        while ((rw & 31) != (g.Ws & 31)) rw += 4;
+    // an LDS image that does not fit: first the plain row stride (bank conflicts on the operand reads
+    // cost less than idle pixels of the tile), then fewer frames / rows per tile
+    auto try_fit = [&](int stride, bool reduce) {
+        t->RW = stride;
+        t->F = PQ >= TP ? 1 : TP / PQ;
+        int rows = PQ >= TP ? TP / g.Ws : g.Hs;
+        for (;;) {
+            t->tiles_per_frame = (g.Hs + rows - 1) / rows;
+            t->PT_H = (g.Hs + t->tiles_per_frame - 1) / t->tiles_per_frame;
+            t->IH = 2 * (t->PT_H - 1) + 5;
+            t->FS = t->IH * stride;
+            t->CHS = t->F * t->FS;
+            t->groups = D2_CC * t->CHS / 4;
+            t->xbuf_floats = 4 * ((t->groups + 63) & ~63);
+            if (t->groups <= D2_THREADS * D2_XK && t->xbuf_floats <= D2_XBUF_FLOATS) return true;
+            if (!reduce) return false;
+            if (t->F > 1) --t->F;
+            else if (rows > 1) --rows;
+            else return false;
+        }
+    };
+    if (!try_fit(rw, false) && !try_fit(2 * g.Ws + 8, false) && !try_fit(2 * g.Ws + 8, true)) return false;
+    t->PTQ = t->PT_H * g.Ws;
     t->inv_chs4 = 1.0f / (float)(t->CHS / 4);
     t->inv_fs4 = 1.0f / (float)(t->FS / 4);
-    t->inv_c4 = 1.0f / (float)(rw / 4);
+    t->inv_c4 = 1.0f / (float)(t->RW / 4);
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
-    if (t->xbuf_floats > D2_XBUF_FLOATS) return false;
     *lds_bytes = ((size_t)2 * D2_XBUF_FLOATS + (size_t)D2_CC * 25 * 32 * MR + 256) * 4;
     return *lds_bytes <= D2_MAX_LDS;
 }
@@ -453,6 +467,14 @@ static int launch_down2(const Down2Tile& t, dim3 grid, size_t lds, const float* 
                        dact_src, g, t, act, dact, slope, cper, zstride);
     BN_LAUNCH_CHECK();
     return 0;
+}
+
+// share of a tile's pixels that are pixels of the map (1 for powers of two), 0 if not served
+float bn_down2_fill(const BnGeom& g, int MR, int NR) {
+    Down2Tile t;
+    size_t lds = 0;
+    if (!bn_down2_supported(g, MR, NR) || !down2_tile(g, MR, NR, &t, &lds)) return 0.f;
+    return (float)(t.F * g.Hs * g.Ws) / (float)(t.tiles_per_frame * 128 * NR);
 }
 
 // reduction splits: a grid that fills less than a quarter of the chip's 512 workgroup slots (a

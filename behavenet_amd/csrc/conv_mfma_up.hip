@@ -241,6 +241,22 @@ struct UP2 {
     static constexpr int TPF = (F == 1) ? Ws / AT_H : 1;             // tiles per frame
 };
 
+// LGW == 0: the tile geometry is a RUNTIME function of the map (any width up to 83 columns, any
+// height: 64x48 or 192x160 frames).  One tile element per thread as above (CHS <= 256 = CHSP); what
+// cannot be an immediate any more is the row stride of the LDS image, so the nine neighbour reads of
+// a lane go through three row base registers instead of one (nothing else enters the MFMA stream).
+// A tile is F whole frames or AT_H rows of one; positions past F * AT_H * Ws, and rows of a frame's
+// last tile below the map, multiply the tile's first position and store nothing.
+template <>
+struct UP2<0> {
+    static constexpr int CHSP = 256;
+};
+struct Up2Geo {
+    int F, AT_H, ATW;             // frames / rows per tile, AT_H * Ws
+    int SWp, FS, CHS;             // LDS row / frame strides of the small tile, elements of a channel
+    int TPF;                      // tiles per frame
+};
+
 __device__ __forceinline__ void up_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voffset, int soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
 }
@@ -252,15 +268,17 @@ template <int LGW, int CC>
 __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, int act, int dact,
-    float slope, int cper, size_t zstride) {
+    float slope, int cper, size_t zstride, Up2Geo tg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using T = UP2<LGW>;
+    constexpr bool RT = LGW == 0;                         // runtime tile geometry (tg)
     // reduction split over workgroups (small batches: gridDim.z slices of cper input channels, raw
     // sums into slab blockIdx.z of the scratch, finished by k_split_epilogue); gridDim.z == 1: all
     const int c_beg = blockIdx.z * cper;
     const int c_end = min(g.Cs, c_beg + cper);
     out += blockIdx.z * zstride;
-    constexpr int RS = 25, TM = 32, Ws = T::Ws, HWs = T::HW, SWp = T::SWp;
+    constexpr int RS = 25, TM = 32;
+    const int Ws = RT ? g.Ws : (1 << LGW), HWs = RT ? g.Hs * g.Ws : (1 << (2 * LGW)), SWp = RT ? tg.SWp : Ws + 2;
     constexpr int XBUF = CC * T::CHSP;                    // floats per input image
     constexpr int WCH = TM * RS;                          // weight floats per channel
     constexpr int WGRP = CC * WCH / 4;                    // 16-byte groups per chunk
@@ -272,18 +290,37 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
 
-    const int grp = blockIdx.x / T::TPF;
-    const int rowt = blockIdx.x - grp * T::TPF;
-    const int n0 = grp * T::F;
-    const int a0 = rowt * T::AT_H;
+    int grp, rowt, n0, a0, pf, aj, bj, tFS, tCHS;
+    bool pvalid;
     const int m0 = blockIdx.y * TM;
-
     // lane -> position (frame f, row aj, col bj) of the small image
-    const int pos = 32 * wv + li;
-    const int pf = pos >> T::lgATW;
-    const int prem = pos & ((1 << T::lgATW) - 1);
-    const int aj = prem >> LGW, bj = prem & (Ws - 1);
-    const bool pvalid = (n0 + pf) < g.N;
+    if constexpr (RT) {
+        grp = blockIdx.x / tg.TPF;
+        rowt = blockIdx.x - grp * tg.TPF;
+        n0 = grp * tg.F;
+        a0 = rowt * tg.AT_H;
+        int pos = 32 * wv + li;
+        const bool inside = pos < tg.F * tg.ATW;
+        if (!inside) pos = 0;
+        pf = pos / tg.ATW;
+        const int prem = pos - pf * tg.ATW;
+        aj = prem / Ws;
+        bj = prem - aj * Ws;
+        pvalid = inside && (n0 + pf) < g.N && (a0 + aj) < g.Hs;
+        tFS = tg.FS; tCHS = tg.CHS;
+    } else {
+        grp = blockIdx.x / T::TPF;
+        rowt = blockIdx.x - grp * T::TPF;
+        n0 = grp * T::F;
+        a0 = rowt * T::AT_H;
+        const int pos = 32 * wv + li;
+        pf = pos >> T::lgATW;
+        const int prem = pos & ((1 << T::lgATW) - 1);
+        aj = prem >> LGW; bj = prem & (Ws - 1);
+        pvalid = (n0 + pf) < g.N;
+        tFS = T::FS; tCHS = T::CHS;
+    }
+    const int Hs_rt = RT ? g.Hs : Ws;
 
     // ---- DMA descriptors (chunk independent) ---------------------------------------------------
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
@@ -291,11 +328,11 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         (void*)w, 0, (int)((size_t)g.Cs * g.Cb * RS * 4), 0x00020000);
     int xvo = OOB;                                        // element tid of a channel's tile
-    if (tid < T::CHS) {
-        const int f = tid / T::FS, r2 = tid - f * T::FS;
+    if (tid < tCHS) {
+        const int f = tid / tFS, r2 = tid - f * tFS;
         const int y = r2 / SWp, x = r2 - y * SWp;
         const int p = a0 - 1 + y, q = x - 1;
-        const bool ok = (n0 + f < g.N) && p >= 0 && p < Ws && q >= 0 && q < Ws;
+        const bool ok = (n0 + f < g.N) && p >= 0 && p < Hs_rt && q >= 0 && q < Ws;
         if (ok) xvo = (f * (g.Cs * HWs) + p * Ws + q) * 4;
     }
     int wvo[WDMA];                                        // group tid + 256 k of [cc][m][tap]
@@ -326,12 +363,19 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
         for (int e = 0; e < 16; ++e) acc[cl][e] = 0.f;
 
     // ---- operand read bases (byte offsets from smem), one per LDS image --------------------------
-    int xb_cur = (pf * T::FS + (aj + 1) * SWp + (bj + 1) + kk * T::CHSP) * 4;
+    int xb_cur = (pf * tFS + (aj + 1) * SWp + (bj + 1) + kk * T::CHSP) * 4;
     int xb_oth = xb_cur + XBUF * 4;
     int wa_cur = (2 * XBUF + (kk * TM + li) * RS) * 4;
     int wa_oth = wa_cur + WBUF * 4;
     asm volatile("" : "+v"(xb_cur)); asm volatile("" : "+v"(xb_oth));
     asm volatile("" : "+v"(wa_cur)); asm volatile("" : "+v"(wa_oth));
+    // runtime row stride: the rows above / below have their own base registers
+    int xu_cur = xb_cur - SWp * 4, xd_cur = xb_cur + SWp * 4;
+    int xu_oth = xb_oth - SWp * 4, xd_oth = xb_oth + SWp * 4;
+    if constexpr (RT) {
+        asm volatile("" : "+v"(xu_cur)); asm volatile("" : "+v"(xd_cur));
+        asm volatile("" : "+v"(xu_oth)); asm volatile("" : "+v"(xd_oth));
+    }
     const char* sm = reinterpret_cast<const char*>(smem);
 
     // tap list of a channel pair in the order of the MFMAs (classes (rho, sigma) = output parity):
@@ -362,14 +406,20 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
         const Tap tp = tap_of(j);
         a[j] = *reinterpret_cast<const float*>(sm + wa + ((2 * cp) * TM * RS + tp.r * 5 + tp.s) * 4);
     };
-    auto load_b = [&](const int xb, const int cp, const int i, float (&b)[9]) __attribute__((always_inline)) {
+    auto load_b = [&](const int xb, const int xu, const int xd, const int cp, const int i, float (&b)[9]) __attribute__((always_inline)) {
         const int dy = i / 3, dx = i - 3 * dy;
-        b[i] = *reinterpret_cast<const float*>(sm + xb + ((2 * cp) * T::CHSP + (dy - 1) * SWp + (dx - 1)) * 4);
+        if constexpr (RT) {
+            const int xr = dy == 0 ? xu : dy == 1 ? xb : xd;
+            b[i] = *reinterpret_cast<const float*>(sm + xr + ((2 * cp) * T::CHSP + (dx - 1)) * 4);
+        } else {
+            constexpr int SW = (1 << LGW) + 2;
+            b[i] = *reinterpret_cast<const float*>(sm + xb + ((2 * cp) * T::CHSP + (dy - 1) * SW + (dx - 1)) * 4);
+        }
     };
-    auto chunk_body = [&](const int xb, const int wa, const int nbuf, const bool more, const int c0n) __attribute__((always_inline)) {
+    auto chunk_body = [&](const int xb, const int xu, const int xd, const int wa, const int nbuf, const bool more, const int c0n) __attribute__((always_inline)) {
         float av[25], bv[2][9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) load_b(xb, 0, i, bv[0]);
+        for (int i = 0; i < 9; ++i) load_b(xb, xu, xd, 0, i, bv[0]);
 #pragma unroll
         for (int j = 0; j < 25; ++j) load_a(wa, 0, j, av);
 #pragma unroll
@@ -381,7 +431,7 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
                                                                   acc[tp.cl], 0, 0, 0);
                 if (cp + 1 < CC / 2) {
                     load_a(wa, cp + 1, j, av);                       // refresh in place
-                    if (j >= 8 && j < 17) load_b(xb, cp + 1, j - 8, bv[(cp + 1) & 1]);
+                    if (j >= 8 && j < 17) load_b(xb, xu, xd, cp + 1, j - 8, bv[(cp + 1) & 1]);
                 }
                 // the next chunk's DMA rides in this wave's own MFMA stream, one instruction per slot
                 if (more && cp * 25 + j >= 2 && cp * 25 + j < 2 + NDMA) issue_dma(cp * 25 + j - 2, nbuf, c0n);
@@ -399,10 +449,14 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
         // reading the other image pair
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        chunk_body(xb_cur, wa_cur, cur ^ 1, c0 + CC < c_end, c0 + CC);
+        chunk_body(xb_cur, xu_cur, xd_cur, wa_cur, cur ^ 1, c0 + CC < c_end, c0 + CC);
         cur ^= 1;
         int tmp = xb_cur; xb_cur = xb_oth; xb_oth = tmp;
         tmp = wa_cur; wa_cur = wa_oth; wa_oth = tmp;
+        if constexpr (RT) {
+            tmp = xu_cur; xu_cur = xu_oth; xu_oth = tmp;
+            tmp = xd_cur; xd_cur = xd_oth; xd_oth = tmp;
+        }
     }
 
     // ---- epilogue: lane owns output pixels (2a+rho, 2b+sig) of channel m(e, kk); the two column
@@ -572,13 +626,83 @@ static int launch_up2(const float* small, const float* w, const float* bias, flo
         const size_t total = (size_t)g.N * g.Cb * g.Hb * g.Wb;
         BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w,
                        (const float*)nullptr, (float*)ws, (const float*)nullptr, g, BN_ACT_NONE,
-                       BN_ACT_NONE, slope, g.Cs / splits, total);
+                       BN_ACT_NONE, slope, g.Cs / splits, total, Up2Geo{});
         BN_LAUNCH_CHECK();
         return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cb,
                                         g.Hb * g.Wb, act, dact, slope, st);
     }
     BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
-                       dact_src, g, act, dact, slope, g.Cs, (size_t)0);
+                       dact_src, g, act, dact, slope, g.Cs, (size_t)0, Up2Geo{});
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- runtime tile geometry (k_up2_mfma<0, CC>): maps that are no power-of-two squares ----------
+// tile = F whole frames, or AT_H rows of one frame (rows spread evenly over a frame's tiles), at most 128
+// positions and 256 elements of the haloed LDS image
+static bool up2g_geo(const BnGeom& g, Up2Geo* t) {
+    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.pt != 1 || g.pl != 1) return false;
+    if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return false;
+    if ((g.Cs % 4) != 0 || (g.Cb & 3) != 0 || g.Cb < 16) return false;
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    if ((size_t)g.Cs * g.Cb * 25 * 4 >= 0x7fffffffull) return false;
+    const int TP = 128, HW = g.Hs * g.Ws;
+    if (g.Ws < 2 || g.Ws > TP) return false;
+    t->SWp = g.Ws + 2;
+    t->F = HW >= TP ? 1 : TP / HW;
+    int rows = HW >= TP ? TP / g.Ws : g.Hs;
+    for (;;) {
+        t->TPF = (g.Hs + rows - 1) / rows;
+        t->AT_H = (g.Hs + t->TPF - 1) / t->TPF;
+        t->FS = (t->AT_H + 2) * t->SWp;
+        t->CHS = t->F * t->FS;
+        if (t->CHS <= UP2<0>::CHSP) break;
+        if (t->F > 1) --t->F;
+        else if (rows > 1) --rows;
+        else return false;
+    }
+    t->ATW = t->AT_H * g.Ws;
+    return true;
+}
+
+static int up2g_splits(const BnGeom& g, const Up2Geo& t, int cc) {
+    const int wgs = ((g.N + t.F - 1) / t.F) * t.TPF * ((g.Cb + 31) / 32);
+    if (wgs > 128) return 1;
+    int s = 256 / wgs;
+    while (s > 1 && (g.Cs % (s * cc) != 0 || g.Cs / s < 32)) --s;
+    return s > 8 ? 8 : (s < 1 ? 1 : s);
+}
+
+static int launch_up2g(const float* small, const float* w, const float* bias, float* out,
+                       const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                       hipStream_t st, int splits, void* ws) {
+    constexpr int CC = 4;
+    Up2Geo t;
+    if (!up2g_geo(g, &t)) return BN_E_SHAPE;
+    constexpr int WDMA = (CC * 32 * 25 / 4 + MF_THREADS - 1) / MF_THREADS;
+    constexpr size_t lds = ((size_t)2 * CC * UP2<0>::CHSP + (size_t)2 * WDMA * MF_THREADS * 4) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_up2_mfma<0, CC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int groups = (g.N + t.F - 1) / t.F;
+    dim3 grid(groups * t.TPF, (g.Cb + 31) / 32, splits);
+    if (splits > 1) {
+        if (!ws) return BN_E_WORKSPACE;
+        const size_t total = (size_t)g.N * g.Cb * g.Hb * g.Wb;
+        BN_LAUNCH_MAIN((k_up2_mfma<0, CC>), grid, dim3(MF_THREADS), lds, st, small, w,
+                       (const float*)nullptr, (float*)ws, (const float*)nullptr, g, BN_ACT_NONE,
+                       BN_ACT_NONE, slope, g.Cs / splits, total, t);
+        BN_LAUNCH_CHECK();
+        return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cb,
+                                        g.Hb * g.Wb, act, dact, slope, st);
+    }
+    BN_LAUNCH_MAIN((k_up2_mfma<0, CC>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+                       dact_src, g, act, dact, slope, g.Cs, (size_t)0, t);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -595,7 +719,19 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
     const int cc = (env_cc == 8 && (g.Cs % 8) == 0) ? 8 : 4;
     const bool ok2 = g.Cb >= 64 && up_tile(g, 2, cc, &t, &nwg2);
     const bool ok1 = up_tile(g, 1, cc, &t, &nwg1);
-    if (!ok1 && !ok2) return p;
+    if (!ok1 && !ok2) {
+        // no power-of-two map: the streamlined kernel with its tile geometry at run time
+        Up2Geo tg;
+        static int off = -1;                      // BN_UP2G=0: off
+        if (off < 0) { const char* e = bn_tune_env("BN_UP2G"); off = (e && e[0] == '0') ? 1 : 0; }
+        if (off || !up2g_geo(g, &tg)) return p;
+        p.supported = true;
+        p.a = 1; p.c = 4; p.variant = 3;
+        p.kernel_name = "k_up2_mfma<0, 4>";
+        p.d = up2g_splits(g, tg, 4);
+        p.ws_bytes = p.d > 1 ? (size_t)p.d * g.N * g.Cb * g.Hb * g.Wb * sizeof(float) : 0;
+        return p;
+    }
     p.supported = true;
     p.a = (ok2 && (nwg2 >= 768 || !ok1)) ? 2 : 1;
     if (env_mr == 2 && ok2) p.a = 2;
@@ -622,6 +758,8 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
                       const float* bias, float* out, const float* dact_src, const BnGeom& g,
                       int act, int dact, float slope, void* ws, hipStream_t st) {
     const int MR = plan.a, CC = plan.c;
+    if (plan.variant == 3)
+        return launch_up2g(small, w, bias, out, dact_src, g, act, dact, slope, st, plan.d > 1 ? plan.d : 1, ws);
     if (plan.variant == 2) {
         const int lgw = ilog2_exact_up(g.Ws);
         const int splits = plan.d > 1 ? plan.d : 1;

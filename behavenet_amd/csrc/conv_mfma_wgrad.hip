@@ -269,7 +269,7 @@ BnFastPlan bn_fast_wgrad_plan(const BnGeom& g) {
 int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float* big, float* dw,
                          const BnGeom& g, int accumulate, void* ws, hipStream_t st, float* db,
                          int bias_side, bool* bias_done) {
-    if (plan.variant == 4)
+    if (plan.variant == 4 || plan.variant == 5)
         return bn_launch_wgrad4(plan, small, big, dw, g, accumulate, ws, st, db, bias_side,
                                 bias_done);
     WgradTile t;

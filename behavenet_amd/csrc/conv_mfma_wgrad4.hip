@@ -226,9 +226,12 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
 //    k-steps of a stage and over the two LDS images;
 //  * one workgroup per CU by __launch_bounds__ (it needs 150 KB of LDS anyway): 256 registers.
 // ---------------------------------------------------------------------------------------------
-template <int LGQ>
+// W4S<Q>: any map width that is a multiple of 4 (the k-step's four pixels lie in one row); a stage is
+// the PT_H = 64 / Q whole rows that fit into 64 pixels, KS k-steps of four pixels
+template <int Q_>
 struct W4S {
-    static constexpr int Q = 1 << LGQ, PT_H = W4_TPX / Q, IH = 2 * (PT_H - 1) + 5;
+    static constexpr int Q = Q_, PT_H = W4_TPX / Q, IH = 2 * (PT_H - 1) + 5;
+    static constexpr int KS = PT_H * Q / 4;
     static constexpr int RW = 2 * Q + 8, C4 = RW / 4;
     static constexpr int ROWG = IH * C4;                         // data groups of a channel image
     static constexpr int GPB = (ROWG & 1) ? ROWG : ROWG + 1;     // odd: conflict-free b64 reads
@@ -245,13 +248,18 @@ __device__ __forceinline__ void w4_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 16, voffset, soffset, 0, 0);
 }
 
-template <int LGQ, int BIAS>
+// GEN: maps that are no powers of two -- the stages of a frame are ceil(Hs / PT_H) (lg_tpf then carries
+// the magic multiplier 2^32 / tiles + 1 of the stage -> frame division), a frame's last stage may hang
+// over its lower edge: the small rows below the map and the big rows below it are left out of the DMA
+// (out-of-range source offset = 0.0f) by a per-group row number against a per-stage scalar limit.
+template <int QQ, int BIAS, bool GEN>
 __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
     float* __restrict__ bias_part, BnGeom g, int n_stages, int splits, int lg_tpf, int nbias) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using T = W4S<LGQ>;
+    using T = W4S<QQ>;
     constexpr int Q = T::Q, RW = T::RW, BUFW = T::BUFW;
+    static_assert((Q & 3) == 0 && T::KS >= 1 && T::KS <= 16, "stage geometry");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ablk = wv >> 1, bblk = wv & 1;
@@ -274,18 +282,20 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(big - g.Wb), 0, (int)(((size_t)g.N * g.Cb * HWb + g.Wb) * 4), 0x00020000);
-    int soff[T::NSM];
+    int soff[T::NSM], srow = 0;
 #pragma unroll
     for (int j = 0; j < T::NSM; ++j) {
         const int e = tid + W4_THREADS * j;
         const int a = e >> 4;
         const int pix0 = 4 * ((e & 15) ^ (a & 15));                  // swizzled source group
-        soff[j] = (a0 + a < g.Cs) ? ((a0 + a) * PQ + pix0) * 4 : W4_OOB;
+        soff[j] = (a0 + a < g.Cs && pix0 < 4 * T::KS) ? ((a0 + a) * PQ + pix0) * 4 : W4_OOB;
+        srow |= (pix0 / Q) << (8 * j);                               // GEN: its row inside the stage
     }
     // rows above the image exist only in a frame's first tile (patch row 0), rows below it only in
     // its last tile (the last two patch rows; Hb == 2 Hs): two class bits per group, all groups of
     // a thread packed into one register
-    int voff[T::NBIG], rowcls = 0;
+    int voff[T::NBIG], rowcls = 0, ypack[2] = {0, 0};
+    static_assert(T::NBIG <= 8, "row numbers of a thread's groups in two registers");
 #pragma unroll
     for (int j = 0; j < T::NBIG; ++j) {
         const int e = tid + W4_THREADS * j;
@@ -295,18 +305,34 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         const bool ok = (e < T::BIGG) && (within < T::ROWG) && (b0 + b < g.Cb) && wb >= 0 && wb < g.Wb;
         voff[j] = ok ? (((b0 + b) * g.Hb + y) * g.Wb + wb) * 4 : W4_OOB;
         rowcls |= ((y == 0 ? 1 : 0) | (y >= T::IH - 2 ? 2 : 0)) << (2 * j);
+        ypack[j >> 2] |= (y & 255) << (8 * (j & 3));
     }
     // one DMA instruction of stage `st` into image `buf`: d < NSM small tile, else big tile
     auto issue_dma = [&](const int d, const int buf, const int n0, const int p0) __attribute__((always_inline)) {
         float* sl = smem + buf * BUFW;
         if (d < T::NSM) {
-            w4_dma16(rs_small, sl + 4 * (W4_THREADS * d + 64 * wv), soff[d], (n0 * g.Cs * PQ + p0 * Q) * 4);
+            int so = soff[d];
+            if constexpr (GEN) {
+                // rows of the stage below the map (a frame's last stage): 0.0f
+                const int row = (srow >> (8 * d)) & 255;
+                so = row < g.Hs - p0 ? so : W4_OOB;
+            }
+            w4_dma16(rs_small, sl + 4 * (W4_THREADS * d + 64 * wv), so, (n0 * g.Cs * PQ + p0 * Q) * 4);
         } else {
             const int j = d - T::NSM;
             if (W4_THREADS * j + 64 * wv < T::BIGG) {                 // wave-uniform
-                // rows above the image (first tile) and below it (last tile) read 0.0f
-                const int smask = ((p0 == 0 ? 1 : 0) | (p0 + T::PT_H >= g.Hs ? 2 : 0)) << (2 * j);
-                const int vo = (rowcls & smask) ? W4_OOB : voff[j];
+                int vo;
+                if constexpr (GEN) {
+                    // patch row y is image row 2 p0 - 1 + y: row 0 of a frame's first stage lies above
+                    // the image, rows from 2 (Hs - p0) + 1 on below it
+                    const int y = (ypack[j >> 2] >> (8 * (j & 3))) & 255;
+                    const int ymin = p0 == 0 ? 1 : 0, ylim = 2 * (g.Hs - p0) + 1;
+                    vo = (y >= ymin && y < ylim) ? voff[j] : W4_OOB;
+                } else {
+                    // rows above the image (first tile) and below it (last tile) read 0.0f
+                    const int smask = ((p0 == 0 ? 1 : 0) | (p0 + T::PT_H >= g.Hs ? 2 : 0)) << (2 * j);
+                    vo = (rowcls & smask) ? W4_OOB : voff[j];
+                }
                 w4_dma16(rs_big, sl + T::SMALLW + 4 * (W4_THREADS * j + 64 * wv), vo,
                          (n0 * g.Cb * g.Hb + 2 * p0) * g.Wb * 4);
             }
@@ -336,7 +362,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         a = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + ao);
     };
     auto load_row = [&](const int bb, const int ks, const int r, const int half, float (&bq)[25]) __attribute__((always_inline)) {
-        const int pj = (4 * ks) >> LGQ, q0 = (4 * ks) & (Q - 1);
+        const int pj = (4 * ks) / Q, q0 = (4 * ks) - pj * Q;
         const float* bp = smem + bb + (2 * pj + r) * RW + 2 * q0;
         if (half == 0) {
             bq[r * 5 + 0] = bp[1];
@@ -352,8 +378,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         load_a(ab, 0, av[0]);
 #pragma unroll
         for (int r = 0; r < 5; ++r) { load_row(bb, 0, r, 0, bv); load_row(bb, 0, r, 1, bv); }
+        constexpr int KS = T::KS;
+        static_assert(NDMA <= KS, "one DMA slot per k-step");
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             if (BIAS == 1) bsum += av[ks & 1];
 #pragma unroll
             for (int tp = 0; tp < 25; ++tp) {
@@ -364,9 +392,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
                 if (BIAS == 2 && tp == 12) bsum += bv[11] + bv[12];
                 // row r-1 of the NEXT k-step goes into its registers during row r (r >= 1); row 4
                 // follows during row 0 of the next k-step
-                if (r >= 1 && ks + 1 < 16 && (sx == 0 || sx == 2)) load_row(bb, ks + 1, r - 1, sx >> 1, bv);
+                if (r >= 1 && ks + 1 < KS && (sx == 0 || sx == 2)) load_row(bb, ks + 1, r - 1, sx >> 1, bv);
                 if (r == 0 && ks >= 1 && (sx == 0 || sx == 2)) load_row(bb, ks, 4, sx >> 1, bv);
-                if (r == 2 && sx == 4 && ks + 1 < 16) load_a(ab, ks + 1, av[(ks + 1) & 1]);
+                if (r == 2 && sx == 4 && ks + 1 < KS) load_a(ab, ks + 1, av[(ks + 1) & 1]);
                 if (r == 3 && sx == 4 && ks < NDMA) {
                     if (more) issue_dma(ks, nbuf, n0n, p0n);
                 }
@@ -376,10 +404,21 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     };
 
     const int tpf_mask = (1 << lg_tpf) - 1;
+    // stage -> (frame, first row): shift / mask, or (GEN) the multiply-high division by the tiles per frame
+    const int tpf_gen = (g.Hs + T::PT_H - 1) / T::PT_H;
+    auto frame_of = [&](const int s) __attribute__((always_inline)) {
+        if constexpr (GEN) return lg_tpf == 0 ? s : (int)__umulhi((unsigned)s, (unsigned)lg_tpf);
+        else return s >> lg_tpf;
+    };
+    auto row_of = [&](const int s, const int f) __attribute__((always_inline)) {
+        if constexpr (GEN) return (s - f * tpf_gen) * T::PT_H;
+        else return (s & tpf_mask) * T::PT_H;
+    };
     int st = blockIdx.y;
     if (st < n_stages) {
+        const int f0 = frame_of(st);
 #pragma unroll
-        for (int d = 0; d < NDMA; ++d) issue_dma(d, 0, st >> lg_tpf, (st & tpf_mask) * T::PT_H);
+        for (int d = 0; d < NDMA; ++d) issue_dma(d, 0, f0, row_of(st, f0));
     }
     // one loop trip = one stage; the base registers of the two LDS images swap after each trip
     int ab_cur = abase[0], ab_oth = abase[1], bb_cur = bbase[0], bb_oth = bbase[1];
@@ -390,7 +429,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int nx = st + splits;
-        stage_body(ab_cur, bb_cur, cur ^ 1, nx < n_stages, nx >> lg_tpf, (nx & tpf_mask) * T::PT_H);
+        const int fx = frame_of(nx);
+        stage_body(ab_cur, bb_cur, cur ^ 1, nx < n_stages, fx, row_of(nx, fx));
         cur ^= 1;
         int tmp = ab_cur; ab_cur = ab_oth; ab_oth = tmp;
         tmp = bb_cur; bb_cur = bb_oth; bb_oth = tmp;
@@ -485,6 +525,27 @@ static bool wgrad4s_ok(const BnGeom& g, const Wgrad4Tile& t) {
     return true;
 }
 
+// maps that are no powers of two on the streamlined kernel (GEN instantiations): widths the kernel is
+// instantiated for, any height, big map exactly twice the small one
+static const int W4G_WIDTHS[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 44};
+static bool wgrad4g_ok(const BnGeom& g) {
+    static int disabled = -1;                          // BN_WGRAD4G=0: off
+    if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4G"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (disabled) return false;
+    if (g.pt != 1 || g.pl != 1 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return false;
+    bool width = false;
+    for (int q : W4G_WIDTHS) width = width || q == g.Ws;
+    if (!width) return false;
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;   // 32-bit offsets
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    const int tpf = (g.Hs + (W4_TPX / g.Ws) - 1) / (W4_TPX / g.Ws);
+    return (size_t)g.N * tpf < (1u << 20);             // multiply-high division of the stage index
+}
+static int wgrad4g_stages(const BnGeom& g) {
+    const int pth = W4_TPX / g.Ws;
+    return g.N * ((g.Hs + pth - 1) / pth);
+}
+
 BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2) return p;
@@ -494,7 +555,19 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     if (disabled) return p;
     Wgrad4Tile t;
     size_t lds = 0;
-    if (!wgrad4_tile(g, &t, &lds)) return p;
+    if (!wgrad4_tile(g, &t, &lds)) {
+        if (!wgrad4g_ok(g)) return p;
+        t.n_stages = wgrad4g_stages(g);
+        p.supported = true;
+        p.variant = 5;
+        p.d = wgrad4_splits(g, t);
+        p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
+        static char names_g[16][40];
+        const int slot = (g.Ws / 4) & 15;
+        snprintf(names_g[slot], sizeof(names_g[slot]), "k_wgrad4s_mfma<%d, gen>", g.Ws);
+        p.kernel_name = names_g[slot];
+        return p;
+    }
     p.supported = true;
     p.variant = 4;
     p.d = wgrad4_splits(g, t);
@@ -504,8 +577,8 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
                                          "k_wgrad4_mfma<3>", "k_wgrad4_mfma<4>", "k_wgrad4_mfma<5>"};
     // (the second template argument of the streamlined kernel, the fused bias side, is not part
     // of the plan's name)
-    static const char* const names_s[6] = {"", "", "", "k_wgrad4s_mfma<3>", "k_wgrad4s_mfma<4>",
-                                           "k_wgrad4s_mfma<5>"};
+    static const char* const names_s[6] = {"", "", "", "k_wgrad4s_mfma<8>", "k_wgrad4s_mfma<16>",
+                                           "k_wgrad4s_mfma<32>"};
     const int lgq = ilog2_exact_w4(g.Ws);
     p.kernel_name = wgrad4s_ok(g, t) ? names_s[lgq] : names[(lgq >= 2 && lgq <= 5) ? lgq : 0];
     return p;
@@ -528,19 +601,20 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
     return 0;
 }
 
-template <int LGQ, int BIAS>
+template <int Q, int BIAS, bool GEN>
 static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const float* big,
                           float* part, float* bias_part, const BnGeom& g, int n_stages, int splits,
                           int lg_tpf, int nbias) {
+    static_assert((size_t)2 * W4S<Q>::BUFW * 4 <= W4_MAX_LDS, "two stage images in LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<LGQ, BIAS>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, W4_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    BN_LAUNCH_MAIN((k_wgrad4s_mfma<LGQ, BIAS>), grid, dim3(W4_THREADS),
-                       (size_t)2 * W4S<LGQ>::BUFW * 4, st, small, big, part, bias_part, g, n_stages,
+    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN>), grid, dim3(W4_THREADS),
+                       (size_t)2 * W4S<Q>::BUFW * 4, st, small, big, part, bias_part, g, n_stages,
                        splits, lg_tpf, nbias);
     BN_LAUNCH_CHECK();
     return 0;
@@ -551,10 +625,16 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
                      int bias_side, bool* bias_done) {
     Wgrad4Tile t;
     size_t lds = 0;
-    if (!wgrad4_tile(g, &t, &lds)) return BN_E_SHAPE;
+    const bool gen = plan.variant == 5;
+    if (gen) {
+        if (!wgrad4g_ok(g)) return BN_E_SHAPE;
+        t.n_stages = wgrad4g_stages(g);
+    } else if (!wgrad4_tile(g, &t, &lds)) return BN_E_SHAPE;
     t.splits = plan.d;
     // the taps {1,2}^2 cover the big image only if it is not larger than 2x the small one
-    const bool fuse = db && (bias_side == 1 || (bias_side == 2 && g.Hb <= 2 * g.Hs &&
+    // (the GEN instantiations leave the big side's sums to the caller's channel-sum kernels: with the
+    // row numbers of the DMA groups on top, the fused form runs out of registers)
+    const bool fuse = db && (bias_side == 1 || (bias_side == 2 && !gen && g.Hb <= 2 * g.Hs &&
                                                 g.Wb <= 2 * g.Ws));
     t.bias_side = fuse ? bias_side : 0;
     t.nbias = bias_side == 1 ? g.Cs : g.Cb;
@@ -562,12 +642,25 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     const int tiles = ((g.Cs + W4_TA - 1) / W4_TA) * ((g.Cb + W4_TB - 1) / W4_TB);
     dim3 grid(tiles, t.splits);
     int rc = BN_E_SHAPE;
-    if (wgrad4s_ok(g, t)) {
+    if (gen) {
+        // stage -> frame by multiply-high: 2^32 / tiles + 1 (exact below 2^32 / tiles stages)
+        const int pth = W4_TPX / g.Ws, tpf = (g.Hs + pth - 1) / pth;
+        const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);
+#define W4G_CASE(QV, B)                                                                          \
+    if (g.Ws == QV && t.bias_side == B)                                                          \
+        rc = launch_wgrad4s<QV, B, true>(grid, st, small, big, (float*)ws, bias_part, g,         \
+                                         t.n_stages, t.splits, magic, t.nbias);
+#define W4G_ALL(QV) W4G_CASE(QV, 0) W4G_CASE(QV, 1)
+        W4G_ALL(8) W4G_ALL(12) W4G_ALL(16) W4G_ALL(20) W4G_ALL(24) W4G_ALL(28) W4G_ALL(32) W4G_ALL(36)
+        W4G_ALL(40) W4G_ALL(44)
+#undef W4G_ALL
+#undef W4G_CASE
+    } else if (wgrad4s_ok(g, t)) {
         const int lgq = ilog2_exact_w4(g.Ws), lg_tpf = ilog2_exact_w4(t.tiles_per_frame);
 #define W4S_CASE(L, B)                                                                         \
     if (lgq == L && t.bias_side == B)                                                          \
-        rc = launch_wgrad4s<L, B>(grid, st, small, big, (float*)ws, bias_part, g, t.n_stages,  \
-                                  t.splits, lg_tpf, t.nbias);
+        rc = launch_wgrad4s<(1 << L), B, false>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                t.n_stages, t.splits, lg_tpf, t.nbias);
         W4S_CASE(3, 0) W4S_CASE(3, 1) W4S_CASE(3, 2) W4S_CASE(4, 0) W4S_CASE(4, 1) W4S_CASE(4, 2)
         W4S_CASE(5, 0) W4S_CASE(5, 1) W4S_CASE(5, 2)
 #undef W4S_CASE

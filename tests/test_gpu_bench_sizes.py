@@ -56,16 +56,16 @@ KERNELS_256 = {
     ('E3', 'fwd'): 'k_down2_mfma<2, 1>',
     ('E1', 'bwd_d'): 'k_up2_mfma<5, 4>', ('E2', 'bwd_d'): 'k_up2_mfma<4, 4>',
     ('E3', 'bwd_d'): 'k_up2_mfma<3, 4>',
-    ('E1', 'bwd_w'): 'k_wgrad4s_mfma<5>', ('E2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
-    ('E3', 'bwd_w'): 'k_wgrad4s_mfma<3>',
+    ('E1', 'bwd_w'): 'k_wgrad4s_mfma<32>', ('E2', 'bwd_w'): 'k_wgrad4s_mfma<16>',
+    ('E3', 'bwd_w'): 'k_wgrad4s_mfma<8>',
     ('E4', 'fwd'): 'k_qgemm<0>', ('E4', 'bwd_d'): 'k_qg2_up', ('E4', 'bwd_w'): 'k_qg2_wgrad',
     ('D0', 'fwd'): 'k_qg2_up', ('D0', 'bwd_d'): 'k_qgemm<0>', ('D0', 'bwd_w'): 'k_qg2_wgrad',
     ('D1', 'fwd'): 'k_up2_mfma<3, 4>', ('D2', 'fwd'): 'k_up2_mfma<4, 4>',
     ('D3', 'fwd'): 'k_up2_mfma<5, 4>',
     ('D1', 'bwd_d'): 'k_down2_mfma<2, 1>', ('D2', 'bwd_d'): 'k_down2_mfma<2, 2>',
     ('D3', 'bwd_d'): 'k_down2_mfma<2, 2>',
-    ('D1', 'bwd_w'): 'k_wgrad4s_mfma<3>', ('D2', 'bwd_w'): 'k_wgrad4s_mfma<4>',
-    ('D3', 'bwd_w'): 'k_wgrad4s_mfma<5>',
+    ('D1', 'bwd_w'): 'k_wgrad4s_mfma<8>', ('D2', 'bwd_w'): 'k_wgrad4s_mfma<16>',
+    ('D3', 'bwd_w'): 'k_wgrad4s_mfma<32>',
     ('E0c2', 'fwd'): 'k_down_c1s<1, false, false, 2, 2>', ('E0c2', 'bwd_w'): 'k_wgrad_c1d',
     ('D4c2', 'fwd'): 'k_up_c1m<false>', ('D4c2', 'bwd_d'): 'k_down_c1s<0, true, false, 2, 2>',
     ('D4c2', 'bwd_w'): 'k_wgrad_c1d',

@@ -93,6 +93,18 @@ CONV_CASES = [
     ('s1_k5_64x64', 2, 16, 64, 64, 32, 5, 1, (2, 2), (2, 2)),
     ('s1_k3_32x32', 3, 32, 32, 32, 64, 3, 1, (1, 1), (1, 1)),
     ('s1_k4_8x8', 3, 64, 8, 8, 64, 4, 1, (1, 2), (1, 2)),
+    # round 4: maps that are no powers of two DIRECTLY on the stride-2 families (runtime tile geometry:
+    # any even width / any height for the gather-down role, any width for the gather-up role, widths
+    # that are multiples of 4 up to 44 for the weight gradient).  Frame counts that leave the last
+    # workgroup's frame group short, tiles with rows below the map, stages that hang over a frame's edge
+    ('np2_16x12', 5, 32, 32, 24, 64, 5, 2, (1, 2), (1, 2)),
+    ('np2_12x10', 7, 64, 24, 20, 128, 5, 2, (1, 2), (1, 2)),
+    ('np2_8x6', 9, 64, 16, 12, 128, 5, 2, (1, 2), (1, 2)),
+    ('np2_6x8', 5, 64, 12, 16, 128, 5, 2, (1, 2), (1, 2)),
+    ('np2_6x5', 11, 128, 12, 10, 256, 5, 2, (1, 2), (1, 2)),
+    ('np2_21x28', 3, 32, 42, 56, 64, 5, 2, (1, 2), (1, 2)),
+    ('np2_5x36', 4, 32, 10, 72, 96, 5, 2, (1, 2), (1, 2)),
+    ('np2_48x40_n5', 5, 32, 96, 80, 64, 5, 2, (1, 2), (1, 2)),
 ]
 
 
@@ -180,6 +192,15 @@ CONVT_CASES = [
     ('k3_8x8', 2, 128, 8, 8, 64, 3, 2, 0, (1, 0, 1, 0), 0),
     ('D4_64ch', 2, 64, 64, 64, 1, 5, 2, 0, (1, 2, 1, 2), 0),
     ('D4_k4_64ch', 2, 64, 64, 64, 1, 4, 2, 0, (1, 1, 1, 1), 0),
+    # round 4: no powers of two, directly on the stride-2 families (see CONV_CASES)
+    ('np2_16x12', 5, 64, 16, 12, 32, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('np2_12x10', 7, 128, 12, 10, 64, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('np2_8x6', 9, 128, 8, 6, 64, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('np2_6x8', 5, 128, 6, 8, 64, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('np2_6x5', 11, 256, 6, 5, 128, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('np2_21x28', 3, 64, 21, 28, 32, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('np2_5x36', 4, 96, 5, 36, 32, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('np2_48x40_n5', 5, 64, 48, 40, 32, 5, 2, 0, (1, 2, 1, 2), 0),
 ]
 
 
@@ -633,9 +654,10 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
 
 
 @pytest.mark.parametrize('case_name, want', [
-    ('tile_48x40', 'on zero-padded 64x64'), ('tile_100x24', 'on zero-padded 128x32'),
-    ('tile_E0_96x80', 'on 2x2 tiles of 64x64'), ('pad_24x20', 'on zero-padded 32x32'),
-    ('k4_64ch_32x32', 'mfma'), ('k4x3_24x20', 'on zero-padded 32x32'),
+    ('tile_48x40', 'k_down2_mfma<'), ('tile_100x24', 'k_down2_mfma<'),
+    ('tile_E0_96x80', 'on 2x2 tiles of 64x64'), ('pad_24x20', 'k_down2_mfma<'),
+    ('k4_64ch_32x32', 'mfma'), ('k4x3_24x20', 'k_down2_mfma<'), ('np2_6x5', 'on zero-padded 6x6'), ('pad_4x3', 'k_down2_mfma<2, 1> on zero-padded 4x4'),
+    ('tile_odd_pl2', 'on zero-padded 47x36'),
     ('s1_k5_64x64', 'k_down_mfma<'), ('s1_k4_8x8', 'k_down_mfma<')])
 def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, want):
     """The dispatch takes the tiled / zero-padded detour (conv_pad.hip), not the direct loops."""
