@@ -53,11 +53,11 @@ SIGNATURES = {
     'bn_batchnorm_finalize': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_float] * 3 + [_c_void_p]),
     'bn_batchnorm_act_fwd': (_c_int, [_c_void_p] * 6 + [_c_int] * 4 + [_c_float, _c_void_p]),
     'bn_batchnorm_train_fwd_chunks': (
-        _c_int, [_c_void_p] * 10 + [_c_int] * 3 + [_c_float, _c_int, _c_float, _c_void_p, _c_size_t,
+        _c_int, [_c_void_p] * 11 + [_c_int] * 3 + [_c_float, _c_int, _c_float, _c_void_p, _c_size_t,
                                                   _c_void_p]),
     'bn_batchnorm_act_bwd_chunks': (
-        _c_int, [_c_void_p] * 9 + [_c_int, _c_void_p] + [_c_int] * 4 + [_c_float, _c_void_p, _c_size_t,
-                                                                       _c_void_p]),
+        _c_int, [_c_void_p] * 10 + [_c_int, _c_void_p] + [_c_int] * 4 + [_c_float, _c_void_p, _c_size_t,
+                                                                        _c_void_p]),
     'bn_batchnorm_act_bwd': (
         _c_int, [_c_void_p] * 9 + [_c_int] * 6 + [_c_float, _c_void_p, _c_size_t, _c_void_p]),
     'bn_batchnorm_moment': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p, _c_size_t, _c_void_p]),
@@ -310,10 +310,14 @@ def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps
 
 
 def batchnorm_train_fwd_chunks(x, gamma, beta, running_mean, running_var, factors, eps, act, slope,
-                               bounds):
+                               bounds, num_batches_tracked=None):
     """Train-mode batch norm with statistics per chunk of frames (``bounds``: [(beg, end)] in order,
     ``factors``: the running-estimate factor of every chunk's update).  One library call.
+    ``num_batches_tracked``: nn.BatchNorm2d's int64 counter, advanced by len(bounds) on the device.
     -> (y, mean (n_chunks, C), invstd (n_chunks, C))."""
+    if num_batches_tracked is not None and (num_batches_tracked.dtype != torch.int64 or
+                                            not num_batches_tracked.is_cuda):
+        raise TypeError('num_batches_tracked must be an int64 device tensor')
     import ctypes
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
@@ -327,13 +331,18 @@ def batchnorm_train_fwd_chunks(x, gamma, beta, running_mean, running_var, factor
     _check(load().bn_batchnorm_train_fwd_chunks(
         _ptr(x, 'x'), _ptr(gamma, 'gamma', allow_none=True), _ptr(beta, 'beta', allow_none=True),
         _ptr(running_mean, 'running_mean', allow_none=True),
-        _ptr(running_var, 'running_var', allow_none=True), _ptr(y, 'y'), _ptr(mean, 'mean'),
+        _ptr(running_var, 'running_var', allow_none=True),
+        num_batches_tracked.data_ptr() if num_batches_tracked is not None else None,
+        _ptr(y, 'y'), _ptr(mean, 'mean'),
         _ptr(invstd, 'invstd'), ctypes.cast(flat, ctypes.c_void_p), ctypes.cast(fac, ctypes.c_void_p),
         k, c, hw, eps, act, slope, ws, nb, _stream()), 'bn_batchnorm_train_fwd_chunks')
     return y, mean, invstd
 
 
-def batchnorm_bwd_chunks(x, y, dy, mean, invstd, gamma, dgamma, dbeta, accumulate, act, slope, bounds):
+def batchnorm_bwd_chunks(x, y, dy, mean, invstd, gamma, dgamma, dbeta, accumulate, act, slope, bounds,
+                         beta=None):
+    """``y`` None (identity / LeakyReLU): the activation's sign is rebuilt from x through (gamma,
+    ``beta``) -- the saved output is not read."""
     import ctypes
     n, c = x.shape[0], x.shape[1]
     hw = x.numel() // (n * c)
@@ -342,8 +351,9 @@ def batchnorm_bwd_chunks(x, y, dy, mean, invstd, gamma, dgamma, dbeta, accumulat
     ws, nb = _bn_ws(max(e - b for b, e in bounds), c, x.device)
     flat = (ctypes.c_int * (2 * k))(*[v for be in bounds for v in be])
     _check(load().bn_batchnorm_act_bwd_chunks(
-        _ptr(x, 'x'), _ptr(y, 'y'), _ptr(dy, 'dy'), _ptr(mean, 'mean'), _ptr(invstd, 'invstd'),
-        _ptr(gamma, 'gamma', allow_none=True), _ptr(dx, 'dx'),
+        _ptr(x, 'x'), _ptr(y, 'y', allow_none=True), _ptr(dy, 'dy'), _ptr(mean, 'mean'),
+        _ptr(invstd, 'invstd'), _ptr(gamma, 'gamma', allow_none=True),
+        _ptr(beta, 'beta', allow_none=True), _ptr(dx, 'dx'),
         _ptr(dgamma, 'dgamma', allow_none=True), _ptr(dbeta, 'dbeta', allow_none=True),
         int(accumulate), ctypes.cast(flat, ctypes.c_void_p), k, c, hw, act, slope, ws, nb, _stream()),
         'bn_batchnorm_act_bwd_chunks')

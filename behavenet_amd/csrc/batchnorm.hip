@@ -92,6 +92,100 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_moment_part(
     if (threadIdx.x == 0) part[((size_t)z * C + c) * S + sp] = s;
 }
 
+// y = x * sc + sh with sc = invstd * gamma, sh = beta - mean * sc: ONE spelling (explicit fused
+// multiply-adds) for the forward pass and for the backward kernels that rebuild the sign of the
+// activation's input from x instead of reading y back (round 4) -- bit-identical in all of them
+__device__ __forceinline__ void bnk_affine(float mean, float invstd, const float* gamma, const float* beta,
+                                           int c, float* sc, float* sh) {
+    *sc = invstd * (gamma ? gamma[c] : 1.f);
+    *sh = fmaf(-mean, *sc, beta ? beta[c] : 0.f);
+}
+
+// Statistics in ONE pass over x (round 4; they were two: mean, then the centred second moment):
+// part1 = sum (x - s), part2 = sum (x - s)^2 around a per-channel shift s = the chunk's first value
+// of the channel.  With s inside the data the subtraction var = E[(x-s)^2] - (E[x-s])^2 loses a
+// factor (1 + (mean - s)^2 / var) of precision -- a few units in the last place for any channel
+// that is not constant, against the catastrophic E[x^2] - mean^2 -- and 0.5 GB less traffic per
+// training step of the batch-norm model.
+__global__ __launch_bounds__(BNK_THREADS) void k_bn_stats_part(
+    const float* __restrict__ x, float* __restrict__ part1, float* __restrict__ part2, BnChunks ch,
+    int C, int HW, int S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, sp = blockIdx.y, z = blockIdx.z;
+    const int N = ch.end[z] - ch.beg[z];
+    const int n_beg = ch.beg[z] + (int)((long)sp * N / S), n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
+    const float sh = x[((size_t)ch.beg[z] * C + c) * HW];
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);
+    if (vec) {
+        const unsigned hw4 = HW >> 2, cnt = (unsigned)(n_end - n_beg) * hw4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (unsigned e = threadIdx.x; e < cnt; e += 2 * BNK_THREADS) {
+            const unsigned e2 = e + BNK_THREADS;
+            const unsigned n = e / hw4, i = e - n * hw4;
+            float4 v = x4[((size_t)(n_beg + n) * C + c) * hw4 + i];
+            float4 w = make_float4(sh, sh, sh, sh);
+            if (e2 < cnt) {
+                const unsigned n2 = e2 / hw4, i2 = e2 - n2 * hw4;
+                w = x4[((size_t)(n_beg + n2) * C + c) * hw4 + i2];
+            }
+            v.x -= sh; v.y -= sh; v.z -= sh; v.w -= sh;
+            w.x -= sh; w.y -= sh; w.z -= sh; w.w -= sh;
+            a1 += (v.x + v.y) + (v.z + v.w);
+            b1 += (w.x + w.y) + (w.z + w.w);
+            a2 += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+            b2 += fmaf(w.x, w.x, w.y * w.y) + fmaf(w.z, w.z, w.w * w.w);
+        }
+    } else {
+        const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
+        for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
+            const unsigned n = e / HW, i = e - n * HW;
+            const float v = x[((size_t)(n_beg + n) * C + c) * HW + i] - sh;
+            a1 += v;
+            a2 = fmaf(v, v, a2);
+        }
+    }
+    const float s1 = bnk_block_sum(a1 + b1, red);
+    const float s2 = bnk_block_sum(a2 + b2, red);
+    if (threadIdx.x == 0) {
+        part1[((size_t)z * C + c) * S + sp] = s1;
+        part2[((size_t)z * C + c) * S + sp] = s2;
+    }
+}
+
+// mean / biased variance / invstd of every chunk from the one-pass partial sums, the running
+// estimates (chunks in order: one update per chunk, factor scale[z], unbiasing aux[z]) and the batch
+// counter in ONE launch (they were two combine launches, the finalize kernel and torch's add_)
+__global__ void k_bn_stats_finalize(const float* __restrict__ x, const float* __restrict__ part1,
+                                    const float* __restrict__ part2, float* __restrict__ mean,
+                                    float* __restrict__ var, float* __restrict__ invstd,
+                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                    long long* __restrict__ num_batches, int C, int HW, int S, float eps,
+                                    BnChunks ch) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches) *num_batches += ch.n;
+    if (c >= C) return;
+    for (int z = 0; z < ch.n; ++z) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+        for (int s = 0; s < S; ++s) {
+            s1 += part1[((size_t)z * C + c) * S + s];
+            s2 += part2[((size_t)z * C + c) * S + s];
+        }
+        const float inv_n = 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW);
+        const float sh = x[((size_t)ch.beg[z] * C + c) * HW];
+        const float d = s1 * inv_n;
+        const float m = sh + d;
+        const float v = fmaxf(fmaf(-d, d, s2 * inv_n), 0.f);
+        mean[z * C + c] = m;
+        if (var) var[z * C + c] = v;
+        if (invstd) invstd[z * C + c] = 1.0f / sqrtf(v + eps);
+        const float momentum = ch.scale[z];
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * v * ch.aux[z];
+    }
+}
+
 // out[z][c] = scale[z] * sum_s part[z][c][s]
 __global__ void k_bn_combine(const float* __restrict__ part, float* __restrict__ out, int C, int S,
                              BnChunks ch) {
@@ -135,8 +229,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd(
     for (unsigned e = blockIdx.x * BNK_THREADS + threadIdx.x; e < total; e += gridDim.x * BNK_THREADS) {
         const unsigned nc = e / hwv;
         const int c = nc % C, zc = bnk_chunk_of(ch, nc / C) * C + c;
-        const float sc = invstd[zc] * (gamma ? gamma[c] : 1.f);
-        const float sh = (beta ? beta[c] : 0.f) - mean[zc] * sc;
+        float sc, sh;
+        bnk_affine(mean[zc], invstd[zc], gamma, beta, c, &sc, &sh);
         if (VEC == 4) {
             const float4 v = reinterpret_cast<const float4*>(x)[e];
             float4 o;
@@ -153,15 +247,22 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd(
 
 // backward reductions: part0[c][sp] = sum dz, part1[c][sp] = sum dz * xhat,
 // dz = dy * act'(y), xhat = (x - mean) * invstd   (one index range per slice, see above)
+// FROMX (identity / LeakyReLU): the sign of the activation's input is rebuilt from x with the forward
+// pass's own affine map (bnk_affine) instead of reading y: 0.5 GB less per pass over the batch
+template <bool FROMX>
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
-    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ part0,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ part0,
     float* __restrict__ part1, BnChunks ch, int C, int HW, int S, int act, float slope) {
     __shared__ float red[4];
     const int c = blockIdx.x, sp = blockIdx.y, z = blockIdx.z;
     const int N = ch.end[z] - ch.beg[z];
     const int n_beg = ch.beg[z] + (int)((long)sp * N / S), n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
     const float m = mean[z * C + c], is = invstd[z * C + c];
+    float sc = 1.f, sh = 0.f;
+    if (FROMX) bnk_affine(m, is, gamma, beta, c, &sc, &sh);
+    const float neg = act == BN_ACT_LRELU ? slope : 1.f;
     float a0 = 0.f, a1 = 0.f;
     const bool vec = (HW & 3) == 0 &&
                      (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy)) & 15u) == 0);
@@ -173,11 +274,20 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
         for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
             const unsigned n = e / hw4, i = e - n * hw4;
             const size_t o = ((size_t)(n_beg + n) * C + c) * hw4 + i;
-            const float4 xv = x4[o], yv = y4[o], dv = d4[o];
-            const float z0 = dv.x * bn_act_grad_from_output(yv.x, act, slope);
-            const float z1 = dv.y * bn_act_grad_from_output(yv.y, act, slope);
-            const float z2 = dv.z * bn_act_grad_from_output(yv.z, act, slope);
-            const float z3 = dv.w * bn_act_grad_from_output(yv.w, act, slope);
+            const float4 xv = x4[o], dv = d4[o];
+            float z0, z1, z2, z3;
+            if (FROMX) {
+                z0 = dv.x * (fmaf(xv.x, sc, sh) > 0.f ? 1.f : neg);
+                z1 = dv.y * (fmaf(xv.y, sc, sh) > 0.f ? 1.f : neg);
+                z2 = dv.z * (fmaf(xv.z, sc, sh) > 0.f ? 1.f : neg);
+                z3 = dv.w * (fmaf(xv.w, sc, sh) > 0.f ? 1.f : neg);
+            } else {
+                const float4 yv = y4[o];
+                z0 = dv.x * bn_act_grad_from_output(yv.x, act, slope);
+                z1 = dv.y * bn_act_grad_from_output(yv.y, act, slope);
+                z2 = dv.z * bn_act_grad_from_output(yv.z, act, slope);
+                z3 = dv.w * bn_act_grad_from_output(yv.w, act, slope);
+            }
             a0 += (z0 + z1) + (z2 + z3);
             a1 += (z0 * ((xv.x - m) * is) + z1 * ((xv.y - m) * is)) +
                   (z2 * ((xv.z - m) * is) + z3 * ((xv.w - m) * is));
@@ -187,7 +297,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
         for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
             const unsigned n = e / HW, i = e - n * HW;
             const size_t o = ((size_t)(n_beg + n) * C + c) * HW + i;
-            const float dz = dy[o] * bn_act_grad_from_output(y[o], act, slope);
+            const float dz = dy[o] * (FROMX ? (fmaf(x[o], sc, sh) > 0.f ? 1.f : neg)
+                                            : bn_act_grad_from_output(y[o], act, slope));
             a0 += dz;
             a1 += dz * ((x[o] - m) * is);
         }
@@ -225,32 +336,48 @@ __global__ void k_bn_bwd_combine(const float* __restrict__ part0, const float* _
 }
 
 // dx = gamma * invstd * (dz - dbeta/n - xhat * dgamma/n), flat like the forward
-template <int VEC>
+template <int VEC, bool FROMX>
 __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply(
     const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
     const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ gamma, const float* __restrict__ sum_dz,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ sum_dz,
     const float* __restrict__ sum_dzx, float* __restrict__ dx, unsigned NC, int C, int HW,
     int act, float slope, BnChunks ch) {
     const unsigned hwv = HW / VEC, total = NC * hwv;
+    const float neg = act == BN_ACT_LRELU ? slope : 1.f;
     for (unsigned e = blockIdx.x * BNK_THREADS + threadIdx.x; e < total; e += gridDim.x * BNK_THREADS) {
         const unsigned nc = e / hwv;
         const int c = nc % C, z = bnk_chunk_of(ch, nc / C), zc = z * C + c;
         const float m = mean[zc], is = invstd[zc], inv_n = ch.scale[z];
         const float g = (gamma ? gamma[c] : 1.f) * is;
         const float k0 = sum_dz[zc] * inv_n, k1 = sum_dzx[zc] * inv_n;
+        float sc = 1.f, sh = 0.f;
+        if (FROMX) bnk_affine(m, is, gamma, beta, c, &sc, &sh);
         if (VEC == 4) {
             const float4 xv = reinterpret_cast<const float4*>(x)[e];
-            const float4 yv = reinterpret_cast<const float4*>(y)[e];
             const float4 dv = reinterpret_cast<const float4*>(dy)[e];
+            float4 f;
+            if (FROMX) {
+                f.x = fmaf(xv.x, sc, sh) > 0.f ? 1.f : neg;
+                f.y = fmaf(xv.y, sc, sh) > 0.f ? 1.f : neg;
+                f.z = fmaf(xv.z, sc, sh) > 0.f ? 1.f : neg;
+                f.w = fmaf(xv.w, sc, sh) > 0.f ? 1.f : neg;
+            } else {
+                const float4 yv = reinterpret_cast<const float4*>(y)[e];
+                f.x = bn_act_grad_from_output(yv.x, act, slope);
+                f.y = bn_act_grad_from_output(yv.y, act, slope);
+                f.z = bn_act_grad_from_output(yv.z, act, slope);
+                f.w = bn_act_grad_from_output(yv.w, act, slope);
+            }
             float4 o;
-            o.x = g * (dv.x * bn_act_grad_from_output(yv.x, act, slope) - k0 - ((xv.x - m) * is) * k1);
-            o.y = g * (dv.y * bn_act_grad_from_output(yv.y, act, slope) - k0 - ((xv.y - m) * is) * k1);
-            o.z = g * (dv.z * bn_act_grad_from_output(yv.z, act, slope) - k0 - ((xv.z - m) * is) * k1);
-            o.w = g * (dv.w * bn_act_grad_from_output(yv.w, act, slope) - k0 - ((xv.w - m) * is) * k1);
+            o.x = g * (dv.x * f.x - k0 - ((xv.x - m) * is) * k1);
+            o.y = g * (dv.y * f.y - k0 - ((xv.y - m) * is) * k1);
+            o.z = g * (dv.z * f.z - k0 - ((xv.z - m) * is) * k1);
+            o.w = g * (dv.w * f.w - k0 - ((xv.w - m) * is) * k1);
             reinterpret_cast<float4*>(dx)[e] = o;
         } else {
-            const float dz = dy[e] * bn_act_grad_from_output(y[e], act, slope);
+            const float dz = dy[e] * (FROMX ? (fmaf(x[e], sc, sh) > 0.f ? 1.f : neg)
+                                            : bn_act_grad_from_output(y[e], act, slope));
             dx[e] = g * (dz - k0 - ((x[e] - m) * is) * k1);
         }
     }
@@ -326,50 +453,58 @@ int bn_launch_bn_act_fwd(const float* x, const float* mean, const float* invstd,
     return bn_launch_act_fwd_chunks(x, mean, invstd, gamma, beta, y, N, C, HW, act, slope, bnk_one_chunk(N), st);
 }
 
+// y == nullptr: the activation's sign from x through (gamma, beta) -- identity / LeakyReLU only
 static int bn_launch_bwd_apply_chunks(const float* x, const float* y, const float* dy, const float* mean,
-                                      const float* invstd, const float* gamma, const float* sum_dz,
-                                      const float* sum_dzx, float* dx, int N, int C, int HW, int act,
-                                      float slope, const BnChunks& ch, hipStream_t st) {
+                                      const float* invstd, const float* gamma, const float* beta,
+                                      const float* sum_dz, const float* sum_dzx, float* dx, int N, int C,
+                                      int HW, int act, float slope, const BnChunks& ch, hipStream_t st) {
     if ((size_t)N * C * HW >= 0xffffffffull) return BN_E_SHAPE;
-    if ((HW & 3) == 0 &&
-        (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15u) == 0))
-        hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3(bnk_flat_blocks((size_t)N * C * (HW >> 2))),
-                           dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx,
-                           (unsigned)(N * C), C, HW, act, slope, ch);
-    else
-        hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3(bnk_flat_blocks((size_t)N * C * HW)), dim3(BNK_THREADS),
-                           0, st, x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx, (unsigned)(N * C), C,
-                           HW, act, slope, ch);
+    if (!y && act != BN_ACT_NONE && act != BN_ACT_LRELU) return BN_E_BADARG;
+    const bool vec = (HW & 3) == 0 &&
+                     (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15u) == 0);
+    const dim3 grid(bnk_flat_blocks((size_t)N * C * (vec ? HW >> 2 : HW)));
+#define BN_APPLY(V, F)                                                                                  \
+    hipLaunchKernelGGL((k_bn_bwd_apply<V, F>), grid, dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,   \
+                       gamma, beta, sum_dz, sum_dzx, dx, (unsigned)(N * C), C, HW, act, slope, ch)
+    if (vec) { if (y) BN_APPLY(4, false); else BN_APPLY(4, true); }
+    else { if (y) BN_APPLY(1, false); else BN_APPLY(1, true); }
+#undef BN_APPLY
     BN_LAUNCH_CHECK();
     return 0;
 }
 
 // backward of all chunks (statistics [ch.n][C]); x / y / dy / dx hold N frames in total
 static int bn_launch_act_bwd_chunks(const float* x, const float* y, const float* dy, const float* mean,
-                                    const float* invstd, const float* gamma, float* dx, float* dgamma,
-                                    float* dbeta, int accumulate, int batch_stats, int N, BnChunks ch,
-                                    int C, int HW, int act, float slope, void* ws, hipStream_t st) {
+                                    const float* invstd, const float* gamma, const float* beta, float* dx,
+                                    float* dgamma, float* dbeta, int accumulate, int batch_stats, int N,
+                                    BnChunks ch, int C, int HW, int act, float slope, void* ws,
+                                    hipStream_t st) {
     const int S = bn_splits(bnk_max_len(ch), C);
     float* part0 = (float*)ws;
     float* part1 = part0 + (size_t)ch.n * C * S;
     float* sum0 = part1 + (size_t)ch.n * C * S;
     float* sum1 = sum0 + (size_t)ch.n * C;
-    hipLaunchKernelGGL(k_bn_bwd_part, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
-                       part0, part1, ch, C, HW, S, act, slope);
+    if (!y && act != BN_ACT_NONE && act != BN_ACT_LRELU) return BN_E_BADARG;
+    if (y)
+        hipLaunchKernelGGL(k_bn_bwd_part<false>, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
+                           invstd, gamma, beta, part0, part1, ch, C, HW, S, act, slope);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_part<true>, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
+                           invstd, gamma, beta, part0, part1, ch, C, HW, S, act, slope);
     hipLaunchKernelGGL(k_bn_bwd_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, part1, sum0, sum1,
                        dgamma, dbeta, C, S, accumulate, ch.n);
     BN_LAUNCH_CHECK();
     for (int z = 0; z < ch.n; ++z)
         ch.scale[z] = batch_stats ? 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW) : 0.0f;
-    return bn_launch_bwd_apply_chunks(x, y, dy, mean, invstd, gamma, sum0, sum1, dx, N, C, HW, act, slope,
-                                      ch, st);
+    return bn_launch_bwd_apply_chunks(x, y, dy, mean, invstd, gamma, beta, sum0, sum1, dx, N, C, HW, act,
+                                      slope, ch, st);
 }
 
 int bn_launch_bn_act_bwd(const float* x, const float* y, const float* dy, const float* mean,
                          const float* invstd, const float* gamma, float* dx, float* dgamma,
                          float* dbeta, int accumulate, int batch_stats, int N, int C, int HW,
                          int act, float slope, void* ws, hipStream_t st) {
-    return bn_launch_act_bwd_chunks(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, accumulate,
+    return bn_launch_act_bwd_chunks(x, y, dy, mean, invstd, gamma, nullptr, dx, dgamma, dbeta, accumulate,
                                     batch_stats, N, bnk_one_chunk(N), C, HW, act, slope, ws, st);
 }
 
@@ -389,37 +524,41 @@ static bool bnk_make_chunks(const int* bounds, int n_chunks, BnChunks* ch, int* 
 }
 
 int bn_launch_bn_train_fwd_chunks(const float* x, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, float* y, float* mean,
-                                  float* invstd, const int* bounds, const float* factors, int n_chunks,
-                                  int C, int HW, float eps, int act, float slope, void* ws,
-                                  hipStream_t st) {
+                                  float* running_mean, float* running_var, long long* num_batches,
+                                  float* y, float* mean, float* invstd, const int* bounds,
+                                  const float* factors, int n_chunks, int C, int HW, float eps, int act,
+                                  float slope, void* ws, hipStream_t st) {
     BnChunks ch;
     int N = 0;
     if (!bnk_make_chunks(bounds, n_chunks, &ch, &N)) return BN_E_SHAPE;
     const int S = bn_splits(bnk_max_len(ch), C);
-    float* var = (float*)ws + (size_t)2 * ch.n * C * S;          // behind the partial arrays
-    int rc = bn_launch_stats_chunks(x, mean, var, ch, C, HW, ws, st);
-    if (rc) return rc;
+    float* part1 = (float*)ws;
+    float* part2 = part1 + (size_t)ch.n * C * S;
+    // one pass over x for both moments, one small launch for everything per channel
+    hipLaunchKernelGGL(k_bn_stats_part, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x, part1, part2, ch, C,
+                       HW, S);
     for (int z = 0; z < ch.n; ++z) {
         const double cnt = (double)(ch.end[z] - ch.beg[z]) * HW;
         ch.scale[z] = factors ? factors[z] : 0.f;
         ch.aux[z] = cnt > 1 ? (float)(cnt / (cnt - 1.0)) : 1.f;
     }
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)mean, (const float*)var,
-                       invstd, running_mean, running_var, C, eps, ch);
+    hipLaunchKernelGGL(k_bn_stats_finalize, dim3((C + 63) / 64), dim3(64), 0, st, x, (const float*)part1,
+                       (const float*)part2, mean, (float*)nullptr, invstd, running_mean, running_var,
+                       num_batches, C, HW, S, eps, ch);
     BN_LAUNCH_CHECK();
     return bn_launch_act_fwd_chunks(x, mean, invstd, gamma, beta, y, N, C, HW, act, slope, ch, st);
 }
 
 int bn_launch_bn_act_bwd_chunks(const float* x, const float* y, const float* dy, const float* mean,
-                                const float* invstd, const float* gamma, float* dx, float* dgamma,
-                                float* dbeta, int accumulate, const int* bounds, int n_chunks, int C,
-                                int HW, int act, float slope, void* ws, hipStream_t st) {
+                                const float* invstd, const float* gamma, const float* beta, float* dx,
+                                float* dgamma, float* dbeta, int accumulate, const int* bounds,
+                                int n_chunks, int C, int HW, int act, float slope, void* ws,
+                                hipStream_t st) {
     BnChunks ch;
     int N = 0;
     if (!bnk_make_chunks(bounds, n_chunks, &ch, &N)) return BN_E_SHAPE;
-    return bn_launch_act_bwd_chunks(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta, accumulate, 1, N, ch,
-                                    C, HW, act, slope, ws, st);
+    return bn_launch_act_bwd_chunks(x, y, dy, mean, invstd, gamma, beta, dx, dgamma, dbeta, accumulate, 1, N,
+                                    ch, C, HW, act, slope, ws, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -451,8 +590,8 @@ int bn_launch_bn_bwd_reduce(const float* x, const float* y, const float* dy, con
     float* part0 = (float*)ws;
     float* part1 = part0 + (size_t)C * S;
     const BnChunks ch = bnk_one_chunk(N);
-    hipLaunchKernelGGL(k_bn_bwd_part, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
-                       part0, part1, ch, C, HW, S, act, slope);
+    hipLaunchKernelGGL(k_bn_bwd_part<false>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
+                       (const float*)nullptr, (const float*)nullptr, part0, part1, ch, C, HW, S, act, slope);
     hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, sum_dz, C, S, ch);
     hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part1, sum_dzx, C, S, ch);
     BN_LAUNCH_CHECK();
@@ -464,6 +603,6 @@ int bn_launch_bn_bwd_apply(const float* x, const float* y, const float* dy, cons
                            const float* invstd, const float* gamma, const float* sum_dz,
                            const float* sum_dzx, float* dx, int N, int C, int HW, float inv_count,
                            int act, float slope, hipStream_t st) {
-    return bn_launch_bwd_apply_chunks(x, y, dy, mean, invstd, gamma, sum_dz, sum_dzx, dx, N, C, HW, act, slope,
-                                      bnk_one_chunk(N, inv_count), st);
+    return bn_launch_bwd_apply_chunks(x, y, dy, mean, invstd, gamma, nullptr, sum_dz, sum_dzx, dx, N, C, HW,
+                                      act, slope, bnk_one_chunk(N, inv_count), st);
 }

@@ -83,14 +83,15 @@ int bn_launch_bn_bwd_reduce(const float* x, const float* y, const float* dy, con
                             const float* invstd, float* sum_dz, float* sum_dzx, int N, int C,
                             int HW, int act, float slope, void* ws, hipStream_t st);
 int bn_launch_bn_train_fwd_chunks(const float* x, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, float* y, float* mean,
-                                  float* invstd, const int* bounds, const float* factors, int n_chunks,
-                                  int C, int HW, float eps, int act, float slope, void* ws,
-                                  hipStream_t st);
+                                  float* running_mean, float* running_var, long long* num_batches,
+                                  float* y, float* mean, float* invstd, const int* bounds,
+                                  const float* factors, int n_chunks, int C, int HW, float eps, int act,
+                                  float slope, void* ws, hipStream_t st);
 int bn_launch_bn_act_bwd_chunks(const float* x, const float* y, const float* dy, const float* mean,
-                                const float* invstd, const float* gamma, float* dx, float* dgamma,
-                                float* dbeta, int accumulate, const int* bounds, int n_chunks, int C,
-                                int HW, int act, float slope, void* ws, hipStream_t st);
+                                const float* invstd, const float* gamma, const float* beta, float* dx,
+                                float* dgamma, float* dbeta, int accumulate, const int* bounds,
+                                int n_chunks, int C, int HW, int act, float slope, void* ws,
+                                hipStream_t st);
 int bn_launch_bn_bwd_apply(const float* x, const float* y, const float* dy, const float* mean,
                            const float* invstd, const float* gamma, const float* sum_dz,
                            const float* sum_dzx, float* dx, int N, int C, int HW, float inv_count,

@@ -268,7 +268,7 @@ static PadPlan pad_plan(int role, const BnGeom& g) {
         {
             const int hmin = 2 * g.Hs >= g.Hb + oh ? g.Hs : (g.Hb + oh + 1) / 2;
             int w0 = 2 * g.Ws >= g.Wb + ow ? g.Ws : (g.Wb + ow + 1) / 2;
-            for (int wq = w0; wq <= wsm && wq <= w0 + 8 && !found; ++wq) {
+            for (int wq = w0; wq <= (wsm > 8 ? wsm : 8) && wq <= w0 + 8 && !found; ++wq) {
                 if (wq == g.Ws && hmin == g.Hs && g.Hb == 2 * g.Hs && g.Wb == 2 * g.Ws && !oh && !ow) continue;
                 p.gp = g;
                 p.gp.Hs = hmin; p.gp.Ws = wq; p.gp.Hb = 2 * hmin; p.gp.Wb = 2 * wq; p.gp.pt = p.gp.pl = 1;
@@ -1031,7 +1031,8 @@ extern "C" int bn_batchnorm_act_bwd(const float* x, const float* y, const float*
 // (rows [bounds[2i], bounds[2i+1]) of x, in order; the running estimates see one update per chunk
 // with factors[i]): one call per layer instead of three per chunk.  mean / invstd: [n_chunks][C].
 extern "C" int bn_batchnorm_train_fwd_chunks(const float* x, const float* gamma, const float* beta,
-                                             float* running_mean, float* running_var, float* y,
+                                             float* running_mean, float* running_var,
+                                             long long* num_batches_tracked, float* y,
                                              float* mean, float* invstd, const int* bounds,
                                              const float* factors, int n_chunks, int C, int HW,
                                              float eps, int act, float slope, void* ws,
@@ -1042,28 +1043,23 @@ extern "C" int bn_batchnorm_train_fwd_chunks(const float* x, const float* gamma,
         int nmax = 0;
         for (int i = 0; i < n_chunks; ++i) nmax = bounds[2 * i + 1] - bounds[2 * i] > nmax ? bounds[2 * i + 1] - bounds[2 * i] : nmax;
         if (nmax > 0 && ws && ws_bytes >= bn_batchnorm_ws_bytes_impl(nmax, C)) {
-            const int rc = bn_launch_bn_train_fwd_chunks(x, gamma, beta, running_mean, running_var, y, mean,
-                                                         invstd, bounds, factors, n_chunks, C, HW, eps, act,
-                                                         slope, ws, st);
+            const int rc = bn_launch_bn_train_fwd_chunks(x, gamma, beta, running_mean, running_var,
+                                                         num_batches_tracked, y, mean, invstd, bounds,
+                                                         factors, n_chunks, C, HW, eps, act, slope, ws, st);
             if (rc != BN_E_SHAPE) return rc;
         }
     }
+    // (more than four chunks, or chunks that are not contiguous: one at a time)
     for (int i = 0; i < n_chunks; ++i) {
-        const int b = bounds[2 * i], n = bounds[2 * i + 1] - b;
-        if (n <= 0 || b < 0) return BN_E_BADARG;
-        // var: the tail of the scratch (behind the two partial arrays, where the backward pass keeps its sums)
-        if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(n, C)) return BN_E_WORKSPACE;
-        float* var = (float*)((char*)ws + bn_batchnorm_ws_bytes_impl(n, C)) - 2 * C;
-        const float* xc = x + (size_t)b * C * HW;
-        int rc = bn_launch_bn_stats(xc, mean + (size_t)i * C, var, n, C, HW, ws, st);
-        if (rc) return rc;
-        const double cnt = (double)n * HW;
-        rc = bn_launch_bn_finalize(mean + (size_t)i * C, var, invstd + (size_t)i * C, running_mean, running_var,
-                                   C, eps, factors ? factors[i] : 0.f,
-                                   cnt > 1 ? (float)(cnt / (cnt - 1.0)) : 1.f, st);
-        if (rc) return rc;
-        rc = bn_launch_bn_act_fwd(xc, mean + (size_t)i * C, invstd + (size_t)i * C, gamma, beta,
-                                  y + (size_t)b * C * HW, n, C, HW, act, slope, st);
+        const int bi[2] = {0, bounds[2 * i + 1] - bounds[2 * i]};
+        if (bi[1] <= 0 || bounds[2 * i] < 0) return BN_E_BADARG;
+        if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(bi[1], C)) return BN_E_WORKSPACE;
+        const size_t o = (size_t)bounds[2 * i] * C * HW;
+        const float fi = factors ? factors[i] : 0.f;
+        const int rc = bn_launch_bn_train_fwd_chunks(x + o, gamma, beta, running_mean, running_var,
+                                                     num_batches_tracked, y + o, mean + (size_t)i * C,
+                                                     invstd + (size_t)i * C, bi, &fi, 1, C, HW, eps, act,
+                                                     slope, ws, st);
         if (rc) return rc;
     }
     return 0;
@@ -1071,32 +1067,36 @@ extern "C" int bn_batchnorm_train_fwd_chunks(const float* x, const float* gamma,
 
 // the backward pass of the same: dgamma / dbeta are accumulated over the chunks (accumulate = 0:
 // they are overwritten by the first chunk)
+// y == NULL (identity / LeakyReLU): the sign of the activation's input is rebuilt from x with the
+// forward pass's affine map through (gamma, beta) -- the saved output is not read back
 extern "C" int bn_batchnorm_act_bwd_chunks(const float* x, const float* y, const float* dy,
                                            const float* mean, const float* invstd,
-                                           const float* gamma, float* dx, float* dgamma,
-                                           float* dbeta, int accumulate, const int* bounds,
-                                           int n_chunks, int C, int HW, int act, float slope,
-                                           void* ws, size_t ws_bytes, bn_stream_t stream) {
-    if (!x || !y || !dy || !mean || !invstd || !dx || !bounds || n_chunks <= 0 || C <= 0 || HW <= 0)
+                                           const float* gamma, const float* beta, float* dx,
+                                           float* dgamma, float* dbeta, int accumulate,
+                                           const int* bounds, int n_chunks, int C, int HW, int act,
+                                           float slope, void* ws, size_t ws_bytes, bn_stream_t stream) {
+    if (!x || !dy || !mean || !invstd || !dx || !bounds || n_chunks <= 0 || C <= 0 || HW <= 0)
         return BN_E_BADARG;
+    if (!y && act != BN_ACT_NONE && act != BN_ACT_LRELU) return BN_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     {
         int nmax = 0;
         for (int i = 0; i < n_chunks; ++i) nmax = bounds[2 * i + 1] - bounds[2 * i] > nmax ? bounds[2 * i + 1] - bounds[2 * i] : nmax;
         if (nmax > 0 && ws && ws_bytes >= bn_batchnorm_ws_bytes_impl(nmax, C)) {
-            const int rc = bn_launch_bn_act_bwd_chunks(x, y, dy, mean, invstd, gamma, dx, dgamma, dbeta,
+            const int rc = bn_launch_bn_act_bwd_chunks(x, y, dy, mean, invstd, gamma, beta, dx, dgamma, dbeta,
                                                        accumulate, bounds, n_chunks, C, HW, act, slope, ws, st);
             if (rc != BN_E_SHAPE) return rc;
         }
     }
     for (int i = 0; i < n_chunks; ++i) {
-        const int b = bounds[2 * i], n = bounds[2 * i + 1] - b;
-        if (n <= 0 || b < 0) return BN_E_BADARG;
-        if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(n, C)) return BN_E_WORKSPACE;
-        const size_t o = (size_t)b * C * HW;
-        const int rc = bn_launch_bn_act_bwd(x + o, y + o, dy + o, mean + (size_t)i * C, invstd + (size_t)i * C,
-                                            gamma, dx + o, dgamma, dbeta, (accumulate || i > 0) ? 1 : 0, 1, n,
-                                            C, HW, act, slope, ws, st);
+        const int bi[2] = {0, bounds[2 * i + 1] - bounds[2 * i]};
+        if (bi[1] <= 0 || bounds[2 * i] < 0) return BN_E_BADARG;
+        if (!ws || ws_bytes < bn_batchnorm_ws_bytes_impl(bi[1], C)) return BN_E_WORKSPACE;
+        const size_t o = (size_t)bounds[2 * i] * C * HW;
+        const int rc = bn_launch_bn_act_bwd_chunks(x + o, y ? y + o : nullptr, dy + o, mean + (size_t)i * C,
+                                                   invstd + (size_t)i * C, gamma, beta, dx + o, dgamma, dbeta,
+                                                   (accumulate || i > 0) ? 1 : 0, bi, 1, C, HW, act, slope, ws,
+                                                   st);
         if (rc) return rc;
     }
     return 0;

@@ -699,18 +699,20 @@ class bn_chunks(object):
 
 
 def _batches_tracked(module, added=1):
-    """``int(module.num_batches_tracked)`` after this node's in-place add, without reading the
-    device counter back every step (momentum=None, the reference's default: the cumulative-average
-    factor is 1 / count -- nine host synchronisations per training step otherwise).  A host
-    mirror follows the counter; it is re-read from the device whenever something else has touched
-    the tensor (load_state_dict, a new tensor, a reset)."""
+    """``int(module.num_batches_tracked)`` BEFORE this node's update, without reading the device
+    counter back every step (momentum=None, the reference's default: the cumulative-average factor
+    is 1 / count -- nine host synchronisations per training step otherwise).  The counter itself is
+    advanced by ``added`` on the device by the statistics kernel (round 4: it was two torch
+    element-wise launches per layer); a host mirror follows it and is re-read from the device
+    whenever something else has touched the tensor (load_state_dict, a new tensor, a reset)."""
     t = module.num_batches_tracked
     mirror = getattr(module, '_bn_count_mirror', None)
-    if mirror is not None and mirror[0] is t and mirror[1] == t._version - 1:
-        value = mirror[2] + added
+    if mirror is not None and mirror[0] is t and mirror[1] == t._version:
+        value = mirror[2]
     else:
         value = int(t.item())
-    module._bn_count_mirror = (t, t._version, value)
+    # (the kernel's in-place add does not move torch's version counter)
+    module._bn_count_mirror = (t, t._version, value + added)
     return value
 
 
@@ -730,52 +732,59 @@ class BatchNormActFn(torch.autograd.Function):
         rm, rv = module.running_mean, module.running_var
         batch_stats = module.training or rm is None
         if batch_stats:
-            factor = 0.0
-            if module.training and module.track_running_stats and rm is not None:
-                module.num_batches_tracked.add_(1)
-                if module.momentum is None:
-                    factor = 1.0 / float(_batches_tracked(module))
-                else:
-                    factor = float(module.momentum)
-            else:
-                rm = rv = None
             from behavenet_amd.fitting import distributed as bdist
             ctx.sync_count = None
             ctx.chunks = None
+            tracking = module.training and module.track_running_stats and rm is not None
+            if not tracking:
+                rm = rv = None
             if bdist.frames_sharded():
                 # the chunk's frames are spread over the ranks: statistics over all of them
                 # (per-channel sums all-reduced), as the single device sees them
                 if bdist._emulated is not None:
                     raise RuntimeError('batch-norm statistics need the other ranks\' frames: '
                                        'not available under emulate_rank')
+                factor = 0.0
+                if tracking:
+                    if module.momentum is None:
+                        factor = 1.0 / float(_batches_tracked(module, 1) + 1)
+                    else:
+                        factor = float(module.momentum)
+                    module.num_batches_tracked.add_(1)
+                    mirror = getattr(module, '_bn_count_mirror', None)
+                    if mirror is not None and module.momentum is None:
+                        # (torch's add_ moved the version counter: the mirror stays valid)
+                        t = module.num_batches_tracked
+                        module._bn_count_mirror = (t, t._version, mirror[2])
+                    else:
+                        module._bn_count_mirror = None
                 y, mean, invstd, ctx.sync_count = _hip.batchnorm_sync_train_fwd(
                     x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE,
                     bdist.all_reduce_)
-            elif _bn_bounds is not None:
-                if x.shape[0] != _bn_bounds[-1][1]:
+            else:
+                bounds = _bn_bounds if _bn_bounds is not None else [(0, int(x.shape[0]))]
+                if x.shape[0] != bounds[-1][1]:
                     # whole-batch statistics here would silently differ from the reference's
                     # per-chunk ones (and advance num_batches_tracked by 1 instead of n_chunks)
                     raise RuntimeError(
                         'batch norm inside bn_chunks(%s): the input has %d frames, the chunk '
-                        'bounds cover %d' % (_bn_bounds, x.shape[0], _bn_bounds[-1][1]))
+                        'bounds cover %d' % (bounds, x.shape[0], bounds[-1][1]))
                 # one pass over the whole batch, statistics per chunk (in chunk order: the
-                # running estimates see the same sequence of updates as in the reference)
-                k = len(_bn_bounds)
-                factors = [factor] * k
-                if rm is not None and k > 1:
-                    # (the first chunk's count was added above)
+                # running estimates see the same sequence of updates as in the reference); the
+                # device counter advances by the number of chunks inside the same library call
+                k = len(bounds)
+                factors = [0.0] * k
+                if tracking:
                     if module.momentum is None:
-                        first = 1.0 / factor
+                        first = _batches_tracked(module, k) + 1
                         factors = [1.0 / (first + i) for i in range(k)]
-                    module.num_batches_tracked.add_(k - 1)
-                    if module.momentum is None:
-                        _batches_tracked(module, k - 1)
+                    else:
+                        factors = [float(module.momentum)] * k
+                        module._bn_count_mirror = None
                 y, mean, invstd = _hip.batchnorm_train_fwd_chunks(
-                    x, g, b, rm, rv, factors, float(module.eps), act, LRELU_SLOPE, _bn_bounds)
-                ctx.chunks = list(_bn_bounds)
-            else:
-                y, mean, invstd = _hip.batchnorm_train_fwd(
-                    x, g, b, rm, rv, factor, float(module.eps), act, LRELU_SLOPE)
+                    x, g, b, rm, rv, factors, float(module.eps), act, LRELU_SLOPE, bounds,
+                    num_batches_tracked=module.num_batches_tracked if tracking else None)
+                ctx.chunks = list(bounds)
         else:
             ctx.sync_count = None
             ctx.chunks = None
@@ -786,12 +795,23 @@ class BatchNormActFn(torch.autograd.Function):
         ctx.batch_stats = bool(batch_stats)
         ctx.act = act
         ctx.param_refs = (gamma, beta)
-        ctx.save_for_backward(x, y, mean, invstd, g)
+        # the chunked backward rebuilds the sign of the activation's input from x (identity /
+        # LeakyReLU): y is not kept for it
+        ctx.from_x = ctx.chunks is not None and act in (_hip.ACT_NONE, _hip.ACT_LRELU)
+        ctx.beta = b
+        if ctx.from_x:
+            ctx.save_for_backward(x, mean, invstd, g)
+        else:
+            ctx.save_for_backward(x, y, mean, invstd, g)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, mean, invstd, g = ctx.saved_tensors
+        if ctx.from_x:
+            x, mean, invstd, g = ctx.saved_tensors
+            y = None
+        else:
+            x, y, mean, invstd, g = ctx.saved_tensors
         gamma, beta = ctx.param_refs
         need_g = gamma is not None and ctx.needs_input_grad[1]
         need_b = beta is not None and ctx.needs_input_grad[2]
@@ -821,7 +841,7 @@ class BatchNormActFn(torch.autograd.Function):
                 dgamma = torch.zeros_like(mean[0]) if need_g else None
                 dbeta = torch.zeros_like(mean[0]) if need_b else None
             dx = _hip.batchnorm_bwd_chunks(x, y, dy, mean, invstd, g, dgamma, dbeta, True, ctx.act,
-                                           LRELU_SLOPE, chunks)
+                                           LRELU_SLOPE, chunks, beta=ctx.beta)
             if direct:
                 dgamma = dbeta = None
             return (dx if ctx.needs_input_grad[0] else None), dgamma, dbeta, None, None

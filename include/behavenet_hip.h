@@ -180,17 +180,23 @@ int bn_batchnorm_act_bwd(const float* x, const float* y, const float* dy, const 
  * bounds[2i+1]) of x, in order -- the reference runs its 200-frame chunks one after another through
  * nn.BatchNorm2d, aes.py:748-771 with :90-97): one call per layer.  mean / invstd: [n_chunks][C];
  * factors[i]: the running-estimate factor of chunk i's update (momentum, or 1 / num_batches_tracked);
- * bounds, factors: host arrays.  ws: bn_batchnorm_ws_bytes(largest chunk, C). */
+ * bounds, factors: host arrays.  ws: bn_batchnorm_ws_bytes(largest chunk, C).
+ * Round 4: both moments in ONE pass over x (shifted sums around the chunk's first value of the channel),
+ * one small launch for mean / invstd / the running estimates / the device counter
+ * num_batches_tracked (+= n_chunks; NULL: none, nn.BatchNorm2d's int64 buffer); the backward pass with
+ * y == NULL (identity / LeakyReLU) rebuilds the sign of the activation's input from x through
+ * (gamma, beta) with the forward pass's own fused multiply-adds instead of reading y back. */
 int bn_batchnorm_train_fwd_chunks(const float* x, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, float* y, float* mean,
+                                  float* running_mean, float* running_var,
+                                  long long* num_batches_tracked, float* y, float* mean,
                                   float* invstd, const int* bounds, const float* factors,
                                   int n_chunks, int C, int HW, float eps, int act, float slope,
                                   void* ws, size_t ws_bytes, bn_stream_t stream);
 int bn_batchnorm_act_bwd_chunks(const float* x, const float* y, const float* dy, const float* mean,
-                                const float* invstd, const float* gamma, float* dx, float* dgamma,
-                                float* dbeta, int accumulate, const int* bounds, int n_chunks,
-                                int C, int HW, int act, float slope, void* ws, size_t ws_bytes,
-                                bn_stream_t stream);
+                                const float* invstd, const float* gamma, const float* beta,
+                                float* dx, float* dgamma, float* dbeta, int accumulate,
+                                const int* bounds, int n_chunks, int C, int HW, int act, float slope,
+                                void* ws, size_t ws_bytes, bn_stream_t stream);
 
 /* Split forms of the two reductions above for statistics taken over ALL ranks' frames (frame-sharded
  * data parallelism; the reference's single-device nn.BatchNorm2d sees the whole chunk, aes.py:90-97):

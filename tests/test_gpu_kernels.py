@@ -410,6 +410,36 @@ def test_batchnorm_act(case, act):
     assert int(mh.num_batches_tracked) == int(mods['f32'].num_batches_tracked)
 
 
+@pytest.mark.parametrize('offset,spread', [(3.0, 0.05), (-40.0, 0.5), (0.0, 1e-3)])
+def test_batchnorm_one_pass_statistics_are_well_conditioned(offset, spread):
+    """Round 4: both moments in one pass (sums shifted by the chunk's first value of the channel).
+    Channels whose mean is many standard deviations away from zero -- where E[x^2] - mean^2 loses
+    everything -- against a float64 nn.BatchNorm2d, two chunks with their own statistics."""
+    from behavenet_amd.hip_functions import BatchNormActFn, bn_chunks
+    N, C, H, W = 24, 16, 16, 12
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((N, C, H, W), generator=g) * spread + offset
+    gy = torch.randn((N, C, H, W), generator=g)
+    bounds = [(0, 17), (17, 24)]
+    outs = {}
+    for key, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        m = torch.nn.BatchNorm2d(C, momentum=None).to(dt).train()
+        xi = x.detach().clone().to(dt).requires_grad_(True)
+        y = torch.cat([F.leaky_relu(m(xi[b:e]), SLOPE) for b, e in bounds])
+        y.backward(gy.to(dt))
+        outs[key] = (y, xi.grad, m)
+    mh = torch.nn.BatchNorm2d(C, momentum=None).to(DEV).train()
+    xh = x.detach().clone().to(DEV).requires_grad_(True)
+    with bn_chunks(bounds):
+        yh = BatchNormActFn.apply(xh, mh.weight, mh.bias, mh, _hip.ACT_LRELU)
+    yh.backward(gy.to(DEV))
+    close(yh, outs['f32'][0], outs['f64'][0], name='bn y')
+    close(xh.grad, outs['f32'][1], outs['f64'][1], name='bn dx')
+    close(mh.running_mean, outs['f32'][2].running_mean, outs['f64'][2].running_mean, name='bn rmean')
+    close(mh.running_var, outs['f32'][2].running_var, outs['f64'][2].running_var, name='bn rvar')
+    assert int(mh.num_batches_tracked) == 2
+
+
 @pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_SIGMOID, _hip.ACT_NONE])
 def test_act_bwd(act):
     g = torch.Generator().manual_seed(0)
