@@ -41,6 +41,8 @@ struct BnGeom {
                       // a wider tensor (0 = Cs: contiguous).  Honoured by the single-channel edge kernels
                       // that serve channel groups in place (k_down_c1p, k_down_c1s, k_wgrad_c1d); every
                       // other kernel requires 0.
+    int KV;           // 5x5 taps zero-extended from a smaller kernel (capi.hip, taps_plan): taps with r >= KV
+                      // or s >= KV are zero and the stride-2 families skip their products (0 = all 25)
 };
 static inline __host__ __device__ int bn_cs_stride(const BnGeom& g) { return g.CsS > 0 ? g.CsS : g.Cs; }
 

@@ -184,14 +184,14 @@ static inline BnGeom conv_geom(int N, int C, int H, int W, int K, int R, int S, 
                                int pad_t, int pad_l, int P, int Q) {
     BnGeom g;
     g.N = N; g.Cs = K; g.Hs = P; g.Ws = Q; g.Cb = C; g.Hb = H; g.Wb = W;
-    g.R = R; g.S = S; g.stride = stride; g.pt = pad_t; g.pl = pad_l; g.CsS = 0;
+    g.R = R; g.S = S; g.stride = stride; g.pt = pad_t; g.pl = pad_l; g.CsS = 0; g.KV = 0;
     return g;
 }
 static inline BnGeom convT_geom(int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                                 int crop_t, int crop_l, int Ho, int Wo) {
     BnGeom g;
     g.N = N; g.Cs = Ci; g.Hs = Hi; g.Ws = Wi; g.Cb = Co; g.Hb = Ho; g.Wb = Wo;
-    g.R = R; g.S = S; g.stride = stride; g.pt = crop_t; g.pl = crop_l; g.CsS = 0;
+    g.R = R; g.S = S; g.stride = stride; g.pt = crop_t; g.pl = crop_l; g.CsS = 0; g.KV = 0;
     return g;
 }
 
@@ -421,6 +421,8 @@ static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
     if (g.R < 2 || g.S < 2) return false;
     *g5 = g;
     g5->R = g5->S = 5;
+    // stride 2: the fifth row and column of taps are zeros the 16-byte-DMA kernels need not multiply
+    g5->KV = (g.stride == 2 && g.R <= 4 && g.S <= 4) ? 4 : 0;
     return served_fast(role, *g5);
 }
 static inline size_t taps_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * 25 * sizeof(float)); }

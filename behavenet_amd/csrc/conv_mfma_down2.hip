@@ -64,7 +64,9 @@ struct Down2Tile {
     float inv_chs4, inv_fs4, inv_c4;
 };
 
-template <int MR, int NR>
+// KV = 4: the 5x5 taps are a smaller kernel zero-extended (BnGeom::KV): rows / columns of taps from KV on
+// are neither read nor multiplied (a 4x4 layer: 16 of 25 products); LDS layouts stay the 5x5 ones
+template <int MR, int NR, int KV>
 __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, Down2Tile t, int act,
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
 #define D2_MARK(slot)
 #endif
     constexpr int CC = D2_CC, R = 5, S = 5, RS = 25;
+    constexpr int RE = KV, SE = KV;                   // rows / columns of taps that are multiplied
     constexpr int TM = 32 * MR;
     constexpr int WS = CC * RS;                       // weight row of one output channel (100 words)
     constexpr int WG = TM * WS / 4;                   // 16-byte groups of the weight slice
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     // `ds_read vaddr offset:imm` only: the image rows of (pixel block, channel pair, kernel row)
     // each have an address register, the second LDS image lies a compile-time distance behind the
     // first, and the weight reads share one lane base.
-    constexpr int NIT = (CC / 2) * R;
+    constexpr int NIT = (CC / 2) * RE;
     // (ds_read2 offsets reach 255 words / double words only: one register per image and per
     // 32-channel weight block, so that no read needs an address add; the asm keeps the compiler
     // from re-deriving them from one another with an add in front of every read)
@@ -230,27 +233,33 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     // double buffered.  The reads of row i+1 are cut into U units of one LDS instruction each and
     // placed by hand between the MFMAs of row i; sched_barrier pins that order (the scheduler's
     // own interleaving put dependent MFMAs back to back).
-    constexpr int NM = S * MR * NR;                  // MFMAs per row
-    constexpr int NU = 3 * MR + 2 * NR;              // read units per row
+    constexpr int NM = SE * MR * NR;                 // MFMAs per row
+    constexpr int WU = SE == 5 ? 3 : 2;              // weight read units per 32-channel block
+    constexpr int NU = WU * MR + 2 * NR;             // read units per row
     static_assert(NU <= NM, "one read unit per MFMA at most");
     auto load_unit = [&](const int BUF, const int it, const int u, float (&a)[S][MR],
                          float (&bq)[S][NR]) __attribute__((always_inline)) {
-        const int cp = it / R, r = it - cp * R;
-        if (u < 3 * MR) {
-            const int mr = u / 3, k = u - 3 * mr;
+        const int cp = it / RE, r = it - cp * RE;
+        if (u < WU * MR) {
+            const int mr = u / WU, k = u - WU * mr;
             const float* wp = smem + wao[mr] + (2 * cp) * RS + r * S;
             if (k == 0) { a[0][mr] = wp[0]; a[1][mr] = wp[1]; }
             else if (k == 1) { a[2][mr] = wp[2]; a[3][mr] = wp[3]; }
             else a[4][mr] = wp[4];
         } else {
             // columns 2q-1 .. 2q+3 = words 1..5 of the aligned six-word run
-            const int v = u - 3 * MR, nr = v / 2;
+            const int v = u - WU * MR, nr = v / 2;
             const float* xb = smem + xro[BUF][nr][cp][r];
             if ((v & 1) == 0) bq[0][nr] = xb[1];
             else {
                 const floatx2d c1p = *reinterpret_cast<const floatx2d*>(xb + 2);
-                const floatx2d c2p = *reinterpret_cast<const floatx2d*>(xb + 4);
-                bq[1][nr] = c1p.x; bq[2][nr] = c1p.y; bq[3][nr] = c2p.x; bq[4][nr] = c2p.y;
+                bq[1][nr] = c1p.x; bq[2][nr] = c1p.y;
+                if (SE == 5) {
+                    const floatx2d c2p = *reinterpret_cast<const floatx2d*>(xb + 4);
+                    bq[3][nr] = c2p.x; bq[4][nr] = c2p.y;
+                } else {
+                    bq[3][nr] = xb[4];
+                }
             }
         }
     };
@@ -452,18 +461,18 @@ bool bn_down2_supported(const BnGeom& g, int MR, int NR) {
     return down2_tile(g, MR, NR, &t, &lds);
 }
 
-template <int MR, int NR>
+template <int MR, int NR, int KV>
 static int launch_down2(const Down2Tile& t, dim3 grid, size_t lds, const float* big, const float* w,
                         const float* bias, float* out, const float* dact_src, const BnGeom& g,
                         int act, int dact, float slope, hipStream_t st, int cper, size_t zstride) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_down2_mfma<MR, NR>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_down2_mfma<MR, NR, KV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, D2_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    BN_LAUNCH_MAIN((k_down2_mfma<MR, NR>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
+    BN_LAUNCH_MAIN((k_down2_mfma<MR, NR, KV>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
                        dact_src, g, t, act, dact, slope, cper, zstride);
     BN_LAUNCH_CHECK();
     return 0;
@@ -510,12 +519,13 @@ int bn_launch_down2(int MR, int NR, const float* big, const float* w, const floa
     const int cper = g.Cb / splits;
     const size_t zs = splits > 1 ? total : 0;
     int rc = BN_E_SHAPE;
-    if (MR == 2 && NR == 2)
-        rc = launch_down2<2, 2>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
-    else if (MR == 2 && NR == 1)
-        rc = launch_down2<2, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
-    else if (MR == 1 && NR == 1)
-        rc = launch_down2<1, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
+    const bool k4 = g.KV == 4;
+#define D2_CASE(mr, nr)                                                                                       \
+    if (MR == mr && NR == nr)                                                                                 \
+        rc = k4 ? launch_down2<mr, nr, 4>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs)   \
+                : launch_down2<mr, nr, 5>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
+    D2_CASE(2, 2) D2_CASE(2, 1) D2_CASE(1, 1)
+#undef D2_CASE
     if (rc || splits == 1) return rc;
     return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cs,
                                     g.Hs * g.Ws, act, dact, slope, st);

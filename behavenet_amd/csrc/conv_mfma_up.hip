@@ -264,7 +264,9 @@ __device__ __forceinline__ void up_dma4(__amdgpu_buffer_rsrc_t rsrc, float* lds,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 4, voffset, soffset, 0, 0);
 }
 
-template <int LGW, int CC>
+// KV = 4: taps with r >= 4 or s >= 4 are zeros (BnGeom::KV, a 4x4 layer on 5x5 taps): neither read nor
+// multiplied -- 16 of the 25 products of a channel pair; the slots of the issue order keep their places
+template <int LGW, int CC, int KV>
 __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, int act, int dact,
@@ -421,16 +423,21 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
 #pragma unroll
         for (int i = 0; i < 9; ++i) load_b(xb, xu, xd, 0, i, bv[0]);
 #pragma unroll
-        for (int j = 0; j < 25; ++j) load_a(wa, 0, j, av);
+        for (int j = 0; j < 25; ++j) {
+            const Tap t0 = tap_of(ORDER[j]);
+            if (t0.r < KV && t0.s < KV) load_a(wa, 0, j, av);
+        }
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp) {
 #pragma unroll
             for (int j = 0; j < 25; ++j) {
                 const Tap tp = tap_of(ORDER[j]);
-                acc[tp.cl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ORDER[j]], bv[cp & 1][tp.dy * 3 + tp.dx],
-                                                                  acc[tp.cl], 0, 0, 0);
+                const bool live = tp.r < KV && tp.s < KV;
+                if (live)
+                    acc[tp.cl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ORDER[j]], bv[cp & 1][tp.dy * 3 + tp.dx],
+                                                                      acc[tp.cl], 0, 0, 0);
                 if (cp + 1 < CC / 2) {
-                    load_a(wa, cp + 1, j, av);                       // refresh in place
+                    if (live) load_a(wa, cp + 1, j, av);             // refresh in place
                     if (j >= 8 && j < 17) load_b(xb, xu, xd, cp + 1, j - 8, bv[(cp + 1) & 1]);
                 }
                 // the next chunk's DMA rides in this wave's own MFMA stream, one instruction per slot
@@ -605,7 +612,7 @@ static int up2_splits(const BnGeom& g, int lgw, int cc) {
     return s > 8 ? 8 : (s < 1 ? 1 : s);
 }
 
-template <int LGW, int CC>
+template <int LGW, int CC, int KV>
 static int launch_up2(const float* small, const float* w, const float* bias, float* out,
                       const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                       hipStream_t st, int splits, void* ws) {
@@ -614,7 +621,7 @@ static int launch_up2(const float* small, const float* w, const float* bias, flo
     constexpr size_t lds = ((size_t)2 * CC * T::CHSP + (size_t)2 * WDMA * MF_THREADS * 4) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_up2_mfma<LGW, CC>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_up2_mfma<LGW, CC, KV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -624,20 +631,20 @@ static int launch_up2(const float* small, const float* w, const float* bias, flo
     if (splits > 1) {
         if (!ws) return BN_E_WORKSPACE;
         const size_t total = (size_t)g.N * g.Cb * g.Hb * g.Wb;
-        BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w,
+        BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC, KV>), grid, dim3(MF_THREADS), lds, st, small, w,
                        (const float*)nullptr, (float*)ws, (const float*)nullptr, g, BN_ACT_NONE,
                        BN_ACT_NONE, slope, g.Cs / splits, total, Up2Geo{});
         BN_LAUNCH_CHECK();
         return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cb,
                                         g.Hb * g.Wb, act, dact, slope, st);
     }
-    BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+    BN_LAUNCH_MAIN((k_up2_mfma<LGW, CC, KV>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                        dact_src, g, act, dact, slope, g.Cs, (size_t)0, Up2Geo{});
     BN_LAUNCH_CHECK();
     return 0;
 }
 
-// ---- runtime tile geometry (k_up2_mfma<0, CC>): maps that are no power-of-two squares ----------
+// ---- runtime tile geometry (k_up2_mfma<0, CC, KV>): maps that are no power-of-two squares ----------
 // tile = F whole frames, or AT_H rows of one frame (rows spread evenly over a frame's tiles), at most 128
 // positions and 256 elements of the haloed LDS image
 static bool up2g_geo(const BnGeom& g, Up2Geo* t) {
@@ -674,6 +681,7 @@ static int up2g_splits(const BnGeom& g, const Up2Geo& t, int cc) {
     return s > 8 ? 8 : (s < 1 ? 1 : s);
 }
 
+template <int KV>
 static int launch_up2g(const float* small, const float* w, const float* bias, float* out,
                        const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                        hipStream_t st, int splits, void* ws) {
@@ -684,7 +692,7 @@ static int launch_up2g(const float* small, const float* w, const float* bias, fl
     constexpr size_t lds = ((size_t)2 * CC * UP2<0>::CHSP + (size_t)2 * WDMA * MF_THREADS * 4) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_up2_mfma<0, CC>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_up2_mfma<0, CC, KV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -694,14 +702,14 @@ static int launch_up2g(const float* small, const float* w, const float* bias, fl
     if (splits > 1) {
         if (!ws) return BN_E_WORKSPACE;
         const size_t total = (size_t)g.N * g.Cb * g.Hb * g.Wb;
-        BN_LAUNCH_MAIN((k_up2_mfma<0, CC>), grid, dim3(MF_THREADS), lds, st, small, w,
+        BN_LAUNCH_MAIN((k_up2_mfma<0, CC, KV>), grid, dim3(MF_THREADS), lds, st, small, w,
                        (const float*)nullptr, (float*)ws, (const float*)nullptr, g, BN_ACT_NONE,
                        BN_ACT_NONE, slope, g.Cs / splits, total, t);
         BN_LAUNCH_CHECK();
         return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cb,
                                         g.Hb * g.Wb, act, dact, slope, st);
     }
-    BN_LAUNCH_MAIN((k_up2_mfma<0, CC>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+    BN_LAUNCH_MAIN((k_up2_mfma<0, CC, KV>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                        dact_src, g, act, dact, slope, g.Cs, (size_t)0, t);
     BN_LAUNCH_CHECK();
     return 0;
@@ -759,13 +767,20 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
                       int act, int dact, float slope, void* ws, hipStream_t st) {
     const int MR = plan.a, CC = plan.c;
     if (plan.variant == 3)
-        return launch_up2g(small, w, bias, out, dact_src, g, act, dact, slope, st, plan.d > 1 ? plan.d : 1, ws);
+        return g.KV == 4
+            ? launch_up2g<4>(small, w, bias, out, dact_src, g, act, dact, slope, st, plan.d > 1 ? plan.d : 1, ws)
+            : launch_up2g<5>(small, w, bias, out, dact_src, g, act, dact, slope, st, plan.d > 1 ? plan.d : 1, ws);
     if (plan.variant == 2) {
         const int lgw = ilog2_exact_up(g.Ws);
         const int splits = plan.d > 1 ? plan.d : 1;
 #define UP2_CASE(L, C)                                                                          \
     if (lgw == L && CC == C)                                                                    \
-        return launch_up2<L, C>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws);
+        return launch_up2<L, C, 5>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws);
+#define UP2_CASE4(L)                                                                            \
+    if (lgw == L && CC == 4 && g.KV == 4)                                                       \
+        return launch_up2<L, 4, 4>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws);
+        UP2_CASE4(3) UP2_CASE4(4) UP2_CASE4(5)
+#undef UP2_CASE4
         UP2_CASE(3, 4) UP2_CASE(4, 4) UP2_CASE(5, 4) UP2_CASE(3, 8) UP2_CASE(4, 8) UP2_CASE(5, 8)
 #undef UP2_CASE
         return BN_E_SHAPE;

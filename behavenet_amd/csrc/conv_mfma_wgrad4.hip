@@ -252,7 +252,9 @@ __device__ __forceinline__ void w4_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 // the magic multiplier 2^32 / tiles + 1 of the stage -> frame division), a frame's last stage may hang
 // over its lower edge: the small rows below the map and the big rows below it are left out of the DMA
 // (out-of-range source offset = 0.0f) by a per-group row number against a per-stage scalar limit.
-template <int QQ, int BIAS, bool GEN>
+// KV = 4: taps with r >= 4 or s >= 4 belong to the zero extension of a smaller kernel (BnGeom::KV): their
+// products are skipped and their (zero) tiles are dropped again by the caller's crop of dW
+template <int QQ, int BIAS, bool GEN, int KV>
 __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
     float* __restrict__ bias_part, BnGeom g, int n_stages, int splits, int lg_tpf, int nbias) {
@@ -386,7 +388,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
 #pragma unroll
             for (int tp = 0; tp < 25; ++tp) {
                 const int r = tp / 5, sx = tp - 5 * r;
-                acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1], bv[tp], acc[tp], 0, 0, 0);
+                if (r < KV && sx < KV)
+                    acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1], bv[tp], acc[tp], 0, 0, 0);
                 // bias side 2: taps (1,1) (1,2), then (2,1) (2,2), right behind their last MFMA
                 if (BIAS == 2 && tp == 7) bsum += bv[6] + bv[7];
                 if (BIAS == 2 && tp == 12) bsum += bv[11] + bv[12];
@@ -601,19 +604,19 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
     return 0;
 }
 
-template <int Q, int BIAS, bool GEN>
+template <int Q, int BIAS, bool GEN, int KV>
 static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const float* big,
                           float* part, float* bias_part, const BnGeom& g, int n_stages, int splits,
                           int lg_tpf, int nbias) {
     static_assert((size_t)2 * W4S<Q>::BUFW * 4 <= W4_MAX_LDS, "two stage images in LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, W4_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN>), grid, dim3(W4_THREADS),
+    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV>), grid, dim3(W4_THREADS),
                        (size_t)2 * W4S<Q>::BUFW * 4, st, small, big, part, bias_part, g, n_stages,
                        splits, lg_tpf, nbias);
     BN_LAUNCH_CHECK();
@@ -648,7 +651,7 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);
 #define W4G_CASE(QV, B)                                                                          \
     if (g.Ws == QV && t.bias_side == B)                                                          \
-        rc = launch_wgrad4s<QV, B, true>(grid, st, small, big, (float*)ws, bias_part, g,         \
+        rc = launch_wgrad4s<QV, B, true, 5>(grid, st, small, big, (float*)ws, bias_part, g,      \
                                          t.n_stages, t.splits, magic, t.nbias);
 #define W4G_ALL(QV) W4G_CASE(QV, 0) W4G_CASE(QV, 1)
         W4G_ALL(8) W4G_ALL(12) W4G_ALL(16) W4G_ALL(20) W4G_ALL(24) W4G_ALL(28) W4G_ALL(32) W4G_ALL(36)
@@ -659,8 +662,11 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         const int lgq = ilog2_exact_w4(g.Ws), lg_tpf = ilog2_exact_w4(t.tiles_per_frame);
 #define W4S_CASE(L, B)                                                                         \
     if (lgq == L && t.bias_side == B)                                                          \
-        rc = launch_wgrad4s<(1 << L), B, false>(grid, st, small, big, (float*)ws, bias_part, g, \
-                                                t.n_stages, t.splits, lg_tpf, t.nbias);
+        rc = g.KV == 4                                                                         \
+            ? launch_wgrad4s<(1 << L), B, false, 4>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                    t.n_stages, t.splits, lg_tpf, t.nbias)     \
+            : launch_wgrad4s<(1 << L), B, false, 5>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                    t.n_stages, t.splits, lg_tpf, t.nbias);
         W4S_CASE(3, 0) W4S_CASE(3, 1) W4S_CASE(3, 2) W4S_CASE(4, 0) W4S_CASE(4, 1) W4S_CASE(4, 2)
         W4S_CASE(5, 0) W4S_CASE(5, 1) W4S_CASE(5, 2)
 #undef W4S_CASE
