@@ -137,6 +137,7 @@ int bn_launch_col_wgrad(const float* small, const float* big, float* dw, const B
                         bool* bias_done);
 // kernels smaller than 5x5 embedded in 5x5 taps (weights [pairs][R][S] <-> [pairs][5][5])
 int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hipStream_t st);
+int bn_launch_flip_taps(const float* w, float* wf, int Cs, int Cb, int RS, hipStream_t st);
 int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S, int accumulate,
                         hipStream_t st, const float* db5 = nullptr, float* db = nullptr, int nb = 0);
 bool bn_s5_down_small_ok(const BnGeom& g);

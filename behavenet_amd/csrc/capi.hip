@@ -388,6 +388,7 @@ static inline size_t tile_ws_bytes(const TilePlan& p) { return p.big_bytes + p.s
 // ---- kernels smaller than 5x5 with stride 2 (ae_arch_2.json: 4x4): 5x5 taps, the added ones zero
 static size_t role_ws_need(int role, const BnGeom& g);
 static bool served_fast(int role, const BnGeom& g);
+static bool flip_plan(const BnGeom& g, BnGeom* gf, BnFastPlan* inner);
 // ---- single- / two-channel edge layers with more than 32 channels on the other side (1 -> 64):
 // groups of 32 small-side channels on contiguous copies (gather-down, weight gradient)
 static bool chan_plan(int role, const BnGeom& g, BnGeom* gg) {
@@ -410,6 +411,11 @@ static bool served_fast(int role, const BnGeom& g) {
     const BnFastPlan pl = role == 0 ? bn_fast_down_plan(g) : role == 1 ? bn_fast_up_plan(g)
                                                                       : bn_fast_wgrad_plan(g);
     if (pl.supported) return true;
+    if (role == 1) {
+        BnGeom gf;
+        BnFastPlan in;
+        if (flip_plan(g, &gf, &in)) return true;
+    }
     return pad_plan(role, g).ok || tile_plan(role, g).ok;
 }
 static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
@@ -417,7 +423,7 @@ static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
     // kernel is instantiated for 3x3 and 5x5 -- a 4x4 layer becomes a 5x5 one where that kernel serves it)
     if (force_generic() || (g.stride != 2 && g.stride != 1) || g.R > 5 || g.S > 5 || (g.R == 5 && g.S == 5))
         return false;
-    if (g.stride == 1 && g.R == 3 && g.S == 3) return false;      // served as it is
+    if (g.stride == 1 && g.R == 3 && g.S == 3 && role != 2) return false;      // served as it is
     if (g.R < 2 || g.S < 2) return false;
     *g5 = g;
     g5->R = g5->S = 5;
@@ -426,6 +432,20 @@ static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
     return served_fast(role, *g5);
 }
 static inline size_t taps_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * 25 * sizeof(float)); }
+
+// ---- stride-1 gather-up (transposed-conv forward, conv data gradient) as a gather-down with the channel
+// roles swapped and the taps reversed (conv_pad.hip, k_flip_taps): no im2col / col2im
+static bool flip_plan(const BnGeom& g, BnGeom* gf, BnFastPlan* inner) {
+    if (force_generic() || g.stride != 1 || g.R != g.S || (g.R != 3 && g.R != 5)) return false;
+    if (g.pt > g.R - 1 || g.pl > g.S - 1) return false;
+    *gf = g;
+    gf->Cs = g.Cb; gf->Hs = g.Hb; gf->Ws = g.Wb;
+    gf->Cb = g.Cs; gf->Hb = g.Hs; gf->Wb = g.Ws;
+    gf->pt = g.R - 1 - g.pt; gf->pl = g.S - 1 - g.pl;
+    *inner = bn_fast_down_plan(*gf);
+    return inner->supported;
+}
+static inline size_t flip_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * g.R * g.S * sizeof(float)); }
 
 static int run_down(int family, const float* big, const float* w, const float* bias, float* out,
                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
@@ -632,6 +652,23 @@ static int run_up(int family, const float* small, const float* w, const float* b
             return 0;
         }
     }
+    if (!generic && !plan.supported) {
+        BnGeom gf;
+        BnFastPlan in;
+        if (flip_plan(g, &gf, &in)) {
+            const size_t fb = flip_bytes(g);
+            if (!ws || ws_bytes < fb + in.ws_bytes) return BN_E_WORKSPACE;
+            static char names[4][96];
+            static int slot = 0;
+            char* nm = names[slot = (slot + 1) & 3];
+            snprintf(nm, 96, "%s on reversed taps", in.kernel_name);
+            BnProfScope prof(family, g.Cs, g.Cb, nm, st);
+            const int rc = bn_launch_flip_taps(w, (float*)ws, g.Cs, g.Cb, g.R * g.S, st);
+            if (rc) return rc;
+            return bn_launch_down_fast(in, small, (const float*)ws, bias, out, dact_src, gf, act, dact, slope,
+                                       (char*)ws + fb, st);
+        }
+    }
     if (!generic && !plan.supported && bn_col_ok(g)) {
         BnProfScope prof(family, g.Cs, g.Cb, "k_gemm_mfma + k_col2im", st);
         return bn_launch_col_up(small, w, bias, out, dact_src, g, act, dact, slope, ws, ws_bytes, st);
@@ -824,6 +861,11 @@ static size_t role_ws_need(int role, const BnGeom& g) {
         if (!plan.supported) plan = bn_fast_wgrad_plan(g);
     }
     if (plan.supported) return plan.ws_bytes;
+    if (role == 1) {
+        BnGeom gf;
+        BnFastPlan in;
+        if (flip_plan(g, &gf, &in)) return flip_bytes(g) + in.ws_bytes;
+    }
     if (role == 0 && bn_s5_down_small_ok(g)) return bn_s5_down_small_ws_bytes(g);
     const PadPlan pp = pad_plan(role, g);
     if (pp.ok) return pad_ws_bytes(pp);

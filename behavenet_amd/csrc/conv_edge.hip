@@ -38,13 +38,19 @@ __device__ __forceinline__ float ed_ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
 #define WC_IH (2 * WC_ROWS + 3)
 #define WC_RW (2 * WC_W + 4)            // big-tile row stride (131 used)
 #define WC_KS (32 * WC_TPX / ED_THREADS)            // 32 small elements per thread per stage
-#define WC_KB ((WC_IH * WC_RW + ED_THREADS - 1) / ED_THREADS)
 
+// ST = 1 (round 4): stride-1 layers with a single-channel side (the first / last layer of a max-pooling
+// architecture: im2col + a GEMM over 4 M rows before).  A frame's stages are blocks of 4 rows x 64
+// columns of the small map (any size: the blocks at the right and lower edge are masked), so the
+// same kernel serves maps wider than 64 columns.
+template <int ST>
 __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
-    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame) {
+    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame, int cblocks) {
+    constexpr int IH = ST * (WC_ROWS - 1) + 5, RW = ST * WC_W + 4;
+    constexpr int KB = (IH * RW + ED_THREADS - 1) / ED_THREADS;
     __shared__ float sl[32 * WC_SP];
-    __shared__ float bl[WC_IH * WC_RW];
+    __shared__ float bl[IH * RW];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
@@ -64,24 +70,27 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     float bsum = 0.f;
 
     float sr[WC_KS];
-    float br[WC_KB];
+    float br[KB];
 
     auto issue_loads = [&](int st) {
         const int n = st / stages_per_frame;
-        const int p0 = (st - n * stages_per_frame) * WC_ROWS;
+        const int rem = st - n * stages_per_frame;
+        const int rblk = rem / cblocks;
+        const int p0 = rblk * WC_ROWS, q00 = (rem - rblk * cblocks) * WC_W;
 #pragma unroll
         for (int k = 0; k < WC_KS; ++k) {
             const int e = tid + ED_THREADS * k;
             const int a = e >> 8, pix = e & (WC_TPX - 1);
-            const bool ok = a < g.Cs && (p0 + (pix >> 6)) < g.Hs;
-            sr[k] = ed_ld(rs, ok ? (((n * g.Cs + a) * g.Hs + p0) * g.Ws + pix) * 4 : ED_OOB);
+            const int row = p0 + (pix >> 6), col = q00 + (pix & (WC_W - 1));
+            const bool ok = a < g.Cs && row < g.Hs && col < g.Ws;
+            sr[k] = ed_ld(rs, ok ? (((n * g.Cs + a) * g.Hs + row) * g.Ws + col) * 4 : ED_OOB);
         }
 #pragma unroll
-        for (int k = 0; k < WC_KB; ++k) {
+        for (int k = 0; k < KB; ++k) {
             const int e = tid + ED_THREADS * k;
-            const int y = e / WC_RW, x = e - y * WC_RW;
-            const int hb = 2 * p0 - g.pt + y, wb = x - g.pl;
-            const bool ok = y < WC_IH && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+            const int y = e / RW, x = e - y * RW;
+            const int hb = ST * p0 - g.pt + y, wb = ST * q00 + x - g.pl;
+            const bool ok = y < IH && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
             br[k] = ed_ld(rb, ok ? (((n * g.Cb + bch) * g.Hb + hb) * g.Wb + wb) * 4 : ED_OOB);
         }
     };
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     // lane-constant part of the B gather: tap j = li -> (r, s); pixel (row wv, column 2t+kk)
     const int tap = li < 25 ? li : 0;
     const int tr = tap / 5, ts = tap - tr * 5;
-    const float* bq = bl + (2 * wv + tr) * WC_RW + ts + 2 * kk;
+    const float* bq = bl + (ST * wv + tr) * RW + ts + ST * kk;
     const float* aq = sl + li * WC_SP + wv * WC_W + kk;
 
     int st = blockIdx.x;
@@ -102,9 +111,9 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
             sl[(e >> 8) * WC_SP + (e & (WC_TPX - 1))] = sr[k];
         }
 #pragma unroll
-        for (int k = 0; k < WC_KB; ++k) {
+        for (int k = 0; k < KB; ++k) {
             const int e = tid + ED_THREADS * k;
-            if (e < WC_IH * WC_RW) bl[e] = br[k];
+            if (e < IH * RW) bl[e] = br[k];
         }
         __syncthreads();
         if (st + (int)gridDim.x < n_stages) issue_loads(st + gridDim.x);
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
         for (int t = 0; t < WC_W / 2; ++t) {
             const float av = aq[2 * t];
             if (bias_part) bsum += av;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[4 * t], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[2 * ST * t], acc, 0, 0, 0);
         }
     }
 
@@ -288,8 +297,10 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
     }
 }
 
+static inline int wgrad_c1_rblocks(const BnGeom& g) { return (g.Hs + WC_ROWS - 1) / WC_ROWS; }
+static inline int wgrad_c1_cblocks(const BnGeom& g) { return (g.Ws + WC_W - 1) / WC_W; }
 static int wgrad_c1_grid(const BnGeom& g) {
-    const int n_stages = g.N * (g.Hs / WC_ROWS);
+    const int n_stages = g.N * wgrad_c1_rblocks(g) * wgrad_c1_cblocks(g);
     // resident workgroups per CU in total: 3 (first generation), 2 (DMA generation: 79 KB of LDS)
     const int cap = ((g.pt == 1 && g.pl == 1) ? 512 : 768) / (g.Cb > 0 ? g.Cb : 1);
     return n_stages < cap ? n_stages : cap;
@@ -297,27 +308,40 @@ static int wgrad_c1_grid(const BnGeom& g) {
 
 BnFastPlan bn_edge_wgrad_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
-    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb > 4) return p;
-    if (g.Cs > 32 || g.Ws != WC_W || (g.Hs % WC_ROWS) != 0) return p;
-    if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
+    if (g.R != 5 || g.S != 5 || (g.stride != 2 && g.stride != 1) || g.Cb > 4) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
+    if (g.stride == 1) {
+        // stride 1 (round 4): any map size, offsets up to the kernel size, the first-generation kernel
+        if (g.Cs > 32 || g.pt > 4 || g.pl > 4 || (g.CsS > 0 && g.CsS != g.Cs)) return p;
+        p.supported = true;
+        p.variant = 1;
+        p.d = wgrad_c1_grid(g);
+        p.ws_bytes = ((size_t)g.Cb * p.d * g.Cs * 25 + (size_t)p.d * 32) * sizeof(float);
+        p.kernel_name = "k_wgrad_c1<1>";
+        return p;
+    }
+    if (g.Cs > 32 || g.Ws != WC_W || (g.Hs % WC_ROWS) != 0) return p;
+    if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     p.supported = true;
     p.d = wgrad_c1_grid(g);
     p.ws_bytes = ((size_t)g.Cb * p.d * g.Cs * 25 + (size_t)p.d * 32) * sizeof(float);
-    p.kernel_name = (g.pt == 1 && g.pl == 1) ? "k_wgrad_c1d" : "k_wgrad_c1";
+    p.kernel_name = (g.pt == 1 && g.pl == 1) ? "k_wgrad_c1d" : "k_wgrad_c1<2>";
     return p;
 }
 
 int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float* big, float* dw,
                          const BnGeom& g, int accumulate, void* ws, hipStream_t st, float* db,
                          int bias_side, bool* bias_done) {
-    const int n_stages = g.N * (g.Hs / WC_ROWS);
+    const int spf = wgrad_c1_rblocks(g) * wgrad_c1_cblocks(g), n_stages = g.N * spf;
     // Conv2d bias gradient (sum of the small side) as a by-product
     float* bias_part = (db && bias_side == 1)
         ? (float*)ws + (size_t)g.Cb * plan.d * g.Cs * 25 : nullptr;
     if (g.CsS > 0 && g.CsS != g.Cs && !(g.pt == 1 && g.pl == 1)) return BN_E_SHAPE;   // k_wgrad_c1d only
-    if (g.pt == 1 && g.pl == 1) {
+    if (g.stride == 1) {
+        BN_LAUNCH_MAIN(k_wgrad_c1<1>, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
+                           (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g));
+    } else if (g.pt == 1 && g.pl == 1) {
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e1 = hipFuncSetAttribute((const void*)k_wgrad_c1d<true>,
@@ -335,8 +359,8 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
             BN_LAUNCH_MAIN(k_wgrad_c1d<false>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
                                big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
     } else {
-        BN_LAUNCH_MAIN(k_wgrad_c1, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
-                           (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
+        BN_LAUNCH_MAIN(k_wgrad_c1<2>, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
+                           (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g));
     }
     BN_LAUNCH_CHECK();
     if (bias_part) {

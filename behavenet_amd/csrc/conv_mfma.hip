@@ -31,7 +31,7 @@ static inline int ilog2_exact(int v) {
 // owns NR pixel blocks and all MR channel blocks); pixels are F frames x PT_H rows x Q columns.
 // =============================================================================================
 struct DownTile {
-    int F, PT_H, lgQ, lgPTQ;
+    int F, PT_H, PTQ;                 // frames / small-map rows per workgroup tile, PT_H * Ws
     int IH, IWp, FS, CHS;
     int tiles_per_frame;
     int TMP;
@@ -75,12 +75,16 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_down_mfma(
     bool pvalid[NR];
 #pragma unroll
     for (int nr = 0; nr < NR; ++nr) {
-        const int pix = 32 * (wv * NR + nr) + li;
-        const int f = pix >> t.lgPTQ;
-        const int rem = pix & ((1 << t.lgPTQ) - 1);
-        const int pj = rem >> t.lgQ, qj = rem & (Q - 1);
+        // (maps that are no powers of two leave pixels of a tile without an output: they multiply the
+        // tile's first pixel and store nothing)
+        int pix = 32 * (wv * NR + nr) + li;
+        const bool inside = pix < t.F * t.PTQ;
+        if (!inside) pix = 0;
+        const int f = pix / t.PTQ;
+        const int rem = pix - f * t.PTQ;
+        const int pj = rem / Q, qj = rem - pj * Q;
         base[nr] = f * t.FS + (ST * pj) * t.IWp + ST * qj + kk * t.CHS;
-        pvalid[nr] = (n0 + f) < g.N;
+        pvalid[nr] = inside && (n0 + f) < g.N && (p0 + pj) < g.Hs;
         opix[nr] = (size_t)(n0 + f) * g.Cs * PQ + (size_t)(p0 + pj) * Q + qj;
     }
 
@@ -269,30 +273,35 @@ int bn_launch_split_epilogue(const float* part, const float* bias, float* out, c
 // ---------------------------------------------------------------------------------------------
 static bool down_tile(const BnGeom& g, int MR, int NR, int CC, DownTile* t, int* n_wg_xy) {
     const int TP = 128 * NR;
-    const int lgQ = ilog2_exact(g.Ws), lgP = ilog2_exact(g.Hs);
-    if (lgQ < 0 || lgP < 0) return false;
+    const bool pow2 = ilog2_exact(g.Ws) >= 0 && ilog2_exact(g.Hs) >= 0;
+    // maps that are no powers of two: stride 1 only (round 4; stride 2 has the second generation, the
+    // stride-5 layers their own families) -- a tile is F whole frames or PT_H rows of one, rows spread
+    // evenly over a frame's tiles, fewer of them until the tile fits LDS and the register budget
+    if (!pow2 && g.stride != 1) return false;
     const int PQ = g.Hs * g.Ws;
     if (g.Ws > TP) return false;
-    if (PQ >= TP) {
-        t->F = 1;
-        t->PT_H = TP / g.Ws;
-    } else {
-        t->F = TP / PQ;
-        t->PT_H = g.Hs;
-    }
-    t->lgQ = lgQ;
-    t->lgPTQ = ilog2_exact(t->PT_H * g.Ws);
-    t->IH = g.stride * (t->PT_H - 1) + g.R;
+    t->F = PQ >= TP ? 1 : TP / PQ;
+    int rows = PQ >= TP ? TP / g.Ws : g.Hs;
+    t->TMP = 32 * MR + 1;
     t->IWp = g.stride * (g.Ws - 1) + g.S;
     t->IWp += (t->IWp & 1);                 // even row stride
-    t->FS = t->IH * t->IWp;
-    t->CHS = t->F * t->FS;
-    t->tiles_per_frame = (t->F == 1) ? g.Hs / t->PT_H : 1;
-    t->TMP = 32 * MR + 1;
-    t->xl_floats = (CC * t->CHS + 3) & ~3;
-    const size_t lds = ((size_t)t->xl_floats + (size_t)CC * g.R * g.S * t->TMP) * 4;
-    if (lds > MF_MAX_LDS) return false;
-    if (t->CHS > MF_THREADS * (g.stride == 1 ? 3 : g.stride == 2 ? 6 : 13)) return false;   // KIN register budget
+    for (;;) {
+        t->tiles_per_frame = (g.Hs + rows - 1) / rows;
+        t->PT_H = (g.Hs + t->tiles_per_frame - 1) / t->tiles_per_frame;
+        t->IH = g.stride * (t->PT_H - 1) + g.R;
+        t->FS = t->IH * t->IWp;
+        t->CHS = t->F * t->FS;
+        t->xl_floats = (CC * t->CHS + 3) & ~3;
+        const size_t lds = ((size_t)t->xl_floats + (size_t)CC * g.R * g.S * t->TMP) * 4;
+        const bool fits = lds <= MF_MAX_LDS &&
+                          t->CHS <= MF_THREADS * (g.stride == 1 ? 3 : g.stride == 2 ? 6 : 13);   // KIN register budget
+        if (fits) break;
+        if (pow2) return false;             // (the tiles of power-of-two maps are as measured)
+        if (t->F > 1) --t->F;
+        else if (rows > 1) --rows;
+        else return false;
+    }
+    t->PTQ = t->PT_H * g.Ws;
     const int groups = (g.N + t->F - 1) / t->F;
     *n_wg_xy = groups * t->tiles_per_frame * ((g.Cs + 32 * MR - 1) / (32 * MR));
     t->splits = 1;
@@ -309,7 +318,10 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     const bool s1 = g.stride == 1 && g.R == g.S && (g.R == 3 || g.R == 5);
     if (!s1 && (g.R != 5 || g.S != 5)) return p;
     if (!s1 && g.stride != 2 && g.stride != 5) return p;
-    if (g.Cb < 2) return p;            // single-channel inputs: conv_edge.hip
+    // single-channel inputs: conv_edge.hip (stride 2).  Stride 1 (round 4): the first layer of a
+    // max-pooling architecture runs here with three of its chunk's four channels masked to zero --
+    // four times the arithmetic of a layer that has almost none, against im2col + a GEMM over 4 M rows
+    if (g.Cb < 2 && !s1) return p;
     if (g.Cs < 16) return p;
     const int CC = (g.stride == 5) ? 2 : 4;
     // stride 2: 64 ch x 128 px tiles whenever they give ~100 workgroups -- measured in situ

@@ -252,10 +252,11 @@ static int launch_wgrad(dim3 grid, size_t lds, hipStream_t st, const float* smal
 
 BnFastPlan bn_fast_wgrad_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
-    if (g.R != 5 || g.S != 5 || g.stride != 2) return p;
+    if (g.R != 5 || g.S != 5 || (g.stride != 2 && g.stride != 1)) return p;
     if (g.Cs < 16 || g.Cb < 16) return p;
     const BnFastPlan p4 = bn_wgrad4_plan(g);        // 16-byte DMA generation where it fits
     if (p4.supported) return p4;
+    if (g.stride != 2) return p;
     WgradTile t;
     size_t lds = 0;
     if (!wgrad_tile(g, &t, &lds)) return p;
@@ -269,7 +270,7 @@ BnFastPlan bn_fast_wgrad_plan(const BnGeom& g) {
 int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float* big, float* dw,
                          const BnGeom& g, int accumulate, void* ws, hipStream_t st, float* db,
                          int bias_side, bool* bias_done) {
-    if (plan.variant == 4 || plan.variant == 5)
+    if (plan.variant == 4 || plan.variant == 5 || plan.variant == 6)
         return bn_launch_wgrad4(plan, small, big, dw, g, accumulate, ws, st, db, bias_side,
                                 bias_done);
     WgradTile t;

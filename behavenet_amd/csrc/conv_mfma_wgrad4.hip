@@ -228,11 +228,13 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
 // ---------------------------------------------------------------------------------------------
 // W4S<Q>: any map width that is a multiple of 4 (the k-step's four pixels lie in one row); a stage is
 // the PT_H = 64 / Q whole rows that fit into 64 pixels, KS k-steps of four pixels
-template <int Q_>
+// ST = 1 (round 4): stride-1 layers (5x5 taps, any offsets up to 4) -- big patch rows PT_H + 4, row stride
+// Q + 8, a lane's five columns are consecutive words (five 4-byte reads instead of 1 + 2 x 8 bytes)
+template <int Q_, int ST_ = 2>
 struct W4S {
-    static constexpr int Q = Q_, PT_H = W4_TPX / Q, IH = 2 * (PT_H - 1) + 5;
+    static constexpr int Q = Q_, ST = ST_, PT_H = W4_TPX / Q, IH = ST * (PT_H - 1) + 5;
     static constexpr int KS = PT_H * Q / 4;
-    static constexpr int RW = 2 * Q + 8, C4 = RW / 4;
+    static constexpr int RW = ST * Q + 8, C4 = RW / 4;
     static constexpr int ROWG = IH * C4;                         // data groups of a channel image
     static constexpr int GPB = (ROWG & 1) ? ROWG : ROWG + 1;     // odd: conflict-free b64 reads
     static constexpr int BCH = 4 * GPB;
@@ -254,12 +256,13 @@ __device__ __forceinline__ void w4_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 // (out-of-range source offset = 0.0f) by a per-group row number against a per-stage scalar limit.
 // KV = 4: taps with r >= 4 or s >= 4 belong to the zero extension of a smaller kernel (BnGeom::KV): their
 // products are skipped and their (zero) tiles are dropped again by the caller's crop of dW
-template <int QQ, int BIAS, bool GEN, int KV>
+template <int QQ, int BIAS, bool GEN, int KV, int ST = 2>
 __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
     float* __restrict__ bias_part, BnGeom g, int n_stages, int splits, int lg_tpf, int nbias) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using T = W4S<QQ>;
+    using T = W4S<QQ, ST>;
+    static_assert(ST == 2 || GEN, "stride 1: the general row limits");
     constexpr int Q = T::Q, RW = T::RW, BUFW = T::BUFW;
     static_assert((Q & 3) == 0 && T::KS >= 1 && T::KS <= 16, "stage geometry");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -282,8 +285,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     // 2 p0 - 1 + y): lane offsets stay non-negative, the stage adds a scalar offset
     const __amdgpu_buffer_rsrc_t rs_small = __builtin_amdgcn_make_buffer_rsrc(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+    const int pt_rows = ST == 2 ? 1 : g.pt;                // patch row 0 = image row ST p0 - pt_rows
     const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(big - g.Wb), 0, (int)(((size_t)g.N * g.Cb * HWb + g.Wb) * 4), 0x00020000);
+        (void*)(big - pt_rows * g.Wb), 0, (int)(((size_t)g.N * g.Cb * HWb + pt_rows * g.Wb) * 4), 0x00020000);
     int soff[T::NSM], srow = 0;
 #pragma unroll
     for (int j = 0; j < T::NSM; ++j) {
@@ -325,10 +329,10 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
             if (W4_THREADS * j + 64 * wv < T::BIGG) {                 // wave-uniform
                 int vo;
                 if constexpr (GEN) {
-                    // patch row y is image row 2 p0 - 1 + y: row 0 of a frame's first stage lies above
-                    // the image, rows from 2 (Hs - p0) + 1 on below it
+                    // patch row y is image row ST p0 - pt + y (stride 2: pt = 1): rows above the image
+                    // (a frame's first stages) and from Hb + pt - ST p0 on below it read 0.0f
                     const int y = (ypack[j >> 2] >> (8 * (j & 3))) & 255;
-                    const int ymin = p0 == 0 ? 1 : 0, ylim = 2 * (g.Hs - p0) + 1;
+                    const int ymin = pt_rows - ST * p0, ylim = g.Hb + pt_rows - ST * p0;
                     vo = (y >= ymin && y < ylim) ? voff[j] : W4_OOB;
                 } else {
                     // rows above the image (first tile) and below it (last tile) read 0.0f
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
                     vo = (rowcls & smask) ? W4_OOB : voff[j];
                 }
                 w4_dma16(rs_big, sl + T::SMALLW + 4 * (W4_THREADS * j + 64 * wv), vo,
-                         (n0 * g.Cb * g.Hb + 2 * p0) * g.Wb * 4);
+                         (n0 * g.Cb * g.Hb + ST * p0) * g.Wb * 4);
             }
         }
     };
@@ -347,7 +351,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
 #pragma unroll
     for (int bf = 0; bf < 2; ++bf) {
         abase[bf] = (bf * BUFW + (ablk * 16 + lj) * W4_TPX + 4 * lj + kk) * 4;      // bytes
-        bbase[bf] = bf * BUFW + T::SMALLW + (bblk * 16 + lj) * T::BCH + (W4_X0 - 2) + 2 * kk;
+        // (a lane's first tap column ST q - pl sits at LDS column ST q - pl + X0; the reads are words 1..5)
+        bbase[bf] = bf * BUFW + T::SMALLW + (bblk * 16 + lj) * T::BCH +
+                    (ST == 2 ? (W4_X0 - 2) + 2 * kk : (W4_X0 - 1 - g.pl) + kk);
         asm volatile("" : "+v"(abase[bf]));
         asm volatile("" : "+v"(bbase[bf]));
     }
@@ -365,8 +371,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     };
     auto load_row = [&](const int bb, const int ks, const int r, const int half, float (&bq)[25]) __attribute__((always_inline)) {
         const int pj = (4 * ks) / Q, q0 = (4 * ks) - pj * Q;
-        const float* bp = smem + bb + (2 * pj + r) * RW + 2 * q0;
-        if (half == 0) {
+        const float* bp = smem + bb + (ST * pj + r) * RW + ST * q0;
+        if (ST == 1) {
+            // consecutive words of either parity: 4-byte reads
+            if (half == 0) { bq[r * 5 + 0] = bp[1]; bq[r * 5 + 1] = bp[2]; }
+            else { bq[r * 5 + 2] = bp[3]; bq[r * 5 + 3] = bp[4]; bq[r * 5 + 4] = bp[5]; }
+        } else if (half == 0) {
             bq[r * 5 + 0] = bp[1];
         } else {
             const floatx2 c1 = *reinterpret_cast<const floatx2*>(bp + 2);
@@ -544,6 +554,19 @@ static bool wgrad4g_ok(const BnGeom& g) {
     const int tpf = (g.Hs + (W4_TPX / g.Ws) - 1) / (W4_TPX / g.Ws);
     return (size_t)g.N * tpf < (1u << 20);             // multiply-high division of the stage index
 }
+// stride 1 (5x5 taps, offsets up to 4): power-of-two widths up to 64, any height
+static bool wgrad4g1_ok(const BnGeom& g) {
+    static int disabled = -1;                          // BN_WGRAD4G1=0: off
+    if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4G1"); disabled = (e && e[0] == '0') ? 1 : 0; }
+    if (disabled) return false;
+    if (g.stride != 1 || g.R != 5 || g.S != 5 || g.pt > 4 || g.pl > 4) return false;
+    if (g.Ws != 8 && g.Ws != 16 && g.Ws != 32 && g.Ws != 64) return false;
+    if ((g.Wb & 3) != 0) return false;                 // 16-byte rows of the big map
+    if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7ffffff0ull - (size_t)4 * g.Wb * 4) return false;
+    if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
+    const int tpf = (g.Hs + (W4_TPX / g.Ws) - 1) / (W4_TPX / g.Ws);
+    return (size_t)g.N * tpf < (1u << 20);
+}
 static int wgrad4g_stages(const BnGeom& g) {
     const int pth = W4_TPX / g.Ws;
     return g.N * ((g.Hs + pth - 1) / pth);
@@ -551,13 +574,24 @@ static int wgrad4g_stages(const BnGeom& g) {
 
 BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
-    if (g.R != 5 || g.S != 5 || g.stride != 2) return p;
+    if (g.R != 5 || g.S != 5 || (g.stride != 2 && g.stride != 1)) return p;
     if (g.Cs < 16 || g.Cb < 16) return p;
     static int disabled = -1;                          // BN_WGRAD4=0: fall back to the dword-DMA kernel
     if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4"); disabled = (e && e[0] == '0') ? 1 : 0; }
     if (disabled) return p;
     Wgrad4Tile t;
     size_t lds = 0;
+    if (g.stride == 1) {
+        if (!wgrad4g1_ok(g)) return p;
+        t.n_stages = wgrad4g_stages(g);
+        p.supported = true;
+        p.variant = 6;
+        p.d = wgrad4_splits(g, t);
+        p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
+        p.kernel_name = g.Ws == 8 ? "k_wgrad4s_mfma<8, stride 1>" : g.Ws == 16 ? "k_wgrad4s_mfma<16, stride 1>"
+                      : g.Ws == 32 ? "k_wgrad4s_mfma<32, stride 1>" : "k_wgrad4s_mfma<64, stride 1>";
+        return p;
+    }
     if (!wgrad4_tile(g, &t, &lds)) {
         if (!wgrad4g_ok(g)) return p;
         t.n_stages = wgrad4g_stages(g);
@@ -604,21 +638,22 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
     return 0;
 }
 
-template <int Q, int BIAS, bool GEN, int KV>
+template <int Q, int BIAS, bool GEN, int KV, int ST = 2>
 static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const float* big,
                           float* part, float* bias_part, const BnGeom& g, int n_stages, int splits,
                           int lg_tpf, int nbias) {
-    static_assert((size_t)2 * W4S<Q>::BUFW * 4 <= W4_MAX_LDS, "two stage images in LDS");
+    static_assert((size_t)2 * W4S<Q, ST>::BUFW * 4 <= W4_MAX_LDS, "two stage images in LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, W4_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV>), grid, dim3(W4_THREADS),
-                       (size_t)2 * W4S<Q>::BUFW * 4, st, small, big, part, bias_part, g, n_stages,
-                       splits, lg_tpf, nbias);
+    using TS = W4S<Q, ST>;
+    constexpr size_t lds = (size_t)2 * TS::BUFW * 4;
+    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST>), grid, dim3(W4_THREADS), lds, st, small, big, part,
+                       bias_part, g, n_stages, splits, lg_tpf, nbias);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -628,9 +663,10 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
                      int bias_side, bool* bias_done) {
     Wgrad4Tile t;
     size_t lds = 0;
-    const bool gen = plan.variant == 5;
+    const bool s1 = plan.variant == 6;
+    const bool gen = plan.variant == 5 || s1;
     if (gen) {
-        if (!wgrad4g_ok(g)) return BN_E_SHAPE;
+        if (s1 ? !wgrad4g1_ok(g) : !wgrad4g_ok(g)) return BN_E_SHAPE;
         t.n_stages = wgrad4g_stages(g);
     } else if (!wgrad4_tile(g, &t, &lds)) return BN_E_SHAPE;
     t.splits = plan.d;
@@ -645,7 +681,17 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     const int tiles = ((g.Cs + W4_TA - 1) / W4_TA) * ((g.Cb + W4_TB - 1) / W4_TB);
     dim3 grid(tiles, t.splits);
     int rc = BN_E_SHAPE;
-    if (gen) {
+    if (s1) {
+        const int pth = W4_TPX / g.Ws, tpf = (g.Hs + pth - 1) / pth;
+        const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);
+#define W4G1_CASE(QV, B)                                                                         \
+    if (g.Ws == QV && t.bias_side == B)                                                          \
+        rc = launch_wgrad4s<QV, B, true, 5, 1>(grid, st, small, big, (float*)ws, bias_part, g,   \
+                                               t.n_stages, t.splits, magic, t.nbias);
+        W4G1_CASE(8, 0) W4G1_CASE(8, 1) W4G1_CASE(16, 0) W4G1_CASE(16, 1) W4G1_CASE(32, 0) W4G1_CASE(32, 1)
+        W4G1_CASE(64, 0) W4G1_CASE(64, 1)
+#undef W4G1_CASE
+    } else if (gen) {
         // stage -> frame by multiply-high: 2^32 / tiles + 1 (exact below 2^32 / tiles stages)
         const int pth = W4_TPX / g.Ws, tpf = (g.Hs + pth - 1) / pth;
         const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);

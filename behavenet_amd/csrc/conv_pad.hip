@@ -133,6 +133,28 @@ int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hi
     BN_LAUNCH_CHECK();
     return 0;
 }
+// ---------------------------------------------------------------------------------------------
+// Stride-1 gather-up as a gather-down (round 4, no im2col / col2im): with stride 1
+//   out[n,m,h,w] = sum_{c,r,s} small[n,c,h+pt-r,w+pl-s] W[c][m][r][s]
+//                = sum_{c,r',s'} small[n,c,h+r'-(R-1-pt),w+s'-(S-1-pl)] W'[m][c][r'][s']
+// with W'[m][c][r'][s'] = W[c][m][R-1-r'][S-1-s']: the channel roles swapped, the taps reversed.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PD_THREADS) void k_flip_taps(const float* __restrict__ w, float* __restrict__ wf,
+                                                           unsigned Cs, unsigned Cb, unsigned RS) {
+    const unsigned total = Cs * Cb * RS;
+    for (unsigned e = blockIdx.x * PD_THREADS + threadIdx.x; e < total; e += gridDim.x * PD_THREADS) {
+        const unsigned t = e % RS, mc = e / RS;
+        const unsigned c = mc % Cs, m = mc / Cs;
+        wf[e] = w[(c * Cb + m) * RS + (RS - 1 - t)];
+    }
+}
+int bn_launch_flip_taps(const float* w, float* wf, int Cs, int Cb, int RS, hipStream_t st) {
+    hipLaunchKernelGGL(k_flip_taps, dim3(pd_blocks((size_t)Cs * Cb * RS)), dim3(PD_THREADS), 0, st, w, wf,
+                       (unsigned)Cs, (unsigned)Cb, (unsigned)RS);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S, int accumulate,
                         hipStream_t st, const float* db5, float* db, int nb) {
     hipLaunchKernelGGL(k_crop_taps, dim3(pd_blocks(pairs * R * S)), dim3(PD_THREADS), 0, st, dw5, dw,

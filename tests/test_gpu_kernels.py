@@ -93,6 +93,14 @@ CONV_CASES = [
     ('s1_k5_64x64', 2, 16, 64, 64, 32, 5, 1, (2, 2), (2, 2)),
     ('s1_k3_32x32', 3, 32, 32, 32, 64, 3, 1, (1, 1), (1, 1)),
     ('s1_k4_8x8', 3, 64, 8, 8, 64, 4, 1, (1, 2), (1, 2)),
+    # round 4: the other two roles of stride-1 layers without im2col -- data gradient on the gather-down
+    # kernel with reversed taps, weight gradient on k_wgrad4s_mfma<Q, stride 1> (rows of a frame's last
+    # stage below the map, offsets other than 2)
+    ('s1_k5_24x16', 5, 32, 24, 16, 32, 5, 1, (2, 2), (2, 2)),
+    ('s1_k5_8x8_n9', 9, 64, 8, 8, 64, 5, 1, (2, 2), (2, 2)),
+    ('s1_k5_valid_60x64', 2, 16, 64, 68, 32, 5, 1, (0, 0), (0, 0)),
+    ('s1_k5_pad13', 3, 32, 16, 16, 64, 5, 1, (1, 3), (3, 1)),
+    ('s1_k5_1ch_128x128', 2, 1, 128, 128, 16, 5, 1, (2, 2), (2, 2)),
     # round 4: maps that are no powers of two DIRECTLY on the stride-2 families (runtime tile geometry:
     # any even width / any height for the gather-down role, any width for the gather-up role, widths
     # that are multiples of 4 up to 44 for the weight gradient).  Frame counts that leave the last
@@ -192,6 +200,13 @@ CONVT_CASES = [
     ('k3_8x8', 2, 128, 8, 8, 64, 3, 2, 0, (1, 0, 1, 0), 0),
     ('D4_64ch', 2, 64, 64, 64, 1, 5, 2, 0, (1, 2, 1, 2), 0),
     ('D4_k4_64ch', 2, 64, 64, 64, 1, 4, 2, 0, (1, 1, 1, 1), 0),
+    # round 4: stride 1 -- forward on the gather-down kernel with reversed taps, weight gradient direct
+    ('s1_k5_16x16', 3, 32, 16, 16, 64, 5, 1, (2, 2), None, 0),
+    ('s1_k3_32x32', 3, 64, 32, 32, 32, 3, 1, (1, 1), None, 0),
+    ('s1_k4_8x8', 5, 64, 8, 8, 64, 4, 1, 0, (1, 2, 1, 2), 0),
+    ('s1_k5_64x64', 2, 32, 64, 64, 16, 5, 1, (2, 2), None, 0),
+    ('s1_k5_to_1ch_42x72', 3, 16, 42, 72, 1, 5, 1, (2, 2), None, 0),
+    ('s1_k5_to_2ch_128x128', 2, 16, 128, 128, 2, 5, 1, (2, 2), None, 0),
     # round 4: no powers of two, directly on the stride-2 families (see CONV_CASES)
     ('np2_16x12', 5, 64, 16, 12, 32, 5, 2, 0, (1, 2, 1, 2), 0),
     ('np2_12x10', 7, 128, 12, 10, 64, 5, 2, 0, (1, 2, 1, 2), 0),
@@ -681,6 +696,30 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
         assert torch.equal(u.cpu(), u_ref.detach())
         dv = _hip.maxunpool2d_bwd(du.to(DEV), idx)
         assert torch.equal(dv.cpu(), vr.grad)
+
+
+@pytest.mark.parametrize('case_name', ['s1_k5_64x64', 's1_k3_32x32', 's1_k4_8x8', 's1_k5_24x16', 's1_k5_pad13'])
+def test_stride1_roles_run_without_im2col(case_name):
+    """Round 4: data gradient = gather-down kernel on reversed taps, weight gradient = the streamlined
+    MFMA kernel's stride-1 instantiation (no k_im2col / k_col2im detour)."""
+    case = [c for c in CONV_CASES if c[0] == case_name][0]
+    x, w, b, geom, ref = _conv_setup(case)
+    N, K, P, Q = geom[0], geom[4], geom[10], geom[11]
+    dy = torch.ones((N, K, P, Q), device=DEV)
+    for prof, fn, want in (
+            (_hip.PROF_CONV_BWD_D, lambda: _hip.conv2d_bwd_data(dy, w.to(DEV), geom, None, _hip.ACT_NONE, SLOPE),
+             'on reversed taps'),
+            (_hip.PROF_CONV_BWD_W, lambda: _hip.conv2d_bwd_weight(
+                x.to(DEV), dy, torch.empty_like(w, device=DEV), torch.empty_like(b, device=DEV), geom, False),
+             'stride 1')):
+        _hip.prof_select(prof, 0, 0)
+        try:
+            fn()
+            torch.cuda.synchronize()
+            _, n, name = _hip.prof_read()
+        finally:
+            _hip.prof_select(_hip.PROF_NONE)
+        assert n >= 1 and want in name and 'im2col' not in name and 'col2im' not in name, name
 
 
 @pytest.mark.parametrize('case_name, want', [
