@@ -709,7 +709,7 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         bool all_done = db && bias_side == 1;
         // k_wgrad_c1d reads a group from its channel window of the small tensor (BnGeom::CsS)
         const BnFastPlan edw = bn_edge_wgrad_plan(g5);
-        if (g.Cb == 1 && edw.supported && g5.pt == 1 && g5.pl == 1) {
+        if (g.Cb == 1 && edw.supported && edw.variant != 1 && g5.pt == 1 && g5.pl == 1) {
             BnGeom gw = g5;
             gw.CsS = g.Cs;
             if (!ws_ok(edw, (char*)ws + cb, ws_bytes - cb)) return BN_E_WORKSPACE;

@@ -321,8 +321,20 @@ BnFastPlan bn_edge_wgrad_plan(const BnGeom& g) {
         p.kernel_name = "k_wgrad_c1<1>";
         return p;
     }
-    if (g.Cs > 32 || g.Ws != WC_W || (g.Hs % WC_ROWS) != 0) return p;
-    if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
+    if (g.Cs > 32) return p;
+    if (g.Ws != WC_W || (g.Hs % WC_ROWS) != 0 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) {
+        // round 4: any other map (64x48, 192x160 frames) in row / column blocks on the first-generation
+        // kernel -- no zero-padded or tiled copies of the two operands
+        static int off = -1;                          // BN_WGRAD_C1G=0: off
+        if (off < 0) { const char* e = bn_tune_env("BN_WGRAD_C1G"); off = (e && e[0] == '0') ? 1 : 0; }
+        if (off || g.pt > 4 || g.pl > 4 || (g.CsS > 0 && g.CsS != g.Cs)) return p;
+        p.supported = true;
+        p.variant = 1;
+        p.d = wgrad_c1_grid(g);
+        p.ws_bytes = ((size_t)g.Cb * p.d * g.Cs * 25 + (size_t)p.d * 32) * sizeof(float);
+        p.kernel_name = "k_wgrad_c1<2>";
+        return p;
+    }
     p.supported = true;
     p.d = wgrad_c1_grid(g);
     p.ws_bytes = ((size_t)g.Cb * p.d * g.Cs * 25 + (size_t)p.d * 32) * sizeof(float);
@@ -341,7 +353,7 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
     if (g.stride == 1) {
         BN_LAUNCH_MAIN(k_wgrad_c1<1>, dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
                            (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g));
-    } else if (g.pt == 1 && g.pl == 1) {
+    } else if (g.pt == 1 && g.pl == 1 && plan.variant != 1) {
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e1 = hipFuncSetAttribute((const void*)k_wgrad_c1d<true>,

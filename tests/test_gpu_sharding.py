@@ -439,7 +439,9 @@ def test_bench_two_ranks_frame_sharded(tmp_path):
     """`python bench.py --gpus 2 --shard frames`: the strong-scaling (parity-exact) reading of
     BASELINE configs[2] -- one 256-frame trial per step, 128 frames per rank, summed gradients;
     the loss it reports is the single-device loss of the same trajectory."""
-    env = _child_env(BN_DIST_BACKEND='gloo')
+    # (BN_BENCH_PRIME: the same number of untimed priming steps in both runs -- a single process
+    # otherwise primes until its step time has settled)
+    env = _child_env(BN_DIST_BACKEND='gloo', BN_BENCH_PRIME='24')
     tail = ['--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary']
     d2 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--shard',
                       'frames'] + tail, env, tmp_path)
