@@ -230,9 +230,11 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
 // the PT_H = 64 / Q whole rows that fit into 64 pixels, KS k-steps of four pixels
 // ST = 1 (round 4): stride-1 layers (5x5 taps, any offsets up to 4) -- big patch rows PT_H + 4, row stride
 // Q + 8, a lane's five columns are consecutive words (five 4-byte reads instead of 1 + 2 x 8 bytes)
-template <int Q_, int ST_ = 2>
+// PTH_ (0 = 64 / Q): rows of a stage -- 4 instead of 8 for 8-column maps of at most four rows (the 4x3
+// maps of 64x48 frames on their 4x8 zero-padded copies: half the k-steps of a stage were zeros)
+template <int Q_, int ST_ = 2, int PTH_ = 0>
 struct W4S {
-    static constexpr int Q = Q_, ST = ST_, PT_H = W4_TPX / Q, IH = ST * (PT_H - 1) + 5;
+    static constexpr int Q = Q_, ST = ST_, PT_H = PTH_ ? PTH_ : W4_TPX / Q, IH = ST * (PT_H - 1) + 5;
     static constexpr int KS = PT_H * Q / 4;
     static constexpr int RW = ST * Q + 8, C4 = RW / 4;
     static constexpr int ROWG = IH * C4;                         // data groups of a channel image
@@ -256,12 +258,12 @@ __device__ __forceinline__ void w4_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 // (out-of-range source offset = 0.0f) by a per-group row number against a per-stage scalar limit.
 // KV = 4: taps with r >= 4 or s >= 4 belong to the zero extension of a smaller kernel (BnGeom::KV): their
 // products are skipped and their (zero) tiles are dropped again by the caller's crop of dW
-template <int QQ, int BIAS, bool GEN, int KV, int ST = 2>
+template <int QQ, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0>
 __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
     float* __restrict__ bias_part, BnGeom g, int n_stages, int splits, int lg_tpf, int nbias) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    using T = W4S<QQ, ST>;
+    using T = W4S<QQ, ST, PTH>;
     static_assert(ST == 2 || GEN, "stride 1: the general row limits");
     constexpr int Q = T::Q, RW = T::RW, BUFW = T::BUFW;
     static_assert((Q & 3) == 0 && T::KS >= 1 && T::KS <= 16, "stage geometry");
@@ -538,6 +540,10 @@ static bool wgrad4s_ok(const BnGeom& g, const Wgrad4Tile& t) {
     return true;
 }
 
+// rows of a stage of the GEN instantiations (W4S::PT_H)
+static inline int w4g_pth(const BnGeom& g) {
+    return (g.stride == 2 && g.Ws == 8 && g.Hs <= 4) ? 4 : W4_TPX / g.Ws;
+}
 // maps that are no powers of two on the streamlined kernel (GEN instantiations): widths the kernel is
 // instantiated for, any height, big map exactly twice the small one
 static const int W4G_WIDTHS[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 44};
@@ -551,7 +557,7 @@ static bool wgrad4g_ok(const BnGeom& g) {
     if (!width) return false;
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;   // 32-bit offsets
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
-    const int tpf = (g.Hs + (W4_TPX / g.Ws) - 1) / (W4_TPX / g.Ws);
+    const int tpf = (g.Hs + w4g_pth(g) - 1) / w4g_pth(g);
     return (size_t)g.N * tpf < (1u << 20);             // multiply-high division of the stage index
 }
 // stride 1 (5x5 taps, offsets up to 4): power-of-two widths up to 64, any height
@@ -564,11 +570,11 @@ static bool wgrad4g1_ok(const BnGeom& g) {
     if ((g.Wb & 3) != 0) return false;                 // 16-byte rows of the big map
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7ffffff0ull - (size_t)4 * g.Wb * 4) return false;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
-    const int tpf = (g.Hs + (W4_TPX / g.Ws) - 1) / (W4_TPX / g.Ws);
+    const int tpf = (g.Hs + w4g_pth(g) - 1) / w4g_pth(g);
     return (size_t)g.N * tpf < (1u << 20);
 }
 static int wgrad4g_stages(const BnGeom& g) {
-    const int pth = W4_TPX / g.Ws;
+    const int pth = w4g_pth(g);
     return g.N * ((g.Hs + pth - 1) / pth);
 }
 
@@ -638,21 +644,21 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
     return 0;
 }
 
-template <int Q, int BIAS, bool GEN, int KV, int ST = 2>
+template <int Q, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0>
 static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const float* big,
                           float* part, float* bias_part, const BnGeom& g, int n_stages, int splits,
                           int lg_tpf, int nbias) {
-    static_assert((size_t)2 * W4S<Q, ST>::BUFW * 4 <= W4_MAX_LDS, "two stage images in LDS");
+    using TS = W4S<Q, ST, PTH>;
+    static_assert((size_t)2 * TS::BUFW * 4 <= W4_MAX_LDS, "two stage images in LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, W4_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    using TS = W4S<Q, ST>;
     constexpr size_t lds = (size_t)2 * TS::BUFW * 4;
-    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST>), grid, dim3(W4_THREADS), lds, st, small, big, part,
+    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH>), grid, dim3(W4_THREADS), lds, st, small, big, part,
                        bias_part, g, n_stages, splits, lg_tpf, nbias);
     BN_LAUNCH_CHECK();
     return 0;
@@ -682,7 +688,7 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     dim3 grid(tiles, t.splits);
     int rc = BN_E_SHAPE;
     if (s1) {
-        const int pth = W4_TPX / g.Ws, tpf = (g.Hs + pth - 1) / pth;
+        const int pth = w4g_pth(g), tpf = (g.Hs + pth - 1) / pth;
         const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);
 #define W4G1_CASE(QV, B)                                                                         \
     if (g.Ws == QV && t.bias_side == B)                                                          \
@@ -693,17 +699,26 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
 #undef W4G1_CASE
     } else if (gen) {
         // stage -> frame by multiply-high: 2^32 / tiles + 1 (exact below 2^32 / tiles stages)
-        const int pth = W4_TPX / g.Ws, tpf = (g.Hs + pth - 1) / pth;
+        const int pth = w4g_pth(g), tpf = (g.Hs + pth - 1) / pth;
         const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);
 #define W4G_CASE(QV, B)                                                                          \
     if (g.Ws == QV && t.bias_side == B)                                                          \
         rc = launch_wgrad4s<QV, B, true, 5>(grid, st, small, big, (float*)ws, bias_part, g,      \
                                          t.n_stages, t.splits, magic, t.nbias);
+        if (g.Ws == 8 && pth == 4) {
+            if (t.bias_side == 0)
+                rc = launch_wgrad4s<8, 0, true, 5, 2, 4>(grid, st, small, big, (float*)ws, bias_part, g,
+                                                          t.n_stages, t.splits, magic, t.nbias);
+            if (t.bias_side == 1)
+                rc = launch_wgrad4s<8, 1, true, 5, 2, 4>(grid, st, small, big, (float*)ws, bias_part, g,
+                                                          t.n_stages, t.splits, magic, t.nbias);
+        } else {
 #define W4G_ALL(QV) W4G_CASE(QV, 0) W4G_CASE(QV, 1)
         W4G_ALL(8) W4G_ALL(12) W4G_ALL(16) W4G_ALL(20) W4G_ALL(24) W4G_ALL(28) W4G_ALL(32) W4G_ALL(36)
         W4G_ALL(40) W4G_ALL(44)
 #undef W4G_ALL
 #undef W4G_CASE
+        }
     } else if (wgrad4s_ok(g, t)) {
         const int lgq = ilog2_exact_w4(g.Ws), lg_tpf = ilog2_exact_w4(t.tiles_per_frame);
 #define W4S_CASE(L, B)                                                                         \
