@@ -270,6 +270,9 @@ static PadPlan pad_plan(int role, const BnGeom& g) {
             int w0 = 2 * g.Ws >= g.Wb + ow ? g.Ws : (g.Wb + ow + 1) / 2;
             for (int wq = w0; wq <= (wsm > 8 ? wsm : 8) && wq <= w0 + 8 && !found; ++wq) {
                 if (wq == g.Ws && hmin == g.Hs && g.Hb == 2 * g.Hs && g.Wb == 2 * g.Ws && !oh && !ow) continue;
+                // (gather-up: the small map is the operand that is copied -- 16-byte rows for k_pad2d, or
+                // no copy at all when only the output is larger)
+                if (role == 1 && (wq & 3) && !(wq == g.Ws && hmin == g.Hs)) continue;
                 p.gp = g;
                 p.gp.Hs = hmin; p.gp.Ws = wq; p.gp.Hb = 2 * hmin; p.gp.Wb = 2 * wq; p.gp.pt = p.gp.pl = 1;
                 if ((size_t)g.N * g.Cb * p.gp.Hb * p.gp.Wb * 4 >= 0x7fffffffull) break;
@@ -616,7 +619,9 @@ static int run_up(int family, const float* small, const float* w, const float* b
             float* outp = (float*)ws;
             float* smallp = (float*)((char*)ws + pp.big_bytes);
             void* iws = (char*)ws + pp.big_bytes + pp.small_bytes;
-            int rc = bn_launch_pad2d(small, smallp, (size_t)g.N * g.Cs, g.Hs, g.Ws, pp.gp.Hs, pp.gp.Ws, 0, 0, st);
+            int rc = 0;
+            if (pp.gp.Hs == g.Hs && pp.gp.Ws == g.Ws) smallp = const_cast<float*>(small);   // only the output grows
+            else rc = bn_launch_pad2d(small, smallp, (size_t)g.N * g.Cs, g.Hs, g.Ws, pp.gp.Hs, pp.gp.Ws, 0, 0, st);
             if (rc) return rc;
             rc = pp.edge ? bn_launch_edge_up(smallp, w, bias, outp, pp.gp, act, slope, st)
                          : bn_launch_up_fast(pp.inner, smallp, w, bias, outp, nullptr, pp.gp, act, BN_ACT_NONE,

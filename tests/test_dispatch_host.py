@@ -1,0 +1,63 @@
+"""Host side of the convolution dispatch (csrc/capi.hip) WITHOUT a GPU: every geometry of a seeded sweep must
+get past plan selection, scratch sizing and argument checks of all three roles -- i.e. reach a kernel launch,
+which on a machine without a device fails with a (positive) HIP error code.  A negative code is the library's
+own refusal (BN_E_BADARG / BN_E_SHAPE / BN_E_WORKSPACE): the class of bug where a plan picks a detour whose
+copy kernel does not take the padded shape (found by this sweep in round 4: a zero-padded copy of a
+gather-up operand with a width that is no multiple of 4).
+
+The sweep is the one of tests/test_gpu_kernels.py::test_random_geometries_all_roles (which checks the numbers
+on the device) with more draws."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from behavenet_amd import _hip
+
+
+def _cases(seed, count):
+    from tests.test_gpu_kernels import _random_conv_cases
+    return _random_conv_cases(seed, count)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='launches real kernels on dummy pointers when a GPU is present')
+def test_every_role_of_a_geometry_sweep_reaches_a_launch():
+    lib = _hip.load()
+    buf = (ctypes.c_char * 256)()
+    p = ctypes.addressof(buf)
+    big = ctypes.c_size_t(1 << 42)
+    refused = []
+    for name, N, C, H, W, K, R, st, (pt, pb), (pl, pr) in _cases(7, 600):
+        P, Q = (H + pt + pb - R) // st + 1, (W + pl + pr - R) // st + 1
+        conv = (N, C, H, W, K, R, R, st, pt, pl, P, Q)
+        rcs = {
+            'conv fwd': lib.bn_conv2d_fwd(p, p, p, p, *conv, 1, 0.05, p, big, None),
+            'conv bwd_data': lib.bn_conv2d_bwd_data(p, p, p, None, *conv, 0, 0.05, p, big, None),
+            'conv bwd_data*lrelu': lib.bn_conv2d_bwd_data(p, p, p, p, *conv, 1, 0.05, p, big, None),
+            'conv bwd_weight': lib.bn_conv2d_bwd_weight(p, p, p, p, *conv, 0, p, big, None),
+            # the transposed layer with the same maps: small (K, P, Q) -> big (C, H, W)
+            'convT fwd': lib.bn_convT2d_fwd(p, p, p, p, N, K, P, Q, C, R, R, st, pt, pl, H, W, 1, 0.05, p, big,
+                                            None),
+            'convT bwd_data': lib.bn_convT2d_bwd_data(p, p, p, p, N, K, P, Q, C, R, R, st, pt, pl, H, W, 1,
+                                                      0.05, p, big, None),
+            'convT bwd_weight': lib.bn_convT2d_bwd_weight(p, p, p, p, N, K, P, Q, C, R, R, st, pt, pl, H, W, 0,
+                                                          p, big, None),
+        }
+        for role, rc in rcs.items():
+            if rc < 0:
+                refused.append((name, role, rc))
+    assert not refused, refused[:10]
+
+
+def test_scratch_sizes_of_the_sweep_are_finite():
+    """bn_conv_ws_bytes of every role: below 4 GB for these (<= 6 M element) operands."""
+    lib = _hip.load()
+    for name, N, C, H, W, K, R, st, (pt, pb), (pl, pr) in _cases(11, 300):
+        P, Q = (H + pt + pb - R) // st + 1, (W + pl + pr - R) // st + 1
+        for op in (1, 2, 3):          # BN_OP_CONV_*
+            ws = lib.bn_conv_ws_bytes(op, N, C, H, W, K, R, R, st, pt, pl, P, Q)
+            assert 0 <= ws < (1 << 32), (name, op, ws)
+        for op in (4, 5, 6):          # BN_OP_CONVT_*: small (K, P, Q) -> big (C, H, W)
+            ws = lib.bn_conv_ws_bytes(op, N, K, P, Q, C, R, R, st, pt, pl, H, W)
+            assert 0 <= ws < (1 << 32), (name, op, ws)

@@ -698,6 +698,71 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
         assert torch.equal(dv.cpu(), vr.grad)
 
 
+def _random_conv_cases(seed, count):
+    """Seeded sweep over what the round-4 tile logic has to get right: map sizes that are no powers of
+    two (tiles with masked lanes, frames' last tiles / stages hanging over the edge, frame groups cut short
+    by the batch), channel counts off the 32 / 64 tile sizes, 3x3 / 4x4 / 5x5 kernels, strides 1 and 2."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < count:
+        st = int(rng.choice([1, 2, 2, 2]))
+        R = int(rng.choice([3, 4, 5, 5, 5]))
+        P, Q = int(rng.randint(1, 41)), int(rng.randint(1, 41))
+        if rng.rand() < 0.4:
+            Q = int(rng.choice([4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48]))
+        C, K = int(rng.choice([16, 32, 48, 64, 96, 128])), int(rng.choice([16, 32, 64, 80, 128]))
+        N = int(rng.randint(1, 10))
+        if st == 2:
+            pt, pl = int(rng.choice([1, 1, 1, 2])), int(rng.choice([1, 1, 1, 2]))
+            H, W = 2 * P - int(rng.rand() < 0.15), 2 * Q - int(rng.rand() < 0.15)
+            pb, pr = (P - 1) * 2 + R - H - pt, (Q - 1) * 2 + R - W - pl
+        else:
+            pt, pl = int(rng.randint(0, R)), int(rng.randint(0, R))
+            H, W = P, Q
+            pb, pr = R - 1 - pt, R - 1 - pl
+        if H < 1 or W < 1 or pb < 0 or pr < 0 or N * C * H * W > 6e6 or N * K * P * Q > 6e6:
+            continue
+        cases.append(('rnd%d_s%d_k%d_%dx%d_c%d_k%d_n%d' % (len(cases), st, R, P, Q, C, K, N),
+                      N, C, H, W, K, R, st, (pt, pb), (pl, pr)))
+    return cases
+
+
+RANDOM_CASES = _random_conv_cases(2026, 72)
+
+
+@pytest.mark.parametrize('case', RANDOM_CASES, ids=[c[0] for c in RANDOM_CASES])
+def test_random_geometries_all_roles(case):
+    """Forward, both data-gradient forms and the weight / bias gradients of a seeded sweep of geometries
+    against float64 (same gate as the named cases)."""
+    x, w, b, geom, pad = _conv_setup(case)
+    st = geom[7]
+    want = act_ref(F.conv2d(F.pad(x, pad), w, b, stride=st), _hip.ACT_LRELU)
+    want64 = act_ref(F.conv2d(F.pad(x.double(), pad), w.double(), b.double(), stride=st), _hip.ACT_LRELU)
+    assert tuple(want.shape[2:]) == (geom[10], geom[11]), (want.shape, geom)
+    got = _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE)
+    close(got, want, want64, name=case[0] + ' fwd')
+    test_conv2d_bwd(case)
+
+
+# the transposed layers between the same maps: small (K, P, Q) -> big (C, H, W), cropped by the conv's pads
+RANDOM_T_CASES = [(c[0] + 'T', c[1], c[5], (c[3] + sum(c[8]) - c[6]) // c[7] + 1,
+                   (c[4] + sum(c[9]) - c[6]) // c[7] + 1, c[2], c[6], c[7], 0,
+                   (c[9][0], c[9][1], c[8][0], c[8][1]), 0) for c in _random_conv_cases(4052, 48)]
+
+
+@pytest.mark.parametrize('case', RANDOM_T_CASES, ids=[c[0] for c in RANDOM_T_CASES])
+def test_random_geometries_all_roles_transposed(case):
+    """The same sweep through the ConvTranspose2d entry points: gather-up with bias + activation, gather-down
+    with the activation derivative of the layer below, weight gradient with the bias sums over the big side."""
+    x, w, b, geom, ref = _convT_setup(case)
+    want = act_ref(ref(x, w, b), _hip.ACT_LRELU)
+    want64 = act_ref(ref(x.double(), w.double(), b.double()), _hip.ACT_LRELU)
+    assert tuple(want.shape[2:]) == (geom[10], geom[11]), (want.shape, geom)
+    got = _hip.convT2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE)
+    close(got, want, want64, name=case[0] + ' fwd')
+    test_convT2d_bwd(case)
+
+
 @pytest.mark.parametrize('case_name', ['s1_k5_64x64', 's1_k3_32x32', 's1_k4_8x8', 's1_k5_24x16', 's1_k5_pad13'])
 def test_stride1_roles_run_without_im2col(case_name):
     """Round 4: data gradient = gather-down kernel on reversed taps, weight gradient = the streamlined
