@@ -892,35 +892,51 @@ class AEMSP(AE):
         batch_size = x.shape[0]
         n_chunks = int(np.ceil(batch_size / chunk_size))
         alpha = self.hparams['msp.alpha']
-        if bdist.frames_sharded():
-            raise NotImplementedError('frame-sharded data parallelism of AEMSP is not '
-                                      'implemented (use dp_shard="trial")')
+        sharded = bdist.frames_sharded()
+        if sharded and (self.hparams.get('ae_batch_norm', False) or not self._whole_batch or
+                        self.model_type != 'conv' or not x.is_cuda):
+            # (every rank takes this branch together: it depends on hparams only)
+            raise NotImplementedError('frame-sharded data parallelism of AEMSP serves the '
+                                      'single-pass conv model without batch norm '
+                                      '(use dp_shard="trial")')
         self._reserve_pools(x)
-        if self._whole_batch_ok(x):
+        if self._whole_batch_ok(x) or sharded:
             # single pass (see AE._loss_whole_batch): every map here is frame-wise, the two MSP
-            # terms are means over a chunk's rows like the pixel term
-            bounds = [(beg, min(beg + chunk_size, batch_size))
-                      for beg in range(0, batch_size, chunk_size)]
+            # terms are means over a chunk's rows like the pixel term.  Frame-sharded (round 4):
+            # this rank's slice of every chunk, every chunk term divided by the GLOBAL chunk
+            # length (the pixel term through `chunk_sizes`, the MSP terms through the rank's share
+            # of the chunk), the table summed over ranks; labels_r2 over all ranks' rows.
+            from behavenet_amd.models.vaes import _FrameShards
+            sh = _FrameShards(batch_size, chunk_size)
+            x_l, y_l, m_l = sh.take(x, y, m)
+            bounds = sh.bounds_l
             with torch.set_grad_enabled(bool(accumulate_grad)), bn_chunks(bounds):
                 P = self._P()
-                z, pool_idx, outsize = self.encoding(x, dataset=dataset)
+                z, pool_idx, outsize = self.encoding(x_l, dataset=dataset)
                 y_hat = linear(z, P, None)
                 x_hat = self.decoding(
                     z, pool_idx, outsize, dataset=dataset,
-                    pixel_loss={'target': x, 'mask': m, 'bounds': bounds, 'kind': 'mse'})
+                    pixel_loss={'target': x_l, 'mask': m_l, 'bounds': bounds, 'kind': 'mse',
+                                'chunk_sizes': sh.sizes})
                 z_back = linear(y_hat, P.t().contiguous(), None)
-                l_mse = losses.mse_chunks(x, x_hat, m, bounds)
-                l_msp = torch.stack([
-                    losses.mse(y[b:e], y_hat[b:e]) + losses.mse(z[b:e], z_back[b:e])
-                    for b, e in bounds])
+                l_mse = losses.mse_chunks(x_l, x_hat, m_l, bounds, sh.sizes)
+                l_msp = sh.row_terms(
+                    lambda yy, yh, zz, zb: losses.mse(yy, yh) + losses.mse(zz, zb),
+                    y_l, y_hat, z, z_back)
                 lossv = l_mse + float(alpha) * l_msp
-            table = Readback(torch.stack([lossv.detach(), l_mse.detach(), l_msp.detach()], dim=1))
-            y_hat_rb, y_rb = Readback(y_hat.detach()), Readback(y)
+            table_t = torch.stack([lossv.detach(), l_mse.detach(), l_msp.detach()], dim=1)
+            if sh.sharded:
+                table_t = bdist.all_reduce_(table_t.clone())
+            table = Readback(table_t)
+            # (labels_r2 is a metric over the whole batch: all ranks' rows, in the same -- rank-major
+            # -- order for both; an emulated rank has only its own)
+            rows = sh.all_rows if bdist._emulated is None else (lambda t: t)
+            y_hat_rb, y_rb = Readback(rows(y_hat.detach())), Readback(rows(y_l))
             if accumulate_grad:
                 backward_chunks([lossv], single_pass=True)
             join_side_streams()
             vals = table.numpy().astype(np.float64)
-            w = np.asarray([e - b for b, e in bounds], dtype=np.float64)[:, None]
+            w = np.asarray(sh.sizes, dtype=np.float64)[:, None]
             tot = (vals * w).sum(axis=0) / batch_size
             r2 = _r2_variance_weighted(y_rb.numpy(), y_hat_rb.numpy())
             return {'loss': float(tot[0]), 'loss_mse': float(tot[1]), 'loss_msp': float(tot[2]),

@@ -67,6 +67,12 @@ def build_case(case):
                                                'max_n_epochs': 10})
         model = BetaTCVAE(hp)
         hip_vaes.set_eps_provider(_Eps())
+    elif case == 'aemsp':
+        from behavenet_amd.models import AEMSP
+        hp = base_hparams(arch, 'cond-ae-msp', {'msp.alpha': 0.05, 'conditional_encoder': False})
+        hp['n_labels'] = 4
+        model = AEMSP(hp)
+        data['labels'] = torch.from_numpy(make_labels(44, 4, seed=2)).to(DEV)[None]
     else:
         raise ValueError(case)
     model = model.to(DEV)
@@ -103,6 +109,11 @@ def build_oracle(case, dtype=torch.float64):
                                                'max_n_epochs': 10})
         model = ref_cpu.BetaTCVAE(hp)
         model.eps_fn = _Eps()
+    elif case == 'aemsp':
+        hp = base_hparams(arch, 'cond-ae-msp', {'msp.alpha': 0.05, 'conditional_encoder': False})
+        hp['n_labels'] = 4
+        model = ref_cpu.AEMSP(hp)
+        data['labels'] = torch.from_numpy(make_labels(44, 4, seed=2)).to(dtype)[None]
     else:
         raise ValueError(case)
     model = model.to(dtype)
@@ -147,7 +158,7 @@ def run_fit(tmp):
 
 
 def run_refusals():
-    """AEMSP and MSPSVAE under frame sharding: EVERY rank must raise before it issues a kernel or
+    """AEMSP with batch norm and MSPSVAE under frame sharding: EVERY rank must raise before it issues a kernel or
     a collective (a rank that went on alone would hang the others in their next collective).  ->
     {class name: message} of what this rank raised."""
     from behavenet_amd.models import AEMSP
@@ -155,7 +166,9 @@ def run_refusals():
     from tests.test_oracle_golden import _msps_case
     got = {}
     arch = load_handcrafted_arch(list(DIM), 8, None, check_memory=False)
-    hp = base_hparams(arch, 'cond-ae-msp', {'msp.alpha': 0.05, 'conditional_encoder': False})
+    # (AEMSP is served since round 4 -- case 'aemsp'; its batch-norm variant is not)
+    hp = base_hparams(arch, 'cond-ae-msp', {'msp.alpha': 0.05, 'conditional_encoder': False,
+                                            'ae_batch_norm': True})
     hp['n_labels'] = 4
     torch.manual_seed(0)
     model = AEMSP(hp).to(DEV)

@@ -242,7 +242,7 @@ def _wait_all(procs, logs, limit_s, what):
     pytest.fail('%s: %s\n%s' % (what, failed, '\n'.join(tails)), pytrace=False)
 
 
-TWO_RANK_CASES = ['ae_bn', 'psvae', 'betatc', 'vae_bn', 'psvae_bn', 'refuse', 'shardopt', 'fit']
+TWO_RANK_CASES = ['ae_bn', 'psvae', 'betatc', 'vae_bn', 'psvae_bn', 'aemsp', 'refuse', 'shardopt', 'fit']
 
 
 def _run_two_ranks(tmp, cases, limit_s=240):
@@ -288,8 +288,9 @@ def test_sharded_optimizer_step_on_two_ranks_equals_the_replicated_step(two_rank
 
 
 def test_frame_sharding_is_refused_on_every_rank_for_the_session_coupled_models(two_rank_dir):
-    """`AEMSP` and `MSPSVAE` are not served by frame sharding (their projection / triplet terms are
-    not sharded here; reference terms vaes.py:1040-1048, aes.py:1062-1065): BOTH ranks must raise
+    """`MSPSVAE` and the batch-norm variant of `AEMSP` are not served by frame sharding (the triplet
+    term couples sessions, reference vaes.py:1040-1048; `AEMSP` itself is since round 4, case
+    'aemsp' of the two-rank test): BOTH ranks must raise
     NotImplementedError from `loss()` -- and reach the barrier behind the case, which they only do
     if neither went on into a collective alone."""
     assert os.path.exists(os.path.join(two_rank_dir, 'refuse.done')), 'the ranks did not finish the case'
@@ -329,8 +330,10 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step(two_rank_dir, case):
         ora, data_o, kw_o = build_oracle(case, dtype)
         with BranchReplay(pattern) as br:
             loss = ora.loss(data_o, dataset=0, accumulate_grad=True, **kw_o)
-        named = [(k, p.grad.double().numpy()) for k, p in ora.named_parameters()
-                 if p.requires_grad]
+        # (AEMSP's U matrix takes no part in the loss: no gradient in the oracle, a zero one in the
+        # model's flat gradient arena)
+        named = [(k, (p.grad if p.grad is not None else torch.zeros_like(p)).double().numpy())
+                 for k, p in ora.named_parameters() if p.requires_grad]
         return loss, named, br
     l64, g64, br = oracle_grads(torch.float64)
     br.assert_only_ties()
