@@ -210,8 +210,16 @@ def secondary_configs(hp_ae, feed_rates=True):
                              'shipped configs/ae_jsons/ae_arch_2.json (5 layers of 64 channels, k4, '
                              'strides 2,2,2,2,1) on 1x128x128'))
     out.append(geometry_step(None, [2, 192, 160],
-                             'default architecture on 2x192x160 frames (maps beyond the tiles of '
-                             'the specialised kernels: spatial tiles with halos)'))
+                             'default architecture on 2x192x160 frames (48x40 / 24x20 / 12x10 maps '
+                             'directly on the stride-2 families since round 4; edge layers on tiles)'))
+    out.append(geometry_step(None, [1, 128, 128],
+                             'default architecture with ae_batch_norm = 1 on 1x128x128 (per-chunk '
+                             'statistics inside one pass; momentum None = cumulative average, the '
+                             'reference\'s default)', names=False, extra={'ae_batch_norm': True}))
+    out.append(geometry_step(os.path.join(REPO, 'tests', 'golden', 'arch_maxpool.json'), [1, 128, 128],
+                             'max-pooling test architecture (tests/golden/arch_maxpool.json: 5x5 stride-1 '
+                             'conv 1 -> 16 / pool / conv 16 -> 32 / pool, mirrored unpooling decoder) on '
+                             '1x128x128', names=False))
     if feed_rates:
         # --- the headline step fed over PCIe: pinned uint8 trials, one-trial look-ahead
         torch.manual_seed(0)
@@ -329,12 +337,12 @@ def live_hbm_traffic(kernel_substr='k_down_c1p', timeout_s=150):
     return (2.0 * got['FETCH_SIZE'] + got['WRITE_SIZE']) * 1024.0, info
 
 
-def geometry_step(arch_json, dim, label, batch=256, names=True):
+def geometry_step(arch_json, dim, label, batch=256, names=True, extra=None):
     """Training step of an architecture / frame size the specialised kernels were NOT tuned for:
     ms per step and, layer by layer and role by role, the kernel the dispatch chose."""
     from tests.golden_utils import base_hparams, make_frames
     arch = load_handcrafted_arch(list(dim), N_LATENTS, arch_json, check_memory=False)
-    hp = base_hparams(arch, 'ae')
+    hp = base_hparams(arch, 'ae', dict(extra) if extra else None)
     hp['device'] = 'cuda'
     torch.manual_seed(0)
     m = AE(hp).to('cuda')
