@@ -566,7 +566,10 @@ static bool wgrad4g1_ok(const BnGeom& g) {
     if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4G1"); disabled = (e && e[0] == '0') ? 1 : 0; }
     if (disabled) return false;
     if (g.stride != 1 || g.R != 5 || g.S != 5 || g.pt > 4 || g.pl > 4) return false;
-    if (g.Ws != 8 && g.Ws != 16 && g.Ws != 32 && g.Ws != 64) return false;
+    static const int widths[] = {8, 12, 16, 20, 24, 32, 40, 48, 64};
+    bool width = false;
+    for (int q : widths) width = width || q == g.Ws;
+    if (!width) return false;
     if ((g.Wb & 3) != 0) return false;                 // 16-byte rows of the big map
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7ffffff0ull - (size_t)4 * g.Wb * 4) return false;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
@@ -594,8 +597,10 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
         p.variant = 6;
         p.d = wgrad4_splits(g, t);
         p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
-        p.kernel_name = g.Ws == 8 ? "k_wgrad4s_mfma<8, stride 1>" : g.Ws == 16 ? "k_wgrad4s_mfma<16, stride 1>"
-                      : g.Ws == 32 ? "k_wgrad4s_mfma<32, stride 1>" : "k_wgrad4s_mfma<64, stride 1>";
+        static char names_1[16][40];
+        const int slot1 = (g.Ws / 4 - 1) & 15;
+        snprintf(names_1[slot1], sizeof(names_1[slot1]), "k_wgrad4s_mfma<%d, stride 1>", g.Ws);
+        p.kernel_name = names_1[slot1];
         return p;
     }
     if (!wgrad4_tile(g, &t, &lds)) {
@@ -694,8 +699,10 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     if (g.Ws == QV && t.bias_side == B)                                                          \
         rc = launch_wgrad4s<QV, B, true, 5, 1>(grid, st, small, big, (float*)ws, bias_part, g,   \
                                                t.n_stages, t.splits, magic, t.nbias);
-        W4G1_CASE(8, 0) W4G1_CASE(8, 1) W4G1_CASE(16, 0) W4G1_CASE(16, 1) W4G1_CASE(32, 0) W4G1_CASE(32, 1)
-        W4G1_CASE(64, 0) W4G1_CASE(64, 1)
+#define W4G1_ALL(QV) W4G1_CASE(QV, 0) W4G1_CASE(QV, 1)
+        W4G1_ALL(8) W4G1_ALL(12) W4G1_ALL(16) W4G1_ALL(20) W4G1_ALL(24) W4G1_ALL(32) W4G1_ALL(40) W4G1_ALL(48)
+        W4G1_ALL(64)
+#undef W4G1_ALL
 #undef W4G1_CASE
     } else if (gen) {
         // stage -> frame by multiply-high: 2^32 / tiles + 1 (exact below 2^32 / tiles stages)

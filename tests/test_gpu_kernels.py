@@ -100,6 +100,9 @@ CONV_CASES = [
     ('s1_k5_8x8_n9', 9, 64, 8, 8, 64, 5, 1, (2, 2), (2, 2)),
     ('s1_k5_valid_60x64', 2, 16, 64, 68, 32, 5, 1, (0, 0), (0, 0)),
     ('s1_k5_pad13', 3, 32, 16, 16, 64, 5, 1, (1, 3), (3, 1)),
+    ('s1_k5_48x40', 2, 16, 48, 40, 32, 5, 1, (2, 2), (2, 2)),
+    ('s1_k3_18x12', 5, 32, 18, 12, 48, 3, 1, (1, 1), (1, 1)),
+    ('s1_k5_7x20', 4, 64, 7, 20, 32, 5, 1, (2, 2), (2, 2)),
     ('s1_k5_1ch_128x128', 2, 1, 128, 128, 16, 5, 1, (2, 2), (2, 2)),
     # round 4: maps that are no powers of two DIRECTLY on the stride-2 families (runtime tile geometry:
     # any even width / any height for the gather-down role, any width for the gather-up role, widths
@@ -763,7 +766,8 @@ def test_random_geometries_all_roles_transposed(case):
     test_convT2d_bwd(case)
 
 
-@pytest.mark.parametrize('case_name', ['s1_k5_64x64', 's1_k3_32x32', 's1_k4_8x8', 's1_k5_24x16', 's1_k5_pad13'])
+@pytest.mark.parametrize('case_name', ['s1_k5_64x64', 's1_k3_32x32', 's1_k4_8x8', 's1_k5_24x16', 's1_k5_pad13',
+                                       's1_k5_48x40', 's1_k3_18x12', 's1_k5_7x20'])
 def test_stride1_roles_run_without_im2col(case_name):
     """Round 4: data gradient = gather-down kernel on reversed taps, weight gradient = the streamlined
     MFMA kernel's stride-1 instantiation (no k_im2col / k_col2im detour)."""
