@@ -23,6 +23,10 @@
 // that is not in its MFMA loop gets about one instruction issued per MFMA of the wave it shares
 // the SIMD with (s_memtime trace: boundary 2.6 k cycles alone, 15.8 k next to a multiplying wave
 // -- longer than the 14.4 k cycle MFMA loop it was meant to hide behind).
+//
+// Round 4: the tile geometry (Down2Tile, computed on the host) takes maps that are no powers of two -- any
+// even width (16-byte rows of the big map), any height: a tile is F whole frames or PT_H rows of one frame,
+// lanes past the tile's pixels store nothing (down2_tile); KV = 4 skips the zero taps of a smaller kernel.
 #include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"

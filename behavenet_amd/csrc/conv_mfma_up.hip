@@ -209,8 +209,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Streamlined variant for square small images of 8x8 / 16x16 / 32x32 (the bench layers), 32 output
-// channels per workgroup.  Same tiling, MFMA roles and summation order as k_up_mfma<1, CC> above
+// Streamlined variant for square small images of 8x8 / 16x16 / 32x32 (the bench layers; LGW = 3 / 4 / 5) and,
+// since round 4, for any other small map up to 83 columns wide (LGW = 0: tile geometry in a kernel
+// argument, see UP2<0> below), 32 output channels per workgroup.  Same tiling, MFMA roles and summation order as k_up_mfma<1, CC> above
 // (results are bit-identical); what changed is everything around the MFMAs:
 //  * a VALU instruction that is not an MFMA costs the matrix pipe 6-13 cycles on this chip, and a
 //    wave that is NOT multiplying cannot issue vector-memory instructions at all while another

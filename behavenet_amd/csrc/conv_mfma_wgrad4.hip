@@ -211,7 +211,8 @@ __global__ __launch_bounds__(W4_THREADS, 2) void k_wgrad4_mfma(
 
 // ---------------------------------------------------------------------------------------------
 // Streamlined variant for stages that lie inside one frame (F == 1: Hs * Ws >= 64, the bench
-// layers).  Same tiles, LDS images and MFMA roles as k_wgrad4_mfma above -- and the same partial
+// layers; since round 4 templated on the map WIDTH: 8-44 in steps of 4 with stride 2, 8-64 with stride 1,
+// any height -- see W4S and the GEN / KV / ST / PTH template arguments of the kernel).  Same tiles, LDS images and MFMA roles as k_wgrad4_mfma above -- and the same partial
 // sums, bit for bit -- but nothing is left for the vector ALU inside the multiply loop:
 //  * on this chip every VALU instruction that is not an MFMA takes 6-13 cycles away from the matrix
 //    pipe (tools/lab/issue_probe.hip), LDS reads and scalar instructions none; the loop above spends
