@@ -436,6 +436,16 @@ static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
 }
 static inline size_t taps_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * 25 * sizeof(float)); }
 
+// stride == kernel layers between maps other than 8x8 and 2x2 (the last layer of 64x48 / 192x160 frames): the
+// weight gradient as ONE GEMM over the (permuted) windows instead of the first-generation direct kernel
+static bool s5_wgrad_by_col(const BnGeom& g) {
+    static int mode = -1;                              // BN_S5_WGRAD_COL=0: off (tuning build)
+    if (mode < 0) { const char* e = bn_tune_env("BN_S5_WGRAD_COL"); mode = (e && e[0] == '0') ? 0 : 1; }
+    if (!mode || force_generic() || g.stride != 5 || g.R != 5 || g.S != 5) return false;
+    if (bn_qg2_wgrad_supported(g) || bn_qgemm_supported(g)) return false;
+    return bn_s5_wgrad_plan(g).supported && bn_col_ok(g) && (size_t)g.N * g.Hs * g.Ws >= 512;
+}
+
 // ---- stride-1 gather-up (transposed-conv forward, conv data gradient) as a gather-down with the channel
 // roles swapped and the taps reversed (conv_pad.hip, k_flip_taps): no im2col / col2im
 static bool flip_plan(const BnGeom& g, BnGeom* gf, BnFastPlan* inner) {
@@ -764,6 +774,10 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<2>", st);
         return bn_launch_qgemm_wgrad(small, big, dw, g, accumulate, ws, st);
     }
+    if (!generic && s5_wgrad_by_col(g)) {
+        BnProfScope prof(family, g.Cb, g.Cs, "k_im2col + k_gemm_mfma (dW, stride 5)", st);
+        return bn_launch_col_wgrad(small, big, dw, g, accumulate, ws, ws_bytes, st, db, bias_side, bias_done);
+    }
     if (!generic) {
         const BnFastPlan s5 = bn_s5_wgrad_plan(g);
         if (s5.supported) {
@@ -858,6 +872,7 @@ static size_t role_ws_need(int role, const BnGeom& g) {
     if (taps_plan(role, g, &g5)) return taps_bytes(g) + (role == 2 ? 4096 : 0) + role_ws_need(role, g5);
     if (chan_plan(role, g, &g5)) return chan_bytes(g) + role_ws_need(role, g5);
     if (bn_qgemm_supported(g)) return bn_qgemm_ws_bytes(role, g);
+    if (role == 2 && s5_wgrad_by_col(g)) return bn_col_ws_bytes(g);
     BnFastPlan plan;
     if (role == 0) plan = bn_fast_down_plan(g);
     else if (role == 1) plan = bn_fast_up_plan(g);
