@@ -272,7 +272,7 @@ static PadPlan pad_plan(int role, const BnGeom& g) {
                 if (wq == g.Ws && hmin == g.Hs && g.Hb == 2 * g.Hs && g.Wb == 2 * g.Ws && !oh && !ow) continue;
                 // (gather-up: the small map is the operand that is copied -- 16-byte rows for k_pad2d, or
                 // no copy at all when only the output is larger)
-                if (role == 1 && (wq & 3) && !(wq == g.Ws && hmin == g.Hs)) continue;
+                if (role >= 1 && (wq & 3) && !(wq == g.Ws && hmin == g.Hs)) continue;
                 p.gp = g;
                 p.gp.Hs = hmin; p.gp.Ws = wq; p.gp.Hb = 2 * hmin; p.gp.Wb = 2 * wq; p.gp.pt = p.gp.pl = 1;
                 if ((size_t)g.N * g.Cb * p.gp.Hb * p.gp.Wb * 4 >= 0x7fffffffull) break;
@@ -806,7 +806,8 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
             void* iws = (char*)ws + pp.big_bytes + pp.small_bytes;
             int rc = bn_launch_pad2d(big, bigp, (size_t)g.N * g.Cb, g.Hb, g.Wb, pp.gp.Hb, pp.gp.Wb, pp.oh, pp.ow, st);
             if (rc) return rc;
-            rc = bn_launch_pad2d(small, smallp, (size_t)g.N * g.Cs, g.Hs, g.Ws, pp.gp.Hs, pp.gp.Ws, 0, 0, st);
+            if (pp.gp.Hs == g.Hs && pp.gp.Ws == g.Ws) smallp = const_cast<float*>(small);   // only the big map grows
+            else rc = bn_launch_pad2d(small, smallp, (size_t)g.N * g.Cs, g.Hs, g.Ws, pp.gp.Hs, pp.gp.Ws, 0, 0, st);
             if (rc) return rc;
             if (pp.edge)
                 return bn_launch_edge_wgrad(pp.inner, smallp, bigp, dw, pp.gp, accumulate, iws, st, db,

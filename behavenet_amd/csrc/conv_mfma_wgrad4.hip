@@ -267,7 +267,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     using T = W4S<QQ, ST, PTH>;
     static_assert(ST == 2 || GEN, "stride 1: the general row limits");
     constexpr int Q = T::Q, RW = T::RW, BUFW = T::BUFW;
-    static_assert((Q & 3) == 0 && T::KS >= 1 && T::KS <= 16, "stage geometry");
+    // widths == 2 (mod 4) (round 4: the 12x10 / 8x6 maps of 160- / 96-pixel-wide frames): every other row of a
+    // stage starts in the middle of a k-step -- pixels 2, 3 of such a k-step lie in the next row, whose
+    // lanes (kk >= 2) read through a second base register that is 2 RW - 2 Q words further on; needs an
+    // even number of rows per stage and per map (the row limits of the DMA are per 16-byte group)
+    constexpr bool HALF = (Q & 3) == 2;
+    static_assert(((Q & 3) == 0 || (HALF && ST == 2 && GEN && (T::PT_H & 1) == 0)) && T::KS >= 1 && T::KS <= 16,
+                  "stage geometry");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ablk = wv >> 1, bblk = wv & 1;
@@ -360,6 +366,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         asm volatile("" : "+v"(abase[bf]));
         asm volatile("" : "+v"(bbase[bf]));
     }
+    int bsp_cur = bbase[0] + (kk >= 2 ? 2 * RW - 2 * Q : 0), bsp_oth = bbase[1] + (kk >= 2 ? 2 * RW - 2 * Q : 0);
+    if (HALF) { asm volatile("" : "+v"(bsp_cur)); asm volatile("" : "+v"(bsp_oth)); }
 
     // Operand registers: the 25 B values of a k-step live in ONE set -- kernel row r of the next
     // k-step is read into the registers of row r while the MFMAs of row r+1 run (an MFMA has taken
@@ -372,8 +380,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         asm volatile("v_xor_b32 %0, %1, %2" : "=v"(ao) : "n"(16 * ks), "v"(ab));
         a = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + ao);
     };
-    auto load_row = [&](const int bb, const int ks, const int r, const int half, float (&bq)[25]) __attribute__((always_inline)) {
+    auto load_row = [&](const int bb_in, const int bs_in, const int ks, const int r, const int half, float (&bq)[25]) __attribute__((always_inline)) {
         const int pj = (4 * ks) / Q, q0 = (4 * ks) - pj * Q;
+        const int bb = (HALF && q0 + 4 > Q) ? bs_in : bb_in;       // k-step across a row boundary
         const float* bp = smem + bb + (ST * pj + r) * RW + ST * q0;
         if (ST == 1) {
             // consecutive words of either parity: 4-byte reads
@@ -387,12 +396,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
             bq[r * 5 + 1] = c1.x; bq[r * 5 + 2] = c1.y; bq[r * 5 + 3] = c2.x; bq[r * 5 + 4] = c2.y;
         }
     };
-    auto stage_body = [&](const int ab, const int bb, const int nbuf, const bool more, const int n0n,
+    auto stage_body = [&](const int ab, const int bb, const int bs, const int nbuf, const bool more, const int n0n,
                           const int p0n) __attribute__((always_inline)) {
         float av[2], bv[25];
         load_a(ab, 0, av[0]);
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { load_row(bb, 0, r, 0, bv); load_row(bb, 0, r, 1, bv); }
+        for (int r = 0; r < 5; ++r) { load_row(bb, bs, 0, r, 0, bv); load_row(bb, bs, 0, r, 1, bv); }
         constexpr int KS = T::KS;
         static_assert(NDMA <= KS, "one DMA slot per k-step");
 #pragma unroll
@@ -408,8 +417,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
                 if (BIAS == 2 && tp == 12) bsum += bv[11] + bv[12];
                 // row r-1 of the NEXT k-step goes into its registers during row r (r >= 1); row 4
                 // follows during row 0 of the next k-step
-                if (r >= 1 && ks + 1 < KS && (sx == 0 || sx == 2)) load_row(bb, ks + 1, r - 1, sx >> 1, bv);
-                if (r == 0 && ks >= 1 && (sx == 0 || sx == 2)) load_row(bb, ks, 4, sx >> 1, bv);
+                if (r >= 1 && ks + 1 < KS && (sx == 0 || sx == 2)) load_row(bb, bs, ks + 1, r - 1, sx >> 1, bv);
+                if (r == 0 && ks >= 1 && (sx == 0 || sx == 2)) load_row(bb, bs, ks, 4, sx >> 1, bv);
                 if (r == 2 && sx == 4 && ks + 1 < KS) load_a(ab, ks + 1, av[(ks + 1) & 1]);
                 if (r == 3 && sx == 4 && ks < NDMA) {
                     if (more) issue_dma(ks, nbuf, n0n, p0n);
@@ -446,10 +455,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         __syncthreads();
         const int nx = st + splits;
         const int fx = frame_of(nx);
-        stage_body(ab_cur, bb_cur, cur ^ 1, nx < n_stages, fx, row_of(nx, fx));
+        stage_body(ab_cur, bb_cur, bsp_cur, cur ^ 1, nx < n_stages, fx, row_of(nx, fx));
         cur ^= 1;
         int tmp = ab_cur; ab_cur = ab_oth; ab_oth = tmp;
         tmp = bb_cur; bb_cur = bb_oth; bb_oth = tmp;
+        if (HALF) { tmp = bsp_cur; bsp_cur = bsp_oth; bsp_oth = tmp; }
     }
 
     if (BIAS != 0) {
@@ -543,11 +553,12 @@ static bool wgrad4s_ok(const BnGeom& g, const Wgrad4Tile& t) {
 
 // rows of a stage of the GEN instantiations (W4S::PT_H)
 static inline int w4g_pth(const BnGeom& g) {
+    if ((g.Ws & 3) == 2) return (W4_TPX / g.Ws) & ~1;          // an even number of rows (W4S<Q, 2, PTH>)
     return (g.stride == 2 && g.Ws == 8 && g.Hs <= 4) ? 4 : W4_TPX / g.Ws;
 }
 // maps that are no powers of two on the streamlined kernel (GEN instantiations): widths the kernel is
 // instantiated for, any height, big map exactly twice the small one
-static const int W4G_WIDTHS[] = {8, 12, 16, 20, 24, 28, 32, 36, 40, 44};
+static const int W4G_WIDTHS[] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40, 44};
 static bool wgrad4g_ok(const BnGeom& g) {
     static int disabled = -1;                          // BN_WGRAD4G=0: off
     if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4G"); disabled = (e && e[0] == '0') ? 1 : 0; }
@@ -556,6 +567,7 @@ static bool wgrad4g_ok(const BnGeom& g) {
     bool width = false;
     for (int q : W4G_WIDTHS) width = width || q == g.Ws;
     if (!width) return false;
+    if ((g.Ws & 3) == 2 && (g.Hs & 1)) return false;   // half-row k-steps: rows come in pairs
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;   // 32-bit offsets
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
     const int tpf = (g.Hs + w4g_pth(g) - 1) / w4g_pth(g);
@@ -713,7 +725,14 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     if (g.Ws == QV && t.bias_side == B)                                                          \
         rc = launch_wgrad4s<QV, B, true, 5>(grid, st, small, big, (float*)ws, bias_part, g,      \
                                          t.n_stages, t.splits, magic, t.nbias);
-        if (g.Ws == 8 && pth == 4) {
+        if ((g.Ws & 3) == 2) {
+#define W4H_CASE(QV, B)                                                                          \
+    if (g.Ws == QV && t.bias_side == B)                                                          \
+        rc = launch_wgrad4s<QV, B, true, 5, 2, ((W4_TPX / QV) & ~1)>(grid, st, small, big, (float*)ws, \
+                                                 bias_part, g, t.n_stages, t.splits, magic, t.nbias);
+            W4H_CASE(6, 0) W4H_CASE(6, 1) W4H_CASE(10, 0) W4H_CASE(10, 1) W4H_CASE(14, 0) W4H_CASE(14, 1)
+#undef W4H_CASE
+        } else if (g.Ws == 8 && pth == 4) {
             if (t.bias_side == 0)
                 rc = launch_wgrad4s<8, 0, true, 5, 2, 4>(grid, st, small, big, (float*)ws, bias_part, g,
                                                           t.n_stages, t.splits, magic, t.nbias);
