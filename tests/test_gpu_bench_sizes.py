@@ -260,6 +260,97 @@ def _wg(fn, xd, dyd, wd, bd, geom):
     return dw, db
 
 
+@pytest.mark.parametrize('dim, n_frames', [([1, 64, 48], 256), ([2, 192, 160], 208)],
+                         ids=['1x64x48_b256', '2x192x160_b208'])
+def test_whole_model_off_the_benchmark_shape_vs_oracle(dim, n_frames):
+    """Round 4: the frame sizes whose maps are no powers of two, at the batch sizes bench.py times them
+    (two chunks: 200 + 56 / 200 + 8), through ``AE.loss`` -- the direct runtime-geometry kernels, their
+    zero-padded neighbours and the edge layers' tiles in one step.  Loss against the fp32 oracle's chunk
+    loop, every parameter gradient against the float64 oracle on the device's LeakyReLU branch pattern."""
+    from behavenet_amd.models import AE
+    from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+    from oracle import ref_cpu
+    from tests.branches import record_branches, BranchReplay
+    from tests.golden_utils import base_hparams, make_frames
+    from tests.test_gpu_model import grads_close_on_same_branches
+
+    arch = load_handcrafted_arch(list(dim), 12, None, check_memory=False)
+    torch.manual_seed(0)
+    hip = AE(base_hparams(arch, 'ae')).to(DEV)
+    torch.manual_seed(0)
+    ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae')).double()
+    x = torch.from_numpy(make_frames(n_frames, dim, seed=23))
+    hip.train()
+    hip.zero_grad(set_to_none=True)
+    with record_branches(hip) as rec:
+        lh = hip.loss({'images': x.to(DEV)[None]}, dataset=0, accumulate_grad=True)['loss']
+    with BranchReplay(rec) as br:
+        l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True)['loss']
+    br.assert_only_ties()
+    assert lh == pytest.approx(l64, rel=1e-5)
+    grads_close_on_same_branches(hip, ora64, 'AE %dx%dx%d batch %d' % (dim[0], dim[1], dim[2], n_frames))
+
+
+@pytest.mark.parametrize('which', ['ae_arch_2', 'maxpool', 'batch_norm'])
+def test_whole_model_other_architectures_at_bench_batch_vs_oracle(which):
+    """Round 4, at 1x128x128 and 208 frames (chunks 200 + 8): the shipped ae_arch_2.json (4x4 kernels on
+    the KV = 4 instantiations, a stride-1 layer without im2col), the max-pooling test architecture
+    (stride-1 roles: reversed taps, k_wgrad4s<64, stride 1>, k_wgrad_c1<1>) and the default architecture
+    with batch norm (one-pass statistics per chunk, no y read-back) -- loss and every gradient against
+    the float64 oracle on the device's LeakyReLU branch pattern."""
+    import os
+    from behavenet_amd.models import AE
+    from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
+    from oracle import ref_cpu
+    from tests.branches import record_branches, BranchReplay
+    from tests.golden_utils import base_hparams, make_frames
+    from tests.test_gpu_model import grads_close_on_same_branches
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (max pooling: 64 frames.  The float64 oracle replays the device's LeakyReLU branches, not its
+    # pooling winners: at 200 frames ~3 of the 20 M pooling windows have their two largest values within
+    # fp32 rounding, the oracle routes those gradients elsewhere and the linear layers' gradients move
+    # by 1e-2 of their maximum -- measured, round 4; with this seed 64 frames have no such window, which
+    # the test asserts before it compares gradients)
+    dim, n_frames = [1, 128, 128], (64 if which == 'maxpool' else 208)
+    js = {'ae_arch_2': os.path.join(repo, 'behavenet_amd', 'configs', 'ae_jsons', 'ae_arch_2.json'),
+          'maxpool': os.path.join(repo, 'tests', 'golden', 'arch_maxpool.json'), 'batch_norm': None}[which]
+    extra = {'ae_batch_norm': True} if which == 'batch_norm' else None
+    arch = load_handcrafted_arch(list(dim), 12, js, check_memory=False)
+    torch.manual_seed(0)
+    hip = AE(base_hparams(arch, 'ae', extra)).to(DEV)
+    torch.manual_seed(0)
+    ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae', extra)).double()
+    x = torch.from_numpy(make_frames(n_frames, dim, seed=29))
+    hip.train()
+    ora64.train()
+    hip.zero_grad(set_to_none=True)
+    with record_branches(hip) as rec:
+        lh = hip.loss({'images': x.to(DEV)[None]}, dataset=0, accumulate_grad=True)['loss']
+    with BranchReplay(rec) as br:
+        l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True)['loss']
+    br.assert_only_ties()
+    assert lh == pytest.approx(l64, rel=1e-5)
+    if which == 'maxpool':
+        with torch.no_grad():
+            _, idx_h, _ = hip.encoding(x.to(DEV), dataset=0)
+            _, idx_o, _ = ora64.encoding(x.double(), dataset=0)
+        keys = sorted(idx_h.keys()) if isinstance(idx_h, dict) else range(len(idx_h))
+        for k in keys:
+            assert int((idx_h[k].cpu().long() != idx_o[k].long()).sum()) == 0, 'pooling winners differ'
+    names = {k for k, _ in hip.named_parameters()}
+    from tests.test_gpu_model import _bias_before_batchnorm
+    for (k, ph), (_, po) in zip(hip.named_parameters(), ora64.named_parameters()):
+        if po.grad is None or _bias_before_batchnorm(k, names):
+            continue            # (a conv bias in front of a batch norm: analytically zero on both sides)
+        w = po.grad.numpy()
+        err = np.abs(ph.grad.cpu().double().numpy() - w).max() / max(np.abs(w).max(), 1e-30)
+        # batch norm: the statistics of the 8-frame chunk's deepest layers (2x2 maps: 32 values per
+        # channel) amplify fp32 rounding; the bar there is the golden batch-norm cases' 2e-4
+        tol = 2e-4 if which == 'batch_norm' else 2e-5
+        assert err <= tol, 'AE %s batch %d grad %s: normalised max err %.3e' % (which, n_frames, k, err)
+
+
 def test_whole_model_batch256_loss_and_gradients_vs_oracle():
     """BASELINE configs[1] at full size through ``AE.loss`` (one forward / one backward pass over
     256 frames, the reference's 200 + 56 chunk normalisation; reference aes.py:722-773): loss
