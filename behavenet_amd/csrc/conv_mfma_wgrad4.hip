@@ -259,13 +259,19 @@ __device__ __forceinline__ void w4_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 // (out-of-range source offset = 0.0f) by a per-group row number against a per-stage scalar limit.
 // KV = 4: taps with r >= 4 or s >= 4 belong to the zero extension of a smaller kernel (BnGeom::KV): their
 // products are skipped and their (zero) tiles are dropped again by the caller's crop of dW
-template <int QQ, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0>
+// CW (round 4): COLUMN WINDOWS -- a map wider than any instantiated width (48 = 2 x 24, 64 = 2 x 32, 96 = 4 x 24:
+// the first matrix-core layer of 192- / 256-pixel-wide frames) is walked in windows of QQ columns: a stage is
+// PT_H rows of ONE window (its small rows lie g.Ws apart, its big patch starts 2 cb QQ columns into the row and
+// has real neighbours on the inner sides: only the first window's left groups and the last window's right
+// groups are padding).  `ncb` windows per row; stages are ordered (frame, window, row block).
+template <int QQ, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0, bool CW = false>
 __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
-    float* __restrict__ bias_part, BnGeom g, int n_stages, int splits, int lg_tpf, int nbias) {
+    float* __restrict__ bias_part, BnGeom g, int n_stages, int splits, int lg_tpf, int nbias, int ncb) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using T = W4S<QQ, ST, PTH>;
     static_assert(ST == 2 || GEN, "stride 1: the general row limits");
+    static_assert(!CW || (GEN && ST == 2 && (QQ & 3) == 0), "column windows: general stride-2 stages");
     constexpr int Q = T::Q, RW = T::RW, BUFW = T::BUFW;
     // widths == 2 (mod 4) (round 4: the 12x10 / 8x6 maps of 160- / 96-pixel-wide frames): every other row of a
     // stage starts in the middle of a k-step -- pixels 2, 3 of such a k-step lie in the next row, whose
@@ -295,21 +301,25 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     const __amdgpu_buffer_rsrc_t rs_small = __builtin_amdgcn_make_buffer_rsrc(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
     const int pt_rows = ST == 2 ? 1 : g.pt;                // patch row 0 = image row ST p0 - pt_rows
+    // (CW: also from W4_X0 columns to the left, so that a window's left neighbour groups have offsets >= 0)
+    const int lead = pt_rows * g.Wb + (CW ? W4_X0 : 0);
     const __amdgpu_buffer_rsrc_t rs_big = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(big - pt_rows * g.Wb), 0, (int)(((size_t)g.N * g.Cb * HWb + pt_rows * g.Wb) * 4), 0x00020000);
+        (void*)(big - lead), 0, (int)(((size_t)g.N * g.Cb * HWb + lead) * 4), 0x00020000);
     int soff[T::NSM], srow = 0;
 #pragma unroll
     for (int j = 0; j < T::NSM; ++j) {
         const int e = tid + W4_THREADS * j;
         const int a = e >> 4;
         const int pix0 = 4 * ((e & 15) ^ (a & 15));                  // swizzled source group
-        soff[j] = (a0 + a < g.Cs && pix0 < 4 * T::KS) ? ((a0 + a) * PQ + pix0) * 4 : W4_OOB;
+        // (a stage's rows are g.Ws apart: the whole row, or one window of it)
+        const int spix = CW ? (pix0 / Q) * g.Ws + (pix0 - (pix0 / Q) * Q) : pix0;
+        soff[j] = (a0 + a < g.Cs && pix0 < 4 * T::KS) ? ((a0 + a) * PQ + spix) * 4 : W4_OOB;
         srow |= (pix0 / Q) << (8 * j);                               // GEN: its row inside the stage
     }
     // rows above the image exist only in a frame's first tile (patch row 0), rows below it only in
     // its last tile (the last two patch rows; Hb == 2 Hs): two class bits per group, all groups of
     // a thread packed into one register
-    int voff[T::NBIG], rowcls = 0, ypack[2] = {0, 0};
+    int voff[T::NBIG], rowcls = 0, ypack[2] = {0, 0}, colcls = 0;
     static_assert(T::NBIG <= 8, "row numbers of a thread's groups in two registers");
 #pragma unroll
     for (int j = 0; j < T::NBIG; ++j) {
@@ -317,14 +327,25 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         const int b = e / T::GPB, within = e - b * T::GPB;
         const int y = within / T::C4, c4 = within - y * T::C4;
         const int wb = 4 * c4 - W4_X0;
-        const bool ok = (e < T::BIGG) && (within < T::ROWG) && (b0 + b < g.Cb) && wb >= 0 && wb < g.Wb;
-        voff[j] = ok ? (((b0 + b) * g.Hb + y) * g.Wb + wb) * 4 : W4_OOB;
+        if constexpr (CW) {
+            // columns relative to the window (2 cb Q columns into the row): left of it only the first
+            // window is padding, from 2 Q on only the last one
+            const bool ok = (e < T::BIGG) && (within < T::ROWG) && (b0 + b < g.Cb);
+            voff[j] = ok ? (((b0 + b) * g.Hb + y) * g.Wb + wb + W4_X0) * 4 : W4_OOB;
+            colcls |= ((wb < 0 ? 1 : 0) | (wb >= 2 * Q ? 2 : 0)) << (2 * j);
+        } else {
+            const bool ok = (e < T::BIGG) && (within < T::ROWG) && (b0 + b < g.Cb) && wb >= 0 && wb < g.Wb;
+            voff[j] = ok ? (((b0 + b) * g.Hb + y) * g.Wb + wb) * 4 : W4_OOB;
+        }
         rowcls |= ((y == 0 ? 1 : 0) | (y >= T::IH - 2 ? 2 : 0)) << (2 * j);
         ypack[j >> 2] |= (y & 255) << (8 * (j & 3));
     }
     // one DMA instruction of stage `st` into image `buf`: d < NSM small tile, else big tile
-    auto issue_dma = [&](const int d, const int buf, const int n0, const int p0) __attribute__((always_inline)) {
+    auto issue_dma = [&](const int d, const int buf, const int n0w, const int p0) __attribute__((always_inline)) {
         float* sl = smem + buf * BUFW;
+        // CW: n0w = frame * ncb + window
+        const int n0 = CW ? n0w / ncb : n0w;
+        const int cb = CW ? n0w - n0 * ncb : 0;
         if (d < T::NSM) {
             int so = soff[d];
             if constexpr (GEN) {
@@ -332,7 +353,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
                 const int row = (srow >> (8 * d)) & 255;
                 so = row < g.Hs - p0 ? so : W4_OOB;
             }
-            w4_dma16(rs_small, sl + 4 * (W4_THREADS * d + 64 * wv), so, (n0 * g.Cs * PQ + p0 * Q) * 4);
+            w4_dma16(rs_small, sl + 4 * (W4_THREADS * d + 64 * wv), so,
+                     (n0 * g.Cs * PQ + p0 * (CW ? g.Ws : Q) + cb * Q) * 4);
         } else {
             const int j = d - T::NSM;
             if (W4_THREADS * j + 64 * wv < T::BIGG) {                 // wave-uniform
@@ -343,13 +365,17 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
                     const int y = (ypack[j >> 2] >> (8 * (j & 3))) & 255;
                     const int ymin = pt_rows - ST * p0, ylim = g.Hb + pt_rows - ST * p0;
                     vo = (y >= ymin && y < ylim) ? voff[j] : W4_OOB;
+                    if constexpr (CW) {
+                        const int cmask = ((cb == 0 ? 1 : 0) | (cb == ncb - 1 ? 2 : 0)) << (2 * j);
+                        vo = (colcls & cmask) ? W4_OOB : vo;
+                    }
                 } else {
                     // rows above the image (first tile) and below it (last tile) read 0.0f
                     const int smask = ((p0 == 0 ? 1 : 0) | (p0 + T::PT_H >= g.Hs ? 2 : 0)) << (2 * j);
                     vo = (rowcls & smask) ? W4_OOB : voff[j];
                 }
                 w4_dma16(rs_big, sl + T::SMALLW + 4 * (W4_THREADS * j + 64 * wv), vo,
-                         (n0 * g.Cb * g.Hb + ST * p0) * g.Wb * 4);
+                         ((n0 * g.Cb * g.Hb + ST * p0) * g.Wb + 2 * cb * Q) * 4);
             }
         }
     };
@@ -551,8 +577,17 @@ static bool wgrad4s_ok(const BnGeom& g, const Wgrad4Tile& t) {
     return true;
 }
 
+// column windows (CW instantiations): the widest instantiated window that divides the map's width, 0 = none
+static inline int w4g_window(const BnGeom& g) {
+    static const int wins[] = {44, 40, 36, 32, 28, 24};
+    if (g.stride != 2 || g.Ws <= 44 || (g.Ws & 3)) return 0;
+    for (int q : wins)
+        if (g.Ws % q == 0 && g.Ws / q <= 8) return q;
+    return 0;
+}
 // rows of a stage of the GEN instantiations (W4S::PT_H)
 static inline int w4g_pth(const BnGeom& g) {
+    if (w4g_window(g)) return W4_TPX / w4g_window(g);
     if ((g.Ws & 3) == 2) return (W4_TPX / g.Ws) & ~1;          // an even number of rows (W4S<Q, 2, PTH>)
     return (g.stride == 2 && g.Ws == 8 && g.Hs <= 4) ? 4 : W4_TPX / g.Ws;
 }
@@ -564,14 +599,15 @@ static bool wgrad4g_ok(const BnGeom& g) {
     if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4G"); disabled = (e && e[0] == '0') ? 1 : 0; }
     if (disabled) return false;
     if (g.pt != 1 || g.pl != 1 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return false;
-    bool width = false;
+    bool width = w4g_window(g) != 0;
     for (int q : W4G_WIDTHS) width = width || q == g.Ws;
     if (!width) return false;
     if ((g.Ws & 3) == 2 && (g.Hs & 1)) return false;   // half-row k-steps: rows come in pairs
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;   // 32-bit offsets
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
     const int tpf = (g.Hs + w4g_pth(g) - 1) / w4g_pth(g);
-    return (size_t)g.N * tpf < (1u << 20);             // multiply-high division of the stage index
+    const int ncb = w4g_window(g) ? g.Ws / w4g_window(g) : 1;
+    return (size_t)g.N * tpf * ncb < (1u << 20);       // multiply-high division of the stage index
 }
 // stride 1 (5x5 taps, offsets up to 4): power-of-two widths up to 64, any height
 static bool wgrad4g1_ok(const BnGeom& g) {
@@ -591,7 +627,8 @@ static bool wgrad4g1_ok(const BnGeom& g) {
 }
 static int wgrad4g_stages(const BnGeom& g) {
     const int pth = w4g_pth(g);
-    return g.N * ((g.Hs + pth - 1) / pth);
+    const int ncb = (g.stride == 2 && w4g_window(g)) ? g.Ws / w4g_window(g) : 1;
+    return g.N * ncb * ((g.Hs + pth - 1) / pth);
 }
 
 BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
@@ -623,9 +660,13 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
         p.variant = 5;
         p.d = wgrad4_splits(g, t);
         p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
-        static char names_g[16][40];
-        const int slot = (g.Ws / 4) & 15;
-        snprintf(names_g[slot], sizeof(names_g[slot]), "k_wgrad4s_mfma<%d, gen>", g.Ws);
+        static char names_g[32][64];
+        const int slot = (g.Ws / 4) & 31;
+        if (w4g_window(g))
+            snprintf(names_g[slot], sizeof(names_g[slot]), "k_wgrad4s_mfma<%d, gen> x %d windows", w4g_window(g),
+                     g.Ws / w4g_window(g));
+        else
+            snprintf(names_g[slot], sizeof(names_g[slot]), "k_wgrad4s_mfma<%d, gen>", g.Ws);
         p.kernel_name = names_g[slot];
         return p;
     }
@@ -662,22 +703,22 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
     return 0;
 }
 
-template <int Q, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0>
+template <int Q, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0, bool CW = false>
 static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const float* big,
                           float* part, float* bias_part, const BnGeom& g, int n_stages, int splits,
-                          int lg_tpf, int nbias) {
+                          int lg_tpf, int nbias, int ncb = 1) {
     using TS = W4S<Q, ST, PTH>;
     static_assert((size_t)2 * TS::BUFW * 4 <= W4_MAX_LDS, "two stage images in LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH, CW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, W4_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     constexpr size_t lds = (size_t)2 * TS::BUFW * 4;
-    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH>), grid, dim3(W4_THREADS), lds, st, small, big, part,
-                       bias_part, g, n_stages, splits, lg_tpf, nbias);
+    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH, CW>), grid, dim3(W4_THREADS), lds, st, small, big, part,
+                       bias_part, g, n_stages, splits, lg_tpf, nbias, ncb);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -725,7 +766,16 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     if (g.Ws == QV && t.bias_side == B)                                                          \
         rc = launch_wgrad4s<QV, B, true, 5>(grid, st, small, big, (float*)ws, bias_part, g,      \
                                          t.n_stages, t.splits, magic, t.nbias);
-        if ((g.Ws & 3) == 2) {
+        if (w4g_window(g)) {
+            const int qw = w4g_window(g), ncb = g.Ws / qw;
+#define W4W_CASE(QV, B)                                                                          \
+    if (qw == QV && t.bias_side == B)                                                            \
+        rc = launch_wgrad4s<QV, B, true, 5, 2, 0, true>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                        t.n_stages, t.splits, magic, t.nbias, ncb);
+            W4W_CASE(24, 0) W4W_CASE(24, 1) W4W_CASE(28, 0) W4W_CASE(28, 1) W4W_CASE(32, 0) W4W_CASE(32, 1)
+            W4W_CASE(36, 0) W4W_CASE(36, 1) W4W_CASE(40, 0) W4W_CASE(40, 1) W4W_CASE(44, 0) W4W_CASE(44, 1)
+#undef W4W_CASE
+        } else if ((g.Ws & 3) == 2) {
 #define W4H_CASE(QV, B)                                                                          \
     if (g.Ws == QV && t.bias_side == B)                                                          \
         rc = launch_wgrad4s<QV, B, true, 5, 2, ((W4_TPX / QV) & ~1)>(grid, st, small, big, (float*)ws, \

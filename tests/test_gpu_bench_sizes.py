@@ -260,11 +260,12 @@ def _wg(fn, xd, dyd, wd, bd, geom):
     return dw, db
 
 
-@pytest.mark.parametrize('dim, n_frames', [([1, 64, 48], 256), ([2, 192, 160], 208)],
-                         ids=['1x64x48_b256', '2x192x160_b208'])
+@pytest.mark.parametrize('dim, n_frames', [([1, 64, 48], 256), ([2, 192, 160], 208), ([1, 192, 192], 96)],
+                         ids=['1x64x48_b256', '2x192x160_b208', '1x192x192_b96'])
 def test_whole_model_off_the_benchmark_shape_vs_oracle(dim, n_frames):
     """Round 4: the frame sizes whose maps are no powers of two, at the batch sizes bench.py times them
-    (two chunks: 200 + 56 / 200 + 8), through ``AE.loss`` -- the direct runtime-geometry kernels, their
+    (two chunks: 200 + 56 / 200 + 8; 1x192x192 -- the frame size of the reference's IBL example,
+    examples/msps-vae/ibl_ephys_params.json: 48x48 maps in column windows -- at 96 frames), through ``AE.loss`` -- the direct runtime-geometry kernels, their
     zero-padded neighbours and the edge layers' tiles in one step.  Loss against the fp32 oracle's chunk
     loop, every parameter gradient against the float64 oracle on the device's LeakyReLU branch pattern."""
     from behavenet_amd.models import AE

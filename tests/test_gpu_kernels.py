@@ -116,6 +116,11 @@ CONV_CASES = [
     ('np2_21x28', 3, 32, 42, 56, 64, 5, 2, (1, 2), (1, 2)),
     ('np2_5x36', 4, 32, 10, 72, 96, 5, 2, (1, 2), (1, 2)),
     ('np2_48x40_n5', 5, 32, 96, 80, 64, 5, 2, (1, 2), (1, 2)),
+    # maps wider than any instantiated weight-gradient width: column windows (48 = 2 x 24, 64 = 2 x 32, 96 = 3 x 32)
+    ('cw_48x48', 3, 32, 96, 96, 64, 5, 2, (1, 2), (1, 2)),
+    ('cw_30x64', 2, 16, 60, 128, 64, 5, 2, (1, 2), (1, 2)),
+    ('cw_9x96', 3, 16, 18, 192, 32, 5, 2, (1, 2), (1, 2)),
+    ('cw_5x56_n7', 7, 32, 10, 112, 32, 5, 2, (1, 2), (1, 2)),
 ]
 
 
@@ -219,6 +224,8 @@ CONVT_CASES = [
     ('np2_21x28', 3, 64, 21, 28, 32, 5, 2, 0, (1, 2, 1, 2), 0),
     ('np2_5x36', 4, 96, 5, 36, 32, 5, 2, 0, (1, 2, 1, 2), 0),
     ('np2_48x40_n5', 5, 64, 48, 40, 32, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('cw_48x48', 3, 64, 48, 48, 32, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('cw_12x72', 4, 32, 12, 72, 16, 5, 2, 0, (1, 2, 1, 2), 0),
 ]
 
 
