@@ -212,6 +212,10 @@ def secondary_configs(hp_ae, feed_rates=True):
     out.append(geometry_step(None, [2, 192, 160],
                              'default architecture on 2x192x160 frames (48x40 / 24x20 / 12x10 maps '
                              'directly on the stride-2 families since round 4; edge layers on tiles)'))
+    out.append(geometry_step(None, [1, 192, 192],
+                             'default architecture on 1x192x192 frames (the frame size of the reference\'s '
+                             'examples/msps-vae/ibl_ephys_params.json; 48x48 maps: weight gradient in '
+                             'column windows)'))
     out.append(geometry_step(None, [1, 128, 128],
                              'default architecture with ae_batch_norm = 1 on 1x128x128 (per-chunk '
                              'statistics inside one pass; momentum None = cumulative average, the '
