@@ -62,7 +62,9 @@ __device__ __forceinline__ void d2_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 struct Down2Tile {
     int F, PT_H, PTQ;             // frames / small-map rows of a workgroup tile, PT_H * Ws
     int IH, RW, FS, CHS;          // patch rows per frame, row stride, per-frame / per-channel floats
-    int tiles_per_frame;
+    int UPF;                      // units per frame: a tile is F UNITS of PT_H rows -- whole frames (UPF = 1),
+                                  // the row blocks of one frame (F = 1), or (round 4) row blocks of adjacent
+                                  // frames: a 12x12 map fills 3 x 72 = 216 of 256 pixels instead of 144
     int groups;                   // 16-byte groups of one chunk image (D2_CC * CHS / 4)
     int xbuf_floats;              // one LDS input image (whole wave rows)
     float inv_chs4, inv_fs4, inv_c4;
@@ -103,10 +105,8 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
 
-    const int grp = blockIdx.x / t.tiles_per_frame;
-    const int rowt = blockIdx.x - grp * t.tiles_per_frame;
-    const int n0 = grp * t.F;
-    const int p0 = rowt * t.PT_H;
+    const int u0 = blockIdx.x * t.F;                 // first unit of this tile
+    const int n0 = u0 / t.UPF;                       // its frame: the scalar part of the DMA offsets
     const int m0 = blockIdx.y * TM;
     const int Q = g.Ws, PQ = g.Hs * g.Ws;
     const int HW = g.Hb * g.Wb;
@@ -125,10 +125,11 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
         const int f = pix / t.PTQ;
         const int rem = pix - f * t.PTQ;
         const int pj = rem / Q, qj = rem - pj * Q;
+        const int un = (u0 + f) / t.UPF, up0 = (u0 + f - un * t.UPF) * t.PT_H;     // the unit's frame, first row
         // pair 0 = columns (2q-2, 2q-1) of the image = LDS columns 2q+2, 2q+3
         base[nr] = f * t.FS + (2 * pj) * t.RW + 2 * qj + (D2_X0 - 2) + kk * t.CHS;
-        pvalid[nr] = inside && (n0 + f) < g.N && (p0 + pj) < g.Hs;
-        opix[nr] = (size_t)(n0 + f) * g.Cs * PQ + (size_t)(p0 + pj) * Q + qj;
+        pvalid[nr] = inside && un < g.N && (up0 + pj) < g.Hs;
+        opix[nr] = (size_t)un * g.Cs * PQ + (size_t)(up0 + pj) * Q + qj;
     }
 
     // chunk-invariant part of this thread's DMA groups: byte offset relative to channel c0 of
@@ -146,10 +147,10 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
         const int r2 = within - f * (t.FS / 4);
         const int y = (int)(((float)r2 + 0.5f) * t.inv_c4);
         const int c4 = r2 - y * C4;
-        const int hb = 2 * p0 - g.pt + y, wb = 4 * c4 - D2_X0;
-        const bool ok = e < t.groups && (n0 + f < g.N) && hb >= 0 && hb < g.Hb && wb >= 0 &&
-                        wb < g.Wb;
-        xoff[k] = ok ? ((f * g.Cb + cc) * HW + hb * g.Wb + wb) * 4 : 0x7fffffff;
+        const int un = (u0 + f) / t.UPF, up0 = (u0 + f - un * t.UPF) * t.PT_H;
+        const int hb = 2 * up0 - g.pt + y, wb = 4 * c4 - D2_X0;
+        const bool ok = e < t.groups && un < g.N && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+        xoff[k] = ok ? (((un - n0) * g.Cb + cc) * HW + hb * g.Wb + wb) * 4 : 0x7fffffff;
     }
     // weight slice of a chunk: rows m0.. of W[m][c0..c0+3][25 taps] = 100 contiguous words per
     // output channel, copied in that order (25 groups per row).  A lane later reads word
@@ -418,34 +419,45 @@ static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* ld
     // rows of one (the rows of a frame spread evenly over its tiles); powers of two fill it exactly
     if (g.Ws < 4 || (g.Ws & 1) || g.Ws > TP || g.Hs < 1) return false;
     const bool pow2 = ilog2_exact_d2(g.Ws) >= 0 && ilog2_exact_d2(g.Hs) >= 0;
-    const int PQ = g.Hs * g.Ws;
     int rw = 2 * g.Ws + 8;
     // the 32 pixels of a half wave (several image rows when Ws < 32 or no power of two) cover the 64
     // banks once with their 8-byte reads if the row stride == Ws (mod 32)
     if ((g.Ws < 32 || !pow2) && (g.Ws & 3) == 0)
         while ((rw & 31) != (g.Ws & 31)) rw += 4;
-    // an LDS image that does not fit: first the plain row stride (bank conflicts on the operand reads
-    // cost less than idle pixels of the tile), then fewer frames / rows per tile
-    auto try_fit = [&](int stride, bool reduce) {
-        t->RW = stride;
-        t->F = PQ >= TP ? 1 : TP / PQ;
-        int rows = PQ >= TP ? TP / g.Ws : g.Hs;
-        for (;;) {
-            t->tiles_per_frame = (g.Hs + rows - 1) / rows;
-            t->PT_H = (g.Hs + t->tiles_per_frame - 1) / t->tiles_per_frame;
-            t->IH = 2 * (t->PT_H - 1) + 5;
-            t->FS = t->IH * stride;
-            t->CHS = t->F * t->FS;
-            t->groups = D2_CC * t->CHS / 4;
-            t->xbuf_floats = 4 * ((t->groups + 63) & ~63);
-            if (t->groups <= D2_THREADS * D2_XK && t->xbuf_floats <= D2_XBUF_FLOATS) return true;
-            if (!reduce) return false;
-            if (t->F > 1) --t->F;
-            else if (rows > 1) --rows;
-            else return false;
-        }
+    // units of PT_H rows, F of them per tile: among the splits of a frame into UPF row blocks the one that
+    // fills the tile best (ties: fewer blocks = less halo); an LDS image that does not fit first drops the
+    // bank-friendly row stride (conflicts on the operand reads cost less than idle pixels), then units
+    auto fits = [&](int pth, int stride, int F) {
+        t->RW = stride; t->PT_H = pth; t->F = F;
+        t->IH = 2 * (pth - 1) + 5;
+        t->FS = t->IH * stride;
+        t->CHS = F * t->FS;
+        t->groups = D2_CC * t->CHS / 4;
+        t->xbuf_floats = 4 * ((t->groups + 63) & ~63);
+        return t->groups <= D2_THREADS * D2_XK && t->xbuf_floats <= D2_XBUF_FLOATS;
     };
-    if (!try_fit(rw, false) && !try_fit(2 * g.Ws + 8, false) && !try_fit(2 * g.Ws + 8, true)) return false;
+    float best = 0.f;
+    int b_upf = 0, b_pth = 0, b_F = 0, b_rw = 0;
+    for (int upf = 1; upf <= g.Hs; ++upf) {
+        const int pth = (g.Hs + upf - 1) / upf;
+        if ((g.Hs + pth - 1) / pth != upf || pth * g.Ws > TP) continue;
+        // (maps that are powers of two keep the tiles they were measured with: whole frames or row blocks)
+        int F = TP / (pth * g.Ws);
+        if (pow2 && upf > 1) F = 1;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int stride = pass == 0 ? rw : 2 * g.Ws + 8;
+            int Fp = F;
+            while (Fp >= 1 && !fits(pth, stride, Fp)) { if (pass == 0) { Fp = 0; break; } --Fp; }
+            if (Fp < 1) continue;
+            const float fill = (float)(Fp * pth * g.Ws) / (float)TP * (float)g.Hs / (float)(upf * pth);
+            if (fill > best + 1e-6f) { best = fill; b_upf = upf; b_pth = pth; b_F = Fp; b_rw = stride; }
+            break;
+        }
+        if (best >= 0.999f) break;
+    }
+    if (b_upf == 0) return false;
+    fits(b_pth, b_rw, b_F);
+    t->UPF = b_upf;
     t->PTQ = t->PT_H * g.Ws;
     t->inv_chs4 = 1.0f / (float)(t->CHS / 4);
     t->inv_fs4 = 1.0f / (float)(t->FS / 4);
@@ -487,7 +499,7 @@ float bn_down2_fill(const BnGeom& g, int MR, int NR) {
     Down2Tile t;
     size_t lds = 0;
     if (!bn_down2_supported(g, MR, NR) || !down2_tile(g, MR, NR, &t, &lds)) return 0.f;
-    return (float)(t.F * g.Hs * g.Ws) / (float)(t.tiles_per_frame * 128 * NR);
+    return (float)(t.F * t.PT_H * g.Ws) / (float)(128 * NR) * (float)g.Hs / (float)(t.UPF * t.PT_H);
 }
 
 // reduction splits: a grid that fills less than a quarter of the chip's 512 workgroup slots (a
@@ -496,7 +508,7 @@ int bn_down2_splits(const BnGeom& g, int MR, int NR) {
     Down2Tile t;
     size_t lds = 0;
     if (!down2_tile(g, MR, NR, &t, &lds)) return 1;
-    const int wgs = ((g.N + t.F - 1) / t.F) * t.tiles_per_frame * ((g.Cs + 32 * MR - 1) / (32 * MR));
+    const int wgs = ((g.N * t.UPF + t.F - 1) / t.F) * ((g.Cs + 32 * MR - 1) / (32 * MR));
     if (wgs > 160) return 1;
     int s = 512 / wgs;
     if (s > 8) s = 8;
@@ -510,9 +522,9 @@ int bn_launch_down2(int MR, int NR, const float* big, const float* w, const floa
     Down2Tile t;
     size_t lds = 0;
     if (!down2_tile(g, MR, NR, &t, &lds)) return BN_E_SHAPE;
-    const int groups = (g.N + t.F - 1) / t.F;
+    const int tiles = (g.N * t.UPF + t.F - 1) / t.F;
     if (splits < 1) splits = 1;
-    dim3 grid(groups * t.tiles_per_frame, (g.Cs + 32 * MR - 1) / (32 * MR), splits);
+    dim3 grid(tiles, (g.Cs + 32 * MR - 1) / (32 * MR), splits);
     const size_t total = (size_t)g.N * g.Cs * g.Hs * g.Ws;
     if (splits > 1 && !ws) return BN_E_WORKSPACE;
     // (split: raw sums into the slabs, no bias / activation / mask in the kernel)

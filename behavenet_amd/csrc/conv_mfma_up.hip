@@ -253,9 +253,10 @@ struct UP2<0> {
     static constexpr int CHSP = 256;
 };
 struct Up2Geo {
-    int F, AT_H, ATW;             // frames / rows per tile, AT_H * Ws
-    int SWp, FS, CHS;             // LDS row / frame strides of the small tile, elements of a channel
-    int TPF;                      // tiles per frame
+    int F, AT_H, ATW;             // UNITS per tile, rows per unit, AT_H * Ws
+    int SWp, FS, CHS;             // LDS row / unit strides of the small tile, elements of a channel
+    int UPF;                      // units (row blocks) per frame: a tile holds F units -- whole frames (UPF = 1),
+                                  // the row blocks of one frame (F = 1) or row blocks of adjacent frames
 };
 
 __device__ __forceinline__ void up_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds, int voffset, int soffset) {
@@ -297,20 +298,24 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     bool pvalid;
     const int m0 = blockIdx.y * TM;
     // lane -> position (frame f, row aj, col bj) of the small image
+    int u0 = 0, lidx = 0;                                 // RT: first unit of the tile; the lane's slot in LDS
     if constexpr (RT) {
-        grp = blockIdx.x / tg.TPF;
-        rowt = blockIdx.x - grp * tg.TPF;
-        n0 = grp * tg.F;
-        a0 = rowt * tg.AT_H;
+        grp = rowt = 0;
+        u0 = blockIdx.x * tg.F;
+        n0 = u0 / tg.UPF;                                 // frame of the first unit: scalar part of the offsets
         int pos = 32 * wv + li;
         const bool inside = pos < tg.F * tg.ATW;
         if (!inside) pos = 0;
-        pf = pos / tg.ATW;
-        const int prem = pos - pf * tg.ATW;
+        const int uf = pos / tg.ATW;                      // unit inside the tile -> its frame and first row
+        const int prem = pos - uf * tg.ATW;
+        const int un = (u0 + uf) / tg.UPF;
+        a0 = (u0 + uf - un * tg.UPF) * tg.AT_H;
         aj = prem / Ws;
         bj = prem - aj * Ws;
-        pvalid = inside && (n0 + pf) < g.N && (a0 + aj) < g.Hs;
+        pvalid = inside && un < g.N && (a0 + aj) < g.Hs;
+        pf = un - n0;                                     // frames behind n0 (the epilogue's n = n0 + pf)
         tFS = tg.FS; tCHS = tg.CHS;
+        lidx = uf;                                        // (its unit's index in the tile, not its frame)
     } else {
         grp = blockIdx.x / T::TPF;
         rowt = blockIdx.x - grp * T::TPF;
@@ -322,6 +327,7 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
         aj = prem >> LGW; bj = prem & (Ws - 1);
         pvalid = (n0 + pf) < g.N;
         tFS = T::FS; tCHS = T::CHS;
+        lidx = pf;
     }
     const int Hs_rt = RT ? g.Hs : Ws;
 
@@ -334,9 +340,15 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     if (tid < tCHS) {
         const int f = tid / tFS, r2 = tid - f * tFS;
         const int y = r2 / SWp, x = r2 - y * SWp;
-        const int p = a0 - 1 + y, q = x - 1;
-        const bool ok = (n0 + f < g.N) && p >= 0 && p < Hs_rt && q >= 0 && q < Ws;
-        if (ok) xvo = (f * (g.Cs * HWs) + p * Ws + q) * 4;
+        int fn = f, fa0 = a0;                             // frame behind n0 and first row of element's unit
+        if constexpr (RT) {
+            const int un = (u0 + f) / tg.UPF;
+            fn = un - n0;
+            fa0 = (u0 + f - un * tg.UPF) * tg.AT_H;
+        }
+        const int p = fa0 - 1 + y, q = x - 1;
+        const bool ok = (n0 + fn < g.N) && p >= 0 && p < Hs_rt && q >= 0 && q < Ws;
+        if (ok) xvo = (fn * (g.Cs * HWs) + p * Ws + q) * 4;
     }
     int wvo[WDMA];                                        // group tid + 256 k of [cc][m][tap]
 #pragma unroll
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
         for (int e = 0; e < 16; ++e) acc[cl][e] = 0.f;
 
     // ---- operand read bases (byte offsets from smem), one per LDS image --------------------------
-    int xb_cur = (pf * tFS + (aj + 1) * SWp + (bj + 1) + kk * T::CHSP) * 4;
+    int xb_cur = (lidx * tFS + (aj + 1) * SWp + (bj + 1) + kk * T::CHSP) * 4;
     int xb_oth = xb_cur + XBUF * 4;
     int wa_cur = (2 * XBUF + (kk * TM + li) * RS) * 4;
     int wa_oth = wa_cur + WBUF * 4;
@@ -658,24 +670,33 @@ static bool up2g_geo(const BnGeom& g, Up2Geo* t) {
     const int TP = 128, HW = g.Hs * g.Ws;
     if (g.Ws < 2 || g.Ws > TP) return false;
     t->SWp = g.Ws + 2;
-    t->F = HW >= TP ? 1 : TP / HW;
-    int rows = HW >= TP ? TP / g.Ws : g.Hs;
-    for (;;) {
-        t->TPF = (g.Hs + rows - 1) / rows;
-        t->AT_H = (g.Hs + t->TPF - 1) / t->TPF;
-        t->FS = (t->AT_H + 2) * t->SWp;
-        t->CHS = t->F * t->FS;
-        if (t->CHS <= UP2<0>::CHSP) break;
-        if (t->F > 1) --t->F;
-        else if (rows > 1) --rows;
-        else return false;
+    (void)HW;
+    // units of AT_H rows, F of them per tile (whole frames, row blocks of one frame, or row blocks of adjacent
+    // frames): the split of a frame into UPF blocks that fills the 128 positions best within the 256 elements
+    // of the haloed LDS image; ties: fewer blocks
+    float best = 0.f;
+    int b_upf = 0, b_ath = 0, b_F = 0;
+    for (int upf = 1; upf <= g.Hs; ++upf) {
+        const int ath = (g.Hs + upf - 1) / upf;
+        if ((g.Hs + ath - 1) / ath != upf || ath * g.Ws > TP) continue;
+        int F = TP / (ath * g.Ws);
+        const int fs = (ath + 2) * t->SWp;
+        while (F >= 1 && F * fs > UP2<0>::CHSP) --F;
+        if (F < 1) continue;
+        const float fill = (float)(F * ath * g.Ws) / (float)TP * (float)g.Hs / (float)(upf * ath);
+        if (fill > best + 1e-6f) { best = fill; b_upf = upf; b_ath = ath; b_F = F; }
+        if (best >= 0.999f) break;
     }
+    if (b_upf == 0) return false;
+    t->UPF = b_upf; t->AT_H = b_ath; t->F = b_F;
+    t->FS = (b_ath + 2) * t->SWp;
+    t->CHS = b_F * t->FS;
     t->ATW = t->AT_H * g.Ws;
     return true;
 }
 
 static int up2g_splits(const BnGeom& g, const Up2Geo& t, int cc) {
-    const int wgs = ((g.N + t.F - 1) / t.F) * t.TPF * ((g.Cb + 31) / 32);
+    const int wgs = ((g.N * t.UPF + t.F - 1) / t.F) * ((g.Cb + 31) / 32);
     if (wgs > 128) return 1;
     int s = 256 / wgs;
     while (s > 1 && (g.Cs % (s * cc) != 0 || g.Cs / s < 32)) --s;
@@ -698,8 +719,7 @@ static int launch_up2g(const float* small, const float* w, const float* bias, fl
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int groups = (g.N + t.F - 1) / t.F;
-    dim3 grid(groups * t.TPF, (g.Cb + 31) / 32, splits);
+    dim3 grid((g.N * t.UPF + t.F - 1) / t.F, (g.Cb + 31) / 32, splits);
     if (splits > 1) {
         if (!ws) return BN_E_WORKSPACE;
         const size_t total = (size_t)g.N * g.Cb * g.Hb * g.Wb;
