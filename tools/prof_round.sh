@@ -9,6 +9,7 @@ tools/prof_cmd.sh ${T}_ae_batchnorm 30 python tools/step_class.py ae bn 20 | hea
 tools/prof_cmd.sh ${T}_ae_arch2 30 python tools/step_arch.py behavenet_amd/configs/ae_jsons/ae_arch_2.json 1 128 128 256 20 | head -3
 tools/prof_cmd.sh ${T}_1x64x48_b256 30 python tools/step_arch.py none 1 64 48 256 20 | head -3
 tools/prof_cmd.sh ${T}_2x192x160_b256 30 python tools/step_arch.py none 2 192 160 256 20 | head -3
+tools/prof_cmd.sh ${T}_1x192x192_b256 30 python tools/step_arch.py none 1 192 192 256 20 | head -3
 tools/prof_cmd.sh ${T}_maxpool_arch 30 python tools/step_arch.py tests/golden/arch_maxpool.json 1 128 128 256 20 | head -3
 bash tools/prof_shape.sh ${T}_frames_rank0of8 1 128 128 256 20 0 8 | head -3
 bash tools/prof_psvae.sh ${T}_psvae | head -3
