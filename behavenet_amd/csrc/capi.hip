@@ -481,7 +481,7 @@ static int run_down(int family, const float* big, const float* w, const float* b
         // Cs channels, BnGeom::CsS) and read the mask there: no contiguous copy, no k_chan_copy
         const bool epi_ok = dact_src ? (act == BN_ACT_NONE && dact == BN_ACT_LRELU)
                                      : (act == BN_ACT_NONE || act == BN_ACT_LRELU);
-        if (g.Cb == 1 && bn_edge_down_plan(g5).supported && epi_ok) {
+        if (g.Cb == 1 && bn_edge_down_plan(g5).supported && bn_edge_down_plan(g5).variant != 9 && epi_ok) {
             BnGeom gw = g5;
             gw.CsS = g.Cs;
             BnProfScope prof(family, g.Cb, g.Cs, bn_edge_down_kernel_name(g5, act, dact_src != nullptr, false), st);
@@ -930,7 +930,7 @@ extern "C" int bn_conv2d_fwd(const float* x, const float* w, const float* b, flo
 }
 
 static bool u8_fast(const BnGeom& g, int act) {
-    return !force_generic() && g.Cb == 1 && bn_edge_down_plan(g).supported &&
+    return !force_generic() && g.Cb == 1 && bn_edge_down_plan(g).supported && bn_edge_down_plan(g).variant != 9 &&
            (act == BN_ACT_NONE || act == BN_ACT_LRELU);
 }
 

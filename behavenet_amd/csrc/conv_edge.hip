@@ -477,7 +477,11 @@ typedef int intx4 __attribute__((ext_vector_type(4)));
 typedef float floatx4e __attribute__((ext_vector_type(4)));
 typedef unsigned int uintx4e __attribute__((ext_vector_type(4)));
 
-template <int ACT, bool MASK>
+// GENW (round 4): any map with a width that is a multiple of 4 -- a unit is two output rows of ONE block of 64
+// columns (`ncb` blocks per row, the last one masked): the patch starts 128 cb columns into the row and has
+// real neighbours on its inner sides (the four-column borders are loaded, not zeros), the rows of the output
+// lie g.Ws apart, an odd last row is masked.  No zero-padded or tiled copies of 64x48 / 192x192 frames.
+template <int ACT, bool MASK, bool GENW = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_WPE))) void k_down_c1(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope,
@@ -486,7 +490,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
     __shared__ __attribute__((aligned(16))) float tw[DC_HALF ? 32 * DC_HTS : DC_SLAB];
     const int lane = threadIdx.x;
     const int li = lane & 31, kk = lane >> 5;
-    const int upf = g.Hs / DC_ROWS;                  // units per frame
+    const int ncb = GENW ? (g.Ws + DC_W - 1) / DC_W : 1;         // column blocks per row
+    const int rpf = GENW ? (g.Hs + DC_ROWS - 1) / DC_ROWS : g.Hs / DC_ROWS;   // row pairs per frame
+    const int upf = rpf * ncb;                       // units per frame
     const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
 #ifdef E0_TRACE      // tools/lab/e0_lab.hip: s_memrealtime marks per wave (100 MHz)
     unsigned long long* trc = e0_trace + (size_t)blockIdx.x * 8;
@@ -506,18 +512,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
     for (int k = 0; k < DC_NLD; ++k) {
         const int e = lane + 64 * k;
         const int y = e / DC_C4, c4 = e - y * DC_C4;
-        const bool col_ok = e < DC_IH * DC_C4 && c4 >= 1 && c4 <= DC_W / 2;
+        // (GENW: the border slots are image columns of the neighbouring blocks, tested per unit)
+        const bool col_ok = e < DC_IH * DC_C4 && (GENW || (c4 >= 1 && c4 <= DC_W / 2));
         ld_y[k] = col_ok ? y : -0x10000;            // fails the row test below
         ld_off[k] = (y * g.Wb + 4 * (c4 - 1)) * 4;
     }
+    int ld_col[DC_NLD];                              // GENW: image column of the slot inside its block
+#pragma unroll
+    for (int k = 0; k < DC_NLD; ++k) {
+        const int e = lane + 64 * k;
+        ld_col[k] = 4 * (e - (e / DC_C4) * DC_C4 - 1);
+    }
     auto issue = [&](int u, intx4 (&st)[DC_NLD]) {
         const int n = u / upf;
-        const int hb0 = 2 * DC_ROWS * (u - n * upf) - g.pt;       // image row of patch row 0
-        const int base = (n * g.Hb + hb0) * g.Wb * 4;
+        const int ur = u - n * upf;
+        const int cb = GENW ? ur % ncb : 0;
+        const int rp = GENW ? ur / ncb : ur;
+        const int hb0 = 2 * DC_ROWS * rp - g.pt;                  // image row of patch row 0
+        const int base = ((n * g.Hb + hb0) * g.Wb + 2 * DC_W * cb) * 4;
 #pragma unroll
         for (int k = 0; k < DC_NLD; ++k) {
             const int hb = hb0 + ld_y[k];
-            const bool ok = hb >= 0 && hb < g.Hb;
+            bool ok = hb >= 0 && hb < g.Hb;
+            if (GENW) {
+                const int wb = 2 * DC_W * cb + ld_col[k];
+                ok = ok && wb >= 0 && wb < g.Wb;
+            }
             st[k] = __builtin_amdgcn_raw_buffer_load_b128(rb, ok ? base + ld_off[k] : ED_OOB, 0, 0);
         }
     };
@@ -553,7 +573,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
         if (u == (int)blockIdx.x) E0_MARK(1);        // first patch in LDS
 
         const int n = u / upf;
-        const int p0 = DC_ROWS * (u - n * upf);
+        const int ur = u - n * upf;
+        const int cbo = GENW ? ur % ncb : 0;                     // this unit's column block
+        const int p0 = DC_ROWS * (GENW ? ur / ncb : ur);
+        const int opitch = GENW ? g.Ws : DC_W;                   // floats between output rows
         const float* aq = bl + a_col;
 #pragma unroll 1
         for (int pr = 0; pr < DC_ROWS; ++pr) {
@@ -596,13 +619,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // 8 lanes x 16 B = one 128-byte half row; 8 channels per store instruction
-                const size_t row0 = ((size_t)n * g.Cs * g.Hs + (p0 + pr)) * DC_W + 32 * qh +
-                                    4 * (lane & 7);
+                const int ocol = DC_W * cbo + 32 * qh + 4 * (lane & 7);
+                const size_t row0 = ((size_t)n * g.Cs * g.Hs + (p0 + pr)) * opitch + ocol;
+                const bool oin = !GENW || (ocol < g.Ws && p0 + pr < g.Hs);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int ch = 8 * i + (lane >> 3);
                     floatx4e v = *reinterpret_cast<const floatx4e*>(tw + ch * DC_HTS + 4 * (lane & 7));
-                    if (ch < g.Cs) {
+                    if (ch < g.Cs && oin) {
                         const size_t o = row0 + (size_t)ch * PQ;
                         if (MASK) {
                             const floatx4e d = *reinterpret_cast<const floatx4e*>(dact_src + o);
@@ -1328,11 +1352,22 @@ static int launch_down_c1w(const float* big, const float* w, const float* bias, 
 BnFastPlan bn_edge_down_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_down_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2 || (g.Cb != 1 && g.Cb != 2)) return p;
-    if (g.Cs > 32 || g.Ws != DC_W || (g.Hs % DC_ROWS) != 0) return p;
-    if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if (g.pl < 0 || g.pl > DC_X0 || g.pt < 0) return p;
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
+    if (g.Cs > 32) return p;
+    if (g.Ws != DC_W || (g.Hs % DC_ROWS) != 0 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) {
+        // round 4: single-channel frames of any other size (widths in multiples of 4) on the first-generation
+        // kernel in blocks of 64 columns -- no zero-padded / tiled copies (variant 9: no uint8 input, no
+        // channel window)
+        static int off = -1;                          // BN_DOWN_C1G=0: off
+        if (off < 0) { const char* e = bn_tune_env("BN_DOWN_C1G"); off = (e && e[0] == '0') ? 1 : 0; }
+        if (off || g.Cb != 1 || (g.Ws & 3) || (g.Wb & 3) || (g.CsS > 0 && g.CsS != g.Cs)) return p;
+        p.supported = true;
+        p.variant = 9;
+        p.kernel_name = "k_down_c1<gen>";
+        return p;
+    }
     p.supported = true;
     p.kernel_name = "k_down_c1";
     return p;
@@ -1370,6 +1405,8 @@ static int launch_down_c1s(const void* big, const float* w, const float* bias, f
 // name of the kernel bn_launch_edge_down dispatches to (profiling scopes, tests)
 const char* bn_edge_down_kernel_name(const BnGeom& g, int act, bool has_dact, bool u8) {
     const bool lrelu = act == BN_ACT_LRELU;
+    if (g.Ws != DC_W || (g.Hs % DC_ROWS) != 0 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws)
+        return has_dact ? "k_down_c1<gen, mask>" : "k_down_c1<gen>";
     if (g.Cb == 2)
         return has_dact ? "k_down_c1s<0, true, false, 2, 2>"
                         : (lrelu ? "k_down_c1s<1, false, false, 2, 2>" : "k_down_c1s<0, false, false, 2, 2>");
@@ -1391,6 +1428,24 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
                         hipStream_t st, const unsigned char* u8) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bn_prof_take_dispatch_events(&e0, &e1);   // stay null unless bench.py's hook is armed
+    if (g.Ws != DC_W || (g.Hs % DC_ROWS) != 0 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) {
+        // any other map of a single-channel frame: blocks of 64 columns (k_down_c1<.., GENW>)
+        if (u8 || g.Cb != 1 || (g.Ws & 3) || (g.Wb & 3) || (g.CsS > 0 && g.CsS != g.Cs)) return BN_E_SHAPE;
+        const int units = g.N * ((g.Hs + DC_ROWS - 1) / DC_ROWS) * ((g.Ws + DC_W - 1) / DC_W);
+        const dim3 grid(down_c1_grid(units));
+        if (act == BN_ACT_LRELU && !dact_src) {
+            hipExtLaunchKernelGGL((k_down_c1<BN_ACT_LRELU, false, true>), grid, dim3(64), 0, st, e0, e1, 0,
+                                  big, w, bias, out, dact_src, g, slope, units);
+        } else if (act == BN_ACT_NONE && !dact_src) {
+            hipExtLaunchKernelGGL((k_down_c1<BN_ACT_NONE, false, true>), grid, dim3(64), 0, st, e0, e1, 0,
+                                  big, w, bias, out, dact_src, g, slope, units);
+        } else {
+            hipExtLaunchKernelGGL((k_down_c1<BN_ACT_NONE, true, true>), grid, dim3(64), 0, st, e0, e1, 0,
+                                  big, w, bias, out, dact_src, g, slope, units);
+        }
+        BN_LAUNCH_CHECK();
+        return 0;
+    }
     // Product choice, measured INSIDE the training step (rocprofv3, 256 frames; the isolated
     // ranking differs): plain forward -> first generation (31.7-32.8 us vs 33.7-34.6 us);
     // data gradient with the LeakyReLU' mask -> second generation, 2-row units (48.2 vs 52.6 us).

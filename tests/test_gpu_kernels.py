@@ -121,6 +121,11 @@ CONV_CASES = [
     ('cw_30x64', 2, 16, 60, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('cw_9x96', 3, 16, 18, 192, 32, 5, 2, (1, 2), (1, 2)),
     ('cw_5x56_n7', 7, 32, 10, 112, 32, 5, 2, (1, 2), (1, 2)),
+    # single-channel frames of other sizes on the first-generation edge kernel in blocks of 64 columns: an odd
+    # number of output rows, a last block of 4 columns, first taps two pixels outside
+    ('edge_gen_35x36', 3, 1, 70, 72, 32, 5, 2, (1, 2), (1, 2)),
+    ('edge_gen_9x68', 5, 1, 18, 136, 16, 5, 2, (1, 2), (1, 2)),
+    ('edge_gen_pt2', 2, 1, 47, 96, 32, 5, 2, (2, 2), (2, 1)),
 ]
 
 
@@ -226,6 +231,8 @@ CONVT_CASES = [
     ('np2_48x40_n5', 5, 64, 48, 40, 32, 5, 2, 0, (1, 2, 1, 2), 0),
     ('cw_48x48', 3, 64, 48, 48, 32, 5, 2, 0, (1, 2, 1, 2), 0),
     ('cw_12x72', 4, 32, 12, 72, 16, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('edge_gen_35x36', 3, 32, 35, 36, 1, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('edge_gen_9x68', 5, 16, 9, 68, 1, 5, 2, 0, (1, 2, 1, 2), 0),
 ]
 
 
@@ -800,7 +807,7 @@ def test_stride1_roles_run_without_im2col(case_name):
 
 @pytest.mark.parametrize('case_name, want', [
     ('tile_48x40', 'k_down2_mfma<'), ('tile_100x24', 'k_down2_mfma<'),
-    ('tile_E0_96x80', 'on 2x2 tiles of 64x64'), ('pad_24x20', 'k_down2_mfma<'),
+    ('tile_E0_96x80', 'k_down_c1<gen>'), ('tile_E0c2_80x128', 'tiles of 64x64'), ('pad_24x20', 'k_down2_mfma<'),
     ('k4_64ch_32x32', 'mfma'), ('k4x3_24x20', 'k_down2_mfma<'), ('np2_6x5', 'on zero-padded 6x6'), ('pad_4x3', 'k_down2_mfma<2, 1> on zero-padded 4x4'),
     ('tile_odd_pl2', 'on zero-padded 47x36'),
     ('s1_k5_64x64', 'k_down_mfma<'), ('s1_k4_8x8', 'k_down_mfma<')])
