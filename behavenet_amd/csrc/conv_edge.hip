@@ -1647,15 +1647,21 @@ __device__ __forceinline__ float uv_shift_from_right(float v) {     // lane q <-
         __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
 
-template <int R, bool LOSS>
+// GENW (round 4): any small map (dec.convT4 of frames other than 128 columns wide, no tiles / zero-padded
+// copies) -- a unit is a strip of R input rows of ONE block of 62 input columns: the wave's 64 lanes hold columns
+// 62 cb - 1 .. 62 cb + 62, so that every lane that stores (1..62) finds both neighbours in the wave and the
+// DPP row shifts stay what they are; the outer two lanes only carry the neighbours (zeros at the frame's edges).
+template <int R, bool LOSS, bool GENW = false>
 __global__ __launch_bounds__(64) void k_up_c1v(
     const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ target, const float* __restrict__ mask,
     float* __restrict__ dpre, float* __restrict__ partial, BnGeom g, int act, float slope,
     int units) {
+    static_assert(!GENW || !LOSS, "the fused pixel loss keeps the 64-column geometry");
     constexpr int NR = R + 2;                        // strip rows + halo above / below
     const int lane = threadIdx.x;
-    const int strips = g.Hs / R;
+    const int strips = GENW ? (g.Hs + R - 1) / R : g.Hs / R;
+    const int ncb = GENW ? (g.Ws + 61) / 62 : 1;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * g.Hs * g.Ws * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
@@ -1669,10 +1675,13 @@ __global__ __launch_bounds__(64) void k_up_c1v(
 
 #pragma unroll 1
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
-        const int strip = u % strips;
-        const int nb = u / strips;
+        const int cbk = GENW ? u % ncb : 0;            // column block
+        const int us = GENW ? u / ncb : u;
+        const int strip = us % strips;
+        const int nb = us / strips;
         const int bch = nb % g.Cb, n = nb / g.Cb;
         const int p0 = strip * R;
+        const int col = GENW ? 62 * cbk - 1 + lane : lane;     // this lane's input column
 
         floatx2p acc[2 * R];                           // .x = column 2q, .y = column 2q+1
 #pragma unroll
@@ -1689,15 +1698,26 @@ __global__ __launch_bounds__(64) void k_up_c1v(
         const int vo_top = p0 > 0 ? lane * 4 : ED_OOB;
         const int vo_bot = p0 + R < g.Hs ? lane * 4 + sh + (NR - 1) * (UV_W * 4) : ED_OOB;
         const int vo_w = lane < 25 ? lane * 4 : ED_OOB;
-        const int frame_row0 = (n * g.Cs * g.Hs + (p0 > 0 ? p0 - 1 : 0)) * (UV_W * 4);
+        const int frame_row0 = GENW ? n * g.Cs * g.Hs * g.Ws * 4
+                                    : (n * g.Cs * g.Hs + (p0 > 0 ? p0 - 1 : 0)) * (UV_W * 4);
+        // GENW: strip row i is image row p0 - 1 + i of a map of g.Ws columns; rows / columns outside read 0.0f
+        int vog[NR];
+        if (GENW) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int row = p0 - 1 + i;
+                vog[i] = (row >= 0 && row < g.Hs && col >= 0 && col < g.Ws) ? (row * g.Ws + col) * 4 : ED_OOB;
+            }
+        }
         auto load_chan = [&](int c, Chan& ch) {
             // channels past the last one (the 3-way unrolled loop overshoots): zero weights, and
             // the rows of the last channel again (finite whenever the frame is)
             const int cx = c < g.Cs ? c : g.Cs - 1;
-            const int so = frame_row0 + cx * g.Hs * (UV_W * 4);
+            const int so = frame_row0 + cx * g.Hs * (GENW ? g.Ws * 4 : UV_W * 4);
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                const int vo = i == 0 ? vo_top : (i == NR - 1 ? vo_bot : vo_mid + i * (UV_W * 4));
+                const int vo = GENW ? vog[i]
+                                    : (i == 0 ? vo_top : (i == NR - 1 ? vo_bot : vo_mid + i * (UV_W * 4)));
                 const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
                 if (i & 1) ch.xx[i >> 1].y = v; else ch.xx[i >> 1].x = v;
             }
@@ -1767,10 +1787,12 @@ __global__ __launch_bounds__(64) void k_up_c1v(
         }
 
         const float bs = bias ? bias[bch] : 0.f;
-        const size_t o0 = (((size_t)n * g.Cb + bch) * g.Hb + 2 * p0) * g.Wb + 2 * lane;
+        const size_t o0 = (((size_t)n * g.Cb + bch) * g.Hb + 2 * p0) * g.Wb + 2 * (GENW ? (col > 0 ? col : 0) : lane);
+        const bool lane_out = !GENW || (lane >= 1 && lane <= 62 && col < g.Ws);
         float sq = 0.f;
 #pragma unroll
         for (int j = 0; j < 2 * R; ++j) {
+            if (GENW && (!lane_out || 2 * p0 + j >= g.Hb)) continue;
             float2 v;
             v.x = acc[j].x + bs;
             v.y = acc[j].y + bs;
@@ -2036,9 +2058,19 @@ static bool up_c1m_ok(const BnGeom& g) {
 BnFastPlan bn_edge_up_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_up_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || g.stride != 2 || g.Cb > 4 || g.pt != 1 || g.pl != 1) return p;
-    if (g.Ws != UV_W || (g.Hs % 8) != 0) return p;
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
+    if (g.Ws != UV_W || (g.Hs % 8) != 0) {
+        // round 4: any other small map in blocks of 62 columns (k_up_c1v<8, false, GENW>; variant 9: no fused
+        // pixel loss)
+        static int off = -1;                          // BN_UP_C1G=0: off
+        if (off < 0) { const char* e = bn_tune_env("BN_UP_C1G"); off = (e && e[0] == '0') ? 1 : 0; }
+        if (off) return p;
+        p.supported = true;
+        p.variant = 9;
+        p.kernel_name = "k_up_c1v<8, false, gen>";
+        return p;
+    }
     p.supported = true;
     p.kernel_name = bn_edge_up_kernel_name(g, false);
     return p;
@@ -2075,6 +2107,14 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
         return 0;
     }
 #endif
+    if (g.Ws != UV_W || (g.Hs % 8) != 0) {
+        if (target) return BN_E_SHAPE;
+        const int unitsg = g.N * g.Cb * ((g.Hs + UV_R - 1) / UV_R) * ((g.Ws + 61) / 62);
+        BN_LAUNCH_MAIN((k_up_c1v<UV_R, false, true>), dim3(unitsg < 256 * 16 ? unitsg : 256 * 16), dim3(64), 0, st,
+                           small, w, bias, out, nullptr, nullptr, nullptr, nullptr, g, act, slope, unitsg);
+        BN_LAUNCH_CHECK();
+        return 0;
+    }
     int use_m = UP_C1_VARIANT == 1 && up_c1m_ok(g);
     if (const char* e = bn_tune_env("BN_UP_C1_M")) use_m = atoi(e) && up_c1m_ok(g);     // (tuning build only)
     if (use_m) {

@@ -233,6 +233,11 @@ CONVT_CASES = [
     ('cw_12x72', 4, 32, 12, 72, 16, 5, 2, 0, (1, 2, 1, 2), 0),
     ('edge_gen_35x36', 3, 32, 35, 36, 1, 5, 2, 0, (1, 2, 1, 2), 0),
     ('edge_gen_9x68', 5, 16, 9, 68, 1, 5, 2, 0, (1, 2, 1, 2), 0),
+    # ... and its forward on k_up_c1v<8, false, gen>: blocks of 62 columns (1, 2 and 3 blocks; a last block of
+    # one column), strips whose last rows lie below the map, two output channels
+    ('edge_gen_up_13x62', 3, 32, 13, 62, 1, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('edge_gen_up_24x125', 2, 16, 24, 125, 2, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('edge_gen_up_5x3', 7, 32, 5, 3, 1, 5, 2, 0, (1, 2, 1, 2), 0),
 ]
 
 
@@ -838,4 +843,4 @@ def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, wan
         finally:
             _hip.prof_select(_hip.PROF_NONE)
         assert n >= 1 and ('tiles of' in name or 'zero-padded' in name or 'mfma' in name or
-                           'k_wgrad_c1<' in name), name
+                           'k_wgrad_c1<' in name or 'k_up_c1v<8, false, gen>' in name), name
