@@ -703,18 +703,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DC_WPE, DC_W
 // ---------------------------------------------------------------------------------------------
 // CB = 2 (two-channel frames, e.g. the PS-VAE's two camera views): the reduction index of the
 // 32x32x2 MFMA is the CHANNEL (lane half kk), one step per tap; a patch per channel in LDS.
-template <int ACT, bool MASK, bool U8, int ROWS, int CB = 1>
+// GENW (round 4, two-channel float frames of any size with a width that is a multiple of 4): a unit is ROWS
+// output rows of ONE block of 64 columns, as in k_down_c1<.., GENW> -- the four-column borders of the patch are
+// image columns of the neighbouring blocks (34 instead of 32 16-byte slots per patch row, tested per unit),
+// output rows lie g.Ws apart, the last block / rows below the map are masked.
+template <int ACT, bool MASK, bool U8, int ROWS, int CB = 1, bool GENW = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 : 3, CB == 1 ? 4 : 3))) void k_down_c1s(
     const void* __restrict__ big_, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, float slope,
     int units) {
     constexpr int IH = 2 * ROWS + 3;                     // patch rows
-    constexpr int NLD = U8 ? (IH * 8 + 63) / 64 : (IH * (DC_W / 2) + 63) / 64;
+    constexpr int PER_ROW = U8 ? 8 : (GENW ? DC_W / 2 + 2 : DC_W / 2);   // 16-byte loads per patch row
+    constexpr int NLD = (IH * PER_ROW + 63) / 64;
     static_assert(CB == 1 || !U8, "uint8 frames: one channel");
+    static_assert(!GENW || !U8, "column blocks: float frames");
     __shared__ __attribute__((aligned(16))) float bl[CB * IH * DC_RW];
     const int lane = threadIdx.x;
     const int li = lane & 31, kk = lane >> 5;
-    const int upf = g.Hs / ROWS;                         // units per frame
+    const int ncb = GENW ? (g.Ws + DC_W - 1) / DC_W : 1;
+    const int upf = GENW ? ((g.Hs + ROWS - 1) / ROWS) * ncb : g.Hs / ROWS;   // units per frame
     const int HWb = g.Hb * g.Wb, PQ = g.Hs * g.Ws;
 
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
@@ -736,22 +743,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int e = lane + 64 * k;
-        constexpr int PER_ROW = U8 ? 8 : DC_W / 2;       // 16-byte loads per image row
-        const int y = e / PER_ROW, c = e - y * PER_ROW;
+        const int y = e / PER_ROW, c = e - y * PER_ROW - (GENW ? 1 : 0);   // GENW: slot -1 = the left border
         ld_y[k] = e < IH * PER_ROW ? y : -0x10000;       // fails the row test below
         ld_off[k] = U8 ? (y * g.Wb + 16 * c) : (y * g.Wb + 4 * c) * 4;
         ld_lds[k] = y * DC_RW + DC_X0 + (U8 ? 16 : 4) * c;
     }
     auto issue = [&](int u, intx4 (&st)[CB * NLD]) {
         const int n = u / upf;
-        const int hb0 = 2 * ROWS * (u - n * upf) - g.pt;             // image row of patch row 0
-        const int base = (n * CB * g.Hb + hb0) * g.Wb * (U8 ? 1 : 4);
+        const int ur = u - n * upf;
+        const int cb = GENW ? ur % ncb : 0;
+        const int hb0 = 2 * ROWS * (GENW ? ur / ncb : ur) - g.pt;    // image row of patch row 0
+        const int base = ((n * CB * g.Hb + hb0) * g.Wb + (GENW ? 2 * DC_W * cb : 0)) * (U8 ? 1 : 4);
 #pragma unroll
         for (int c = 0; c < CB; ++c)
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
                 const int hb = hb0 + ld_y[k];
-                const bool ok = hb >= 0 && hb < g.Hb;
+                bool ok = hb >= 0 && hb < g.Hb;
+                if (GENW) {
+                    const int wb = 2 * DC_W * cb + (ld_lds[k] - ld_y[k] * DC_RW - DC_X0);   // image column
+                    ok = ok && wb >= 0 && wb < g.Wb;
+                }
                 st[c * NLD + k] = __builtin_amdgcn_raw_buffer_load_b128(
                     rb, ok ? base + ld_off[k] : ED_OOB, c * HWb * (U8 ? 1 : 4), 0);
             }
@@ -813,10 +825,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         const int n = u / upf;
-        const int p0 = ROWS * (u - n * upf);
+        const int urr = u - n * upf;
+        const int cbo = GENW ? urr % ncb : 0;                        // this unit's column block
+        const int p0 = ROWS * (GENW ? urr / ncb : urr);
+        const int opitch = GENW ? g.Ws : DC_W;                       // floats between output rows
         const float* aq = bl + a_col;
 #pragma unroll 1
         for (int pr = 0; pr < ROWS; ++pr) {
+            if (GENW && p0 + pr >= g.Hs) break;                      // (wave-uniform: rows below the map)
             floatx16 acc[2];
 #pragma unroll
             for (int qh = 0; qh < 2; ++qh)
@@ -847,15 +863,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 
                                                                    acc[qh], 0, 0, 0);
             }
             // 16 x 2 dword stores: lanes 0-31 one 128-byte line of channel ch, lanes 32-63 of ch+4
-            const int row_off = ((n * css * g.Hs + (p0 + pr)) * DC_W) * 4;
+            const int row_off = ((n * css * g.Hs + (p0 + pr)) * opitch + DC_W * cbo) * 4;
 #pragma unroll
             for (int qh = 0; qh < 2; ++qh) {
+                const bool cin = !GENW || DC_W * cbo + 32 * qh + li < g.Ws;   // this lane's column exists
                 float d[16];
                 if (MASK) {         // all 16 mask loads of the half row in flight together
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int chb = (e & 3) + 8 * (e >> 2);
-                        const bool ok = chb + 4 * kk < g.Cs;
+                        const bool ok = chb + 4 * kk < g.Cs && cin;
                         d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                             rd, ok ? st_lane : ED_OOB, row_off + (chb * PQ + 32 * qh) * 4, 0));
                     }
@@ -871,7 +888,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CB == 1 ? 4 
                 for (int e = 0; e < 16; ++e) {
                     const int chb = (e & 3) + 8 * (e >> 2);           // + 4*kk in st_lane
                     const int so = row_off + (chb * PQ + 32 * qh) * 4;
-                    const bool ok = chb + 4 * kk < g.Cs;
+                    const bool ok = chb + 4 * kk < g.Cs && cin;
                     float v = av[e];
                     if (MASK) v *= d[e] > 0.f ? 1.f : slope;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro,
@@ -1362,10 +1379,10 @@ BnFastPlan bn_edge_down_plan(const BnGeom& g) {
         // channel window)
         static int off = -1;                          // BN_DOWN_C1G=0: off
         if (off < 0) { const char* e = bn_tune_env("BN_DOWN_C1G"); off = (e && e[0] == '0') ? 1 : 0; }
-        if (off || g.Cb != 1 || (g.Ws & 3) || (g.Wb & 3) || (g.CsS > 0 && g.CsS != g.Cs)) return p;
+        if (off || (g.Ws & 3) || (g.Wb & 3) || (g.CsS > 0 && g.CsS != g.Cs)) return p;
         p.supported = true;
         p.variant = 9;
-        p.kernel_name = "k_down_c1<gen>";
+        p.kernel_name = g.Cb == 2 ? "k_down_c1s<.., 2, 2, gen>" : "k_down_c1<gen>";
         return p;
     }
     p.supported = true;
@@ -1405,8 +1422,10 @@ static int launch_down_c1s(const void* big, const float* w, const float* bias, f
 // name of the kernel bn_launch_edge_down dispatches to (profiling scopes, tests)
 const char* bn_edge_down_kernel_name(const BnGeom& g, int act, bool has_dact, bool u8) {
     const bool lrelu = act == BN_ACT_LRELU;
-    if (g.Ws != DC_W || (g.Hs % DC_ROWS) != 0 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws)
+    if (g.Ws != DC_W || (g.Hs % DC_ROWS) != 0 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) {
+        if (g.Cb == 2) return has_dact ? "k_down_c1s<.., 2, 2, gen, mask>" : "k_down_c1s<.., 2, 2, gen>";
         return has_dact ? "k_down_c1<gen, mask>" : "k_down_c1<gen>";
+    }
     if (g.Cb == 2)
         return has_dact ? "k_down_c1s<0, true, false, 2, 2>"
                         : (lrelu ? "k_down_c1s<1, false, false, 2, 2>" : "k_down_c1s<0, false, false, 2, 2>");
@@ -1430,8 +1449,21 @@ int bn_launch_edge_down(const float* big, const float* w, const float* bias, flo
     bn_prof_take_dispatch_events(&e0, &e1);   // stay null unless bench.py's hook is armed
     if (g.Ws != DC_W || (g.Hs % DC_ROWS) != 0 || g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) {
         // any other map of a single-channel frame: blocks of 64 columns (k_down_c1<.., GENW>)
-        if (u8 || g.Cb != 1 || (g.Ws & 3) || (g.Wb & 3) || (g.CsS > 0 && g.CsS != g.Cs)) return BN_E_SHAPE;
+        if (u8 || (g.Ws & 3) || (g.Wb & 3) || (g.CsS > 0 && g.CsS != g.Cs)) return BN_E_SHAPE;
         const int units = g.N * ((g.Hs + DC_ROWS - 1) / DC_ROWS) * ((g.Ws + DC_W - 1) / DC_W);
+        if (g.Cb == 2) {     // two-channel frames: the swapped-role kernel (2-row units) in column blocks
+            int grid2 = 256 * DC_MAX_WAVES_PER_CU;
+            if (grid2 > units) grid2 = units;
+#define C1S_GEN(A, M)                                                                                     \
+    hipExtLaunchKernelGGL((k_down_c1s<A, M, false, 2, 2, true>), dim3(grid2), dim3(64), 0, st, e0, e1, 0,  \
+                          (const void*)big, w, bias, out, dact_src, g, slope, units)
+            if (act == BN_ACT_LRELU && !dact_src) C1S_GEN(BN_ACT_LRELU, false);
+            else if (!dact_src) C1S_GEN(BN_ACT_NONE, false);
+            else C1S_GEN(BN_ACT_NONE, true);
+#undef C1S_GEN
+            BN_LAUNCH_CHECK();
+            return 0;
+        }
         const dim3 grid(down_c1_grid(units));
         if (act == BN_ACT_LRELU && !dact_src) {
             hipExtLaunchKernelGGL((k_down_c1<BN_ACT_LRELU, false, true>), grid, dim3(64), 0, st, e0, e1, 0,

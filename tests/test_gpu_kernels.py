@@ -126,6 +126,8 @@ CONV_CASES = [
     ('edge_gen_35x36', 3, 1, 70, 72, 32, 5, 2, (1, 2), (1, 2)),
     ('edge_gen_9x68', 5, 1, 18, 136, 16, 5, 2, (1, 2), (1, 2)),
     ('edge_gen_pt2', 2, 1, 47, 96, 32, 5, 2, (2, 2), (2, 1)),
+    ('edge_gen_2ch_35x36', 3, 2, 70, 72, 32, 5, 2, (1, 2), (1, 2)),
+    ('edge_gen_2ch_9x68', 5, 2, 18, 136, 16, 5, 2, (1, 2), (1, 2)),
 ]
 
 
@@ -238,6 +240,7 @@ CONVT_CASES = [
     ('edge_gen_up_13x62', 3, 32, 13, 62, 1, 5, 2, 0, (1, 2, 1, 2), 0),
     ('edge_gen_up_24x125', 2, 16, 24, 125, 2, 5, 2, 0, (1, 2, 1, 2), 0),
     ('edge_gen_up_5x3', 7, 32, 5, 3, 1, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('edge_gen_2ch_35x36', 3, 32, 35, 36, 2, 5, 2, 0, (1, 2, 1, 2), 0),
 ]
 
 
@@ -812,7 +815,7 @@ def test_stride1_roles_run_without_im2col(case_name):
 
 @pytest.mark.parametrize('case_name, want', [
     ('tile_48x40', 'k_down2_mfma<'), ('tile_100x24', 'k_down2_mfma<'),
-    ('tile_E0_96x80', 'k_down_c1<gen>'), ('tile_E0c2_80x128', 'tiles of 64x64'), ('pad_24x20', 'k_down2_mfma<'),
+    ('tile_E0_96x80', 'k_down_c1<gen>'), ('tile_E0c2_80x128', 'k_down_c1s<.., 2, 2, gen>'), ('pad_24x20', 'k_down2_mfma<'),
     ('k4_64ch_32x32', 'mfma'), ('k4x3_24x20', 'k_down2_mfma<'), ('np2_6x5', 'on zero-padded 6x6'), ('pad_4x3', 'k_down2_mfma<2, 1> on zero-padded 4x4'),
     ('tile_odd_pl2', 'on zero-padded 47x36'),
     ('s1_k5_64x64', 'k_down_mfma<'), ('s1_k4_8x8', 'k_down_mfma<')])
