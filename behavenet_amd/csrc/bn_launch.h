@@ -136,10 +136,12 @@ int bn_launch_col_wgrad(const float* small, const float* big, float* dw, const B
                         void* ws, size_t ws_bytes, hipStream_t st, float* db, int bias_side,
                         bool* bias_done);
 // kernels smaller than 5x5 embedded in 5x5 taps (weights [pairs][R][S] <-> [pairs][5][5])
-int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hipStream_t st);
+int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hipStream_t st, int dr = 0,
+                       int ds = 0);
 int bn_launch_flip_taps(const float* w, float* wf, int Cs, int Cb, int RS, hipStream_t st);
 int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S, int accumulate,
-                        hipStream_t st, const float* db5 = nullptr, float* db = nullptr, int nb = 0);
+                        hipStream_t st, const float* db5 = nullptr, float* db = nullptr, int nb = 0,
+                        int dr = 0, int ds = 0);
 bool bn_s5_down_small_ok(const BnGeom& g);
 size_t bn_s5_down_small_ws_bytes(const BnGeom& g);
 int bn_launch_s5_down_small(const float* big, const float* w, const float* bias, float* out,

@@ -421,6 +421,8 @@ static bool served_fast(int role, const BnGeom& g) {
     }
     return pad_plan(role, g).ok || tile_plan(role, g).ok;
 }
+static inline int taps_dr(const BnGeom& g) { return (g.stride == 2 && g.pt == 0 && g.R <= 4) ? 1 : 0; }
+static inline int taps_ds(const BnGeom& g) { return (g.stride == 2 && g.pl == 0 && g.S <= 4) ? 1 : 0; }
 static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
     // (stride 1 too: the index relation p * stride - pt + r does not care, and the stride-1 gather-down
     // kernel is instantiated for 3x3 and 5x5 -- a 4x4 layer becomes a 5x5 one where that kernel serves it)
@@ -430,8 +432,13 @@ static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
     if (g.R < 2 || g.S < 2) return false;
     *g5 = g;
     g5->R = g5->S = 5;
+    // stride 2, first tap ON the frame (TF-"same" padding of a 3x3 kernel: pt = pl = 0): the taps go one row /
+    // column into the 5x5 ones, which makes it a layer with the offsets (1, 1) the streamlined families take
+    const int dr = taps_dr(g), ds = taps_ds(g);
+    g5->pt = g.pt + dr;
+    g5->pl = g.pl + ds;
     // stride 2: the fifth row and column of taps are zeros the 16-byte-DMA kernels need not multiply
-    g5->KV = (g.stride == 2 && g.R <= 4 && g.S <= 4) ? 4 : 0;
+    g5->KV = (g.stride == 2 && g.R + dr <= 4 && g.S + ds <= 4) ? 4 : 0;
     return served_fast(role, *g5);
 }
 static inline size_t taps_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * 25 * sizeof(float)); }
@@ -468,7 +475,7 @@ static int run_down(int family, const float* big, const float* w, const float* b
     if (!generic && taps_plan(0, g, &g5)) {
         const size_t wb = taps_bytes(g);
         if (!ws || ws_bytes < wb + role_ws_need(0, g5)) return BN_E_WORKSPACE;
-        const int rc = bn_launch_pad_taps(w, (float*)ws, (size_t)g.Cs * g.Cb, g.R, g.S, st);
+        const int rc = bn_launch_pad_taps(w, (float*)ws, (size_t)g.Cs * g.Cb, g.R, g.S, st, taps_dr(g), taps_ds(g));
         if (rc) return rc;
         return run_down(family, big, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
                         (char*)ws + wb, ws_bytes - wb, st);
@@ -591,7 +598,7 @@ static int run_up(int family, const float* small, const float* w, const float* b
     if (!generic && taps_plan(1, g, &g5)) {
         const size_t wb = taps_bytes(g);
         if (!ws || ws_bytes < wb + role_ws_need(1, g5)) return BN_E_WORKSPACE;
-        const int rc = bn_launch_pad_taps(w, (float*)ws, (size_t)g.Cs * g.Cb, g.R, g.S, st);
+        const int rc = bn_launch_pad_taps(w, (float*)ws, (size_t)g.Cs * g.Cb, g.R, g.S, st, taps_dr(g), taps_ds(g));
         if (rc) return rc;
         return run_up(family, small, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
                       (char*)ws + wb, ws_bytes - wb, st);
@@ -715,7 +722,7 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         if (rc) return rc;
         if (done && bias_done) *bias_done = true;
         return bn_launch_crop_taps((const float*)ws, dw, (size_t)g.Cs * g.Cb, g.R, g.S, accumulate, st,
-                                   done ? db5 : nullptr, db, nb);
+                                   done ? db5 : nullptr, db, nb, taps_dr(g), taps_ds(g));
     }
     if (!generic && chan_plan(2, g, &g5)) {
         const size_t cb = chan_bytes(g);

@@ -100,14 +100,18 @@ int bn_launch_crop2d(const float* src, float* dst, size_t planes, int H, int W, 
 // big row 2p - pt + r), so every role is exact; the weight gradient of the added taps is dropped.
 // ---------------------------------------------------------------------------------------------
 // w5[pair][5][5] <- w[pair][R][S]
+// (dr, ds): where tap (0, 0) sits inside the 5x5 taps.  Small pixel p meets big row st p + r - pt = st p + (r + dr) -
+// (pt + dr): a 3x3 stride-2 layer with TF-"same" padding (first tap ON the frame, pt = pl = 0) embedded at (1, 1) is a
+// 5x5 layer with pt = pl = 1 -- the offsets the streamlined stride-2 families are built for (round 4: it ran on the
+// first-generation kernels and the col2im detour, 8.0 ms/step for 36 % of the default architecture's arithmetic).
 __global__ __launch_bounds__(PD_THREADS) void k_pad_taps(const float* __restrict__ w,
                                                           float* __restrict__ w5, unsigned pairs,
-                                                          int R, int S) {
+                                                          int R, int S, int dr, int ds) {
     const unsigned total = pairs * 25;
     for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
         const unsigned pr = q / 25, t = q - pr * 25;
-        const int r = t / 5, c = t - 5 * r;
-        w5[q] = (r < R && c < S) ? w[pr * (R * S) + r * S + c] : 0.f;
+        const int r = (int)(t / 5) - dr, c = (int)(t - 5 * (t / 5)) - ds;
+        w5[q] = (r >= 0 && r < R && c >= 0 && c < S) ? w[pr * (R * S) + r * S + c] : 0.f;
     }
 }
 // dw[pair][R][S] (+)= dw5[pair][5][5];  db[i] (+)= db5[i] (the bias gradient the inner kernel left in
@@ -116,20 +120,20 @@ __global__ __launch_bounds__(PD_THREADS) void k_crop_taps(const float* __restric
                                                            float* __restrict__ dw, unsigned pairs,
                                                            int R, int S, int accumulate,
                                                            const float* __restrict__ db5,
-                                                           float* __restrict__ db, unsigned nb) {
+                                                           float* __restrict__ db, unsigned nb, int dr, int ds) {
     const unsigned total = pairs * R * S;
     if (db5 && blockIdx.x == 0)
         for (unsigned i = threadIdx.x; i < nb; i += PD_THREADS) db[i] = accumulate ? db[i] + db5[i] : db5[i];
     for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
         const unsigned pr = q / (R * S), t = q - pr * (R * S);
         const int r = t / S, c = t - S * r;
-        const float v = dw5[pr * 25 + r * 5 + c];
+        const float v = dw5[pr * 25 + (r + dr) * 5 + c + ds];
         dw[q] = accumulate ? dw[q] + v : v;
     }
 }
-int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hipStream_t st) {
+int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hipStream_t st, int dr, int ds) {
     hipLaunchKernelGGL(k_pad_taps, dim3(pd_blocks(pairs * 25)), dim3(PD_THREADS), 0, st, w, w5,
-                       (unsigned)pairs, R, S);
+                       (unsigned)pairs, R, S, dr, ds);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -156,9 +160,9 @@ int bn_launch_flip_taps(const float* w, float* wf, int Cs, int Cb, int RS, hipSt
 }
 
 int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S, int accumulate,
-                        hipStream_t st, const float* db5, float* db, int nb) {
+                        hipStream_t st, const float* db5, float* db, int nb, int dr, int ds) {
     hipLaunchKernelGGL(k_crop_taps, dim3(pd_blocks(pairs * R * S)), dim3(PD_THREADS), 0, st, dw5, dw,
-                       (unsigned)pairs, R, S, accumulate, db5, db, (unsigned)nb);
+                       (unsigned)pairs, R, S, accumulate, db5, db, (unsigned)nb, dr, ds);
     BN_LAUNCH_CHECK();
     return 0;
 }

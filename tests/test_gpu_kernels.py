@@ -86,6 +86,12 @@ CONV_CASES = [
     ('k4_64ch_8x8', 3, 64, 16, 16, 64, 4, 2, (1, 1), (1, 1)),
     ('k3_16x16', 2, 32, 32, 32, 64, 3, 2, (1, 1), (1, 1)),
     ('k4x3_24x20', 2, 32, 48, 40, 64, 4, 2, (1, 1), (1, 1)),
+    # 3x3 stride 2 with TF-"same" padding (first tap ON the frame: what the reference's random architecture search
+    # draws a quarter of the time): the taps sit at (1, 1) of the 5x5 ones, the layer runs with offsets (1, 1)
+    ('k3s2_same_32x32', 3, 32, 64, 64, 64, 3, 2, (0, 1), (0, 1)),
+    ('k3s2_same_12x10', 5, 64, 24, 20, 128, 3, 2, (0, 1), (0, 1)),
+    ('k3s2_pt0_pl1', 2, 32, 32, 32, 64, 3, 2, (0, 1), (1, 0)),
+    ('k3s2_same_E0', 2, 1, 128, 128, 32, 3, 2, (0, 1), (0, 1)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
@@ -213,6 +219,8 @@ CONVT_CASES = [
     ('tile_D4c2_80x128', 2, 32, 80, 128, 2, 5, 2, 0, (1, 2, 1, 2), 0),
     ('k4_64ch_16x16', 3, 64, 16, 16, 64, 4, 2, 0, (1, 1, 1, 1), 0),
     ('k3_8x8', 2, 128, 8, 8, 64, 3, 2, 0, (1, 0, 1, 0), 0),
+    ('k3s2_same_16x16', 3, 128, 16, 16, 64, 3, 2, 0, (0, 1, 0, 1), 0),
+    ('k3s2_same_D4', 2, 32, 64, 64, 1, 3, 2, 0, (0, 1, 0, 1), 0),
     ('D4_64ch', 2, 64, 64, 64, 1, 5, 2, 0, (1, 2, 1, 2), 0),
     ('D4_k4_64ch', 2, 64, 64, 64, 1, 4, 2, 0, (1, 1, 1, 1), 0),
     # round 4: stride 1 -- forward on the gather-down kernel with reversed taps, weight gradient direct
