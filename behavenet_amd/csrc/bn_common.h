@@ -43,6 +43,7 @@ struct BnGeom {
                       // other kernel requires 0.
     int KV;           // 5x5 taps zero-extended from a smaller kernel (capi.hip, taps_plan): taps with r >= KV
                       // or s >= KV are zero and the stride-2 families skip their products (0 = all 25)
+    int K0;           // ... and taps with r < K0 or s < K0 (a 3x3 kernel embedded at (1, 1): K0 = 1, KV = 4)
 };
 static inline __host__ __device__ int bn_cs_stride(const BnGeom& g) { return g.CsS > 0 ? g.CsS : g.Cs; }
 

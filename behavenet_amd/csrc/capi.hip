@@ -184,14 +184,14 @@ static inline BnGeom conv_geom(int N, int C, int H, int W, int K, int R, int S, 
                                int pad_t, int pad_l, int P, int Q) {
     BnGeom g;
     g.N = N; g.Cs = K; g.Hs = P; g.Ws = Q; g.Cb = C; g.Hb = H; g.Wb = W;
-    g.R = R; g.S = S; g.stride = stride; g.pt = pad_t; g.pl = pad_l; g.CsS = 0; g.KV = 0;
+    g.R = R; g.S = S; g.stride = stride; g.pt = pad_t; g.pl = pad_l; g.CsS = 0; g.KV = 0; g.K0 = 0;
     return g;
 }
 static inline BnGeom convT_geom(int N, int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                                 int crop_t, int crop_l, int Ho, int Wo) {
     BnGeom g;
     g.N = N; g.Cs = Ci; g.Hs = Hi; g.Ws = Wi; g.Cb = Co; g.Hb = Ho; g.Wb = Wo;
-    g.R = R; g.S = S; g.stride = stride; g.pt = crop_t; g.pl = crop_l; g.CsS = 0; g.KV = 0;
+    g.R = R; g.S = S; g.stride = stride; g.pt = crop_t; g.pl = crop_l; g.CsS = 0; g.KV = 0; g.K0 = 0;
     return g;
 }
 
@@ -421,8 +421,11 @@ static bool served_fast(int role, const BnGeom& g) {
     }
     return pad_plan(role, g).ok || tile_plan(role, g).ok;
 }
-static inline int taps_dr(const BnGeom& g) { return (g.stride == 2 && g.pt == 0 && g.R <= 4) ? 1 : 0; }
-static inline int taps_ds(const BnGeom& g) { return (g.stride == 2 && g.pl == 0 && g.S <= 4) ? 1 : 0; }
+// (a stride-1 3x3 layer comes here for its weight gradient only -- taps_plan -- and goes in at (1, 1) as well:
+// the 3x3 window of taps is the one instantiation both strides share)
+static inline bool taps_s1k3(const BnGeom& g) { return g.stride == 1 && g.R == 3 && g.S == 3 && g.pt <= 3 && g.pl <= 3; }
+static inline int taps_dr(const BnGeom& g) { return ((g.stride == 2 && g.pt == 0 && g.R <= 4) || taps_s1k3(g)) ? 1 : 0; }
+static inline int taps_ds(const BnGeom& g) { return ((g.stride == 2 && g.pl == 0 && g.S <= 4) || taps_s1k3(g)) ? 1 : 0; }
 static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
     // (stride 1 too: the index relation p * stride - pt + r does not care, and the stride-1 gather-down
     // kernel is instantiated for 3x3 and 5x5 -- a 4x4 layer becomes a 5x5 one where that kernel serves it)
@@ -438,7 +441,9 @@ static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
     g5->pt = g.pt + dr;
     g5->pl = g.pl + ds;
     // stride 2: the fifth row and column of taps are zeros the 16-byte-DMA kernels need not multiply
-    g5->KV = (g.stride == 2 && g.R + dr <= 4 && g.S + ds <= 4) ? 4 : 0;
+    g5->KV = ((g.stride == 2 || taps_s1k3(g)) && g.R + dr <= 4 && g.S + ds <= 4) ? 4 : 0;
+    // ... and neither the first ones of a kernel that went in at (1, 1): 9 products of 25 for a 3x3 layer
+    g5->K0 = (g5->KV == 4 && dr == 1 && ds == 1) ? 1 : 0;
     return served_fast(role, *g5);
 }
 static inline size_t taps_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * 25 * sizeof(float)); }

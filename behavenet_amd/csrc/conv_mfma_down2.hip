@@ -71,8 +71,9 @@ struct Down2Tile {
 };
 
 // KV = 4: the 5x5 taps are a smaller kernel zero-extended (BnGeom::KV): rows / columns of taps from KV on
-// are neither read nor multiplied (a 4x4 layer: 16 of 25 products); LDS layouts stay the 5x5 ones
-template <int MR, int NR, int KV>
+// are neither read nor multiplied (a 4x4 layer: 16 of 25 products); LDS layouts stay the 5x5 ones.
+// K0 = 1: so are row 0 / column 0 (BnGeom::K0, a 3x3 layer embedded at (1, 1): 9 of 25 products)
+template <int MR, int NR, int KV, int K0 = 0>
 __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, Down2Tile t, int act,
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
 #define D2_MARK(slot)
 #endif
     constexpr int CC = D2_CC, R = 5, S = 5, RS = 25;
-    constexpr int RE = KV, SE = KV;                   // rows / columns of taps that are multiplied
+    constexpr int RE = KV - K0, SE = KV - K0;         // rows / columns of taps that are multiplied
     constexpr int TM = 32 * MR;
     constexpr int WS = CC * RS;                       // weight row of one output channel (100 words)
     constexpr int WG = TM * WS / 4;                   // 16-byte groups of the weight slice
@@ -241,21 +242,31 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     constexpr int NM = SE * MR * NR;                 // MFMAs per row
     constexpr int WU = SE == 5 ? 3 : 2;              // weight read units per 32-channel block
     constexpr int NU = WU * MR + 2 * NR;             // read units per row
-    static_assert(NU <= NM, "one read unit per MFMA at most");
+    static_assert(NU <= NM || K0 > 0, "one read unit per MFMA at most");
     auto load_unit = [&](const int BUF, const int it, const int u, float (&a)[S][MR],
                          float (&bq)[S][NR]) __attribute__((always_inline)) {
-        const int cp = it / RE, r = it - cp * RE;
+        const int cp = it / RE, r = K0 + it - cp * RE;
         if (u < WU * MR) {
             const int mr = u / WU, k = u - WU * mr;
             const float* wp = smem + wao[mr] + (2 * cp) * RS + r * S;
-            if (k == 0) { a[0][mr] = wp[0]; a[1][mr] = wp[1]; }
+            if (K0 == 1) {
+                if (k == 0) { a[1][mr] = wp[1]; a[2][mr] = wp[2]; }
+                else a[3][mr] = wp[3];
+            } else if (k == 0) { a[0][mr] = wp[0]; a[1][mr] = wp[1]; }
             else if (k == 1) { a[2][mr] = wp[2]; a[3][mr] = wp[3]; }
             else a[4][mr] = wp[4];
         } else {
             // columns 2q-1 .. 2q+3 = words 1..5 of the aligned six-word run
             const int v = u - WU * MR, nr = v / 2;
             const float* xb = smem + xro[BUF][nr][cp][r];
-            if ((v & 1) == 0) bq[0][nr] = xb[1];
+            if (K0 == 1) {
+                if ((v & 1) == 0) {
+                    const floatx2d c1p = *reinterpret_cast<const floatx2d*>(xb + 2);
+                    bq[1][nr] = c1p.x; bq[2][nr] = c1p.y;
+                } else {
+                    bq[3][nr] = xb[4];
+                }
+            } else if ((v & 1) == 0) bq[0][nr] = xb[1];
             else {
                 const floatx2d c1p = *reinterpret_cast<const floatx2d*>(xb + 2);
                 bq[1][nr] = c1p.x; bq[2][nr] = c1p.y;
@@ -276,7 +287,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
         for (int it = 0; it < NIT; ++it) {
 #pragma unroll
             for (int j = 0; j < NM; ++j) {
-                const int s = j / (MR * NR), mr = (j / NR) % MR, nr = j % NR;
+                const int s = K0 + j / (MR * NR), mr = (j / NR) % MR, nr = j % NR;
                 acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(
                     av[it & 1][s][mr], bv[it & 1][s][nr], acc[mr][nr], 0, 0, 0);
                 if (it + 1 < NIT) {
@@ -477,18 +488,18 @@ bool bn_down2_supported(const BnGeom& g, int MR, int NR) {
     return down2_tile(g, MR, NR, &t, &lds);
 }
 
-template <int MR, int NR, int KV>
+template <int MR, int NR, int KV, int K0 = 0>
 static int launch_down2(const Down2Tile& t, dim3 grid, size_t lds, const float* big, const float* w,
                         const float* bias, float* out, const float* dact_src, const BnGeom& g,
                         int act, int dact, float slope, hipStream_t st, int cper, size_t zstride) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_down2_mfma<MR, NR, KV>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_down2_mfma<MR, NR, KV, K0>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, D2_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    BN_LAUNCH_MAIN((k_down2_mfma<MR, NR, KV>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
+    BN_LAUNCH_MAIN((k_down2_mfma<MR, NR, KV, K0>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
                        dact_src, g, t, act, dact, slope, cper, zstride);
     BN_LAUNCH_CHECK();
     return 0;
@@ -535,10 +546,11 @@ int bn_launch_down2(int MR, int NR, const float* big, const float* w, const floa
     const int cper = g.Cb / splits;
     const size_t zs = splits > 1 ? total : 0;
     int rc = BN_E_SHAPE;
-    const bool k4 = g.KV == 4;
+    const bool k4 = g.KV == 4, k3 = k4 && g.K0 == 1;
 #define D2_CASE(mr, nr)                                                                                       \
     if (MR == mr && NR == nr)                                                                                 \
-        rc = k4 ? launch_down2<mr, nr, 4>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs)   \
+        rc = k3 ? launch_down2<mr, nr, 4, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs) \
+           : k4 ? launch_down2<mr, nr, 4>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs)   \
                 : launch_down2<mr, nr, 5>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
     D2_CASE(2, 2) D2_CASE(2, 1) D2_CASE(1, 1)
 #undef D2_CASE

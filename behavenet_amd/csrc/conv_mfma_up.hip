@@ -266,8 +266,14 @@ __device__ __forceinline__ void up_dma4(__amdgpu_buffer_rsrc_t rsrc, float* lds,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds, 4, voffset, soffset, 0, 0);
 }
 
+template <int KV>
+__device__ __forceinline__ constexpr bool up2_tap_live(int r, int s) {
+    return r >= KV / 10 && r < KV % 10 && s >= KV / 10 && s < KV % 10;
+}
+
 // KV = 4: taps with r >= 4 or s >= 4 are zeros (BnGeom::KV, a 4x4 layer on 5x5 taps): neither read nor
-// multiplied -- 16 of the 25 products of a channel pair; the slots of the issue order keep their places
+// multiplied -- 16 of the 25 products of a channel pair; the slots of the issue order keep their places.
+// KV = 14: row 0 / column 0 are zeros as well (BnGeom::K0 = 1, a 3x3 layer embedded at (1, 1)): 9 products
 template <int LGW, int CC, int KV>
 __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     const float* __restrict__ small, const float* __restrict__ w, const float* __restrict__ bias,
@@ -438,14 +444,14 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
 #pragma unroll
         for (int j = 0; j < 25; ++j) {
             const Tap t0 = tap_of(ORDER[j]);
-            if (t0.r < KV && t0.s < KV) load_a(wa, 0, j, av);
+            if (up2_tap_live<KV>(t0.r, t0.s)) load_a(wa, 0, j, av);
         }
 #pragma unroll
         for (int cp = 0; cp < CC / 2; ++cp) {
 #pragma unroll
             for (int j = 0; j < 25; ++j) {
                 const Tap tp = tap_of(ORDER[j]);
-                const bool live = tp.r < KV && tp.s < KV;
+                const bool live = up2_tap_live<KV>(tp.r, tp.s);
                 if (live)
                     acc[tp.cl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ORDER[j]], bv[cp & 1][tp.dy * 3 + tp.dx],
                                                                       acc[tp.cl], 0, 0, 0);
@@ -788,7 +794,9 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
                       int act, int dact, float slope, void* ws, hipStream_t st) {
     const int MR = plan.a, CC = plan.c;
     if (plan.variant == 3)
-        return g.KV == 4
+        return g.KV == 4 && g.K0 == 1
+            ? launch_up2g<14>(small, w, bias, out, dact_src, g, act, dact, slope, st, plan.d > 1 ? plan.d : 1, ws)
+            : g.KV == 4
             ? launch_up2g<4>(small, w, bias, out, dact_src, g, act, dact, slope, st, plan.d > 1 ? plan.d : 1, ws)
             : launch_up2g<5>(small, w, bias, out, dact_src, g, act, dact, slope, st, plan.d > 1 ? plan.d : 1, ws);
     if (plan.variant == 2) {
@@ -798,6 +806,8 @@ int bn_launch_up_fast(const BnFastPlan& plan, const float* small, const float* w
     if (lgw == L && CC == C)                                                                    \
         return launch_up2<L, C, 5>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws);
 #define UP2_CASE4(L)                                                                            \
+    if (lgw == L && CC == 4 && g.KV == 4 && g.K0 == 1)                                          \
+        return launch_up2<L, 4, 14>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws); \
     if (lgw == L && CC == 4 && g.KV == 4)                                                       \
         return launch_up2<L, 4, 4>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws);
         UP2_CASE4(3) UP2_CASE4(4) UP2_CASE4(5)

@@ -258,7 +258,8 @@ __device__ __forceinline__ void w4_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 // over its lower edge: the small rows below the map and the big rows below it are left out of the DMA
 // (out-of-range source offset = 0.0f) by a per-group row number against a per-stage scalar limit.
 // KV = 4: taps with r >= 4 or s >= 4 belong to the zero extension of a smaller kernel (BnGeom::KV): their
-// products are skipped and their (zero) tiles are dropped again by the caller's crop of dW
+// products are skipped and their (zero) tiles are dropped again by the caller's crop of dW; KV = 10 K0 + K1
+// in general: the taps [K0, K1)^2 are the layer's (14 = a 3x3 kernel embedded at (1, 1), BnGeom::K0 = 1)
 // CW (round 4): COLUMN WINDOWS -- a map wider than any instantiated width (48 = 2 x 24, 64 = 2 x 32, 96 = 4 x 24:
 // the first matrix-core layer of 192- / 256-pixel-wide frames) is walked in windows of QQ columns: a stage is
 // PT_H rows of ONE window (its small rows lie g.Ws apart, its big patch starts 2 cb QQ columns into the row and
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
 #pragma unroll
             for (int tp = 0; tp < 25; ++tp) {
                 const int r = tp / 5, sx = tp - 5 * r;
-                if (r < KV && sx < KV)
+                if (r >= KV / 10 && r < KV % 10 && sx >= KV / 10 && sx < KV % 10)
                     acc[tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks & 1], bv[tp], acc[tp], 0, 0, 0);
                 // bias side 2: taps (1,1) (1,2), then (2,1) (2,2), right behind their last MFMA
                 if (BIAS == 2 && tp == 7) bsum += bv[6] + bv[7];
@@ -749,10 +750,13 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     if (s1) {
         const int pth = w4g_pth(g), tpf = (g.Hs + pth - 1) / pth;
         const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);
+        const bool k3 = g.KV == 4 && g.K0 == 1;
 #define W4G1_CASE(QV, B)                                                                         \
     if (g.Ws == QV && t.bias_side == B)                                                          \
-        rc = launch_wgrad4s<QV, B, true, 5, 1>(grid, st, small, big, (float*)ws, bias_part, g,   \
-                                               t.n_stages, t.splits, magic, t.nbias);
+        rc = k3 ? launch_wgrad4s<QV, B, true, 14, 1>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                     t.n_stages, t.splits, magic, t.nbias)       \
+                : launch_wgrad4s<QV, B, true, 5, 1>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                    t.n_stages, t.splits, magic, t.nbias);
 #define W4G1_ALL(QV) W4G1_CASE(QV, 0) W4G1_CASE(QV, 1)
         W4G1_ALL(8) W4G1_ALL(12) W4G1_ALL(16) W4G1_ALL(20) W4G1_ALL(24) W4G1_ALL(32) W4G1_ALL(40) W4G1_ALL(48)
         W4G1_ALL(64)
@@ -762,10 +766,14 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         // stage -> frame by multiply-high: 2^32 / tiles + 1 (exact below 2^32 / tiles stages)
         const int pth = w4g_pth(g), tpf = (g.Hs + pth - 1) / pth;
         const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);
+        // (the 3x3 window of taps -- BnGeom::K0 -- is instantiated for the plain widths only)
+        const bool k3 = g.KV == 4 && g.K0 == 1;
 #define W4G_CASE(QV, B)                                                                          \
     if (g.Ws == QV && t.bias_side == B)                                                          \
-        rc = launch_wgrad4s<QV, B, true, 5>(grid, st, small, big, (float*)ws, bias_part, g,      \
-                                         t.n_stages, t.splits, magic, t.nbias);
+        rc = k3 ? launch_wgrad4s<QV, B, true, 14>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                  t.n_stages, t.splits, magic, t.nbias)          \
+                : launch_wgrad4s<QV, B, true, 5>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                 t.n_stages, t.splits, magic, t.nbias);
         if (w4g_window(g)) {
             const int qw = w4g_window(g), ncb = g.Ws / qw;
 #define W4W_CASE(QV, B)                                                                          \
@@ -783,12 +791,12 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
             W4H_CASE(6, 0) W4H_CASE(6, 1) W4H_CASE(10, 0) W4H_CASE(10, 1) W4H_CASE(14, 0) W4H_CASE(14, 1)
 #undef W4H_CASE
         } else if (g.Ws == 8 && pth == 4) {
-            if (t.bias_side == 0)
-                rc = launch_wgrad4s<8, 0, true, 5, 2, 4>(grid, st, small, big, (float*)ws, bias_part, g,
-                                                          t.n_stages, t.splits, magic, t.nbias);
-            if (t.bias_side == 1)
-                rc = launch_wgrad4s<8, 1, true, 5, 2, 4>(grid, st, small, big, (float*)ws, bias_part, g,
-                                                          t.n_stages, t.splits, magic, t.nbias);
+#define W4P_CASE(B, K)                                                                           \
+    if (t.bias_side == B && (k3 ? 14 : 5) == K)                                                  \
+        rc = launch_wgrad4s<8, B, true, K, 2, 4>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                 t.n_stages, t.splits, magic, t.nbias);
+            W4P_CASE(0, 5) W4P_CASE(1, 5) W4P_CASE(0, 14) W4P_CASE(1, 14)
+#undef W4P_CASE
         } else {
 #define W4G_ALL(QV) W4G_CASE(QV, 0) W4G_CASE(QV, 1)
         W4G_ALL(8) W4G_ALL(12) W4G_ALL(16) W4G_ALL(20) W4G_ALL(24) W4G_ALL(28) W4G_ALL(32) W4G_ALL(36)
@@ -800,7 +808,10 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         const int lgq = ilog2_exact_w4(g.Ws), lg_tpf = ilog2_exact_w4(t.tiles_per_frame);
 #define W4S_CASE(L, B)                                                                         \
     if (lgq == L && t.bias_side == B)                                                          \
-        rc = g.KV == 4                                                                         \
+        rc = g.KV == 4 && g.K0 == 1                                                            \
+            ? launch_wgrad4s<(1 << L), B, false, 14>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                     t.n_stages, t.splits, lg_tpf, t.nbias)    \
+            : g.KV == 4                                                                        \
             ? launch_wgrad4s<(1 << L), B, false, 4>(grid, st, small, big, (float*)ws, bias_part, g, \
                                                     t.n_stages, t.splits, lg_tpf, t.nbias)     \
             : launch_wgrad4s<(1 << L), B, false, 5>(grid, st, small, big, (float*)ws, bias_part, g, \

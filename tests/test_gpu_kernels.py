@@ -92,6 +92,9 @@ CONV_CASES = [
     ('k3s2_same_12x10', 5, 64, 24, 20, 128, 3, 2, (0, 1), (0, 1)),
     ('k3s2_pt0_pl1', 2, 32, 32, 32, 64, 3, 2, (0, 1), (1, 0)),
     ('k3s2_same_E0', 2, 1, 128, 128, 32, 3, 2, (0, 1), (0, 1)),
+    ('k3s2_same_8x8_4x4', 9, 64, 8, 8, 96, 3, 2, (0, 1), (0, 1)),
+    ('k3s2_same_16x16_8x8', 5, 64, 16, 16, 96, 3, 2, (0, 1), (0, 1)),
+    ('k2s2_same_16x16', 3, 32, 16, 16, 64, 2, 2, (0, 0), (0, 0)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
@@ -221,6 +224,8 @@ CONVT_CASES = [
     ('k3_8x8', 2, 128, 8, 8, 64, 3, 2, 0, (1, 0, 1, 0), 0),
     ('k3s2_same_16x16', 3, 128, 16, 16, 64, 3, 2, 0, (0, 1, 0, 1), 0),
     ('k3s2_same_D4', 2, 32, 64, 64, 1, 3, 2, 0, (0, 1, 0, 1), 0),
+    ('k3s2_same_4x4_8x8', 9, 96, 4, 4, 64, 3, 2, 0, (0, 1, 0, 1), 0),
+    ('k3s2_same_10x12', 4, 64, 10, 12, 32, 3, 2, 0, (0, 1, 0, 1), 0),
     ('D4_64ch', 2, 64, 64, 64, 1, 5, 2, 0, (1, 2, 1, 2), 0),
     ('D4_k4_64ch', 2, 64, 64, 64, 1, 4, 2, 0, (1, 1, 1, 1), 0),
     # round 4: stride 1 -- forward on the gather-down kernel with reversed taps, weight gradient direct
