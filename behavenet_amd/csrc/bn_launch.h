@@ -142,6 +142,15 @@ int bn_launch_flip_taps(const float* w, float* wf, int Cs, int Cb, int RS, hipSt
 int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S, int accumulate,
                         hipStream_t st, const float* db5 = nullptr, float* db = nullptr, int nb = 0,
                         int dr = 0, int ds = 0);
+// kernels larger than 5x5 with stride 2 as stride-1 5x5 layers on the phases of the big map (conv_pad.hip)
+int bn_launch_space_to_depth(const float* x, float* X, int N, int C, int Hy, int Wy, hipStream_t st);
+int bn_launch_bigk_phase_pack(const float* w, float* w1, int Cs, int Cb, int R, int S, const int* kr, const int* ofr,
+                              const int* kc, const int* ofc, int sgn, int phase_out, hipStream_t st);
+int bn_launch_bigk_phase_unpack(const float* dw1, float* dw, int Cs, int Cb, int R, int S, const int* kr,
+                                const int* ofr, const int* kc, const int* ofc, int accumulate, const float* db5,
+                                float* db, int nb, hipStream_t st);
+int bn_launch_depth_to_space(const float* y, float* out, const float* bias, const float* dact_src, int N, int C,
+                             int Hy, int Wy, int act, int dact, float slope, hipStream_t st);
 bool bn_s5_down_small_ok(const BnGeom& g);
 size_t bn_s5_down_small_ws_bytes(const BnGeom& g);
 int bn_launch_s5_down_small(const float* big, const float* w, const float* bias, float* out,

@@ -448,6 +448,58 @@ static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
 }
 static inline size_t taps_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * 25 * sizeof(float)); }
 
+// ---- kernels larger than 5x5 with stride 2 (7x7, 9x9): conv_pad.hip, "Kernels LARGER than 5x5"
+struct BigK {
+    int kr[2], ofr[2], kc[2], ofc[2];   // parity of a phase's taps; tap u' of the phase is tap u = sgn u' + of
+    int sgn;                            // +1: gather-down / weight gradient, -1: gather-up
+    int Hy, Wy;                         // the phase maps
+};
+static bool bigk_enabled() {
+    static int mode = -1;                              // BN_BIGK=0: off (the im2col detour, tuning builds)
+    if (mode < 0) { const char* e = bn_tune_env("BN_BIGK"); mode = (e && e[0] == '0') ? 0 : 1; }
+    return mode == 1;
+}
+// one axis: phase rho of the big map meets the taps 2u + k (k = parity of rho + pad, u < U) at small pixel
+// p = i + o - u.  As a stride-1 5-tap kernel with padding p1 that is tap u' = u - o + p1 (gather-down, sgn +1) or
+// u' = o + p1 - u (gather-up, sgn -1); false if no p1 in 0..4 holds both phases in 5 taps
+static bool bigk_phase_axis(int R, int pad, int sgn, int* k, int* of, int* p1) {
+    for (int q = 0; q <= 4; ++q) {
+        bool ok = true;
+        for (int rho = 0; rho < 2; ++rho) {
+            k[rho] = (rho + pad) & 1;
+            const int U = (R - k[rho] + 1) / 2, o = (rho + pad - k[rho]) / 2;
+            if (sgn > 0) { of[rho] = o - q; ok = ok && q >= o && (U - 1) - o + q <= 4; }
+            else { of[rho] = o + q; ok = ok && of[rho] <= 4 && of[rho] - (U - 1) >= 0; }
+        }
+        if (ok) { *p1 = q; return true; }
+    }
+    return false;
+}
+static bool bigk_plan(int role, const BnGeom& g, BnGeom* g5, BigK* k) {
+    if (force_generic() || !bigk_enabled() || g.stride != 2 || g.CsS) return false;
+    if (g.R < 6 || g.R > 10 || g.S < 6 || g.S > 10) return false;
+    if ((g.Hb & 1) || (g.Wb & 3)) return false;
+    int pt1 = 0, pl1 = 0;
+    k->sgn = role == 1 ? -1 : 1;
+    if (!bigk_phase_axis(g.R, g.pt, k->sgn, k->kr, k->ofr, &pt1)) return false;
+    if (!bigk_phase_axis(g.S, g.pl, k->sgn, k->kc, k->ofc, &pl1)) return false;
+    k->Hy = g.Hb / 2; k->Wy = g.Wb / 2;
+    if ((size_t)g.N * 4 * g.Cb * k->Hy * k->Wy * 4 >= 0x7fffffffull) return false;
+    *g5 = g;
+    g5->R = g5->S = 5;
+    g5->stride = 1; g5->pt = pt1; g5->pl = pl1; g5->KV = 0; g5->K0 = 0;
+    if (role == 1) {
+        // the phases are the OUTPUT of a gather-down from the small map
+        g5->Cs = 4 * g.Cb; g5->Hs = k->Hy; g5->Ws = k->Wy;
+        g5->Cb = g.Cs; g5->Hb = g.Hs; g5->Wb = g.Ws;
+        return served_fast(0, *g5);
+    }
+    g5->Cb = 4 * g.Cb; g5->Hb = k->Hy; g5->Wb = k->Wy;
+    return served_fast(role, *g5);
+}
+static inline size_t bigk_map_bytes(const BnGeom& g) { return align256((size_t)g.N * g.Cb * g.Hb * g.Wb * sizeof(float)); }
+static inline size_t bigk_w_bytes(const BnGeom& g) { return align256((size_t)g.Cs * 4 * g.Cb * 25 * sizeof(float)); }
+
 // stride == kernel layers between maps other than 8x8 and 2x2 (the last layer of 64x48 / 192x160 frames): the
 // weight gradient as ONE GEMM over the (permuted) windows instead of the first-generation direct kernel
 static bool s5_wgrad_by_col(const BnGeom& g) {
@@ -484,6 +536,19 @@ static int run_down(int family, const float* big, const float* w, const float* b
         if (rc) return rc;
         return run_down(family, big, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
                         (char*)ws + wb, ws_bytes - wb, st);
+    }
+    BigK bk;
+    if (!generic && bigk_plan(0, g, &g5, &bk)) {
+        const size_t xb = bigk_map_bytes(g), wb = bigk_w_bytes(g);
+        if (!ws || ws_bytes < xb + wb + role_ws_need(0, g5)) return BN_E_WORKSPACE;
+        float* X = (float*)ws;
+        float* w1 = (float*)((char*)ws + xb);
+        int rc = bn_launch_space_to_depth(big, X, g.N, g.Cb, bk.Hy, bk.Wy, st);
+        if (rc) return rc;
+        rc = bn_launch_bigk_phase_pack(w, w1, g.Cs, g.Cb, g.R, g.S, bk.kr, bk.ofr, bk.kc, bk.ofc, 1, 0, st);
+        if (rc) return rc;
+        return run_down(family, X, w1, bias, out, dact_src, g5, act, dact, slope, (char*)ws + xb + wb,
+                        ws_bytes - xb - wb, st);
     }
     if (!generic && chan_plan(0, g, &g5)) {
         const size_t cb = chan_bytes(g);
@@ -608,6 +673,19 @@ static int run_up(int family, const float* small, const float* w, const float* b
         return run_up(family, small, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
                       (char*)ws + wb, ws_bytes - wb, st);
     }
+    BigK bk;
+    if (!generic && bigk_plan(1, g, &g5, &bk)) {
+        const size_t yb = bigk_map_bytes(g), wb = bigk_w_bytes(g);
+        if (!ws || ws_bytes < yb + wb + role_ws_need(0, g5)) return BN_E_WORKSPACE;
+        float* y = (float*)ws;
+        float* w1 = (float*)((char*)ws + yb);
+        int rc = bn_launch_bigk_phase_pack(w, w1, g.Cs, g.Cb, g.R, g.S, bk.kr, bk.ofr, bk.kc, bk.ofc, -1, 1, st);
+        if (rc) return rc;
+        rc = run_down(family, small, w1, nullptr, y, nullptr, g5, BN_ACT_NONE, BN_ACT_NONE, slope,
+                      (char*)ws + yb + wb, ws_bytes - yb - wb, st);
+        if (rc) return rc;
+        return bn_launch_depth_to_space(y, out, bias, dact_src, g.N, g.Cb, bk.Hy, bk.Wy, act, dact, slope, st);
+    }
     if (!generic && bn_qg2_up_supported(g, act, dact_src ? dact : BN_ACT_NONE)) {
         BnProfScope prof(family, g.Cs, g.Cb, "k_qg2_up", st);
         return bn_launch_qg2_up(small, w, bias, out, dact_src, g, act, dact, slope, st);
@@ -728,6 +806,25 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         if (done && bias_done) *bias_done = true;
         return bn_launch_crop_taps((const float*)ws, dw, (size_t)g.Cs * g.Cb, g.R, g.S, accumulate, st,
                                    done ? db5 : nullptr, db, nb, taps_dr(g), taps_ds(g));
+    }
+    BigK bk;
+    if (!generic && bigk_plan(2, g, &g5, &bk)) {
+        // as above: dw1 and the small side's bias gradient are written into scratch, k_bigk_phase_unpack adds them;
+        // the big side's channel sums are left to the caller
+        const size_t xb = bigk_map_bytes(g), wb = bigk_w_bytes(g) + 4096;
+        if (!ws || ws_bytes < xb + wb + role_ws_need(2, g5)) return BN_E_WORKSPACE;
+        float* X = (float*)ws;
+        float* dw1 = (float*)((char*)ws + xb);
+        float* db5 = (db && bias_side == 1 && g.Cs <= 1024) ? (float*)((char*)ws + xb + bigk_w_bytes(g)) : nullptr;
+        int rc = bn_launch_space_to_depth(big, X, g.N, g.Cb, bk.Hy, bk.Wy, st);
+        if (rc) return rc;
+        bool done = false;
+        rc = run_wgrad(family, small, X, dw1, g5, 0, (char*)ws + xb + wb, ws_bytes - xb - wb, st, db5,
+                       bias_side, &done);
+        if (rc) return rc;
+        if (done && bias_done) *bias_done = true;
+        return bn_launch_bigk_phase_unpack(dw1, dw, g.Cs, g.Cb, g.R, g.S, bk.kr, bk.ofr, bk.kc, bk.ofc, accumulate,
+                                           done ? db5 : nullptr, db, g.Cs, st);
     }
     if (!generic && chan_plan(2, g, &g5)) {
         const size_t cb = chan_bytes(g);
@@ -883,6 +980,9 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
 static size_t role_ws_need(int role, const BnGeom& g) {
     BnGeom g5;
     if (taps_plan(role, g, &g5)) return taps_bytes(g) + (role == 2 ? 4096 : 0) + role_ws_need(role, g5);
+    BigK bk;
+    if (bigk_plan(role, g, &g5, &bk))
+        return bigk_map_bytes(g) + bigk_w_bytes(g) + (role == 2 ? 4096 : 0) + role_ws_need(role == 1 ? 0 : role, g5);
     if (chan_plan(role, g, &g5)) return chan_bytes(g) + role_ws_need(role, g5);
     if (bn_qgemm_supported(g)) return bn_qgemm_ws_bytes(role, g);
     if (role == 2 && s5_wgrad_by_col(g)) return bn_col_ws_bytes(g);

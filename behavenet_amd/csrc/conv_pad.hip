@@ -168,6 +168,146 @@ int bn_launch_crop_taps(const float* dw5, float* dw, size_t pairs, int R, int S,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernels LARGER than 5x5 with stride 2 (7x7, 9x9: the reference's architecture search draws 3 / 5 / 7 / 9 with equal
+// probability) on the stride-1 5x5 kernels, without im2col / col2im: big pixel (2i + rho, 2j + sig) only meets the taps
+// of one parity per axis -- at most 5 x 5 of them for kernels up to 10 x 10 -- and meets them at stride 1 on the
+// small map.  With the big map cut into its four phases X[(rho, sig) C + c][i][j] = x[c][2i + rho][2j + sig]
+// (k_space_to_depth; zero padding of X = zero padding of x), every role of the layer is the same role of ONE stride-1
+// 5x5 layer between the small map and the 4 Cb phase channels:
+//   gather-down      out[m][p] = sum_{(rho sig) c, u'} X[..][p - pt1 + u'] W1[m][(rho sig) c][u']
+//   weight gradient  dW1[m][(rho sig) c][u'] -> dW (k_bigk_phase_unpack)
+//   gather-up        Y[(rho sig) c][i] = sum_{m, u'} small[m][i - pt1 + u'] W1'[(rho sig) c][m][u'], interleaved
+//                    by k_depth_to_space, which also carries the epilogue (bias, activation, mask of the layer below)
+// 7x7: 16 / 12 / 12 / 9 taps in the four phases, 9x9: 25 / 20 / 20 / 16 -- of 25 multiplied each.
+// ---------------------------------------------------------------------------------------------
+// X[n][(2 rho + sig) C + c][i][j] = x[n][c][2i + rho][2j + sig]; one 16-byte read, two 8-byte writes per thread
+__global__ __launch_bounds__(PD_THREADS) void k_space_to_depth(const float* __restrict__ x, float* __restrict__ X,
+                                                                unsigned N, unsigned C, int Hy, int Wy) {
+    const int Hb = 2 * Hy;
+    const unsigned wq = Wy / 2, total = N * C * Hb * wq;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned w4 = q % wq, t = q / wq;
+        const int h = t % Hb;
+        const unsigned nc = t / Hb, c = nc % C, n = nc / C;
+        const int rho = h & 1, i = h >> 1;
+        const float4 v = reinterpret_cast<const float4*>(x)[q];
+        float* p0 = X + (((size_t)(n * 4 + 2 * rho) * C + c) * Hy + i) * Wy + 2 * w4;
+        *reinterpret_cast<float2*>(p0) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2*>(p0 + (size_t)C * Hy * Wy) = make_float2(v.y, v.w);
+    }
+}
+int bn_launch_space_to_depth(const float* x, float* X, int N, int C, int Hy, int Wy, hipStream_t st) {
+    const size_t total = (size_t)N * C * 4 * Hy * Wy;
+    if (total >= (1ull << 32) || (Wy & 1)) return BN_E_SHAPE;
+    hipLaunchKernelGGL(k_space_to_depth, dim3(pd_blocks(total / 4)), dim3(PD_THREADS), 0, st, x, X, (unsigned)N,
+                       (unsigned)C, Hy, Wy);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+// tap (u', v') of phase (rho, sig) is tap (2u + kr[rho], 2v + kc[sig]) of the layer, u = sgn u' + ofr[rho] (sgn = +1:
+// the phases are the layer's big side -- gather-down, weight gradient; -1: gather-up, the taps reversed), 0.0f where
+// that tap does not exist.
+//   phase_out = 0: w1[m][(2 rho + sig) Cb + c][u'][v']     1: w1[(2 rho + sig) Cb + c][m][u'][v']
+struct BigKTaps { int kr[2], ofr[2], kc[2], ofc[2], sgn; };
+__global__ __launch_bounds__(PD_THREADS) void k_bigk_phase_pack(const float* __restrict__ w, float* __restrict__ w1,
+                                                                 unsigned Cs, unsigned Cb, int R, int S,
+                                                                 BigKTaps k, int phase_out) {
+    const unsigned total = 4 * Cb * Cs * 25;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned t = q % 25;
+        unsigned m, pc;
+        if (phase_out) { m = (q / 25) % Cs; pc = q / (25 * Cs); }
+        else { pc = (q / 25) % (4 * Cb); m = q / (25 * 4 * Cb); }
+        const unsigned c = pc % Cb, ph = pc / Cb;
+        const int rho = ph >> 1, sig = ph & 1;
+        const int u = k.sgn * (int)(t / 5) + k.ofr[rho], v = k.sgn * (int)(t % 5) + k.ofc[sig];
+        const int r = 2 * u + k.kr[rho], sx = 2 * v + k.kc[sig];
+        w1[q] = (u >= 0 && v >= 0 && r < R && sx < S) ? w[((size_t)(m * Cb + c) * R + r) * S + sx] : 0.f;
+    }
+}
+static BigKTaps bigk_taps(const int* kr, const int* ofr, const int* kc, const int* ofc, int sgn) {
+    BigKTaps k;
+    for (int i = 0; i < 2; ++i) { k.kr[i] = kr[i]; k.ofr[i] = ofr[i]; k.kc[i] = kc[i]; k.ofc[i] = ofc[i]; }
+    k.sgn = sgn;
+    return k;
+}
+int bn_launch_bigk_phase_pack(const float* w, float* w1, int Cs, int Cb, int R, int S, const int* kr, const int* ofr,
+                              const int* kc, const int* ofc, int sgn, int phase_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_bigk_phase_pack, dim3(pd_blocks((size_t)4 * Cb * Cs * 25)), dim3(PD_THREADS), 0, st, w, w1,
+                       (unsigned)Cs, (unsigned)Cb, R, S, bigk_taps(kr, ofr, kc, ofc, sgn), phase_out);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+// dw[m][c][r][s] (+)= dw1[m][(2 rho + sig) Cb + c][u'][v'] of the phase that holds tap (r, s);  db[i] (+)= db5[i] as
+// in k_crop_taps
+__global__ __launch_bounds__(PD_THREADS) void k_bigk_phase_unpack(const float* __restrict__ dw1,
+                                                                   float* __restrict__ dw, unsigned Cs, unsigned Cb,
+                                                                   int R, int S, BigKTaps k, int accumulate,
+                                                                   const float* __restrict__ db5,
+                                                                   float* __restrict__ db, unsigned nb) {
+    const unsigned total = Cs * Cb * R * S;
+    if (db5 && blockIdx.x == 0)
+        for (unsigned i = threadIdx.x; i < nb; i += PD_THREADS) db[i] = accumulate ? db[i] + db5[i] : db5[i];
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned t = q % (R * S), mc = q / (R * S);
+        const unsigned c = mc % Cb, m = mc / Cb;
+        const int r = t / S, sx = t - S * r;
+        const int rho = (k.kr[0] == (r & 1)) ? 0 : 1, sig = (k.kc[0] == (sx & 1)) ? 0 : 1;
+        const int up = (r >> 1) - k.ofr[rho], vp = (sx >> 1) - k.ofc[sig];        // sgn = +1
+        const float v = dw1[((size_t)(m * 4 + 2 * rho + sig) * Cb + c) * 25 + up * 5 + vp];
+        dw[q] = accumulate ? dw[q] + v : v;
+    }
+}
+int bn_launch_bigk_phase_unpack(const float* dw1, float* dw, int Cs, int Cb, int R, int S, const int* kr,
+                                const int* ofr, const int* kc, const int* ofc, int accumulate, const float* db5,
+                                float* db, int nb, hipStream_t st) {
+    hipLaunchKernelGGL(k_bigk_phase_unpack, dim3(pd_blocks((size_t)Cs * Cb * R * S)), dim3(PD_THREADS), 0, st, dw1,
+                       dw, (unsigned)Cs, (unsigned)Cb, R, S, bigk_taps(kr, ofr, kc, ofc, 1), accumulate, db5, db,
+                       (unsigned)nb);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+// out[n][c][2i + rho][2j + sig] = epilogue(y[n][(2 rho + sig) C + c][i][j] + bias[c]); four output columns per thread
+__global__ __launch_bounds__(PD_THREADS) void k_depth_to_space(const float* __restrict__ y, float* __restrict__ out,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ dact_src, unsigned N,
+                                                                unsigned C, int Hy, int Wy, int act, int dact,
+                                                                float slope) {
+    const int Hb = 2 * Hy, Wb = 2 * Wy;
+    const unsigned wq = Wb / 4, total = N * C * Hb * wq;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned w4 = q % wq, t = q / wq;
+        const int h = t % Hb;
+        const unsigned nc = t / Hb, c = nc % C, n = nc / C;
+        const int rho = h & 1, i = h >> 1;
+        const float* p0 = y + (((size_t)(n * 4 + 2 * rho) * C + c) * Hy + i) * Wy + 2 * w4;
+        const float* p1 = p0 + (size_t)C * Hy * Wy;
+        const float2 a = *reinterpret_cast<const float2*>(p0), b = *reinterpret_cast<const float2*>(p1);
+        const float bz = bias ? bias[c] : 0.f;
+        float v[4] = {a.x + bz, b.x + bz, a.y + bz, b.y + bz};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = bn_apply_act(v[k], act, slope);
+        if (dact_src) {
+            const float4 d = reinterpret_cast<const float4*>(dact_src)[q];
+            v[0] *= bn_act_grad_from_output(d.x, dact, slope);
+            v[1] *= bn_act_grad_from_output(d.y, dact, slope);
+            v[2] *= bn_act_grad_from_output(d.z, dact, slope);
+            v[3] *= bn_act_grad_from_output(d.w, dact, slope);
+        }
+        reinterpret_cast<float4*>(out)[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+int bn_launch_depth_to_space(const float* y, float* out, const float* bias, const float* dact_src, int N, int C,
+                             int Hy, int Wy, int act, int dact, float slope, hipStream_t st) {
+    const size_t total = (size_t)N * C * 4 * Hy * Wy;
+    if (total >= (1ull << 32) || (Wy & 1)) return BN_E_SHAPE;
+    hipLaunchKernelGGL(k_depth_to_space, dim3(pd_blocks(total / 4)), dim3(PD_THREADS), 0, st, y, out, bias, dact_src,
+                       (unsigned)N, (unsigned)C, Hy, Wy, act, dact, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Channel groups: the single-channel edge kernels take up to 32 channels on their many-channel
 // side; a layer with more (ae_arch_2.json: 1 -> 64) is run group by group on contiguous copies
 // (gather-down and weight gradient are independent per small-side channel).

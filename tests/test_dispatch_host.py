@@ -19,7 +19,7 @@ from behavenet_amd import _hip
 def _cases(seed, count):
     """The seeded sweep plus every named conv case of the device tests."""
     from tests.test_gpu_kernels import _random_conv_cases, CONV_CASES
-    return list(CONV_CASES) + _random_conv_cases(seed, count)
+    return list(CONV_CASES) + _random_conv_cases(seed, count) + _random_conv_cases(seed + 1, count // 4, big=True)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='launches real kernels on dummy pointers when a GPU is present')

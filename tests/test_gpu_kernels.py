@@ -95,6 +95,15 @@ CONV_CASES = [
     ('k3s2_same_8x8_4x4', 9, 64, 8, 8, 96, 3, 2, (0, 1), (0, 1)),
     ('k3s2_same_16x16_8x8', 5, 64, 16, 16, 96, 3, 2, (0, 1), (0, 1)),
     ('k2s2_same_16x16', 3, 32, 16, 16, 64, 2, 2, (0, 0), (0, 0)),
+    # kernels larger than 5x5 with stride 2 (the architecture search draws 7 and 9): tap blocks on shifted copies /
+    # phases at stride 1 (csrc/conv_pad.hip)
+    ('k7s2_same_32x32', 3, 32, 32, 32, 64, 7, 2, (2, 3), (2, 3)),
+    ('k9s2_same_32x32', 2, 64, 32, 32, 128, 9, 2, (3, 4), (3, 4)),
+    ('k9s2_same_16x16', 4, 32, 16, 16, 64, 9, 2, (3, 4), (3, 4)),
+    ('k7s2_same_24x20', 3, 32, 24, 20, 64, 7, 2, (2, 3), (2, 3)),
+    ('k7s2_same_E0', 2, 1, 64, 64, 32, 7, 2, (2, 3), (2, 3)),
+    ('k9s2_same_E0', 2, 1, 128, 128, 16, 9, 2, (3, 4), (3, 4)),
+    ('k6s2_k8', 2, 32, 16, 16, 32, 8, 2, (3, 3), (3, 3)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
@@ -226,6 +235,10 @@ CONVT_CASES = [
     ('k3s2_same_D4', 2, 32, 64, 64, 1, 3, 2, 0, (0, 1, 0, 1), 0),
     ('k3s2_same_4x4_8x8', 9, 96, 4, 4, 64, 3, 2, 0, (0, 1, 0, 1), 0),
     ('k3s2_same_10x12', 4, 64, 10, 12, 32, 3, 2, 0, (0, 1, 0, 1), 0),
+    ('k7s2_same_16x16', 3, 64, 16, 16, 32, 7, 2, 0, (2, 3, 2, 3), 0),
+    ('k9s2_same_8x8', 3, 128, 8, 8, 64, 9, 2, 0, (3, 4, 3, 4), 0),
+    ('k9s2_same_D4', 2, 32, 64, 64, 1, 9, 2, 0, (3, 4, 3, 4), 0),
+    ('k7s2_same_10x12', 3, 64, 10, 12, 32, 7, 2, 0, (2, 3, 2, 3), 0),
     ('D4_64ch', 2, 64, 64, 64, 1, 5, 2, 0, (1, 2, 1, 2), 0),
     ('D4_k4_64ch', 2, 64, 64, 64, 1, 4, 2, 0, (1, 1, 1, 1), 0),
     # round 4: stride 1 -- forward on the gather-down kernel with reversed taps, weight gradient direct
@@ -736,15 +749,15 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
         assert torch.equal(dv.cpu(), vr.grad)
 
 
-def _random_conv_cases(seed, count):
+def _random_conv_cases(seed, count, big=False):
     """Seeded sweep over what the round-4 tile logic has to get right: map sizes that are no powers of
     two (tiles with masked lanes, frames' last tiles / stages hanging over the edge, frame groups cut short
     by the batch), channel counts off the 32 / 64 tile sizes, 3x3 / 4x4 / 5x5 kernels, strides 1 and 2."""
     rng = np.random.RandomState(seed)
     cases = []
     while len(cases) < count:
-        st = int(rng.choice([1, 2, 2, 2]))
-        R = int(rng.choice([3, 4, 5, 5, 5]))
+        st = 2 if big else int(rng.choice([1, 2, 2, 2]))
+        R = int(rng.choice([6, 7, 7, 8, 9, 9])) if big else int(rng.choice([3, 4, 5, 5, 5]))
         P, Q = int(rng.randint(1, 41)), int(rng.randint(1, 41))
         if rng.rand() < 0.4:
             Q = int(rng.choice([4, 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48]))
@@ -752,6 +765,10 @@ def _random_conv_cases(seed, count):
         N = int(rng.randint(1, 10))
         if st == 2:
             pt, pl = int(rng.choice([1, 1, 1, 2])), int(rng.choice([1, 1, 1, 2]))
+            if big:
+                # TF-"same" offsets most of the time ((R - 2) // 2 above / left), any other now and then
+                pt = (R - 2) // 2 if rng.rand() < 0.6 else int(rng.randint(0, R - 1))
+                pl = (R - 2) // 2 if rng.rand() < 0.6 else int(rng.randint(0, R - 1))
             H, W = 2 * P - int(rng.rand() < 0.15), 2 * Q - int(rng.rand() < 0.15)
             pb, pr = (P - 1) * 2 + R - H - pt, (Q - 1) * 2 + R - W - pl
         else:
@@ -766,9 +783,10 @@ def _random_conv_cases(seed, count):
 
 
 RANDOM_CASES = _random_conv_cases(2026, 72)
+RANDOM_BIG_CASES = _random_conv_cases(2027, 32, big=True)
 
 
-@pytest.mark.parametrize('case', RANDOM_CASES, ids=[c[0] for c in RANDOM_CASES])
+@pytest.mark.parametrize('case', RANDOM_CASES + RANDOM_BIG_CASES, ids=[c[0] for c in RANDOM_CASES + RANDOM_BIG_CASES])
 def test_random_geometries_all_roles(case):
     """Forward, both data-gradient forms and the weight / bias gradients of a seeded sweep of geometries
     against float64 (same gate as the named cases)."""
@@ -785,7 +803,8 @@ def test_random_geometries_all_roles(case):
 # the transposed layers between the same maps: small (K, P, Q) -> big (C, H, W), cropped by the conv's pads
 RANDOM_T_CASES = [(c[0] + 'T', c[1], c[5], (c[3] + sum(c[8]) - c[6]) // c[7] + 1,
                    (c[4] + sum(c[9]) - c[6]) // c[7] + 1, c[2], c[6], c[7], 0,
-                   (c[9][0], c[9][1], c[8][0], c[8][1]), 0) for c in _random_conv_cases(4052, 48)]
+                   (c[9][0], c[9][1], c[8][0], c[8][1]), 0)
+                  for c in _random_conv_cases(4052, 48) + _random_conv_cases(4053, 20, big=True)]
 
 
 @pytest.mark.parametrize('case', RANDOM_T_CASES, ids=[c[0] for c in RANDOM_T_CASES])
@@ -816,6 +835,32 @@ def test_stride1_roles_run_without_im2col(case_name):
             (_hip.PROF_CONV_BWD_W, lambda: _hip.conv2d_bwd_weight(
                 x.to(DEV), dy, torch.empty_like(w, device=DEV), torch.empty_like(b, device=DEV), geom, False),
              'stride 1')):
+        _hip.prof_select(prof, 0, 0)
+        try:
+            fn()
+            torch.cuda.synchronize()
+            _, n, name = _hip.prof_read()
+        finally:
+            _hip.prof_select(_hip.PROF_NONE)
+        assert n >= 1 and want in name and 'im2col' not in name and 'col2im' not in name, name
+
+
+@pytest.mark.parametrize('case_name', ['k7s2_same_32x32', 'k9s2_same_32x32', 'k9s2_same_16x16'])
+def test_kernels_larger_than_5x5_run_without_im2col(case_name):
+    """Round 4: 7x7 / 9x9 stride-2 layers are stride-1 5x5 layers on the four phases of the big map
+    (csrc/conv_pad.hip, k_space_to_depth / k_depth_to_space): every role on the matrix-core kernels."""
+    case = [c for c in CONV_CASES if c[0] == case_name][0]
+    x, w, b, geom, ref = _conv_setup(case)
+    N, K, P, Q = geom[0], geom[4], geom[10], geom[11]
+    dy = torch.ones((N, K, P, Q), device=DEV)
+    for prof, fn, want in (
+            (_hip.PROF_CONV_FWD, lambda: _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE),
+             'k_down_mfma<'),
+            (_hip.PROF_CONV_BWD_D, lambda: _hip.conv2d_bwd_data(dy, w.to(DEV), geom, None, _hip.ACT_NONE, SLOPE),
+             'k_down_mfma<'),
+            (_hip.PROF_CONV_BWD_W, lambda: _hip.conv2d_bwd_weight(
+                x.to(DEV), dy, torch.empty_like(w, device=DEV), torch.empty_like(b, device=DEV), geom, False),
+             'k_wgrad4s_mfma<')):
         _hip.prof_select(prof, 0, 0)
         try:
             fn()
