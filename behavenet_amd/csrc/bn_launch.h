@@ -149,6 +149,12 @@ int bn_launch_bigk_phase_pack(const float* w, float* w1, int Cs, int Cb, int R, 
 int bn_launch_bigk_phase_unpack(const float* dw1, float* dw, int Cs, int Cb, int R, int S, const int* kr,
                                 const int* ofr, const int* kc, const int* ofc, int accumulate, const float* db5,
                                 float* db, int nb, hipStream_t st);
+// ... and with stride 1: four shifted copies of the big map against the four blocks of taps
+int bn_launch_shift_cat(const float* x, float* y, int N, int C, int H, int W, int Ho, int Wo, int dr0, int dr1,
+                        int dc0, int dc1, hipStream_t st);
+int bn_launch_bigk_pack(const float* w, float* w5, int Cs, int Cb, int R, int S, int L0r, int L0c, hipStream_t st);
+int bn_launch_bigk_unpack(const float* dw5, float* dw, int Cs, int Cb, int R, int S, int L0r, int L0c,
+                          int accumulate, const float* db5, float* db, int nb, hipStream_t st);
 int bn_launch_depth_to_space(const float* y, float* out, const float* bias, const float* dact_src, int N, int C,
                              int Hy, int Wy, int act, int dact, float slope, hipStream_t st);
 bool bn_s5_down_small_ok(const BnGeom& g);

@@ -392,6 +392,7 @@ static inline size_t tile_ws_bytes(const TilePlan& p) { return p.big_bytes + p.s
 static size_t role_ws_need(int role, const BnGeom& g);
 static bool served_fast(int role, const BnGeom& g);
 static bool flip_plan(const BnGeom& g, BnGeom* gf, BnFastPlan* inner);
+static bool bigk1_flip_plan(const BnGeom& g, BnGeom* gf);
 // ---- single- / two-channel edge layers with more than 32 channels on the other side (1 -> 64):
 // groups of 32 small-side channels on contiguous copies (gather-down, weight gradient)
 static bool chan_plan(int role, const BnGeom& g, BnGeom* gg) {
@@ -405,6 +406,7 @@ static bool chan_plan(int role, const BnGeom& g, BnGeom* gg) {
 static inline size_t chan_bytes(const BnGeom& g) { return align256((size_t)g.N * 32 * g.Hs * g.Ws * 4); }
 static bool served_fast(int role, const BnGeom& g) {
     BnGeom gg;
+    if (role == 0 && bn_s1c1_ok(g)) return true;
     if (chan_plan(role, g, &gg)) return true;
     if (g.Cb <= 4) {
         const BnFastPlan ed = role == 0 ? bn_edge_down_plan(g) : role == 1 ? bn_edge_up_plan(g)
@@ -418,6 +420,7 @@ static bool served_fast(int role, const BnGeom& g) {
         BnGeom gf;
         BnFastPlan in;
         if (flip_plan(g, &gf, &in)) return true;
+        if (bigk1_flip_plan(g, &gf)) return true;
     }
     return pad_plan(role, g).ok || tile_plan(role, g).ok;
 }
@@ -498,6 +501,58 @@ static bool bigk_plan(int role, const BnGeom& g, BnGeom* g5, BigK* k) {
     return served_fast(role, *g5);
 }
 static inline size_t bigk_map_bytes(const BnGeom& g) { return align256((size_t)g.N * g.Cb * g.Hb * g.Wb * sizeof(float)); }
+// ---- ... and with stride 1 (conv_pad.hip, k_shift_cat): 2 x 2 blocks of taps on four shifted copies of the big map,
+// frames in blocks that keep the copies below 2 GB (the kernels' 32-bit offsets)
+struct BigK1 { int L0r, L0c, dr[2], dc[2], Ho, Wo, nb; };
+static bool bigk1_plan(int role, const BnGeom& g, BnGeom* g5, BigK1* k) {
+    if (force_generic() || !bigk_enabled() || g.stride != 1 || g.CsS || role == 1) return false;
+    if (g.R < 6 || g.R > 10 || g.S < 6 || g.S > 10) return false;
+    k->L0r = (g.R + 1) / 2; k->L0c = (g.S + 1) / 2;
+    k->dr[0] = -g.pt; k->dr[1] = k->L0r - g.pt;
+    k->dc[0] = -g.pl; k->dc[1] = k->L0c - g.pl;
+    k->Ho = g.Hs + 4; k->Wo = (g.Ws + 4 + 3) & ~3;
+    const size_t per_frame = (size_t)4 * g.Cb * k->Ho * k->Wo * sizeof(float);
+    if (per_frame >= 0x40000000ull) return false;
+    const size_t nb = 0x70000000ull / per_frame;
+    k->nb = nb < (size_t)g.N ? (int)nb : g.N;
+    *g5 = g;
+    g5->N = k->nb;
+    g5->Cb = 4 * g.Cb; g5->Hb = k->Ho; g5->Wb = k->Wo;
+    g5->R = g5->S = 5; g5->pt = g5->pl = 0; g5->KV = 0; g5->K0 = 0;
+    if (!served_fast(role, *g5)) return false;
+    if (g.N % k->nb) {                                  // the last, shorter block of frames
+        BnGeom gl = *g5;
+        gl.N = g.N % k->nb;
+        if (!served_fast(role, gl)) return false;
+    }
+    return true;
+}
+static inline size_t bigk1_map_bytes(const BnGeom& g, const BigK1& k) {
+    return align256((size_t)k.nb * 4 * g.Cb * k.Ho * k.Wo * sizeof(float));
+}
+static size_t bigk1_inner_ws(int role, const BnGeom& g, const BnGeom& g5, const BigK1& k) {
+    size_t need = role_ws_need(role, g5);
+    if (g.N % k.nb) {
+        BnGeom gl = g5;
+        gl.N = g.N % k.nb;
+        const size_t l = role_ws_need(role, gl);
+        if (l > need) need = l;
+    }
+    return need;
+}
+// the gather-up role of such a layer: the gather-down of the flipped layer (as flip_plan, whose inner plan is the
+// shifted-copies one)
+static bool bigk1_flip_plan(const BnGeom& g, BnGeom* gf) {
+    if (force_generic() || g.stride != 1 || g.pt > g.R - 1 || g.pl > g.S - 1) return false;
+    *gf = g;
+    gf->Cs = g.Cb; gf->Hs = g.Hb; gf->Ws = g.Wb;
+    gf->Cb = g.Cs; gf->Hb = g.Hs; gf->Wb = g.Ws;
+    gf->pt = g.R - 1 - g.pt; gf->pl = g.S - 1 - g.pl;
+    if (bn_s1c1_ok(*gf)) return true;                   // onto one / two channels: the vector kernel (conv_edge.hip)
+    BnGeom g5;
+    BigK1 k;
+    return g.R >= 6 && g.S >= 6 && bigk1_plan(0, *gf, &g5, &k);
+}
 static inline size_t bigk_w_bytes(const BnGeom& g) { return align256((size_t)g.Cs * 4 * g.Cb * 25 * sizeof(float)); }
 
 // stride == kernel layers between maps other than 8x8 and 2x2 (the last layer of 64x48 / 192x160 frames): the
@@ -537,6 +592,11 @@ static int run_down(int family, const float* big, const float* w, const float* b
         return run_down(family, big, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
                         (char*)ws + wb, ws_bytes - wb, st);
     }
+    if (!generic && bn_s1c1_ok(g)) {
+        static const char* names[4] = {"k_down_s1_c1<3>", "k_down_s1_c1<5>", "k_down_s1_c1<7>", "k_down_s1_c1<9>"};
+        BnProfScope prof(family, g.Cb, g.Cs, names[(g.R - 3) / 2], st);
+        return bn_launch_s1c1(big, w, bias, out, dact_src, g, act, dact, slope, st);
+    }
     BigK bk;
     if (!generic && bigk_plan(0, g, &g5, &bk)) {
         const size_t xb = bigk_map_bytes(g), wb = bigk_w_bytes(g);
@@ -549,6 +609,27 @@ static int run_down(int family, const float* big, const float* w, const float* b
         if (rc) return rc;
         return run_down(family, X, w1, bias, out, dact_src, g5, act, dact, slope, (char*)ws + xb + wb,
                         ws_bytes - xb - wb, st);
+    }
+    BigK1 b1;
+    if (!generic && bigk1_plan(0, g, &g5, &b1)) {
+        const size_t xb = bigk1_map_bytes(g, b1), wb = bigk_w_bytes(g), iw = bigk1_inner_ws(0, g, g5, b1);
+        if (!ws || ws_bytes < xb + wb + iw) return BN_E_WORKSPACE;
+        float* xcat = (float*)ws;
+        float* w5 = (float*)((char*)ws + xb);
+        int rc = bn_launch_bigk_pack(w, w5, g.Cs, g.Cb, g.R, g.S, b1.L0r, b1.L0c, st);
+        if (rc) return rc;
+        const size_t fb = (size_t)g.Cb * g.Hb * g.Wb, fs = (size_t)g.Cs * g.Hs * g.Ws;
+        for (int n0 = 0; n0 < g.N; n0 += b1.nb) {
+            BnGeom gb = g5;
+            gb.N = g.N - n0 < b1.nb ? g.N - n0 : b1.nb;
+            rc = bn_launch_shift_cat(big + n0 * fb, xcat, gb.N, g.Cb, g.Hb, g.Wb, b1.Ho, b1.Wo, b1.dr[0], b1.dr[1],
+                                     b1.dc[0], b1.dc[1], st);
+            if (rc) return rc;
+            rc = run_down(family, xcat, w5, bias, out + n0 * fs, dact_src ? dact_src + n0 * fs : nullptr, gb, act,
+                          dact, slope, (char*)ws + xb + wb, ws_bytes - xb - wb, st);
+            if (rc) return rc;
+        }
+        return 0;
     }
     if (!generic && chan_plan(0, g, &g5)) {
         const size_t cb = chan_bytes(g);
@@ -773,6 +854,14 @@ static int run_up(int family, const float* small, const float* w, const float* b
             return bn_launch_down_fast(in, small, (const float*)ws, bias, out, dact_src, gf, act, dact, slope,
                                        (char*)ws + fb, st);
         }
+        if (bigk1_flip_plan(g, &gf)) {
+            const size_t fb = flip_bytes(g);
+            if (!ws || ws_bytes < fb + role_ws_need(0, gf)) return BN_E_WORKSPACE;
+            const int rc = bn_launch_flip_taps(w, (float*)ws, g.Cs, g.Cb, g.R * g.S, st);
+            if (rc) return rc;
+            return run_down(family, small, (const float*)ws, bias, out, dact_src, gf, act, dact, slope,
+                            (char*)ws + fb, ws_bytes - fb, st);
+        }
     }
     if (!generic && !plan.supported && bn_col_ok(g)) {
         BnProfScope prof(family, g.Cs, g.Cb, "k_gemm_mfma + k_col2im", st);
@@ -825,6 +914,31 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         if (done && bias_done) *bias_done = true;
         return bn_launch_bigk_phase_unpack(dw1, dw, g.Cs, g.Cb, g.R, g.S, bk.kr, bk.ofr, bk.kc, bk.ofc, accumulate,
                                            done ? db5 : nullptr, db, g.Cs, st);
+    }
+    BigK1 b1;
+    if (!generic && bigk1_plan(2, g, &g5, &b1)) {
+        const size_t xb = bigk1_map_bytes(g, b1), wb = bigk_w_bytes(g) + 4096, iw = bigk1_inner_ws(2, g, g5, b1);
+        if (!ws || ws_bytes < xb + wb + iw) return BN_E_WORKSPACE;
+        float* xcat = (float*)ws;
+        float* dw5 = (float*)((char*)ws + xb);
+        // (the small side's bias sums ride with the inner kernel only when one block of frames holds the batch)
+        float* db5 = (db && bias_side == 1 && g.Cs <= 1024 && b1.nb == g.N)
+                         ? (float*)((char*)ws + xb + bigk_w_bytes(g)) : nullptr;
+        const size_t fb = (size_t)g.Cb * g.Hb * g.Wb, fs = (size_t)g.Cs * g.Hs * g.Ws;
+        bool done = false;
+        for (int n0 = 0; n0 < g.N; n0 += b1.nb) {
+            BnGeom gb = g5;
+            gb.N = g.N - n0 < b1.nb ? g.N - n0 : b1.nb;
+            int rc = bn_launch_shift_cat(big + n0 * fb, xcat, gb.N, g.Cb, g.Hb, g.Wb, b1.Ho, b1.Wo, b1.dr[0],
+                                         b1.dr[1], b1.dc[0], b1.dc[1], st);
+            if (rc) return rc;
+            rc = run_wgrad(family, small + n0 * fs, xcat, dw5, gb, n0 > 0, (char*)ws + xb + wb, ws_bytes - xb - wb,
+                           st, db5, bias_side, &done);
+            if (rc) return rc;
+        }
+        if (done && bias_done) *bias_done = true;
+        return bn_launch_bigk_unpack(dw5, dw, g.Cs, g.Cb, g.R, g.S, b1.L0r, b1.L0c, accumulate,
+                                     done ? db5 : nullptr, db, g.Cs, st);
     }
     if (!generic && chan_plan(2, g, &g5)) {
         const size_t cb = chan_bytes(g);
@@ -980,9 +1094,13 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
 static size_t role_ws_need(int role, const BnGeom& g) {
     BnGeom g5;
     if (taps_plan(role, g, &g5)) return taps_bytes(g) + (role == 2 ? 4096 : 0) + role_ws_need(role, g5);
+    if (role == 0 && bn_s1c1_ok(g)) return 0;
     BigK bk;
     if (bigk_plan(role, g, &g5, &bk))
         return bigk_map_bytes(g) + bigk_w_bytes(g) + (role == 2 ? 4096 : 0) + role_ws_need(role == 1 ? 0 : role, g5);
+    BigK1 b1;
+    if (bigk1_plan(role, g, &g5, &b1))
+        return bigk1_map_bytes(g, b1) + bigk_w_bytes(g) + (role == 2 ? 4096 : 0) + bigk1_inner_ws(role, g, g5, b1);
     if (chan_plan(role, g, &g5)) return chan_bytes(g) + role_ws_need(role, g5);
     if (bn_qgemm_supported(g)) return bn_qgemm_ws_bytes(role, g);
     if (role == 2 && s5_wgrad_by_col(g)) return bn_col_ws_bytes(g);
@@ -998,6 +1116,7 @@ static size_t role_ws_need(int role, const BnGeom& g) {
         BnGeom gf;
         BnFastPlan in;
         if (flip_plan(g, &gf, &in)) return flip_bytes(g) + in.ws_bytes;
+        if (bigk1_flip_plan(g, &gf)) return flip_bytes(g) + role_ws_need(0, gf);
     }
     if (role == 0 && bn_s5_down_small_ok(g)) return bn_s5_down_small_ws_bytes(g);
     const PadPlan pp = pad_plan(role, g);

@@ -2191,3 +2191,112 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
     BN_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Stride-1 gather-down onto ONE or TWO channels (round 4): the last transposed layer of a max-pooling architecture
+// (its forward is the gather-down of the flipped layer, capi.hip) with any odd kernel the reference's search draws
+// (3 / 5 / 7 / 9).  One output channel leaves 31 of the 32 rows of a matrix-core tile idle, so this is a vector
+// kernel: a workgroup owns 16 x 64 output pixels of a frame, walks the input channels four at a time through LDS
+// ((16 + K - 1) x (64 + K - 1) pixels each, 0.0f off the frame: any padding, any map) and every thread keeps four
+// adjacent pixels of a row per output channel -- a row of K + 3 LDS words feeds 4 K multiply-adds per output channel;
+// the taps are wave-uniform (scalar loads).  It ran as k_gemm_mfma + k_col2im: 1.6 ms per launch for 16 -> 1 channels,
+// 9x9 on 128x128 frames.
+// ---------------------------------------------------------------------------------------------
+#define S1C_TH 16
+#define S1C_TW 64
+#define S1C_CC 4
+template <int KS, int NOUT>
+__global__ __launch_bounds__(256) void k_down_s1_c1(const float* __restrict__ big, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     const float* __restrict__ dact_src, BnGeom g, int act, int dact,
+                                                     float slope, int tiles_h, int tiles_w) {
+    constexpr int IH = S1C_TH + KS - 1, IWP = (S1C_TW + KS - 1 + 3) & ~3, NV = (KS + 3 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float tile[S1C_CC * IH * IWP];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w; b /= tiles_w;
+    const int th = b % tiles_h;
+    const int n = b / tiles_h;
+    const int h0 = th * S1C_TH, w0 = tw * S1C_TW;
+    const size_t HWb = (size_t)g.Hb * g.Wb;
+    float acc[NOUT][4];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+    for (int c0 = 0; c0 < g.Cb; c0 += S1C_CC) {
+        __syncthreads();
+        for (int e = tid; e < S1C_CC * IH * IWP; e += 256) {
+            const int cc = e / (IH * IWP), rem = e - cc * (IH * IWP);
+            const int y = rem / IWP, xx = rem - y * IWP;
+            const int hb = h0 - g.pt + y, wb = w0 - g.pl + xx;
+            const bool ok = (c0 + cc) < g.Cb && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+            tile[e] = ok ? big[((size_t)n * g.Cb + c0 + cc) * HWb + (size_t)hb * g.Wb + wb] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cc = 0; cc < S1C_CC; ++cc) {
+            const int c = min(c0 + cc, g.Cb - 1);          // (past the last channel the tile holds zeros)
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+                float row[4 * NV];
+                const float4* rp = reinterpret_cast<const float4*>(tile + (cc * IH + ty + r) * IWP + 4 * tx);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float4 q = rp[v];
+                    row[4 * v] = q.x; row[4 * v + 1] = q.y; row[4 * v + 2] = q.z; row[4 * v + 3] = q.w;
+                }
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const float* wr = w + (((size_t)o * g.Cb + c) * KS + r) * KS;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const float wv = wr[s];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(row[s + j], wv, acc[o][j]);
+                    }
+                }
+            }
+        }
+    }
+    const int h = h0 + ty, wq = w0 + 4 * tx;
+    if (h >= g.Hs) return;
+    const size_t PQ = (size_t)g.Hs * g.Ws;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const float bz = bias ? bias[o] : 0.f;
+        const size_t base = ((size_t)n * NOUT + o) * PQ + (size_t)h * g.Ws + wq;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (wq + j >= g.Ws) continue;
+            float v = bn_apply_act(acc[o][j] + bz, act, slope);
+            if (dact_src) v *= bn_act_grad_from_output(dact_src[base + j], dact, slope);
+            out[base + j] = v;
+        }
+    }
+}
+
+bool bn_s1c1_ok(const BnGeom& g) {
+    if (g.stride != 1 || g.R != g.S || (g.R != 3 && g.R != 5 && g.R != 7 && g.R != 9)) return false;
+    if (g.Cs > 2 || g.CsS) return false;
+    const size_t tiles = (size_t)g.N * ((g.Hs + S1C_TH - 1) / S1C_TH) * ((g.Ws + S1C_TW - 1) / S1C_TW);
+    return tiles < 0x7fffffffull;
+}
+
+int bn_launch_s1c1(const float* big, const float* w, const float* bias, float* out, const float* dact_src,
+                   const BnGeom& g, int act, int dact, float slope, hipStream_t st) {
+    if (!bn_s1c1_ok(g)) return BN_E_SHAPE;
+    const int tiles_h = (g.Hs + S1C_TH - 1) / S1C_TH, tiles_w = (g.Ws + S1C_TW - 1) / S1C_TW;
+    const dim3 grid((unsigned)((size_t)g.N * tiles_h * tiles_w));
+#define S1C_CASE(K, O)                                                                                      \
+    if (g.R == K && g.Cs == O) {                                                                            \
+        BN_LAUNCH_MAIN((k_down_s1_c1<K, O>), grid, dim3(256), 0, st, big, w, bias, out, dact_src, g, act,   \
+                       dact, slope, tiles_h, tiles_w);                                                      \
+        BN_LAUNCH_CHECK();                                                                                  \
+        return 0;                                                                                           \
+    }
+    S1C_CASE(3, 1) S1C_CASE(3, 2) S1C_CASE(5, 1) S1C_CASE(5, 2) S1C_CASE(7, 1) S1C_CASE(7, 2) S1C_CASE(9, 1)
+    S1C_CASE(9, 2)
+#undef S1C_CASE
+    return BN_E_SHAPE;
+}

@@ -267,6 +267,87 @@ int bn_launch_bigk_phase_unpack(const float* dw1, float* dw, int Cs, int Cb, int
     BN_LAUNCH_CHECK();
     return 0;
 }
+// ---------------------------------------------------------------------------------------------
+// ... and with stride 1 (under max pooling the search draws the same kernel sizes): the taps are cut into 2 x 2 blocks
+// of at most 5 x 5 (rows [0, L0r) and [L0r, R), columns likewise); small pixel p meets big row p - pt + r0 + r' = row
+// p + r' of the big map SHIFTED by r0 - pt rows.  The four shifted copies, each (Hs + 4) x (Ws + 4) so that every row a
+// 5-tap window can reach is IN the copy (k_shift_cat writes 0.0f where the frame ends), concatenated along the channel
+// axis, make the layer ONE 5x5 layer without padding over 4 Cb channels (weights k_bigk_pack / k_bigk_unpack).  The
+// gather-up role is the gather-down of the flipped layer (k_flip_taps above).
+// ---------------------------------------------------------------------------------------------
+// y[n][b C + c][h][w] = x[n][c][h + dr[b >> 1]][w + dc[b & 1]], h < Ho, w < Wo (0.0f off the frame)
+__global__ __launch_bounds__(PD_THREADS) void k_shift_cat(const float* __restrict__ x, float* __restrict__ y,
+                                                           unsigned N, unsigned C, int H, int W, int Ho, int Wo,
+                                                           int dr0, int dr1, int dc0, int dc1) {
+    const unsigned wq = Wo / 4, total = N * 4 * C * Ho * wq;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned w4 = q % wq, t = q / wq;
+        const int h = t % Ho;
+        const unsigned pc = t / Ho;                      // n * 4C + b * C + c
+        const unsigned c = pc % C, b = (pc / C) & 3, n = pc / (4 * C);
+        const int hs = h + ((b >> 1) ? dr1 : dr0), w0 = 4 * (int)w4 + ((b & 1) ? dc1 : dc0);
+        const float* row = x + ((size_t)(n * C + c) * H + hs) * W;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[k] = (hs >= 0 && hs < H && w0 + k >= 0 && w0 + k < W) ? row[w0 + k] : 0.f;
+        reinterpret_cast<float4*>(y)[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+int bn_launch_shift_cat(const float* x, float* y, int N, int C, int H, int W, int Ho, int Wo, int dr0, int dr1,
+                        int dc0, int dc1, hipStream_t st) {
+    const size_t total = (size_t)N * 4 * C * Ho * Wo;
+    if (total >= (1ull << 32) || (Wo & 3)) return BN_E_SHAPE;
+    hipLaunchKernelGGL(k_shift_cat, dim3(pd_blocks(total / 4)), dim3(PD_THREADS), 0, st, x, y, (unsigned)N,
+                       (unsigned)C, H, W, Ho, Wo, dr0, dr1, dc0, dc1);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+// w5[m][b Cb + c][r'][s'] = w[m][c][r0(b) + r'][s0(b) + s'] inside block b, 0.0f past it
+__global__ __launch_bounds__(PD_THREADS) void k_bigk_pack(const float* __restrict__ w, float* __restrict__ w5,
+                                                           unsigned Cs, unsigned Cb, int R, int S, int L0r,
+                                                           int L0c) {
+    const unsigned total = Cs * 4 * Cb * 25;
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned t = q % 25, bc = (q / 25) % (4 * Cb), m = q / (25 * 4 * Cb);
+        const unsigned b = bc / Cb, c = bc - b * Cb;
+        const int r = (int)(t / 5) + ((b >> 1) ? L0r : 0), sx = (int)(t % 5) + ((b & 1) ? L0c : 0);
+        const int rl = (b >> 1) ? R : L0r, sl = (b & 1) ? S : L0c;
+        w5[q] = (r < rl && sx < sl) ? w[((size_t)(m * Cb + c) * R + r) * S + sx] : 0.f;
+    }
+}
+int bn_launch_bigk_pack(const float* w, float* w5, int Cs, int Cb, int R, int S, int L0r, int L0c, hipStream_t st) {
+    hipLaunchKernelGGL(k_bigk_pack, dim3(pd_blocks((size_t)Cs * 4 * Cb * 25)), dim3(PD_THREADS), 0, st, w, w5,
+                       (unsigned)Cs, (unsigned)Cb, R, S, L0r, L0c);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+// dw[m][c][r][s] (+)= dw5[m][b(r, s) Cb + c][r - r0][s - s0];  db[i] (+)= db5[i] as in k_crop_taps
+__global__ __launch_bounds__(PD_THREADS) void k_bigk_unpack(const float* __restrict__ dw5, float* __restrict__ dw,
+                                                             unsigned Cs, unsigned Cb, int R, int S, int L0r,
+                                                             int L0c, int accumulate,
+                                                             const float* __restrict__ db5, float* __restrict__ db,
+                                                             unsigned nb) {
+    const unsigned total = Cs * Cb * R * S;
+    if (db5 && blockIdx.x == 0)
+        for (unsigned i = threadIdx.x; i < nb; i += PD_THREADS) db[i] = accumulate ? db[i] + db5[i] : db5[i];
+    for (unsigned q = blockIdx.x * PD_THREADS + threadIdx.x; q < total; q += gridDim.x * PD_THREADS) {
+        const unsigned t = q % (R * S), mc = q / (R * S);
+        const unsigned c = mc % Cb, m = mc / Cb;
+        const int r = t / S, sx = t - S * r;
+        const int br = r >= L0r, bs = sx >= L0c;
+        const float v = dw5[((size_t)(m * 4 + 2 * br + bs) * Cb + c) * 25 + (r - (br ? L0r : 0)) * 5 +
+                            (sx - (bs ? L0c : 0))];
+        dw[q] = accumulate ? dw[q] + v : v;
+    }
+}
+int bn_launch_bigk_unpack(const float* dw5, float* dw, int Cs, int Cb, int R, int S, int L0r, int L0c,
+                          int accumulate, const float* db5, float* db, int nb, hipStream_t st) {
+    hipLaunchKernelGGL(k_bigk_unpack, dim3(pd_blocks((size_t)Cs * Cb * R * S)), dim3(PD_THREADS), 0, st, dw5, dw,
+                       (unsigned)Cs, (unsigned)Cb, R, S, L0r, L0c, accumulate, db5, db, (unsigned)nb);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
 // out[n][c][2i + rho][2j + sig] = epilogue(y[n][(2 rho + sig) C + c][i][j] + bias[c]); four output columns per thread
 __global__ __launch_bounds__(PD_THREADS) void k_depth_to_space(const float* __restrict__ y, float* __restrict__ out,
                                                                 const float* __restrict__ bias,

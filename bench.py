@@ -224,6 +224,14 @@ def secondary_configs(hp_ae, feed_rates=True):
                              'max-pooling test architecture (tests/golden/arch_maxpool.json: 5x5 stride-1 '
                              'conv 1 -> 16 / pool / conv 16 -> 32 / pool, mirrored unpooling decoder) on '
                              '1x128x128', names=False))
+    # two architectures as the reference's random search draws them (kernel sizes 3 / 5 / 7 / 9 with equal weight,
+    # models/ae_model_architecture_generator.py:94 of the reference)
+    out.append(geometry_step(os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k3.json'), [1, 128, 128],
+                             'drawn architecture, all 3x3 stride 2 (32-64-128-256-512; the tap window [1, 4) of the '
+                             '5x5 stride-2 families) on 1x128x128', names=False))
+    out.append(geometry_step(os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k7_k5_k9_k3.json'), [1, 128, 128],
+                             'drawn architecture, kernels 7-5-9-3 stride 2 (32-64-128-256; 7x7 / 9x9 as stride-1 5x5 '
+                             'layers on the four phases of the big map, no im2col) on 1x128x128', names=False))
     if feed_rates:
         # --- the headline step fed over PCIe: pinned uint8 trials, one-trial look-ahead
         torch.manual_seed(0)

@@ -292,7 +292,8 @@ def test_whole_model_off_the_benchmark_shape_vs_oracle(dim, n_frames):
     grads_close_on_same_branches(hip, ora64, 'AE %dx%dx%d batch %d' % (dim[0], dim[1], dim[2], n_frames))
 
 
-@pytest.mark.parametrize('which', ['ae_arch_2', 'maxpool', 'batch_norm', 'drawn_k3', 'drawn_k7_k5_k9_k3'])
+@pytest.mark.parametrize('which', ['ae_arch_2', 'maxpool', 'batch_norm', 'drawn_k3', 'drawn_k7_k5_k9_k3',
+                                   'maxpool_k9_k7'])
 def test_whole_model_other_architectures_at_bench_batch_vs_oracle(which):
     """Round 4, at 1x128x128 and 208 frames (chunks 200 + 8): the shipped ae_arch_2.json (4x4 kernels on
     the KV = 4 instantiations, a stride-1 layer without im2col), the max-pooling test architecture
@@ -316,9 +317,12 @@ def test_whole_model_other_architectures_at_bench_batch_vs_oracle(which):
     # (the two architectures as the reference's random search draws them -- tools/arch_jsons: 3x3 layers on the
     # tap window [1, 4) of the 5x5 families; 7x7 / 9x9 layers as stride-1 5x5 layers on the phases of the big map --
     # at 72 frames: the float64 oracle of the 9x9 layers is the slow side)
-    dim, n_frames = [1, 128, 128], (64 if which == 'maxpool' else 72 if which.startswith('drawn') else 208)
+    # (maxpool_k9_k7: the max-pooling test architecture with 9x9 / 7x7 stride-1 layers -- four shifted copies of the
+    # big map against 2 x 2 blocks of taps, k_down_s1_c1<9> for the last transposed layer)
+    dim, n_frames = [1, 128, 128], (64 if which.startswith('maxpool') else 72 if which.startswith('drawn') else 208)
     js = {'ae_arch_2': os.path.join(repo, 'behavenet_amd', 'configs', 'ae_jsons', 'ae_arch_2.json'),
           'maxpool': os.path.join(repo, 'tests', 'golden', 'arch_maxpool.json'), 'batch_norm': None,
+          'maxpool_k9_k7': os.path.join(repo, 'tools', 'arch_jsons', 'drawn_maxpool_k9_k7.json'),
           'drawn_k3': os.path.join(repo, 'tools', 'arch_jsons', 'drawn_k3.json'),
           'drawn_k7_k5_k9_k3': os.path.join(repo, 'tools', 'arch_jsons', 'drawn_k7_k5_k9_k3.json')}[which]
     extra = {'ae_batch_norm': True} if which == 'batch_norm' else None
@@ -337,7 +341,7 @@ def test_whole_model_other_architectures_at_bench_batch_vs_oracle(which):
         l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True)['loss']
     br.assert_only_ties()
     assert lh == pytest.approx(l64, rel=1e-5)
-    if which == 'maxpool':
+    if which.startswith('maxpool'):
         with torch.no_grad():
             _, idx_h, _ = hip.encoding(x.to(DEV), dataset=0)
             _, idx_o, _ = ora64.encoding(x.double(), dataset=0)

@@ -104,6 +104,12 @@ CONV_CASES = [
     ('k7s2_same_E0', 2, 1, 64, 64, 32, 7, 2, (2, 3), (2, 3)),
     ('k9s2_same_E0', 2, 1, 128, 128, 16, 9, 2, (3, 4), (3, 4)),
     ('k6s2_k8', 2, 32, 16, 16, 32, 8, 2, (3, 3), (3, 3)),
+    # ... and with stride 1 (under max pooling): 2 x 2 blocks of taps on four shifted copies of the big map
+    ('s1_k7_32x32', 3, 32, 32, 32, 64, 7, 1, (3, 3), (3, 3)),
+    ('s1_k9_24x20', 2, 16, 24, 20, 32, 9, 1, (4, 4), (4, 4)),
+    ('s1_k9_1ch_64x64', 2, 1, 64, 64, 16, 9, 1, (4, 4), (4, 4)),
+    ('s1_k7_valid_16x12', 2, 32, 22, 18, 32, 7, 1, (0, 0), (0, 0)),
+    ('s1_k9_16x16_n9', 9, 64, 16, 16, 32, 9, 1, (4, 4), (4, 4)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
@@ -247,6 +253,12 @@ CONVT_CASES = [
     ('s1_k4_8x8', 5, 64, 8, 8, 64, 4, 1, 0, (1, 2, 1, 2), 0),
     ('s1_k5_64x64', 2, 32, 64, 64, 16, 5, 1, (2, 2), None, 0),
     ('s1_k5_to_1ch_42x72', 3, 16, 42, 72, 1, 5, 1, (2, 2), None, 0),
+    ('s1_k7_16x16', 3, 64, 16, 16, 32, 7, 1, (3, 3), None, 0),
+    ('s1_k9_32x32', 2, 32, 32, 32, 16, 9, 1, (4, 4), None, 0),
+    ('s1_k9_to_1ch_64x64', 2, 16, 64, 64, 1, 9, 1, (4, 4), None, 0),
+    ('s1_k7_to_2ch_40x72', 3, 18, 40, 72, 2, 7, 1, (3, 3), None, 0),
+    ('s1_k3_to_1ch_50x30', 2, 7, 50, 30, 1, 3, 1, (1, 1), None, 0),
+    ('s1_k5_to_1ch_pad04', 2, 16, 20, 24, 1, 5, 1, 0, (0, 4, 4, 0), 0),
     ('s1_k5_to_2ch_128x128', 2, 16, 128, 128, 2, 5, 1, (2, 2), None, 0),
     # round 4: no powers of two, directly on the stride-2 families (see CONV_CASES)
     ('np2_16x12', 5, 64, 16, 12, 32, 5, 2, 0, (1, 2, 1, 2), 0),
@@ -756,7 +768,7 @@ def _random_conv_cases(seed, count, big=False):
     rng = np.random.RandomState(seed)
     cases = []
     while len(cases) < count:
-        st = 2 if big else int(rng.choice([1, 2, 2, 2]))
+        st = int(rng.choice([1, 2, 2])) if big else int(rng.choice([1, 2, 2, 2]))
         R = int(rng.choice([6, 7, 7, 8, 9, 9])) if big else int(rng.choice([3, 4, 5, 5, 5]))
         P, Q = int(rng.randint(1, 41)), int(rng.randint(1, 41))
         if rng.rand() < 0.4:
@@ -845,10 +857,12 @@ def test_stride1_roles_run_without_im2col(case_name):
         assert n >= 1 and want in name and 'im2col' not in name and 'col2im' not in name, name
 
 
-@pytest.mark.parametrize('case_name', ['k7s2_same_32x32', 'k9s2_same_32x32', 'k9s2_same_16x16'])
+@pytest.mark.parametrize('case_name', ['k7s2_same_32x32', 'k9s2_same_32x32', 'k9s2_same_16x16', 's1_k7_32x32',
+                                       's1_k9_16x16_n9', 's1_k9_24x20'])
 def test_kernels_larger_than_5x5_run_without_im2col(case_name):
     """Round 4: 7x7 / 9x9 stride-2 layers are stride-1 5x5 layers on the four phases of the big map
-    (csrc/conv_pad.hip, k_space_to_depth / k_depth_to_space): every role on the matrix-core kernels."""
+    (csrc/conv_pad.hip, k_space_to_depth / k_depth_to_space), stride-1 ones 5x5 layers on four shifted copies
+    (k_shift_cat): every role on the matrix-core kernels."""
     case = [c for c in CONV_CASES if c[0] == case_name][0]
     x, w, b, geom, ref = _conv_setup(case)
     N, K, P, Q = geom[0], geom[4], geom[10], geom[11]
