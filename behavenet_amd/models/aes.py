@@ -73,6 +73,15 @@ def _bn_modules(container, layer_names):
     return out
 
 
+
+def _tap_signs(plan, j, layer, h):
+    """Tests only (tests/branches.py): the layer-by-layer paths of max-pooling architectures run every layer as
+    its own one-layer stack, so the LeakyReLU signs are filed under the module's plan here."""
+    from behavenet_amd import hip_functions as hf
+    if hf._sign_tap is not None and layer.act == _hip.ACT_LRELU:
+        hf._sign_tap.setdefault(id(plan), [[] for _ in plan])[j].append((h.detach() > 0).cpu())
+
+
 class ConvAEEncoder(BaseModule):
     """Convolutional encoder (ref aes.py:17-218)."""
 
@@ -225,6 +234,7 @@ class ConvAEEncoder(BaseModule):
                 h, idx = max_pool(h, k, stride, pad, out_hw)
                 pool_idx.append(idx)
                 h = activation(h, _hip.ACT_LRELU)
+            _tap_signs(self._plan, j, layer, h)
         self._pool_state = (pool_idx, sizes)
         return h.reshape(h.size(0), -1)
 
@@ -455,6 +465,7 @@ class ConvAEDecoder(BaseModule):
                     h = conv_stack_bn([layer], h, params[2 * j:2 * j + 2], [bns[j]])
                 else:
                     h = conv_stack([layer], h, params[2 * j:2 * j + 2])
+                _tap_signs(self._plan, j, layer, h)
         elif hp['ae_batch_norm']:
             h = conv_stack_bn(self._plan, h, params, _bn_modules(self.decoder, self._layer_names))
         else:

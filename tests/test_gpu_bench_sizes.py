@@ -332,6 +332,11 @@ def test_whole_model_other_architectures_at_bench_batch_vs_oracle(which):
     torch.manual_seed(0)
     ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae', extra)).double()
     x = torch.from_numpy(make_frames(n_frames, dim, seed=29))
+    if which == 'maxpool_k9_k7':
+        # (the smooth synthetic frames leave windows of equal values behind 9x9 kernels -- every seed has pooling
+        # winners that fp32 and float64 break differently; 32 frames of noise with this seed have none)
+        n_frames = 32
+        x = torch.rand((n_frames, 1, 128, 128), generator=torch.Generator().manual_seed(31))
     hip.train()
     ora64.train()
     hip.zero_grad(set_to_none=True)

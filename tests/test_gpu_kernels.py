@@ -110,6 +110,10 @@ CONV_CASES = [
     ('s1_k9_1ch_64x64', 2, 1, 64, 64, 16, 9, 1, (4, 4), (4, 4)),
     ('s1_k7_valid_16x12', 2, 32, 22, 18, 32, 7, 1, (0, 0), (0, 0)),
     ('s1_k9_16x16_n9', 9, 64, 16, 16, 32, 9, 1, (4, 4), (4, 4)),
+    ('s1_k9_1ch_128x128', 2, 1, 128, 128, 16, 9, 1, (4, 4), (4, 4)),
+    ('s1_k5_valid_4ch_128x128', 2, 4, 132, 132, 16, 5, 1, (0, 0), (0, 0)),
+    ('s1_k7_64x64', 2, 16, 64, 64, 32, 7, 1, (3, 3), (3, 3)),
+    ('s1_k5_valid_64ch_64x64', 2, 64, 68, 68, 32, 5, 1, (0, 0), (0, 0)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
