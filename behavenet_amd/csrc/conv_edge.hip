@@ -2278,7 +2278,8 @@ __global__ __launch_bounds__(256) void k_down_s1_c1(const float* __restrict__ bi
 
 bool bn_s1c1_ok(const BnGeom& g) {
     if (g.stride != 1 || g.R != g.S || (g.R != 3 && g.R != 5 && g.R != 7 && g.R != 9)) return false;
-    if (g.Cs > 2 || g.CsS) return false;
+    // (four channels with 5x5 taps: the four phases of a 7x7 / 9x9 stride-2 gather-up onto one channel, capi.hip)
+    if ((g.Cs > 2 && !(g.Cs == 4 && g.R == 5)) || g.CsS) return false;
     const size_t tiles = (size_t)g.N * ((g.Hs + S1C_TH - 1) / S1C_TH) * ((g.Ws + S1C_TW - 1) / S1C_TW);
     return tiles < 0x7fffffffull;
 }
@@ -2295,7 +2296,7 @@ int bn_launch_s1c1(const float* big, const float* w, const float* bias, float* o
         BN_LAUNCH_CHECK();                                                                                  \
         return 0;                                                                                           \
     }
-    S1C_CASE(3, 1) S1C_CASE(3, 2) S1C_CASE(5, 1) S1C_CASE(5, 2) S1C_CASE(7, 1) S1C_CASE(7, 2) S1C_CASE(9, 1)
+    S1C_CASE(3, 1) S1C_CASE(3, 2) S1C_CASE(5, 1) S1C_CASE(5, 2) S1C_CASE(5, 4) S1C_CASE(7, 1) S1C_CASE(7, 2) S1C_CASE(9, 1)
     S1C_CASE(9, 2)
 #undef S1C_CASE
     return BN_E_SHAPE;
