@@ -324,6 +324,31 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     if (g.Cb < 2 && !s1) return p;
     if (g.Cs < 16) return p;
     const int CC = (g.stride == 5) ? 2 : 4;
+    if (g.stride == 1 && g.R == 5 && g.S == 5) {
+        // round 4: the streamlined kernel's stride-1 instantiation (16-byte LDS-DMA, double-buffered images, pinned
+        // issue order) where its tile serves the map; the tile shape that wastes the fewest pixels
+        float fill = 0.f;
+        int bi = -1;
+        static const int cand1[3][2] = {{2, 1}, {2, 2}, {1, 1}};
+        for (int i = 0; i < 3; ++i) {
+            if (cand1[i][0] == 2 && g.Cs < 64) continue;
+            const float f = bn_down2_fill(g, cand1[i][0], cand1[i][1]);
+            if (f > fill + 0.02f) { fill = f; bi = i; }
+        }
+        if (bi >= 0) {
+            static const char* const names2s[3] = {"k_down2_mfma<2, 1, 5, 0, 1>", "k_down2_mfma<2, 2, 5, 0, 1>",
+                                                   "k_down2_mfma<1, 1, 5, 0, 1>"};
+            p.supported = true;
+            p.a = cand1[bi][0]; p.b = cand1[bi][1]; p.c = CC; p.d = 1; p.variant = 2;
+            p.kernel_name = names2s[bi];
+            const int s2 = bn_down2_splits(g, p.a, p.b);
+            if (s2 > 1) {
+                p.d = s2;
+                p.ws_bytes = (size_t)s2 * g.N * g.Cs * g.Hs * g.Ws * sizeof(float);
+            }
+            return p;
+        }
+    }
     // stride 2: 64 ch x 128 px tiles whenever they give ~100 workgroups -- measured in situ
     // (bench.py, other streams' kernels fill the machine) they beat both the larger 64x256 tiles
     // and the 32x128 tiles with more workgroups; stride 5: 64x128 tiles, the reduction split

@@ -73,7 +73,11 @@ struct Down2Tile {
 // KV = 4: the 5x5 taps are a smaller kernel zero-extended (BnGeom::KV): rows / columns of taps from KV on
 // are neither read nor multiplied (a 4x4 layer: 16 of 25 products); LDS layouts stay the 5x5 ones.
 // K0 = 1: so are row 0 / column 0 (BnGeom::K0, a 3x3 layer embedded at (1, 1): 9 of 25 products)
-template <int MR, int NR, int KV, int K0 = 0>
+// ST = 1 (round 4): the stride-1 layers -- max-pooling architectures, and every 7x7 / 9x9 layer after its rewrite as a
+// 5x5 layer on phases / shifted copies (capi.hip) -- on the same schedule: image rows `Ws + 8` words, a unit's image
+// PT_H + 4 rows, a lane's five columns are consecutive words of either parity (4-byte reads paired by ds_read2_b32
+// instead of 8-byte ones), any column offset 0..4.  KV = 5 only.
+template <int MR, int NR, int KV, int K0 = 0, int ST = 2>
 __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, Down2Tile t, int act,
@@ -128,7 +132,9 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
         const int pj = rem / Q, qj = rem - pj * Q;
         const int un = (u0 + f) / t.UPF, up0 = (u0 + f - un * t.UPF) * t.PT_H;     // the unit's frame, first row
         // pair 0 = columns (2q-2, 2q-1) of the image = LDS columns 2q+2, 2q+3
-        base[nr] = f * t.FS + (2 * pj) * t.RW + 2 * qj + (D2_X0 - 2) + kk * t.CHS;
+        // (stride 1: word 1 of the lane's run = image column q - pl = LDS column q - pl + D2_X0)
+        base[nr] = ST == 2 ? f * t.FS + (2 * pj) * t.RW + 2 * qj + (D2_X0 - 2) + kk * t.CHS
+                           : f * t.FS + pj * t.RW + qj + (D2_X0 - 1 - g.pl) + kk * t.CHS;
         pvalid[nr] = inside && un < g.N && (up0 + pj) < g.Hs;
         opix[nr] = (size_t)un * g.Cs * PQ + (size_t)(up0 + pj) * Q + qj;
     }
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
         const int y = (int)(((float)r2 + 0.5f) * t.inv_c4);
         const int c4 = r2 - y * C4;
         const int un = (u0 + f) / t.UPF, up0 = (u0 + f - un * t.UPF) * t.PT_H;
-        const int hb = 2 * up0 - g.pt + y, wb = 4 * c4 - D2_X0;
+        const int hb = ST * up0 - g.pt + y, wb = 4 * c4 - D2_X0;
         const bool ok = e < t.groups && un < g.N && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
         xoff[k] = ok ? (((un - n0) * g.Cb + cc) * HW + hb * g.Wb + wb) * 4 : 0x7fffffff;
     }
@@ -259,7 +265,11 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
             // columns 2q-1 .. 2q+3 = words 1..5 of the aligned six-word run
             const int v = u - WU * MR, nr = v / 2;
             const float* xb = smem + xro[BUF][nr][cp][r];
-            if (K0 == 1) {
+            if (ST == 1) {
+                // either parity: 4-byte words (the compiler pairs them into ds_read2_b32)
+                if ((v & 1) == 0) bq[0][nr] = xb[1];
+                else { bq[1][nr] = xb[2]; bq[2][nr] = xb[3]; bq[3][nr] = xb[4]; bq[4][nr] = xb[5]; }
+            } else if (K0 == 1) {
                 if ((v & 1) == 0) {
                     const floatx2d c1p = *reinterpret_cast<const floatx2d*>(xb + 2);
                     bq[1][nr] = c1p.x; bq[2][nr] = c1p.y;
@@ -423,14 +433,17 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
 }
 
 static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* lds_bytes) {
-    if (g.R != 5 || g.S != 5 || g.stride != 2 || g.pl != 1 || g.pt < 0) return false;
+    const int ST = g.stride;
+    if (g.R != 5 || g.S != 5 || (ST != 2 && ST != 1) || g.pt < 0) return false;
+    if (ST == 2 ? g.pl != 1 : (g.pl < 0 || g.pl > 4 || g.KV == 4)) return false;
     if ((g.Cb % D2_CC) != 0 || (g.Wb & 3) != 0) return false;
     const int TP = 128 * NR;
     // any even map width (16-byte rows of the big map), any height: a tile is F whole frames or PT_H
     // rows of one (the rows of a frame spread evenly over its tiles); powers of two fill it exactly
-    if (g.Ws < 4 || (g.Ws & 1) || g.Ws > TP || g.Hs < 1) return false;
+    if (g.Ws < 4 || (ST == 2 && (g.Ws & 1)) || g.Ws > TP || g.Hs < 1) return false;
     const bool pow2 = ilog2_exact_d2(g.Ws) >= 0 && ilog2_exact_d2(g.Hs) >= 0;
-    int rw = 2 * g.Ws + 8;
+    const int rw0 = ST == 2 ? 2 * g.Ws + 8 : (g.Ws + 8 + 3) & ~3;
+    int rw = rw0;
     // the 32 pixels of a half wave (several image rows when Ws < 32 or no power of two) cover the 64
     // banks once with their 8-byte reads if the row stride == Ws (mod 32)
     if ((g.Ws < 32 || !pow2) && (g.Ws & 3) == 0)
@@ -440,7 +453,7 @@ static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* ld
     // bank-friendly row stride (conflicts on the operand reads cost less than idle pixels), then units
     auto fits = [&](int pth, int stride, int F) {
         t->RW = stride; t->PT_H = pth; t->F = F;
-        t->IH = 2 * (pth - 1) + 5;
+        t->IH = ST * (pth - 1) + 5;
         t->FS = t->IH * stride;
         t->CHS = F * t->FS;
         t->groups = D2_CC * t->CHS / 4;
@@ -456,7 +469,7 @@ static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* ld
         int F = TP / (pth * g.Ws);
         if (pow2 && upf > 1) F = 1;
         for (int pass = 0; pass < 2; ++pass) {
-            const int stride = pass == 0 ? rw : 2 * g.Ws + 8;
+            const int stride = pass == 0 ? rw : rw0;
             int Fp = F;
             while (Fp >= 1 && !fits(pth, stride, Fp)) { if (pass == 0) { Fp = 0; break; } --Fp; }
             if (Fp < 1) continue;
@@ -488,18 +501,18 @@ bool bn_down2_supported(const BnGeom& g, int MR, int NR) {
     return down2_tile(g, MR, NR, &t, &lds);
 }
 
-template <int MR, int NR, int KV, int K0 = 0>
+template <int MR, int NR, int KV, int K0 = 0, int ST = 2>
 static int launch_down2(const Down2Tile& t, dim3 grid, size_t lds, const float* big, const float* w,
                         const float* bias, float* out, const float* dact_src, const BnGeom& g,
                         int act, int dact, float slope, hipStream_t st, int cper, size_t zstride) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_down2_mfma<MR, NR, KV, K0>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_down2_mfma<MR, NR, KV, K0, ST>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, D2_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    BN_LAUNCH_MAIN((k_down2_mfma<MR, NR, KV, K0>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
+    BN_LAUNCH_MAIN((k_down2_mfma<MR, NR, KV, K0, ST>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
                        dact_src, g, t, act, dact, slope, cper, zstride);
     BN_LAUNCH_CHECK();
     return 0;
@@ -549,7 +562,8 @@ int bn_launch_down2(int MR, int NR, const float* big, const float* w, const floa
     const bool k4 = g.KV == 4, k3 = k4 && g.K0 == 1;
 #define D2_CASE(mr, nr)                                                                                       \
     if (MR == mr && NR == nr)                                                                                 \
-        rc = k3 ? launch_down2<mr, nr, 4, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs) \
+        rc = g.stride == 1 ? launch_down2<mr, nr, 5, 0, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs) \
+           : k3 ? launch_down2<mr, nr, 4, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs) \
            : k4 ? launch_down2<mr, nr, 4>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs)   \
                 : launch_down2<mr, nr, 5>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
     D2_CASE(2, 2) D2_CASE(2, 1) D2_CASE(1, 1)

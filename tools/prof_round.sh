@@ -11,6 +11,9 @@ tools/prof_cmd.sh ${T}_1x64x48_b256 30 python tools/step_arch.py none 1 64 48 25
 tools/prof_cmd.sh ${T}_2x192x160_b256 30 python tools/step_arch.py none 2 192 160 256 20 | head -3
 tools/prof_cmd.sh ${T}_1x192x192_b256 30 python tools/step_arch.py none 1 192 192 256 20 | head -3
 tools/prof_cmd.sh ${T}_maxpool_arch 30 python tools/step_arch.py tests/golden/arch_maxpool.json 1 128 128 256 20 | head -3
+tools/prof_cmd.sh ${T}_drawn_k3 30 python tools/step_arch.py tools/arch_jsons/drawn_k3.json 1 128 128 256 20 | head -3
+tools/prof_cmd.sh ${T}_drawn_k7_k5_k9_k3 30 python tools/step_arch.py tools/arch_jsons/drawn_k7_k5_k9_k3.json 1 128 128 256 20 | head -3
+tools/prof_cmd.sh ${T}_drawn_maxpool_k9_k7 30 python tools/step_arch.py tools/arch_jsons/drawn_maxpool_k9_k7.json 1 128 128 256 20 | head -3
 bash tools/prof_shape.sh ${T}_frames_rank0of8 1 128 128 256 20 0 8 | head -3
 bash tools/prof_psvae.sh ${T}_psvae | head -3
 for spec in "e0 E0 fwd" "e0w E0 bwd_w" "d4w D4 bwd_w" "d4l D4 fwd_sqerr"; do set -- $spec; bash tools/pmc_hbm.sh ${T}_$1 $2 $3; done
