@@ -45,26 +45,7 @@ def enabled_by_default():
     return os.environ.get('BN_GRAPH', '0') == '1'
 
 
-class LazyLoss(collections.abc.Mapping):
-    """The loss dict of a replayed step; the values are fetched when first looked at."""
-
-    def __init__(self, readbacks, fn):
-        self._rbs, self._fn, self._dict = readbacks, fn, None
-
-    def resolve(self):
-        if self._dict is None:
-            self._dict = self._fn(*[None if rb is None else rb.numpy() for rb in self._rbs])
-            self._rbs = self._fn = None
-        return self._dict
-
-    def __getitem__(self, key):
-        return self.resolve()[key]
-
-    def __iter__(self):
-        return iter(self.resolve())
-
-    def __len__(self):
-        return len(self.resolve())
+LazyLoss = hf.LazyLoss      # (the class lives next to Readback: eager steps hand it out as well, set_lazy_losses)
 
 
 def _tensor_slots(data):

@@ -180,7 +180,20 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
 
     ``optimizer`` (optional) injects an object with ``zero_grad()``/``step()``; by default a
     :class:`FlatAdamAMSGrad` over ``model.get_parameters()`` is built.
+
+    The loss dicts of the eager steps are handed to the logger unresolved (hip_functions.set_lazy_losses;
+    ``hparams['lazy_losses'] = False`` turns that off): same values in the same order in the metric rows,
+    but the host does not wait for the forward pass of a step before it queues the next one.
     """
+    from behavenet_amd import hip_functions as hf
+    prev = hf.set_lazy_losses(bool(hparams.get('lazy_losses', True)))
+    try:
+        return _fit(hparams, model, data_generator, exp, method=method, optimizer=optimizer)
+    finally:
+        hf.set_lazy_losses(prev)
+
+
+def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
     # hparams['shard_optimizer'] (BN_SHARD_OPTIMIZER=1): reduce-scatter -> Adam on this rank's 1/R
     # shard of the arena -> all-gather, instead of all-reduce + R identical steps
     # (fitting/distributed.py sharded_step; off by default)

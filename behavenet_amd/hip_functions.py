@@ -13,6 +13,7 @@ calls the C ABI (behavenet_amd/_hip.py) for both directions; torch autograd only
 * :class:`ReparamFn`, :class:`KLFn` -- the variational tail (vaes.py:33-35, losses.py:146-147).
 """
 
+import collections.abc
 import os
 
 import torch
@@ -163,11 +164,52 @@ class DeferredLoss(object):
         self.tensors, self.fn = tensors, fn
 
 
+class LazyLoss(collections.abc.Mapping):
+    """A loss dict whose values are still on their way from the device: fetched (one event wait) when
+    somebody first looks at it.  ``fit``'s logger adds such dicts up a few steps later, so the host
+    never waits for a step it has just launched (fitting/training.py, Logger.update_metrics)."""
+
+    def __init__(self, readbacks, fn):
+        self._rbs, self._fn, self._dict = readbacks, fn, None
+
+    def resolve(self):
+        if self._dict is None:
+            self._dict = self._fn(*[None if rb is None else rb.numpy() for rb in self._rbs])
+            self._rbs = self._fn = None
+        return self._dict
+
+    def __getitem__(self, key):
+        return self.resolve()[key]
+
+    def __iter__(self):
+        return iter(self.resolve())
+
+    def __len__(self):
+        return len(self.resolve())
+
+
+# Eager steps: ``loss`` returns a plain dict (it waits for the read-back of the forward's chunk losses
+# after it has queued the backward launches -- the host is at most one backward pass ahead of the
+# device, and a host hiccup longer than that idles the device).  With lazy losses on (``fit``,
+# bench.py) it returns a LazyLoss instead and the host runs ahead as far as the HIP queue lets it.
+_lazy_losses = False
+
+
+def set_lazy_losses(flag):
+    """-> the previous setting."""
+    global _lazy_losses
+    prev, _lazy_losses = _lazy_losses, bool(flag)
+    return prev
+
+
 def finish_loss(readbacks, fn):
     """``fn(*arrays)`` -> loss dict, with arrays = the values of `readbacks` (None entries stay
-    None).  Eager: waits for the read-backs and calls `fn`; under capture: defers both."""
+    None).  Eager: waits for the read-backs and calls `fn` (or hands out a LazyLoss that will, see
+    set_lazy_losses); under capture: defers both."""
     if _capturing:
         return DeferredLoss([None if rb is None else rb.tensor for rb in readbacks], fn)
+    if _lazy_losses:
+        return LazyLoss(readbacks, fn)
     return fn(*[None if rb is None else rb.numpy() for rb in readbacks])
 
 
@@ -181,6 +223,7 @@ class Readback(object):
     step and the next batch's forward follow them without a bubble.
     """
     _pool = {}
+    _dropped = {}
 
     def __init__(self, t):
         t = t.detach()
@@ -189,10 +232,21 @@ class Readback(object):
             return
         self._key = (t.dtype, tuple(t.shape))
         free = Readback._pool.setdefault(self._key, [])
+        if not free:
+            # buffers of read-backs nobody looked at (a LazyLoss that was dropped): back once their copy is done
+            flying = Readback._dropped.get(self._key)
+            while flying and flying[0][0].query():
+                free.append(flying.pop(0)[1])
         self._buf = free.pop() if free else torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         self._buf.copy_(t, non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
+
+    def __del__(self):
+        buf = getattr(self, '_buf', None)
+        if buf is not None and Readback is not None:
+            Readback._dropped.setdefault(self._key, []).append((self._event, buf))
+            self._buf = None
 
     def numpy(self):
         if _capturing:

@@ -491,6 +491,10 @@ def main():
                          "'frames' = the ranks share ONE trial, each takes its slice of every "
                          "200-frame chunk (strong scaling, parity-exact)")
     args = ap.parse_args()
+    # the product's fit() hands loss dicts to its logger unresolved (hip_functions.set_lazy_losses): the host queues
+    # step k + 1 without waiting for the forward pass of step k.  BN_BENCH_LAZY=0: the plain dict (one event wait per step)
+    from behavenet_amd import hip_functions as _hf
+    _hf.set_lazy_losses(os.environ.get('BN_BENCH_LAZY', '1') != '0')
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False')
