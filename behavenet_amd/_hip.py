@@ -37,6 +37,7 @@ SIGNATURES = {
     'bn_build_arch': (ctypes.c_char_p, []),
     'bn_error_string': (ctypes.c_char_p, [_c_int]),
     'bn_set_force_generic': (_c_int, [_c_int]),
+    'bn_set_bigk1_block_bytes': (_c_size_t, [_c_size_t]),
     'bn_conv_ws_bytes': (_c_size_t, [_c_int] + _CONV_GEOM),
     'bn_conv2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_conv2d_fwd_u8_ws_bytes': (_c_size_t, _CONV_GEOM + [_c_int]),
@@ -266,6 +267,11 @@ def convT2d_bwd_weight(x, dy, dw, db, geom, accumulate):
 def set_force_generic(on):
     """Route convolutions through the shape-agnostic kernels (test hook); returns previous."""
     return bool(load().bn_set_force_generic(1 if on else 0))
+
+
+def set_bigk1_block_bytes(nbytes):
+    """Frame-block size of the shifted-copies path of stride-1 7x7 / 9x9 layers (test hook); returns previous."""
+    return int(load().bn_set_bigk1_block_bytes(int(nbytes)))
 
 
 def lib_call(name):

@@ -504,6 +504,12 @@ static inline size_t bigk_map_bytes(const BnGeom& g) { return align256((size_t)g
 // ---- ... and with stride 1 (conv_pad.hip, k_shift_cat): 2 x 2 blocks of taps on four shifted copies of the big map,
 // frames in blocks that keep the copies below 2 GB (the kernels' 32-bit offsets)
 struct BigK1 { int L0r, L0c, dr[2], dc[2], Ho, Wo, nb; };
+static size_t g_bigk1_block_bytes = 0x70000000ull;    // bytes of shifted copies per block of frames (test hook below)
+extern "C" size_t bn_set_bigk1_block_bytes(size_t bytes) {
+    const size_t prev = g_bigk1_block_bytes;
+    g_bigk1_block_bytes = (bytes && bytes < 0x70000000ull) ? bytes : 0x70000000ull;
+    return prev;
+}
 static bool bigk1_plan(int role, const BnGeom& g, BnGeom* g5, BigK1* k) {
     if (force_generic() || !bigk_enabled() || g.stride != 1 || g.CsS || role == 1) return false;
     if (g.R < 6 || g.R > 10 || g.S < 6 || g.S > 10) return false;
@@ -513,7 +519,7 @@ static bool bigk1_plan(int role, const BnGeom& g, BnGeom* g5, BigK1* k) {
     k->Ho = g.Hs + 4; k->Wo = (g.Ws + 4 + 3) & ~3;
     const size_t per_frame = (size_t)4 * g.Cb * k->Ho * k->Wo * sizeof(float);
     if (per_frame >= 0x40000000ull) return false;
-    const size_t nb = 0x70000000ull / per_frame;
+    const size_t nb = g_bigk1_block_bytes / per_frame > 0 ? g_bigk1_block_bytes / per_frame : 1;
     k->nb = nb < (size_t)g.N ? (int)nb : g.N;
     *g5 = g;
     g5->N = k->nb;

@@ -70,6 +70,10 @@ const char* bn_error_string(int code);        /* static string for a BN_E_* / hi
  * specialised ones can be cross-checked on the device).  Returns the previous setting.  The
  * environment variable BN_FORCE_GENERIC=1 sets the initial value. */
 int bn_set_force_generic(int on);
+/* Test hook: stride-1 layers with kernels larger than 5x5 run on four shifted copies of their big map, frames in
+ * blocks whose copies stay below `bytes` (default and maximum 0x70000000: the kernels' 32-bit offsets); a small value
+ * makes a few frames exercise the block loop.  0 restores the default.  Returns the previous setting. */
+size_t bn_set_bigk1_block_bytes(size_t bytes);
 size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, int R, int S, int stride,
                         int off_t, int off_l, int P, int Q);
 

@@ -861,6 +861,22 @@ def test_stride1_roles_run_without_im2col(case_name):
         assert n >= 1 and want in name and 'im2col' not in name and 'col2im' not in name, name
 
 
+@pytest.mark.parametrize('case_name', ['s1_k9_16x16_n9', 's1_k7_32x32', 's1_k9_24x20'])
+def test_stride1_large_kernels_in_blocks_of_frames(case_name):
+    """The shifted copies of a stride-1 7x7 / 9x9 layer are made for blocks of frames that keep them below 2 GB
+    (256 frames of 32 channels at 128x128 are more): with the block size turned down to two frames' worth, the
+    forward and all gradients of 9 / 3 / 2 frames (a shorter last block, an accumulated weight gradient)."""
+    case = [c for c in CONV_CASES if c[0] == case_name][0]
+    N, C, H, W = case[1:5]
+    per_frame = 4 * C * (H + 4) * ((W + 4 + 3) // 4 * 4) * 4
+    prev = _hip.set_bigk1_block_bytes(2 * per_frame + 64)
+    try:
+        test_conv2d_fwd(case, _hip.ACT_LRELU)
+        test_conv2d_bwd(case)
+    finally:
+        _hip.set_bigk1_block_bytes(prev)
+
+
 @pytest.mark.parametrize('case_name', ['k7s2_same_32x32', 'k9s2_same_32x32', 'k9s2_same_16x16', 's1_k7_32x32',
                                        's1_k9_16x16_n9', 's1_k9_24x20'])
 def test_kernels_larger_than_5x5_run_without_im2col(case_name):
