@@ -38,6 +38,11 @@
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx2d __attribute__((ext_vector_type(2)));
 
+#define D2_STR2(x) #x
+#define D2_STR(x) D2_STR2(x)
+#ifndef D2_LOOP_SHIFT
+#define D2_LOOP_SHIFT 0
+#endif
 #define D2_THREADS 256
 #define D2_CC 4
 #define D2_X0 4                 // LDS column of image column 0
@@ -332,6 +337,9 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     for (int k = 0; k < D2_XK; ++k) issue_image(k, c_beg, 0);
 #pragma unroll
     for (int k = 0; k < WK; ++k) load_weights(k, c_beg);
+#ifdef D2_LOOP_ALIGN
+    asm volatile(".p2align " D2_STR(D2_LOOP_ALIGN) "\n .rept " D2_STR(D2_LOOP_SHIFT) "\n s_nop 0\n .endr" ::: "memory");
+#endif
     for (int c0 = c_beg; c0 < c_end; c0 += 2 * CC) {
         if (c0 < 6 * CC) D2_MARK(4 + 2 * (c0 / CC));
         boundary(c0);

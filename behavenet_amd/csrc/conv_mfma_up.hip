@@ -228,6 +228,22 @@ __global__ __launch_bounds__(MF_THREADS, 2) void k_up_mfma(
 //    place, an MFMA has taken its operands when it issues); sched_barrier pins the order;
 //  * the epilogue batches its loads and is branch-free (buffer stores with out-of-range lanes).
 // ---------------------------------------------------------------------------------------------
+#define UP2_STR2(x) #x
+#define UP2_STR(x) UP2_STR2(x)
+// Placement of k_up2_mfma's chunk loop in the code object: `.p2align UP2_LOOP_ALIGN` plus UP2_LOOP_SHIFT s_nop in front of
+// it.  The loop is the same instruction stream wherever it lies, but not the same speed: the 16x16-map instantiation
+// (dec.convT2 forward, enc.conv2's data gradient) ran 206-239 us in the training step depending on the shift alone --
+// it had gone from 202 to 232 us when two kernel arguments were added in front of it (the small-batch reduction split)
+// and nothing in the loop changed (ISA diffed, round 4).  A sweep of the shift in steps of 32 bytes inside the step
+// (tools/ab_layers.sh): 0: 227, 32 B: 237, 64: 228, 96: 208, 128: 207, 160: 217, 192: 218, 224: 206 us; the 32x32-map
+// instantiation 213 -> 204.  256-byte alignment + 32 s_nop = 128 bytes: the six launches of the step 1296 -> 1218 us.
+// k_down2_mfma and k_wgrad4s_mfma have the same hook (D2_LOOP_ALIGN, W4_LOOP_ALIGN) and did not react to it.
+#ifndef UP2_LOOP_ALIGN
+#define UP2_LOOP_ALIGN 8
+#endif
+#ifndef UP2_LOOP_SHIFT
+#define UP2_LOOP_SHIFT 32
+#endif
 #ifndef UP2_WGS
 #define UP2_WGS 2      // min workgroups per CU for the register budget (4 = 128 VGPRs measured no faster)
 #endif
@@ -470,6 +486,9 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
 #pragma unroll
     for (int d = 0; d < NDMA; ++d) issue_dma(d, 0, c_beg);
     int cur = 0;
+#ifdef UP2_LOOP_ALIGN
+    asm volatile(".p2align " UP2_STR(UP2_LOOP_ALIGN) "\n .rept " UP2_STR(UP2_LOOP_SHIFT) "\n s_nop 0\n .endr" ::: "memory");
+#endif
     for (int c0 = c_beg; c0 < c_end; c0 += CC) {
         // own DMA of this chunk landed; after the barrier everyone's has, and every wave is done
         // reading the other image pair

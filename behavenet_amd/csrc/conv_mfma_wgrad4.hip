@@ -26,6 +26,11 @@
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
+#define W4_STR2(x) #x
+#define W4_STR(x) W4_STR2(x)
+#ifndef W4_LOOP_SHIFT
+#define W4_LOOP_SHIFT 0
+#endif
 #define W4_THREADS 512
 #define W4_TA 64            // a-channels per workgroup tile
 #define W4_TB 32            // b-channels per workgroup tile
@@ -475,6 +480,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     // one loop trip = one stage; the base registers of the two LDS images swap after each trip
     int ab_cur = abase[0], ab_oth = abase[1], bb_cur = bbase[0], bb_oth = bbase[1];
     int cur = 0;
+#ifdef W4_LOOP_ALIGN
+    asm volatile(".p2align " W4_STR(W4_LOOP_ALIGN) "\n .rept " W4_STR(W4_LOOP_SHIFT) "\n s_nop 0\n .endr" ::: "memory");
+#endif
     for (; st < n_stages; st += splits) {
         // own DMAs of this stage have landed; after the barrier everyone's have, and every wave
         // is done reading the other image

@@ -736,8 +736,12 @@ def main():
                 ('enc.conv4 fwd (stride 5; executed FLOPs)', _hip.PROF_CONV_FWD, 256, 512, E4),
                 ('enc.conv1 bwd-weight', _hip.PROF_CONV_BWD_W, 32, 64, 104857600.0),
                 ('enc.conv3 bwd-weight', _hip.PROF_CONV_BWD_W, 128, 256, 104857600.0),
+                ('enc.conv2 bwd-weight', _hip.PROF_CONV_BWD_W, 64, 128, 104857600.0),
                 ('enc.conv1 bwd-data', _hip.PROF_CONV_BWD_D, 64, 32, 104857600.0),
+                ('enc.conv2 bwd-data', _hip.PROF_CONV_BWD_D, 128, 64, 104857600.0),
                 ('enc.conv3 bwd-data', _hip.PROF_CONV_BWD_D, 256, 128, 104857600.0),
+                ('dec.convT1 fwd', _hip.PROF_CONVT_FWD, 256, 128, 104857600.0),
+                ('dec.convT2 fwd', _hip.PROF_CONVT_FWD, 128, 64, 104857600.0),
                 ('dec.convT3 fwd', _hip.PROF_CONVT_FWD, 64, 32, 104857600.0),
                 ('dec.convT0 fwd (stride 5; executed FLOPs)', _hip.PROF_CONVT_FWD, 512, 256, E4),
                 # the true dense GEMMs of the path (north_star: MFMA utilisation of the linear
