@@ -31,6 +31,12 @@ static inline const char* bn_tune_env(const char*) { return nullptr; }
 // w[k][c][r][s] with k on the small side) -- and a ConvTranspose2d weight w[ci][co][r][s] has
 // exactly the same layout (ci is on the small side).
 // ---------------------------------------------------------------------------------------------
+// Placement of a hot loop in the code object: `.p2align A` plus S s_nop in front of it (conv_mfma_up.hip, UP2_LOOP_SHIFT,
+// has the story: the same instruction stream runs 206-239 us depending on where it lies)
+#define BN_STR2(x) #x
+#define BN_STR(x) BN_STR2(x)
+#define BN_LOOP_PLACE(A, S) asm volatile(".p2align " BN_STR(A) "\n .rept " BN_STR(S) "\n s_nop 0\n .endr" ::: "memory")
+
 struct BnGeom {
     int N;
     int Cs, Hs, Ws;   // small side: channels, height, width

@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void k_qgemm(QGArgs a) {
 
     if (kbeg < kend) fetch(0, kbeg);
     int sidx = 0;
+#ifdef QG_LOOP_SHIFT
+    BN_LOOP_PLACE(8, QG_LOOP_SHIFT);
+#endif
     for (int k0 = kbeg; k0 < kend; k0 += QG_KS, ++sidx) {
         __syncthreads();                       // everyone is done reading the previous stage
 #pragma unroll

@@ -115,6 +115,9 @@ __global__ __launch_bounds__(Q2_THREADS, 1) void k_qg2_up(
 #pragma unroll
     for (int d = 0; d < Q2U_NDMA; ++d) issue_dma(d, 0, 0);
 
+#ifdef Q2U_LOOP_SHIFT
+    BN_LOOP_PLACE(8, Q2U_LOOP_SHIFT);
+#endif
     for (int st = 0; st < n_stages; ++st) {
         // own DMAs of this stage have landed; behind the barrier everyone's have, and every wave is
         // done reading the other image
@@ -306,6 +309,9 @@ __global__ __launch_bounds__(Q2_THREADS, 1) void k_qg2_wgrad(
     }
 
     int buf = 0;
+#ifdef Q2W_LOOP_SHIFT
+    BN_LOOP_PLACE(8, Q2W_LOOP_SHIFT);
+#endif
     for (int st = 0; st < n_stages; ++st) {
         // this stage's pieces have landed (the next stage's twelve may still be in flight)
         if (st + 1 < n_stages) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
