@@ -69,6 +69,7 @@ SIGNATURES = {
     'bn_maxpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
     'bn_maxpool2d_bwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
     'bn_maxunpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
+    'bn_maxunpool2d_fwd_k2': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
     'bn_maxunpool2d_bwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
     'bn_act_fwd': (_c_int, [_c_void_p] * 2 + [_c_size_t, _c_int, _c_float, _c_void_p]),
     'bn_act_bwd': (_c_int, [_c_void_p] * 3 + [_c_size_t, _c_int, _c_float, _c_void_p]),
@@ -755,10 +756,17 @@ def maxpool2d_bwd(dy, idx, in_hw, k, stride, pad):
     return dx
 
 
-def maxunpool2d_fwd(x, idx, out_hw):
+def maxunpool2d_fwd(x, idx, out_hw, own_window=False):
+    """``own_window``: idx are the indices of the 2x2 / stride-2 pooling this layer undoes (each inside its own
+    window): the one-pass kernel where the maps qualify."""
     N, C, Hi, Wi = x.shape
     Ho, Wo = out_hw
     y = torch.empty((N, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    if own_window and (Ho, Wo) == (2 * Hi, 2 * Wi) and Wi % 2 == 0:
+        rc = load().bn_maxunpool2d_fwd_k2(_ptr(x, 'x'), _ptr(idx, 'idx', torch.int32), _ptr(y, 'y'), N * C, Hi, Wi,
+                                          _stream())
+        if rc == 0:
+            return y
     _check(load().bn_maxunpool2d_fwd(_ptr(x, 'x'), _ptr(idx, 'idx', torch.int32), _ptr(y, 'y'),
                                      N * C, Hi * Wi, Ho * Wo, _stream()), 'bn_maxunpool2d_fwd')
     return y

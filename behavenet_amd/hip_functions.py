@@ -1136,29 +1136,34 @@ class MaxPoolFn(torch.autograd.Function):
 
 
 def max_pool(x, k, stride, pad, out_hw):
-    return MaxPoolFn.apply(x, int(k), int(stride), (int(pad[0]), int(pad[1])),
-                           (int(out_hw[0]), int(out_hw[1])))
+    y, idx = MaxPoolFn.apply(x, int(k), int(stride), (int(pad[0]), int(pad[1])),
+                             (int(out_hw[0]), int(out_hw[1])))
+    # (a 2x2 / stride-2 / unpadded pooling of an even map: every index lies in its own window, which lets the
+    # unpooling that receives THIS tensor run in one pass -- max_unpool)
+    idx.bn_own_window = (int(k) == 2 and int(stride) == 2 and int(pad[0]) == 0 and int(pad[1]) == 0 and
+                         x.shape[2] == 2 * int(out_hw[0]) and x.shape[3] == 2 * int(out_hw[1]))
+    return y, idx
 
 
 class MaxUnpoolFn(torch.autograd.Function):
     """nn.MaxUnpool2d with the encoder's indices and pre-pool size (ref aes.py:281-294,460-464)."""
 
     @staticmethod
-    def forward(ctx, x, idx, out_hw):
+    def forward(ctx, x, idx, out_hw, own_window=False):
         ctx.save_for_backward(idx)
-        return _hip.maxunpool2d_fwd(x.contiguous(), idx, out_hw)
+        return _hip.maxunpool2d_fwd(x.contiguous(), idx, out_hw, own_window)
 
     @staticmethod
     def backward(ctx, dy):
         idx, = ctx.saved_tensors
-        return _hip.maxunpool2d_bwd(dy.contiguous(), idx), None, None
+        return _hip.maxunpool2d_bwd(dy.contiguous(), idx), None, None, None
 
 
 def max_unpool(x, idx, out_hw):
     if tuple(idx.shape) != tuple(x.shape):
         raise ValueError('unpool indices %s do not match the input %s' % (
             tuple(idx.shape), tuple(x.shape)))
-    return MaxUnpoolFn.apply(x, idx, (int(out_hw[0]), int(out_hw[1])))
+    return MaxUnpoolFn.apply(x, idx, (int(out_hw[0]), int(out_hw[1])), bool(getattr(idx, 'bn_own_window', False)))
 
 
 class DecomposedKLFn(torch.autograd.Function):

@@ -151,6 +151,10 @@ int bn_maxpool2d_bwd(const float* dy, const int* idx, float* dx, int planes, int
                      int Ho, int Wo, int k, int stride, int pad_t, int pad_l, bn_stream_t stream);
 int bn_maxunpool2d_fwd(const float* x, const int* idx, float* y, int planes, int in_plane,
                        int out_plane, bn_stream_t stream);
+/* The same for the indices of a 2x2 / stride-2 / unpadded pooling of a (2 Hi) x (2 Wi) map (every index lies inside its
+ * own window -- the caller vouches for it; what nn.MaxPool2d(2, return_indices=True) hands to the decoder,
+ * aes.py:204-207,460-464): one pass without the memset.  BN_E_SHAPE if Wi is odd or a pointer is not 16-byte aligned. */
+int bn_maxunpool2d_fwd_k2(const float* x, const int* idx, float* y, int planes, int Hi, int Wi, bn_stream_t stream);
 int bn_maxunpool2d_bwd(const float* dy, const int* idx, float* dx, int planes, int in_plane,
                        int out_plane, bn_stream_t stream);
 

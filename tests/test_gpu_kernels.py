@@ -733,6 +733,9 @@ def test_errors_are_loud():
 
 @pytest.mark.parametrize('shape,k,s,pad', [
     ((3, 5, 32, 32), 2, 2, (0, 0)),       # the non-overlapping pooling of the reference archs
+    ((4, 16, 64, 48), 2, 2, (0, 0)),      # ... on the two-windows-per-thread kernels (even output width)
+    ((2, 3, 8, 12), 2, 2, (0, 0)),
+    ((2, 3, 6, 10), 2, 2, (0, 0)),        # odd output width: the general kernels
     ((2, 4, 17, 13), 2, 2, (0, 0)),       # ceil_mode: clipped last windows
     ((2, 3, 16, 20), 3, 2, (1, 1)),       # overlapping windows with padding
     ((1, 2, 9, 9), 3, 3, (0, 0)),
@@ -742,6 +745,8 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
     ceil_mode=True) / F.max_unpool2d and their autograd (bit-exact: selections and copies)."""
     g = torch.Generator().manual_seed(11)
     x = torch.randn(shape, generator=g)
+    if shape[1] == 16:
+        x = torch.round(x * 2) / 2          # many exact ties inside a window: the first one in scan order wins
     xr = x.clone().requires_grad_(True)
     y_ref, idx_ref = F.max_pool2d(xr, k, s, padding=pad, return_indices=True, ceil_mode=True)
     dy = torch.randn(y_ref.shape, generator=g)
@@ -761,6 +766,10 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
         u_ref.backward(du)
         u = _hip.maxunpool2d_fwd(v.to(DEV), idx, tuple(shape[2:]))
         assert torch.equal(u.cpu(), u_ref.detach())
+        if k == 2 and shape[2] % 2 == 0 and shape[3] % 2 == 0:
+            # the one-pass form for indices that lie in their own windows (what max_pool hands to max_unpool)
+            u2 = _hip.maxunpool2d_fwd(v.to(DEV), idx, tuple(shape[2:]), True)
+            assert torch.equal(u2.cpu(), u_ref.detach())
         dv = _hip.maxunpool2d_bwd(du.to(DEV), idx)
         assert torch.equal(dv.cpu(), vr.grad)
 
