@@ -62,6 +62,10 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
 bool bn_s1c1_ok(const BnGeom& g);
 int bn_launch_s1c1(const float* big, const float* w, const float* bias, float* out, const float* dact_src,
                    const BnGeom& g, int act, int dact, float slope, hipStream_t st);
+// stride-1 gather-down FROM one or two channels, kernels 3 / 5 / 7 / 9 (conv_edge.hip, k_down_s1_in1)
+bool bn_s1in1_ok(const BnGeom& g);
+int bn_launch_s1in1(const float* big, const float* w, const float* bias, float* out, const float* dact_src,
+                    const BnGeom& g, int act, int dact, float slope, hipStream_t st);
 BnFastPlan bn_edge_down_plan(const BnGeom& g);
 const char* bn_edge_down_kernel_name(const BnGeom& g, int act, bool has_dact, bool u8);
 const char* bn_edge_up_kernel_name(const BnGeom& g, bool loss);

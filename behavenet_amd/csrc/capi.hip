@@ -406,7 +406,7 @@ static bool chan_plan(int role, const BnGeom& g, BnGeom* gg) {
 static inline size_t chan_bytes(const BnGeom& g) { return align256((size_t)g.N * 32 * g.Hs * g.Ws * 4); }
 static bool served_fast(int role, const BnGeom& g) {
     BnGeom gg;
-    if (role == 0 && bn_s1c1_ok(g)) return true;
+    if (role == 0 && (bn_s1c1_ok(g) || bn_s1in1_ok(g))) return true;
     if (chan_plan(role, g, &gg)) return true;
     if (g.Cb <= 4) {
         const BnFastPlan ed = role == 0 ? bn_edge_down_plan(g) : role == 1 ? bn_edge_up_plan(g)
@@ -597,6 +597,11 @@ static int run_down(int family, const float* big, const float* w, const float* b
         if (rc) return rc;
         return run_down(family, big, (const float*)ws, bias, out, dact_src, g5, act, dact, slope,
                         (char*)ws + wb, ws_bytes - wb, st);
+    }
+    if (!generic && bn_s1in1_ok(g)) {
+        static const char* names1[4] = {"k_down_s1_in1<3>", "k_down_s1_in1<5>", "k_down_s1_in1<7>", "k_down_s1_in1<9>"};
+        BnProfScope prof(family, g.Cb, g.Cs, names1[(g.R - 3) / 2], st);
+        return bn_launch_s1in1(big, w, bias, out, dact_src, g, act, dact, slope, st);
     }
     if (!generic && bn_s1c1_ok(g)) {
         static const char* names[4] = {"k_down_s1_c1<3>", "k_down_s1_c1<5>", "k_down_s1_c1<7>", "k_down_s1_c1<9>"};
@@ -1100,7 +1105,7 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
 static size_t role_ws_need(int role, const BnGeom& g) {
     BnGeom g5;
     if (taps_plan(role, g, &g5)) return taps_bytes(g) + (role == 2 ? 4096 : 0) + role_ws_need(role, g5);
-    if (role == 0 && bn_s1c1_ok(g)) return 0;
+    if (role == 0 && (bn_s1c1_ok(g) || bn_s1in1_ok(g))) return 0;
     BigK bk;
     if (bigk_plan(role, g, &g5, &bk))
         return bigk_map_bytes(g) + bigk_w_bytes(g) + (role == 2 ? 4096 : 0) + role_ws_need(role == 1 ? 0 : role, g5);

@@ -2301,3 +2301,124 @@ int bn_launch_s1c1(const float* big, const float* w, const float* bias, float* o
 #undef S1C_CASE
     return BN_E_SHAPE;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Stride-1 gather-down FROM one or two channels (round 4): the first layer of every max-pooling architecture (1 -> 16
+// channels on the full frame) and the data gradient of its mirror image in the decoder.  It ran on the matrix-core
+// kernel with three of the four channels of a chunk masked to zero (321 us for 1 -> 16 channels, 5x5, 256 frames of
+// 128x128: 3.4 GFLOP of arithmetic and 268 MB of output).  A vector kernel again: a workgroup loads ONE
+// (16 + K - 1) x (64 + K - 1) input tile per input channel and walks the output channels eight at a time over it;
+// a thread keeps four adjacent pixels of eight channels (a row of K + 3 LDS words feeds 32 K multiply-adds), the
+// taps are wave-uniform (scalar loads), the four pixels leave as one 16-byte store where the row allows it.
+// ---------------------------------------------------------------------------------------------
+#define S1I_MG 8
+template <int KS>
+__global__ __launch_bounds__(256) void k_down_s1_in1(const float* __restrict__ big, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      const float* __restrict__ dact_src, BnGeom g, int act, int dact,
+                                                      float slope, int tiles_h, int tiles_w) {
+    constexpr int IH = S1C_TH + KS - 1, IWP = (S1C_TW + KS - 1 + 3) & ~3, NV = (KS + 3 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float tile[2 * IH * IWP];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w; b /= tiles_w;
+    const int th = b % tiles_h;
+    const int n = b / tiles_h;
+    const int h0 = th * S1C_TH, w0 = tw * S1C_TW;
+    const size_t HWb = (size_t)g.Hb * g.Wb;
+    for (int e = tid; e < g.Cb * IH * IWP; e += 256) {
+        const int cc = e / (IH * IWP), rem = e - cc * (IH * IWP);
+        const int y = rem / IWP, xx = rem - y * IWP;
+        const int hb = h0 - g.pt + y, wb = w0 - g.pl + xx;
+        const bool ok = hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+        tile[e] = ok ? big[((size_t)n * g.Cb + cc) * HWb + (size_t)hb * g.Wb + wb] : 0.f;
+    }
+    __syncthreads();
+    const int h = h0 + ty, wq = w0 + 4 * tx;
+    const size_t PQ = (size_t)g.Hs * g.Ws;
+    const bool vec = (g.Ws & 3) == 0 && ((((uintptr_t)out) | ((uintptr_t)dact_src)) & 15u) == 0;
+    for (int m0 = 0; m0 < g.Cs; m0 += S1I_MG) {
+        float acc[S1I_MG][4];
+#pragma unroll
+        for (int o = 0; o < S1I_MG; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+        for (int c = 0; c < g.Cb; ++c) {
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+                float row[4 * NV];
+                const float4* rp = reinterpret_cast<const float4*>(tile + (c * IH + ty + r) * IWP + 4 * tx);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float4 q = rp[v];
+                    row[4 * v] = q.x; row[4 * v + 1] = q.y; row[4 * v + 2] = q.z; row[4 * v + 3] = q.w;
+                }
+#pragma unroll
+                for (int o = 0; o < S1I_MG; ++o) {
+                    const int m = min(m0 + o, g.Cs - 1);            // (channels past the last one are not stored)
+                    const float* wr = w + (((size_t)m * g.Cb + c) * KS + r) * KS;
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        const float wv = wr[s];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[o][j] = fmaf(row[s + j], wv, acc[o][j]);
+                    }
+                }
+            }
+        }
+        if (h < g.Hs) {
+#pragma unroll
+            for (int o = 0; o < S1I_MG; ++o) {
+                const int m = m0 + o;
+                if (m >= g.Cs) break;
+                const float bz = bias ? bias[m] : 0.f;
+                const size_t base = ((size_t)n * g.Cs + m) * PQ + (size_t)h * g.Ws + wq;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = bn_apply_act(acc[o][j] + bz, act, slope);
+                if (vec && wq + 3 < g.Ws) {
+                    if (dact_src) {
+                        const float4 d = *reinterpret_cast<const float4*>(dact_src + base);
+                        v[0] *= bn_act_grad_from_output(d.x, dact, slope);
+                        v[1] *= bn_act_grad_from_output(d.y, dact, slope);
+                        v[2] *= bn_act_grad_from_output(d.z, dact, slope);
+                        v[3] *= bn_act_grad_from_output(d.w, dact, slope);
+                    }
+                    *reinterpret_cast<float4*>(out + base) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (wq + j >= g.Ws) continue;
+                        float u = v[j];
+                        if (dact_src) u *= bn_act_grad_from_output(dact_src[base + j], dact, slope);
+                        out[base + j] = u;
+                    }
+                }
+            }
+        }
+    }
+}
+
+bool bn_s1in1_ok(const BnGeom& g) {
+    if (g.stride != 1 || g.R != g.S || (g.R != 3 && g.R != 5 && g.R != 7 && g.R != 9)) return false;
+    if (g.Cb > 2 || g.Cs < 3 || g.CsS) return false;      // (one / two OUTPUT channels: k_down_s1_c1)
+    const size_t tiles = (size_t)g.N * ((g.Hs + S1C_TH - 1) / S1C_TH) * ((g.Ws + S1C_TW - 1) / S1C_TW);
+    return tiles < 0x7fffffffull;
+}
+
+int bn_launch_s1in1(const float* big, const float* w, const float* bias, float* out, const float* dact_src,
+                    const BnGeom& g, int act, int dact, float slope, hipStream_t st) {
+    if (!bn_s1in1_ok(g)) return BN_E_SHAPE;
+    const int tiles_h = (g.Hs + S1C_TH - 1) / S1C_TH, tiles_w = (g.Ws + S1C_TW - 1) / S1C_TW;
+    const dim3 grid((unsigned)((size_t)g.N * tiles_h * tiles_w));
+#define S1I_CASE(K)                                                                                         \
+    if (g.R == K) {                                                                                         \
+        BN_LAUNCH_MAIN((k_down_s1_in1<K>), grid, dim3(256), 0, st, big, w, bias, out, dact_src, g, act,     \
+                       dact, slope, tiles_h, tiles_w);                                                      \
+        BN_LAUNCH_CHECK();                                                                                  \
+        return 0;                                                                                           \
+    }
+    S1I_CASE(3) S1I_CASE(5) S1I_CASE(7) S1I_CASE(9)
+#undef S1I_CASE
+    return BN_E_SHAPE;
+}

@@ -111,6 +111,10 @@ CONV_CASES = [
     ('s1_k7_valid_16x12', 2, 32, 22, 18, 32, 7, 1, (0, 0), (0, 0)),
     ('s1_k9_16x16_n9', 9, 64, 16, 16, 32, 9, 1, (4, 4), (4, 4)),
     ('s1_k9_1ch_128x128', 2, 1, 128, 128, 16, 9, 1, (4, 4), (4, 4)),
+    # from one / two channels at stride 1 (the first layer under max pooling): k_down_s1_in1
+    ('s1_k7_2ch_50x70', 2, 2, 50, 70, 24, 7, 1, (3, 3), (3, 3)),
+    ('s1_k3_1ch_33x20', 3, 1, 33, 20, 5, 3, 1, (1, 1), (1, 1)),
+    ('s1_k5_1ch_valid_60x64', 2, 1, 64, 68, 32, 5, 1, (0, 0), (0, 0)),
     ('s1_k5_valid_4ch_128x128', 2, 4, 132, 132, 16, 5, 1, (0, 0), (0, 0)),
     ('s1_k7_64x64', 2, 16, 64, 64, 32, 7, 1, (3, 3), (3, 3)),
     ('s1_k5_valid_64ch_64x64', 2, 64, 68, 68, 32, 5, 1, (0, 0), (0, 0)),
