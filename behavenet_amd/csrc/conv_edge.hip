@@ -2224,16 +2224,36 @@ __global__ __launch_bounds__(256) void k_down_s1_c1(const float* __restrict__ bi
     for (int o = 0; o < NOUT; ++o)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+    // the tile of the NEXT four channels travels through registers while this one is multiplied (its element ->
+    // (channel, row, column) decode and the frame-edge test are done once per thread, not once per chunk)
+    constexpr int NL = (S1C_CC * IH * IWP + 255) / 256;
+    int goff[NL];                                         // offset inside the frame's channel block, -1 = off the frame
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int e = tid + 256 * i;
+        const int cc = e / (IH * IWP), rem = e - cc * (IH * IWP);
+        const int y = rem / IWP, xx = rem - y * IWP;
+        const int hb = h0 - g.pt + y, wb = w0 - g.pl + xx;
+        const bool ok = e < S1C_CC * IH * IWP && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+        goff[i] = ok ? (cc << 24) | (hb * g.Wb + wb) : -1;
+    }
+    const float* frame = big + (size_t)n * g.Cb * HWb;
+    float nxt[NL];
+    auto fetch = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int cc = goff[i] >> 24;
+            nxt[i] = (goff[i] >= 0 && c0 + cc < g.Cb) ? frame[(size_t)(c0 + cc) * HWb + (goff[i] & 0xffffff)] : 0.f;
+        }
+    };
+    fetch(0);
     for (int c0 = 0; c0 < g.Cb; c0 += S1C_CC) {
         __syncthreads();
-        for (int e = tid; e < S1C_CC * IH * IWP; e += 256) {
-            const int cc = e / (IH * IWP), rem = e - cc * (IH * IWP);
-            const int y = rem / IWP, xx = rem - y * IWP;
-            const int hb = h0 - g.pt + y, wb = w0 - g.pl + xx;
-            const bool ok = (c0 + cc) < g.Cb && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
-            tile[e] = ok ? big[((size_t)n * g.Cb + c0 + cc) * HWb + (size_t)hb * g.Wb + wb] : 0.f;
-        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            if (tid + 256 * i < S1C_CC * IH * IWP) tile[tid + 256 * i] = nxt[i];
         __syncthreads();
+        if (c0 + S1C_CC < g.Cb) fetch(c0 + S1C_CC);
 #pragma unroll
         for (int cc = 0; cc < S1C_CC; ++cc) {
             const int c = min(c0 + cc, g.Cb - 1);          // (past the last channel the tile holds zeros)
@@ -2280,6 +2300,7 @@ bool bn_s1c1_ok(const BnGeom& g) {
     if (g.stride != 1 || g.R != g.S || (g.R != 3 && g.R != 5 && g.R != 7 && g.R != 9)) return false;
     // (four channels with 5x5 taps: the four phases of a 7x7 / 9x9 stride-2 gather-up onto one channel, capi.hip)
     if ((g.Cs > 2 && !(g.Cs == 4 && g.R == 5)) || g.CsS) return false;
+    if ((size_t)g.Hb * g.Wb >= (1u << 24)) return false;        // (a pixel's offset in its plane rides in 24 bits)
     const size_t tiles = (size_t)g.N * ((g.Hs + S1C_TH - 1) / S1C_TH) * ((g.Ws + S1C_TW - 1) / S1C_TW);
     return tiles < 0x7fffffffull;
 }
