@@ -270,7 +270,12 @@ __device__ __forceinline__ void w4_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 // PT_H rows of ONE window (its small rows lie g.Ws apart, its big patch starts 2 cb QQ columns into the row and
 // has real neighbours on the inner sides: only the first window's left groups and the last window's right
 // groups are padding).  `ncb` windows per row; stages are ordered (frame, window, row block).
-template <int QQ, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0, bool CW = false>
+// NA x NB (round 4): 16-channel blocks of the tile that hold channels (default 4 x 2 = the whole 64 x 32 tile).  A layer
+// with at most 32 small-side / 16 big-side channels (the 16- and 32-channel layers of max-pooling architectures) left
+// six of the eight waves multiplying zero rows; with NA x NB < 8 the waves form NG = 8 / (NA NB) groups, every group owns
+// the SAME blocks for its own 1 / NG of a stage's k-steps (an offset in its two LDS base registers) and writes its own
+// partial tile: the caller's sum over splits runs over NG times as many slabs.
+template <int QQ, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0, bool CW = false, int NA = 4, int NB = 2>
 __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
     float* __restrict__ bias_part, BnGeom g, int n_stages, int splits, int lg_tpf, int nbias, int ncb) {
@@ -288,7 +293,12 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
                   "stage geometry");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ablk = wv >> 1, bblk = wv & 1;
+    constexpr int NG = 8 / (NA * NB), KSG = T::KS / NG;      // wave groups, k-steps of a stage per group
+    static_assert(NA * NB * NG == 8 && KSG * NG == T::KS && KSG >= 1 && NG <= 4, "wave groups");
+    static_assert(NG == 1 || (!HALF && !CW && (KSG & (KSG - 1)) == 0 &&
+                              ((4 * KSG) % Q == 0 || Q % (4 * KSG) == 0)), "wave groups: whole rows or parts of one");
+    const int blk = wv % (NA * NB), grp = wv / (NA * NB);
+    const int ablk = NG == 1 ? wv >> 1 : blk / NB, bblk = NG == 1 ? wv & 1 : blk % NB;
     const int lj = lane & 15, kk = lane >> 4;
 
     const int n_btiles = (g.Cb + W4_TB - 1) / W4_TB;
@@ -395,6 +405,13 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         // (a lane's first tap column ST q - pl sits at LDS column ST q - pl + X0; the reads are words 1..5)
         bbase[bf] = bf * BUFW + T::SMALLW + (bblk * 16 + lj) * T::BCH +
                     (ST == 2 ? (W4_X0 - 2) + 2 * kk : (W4_X0 - 1 - g.pl) + kk);
+        if (NG > 1) {
+            // this group's first k-step: (4 lj) ^ (4 (ks0 + k)) = ((4 lj) ^ (4 ks0)) ^ (4 k) for k < KSG, and the pixels of
+            // k-step ks0 start pj0 rows / q00 columns into the stage
+            const int ks0 = grp * KSG, pj0 = (4 * ks0) / Q, q00 = 4 * ks0 - pj0 * Q;
+            abase[bf] ^= 16 * ks0;
+            bbase[bf] += ST * (pj0 * RW + q00);
+        }
         asm volatile("" : "+v"(abase[bf]));
         asm volatile("" : "+v"(bbase[bf]));
     }
@@ -434,8 +451,8 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         load_a(ab, 0, av[0]);
 #pragma unroll
         for (int r = 0; r < 5; ++r) { load_row(bb, bs, 0, r, 0, bv); load_row(bb, bs, 0, r, 1, bv); }
-        constexpr int KS = T::KS;
-        static_assert(NDMA <= KS, "one DMA slot per k-step");
+        constexpr int KS = KSG;
+        static_assert(NDMA <= T::KS, "one DMA slot per k-step of the stage");
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (BIAS == 1) bsum += av[ks & 1];
@@ -452,8 +469,14 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
                 if (r >= 1 && ks + 1 < KS && (sx == 0 || sx == 2)) load_row(bb, bs, ks + 1, r - 1, sx >> 1, bv);
                 if (r == 0 && ks >= 1 && (sx == 0 || sx == 2)) load_row(bb, bs, ks, 4, sx >> 1, bv);
                 if (r == 2 && sx == 4 && ks + 1 < KS) load_a(ab, ks + 1, av[(ks + 1) & 1]);
-                if (r == 3 && sx == 4 && ks < NDMA) {
-                    if (more) issue_dma(ks, nbuf, n0n, p0n);
+                if (NG == 1) {
+                    if (r == 3 && sx == 4 && ks < NDMA) {
+                        if (more) issue_dma(ks, nbuf, n0n, p0n);
+                    }
+                } else if (sx == 4 && r < NG && ks * NG + r < NDMA) {
+                    // (a group has 1 / NG of the k-steps for the same DMA slots: up to NG of them per k-step, one per
+                    // row of taps)
+                    if (more) issue_dma(ks * NG + r, nbuf, n0n, p0n);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -501,7 +524,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
         // lanes lj + 16 kk hold the four pixel phases of one channel: fixed-order butterfly
         bsum += __shfl_xor(bsum, 16, 64);
         bsum += __shfl_xor(bsum, 32, 64);
-        float* bdst = bias_part + (size_t)blockIdx.y * nbias;
+        float* bdst = bias_part + ((size_t)blockIdx.y * NG + grp) * nbias;
         if (BIAS == 1 && btile == 0 && bblk == 0 && kk == 0) {
             const int a = a0 + ablk * 16 + lj;
             if (a < g.Cs) bdst[a] = bsum;
@@ -513,7 +536,7 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
     }
 
     // partial tile -> scratch [split][tap][a][b]; lane holds D[i = 4*kk + e][j = lj]
-    float* dst = part + (size_t)blockIdx.y * 25 * g.Cs * g.Cb;
+    float* dst = part + ((size_t)blockIdx.y * NG + grp) * 25 * g.Cs * g.Cb;
     const int b = b0 + bblk * 16 + lj;
     if (b < g.Cb) {
 #pragma unroll
@@ -640,6 +663,19 @@ static int wgrad4g_stages(const BnGeom& g) {
     return g.N * ncb * ((g.Hs + pth - 1) / pth);
 }
 
+// wave groups of the stride-1 instantiations (k_wgrad4s_mfma<.., NA, NB>): layers with at most 32 small-side channels
+// on 16- / 32- / 64-pixel-wide maps; 1 = none
+static int w4g1_groups(const BnGeom& g, int* na, int* nb) {
+    *na = 4; *nb = 2;
+    static int off = -1;                               // BN_W4_GROUPS=0: off (tuning build)
+    if (off < 0) { const char* e = bn_tune_env("BN_W4_GROUPS"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off || g.stride != 1 || g.Cs > 32 || (g.Ws != 16 && g.Ws != 32 && g.Ws != 64)) return 1;
+    if (g.KV == 4) return 1;                           // (the 3x3 window is instantiated without groups)
+    *na = 2;
+    *nb = g.Cb <= 16 ? 1 : 2;
+    return 8 / (*na * *nb);
+}
+
 BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     BnFastPlan p = {false, "k_wgrad_generic", 0, 0, 0, 0, 0, 0};
     if (g.R != 5 || g.S != 5 || (g.stride != 2 && g.stride != 1)) return p;
@@ -654,7 +690,8 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
         t.n_stages = wgrad4g_stages(g);
         p.supported = true;
         p.variant = 6;
-        p.d = wgrad4_splits(g, t);
+        int na, nb;
+        p.d = wgrad4_splits(g, t) * w4g1_groups(g, &na, &nb);     // partial tiles: one per (split, wave group)
         p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
         static char names_1[16][40];
         const int slot1 = (g.Ws / 4 - 1) & 15;
@@ -712,7 +749,7 @@ static int launch_wgrad4(dim3 grid, size_t lds, hipStream_t st, const float* sma
     return 0;
 }
 
-template <int Q, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0, bool CW = false>
+template <int Q, int BIAS, bool GEN, int KV, int ST = 2, int PTH = 0, bool CW = false, int NA = 4, int NB = 2>
 static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const float* big,
                           float* part, float* bias_part, const BnGeom& g, int n_stages, int splits,
                           int lg_tpf, int nbias, int ncb = 1) {
@@ -720,13 +757,13 @@ static int launch_wgrad4s(dim3 grid, hipStream_t st, const float* small, const f
     static_assert((size_t)2 * TS::BUFW * 4 <= W4_MAX_LDS, "two stage images in LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH, CW>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH, CW, NA, NB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, W4_MAX_LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     constexpr size_t lds = (size_t)2 * TS::BUFW * 4;
-    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH, CW>), grid, dim3(W4_THREADS), lds, st, small, big, part,
+    BN_LAUNCH_MAIN((k_wgrad4s_mfma<Q, BIAS, GEN, KV, ST, PTH, CW, NA, NB>), grid, dim3(W4_THREADS), lds, st, small, big, part,
                        bias_part, g, n_stages, splits, lg_tpf, nbias, ncb);
     BN_LAUNCH_CHECK();
     return 0;
@@ -758,6 +795,20 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
     if (s1) {
         const int pth = w4g_pth(g), tpf = (g.Hs + pth - 1) / pth;
         const int magic = tpf == 1 ? 0 : (int)(unsigned)((1ull << 32) / (unsigned)tpf + 1ull);
+        int na = 4, nb = 2;
+        const int ng = w4g1_groups(g, &na, &nb);
+        if (ng > 1) {
+            if (t.splits % ng) return BN_E_BADARG;
+            dim3 gridg(tiles, t.splits / ng);
+#define W4GG_CASE(QV, B, A_, B_)                                                                 \
+    if (g.Ws == QV && t.bias_side == B && na == A_ && nb == B_)                                  \
+        rc = launch_wgrad4s<QV, B, true, 5, 1, 0, false, A_, B_>(gridg, st, small, big, (float*)ws, bias_part, g, \
+                                                                 t.n_stages, t.splits / ng, magic, t.nbias);
+#define W4GG_ALL(QV) W4GG_CASE(QV, 0, 2, 2) W4GG_CASE(QV, 1, 2, 2) W4GG_CASE(QV, 0, 2, 1) W4GG_CASE(QV, 1, 2, 1)
+            W4GG_ALL(16) W4GG_ALL(32) W4GG_ALL(64)
+#undef W4GG_ALL
+#undef W4GG_CASE
+        } else {
         const bool k3 = g.KV == 4 && g.K0 == 1;
 #define W4G1_CASE(QV, B)                                                                         \
     if (g.Ws == QV && t.bias_side == B)                                                          \
@@ -770,6 +821,7 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         W4G1_ALL(64)
 #undef W4G1_ALL
 #undef W4G1_CASE
+        }
     } else if (gen) {
         // stage -> frame by multiply-high: 2^32 / tiles + 1 (exact below 2^32 / tiles stages)
         const int pth = w4g_pth(g), tpf = (g.Hs + pth - 1) / pth;

@@ -115,6 +115,11 @@ CONV_CASES = [
     ('s1_k7_2ch_50x70', 2, 2, 50, 70, 24, 7, 1, (3, 3), (3, 3)),
     ('s1_k3_1ch_33x20', 3, 1, 33, 20, 5, 3, 1, (1, 1), (1, 1)),
     ('s1_k5_1ch_valid_60x64', 2, 1, 64, 68, 32, 5, 1, (0, 0), (0, 0)),
+    # at most 32 small-side channels on 16 / 32 / 64-wide maps: the weight gradient's wave groups (k_wgrad4s_mfma<.., NA, NB>)
+    ('s1_k5_32x32_c16', 3, 16, 32, 32, 32, 5, 1, (2, 2), (2, 2)),
+    ('s1_k5_16x16_c32', 5, 32, 16, 16, 16, 5, 1, (2, 2), (2, 2)),
+    ('s1_k5_64x64_c48', 2, 48, 64, 64, 24, 5, 1, (2, 2), (2, 2)),
+    ('s1_k5_60x64_c16', 3, 16, 60, 64, 32, 5, 1, (2, 2), (2, 2)),
     ('s1_k5_valid_4ch_128x128', 2, 4, 132, 132, 16, 5, 1, (0, 0), (0, 0)),
     ('s1_k7_64x64', 2, 16, 64, 64, 32, 7, 1, (3, 3), (3, 3)),
     ('s1_k5_valid_64ch_64x64', 2, 64, 68, 68, 32, 5, 1, (0, 0), (0, 0)),
