@@ -669,7 +669,9 @@ static int w4g1_groups(const BnGeom& g, int* na, int* nb) {
     *na = 4; *nb = 2;
     static int off = -1;                               // BN_W4_GROUPS=0: off (tuning build)
     if (off < 0) { const char* e = bn_tune_env("BN_W4_GROUPS"); off = (e && e[0] == '0') ? 1 : 0; }
-    if (off || g.stride != 1 || g.Cs > 32 || (g.Ws != 16 && g.Ws != 32 && g.Ws != 64)) return 1;
+    if (off || g.Cs > 32) return 1;
+    // (stride 2: the power-of-two instantiations, 8 / 16 / 32-wide small maps -- the caller has checked wgrad4s_ok)
+    if (g.stride == 1 ? (g.Ws != 16 && g.Ws != 32 && g.Ws != 64) : (g.Ws != 8 && g.Ws != 16 && g.Ws != 32)) return 1;
     if (g.KV == 4) return 1;                           // (the 3x3 window is instantiated without groups)
     *na = 2;
     *nb = g.Cb <= 16 ? 1 : 2;
@@ -719,6 +721,10 @@ BnFastPlan bn_wgrad4_plan(const BnGeom& g) {
     p.supported = true;
     p.variant = 4;
     p.d = wgrad4_splits(g, t);
+    if (wgrad4s_ok(g, t)) {
+        int na, nb;
+        p.d *= w4g1_groups(g, &na, &nb);                // partial tiles: one per (split, wave group)
+    }
     // partial dW tiles + partial bias rows (either side) of every split
     p.ws_bytes = (size_t)p.d * (25 * g.Cs * g.Cb + (g.Cs > g.Cb ? g.Cs : g.Cb)) * sizeof(float);
     static const char* const names[6] = {"k_wgrad4_mfma<?>", "k_wgrad4_mfma<?>", "k_wgrad4_mfma<2>",
@@ -866,6 +872,21 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         }
     } else if (wgrad4s_ok(g, t)) {
         const int lgq = ilog2_exact_w4(g.Ws), lg_tpf = ilog2_exact_w4(t.tiles_per_frame);
+        int na = 4, nb = 2;
+        const int ng = w4g1_groups(g, &na, &nb);
+        if (ng > 1) {
+            if (t.splits % ng) return BN_E_BADARG;
+            dim3 gridg(tiles, t.splits / ng);
+#define W4SG_CASE(L, B, A_, B_)                                                                  \
+    if (lgq == L && t.bias_side == B && na == A_ && nb == B_)                                    \
+        rc = launch_wgrad4s<(1 << L), B, false, 5, 2, 0, false, A_, B_>(gridg, st, small, big, (float*)ws, bias_part, \
+                                                                       g, t.n_stages, t.splits / ng, lg_tpf, t.nbias);
+#define W4SG_ALL(L) W4SG_CASE(L, 0, 2, 2) W4SG_CASE(L, 1, 2, 2) W4SG_CASE(L, 2, 2, 2) W4SG_CASE(L, 0, 2, 1)      \
+                    W4SG_CASE(L, 1, 2, 1) W4SG_CASE(L, 2, 2, 1)
+            W4SG_ALL(3) W4SG_ALL(4) W4SG_ALL(5)
+#undef W4SG_ALL
+#undef W4SG_CASE
+        } else {
 #define W4S_CASE(L, B)                                                                         \
     if (lgq == L && t.bias_side == B)                                                          \
         rc = g.KV == 4 && g.K0 == 1                                                            \
@@ -879,6 +900,7 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         W4S_CASE(3, 0) W4S_CASE(3, 1) W4S_CASE(3, 2) W4S_CASE(4, 0) W4S_CASE(4, 1) W4S_CASE(4, 2)
         W4S_CASE(5, 0) W4S_CASE(5, 1) W4S_CASE(5, 2)
 #undef W4S_CASE
+        }
     } else
     switch (ilog2_exact_w4(g.Ws)) {
         case 2: rc = launch_wgrad4<2>(grid, lds, st, small, big, (float*)ws, bias_part, g, t); break;

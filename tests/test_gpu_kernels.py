@@ -120,6 +120,9 @@ CONV_CASES = [
     ('s1_k5_16x16_c32', 5, 32, 16, 16, 16, 5, 1, (2, 2), (2, 2)),
     ('s1_k5_64x64_c48', 2, 48, 64, 64, 24, 5, 1, (2, 2), (2, 2)),
     ('s1_k5_60x64_c16', 3, 16, 60, 64, 32, 5, 1, (2, 2), (2, 2)),
+    ('s2_c16_to_32_64x64', 3, 16, 64, 64, 32, 5, 2, (1, 2), (1, 2)),
+    ('s2_c32_to_32_32x32', 5, 32, 32, 32, 32, 5, 2, (1, 2), (1, 2)),
+    ('s2_c48_to_24_16x16', 9, 48, 16, 16, 24, 5, 2, (1, 2), (1, 2)),
     ('s1_k5_valid_4ch_128x128', 2, 4, 132, 132, 16, 5, 1, (0, 0), (0, 0)),
     ('s1_k7_64x64', 2, 16, 64, 64, 32, 7, 1, (3, 3), (3, 3)),
     ('s1_k5_valid_64ch_64x64', 2, 64, 68, 68, 32, 5, 1, (0, 0), (0, 0)),
@@ -255,6 +258,8 @@ CONVT_CASES = [
     ('k3s2_same_4x4_8x8', 9, 96, 4, 4, 64, 3, 2, 0, (0, 1, 0, 1), 0),
     ('k3s2_same_10x12', 4, 64, 10, 12, 32, 3, 2, 0, (0, 1, 0, 1), 0),
     ('k7s2_same_16x16', 3, 64, 16, 16, 32, 7, 2, 0, (2, 3, 2, 3), 0),
+    ('s2_c32_to_16_16x16', 3, 32, 16, 16, 16, 5, 2, 0, (1, 2, 1, 2), 0),
+    ('s2_c16_to_16_32x32', 2, 16, 32, 32, 16, 5, 2, 0, (1, 2, 1, 2), 0),
     ('k9s2_same_8x8', 3, 128, 8, 8, 64, 9, 2, 0, (3, 4, 3, 4), 0),
     ('k9s2_same_D4', 2, 32, 64, 64, 1, 9, 2, 0, (3, 4, 3, 4), 0),
     ('k7s2_same_10x12', 3, 64, 10, 12, 32, 7, 2, 0, (2, 3, 2, 3), 0),
