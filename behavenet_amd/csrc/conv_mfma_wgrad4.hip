@@ -672,7 +672,7 @@ static int w4g1_groups(const BnGeom& g, int* na, int* nb) {
     if (off || g.Cs > 32) return 1;
     // (stride 2: the power-of-two instantiations, 8 / 16 / 32-wide small maps -- the caller has checked wgrad4s_ok)
     if (g.stride == 1 ? (g.Ws != 16 && g.Ws != 32 && g.Ws != 64) : (g.Ws != 8 && g.Ws != 16 && g.Ws != 32)) return 1;
-    if (g.KV == 4) return 1;                           // (the 3x3 window is instantiated without groups)
+    if (g.KV == 4 && g.K0 != 1) return 1;              // (4x4 kernels: instantiated without groups; 3x3: with)
     *na = 2;
     *nb = g.Cb <= 16 ? 1 : 2;
     return 8 / (*na * *nb);
@@ -806,10 +806,13 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         if (ng > 1) {
             if (t.splits % ng) return BN_E_BADARG;
             dim3 gridg(tiles, t.splits / ng);
+            const bool k3g = g.KV == 4;
 #define W4GG_CASE(QV, B, A_, B_)                                                                 \
     if (g.Ws == QV && t.bias_side == B && na == A_ && nb == B_)                                  \
-        rc = launch_wgrad4s<QV, B, true, 5, 1, 0, false, A_, B_>(gridg, st, small, big, (float*)ws, bias_part, g, \
-                                                                 t.n_stages, t.splits / ng, magic, t.nbias);
+        rc = k3g ? launch_wgrad4s<QV, B, true, 14, 1, 0, false, A_, B_>(gridg, st, small, big, (float*)ws, bias_part, g, \
+                                                                        t.n_stages, t.splits / ng, magic, t.nbias) \
+                 : launch_wgrad4s<QV, B, true, 5, 1, 0, false, A_, B_>(gridg, st, small, big, (float*)ws, bias_part, g, \
+                                                                       t.n_stages, t.splits / ng, magic, t.nbias);
 #define W4GG_ALL(QV) W4GG_CASE(QV, 0, 2, 2) W4GG_CASE(QV, 1, 2, 2) W4GG_CASE(QV, 0, 2, 1) W4GG_CASE(QV, 1, 2, 1)
             W4GG_ALL(16) W4GG_ALL(32) W4GG_ALL(64)
 #undef W4GG_ALL
@@ -877,10 +880,13 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
         if (ng > 1) {
             if (t.splits % ng) return BN_E_BADARG;
             dim3 gridg(tiles, t.splits / ng);
+            const bool k3g = g.KV == 4;
 #define W4SG_CASE(L, B, A_, B_)                                                                  \
     if (lgq == L && t.bias_side == B && na == A_ && nb == B_)                                    \
-        rc = launch_wgrad4s<(1 << L), B, false, 5, 2, 0, false, A_, B_>(gridg, st, small, big, (float*)ws, bias_part, \
-                                                                       g, t.n_stages, t.splits / ng, lg_tpf, t.nbias);
+        rc = k3g ? launch_wgrad4s<(1 << L), B, false, 14, 2, 0, false, A_, B_>(gridg, st, small, big, (float*)ws,      \
+                                                          bias_part, g, t.n_stages, t.splits / ng, lg_tpf, t.nbias) \
+                 : launch_wgrad4s<(1 << L), B, false, 5, 2, 0, false, A_, B_>(gridg, st, small, big, (float*)ws,       \
+                                                          bias_part, g, t.n_stages, t.splits / ng, lg_tpf, t.nbias);
 #define W4SG_ALL(L) W4SG_CASE(L, 0, 2, 2) W4SG_CASE(L, 1, 2, 2) W4SG_CASE(L, 2, 2, 2) W4SG_CASE(L, 0, 2, 1)      \
                     W4SG_CASE(L, 1, 2, 1) W4SG_CASE(L, 2, 2, 1)
             W4SG_ALL(3) W4SG_ALL(4) W4SG_ALL(5)

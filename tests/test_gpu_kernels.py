@@ -123,6 +123,9 @@ CONV_CASES = [
     ('s2_c16_to_32_64x64', 3, 16, 64, 64, 32, 5, 2, (1, 2), (1, 2)),
     ('s2_c32_to_32_32x32', 5, 32, 32, 32, 32, 5, 2, (1, 2), (1, 2)),
     ('s2_c48_to_24_16x16', 9, 48, 16, 16, 24, 5, 2, (1, 2), (1, 2)),
+    ('k3s2_same_c16_to_32', 3, 16, 64, 64, 32, 3, 2, (0, 1), (0, 1)),
+    ('k3s1_c16_to_32_64x64', 2, 16, 64, 64, 32, 3, 1, (1, 1), (1, 1)),
+    ('k3s1_c32_to_16_32x32', 3, 32, 32, 32, 16, 3, 1, (1, 1), (1, 1)),
     ('s1_k5_valid_4ch_128x128', 2, 4, 132, 132, 16, 5, 1, (0, 0), (0, 0)),
     ('s1_k7_64x64', 2, 16, 64, 64, 32, 7, 1, (3, 3), (3, 3)),
     ('s1_k5_valid_64ch_64x64', 2, 64, 68, 68, 32, 5, 1, (0, 0), (0, 0)),
