@@ -329,15 +329,17 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
         // issue order) where its tile serves the map; the tile shape that wastes the fewest pixels
         float fill = 0.f;
         int bi = -1;
-        static const int cand1[3][2] = {{2, 1}, {2, 2}, {1, 1}};
-        for (int i = 0; i < 3; ++i) {
+        // (32 channels x 256 pixels for layers with fewer than 64 small-side channels: half the weight traffic and
+        // half the halo rows per pixel of the 32 x 128 tile)
+        static const int cand1[4][2] = {{2, 1}, {2, 2}, {1, 2}, {1, 1}};
+        for (int i = 0; i < 4; ++i) {
             if (cand1[i][0] == 2 && g.Cs < 64) continue;
             const float f = bn_down2_fill(g, cand1[i][0], cand1[i][1]);
             if (f > fill + 0.02f) { fill = f; bi = i; }
         }
         if (bi >= 0) {
-            static const char* const names2s[3] = {"k_down2_mfma<2, 1, 5, 0, 1>", "k_down2_mfma<2, 2, 5, 0, 1>",
-                                                   "k_down2_mfma<1, 1, 5, 0, 1>"};
+            static const char* const names2s[4] = {"k_down2_mfma<2, 1, 5, 0, 1>", "k_down2_mfma<2, 2, 5, 0, 1>",
+                                                   "k_down2_mfma<1, 2, 5, 0, 1>", "k_down2_mfma<1, 1, 5, 0, 1>"};
             p.supported = true;
             p.a = cand1[bi][0]; p.b = cand1[bi][1]; p.c = CC; p.d = 1; p.variant = 2;
             p.kernel_name = names2s[bi];

@@ -574,7 +574,7 @@ int bn_launch_down2(int MR, int NR, const float* big, const float* w, const floa
            : k3 ? launch_down2<mr, nr, 4, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs) \
            : k4 ? launch_down2<mr, nr, 4>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs)   \
                 : launch_down2<mr, nr, 5>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
-    D2_CASE(2, 2) D2_CASE(2, 1) D2_CASE(1, 1)
+    D2_CASE(2, 2) D2_CASE(2, 1) D2_CASE(1, 1) D2_CASE(1, 2)
 #undef D2_CASE
     if (rc || splits == 1) return rc;
     return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cs,

@@ -936,7 +936,7 @@ def test_kernels_larger_than_5x5_run_without_im2col(case_name):
     ('tile_E0_96x80', 'k_down_c1<gen>'), ('tile_E0c2_80x128', 'k_down_c1s<.., 2, 2, gen>'), ('pad_24x20', 'k_down2_mfma<'),
     ('k4_64ch_32x32', 'mfma'), ('k4x3_24x20', 'k_down2_mfma<'), ('np2_6x5', 'on zero-padded 6x6'), ('pad_4x3', 'k_down2_mfma<2, 1> on zero-padded 4x4'),
     ('tile_odd_pl2', 'on zero-padded 47x36'),
-    ('s1_k5_64x64', 'k_down2_mfma<1, 1, 5, 0, 1>'), ('s1_k4_8x8', 'k_down2_mfma<')])
+    ('s1_k5_64x64', 'k_down2_mfma<1, 2, 5, 0, 1>'), ('s1_k4_8x8', 'k_down2_mfma<')])
 def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, want):
     """The dispatch takes the tiled / zero-padded detour (conv_pad.hip), not the direct loops."""
     case = [c for c in CONV_CASES if c[0] == case_name][0]
