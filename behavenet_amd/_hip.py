@@ -68,6 +68,8 @@ SIGNATURES = {
         _c_int, [_c_void_p] * 9 + [_c_int] * 3 + [_c_float, _c_int, _c_float, _c_void_p]),
     'bn_maxpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
     'bn_maxpool2d_bwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
+    'bn_maxpool2d_act_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [ctypes.c_float, _c_void_p]),
+    'bn_maxpool2d_act_bwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_void_p]),
     'bn_maxunpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
     'bn_maxunpool2d_fwd_k2': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
     'bn_maxunpool2d_bwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
@@ -744,6 +746,27 @@ def maxpool2d_fwd(x, k, stride, pad, out_hw):
                                    N * C, H, W, Ho, Wo, k, stride, pad[0], pad[1], _stream()),
            'bn_maxpool2d_fwd')
     return y, idx
+
+
+def maxpool2d_act_fwd(x, act, slope):
+    """2x2 / stride-2 pooling + activation in one pass -> (y, idx) or None where the kernel does not apply."""
+    N, C, H, W = x.shape
+    if H % 2 or W % 4:
+        return None
+    y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, C, H // 2, W // 2), dtype=torch.int32, device=x.device)
+    rc = load().bn_maxpool2d_act_fwd(_ptr(x, 'x'), _ptr(y, 'y'), _ptr(idx, 'idx', torch.int32), N * C, H, W,
+                                     int(act), float(slope), _stream())
+    return (y, idx) if rc == 0 else None
+
+
+def maxpool2d_act_bwd(dy, y, idx, in_hw, act, slope):
+    N, C, Ho, Wo = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    _check(load().bn_maxpool2d_act_bwd(_ptr(dy, 'dy'), _ptr(y, 'y'), _ptr(idx, 'idx', torch.int32), _ptr(dx, 'dx'),
+                                       N * C, H, W, int(act), float(slope), _stream()), 'bn_maxpool2d_act_bwd')
+    return dx
 
 
 def maxpool2d_bwd(dy, idx, in_hw, k, stride, pad):

@@ -89,9 +89,11 @@ __global__ __launch_bounds__(256) void k_maxunpool_bwd(const float* __restrict__
 __device__ __forceinline__ void pool2_pick(float v, int i, float& best, int& bi) {
     if (v > best || isnan(v)) { best = v; bi = i; }
 }
+// (act / slope: the activation that follows the pooling -- aes.py:204-211 -- applied on the way out; it is monotonic,
+// so the winner is the same)
 __global__ __launch_bounds__(256) void k_maxpool_fwd_k2(const float* __restrict__ x, float* __restrict__ y,
                                                         int* __restrict__ idx, size_t pairs, int Ho, int Wo2,
-                                                        int W) {
+                                                        int W, int act, float slope) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= pairs) return;
     const int q2 = (int)(i % Wo2);
@@ -107,14 +109,15 @@ __global__ __launch_bounds__(256) void k_maxpool_fwd_k2(const float* __restrict_
     pool2_pick(b.x, me + W, b0, i0); pool2_pick(b.y, me + W + 1, b0, i0);
     pool2_pick(a.z, me + 2, b1, i1); pool2_pick(a.w, me + 3, b1, i1);
     pool2_pick(b.z, me + W + 2, b1, i1); pool2_pick(b.w, me + W + 3, b1, i1);
-    reinterpret_cast<float2*>(y)[i] = make_float2(b0, b1);
+    reinterpret_cast<float2*>(y)[i] = make_float2(bn_apply_act(b0, act, slope), bn_apply_act(b1, act, slope));
     reinterpret_cast<int2*>(idx)[i] = make_int2(i0, i1);
 }
 // big[plane][h][w] = small[plane][p][q] where idx[plane][p][q] == h W + w inside window (p, q), 0.0f elsewhere: the
 // backward pass of the pooling (small = dy) and the forward pass of the unpooling that undoes it (small = x)
+// (yact: the saved output of the activation behind the pooling; small is multiplied by its derivative first)
 __global__ __launch_bounds__(256) void k_pool_spread_k2(const float* __restrict__ small, const int* __restrict__ idx,
                                                         float* __restrict__ big, size_t pairs, int Ho, int Wo2,
-                                                        int W) {
+                                                        int W, const float* __restrict__ yact, int act, float slope) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= pairs) return;
     const int q2 = (int)(i % Wo2);
@@ -122,7 +125,12 @@ __global__ __launch_bounds__(256) void k_pool_spread_k2(const float* __restrict_
     const int ho = (int)(t % Ho);
     const size_t plane = t / Ho;
     const int me = 2 * ho * W + 4 * q2;
-    const float2 v = reinterpret_cast<const float2*>(small)[i];
+    float2 v = reinterpret_cast<const float2*>(small)[i];
+    if (yact) {
+        const float2 ya = reinterpret_cast<const float2*>(yact)[i];
+        v.x *= bn_act_grad_from_output(ya.x, act, slope);
+        v.y *= bn_act_grad_from_output(ya.y, act, slope);
+    }
     const int2 id = reinterpret_cast<const int2*>(idx)[i];
     float* r0 = big + plane * (size_t)(2 * Ho) * W + me;
     *reinterpret_cast<float4*>(r0) = make_float4(id.x == me ? v.x : 0.f, id.x == me + 1 ? v.x : 0.f,
@@ -148,7 +156,7 @@ extern "C" int bn_maxpool2d_fwd(const float* x, float* y, int* idx, int planes, 
     const size_t total = (size_t)planes * Ho * Wo;
     if (pool_k2_ok(H, W, Ho, Wo, k, stride, pad_t, pad_l, x, y, idx)) {
         hipLaunchKernelGGL(k_maxpool_fwd_k2, dim3(pool_blocks(total / 2)), dim3(256), 0, (hipStream_t)stream, x, y,
-                           idx, total / 2, Ho, Wo / 2, W);
+                           idx, total / 2, Ho, Wo / 2, W, BN_ACT_NONE, 0.f);
         BN_LAUNCH_CHECK();
         return 0;
     }
@@ -168,12 +176,37 @@ extern "C" int bn_maxpool2d_bwd(const float* dy, const int* idx, float* dx, int 
     if (pool_k2_ok(H, W, Ho, Wo, k, stride, pad_t, pad_l, dy, dx, idx)) {
         const size_t pairs = (size_t)planes * Ho * Wo / 2;
         hipLaunchKernelGGL(k_pool_spread_k2, dim3(pool_blocks(pairs)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
-                           pairs, Ho, Wo / 2, W);
+                           pairs, Ho, Wo / 2, W, (const float*)nullptr, BN_ACT_NONE, 0.f);
         BN_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL(k_maxpool_bwd, dim3(pool_blocks(total)), dim3(256), 0, (hipStream_t)stream,
                        dy, idx, dx, total, H, W, Ho, Wo, k, stride, pad_t, pad_l);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// 2x2 / stride-2 / unpadded pooling of an even map with the activation that follows it in one pass each way
+// (BN_E_SHAPE where the two-windows-per-thread kernels do not apply: pool, then activate)
+extern "C" int bn_maxpool2d_act_fwd(const float* x, float* y, int* idx, int planes, int H, int W, int act,
+                                    float slope, bn_stream_t stream) {
+    if (!x || !y || !idx || planes <= 0 || H <= 0 || W <= 0) return BN_E_BADARG;
+    if ((H & 1) || (W & 1) || !pool_k2_ok(H, W, H / 2, W / 2, 2, 2, 0, 0, x, y, idx)) return BN_E_SHAPE;
+    const size_t pairs = (size_t)planes * (H / 2) * (W / 2) / 2;
+    hipLaunchKernelGGL(k_maxpool_fwd_k2, dim3(pool_blocks(pairs)), dim3(256), 0, (hipStream_t)stream, x, y, idx, pairs,
+                       H / 2, W / 4, W, act, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+// dx = spread( dy * act'(y) ) with y the saved output of bn_maxpool2d_act_fwd
+extern "C" int bn_maxpool2d_act_bwd(const float* dy, const float* y, const int* idx, float* dx, int planes, int H,
+                                    int W, int act, float slope, bn_stream_t stream) {
+    if (!dy || !y || !dx || !idx || planes <= 0 || H <= 0 || W <= 0) return BN_E_BADARG;
+    if ((H & 1) || (W & 1) || !pool_k2_ok(H, W, H / 2, W / 2, 2, 2, 0, 0, dy, dx, idx) || (((uintptr_t)y) & 15u))
+        return BN_E_SHAPE;
+    const size_t pairs = (size_t)planes * (H / 2) * (W / 2) / 2;
+    hipLaunchKernelGGL(k_pool_spread_k2, dim3(pool_blocks(pairs)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx,
+                       pairs, H / 2, W / 4, W, y, act, slope);
     BN_LAUNCH_CHECK();
     return 0;
 }
@@ -201,7 +234,7 @@ extern "C" int bn_maxunpool2d_fwd_k2(const float* x, const int* idx, float* y, i
     if (!pool_k2_ok(2 * Hi, 2 * Wi, Hi, Wi, 2, 2, 0, 0, x, y, idx)) return BN_E_SHAPE;
     const size_t pairs = (size_t)planes * Hi * Wi / 2;
     hipLaunchKernelGGL(k_pool_spread_k2, dim3(pool_blocks(pairs)), dim3(256), 0, (hipStream_t)stream, x, idx, y, pairs,
-                       Hi, Wi / 2, 2 * Wi);
+                       Hi, Wi / 2, 2 * Wi, (const float*)nullptr, BN_ACT_NONE, 0.f);
     BN_LAUNCH_CHECK();
     return 0;
 }

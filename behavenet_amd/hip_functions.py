@@ -1135,6 +1135,43 @@ class MaxPoolFn(torch.autograd.Function):
             None
 
 
+class MaxPoolActFn(torch.autograd.Function):
+    """2x2 / stride-2 / unpadded max pooling and the activation behind it (ref aes.py:204-211) in one pass each
+    way -> (y, idx int32); only built by max_pool_act where bn_maxpool2d_act_fwd applies."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x.contiguous()
+        out = _hip.maxpool2d_act_fwd(x, act, LRELU_SLOPE)
+        if out is None:
+            raise RuntimeError('max_pool_act: geometry not served')
+        y, idx = out
+        ctx.save_for_backward(idx, y)
+        ctx.args = (tuple(x.shape[2:]), act)
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, dy, _didx):
+        idx, y = ctx.saved_tensors
+        in_hw, act = ctx.args
+        return _hip.maxpool2d_act_bwd(dy.contiguous(), y, idx, in_hw, act, LRELU_SLOPE), None
+
+
+def max_pool_act(x, k, stride, pad, out_hw, act):
+    """max_pool followed by ``activation(., act)``; fused where the pooling is 2x2 / stride 2 / unpadded on an even
+    map whose pooled width is even (the only pooling the reference's generator draws)."""
+    fused = (int(k) == 2 and int(stride) == 2 and int(pad[0]) == 0 and int(pad[1]) == 0 and x.is_cuda and
+             x.shape[2] == 2 * int(out_hw[0]) and x.shape[3] == 2 * int(out_hw[1]) and x.shape[3] % 4 == 0 and
+             x.data_ptr() % 16 == 0)
+    if not fused:
+        y, idx = max_pool(x, k, stride, pad, out_hw)
+        return activation(y, act), idx
+    y, idx = MaxPoolActFn.apply(x, int(act))
+    idx.bn_own_window = True
+    return y, idx
+
+
 def max_pool(x, k, stride, pad, out_hw):
     y, idx = MaxPoolFn.apply(x, int(k), int(stride), (int(pad[0]), int(pad[1])),
                              (int(out_hw[0]), int(out_hw[1])))

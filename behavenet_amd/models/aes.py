@@ -22,7 +22,7 @@ from behavenet_amd.hip_functions import (
     ChunkScalars, ConvLayerPlan, FusedPixelLoss, Readback, activation, backward_chunks, bn_chunks,
     capturing, finish_loss,
     chunked_sq_err, conv_stack, conv_stack_bn, conv_stack_sq_err, first_layer_forward,
-    join_side_streams, linear, begin_chunks, chunk_stream, max_pool, max_unpool,
+    join_side_streams, linear, begin_chunks, chunk_stream, max_pool, max_pool_act, max_unpool,
     pixel_loss_scales, reserve_device_pools)
 
 __all__ = [
@@ -231,9 +231,8 @@ class ConvAEEncoder(BaseModule):
             if pool is not None:
                 k, stride, pad, out_hw = pool
                 sizes.append(h.size())
-                h, idx = max_pool(h, k, stride, pad, out_hw)
+                h, idx = max_pool_act(h, k, stride, pad, out_hw, _hip.ACT_LRELU)
                 pool_idx.append(idx)
-                h = activation(h, _hip.ACT_LRELU)
             _tap_signs(self._plan, j, layer, h)
         self._pool_state = (pool_idx, sizes)
         return h.reshape(h.size(0), -1)

@@ -149,6 +149,13 @@ int bn_maxpool2d_fwd(const float* x, float* y, int* idx, int planes, int H, int 
                      int k, int stride, int pad_t, int pad_l, bn_stream_t stream);
 int bn_maxpool2d_bwd(const float* dy, const int* idx, float* dx, int planes, int H, int W,
                      int Ho, int Wo, int k, int stride, int pad_t, int pad_l, bn_stream_t stream);
+/* 2x2 / stride-2 / unpadded max pooling of an even map WITH the activation that follows it (aes.py:204-211: conv ->
+ * pool -> LeakyReLU), one pass each way: y = act(max), idx as bn_maxpool2d_fwd; dx = spread(dy * act'(y)).
+ * BN_E_SHAPE if W / 2 is odd or a pointer is not 16-byte aligned (use bn_maxpool2d_fwd + the activation then). */
+int bn_maxpool2d_act_fwd(const float* x, float* y, int* idx, int planes, int H, int W, int act, float slope,
+                         bn_stream_t stream);
+int bn_maxpool2d_act_bwd(const float* dy, const float* y, const int* idx, float* dx, int planes, int H, int W,
+                         int act, float slope, bn_stream_t stream);
 int bn_maxunpool2d_fwd(const float* x, const int* idx, float* y, int planes, int in_plane,
                        int out_plane, bn_stream_t stream);
 /* The same for the indices of a 2x2 / stride-2 / unpadded pooling of a (2 Hi) x (2 Wi) map (every index lies inside its

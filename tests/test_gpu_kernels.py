@@ -791,6 +791,27 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
         assert torch.equal(dv.cpu(), vr.grad)
 
 
+@pytest.mark.parametrize('shape', [(3, 16, 64, 48), (2, 5, 8, 12), (2, 3, 6, 10)])
+def test_maxpool_with_activation_vs_torch(shape):
+    """max_pool_act (2x2 / stride-2 pooling + LeakyReLU in one pass each way where the pooled width is even, the two
+    separate ops elsewhere) against F.max_pool2d + F.leaky_relu and their autograd: bit-exact."""
+    from behavenet_amd import hip_functions as hf
+    g = torch.Generator().manual_seed(5)
+    x = torch.round(torch.randn(shape, generator=g) * 4) / 4
+    xr = x.clone().requires_grad_(True)
+    p_ref, idx_ref = F.max_pool2d(xr, 2, 2, return_indices=True)
+    y_ref = F.leaky_relu(p_ref, SLOPE)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    xd = x.to(DEV).requires_grad_(True)
+    y, idx = hf.max_pool_act(xd, 2, 2, (0, 0), tuple(y_ref.shape[2:]), _hip.ACT_LRELU)
+    assert torch.equal(y.detach().cpu(), y_ref.detach())
+    assert torch.equal(idx.cpu().long(), idx_ref)
+    assert getattr(idx, 'bn_own_window', False)
+    y.backward(dy.to(DEV))
+    assert torch.equal(xd.grad.cpu(), xr.grad)
+
+
 def _random_conv_cases(seed, count, big=False):
     """Seeded sweep over what the round-4 tile logic has to get right: map sizes that are no powers of
     two (tiles with masked lanes, frames' last tiles / stages hanging over the edge, frame groups cut short
