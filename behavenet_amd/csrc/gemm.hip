@@ -17,7 +17,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // waves (wave `ws` of them; combined through `red` = nw * 1024 floats in the fixed order of the wave
 // index).  Every wave of the tile must call it; the caller's block may hold other tiles.
 __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const int by, const int bz,
-                                          const int nw, const int ws, float* red) {
+                                          const int nw, const int ws, float* red,
+                                          const bool live = true) {
     const int lane = threadIdx.x & 63;
     const int i0 = by * 32, j0 = bx * 32;
     const int li = lane & 31, lk = lane >> 5;
@@ -122,7 +123,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
     if (nw > 1) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) red[(ws * 16 + t) * 64 + lane] = acc[t];
-        __syncthreads();
+        __syncthreads();      // (the LAST barrier of the workgroup: waves may leave from here on)
         if (ws != 0) return;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -133,7 +134,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
     }
 
     const int j = j0 + (lane & 31);
-    if (j >= a.N) return;
+    if (j >= a.N || !live) return;
     if (a.part) {       // cross-workgroup split: raw partial tile, combined by k_gemm_combine
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -187,11 +188,17 @@ __global__ __launch_bounds__(64 * GJ_WAVES) void k_linear_jobs(LinearJobs p) {
         const GemmJob& job = p.g[q];
         if (b < job.blocks) {
             const int upb = GJ_WAVES / job.nw;
-            const int unit = b * upb + wave / job.nw;
-            if (unit >= job.tiles * job.slices) return;
+            // the waves of a unit past the last one (two units per workgroup, odd unit count) stay
+            // alive through gemm_tile's barrier -- they redo the last unit and store nothing --
+            // instead of returning in front of it (a barrier that other waves of the
+            // workgroup never reach is undefined in HIP, whatever gfx950's s_barrier does)
+            const int units = job.tiles * job.slices;
+            const int unit_w = b * upb + wave / job.nw;
+            const bool live = unit_w < units;
+            const int unit = live ? unit_w : units - 1;
             const int tile = unit / job.slices, slice = unit - tile * job.slices;
             gemm_tile(job.a, tile % job.tiles_x, tile / job.tiles_x, slice, job.nw, wave % job.nw,
-                      red + (wave / job.nw) * job.nw * 1024);
+                      red + (wave / job.nw) * job.nw * 1024, live);
             return;
         }
         b -= job.blocks;

@@ -114,6 +114,12 @@ class SyntheticSessionsGenerator(object):
         # host_u8 prefetcher: two device staging buffers per trial shape, one copy stream
         self._pf = None          # (key, device uint8 tensor, ready event) of the prefetched trial
         self.lookahead = 0       # queue position of this rank's next trial ('trial' mode: W - 1)
+        # uint8 placements: hand out the device uint8 frames as they are (inference: the first conv
+        # layer converts in flight, no float copy of the trial is made; fitting/eval.py sets it)
+        self.serve_uint8 = False
+        self.read_ahead = 4      # file-backed sessions: trials requested from the reader threads ahead of use
+        self._skip_pred = None   # predicate of the last next_batch(skip=callable): steers the look-ahead
+        self._last_slot = None
         self._pf_bufs = {}
         self._pf_stream = None
         self._queues = [{k: [] for k in self._dtypes} for _ in self.datasets]
@@ -179,7 +185,11 @@ class SyntheticSessionsGenerator(object):
 
         ``skip=True`` (data-parallel 'trial' mode: the trial belongs to another rank) advances
         the generator exactly as a normal call would -- same queue pops, same RNG draws -- but
-        does not read, copy or convert the trial: returns ``(SKIPPED, session)``."""
+        does not read, copy or convert the trial: returns ``(SKIPPED, session)``.  ``skip`` may
+        also be a predicate ``skip(session, trial) -> bool`` asked once the trial is known
+        (``export_latents``: a trial belongs to a rank by its identity); the look-ahead of the
+        uint8 feed then requests only trials the predicate lets through."""
+        self._skip_pred = skip if callable(skip) else None
         if self.n_sessions_per_batch > 1 and dtype == 'train' and return_multiple:
             samples, sessions = [], []
             ratios = np.array(self.batch_ratios, dtype=np.float64)
@@ -194,6 +204,7 @@ class SyntheticSessionsGenerator(object):
                     if self._n_left(sess, dtype):
                         trial = self._queue(sess, dtype).pop(0)
                         break
+                skip = bool(skip)       # (multi-session batches: all or nothing)
                 samples.append(SKIPPED if skip else self._sample(sess, trial, dtype))
                 sessions.append(sess)
             return (SKIPPED if skip else samples), sessions
@@ -204,7 +215,7 @@ class SyntheticSessionsGenerator(object):
             if self._n_left(sess, dtype):
                 trial = self._queue(sess, dtype).pop(0)
                 break
-        if skip:
+        if (skip(sess, trial) if callable(skip) else skip):
             return SKIPPED, sess
         return self._sample(sess, trial, dtype), sess
 
@@ -214,7 +225,7 @@ class SyntheticSessionsGenerator(object):
         if self.placement == 'host':
             img = img.to(self.device, non_blocking=True)
         elif self.placement == 'device_u8':
-            img = _hip.u8_to_unit_float(img)
+            img = img if self.serve_uint8 else _hip.u8_to_unit_float(img)
         elif self.placement == 'host_u8':
             img = self._fetch_host_u8(sess, trial, dtype)
         sample = {'images': img[None], 'batch_idx': torch.tensor([trial])}
@@ -244,12 +255,41 @@ class SyntheticSessionsGenerator(object):
             self._pf_bufs[key] = buf
         return buf
 
+    def _upcoming(self, sess, dtype, n):
+        """Up to ``n`` trials of this session's queue that THIS process will ask for next, in order:
+        those the skip predicate lets through (export_latents), every W-th one ('trial' mode of
+        ``fit``: ``lookahead`` = W - 1 trials in between go to the other ranks), or simply the head."""
+        queue = self._queues[sess][dtype]      # (None: the session's order is not drawn yet)
+        if not queue:
+            return []
+        pred = self._skip_pred
+        if pred is not None:
+            out = []
+            for t in queue:
+                if not pred(sess, t):
+                    out.append(t)
+                    if len(out) == n:
+                        break
+            return out
+        # (only the TRAINING loop deals trials out to the ranks; validation and test loops consume
+        # every trial on every rank, their next request is the head of the queue)
+        ahead = int(getattr(self, 'lookahead', 0)) if dtype == 'train' else 0
+        return list(queue[ahead::ahead + 1][:n])
+
     def _fetch_host_u8(self, sess, trial, dtype):
         main = torch.cuda.current_stream()
         if self._pf_stream is None:
             self._pf_stream = torch.cuda.Stream()
             self._pf_slot = 0
             self._pf_done = [None, None]      # main-stream events: staging slot consumed
+        if self._last_slot is not None:
+            # whatever consumed the trial served last (the conversion kernel, or -- serve_uint8 --
+            # the encoder's first layer reading the staging buffer itself) has been queued on the
+            # main stream by now: the slot is free once THIS point of the stream is reached
+            done = torch.cuda.Event()
+            done.record(main)
+            self._pf_done[self._last_slot] = done
+        store = self._store[sess][0]
         pf = self._pf
         self._pf = None
         if pf is not None and pf[0] == (sess, trial):
@@ -257,7 +297,7 @@ class SyntheticSessionsGenerator(object):
             main.wait_event(ready)
         else:
             # nothing (or something else) was prefetched: copy on the main stream
-            host = self._store[sess][0][trial]
+            host = store[trial]
             slot = self._pf_slot
             dev_u8 = self._staging(host.shape, slot)
             if pf is not None:
@@ -267,21 +307,22 @@ class SyntheticSessionsGenerator(object):
             if self._pf_done[slot] is not None:
                 main.wait_event(self._pf_done[slot])
             dev_u8.copy_(host, non_blocking=True)
-        img = _hip.u8_to_unit_float(dev_u8)
+        img = dev_u8 if self.serve_uint8 else _hip.u8_to_unit_float(dev_u8)
         done = torch.cuda.Event()
         done.record(main)
         self._pf_done[slot] = done
+        self._last_slot = slot
         self._pf_slot = slot ^ 1
-        # look ahead: the head of this session's queue is (very likely) the next trial -- in
-        # data-parallel 'trial' mode the one `lookahead` = world - 1 places further down (the
-        # trials in between go to the other ranks, `next_batch(skip=True)`)
-        queue = self._queues[sess][dtype]      # (None: the session's order is not drawn yet)
-        # (only the TRAINING loop deals trials out to the ranks; validation and test loops consume
-        # every trial on every rank, their next request is the head of the queue)
-        ahead = int(getattr(self, 'lookahead', 0)) if dtype == 'train' else 0
-        if queue and len(queue) > ahead:
-            nxt = queue[ahead]
-            host = self._store[sess][0][nxt]
+        # look ahead: the next trials this process will ask this session for.  File-backed sessions
+        # hand them to their reader threads now (one pread per trial into pinned memory, off the
+        # main thread); the first of them is also copied to the device on the copy stream.
+        coming = self._upcoming(sess, dtype, max(1, int(self.read_ahead)))
+        if coming and hasattr(store, 'prefetch'):
+            for t in coming:
+                store.prefetch(t)
+        if coming:
+            nxt = coming[0]
+            host = store[nxt]
             nslot = self._pf_slot
             buf = self._staging(host.shape, nslot)
             with torch.cuda.stream(self._pf_stream):
@@ -302,21 +343,52 @@ _FRAME_SIGNALS = ('images', 'masks', 'labels', 'labels_sc', 'labels_masks')
 
 class _LazyTrials(object):
     """List-like over the trials of one signal: read from the store on first use, then kept (the
-    images as PINNED uint8 -- 1 byte per pixel, a quarter of the reference's float32 batches)."""
+    images as PINNED uint8 -- 1 byte per pixel, a quarter of the reference's float32 batches).
 
-    def __init__(self, dataset, signal, convert):
-        self.dataset, self.signal, self.convert = dataset, signal, convert
+    ``prefetch(trial)`` hands the read to a small pool of reader threads (the generator's
+    look-ahead calls it for the next few trials): with ``direct`` set the trial goes from the file
+    into a pinned tensor by one ``pread`` (``trial_store._NpzStore.read_into``: no zipfile pass, no
+    intermediate copy, GIL released), so the disk side of trial k + 1 .. k + 4 runs underneath the
+    device's work on trial k."""
+
+    _pool = None
+
+    def __init__(self, dataset, signal, convert, direct=None):
+        self.dataset, self.signal, self.convert, self.direct = dataset, signal, convert, direct
         self.cache = {}
+        self._pending = {}
 
     def __len__(self):
         return self.dataset.n_trials
 
+    def _load(self, trial):
+        if self.direct is not None:
+            t = self.direct(trial)
+            if t is not None:
+                return t
+        return self.convert(self.dataset.read(self.signal, trial))
+
+    def prefetch(self, trial):
+        if trial in self.cache or trial in self._pending:
+            return
+        if _LazyTrials._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _LazyTrials._pool = ThreadPoolExecutor(
+                max_workers=int(os.environ.get('BN_READ_THREADS', '3')),
+                thread_name_prefix='bn-trial-reader')
+        self._pending[trial] = _LazyTrials._pool.submit(self._load, trial)
+
     def __getitem__(self, trial):
         t = self.cache.get(trial)
         if t is None:
-            t = self.convert(self.dataset.read(self.signal, trial))
+            fut = self._pending.pop(trial, None)
+            t = fut.result() if fut is not None else self._load(trial)
             if self.dataset.keep_in_memory:
                 self.cache[trial] = t
+            elif len(self._pending) > 64:
+                # (requested ahead but never asked for: do not let them pile up)
+                for k in list(self._pending)[:-32]:
+                    self._pending.pop(k).cancel()
         return t
 
 
@@ -500,7 +572,22 @@ class ConcatSessionsGenerator(SyntheticSessionsGenerator):
                  if sig not in ('images', 'labels')}
         self._extra.append(extra)
         labels = _LazyTrials(ds, 'labels', floats('labels')) if 'labels' in ds.signals else None
-        return _LazyTrials(ds, 'images', images), labels
+        direct = None
+        if self.placement == 'host_u8' and device == 'cuda':
+            store = ds._store('images')
+
+            def direct(trial):
+                # file -> pinned tensor in one read (the caching host allocator recycles the block
+                # once the tensor is dropped and the copies queued from it have completed)
+                lay = store.layout('images', trial) if hasattr(store, 'layout') else None
+                if lay is None:
+                    return None
+                if lay[0] != np.uint8:
+                    raise ValueError('images must be stored as uint8 (got %s)' % lay[0])
+                t = torch.empty(lay[1], dtype=torch.uint8, pin_memory=True)
+                store.read_into('images', trial, t.numpy())
+                return t
+        return _LazyTrials(ds, 'images', images, direct), labels
 
     def _extra_signals(self, sample, sess, trial):
         for signal, trials in self._extra[sess].items():

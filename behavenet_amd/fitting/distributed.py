@@ -46,15 +46,22 @@ def _loopback(addr):
     return addr in ('127.0.0.1', 'localhost', '::1')
 
 
-def init_from_env(backend=None, timeout_s=None):
+def init_from_env(backend=None, timeout_s=None, rendezvous_timeout_s=None):
     """Initialise the default process group from RANK/WORLD_SIZE/MASTER_* (torchrun env).
 
-    ``timeout_s`` (or env BN_DIST_TIMEOUT_S; default 600): how long the rendezvous and any later
-    collective may wait for a missing rank before it raises -- torch's default of 30 minutes turns
-    a rank that died into a job that hangs.  When the rendezvous address is the loopback interface
-    (one node: what ``torchrun --master-addr 127.0.0.1`` and bench.py use) gloo and the RCCL
-    bootstrap are pinned to ``lo`` unless the user chose an interface: both otherwise pick theirs
-    from the HOST NAME, which on a container need not resolve to anything reachable."""
+    Two time limits (one short limit for both aborted jobs whose rank 0 spent more than
+    ten minutes writing a checkpoint between two collectives):
+
+    * ``rendezvous_timeout_s`` (env BN_DIST_RDZV_TIMEOUT_S; default 120): how long the ranks wait
+      for each other at start-up.  A rank that never comes up (a GPU that is not there, a crashed
+      import) then fails the job within two minutes instead of torch's thirty.
+    * ``timeout_s`` (env BN_DIST_TIMEOUT_S; default 1800, torch's own): how long a collective may
+      wait for a missing rank.  ``bench.py --gpus N`` sets a short one for itself.
+
+    When the rendezvous address is the loopback interface (one node: what ``torchrun --master-addr
+    127.0.0.1`` and bench.py use) gloo and the RCCL bootstrap are pinned to ``lo`` unless the user
+    chose an interface: both otherwise pick theirs from the HOST NAME, which on a container need
+    not resolve to anything reachable."""
     if dist.is_initialized():
         return rank(), world_size()
     ws = int(os.environ.get('WORLD_SIZE', '1'))
@@ -72,11 +79,37 @@ def init_from_env(backend=None, timeout_s=None):
             'nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        # a collective that times out (or a peer that died) raises on this rank instead of
+        # leaving it spinning inside a kernel
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
     if timeout_s is None:
-        timeout_s = float(os.environ.get('BN_DIST_TIMEOUT_S', '600'))
+        timeout_s = float(os.environ.get('BN_DIST_TIMEOUT_S', '1800'))
+    if rendezvous_timeout_s is None:
+        rendezvous_timeout_s = float(os.environ.get('BN_DIST_RDZV_TIMEOUT_S', '120'))
     import datetime
-    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws,
+    r = int(os.environ['RANK'])
+    # the store (= the rendezvous) with its own, short limit.  Under torchrun the agent already
+    # serves a store on MASTER_PORT (TORCHELASTIC_USE_AGENT_STORE): every worker is a client of it,
+    # with a per-attempt key prefix, as torch's own env:// handler does
+    agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '') == 'True'
+    store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), ws,
+                          (r == 0) and not agent_store,
+                          timeout=datetime.timedelta(seconds=float(rendezvous_timeout_s)))
+    if agent_store:
+        store = dist.PrefixStore('/bn/attempt_%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'),
+                                 store)
+    dist.init_process_group(backend=backend, store=store, rank=r, world_size=ws,
                             timeout=datetime.timedelta(seconds=float(timeout_s)))
+    # everybody is here (waits at most the rendezvous limit: the store's)
+    store.add('bn_ranks_up', 1)
+    store.wait(['bn_ranks_up'])
+    import time
+    t_end = time.time() + float(rendezvous_timeout_s)
+    while int(store.add('bn_ranks_up', 0)) < ws:
+        if time.time() > t_end:
+            raise RuntimeError('rendezvous: %d of %d ranks came up within %.0f s' % (
+                int(store.add('bn_ranks_up', 0)), ws, float(rendezvous_timeout_s)))
+        time.sleep(0.01)
     return rank(), world_size()
 
 
@@ -384,7 +417,14 @@ def sharded_step(optimizer, average=False, divide_by=None):
     The update is element-wise, so the parameters come out as after the replicated step wherever
     the two reductions add the ranks' terms in the same order (two ranks: always).  Needs an
     optimizer built with ``shard_over == world_size()``; the moments of the other ranks' shards
-    are never touched on this rank."""
+    are never touched on this rank.
+
+    What a caller must know: after the step ``flat_g`` holds the reduced gradient in
+    THIS rank's shard only (the rest is this rank's local gradient, or what gloo's reduce left
+    there) -- gradient norms and the like must be taken before the step or over the owned shard;
+    and every rank holds 1/R of the Adam moments: ``gather_optimizer_state_`` makes them whole
+    before an optimizer checkpoint or a switch to the replicated step (``fit`` saves the model's
+    ``state_dict`` only, like the reference, training.py:390)."""
     if not is_active() or world_size() == 1 or _emulated is not None:
         reduce_gradients(optimizer, average=average)
         if divide_by is not None:
@@ -426,6 +466,44 @@ def sharded_step(optimizer, average=False, divide_by=None):
             for q, part in enumerate(parts):
                 qlo, qhi = optimizer.shard_range(q)
                 flat_p[qlo:qhi].copy_(part)
+
+
+def gather_optimizer_state_(optimizer):
+    """All-gather the Adam moments of a sharded optimizer so that every rank holds the whole state
+    (before saving it, or before continuing with replicated steps / another world size)."""
+    if not is_active() or world_size() == 1 or getattr(optimizer, 'shard_over', 1) == 1:
+        return optimizer
+    lo, hi = optimizer.shard_range(rank())
+    for arena in (optimizer.exp_avg, optimizer.exp_avg_sq, optimizer.max_exp_avg_sq):
+        if _backend() == 'nccl':
+            dist.all_gather_into_tensor(arena, arena[lo:hi].clone())
+        else:
+            staged = arena.is_cuda
+            mine = arena[lo:hi].detach().cpu() if staged else arena[lo:hi].detach().clone()
+            parts = [torch.empty_like(mine) for _ in range(world_size())]
+            dist.all_gather(parts, mine)
+            for q, part in enumerate(parts):
+                qlo, qhi = optimizer.shard_range(q)
+                arena[qlo:qhi].copy_(part)
+    return optimizer
+
+
+def default_shard_optimizer(world=None, mode=None):
+    """Is the sharded optimizer step (``sharded_step``) the default for this job?
+
+    ``BN_SHARD_OPTIMIZER=0/1`` decides when set.  Otherwise: ON for frame sharding ('frames') over
+    four or more ranks, OFF elsewhere.  Why there: a rank of an 8-rank frame-sharded step runs 32
+    frames in ~1 ms, of which the replicated Adam(amsgrad) -- 9 streams x 35 MB, 49 us, the same on
+    every rank whatever the shard -- is 4-5 %; on 1/R of the arena it is 6 us (R = 8), and the
+    backward pass of so small a shard is too short to hide the bucketed all-reduce behind anyway.
+    In 'trial' mode (one whole trial per rank, 4.4 ms steps) the overlapped all-reduce is hidden
+    completely and the all-gather behind a sharded step would be exposed: replicated stays."""
+    env = os.environ.get('BN_SHARD_OPTIMIZER')
+    if env is not None:
+        return env == '1'
+    world = world_size() if world is None else world
+    mode = shard_mode() if mode is None else mode
+    return mode == 'frames' and world >= 4
 
 
 def all_reduce_scalars(values):

@@ -17,11 +17,17 @@ import torch
 from behavenet_amd import _hip
 from behavenet_amd.fitting import distributed as bdist
 
-__all__ = ['export_latents', 'encode_trial']
+__all__ = ['export_latents', 'encode_trial', 'encode_trial_device']
 
 
 def encode_trial(model, y, sess=None, labels_2d=None, chunk_size=200):
     """Latents (T x D numpy) of one trial, encoded in 200-frame chunks (ref eval.py:51-97)."""
+    return encode_trial_device(model, y, sess, labels_2d, chunk_size).cpu().numpy()
+
+
+def encode_trial_device(model, y, sess=None, labels_2d=None, chunk_size=200):
+    """The same latents as a DEVICE tensor: nothing waits for the host (``export_latents`` keeps
+    the trials' latents on the device and fetches them once at the end)."""
     mc = model.hparams['model_class']
     if y.dtype == torch.uint8 and (labels_2d is not None or
                                    model.hparams.get('model_type', 'conv') != 'conv'):
@@ -46,7 +52,7 @@ def encode_trial(model, y, sess=None, labels_2d=None, chunk_size=200):
             if mc == 'cond-ae-msp':
                 cur = model.U(cur)
             parts.append(cur)
-    return torch.cat(parts, dim=0).cpu().numpy()
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
 
 def export_latents(data_generator, model, filename=None):
@@ -68,19 +74,57 @@ def export_latents(data_generator, model, filename=None):
     wanted = sorted((s_, int(t)) for s_, ds in enumerate(data_generator.datasets)
                     for dt in ('train', 'val', 'test') for t in ds.batch_idxs[dt])
     owner = {key: i % world for i, key in enumerate(wanted)}
-    for dtype in ['train', 'val', 'test']:
-        data_generator.reset_iterators(dtype)
-        n_batches = data_generator.n_tot_batches[dtype]
-        if single and dtype == 'train':      # the multi generator counts training ITERATIONS
-            n_batches = sum(ds.n_batches['train'] for ds in data_generator.datasets)
-        for _ in range(n_batches):
-            data, sess = data_generator.next_batch(dtype, **single)
-            idx = data['batch_idx']
-            idx = idx.item() if hasattr(idx, 'item') else int(idx)
-            if owner[(sess, idx)] != rank:
-                continue
-            labels_2d = data['labels_sc'][0] if cond_enc else None
-            latents[sess][idx] = encode_trial(model, data['images'][0], sess, labels_2d)
+    # generators that can be told to pass over a trial (this package's) are asked not to read,
+    # copy or convert the other ranks' trials -- round 4 fetched every trial on every rank -- and to
+    # hand out stored uint8 frames as they are (the first conv layer converts in flight)
+    import inspect
+    try:
+        can_skip = 'skip' in inspect.signature(data_generator.next_batch).parameters
+    except (TypeError, ValueError):
+        can_skip = False
+    skip = {'skip': (lambda s_, t_: owner.get((s_, int(t_)), rank) != rank)} \
+        if (can_skip and world > 1) else {}
+    conv_u8 = model.hparams.get('model_type', 'conv') == 'conv' and not cond_enc
+    serve_prev = getattr(data_generator, 'serve_uint8', None)
+    if serve_prev is not None and conv_u8:
+        data_generator.serve_uint8 = True
+    on_device = {}          # (session, trial) -> device tensor: ONE transfer to the host at the end
+    try:
+        for dtype in ['train', 'val', 'test']:
+            data_generator.reset_iterators(dtype)
+            n_batches = data_generator.n_tot_batches[dtype]
+            if single and dtype == 'train':      # the multi generator counts training ITERATIONS
+                n_batches = sum(ds.n_batches['train'] for ds in data_generator.datasets)
+            for _ in range(n_batches):
+                data, sess = data_generator.next_batch(dtype, **single, **skip)
+                if data is None:
+                    break
+                if not isinstance(data, dict):       # SKIPPED: another rank's trial
+                    continue
+                idx = data['batch_idx']
+                idx = idx.item() if hasattr(idx, 'item') else int(idx)
+                if owner[(sess, idx)] != rank:
+                    continue
+                labels_2d = data['labels_sc'][0] if cond_enc else None
+                images = data['images'][0]
+                if not torch.is_tensor(images):      # generators serving numpy arrays (as_numpy)
+                    images = torch.from_numpy(np.asarray(images))
+                if images.is_cuda:
+                    on_device[(sess, idx)] = encode_trial_device(model, images, sess, labels_2d)
+                else:
+                    latents[sess][idx] = encode_trial(model, images, sess, labels_2d)
+    finally:
+        if serve_prev is not None:
+            data_generator.serve_uint8 = serve_prev
+    if on_device:
+        keys = list(on_device)
+        flat = torch.cat([on_device[k] for k in keys], dim=0).cpu().numpy()
+        pos = 0
+        for k in keys:
+            n = on_device[k].shape[0]
+            latents[k[0]][k[1]] = flat[pos:pos + n].copy()
+            pos += n
+        del on_device
 
     if world > 1:
         import torch.distributed as dist

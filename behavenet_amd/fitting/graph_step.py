@@ -127,7 +127,12 @@ class GraphedLoss(object):
         rec.graph.replay()
         self.n_replays += 1
         d = rec.deferred
-        return LazyLoss([None if t is None else hf.Readback(t) for t in d.tensors], d.fn)
+        tensors = d.tensors
+        if d.reduce_over_ranks:
+            # frame-sharded step of real ranks: the recording holds this rank's chunk terms; their
+            # sum over ranks is the one collective of the step, issued here, behind the replay
+            tensors = [None if t is None else bdist.all_reduce_(t.clone()) for t in tensors]
+        return LazyLoss([None if t is None else hf.Readback(t) for t in tensors], d.fn)
 
     # ------------------------------------------------------------------------------------------
     def _record(self, key, data, dataset, accumulate_grad):

@@ -90,11 +90,11 @@ class FlatAdamAMSGrad(object):
         """One Adam(amsgrad) step of the arena elements [lo, hi) only (the update is element-wise: a
         range stepped alone gets bit for bit what a step of the whole arena gives it).  ``lo`` and
         ``hi`` must be multiples of 4 (16-byte groups)."""
+        if lo % _ALIGN or hi % _ALIGN:
+            raise ValueError('step_range: [%d, %d) is not 16-byte aligned' % (lo, hi))
         join_side_streams()   # weight gradients queued on the side stream are complete
         self._grads_in_arena()
         self.step_count += 1
-        if lo % _ALIGN or hi % _ALIGN:
-            raise ValueError('step_range: [%d, %d) is not 16-byte aligned' % (lo, hi))
         if self.flat_p.is_cuda:
             _hip.adam_amsgrad_step(
                 self.flat_p[lo:hi], self.flat_g[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],

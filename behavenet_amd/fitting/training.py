@@ -129,8 +129,31 @@ class EarlyStopping(object):
             self.stopped_epoch, self.should_stop = epoch, True
 
 
-def _snapshot(model, hparams):
-    """deepcopy with ``hparams`` detached, as the reference does (training.py:393-396)."""
+def _snapshot(model, hparams, into=None):
+    """The reference's ``copy.deepcopy`` of the model with ``hparams`` detached (training.py:393-396).
+
+    ``into``: the previous snapshot.  While it still has the model's tensors (same state-dict keys,
+    shapes, dtypes) it is REFRESHED -- one multi-tensor device copy, queued like any kernel, nothing
+    allocated, no module tree walked -- instead of being rebuilt: a fresh deepcopy costs a few
+    milliseconds of host time at a moment when the device has just run dry (the decision to take a
+    snapshot needs the validation loss on the host)."""
+    if into is not None:
+        src, dst = model.state_dict(), into.state_dict()
+        if list(src.keys()) == list(dst.keys()) and all(
+                a.shape == b.shape and a.dtype == b.dtype and a.device == b.device
+                for a, b in zip(src.values(), dst.values())):
+            with torch.no_grad():
+                torch._foreach_copy_([t for t in dst.values()], [t.detach() for t in src.values()])
+            for name in ('curr_epoch', 'version', 'training'):
+                if hasattr(model, name):
+                    try:
+                        setattr(into, name, getattr(model, name))
+                    except AttributeError:
+                        pass
+            if into.training != model.training:
+                into.train(model.training)
+            into.hparams = hparams
+            return into
     model.hparams = None
     snap = copy.deepcopy(model)
     model.hparams = hparams
@@ -138,12 +161,82 @@ def _snapshot(model, hparams):
     return snap
 
 
-def _save_checkpoint(model, path, is_main):
+class _CheckpointWriter(object):
+    """``model.save(path)`` without stalling the device: the state dict is copied device-side on
+    the compute stream (microseconds), brought to pinned host memory on a side stream, and pickled
+    to ``path`` by a background thread (written next to it, then renamed: a reader never sees a
+    half-written file).  The reference writes the same file synchronously
+    (training.py:388-397); nothing says the device has to wait for the disk.  ``wait()`` before
+    anybody reads the file; one write at a time per writer."""
+
+    def __init__(self):
+        self._thread = None
+        self._error = None
+        self._stream = None
+
+    def wait(self):
+        if self._thread is not None:
+            self._thread.join()
+            self._thread = None
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+
+    def save(self, model, path):
+        from behavenet_amd.models.base import BaseModel
+        state = model.state_dict()
+        plain = getattr(type(model), 'save', None) is BaseModel.save
+        if not plain or not any(t.is_cuda for t in state.values()):
+            # classes whose ``save`` does more than write the state dict (AEMSP), host models
+            self.wait()
+            model.save(path)
+            return
+        self.wait()
+        import threading
+        dev = next(t.device for t in state.values() if t.is_cuda)
+        main = torch.cuda.current_stream(dev)
+        with torch.no_grad():
+            frozen = {k: v.detach().clone() for k, v in state.items()}     # device-side, in stream order
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._stream.wait_event(ev)
+        host = {}
+        with torch.cuda.stream(self._stream):
+            for k, v in frozen.items():
+                if v.is_cuda:
+                    h = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                    h.copy_(v, non_blocking=True)
+                    v.record_stream(self._stream)
+                    host[k] = h
+                else:
+                    host[k] = v
+            done = torch.cuda.Event()
+            done.record(self._stream)
+
+        def write():
+            try:
+                done.synchronize()
+                tmp = '%s.tmp.%d' % (path, os.getpid())
+                # (plain, unpinned tensors in the file -- what the reference's checkpoints hold)
+                torch.save({k: v.clone() for k, v in host.items()}, tmp)
+                os.replace(tmp, path)
+            except BaseException as err:            # noqa: BLE001 (re-raised by wait())
+                self._error = err
+        self._thread = threading.Thread(target=write, name='bn-checkpoint', daemon=False)
+        self._thread.start()
+
+
+def _save_checkpoint(model, path, is_main, writer=None):
     """``model.save`` on the main rank.  Classes whose ``save`` also finalises derived state
     (AEMSP builds its orthogonal matrix U there, ref aes.py:1062-1065) do that on EVERY rank, so
     that the snapshots the other ranks keep (and export latents through) carry it too."""
     if is_main:
-        model.save(path)
+        if writer is not None:
+            writer.save(model, path)
+        else:
+            model.save(path)
     elif hasattr(model, 'create_orthogonal_matrix'):
         model.create_orthogonal_matrix()
 
@@ -194,11 +287,15 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
 
 
 def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
-    # hparams['shard_optimizer'] (BN_SHARD_OPTIMIZER=1): reduce-scatter -> Adam on this rank's 1/R
+    if hparams.get('dp_shard') is not None:
+        bdist.set_shard_mode(hparams['dp_shard'])
+    # hparams['shard_optimizer'] (BN_SHARD_OPTIMIZER=0/1): reduce-scatter -> Adam on this rank's 1/R
     # shard of the arena -> all-gather, instead of all-reduce + R identical steps
-    # (fitting/distributed.py sharded_step; off by default)
-    shard_opt = bool(hparams.get('shard_optimizer', os.environ.get('BN_SHARD_OPTIMIZER') == '1')) \
-        and bdist.is_active() and bdist.world_size() > 1
+    # (fitting/distributed.py sharded_step, default_shard_optimizer: on for frame sharding over >= 4 ranks)
+    shard_opt = hparams.get('shard_optimizer')
+    if shard_opt is None:
+        shard_opt = bdist.default_shard_optimizer()
+    shard_opt = bool(shard_opt) and bdist.is_active() and bdist.world_size() > 1
     if optimizer is None:
         from behavenet_amd.fitting.optim import FlatAdamAMSGrad
         optimizer = FlatAdamAMSGrad(
@@ -207,8 +304,6 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
             shard_over=bdist.world_size() if shard_opt else 1)
     shard_opt = shard_opt and getattr(optimizer, 'shard_over', 1) == bdist.world_size()
     flat_g = getattr(optimizer, 'flat_g', None)
-    if hparams.get('dp_shard') is not None:
-        bdist.set_shard_mode(hparams['dp_shard'])
     world = bdist.world_size() if bdist.is_active() else 1
     rank = bdist.rank()
     trial_mode = world > 1 and bdist.shard_mode() == 'trial'
@@ -257,6 +352,8 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
     best_val_epoch = None
     best_val_model = None
     best_model_saved = False
+    # checkpoints leave through a background writer unless hparams['async_checkpoint'] is False
+    writer = _CheckpointWriter() if hparams.get('async_checkpoint', True) else None
 
     if hparams.get('rng_seed_train', None) is None:
         rng_train = np.random.randint(0, 10000)
@@ -353,9 +450,10 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
 
                 if logger.get_loss('val') < best_val_loss:
                     best_val_loss = logger.get_loss('val')
-                    _save_checkpoint(model, os.path.join(expt_dir, 'best_val_model.pt'), is_main)
+                    _save_checkpoint(model, os.path.join(expt_dir, 'best_val_model.pt'), is_main,
+                                     writer)
                     best_model_saved = True
-                    best_val_model = _snapshot(model, hparams)
+                    best_val_model = _snapshot(model, hparams, into=best_val_model)
                     best_val_epoch = i_epoch
 
                 exp.log(logger.create_metric_row(
@@ -375,11 +473,11 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
                 break
 
     if not best_model_saved:
-        _save_checkpoint(model, os.path.join(expt_dir, 'best_val_model.pt'), is_main)
+        _save_checkpoint(model, os.path.join(expt_dir, 'best_val_model.pt'), is_main, writer)
         best_val_model = _snapshot(model, hparams)
 
     if hparams.get('save_last_model', False):
-        _save_checkpoint(model, os.path.join(expt_dir, 'last_model.pt'), is_main)
+        _save_checkpoint(model, os.path.join(expt_dir, 'last_model.pt'), is_main, writer)
 
     # test loss, one row per test trial.  NB the reference evaluates `model`, not
     # `best_val_model`, here (training.py:433,442) -- kept.
@@ -396,6 +494,8 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
         exp.log(logger.create_metric_row(
             'test', i_epoch, i_test, dataset, trial=trial, by_dataset=True))
     exp.save()
+    if writer is not None:
+        writer.wait()           # the checkpoint files are complete before fit() returns
 
     if method == 'ae' and hparams['export_latents']:
         if is_main:

@@ -344,18 +344,32 @@ def create_experiment(hparams):
         hparams, session_source=hparams.get('all_source', 'save'))
     hparams['expt_dir'] = get_expt_dir(hparams)
     version = None
+    failure = None
     if main:
-        if not os.path.isdir(hparams['session_dir']):
-            os.makedirs(hparams['session_dir'])
-            export_session_info_to_csv(hparams['session_dir'], sess_ids)
-        os.makedirs(hparams['expt_dir'], exist_ok=True)
-        if not experiment_exists(hparams):
-            exp = Experiment(name=hparams['experiment_name'], debug=False,
-                             save_dir=os.path.dirname(hparams['expt_dir']))
-            exp.save()
-            version = exp.version
+        try:
+            if not os.path.isdir(hparams['session_dir']):
+                os.makedirs(hparams['session_dir'])
+                export_session_info_to_csv(hparams['session_dir'], sess_ids)
+            os.makedirs(hparams['expt_dir'], exist_ok=True)
+            if not experiment_exists(hparams):
+                exp = Experiment(name=hparams['experiment_name'], debug=False,
+                                 save_dir=os.path.dirname(hparams['expt_dir']))
+                exp.save()
+                version = exp.version
+        except Exception as err:                     # noqa: BLE001 (re-raised below, on every rank)
+            if not dp:
+                raise
+            failure = err
     if dp:
-        version = bdist.broadcast_object(version, src=0)
+        # rank 0's failure travels with the version: the other ranks raise at once instead of
+        # sitting in the broadcast until the collective timeout
+        version, failed = bdist.broadcast_object(
+            (version, None if failure is None else '%s: %s' % (type(failure).__name__, failure)),
+            src=0)
+        if failure is not None:
+            raise failure
+        if failed is not None:
+            raise RuntimeError('create_experiment failed on rank 0 (%s)' % failed)
         if version is not None and not main:
             exp = Experiment(name=hparams['experiment_name'], debug=True, version=version,
                              save_dir=os.path.dirname(hparams['expt_dir']))

@@ -160,8 +160,11 @@ class DeferredLoss(object):
     """What ``model.loss`` returns while a step is being captured: the device tensors its
     read-backs would have copied and the host function that turns their values into the dict."""
 
-    def __init__(self, tensors, fn):
+    def __init__(self, tensors, fn, reduce_over_ranks=False):
         self.tensors, self.fn = tensors, fn
+        # the tensors are this rank's terms of a frame-sharded step: whoever replays the recording
+        # sums them over ranks (one collective behind the replay) before reading them back
+        self.reduce_over_ranks = bool(reduce_over_ranks)
 
 
 class LazyLoss(collections.abc.Mapping):
@@ -202,12 +205,14 @@ def set_lazy_losses(flag):
     return prev
 
 
-def finish_loss(readbacks, fn):
+def finish_loss(readbacks, fn, reduce_over_ranks=False):
     """``fn(*arrays)`` -> loss dict, with arrays = the values of `readbacks` (None entries stay
     None).  Eager: waits for the read-backs and calls `fn` (or hands out a LazyLoss that will, see
-    set_lazy_losses); under capture: defers both."""
+    set_lazy_losses); under capture: defers both.  ``reduce_over_ranks``: only read under capture --
+    the eager caller has summed its tensors over ranks already, a recording must not."""
     if _capturing:
-        return DeferredLoss([None if rb is None else rb.tensor for rb in readbacks], fn)
+        return DeferredLoss([None if rb is None else rb.tensor for rb in readbacks], fn,
+                            reduce_over_ranks)
     if _lazy_losses:
         return LazyLoss(readbacks, fn)
     return fn(*[None if rb is None else rb.numpy() for rb in readbacks])

@@ -550,12 +550,13 @@ class AE(BaseModel):
 
     def graph_capturable_for(self, x):
         # (batch norm with momentum=None reads its batch counter on the host for the cumulative
-        # average factor: not recordable; a frame-sharded step of REAL ranks issues collectives from
-        # inside `loss` -- the per-chunk loss table, and a rank with an empty shard takes another
-        # branch than the ones that record -- so it runs eagerly: every rank then issues the same
-        # sequence at the same points)
+        # average factor: not recordable.  A frame-sharded step of REAL ranks is recordable since
+        # round 5 -- its one collective, the per-chunk loss table, is issued behind the replay --
+        # unless a rank could end up without frames: that rank takes another branch than the ones
+        # that record, so the decision is taken from what every rank knows, the batch size)
         from behavenet_amd.fitting import distributed as bdist
-        if bdist.frames_sharded() and bdist._emulated is None:
+        if bdist.frames_sharded() and bdist._emulated is None and \
+                x.shape[0] < bdist.world_size():
             return False
         return self._whole_batch_ok(x) and not (
             self.hparams.get('ae_batch_norm', False) and
@@ -679,25 +680,30 @@ class AE(BaseModel):
                                     'chunk_sizes': sizes},
                         **fwd_kwargs)
                 chunk_losses = losses.mse_chunks(x, x_hat, m, bounds_l, sizes)
-            # (under graph capture the ranks' chunk terms are added on the host instead: no
-            # collective inside the recorded step)
-            totals = chunk_losses.detach() if capturing() else \
-                bdist.all_reduce_(chunk_losses.detach().clone())
         else:       # more ranks than frames: nothing local, but the collectives still line up
             chunk_losses = None
-            totals = bdist.all_reduce_(torch.zeros(len(bounds), device=x.device))
-        vals = Readback(totals)
+        sharded = local != bounds
+        local_vals = chunk_losses.detach() if chunk_losses is not None else \
+            torch.zeros(len(bounds), device=x.device)
+        # one device: the read-back of the chunk terms is queued in front of the backward pass
+        # (a caller that looks at the value waits for the forward pass only)
+        vals = None if sharded else Readback(local_vals)
         if accumulate_grad and chunk_losses is not None:
             backward_chunks([chunk_losses], single_pass=True)
         join_side_streams()
-        host_sum = capturing() and local != bounds
+        if sharded:
+            # The ranks' chunk terms are summed by ONE collective BEHIND the backward pass (it used
+            # to sit between the forward and the backward pass: a launch gap on every rank, and a
+            # step that could not be recorded into a HIP graph).  Under capture the collective is
+            # left to the caller: graph_step.GraphedLoss issues it after every replay on the
+            # recorded tensor (DeferredLoss.reduce_over_ranks) -- a recorded step contains no
+            # collective at all.
+            vals = Readback(local_vals if capturing() else bdist.all_reduce_(local_vals.clone()))
 
         def to_dict(v):
             v = v.astype(np.float64)
-            if host_sum:
-                v = np.asarray(bdist.all_reduce_scalars(v.tolist()), dtype=np.float64)
             return {'loss': float(np.sum(v * np.asarray(sizes, dtype=np.float64)) / batch_size)}
-        return finish_loss([vals], to_dict)
+        return finish_loss([vals], to_dict, reduce_over_ranks=sharded)
 
     def _chunk_streams_ok(self):
         """Chunks may run on two HIP streams unless a layer accumulates outside the weight-

@@ -48,6 +48,7 @@ from behavenet_amd.fitting.optim import FlatAdamAMSGrad  # noqa: E402
 from behavenet_amd.models import AE  # noqa: E402
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch  # noqa: E402
 
+METRIC = 'AE training frames/sec (128x128x1, batch 256)'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
 DIM = [1, 128, 128]
@@ -97,7 +98,7 @@ def one_step(model, opt, gen):
 def cpu_baseline(hp_template, budget_s=20.0):
     """Time the CPU oracle on the same workload (bounded sample) on this host's cores."""
     from oracle import ref_cpu
-    from tests.golden_utils import make_frames
+    from behavenet_amd.data.synthetic import make_frames
     from behavenet_amd.hostinfo import limit_host_threads, usable_cpus
     # threads = the CPUs this container may use (cgroup quota), not the machine's core count:
     # torch's default of 128 threads on a 16-CPU quota ran this baseline ~4 x slower (round 3's
@@ -144,7 +145,7 @@ def secondary_configs(hp_ae, feed_rates=True):
     workload (pinned uint8 trials prefetched per batch).  Same synthetic data recipe, same
     timing brackets (synchronize on both sides) as the headline."""
     from behavenet_amd.models import PSVAE
-    from tests.golden_utils import base_hparams, make_frames, make_labels
+    from behavenet_amd.data.synthetic import base_hparams, make_frames, make_labels
     out = []
     # --- configs[3]: PS-VAE, 2x128x128, 16 latents, 4 labels, batch 256
     dim4 = [2, 128, 128]
@@ -196,6 +197,7 @@ def secondary_configs(hp_ae, feed_rates=True):
                              'frac': round(0.3474e9 * BATCH / t5 / 1e12 / FP32_PEAK_TFLOPS, 4),
                              'note': 'encoder forward, algorithmic 0.3474 GFLOP/frame'}})
     del ae
+    out.append(export_latents_throughput(hp_ae))
     # --- the product entry point itself: fit() on the headline workload
     out.append(fit_throughput(hp_ae))
     # --- geometries OFF the benchmark's fast paths (their cost was never measured)
@@ -299,11 +301,72 @@ def fit_throughput(hp_ae, n_epochs=2):
     shutil.rmtree(tmp, ignore_errors=True)
     return {'config': 'configs[1] through the product entry point fit(): epoch 0 + %d epochs over %d '
                       'train / %d val / %d test trials of 256 frames (resident float32), validation '
-                      'after every epoch, metric rows, best-model snapshot (deepcopy), test rows'
+                      'after every epoch, metric rows, best-model snapshot (device-side refresh) and best_val_model.pt (background writer), test rows'
                       % (n_epochs, n['train'], n['val'], n['test']),
             'value': round(trials * BATCH / dt, 1), 'unit': 'frames/s (train + val + test trials)',
             'seconds': round(dt, 4), 'trials_through_the_model': trials, 'metric_rows': rows,
             'ms_per_trial': round(dt * 1e3 / trials, 3)}
+
+
+def export_latents_throughput(hp_ae, n_trials=2048):
+    """BASELINE configs[4] through the product entry point: ``export_latents()`` (reference
+    fitting/eval.py:6-118) over a FILE-BACKED session -- ``n_trials`` trials of 256 uint8 frames in a
+    ``data.npz`` trial store (the mirror of the reference's ``data.hdf5``, one member per trial) ->
+    ``ConcatSessionsGenerator`` (pinned uint8, reader threads, one-trial-ahead device copy) -> encoder
+    (uint8 -> float fused into enc.conv0) -> latents kept on the device -> one transfer -> the pickle the
+    ARHMM stage reads.  Timed end to end: generator iteration, file reads, H2D copies, encode, D2H, pickle."""
+    import pickle
+    import shutil
+    import tempfile
+    from behavenet_amd.data.data_generator import ConcatSessionsGenerator
+    from behavenet_amd.data.synthetic import make_frames_u8
+    from behavenet_amd.data.trial_store import write_npz_session
+    from behavenet_amd.fitting.eval import export_latents
+    tmp = tempfile.mkdtemp(prefix='bn_export_', dir='/tmp')
+    try:
+        ids = {'lab': 'lab', 'expt': 'expt', 'animal': 'animal', 'session': 'sess'}
+        sess_dir = os.path.join(tmp, 'lab', 'expt', 'animal', 'sess')
+        os.makedirs(sess_dir)
+        # (the frames' content does not matter for the rate: 64 distinct noise trials, written n_trials / 64 times)
+        block = [make_frames_u8(BATCH, DIM, seed=1000 + i) for i in range(64)]
+        t_w = time.perf_counter()
+        write_npz_session(os.path.join(sess_dir, 'data.npz'),
+                          {'images': [block[i % 64] for i in range(n_trials)]})
+        t_w = time.perf_counter() - t_w
+        gen = ConcatSessionsGenerator(tmp, [ids], signals_list=[['images']], transforms_list=[[None]],
+                                      paths_list=[[os.path.join(sess_dir, 'data.npz')]], device='cuda',
+                                      placement='host_u8', keep_in_memory=False)
+        hp = dict(hp_ae)
+        hp.update({'expt_dir': tmp, 'device': 'cuda'})
+        torch.manual_seed(0)
+        ae = AE(hp).to('cuda')
+        ae.version = 0
+        out_file = os.path.join(tmp, 'latents.pkl')
+
+        def run():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):
+                export_latents(gen, ae, filename=out_file)
+            return time.perf_counter() - t0
+        run()                                   # (page cache, allocator pools, reader threads)
+        dt = run()
+        with open(out_file, 'rb') as f:
+            got = pickle.load(f)
+        n_done = sum(1 for a in got['latents'] if a.shape == (BATCH, N_LATENTS))
+        frames = n_done * BATCH
+        return {'config': 'configs[4] through the product entry point export_latents(): %d trials of 256 uint8 '
+                          'frames (1x128x128) from a data.npz trial store on local disk (page cache warm: second '
+                          'pass) -> ConcatSessionsGenerator (pinned uint8, 3 reader threads, device copy one trial '
+                          'ahead) -> encoder -> latents on the device -> one D2H -> *_latents.pkl' % n_trials,
+                'value': round(frames / dt, 1), 'unit': 'frames/s', 'seconds': round(dt, 3),
+                'trials_encoded': n_done, 'ms_per_trial': round(dt * 1e3 / max(n_done, 1), 3),
+                'seconds_per_1M_frames': round(1e6 * dt / max(frames, 1), 2),
+                'store_bytes': os.path.getsize(os.path.join(sess_dir, 'data.npz')),
+                'store_write_seconds': round(t_w, 2)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def live_hbm_traffic(kernel_substr='k_down_c1p', timeout_s=150):
@@ -352,7 +415,7 @@ def live_hbm_traffic(kernel_substr='k_down_c1p', timeout_s=150):
 def geometry_step(arch_json, dim, label, batch=256, names=True, extra=None):
     """Training step of an architecture / frame size the specialised kernels were NOT tuned for:
     ms per step and, layer by layer and role by role, the kernel the dispatch chose."""
-    from tests.golden_utils import base_hparams, make_frames
+    from behavenet_amd.data.synthetic import base_hparams, make_frames
     arch = load_handcrafted_arch(list(dim), N_LATENTS, arch_json, check_memory=False)
     hp = base_hparams(arch, 'ae', dict(extra) if extra else None)
     hp['device'] = 'cuda'
@@ -423,10 +486,37 @@ def profile_kernel(model, opt, gen, family, C, K, steps=2):
     return ms, n, name, main_ms, main_n
 
 
-def self_launch(n_gpus):
-    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N
-    processes on this node (rendezvous on 127.0.0.1, a free port), same arguments."""
+def error_line(message, **extra):
+    """The one JSON line of a run that failed: same metric name, no value, an ``error`` string."""
+    out = {'metric': METRIC, 'value': None, 'unit': 'frames/s', 'error': str(message)[:2000]}
+    out.update(extra)
+    return json.dumps(out)
+
+
+def first_to_report():
+    """Several ranks may notice a failure: the first one to claim the job's marker file prints the line."""
+    path = os.path.join('/tmp', 'bn_bench_error_%s_%s' % (os.environ.get('MASTER_PORT', '0'),
+                                                          os.getppid()))
+    try:
+        os.close(os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY))
+        return True
+    except OSError:
+        return False
+
+
+def self_launch(n_gpus, limit_s):
+    """`python bench.py --gpus N` without a launcher: run `torch.distributed.run` with N processes
+    on this node (rendezvous on 127.0.0.1, a free port, same arguments) as a supervised child:
+    its output is passed through, and if it ends without the JSON line (a rank died, a collective
+    timed out and the launcher tore the job down, the whole thing exceeded ``limit_s``) ONE line
+    with an ``error`` field is printed and the exit status is non-zero -- never a hang."""
     import socket
+    import subprocess
+    import threading
+    if torch.cuda.device_count() < n_gpus and os.environ.get('BN_DIST_BACKEND') != 'gloo':
+        print(error_line('--gpus %d but this node shows %d GPU(s)' % (n_gpus, torch.cuda.device_count()),
+                         n_gpus=n_gpus))
+        raise SystemExit(2)
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
@@ -439,7 +529,60 @@ def self_launch(n_gpus):
            os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     sys.stderr.flush()
-    os.execvpe(sys.executable, cmd, env)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    seen = {'line': False}
+
+    def pump():
+        for line in child.stdout:
+            if line.startswith('{') and '"metric"' in line:
+                seen['line'] = True
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        rc = child.wait(timeout=limit_s)
+        why = 'the launcher exited with status %d' % rc
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(child.pid, signal.SIGKILL)        # (its own session: the launcher and all ranks)
+        child.wait()
+        rc, why = 124, 'no result within %d s: job killed' % limit_s
+    t.join(timeout=5)
+    if not seen['line']:
+        print(error_line('%d-rank run produced no result line (%s)' % (n_gpus, why), n_gpus=n_gpus))
+        rc = rc or 1
+    raise SystemExit(rc)
+
+
+class Watchdog(object):
+    """A rank that makes no progress for ``limit_s`` prints the error line and leaves (os._exit: a
+    rank stuck inside a collective cannot raise).  ``pet()`` at every phase boundary / every few steps."""
+
+    def __init__(self, limit_s, rank, world):
+        import threading
+        self.limit_s, self.rank, self.world = float(limit_s), rank, world
+        self._last, self._where = time.monotonic(), 'start'
+        self._stop = False
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def pet(self, where):
+        self._last, self._where = time.monotonic(), where
+
+    def stop(self):
+        self._stop = True
+
+    def _run(self):
+        while not self._stop:
+            time.sleep(1.0)
+            idle = time.monotonic() - self._last
+            if idle > self.limit_s and not self._stop:
+                if first_to_report():
+                    print(error_line('rank %d of %d made no progress for %.0f s in phase "%s" (a peer died or a '
+                                     'collective hangs)' % (self.rank, self.world, idle, self._where),
+                                     n_gpus=self.world, rank=self.rank), flush=True)
+                os._exit(3)
 
 
 def measure_allreduce(opt, iters=10):
@@ -483,14 +626,39 @@ def main():
                     help="where the trials live (default 'device': resident float32, the headline "
                          "metric; 'host_u8' = pinned uint8 + prefetch, the PCIe-inclusive rate)")
     ap.add_argument('--cpu-budget', type=float, default=20.0)
-    ap.add_argument('--shard-optimizer', action='store_true',
+    ap.add_argument('--shard-optimizer', dest='shard_optimizer', action='store_true', default=None,
                     help='N > 1: reduce-scatter -> Adam on 1/N of the arena per rank -> all-gather, instead '
-                         'of the overlapped bucketed all-reduce + N identical steps')
+                         'of the overlapped bucketed all-reduce + N identical steps (default: on for '
+                         '--shard frames with N >= 4, fitting/distributed.py default_shard_optimizer)')
+    ap.add_argument('--no-shard-optimizer', dest='shard_optimizer', action='store_false')
+    ap.add_argument('--time-limit', type=float, default=float(os.environ.get('BN_BENCH_TIME_LIMIT_S', '1500')),
+                    help='N > 1, self-launched: the whole job is killed (and an error line printed) after this many seconds')
     ap.add_argument('--shard', default='trial', choices=['trial', 'frames'],
                     help="N > 1: 'trial' = one 256-frame trial per rank per step (weak scaling), "
                          "'frames' = the ranks share ONE trial, each takes its slice of every "
                          "200-frame chunk (strong scaling, parity-exact)")
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False')
+        self_launch(args.gpus, args.time_limit)          # does not return
+    try:
+        run(args)
+    except SystemExit:
+        raise
+    except BaseException as err:                         # noqa: BLE001 (reported as the JSON line, then re-raised)
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get('WORLD_SIZE', '1')) == 1 or first_to_report():
+            print(error_line('%s: %s' % (type(err).__name__, err), n_gpus=args.gpus,
+                             rank=int(os.environ.get('RANK', '0'))), flush=True)
+        # (os._exit: a process group whose peer is gone can hang in its destructor)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
+
+
+def run(args):
     # the product's fit() hands loss dicts to its logger unresolved (hip_functions.set_lazy_losses): the host queues
     # step k + 1 without waiting for the forward pass of step k.  BN_BENCH_LAZY=0: the plain dict (one event wait per step)
     from behavenet_amd import hip_functions as _hf
@@ -498,26 +666,68 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: torch.cuda.is_available() is False')
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        self_launch(args.gpus)          # does not return
+    n_env = int(os.environ.get('WORLD_SIZE', '1'))
+    gloo_test = os.environ.get('BN_DIST_BACKEND') == 'gloo'
+    if n_env > 1:
+        # fail in seconds, with a line, not in half an hour: short limits for the rendezvous and for
+        # every collective of this short job (a user's BN_DIST_* settings win), errors of the
+        # collective library raised instead of swallowed
+        os.environ.setdefault('BN_DIST_RDZV_TIMEOUT_S', '120')
+        os.environ.setdefault('BN_DIST_TIMEOUT_S', '120')
+        os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        if not gloo_test and torch.cuda.device_count() <= local:
+            raise RuntimeError('LOCAL_RANK %d but this node shows %d GPU(s): --gpus %d needs one GPU per rank'
+                               % (local, torch.cuda.device_count(), args.gpus))
     rank, world = bdist.init_from_env()
     if world != max(1, args.gpus):
-        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+        raise RuntimeError('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    dog = Watchdog(float(os.environ.get('BN_BENCH_WATCHDOG_S', '150')), rank, world) if world > 1 else None
+    if world > 1:
+        # the launcher stops the surviving ranks with SIGTERM when one of them has died: the first of
+        # them to get here says so in the line before it goes
+        import signal
+
+        def on_term(signum, frame):
+            if first_to_report():
+                print(error_line('rank %d of %d was stopped by the launcher (SIGTERM): another rank died or '
+                                 'timed out' % (rank, world), n_gpus=world, rank=rank), flush=True)
+            os._exit(1)
+        signal.signal(signal.SIGTERM, on_term)
+
+    def pet(where):
+        if dog is not None:
+            dog.pet(where)
     global _AVERAGE
     strong = world > 1 and args.shard == 'frames'
     if world > 1:
         bdist.set_shard_mode(args.shard)
         _AVERAGE = not strong
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if os.environ.get('BN_DIST_BACKEND') == 'gloo':
+    if gloo_test:
         local = 0           # control-flow test of the N > 1 path: all ranks share the one GPU
     torch.cuda.set_device(local)
     _hip.load()
+    devices = None
+    if bdist.is_active():
+        # one GPU per rank, and not the same one twice (the PCI bus id tells boards apart whatever
+        # HIP_VISIBLE_DEVICES did to the ordinals)
+        props = torch.cuda.get_device_properties(local)
+        mine = {'rank': rank, 'local_rank': int(os.environ.get('LOCAL_RANK', '0')), 'device': local,
+                'name': props.name, 'pci': getattr(props, 'pci_bus_id', None),
+                'uuid': str(getattr(props, 'uuid', ''))}
+        devices = [None] * world
+        torch.distributed.all_gather_object(devices, mine)
+        ids = [(d['device'], d['uuid'] or d['pci']) for d in devices]
+        if not gloo_test and len(set(ids)) != world:
+            raise RuntimeError('ranks share a GPU: %s' % devices)
+    pet('model')
 
     hp = build_hparams()
     torch.manual_seed(hp['rng_seed_model'])
     model = AE(hp).to('cuda')
-    shard_opt = args.shard_optimizer and world > 1
+    shard_default = bdist.default_shard_optimizer(world, args.shard)
+    shard_opt = (shard_default if args.shard_optimizer is None else args.shard_optimizer) and world > 1
     opt = FlatAdamAMSGrad(model.get_parameters(), lr=hp['learning_rate'],
                           weight_decay=hp['l2_reg'], shard_over=world if shard_opt else 1)
     bdist.broadcast_parameters_(opt.flat_p)
@@ -543,9 +753,13 @@ def main():
     # ranks' steps are collective.
     # BN_BENCH_PRIME=<count>: exactly that many (tests that compare the training trajectories of runs).
     fixed = os.environ.get('BN_BENCH_PRIME')
+    primed = 0
     if fixed is not None or bdist.is_active():
         for _ in range(int(fixed) if fixed is not None else PRIME_STEPS + 16):
             one_step(model, opt, gen)
+            primed += 1
+            if primed % 8 == 0:
+                pet('priming')
     else:
         best, streak, done = float('inf'), 0, 0
         while done < PRIME_MAX:
@@ -560,6 +774,7 @@ def main():
             best = min(best, dt)
             if done >= PRIME_STEPS and streak >= 2:
                 break
+        primed = done
 
     def barrier():
         if bdist.is_active():
@@ -572,6 +787,53 @@ def main():
     # Measure both (all ranks agree on the max over ranks) and keep the faster one.
     allreduce_mode = None
     reducer = getattr(opt, 'reducer', None)
+    pet('setup')
+    extra_untimed = 0
+    # N > 1: what ONE GPU of this job does on its own -- every rank runs the unsharded 256-frame step
+    # without any exchange, all ranks at the same time (so the node's power / thermal state is the
+    # job's), parameters and optimizer state put back afterwards.  This is the N = 1 figure the
+    # scaling curve is measured against, taken on the same boxes in the same process.
+    single_ref = None
+    if bdist.is_active():
+        keep = [t.clone() for t in (opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.max_exp_avg_sq)]
+        keep_count = opt.step_count
+        prev_mode = bdist.set_shard_mode('trial')
+
+        # (its own noise trial: the generator's position, hence the job's trajectory, is untouched)
+        ref_data = {'images': torch.rand((1, BATCH) + tuple(DIM), device='cuda')}
+
+        def local_step():
+            opt.zero_grad()
+            with bdist.emulate_rank(0, 1):          # collectives are identities in here
+                model.loss(ref_data, dataset=0, accumulate_grad=True)
+            opt.step()
+        if reducer is not None:
+            reducer.overlap = False
+        for _ in range(5):
+            local_step()
+        barrier()
+        t_l = time.perf_counter()
+        for _ in range(10):
+            local_step()
+        torch.cuda.synchronize()
+        mine_ms = (time.perf_counter() - t_l) / 10 * 1e3
+        barrier()
+        every = [None] * world
+        torch.distributed.all_gather_object(every, round(mine_ms, 3))
+        single_ref = {'ms_per_step_per_rank': every, 'ms_per_step_max': max(every),
+                      'frames_per_s_one_gpu': round(BATCH / (max(every) * 1e-3), 1),
+                      'what': 'the unsharded 256-frame step (no gradient exchange) run by every rank at the same '
+                              'time, 10 steps after 5: the N = 1 reference of this node inside this job'}
+        bdist.set_shard_mode(prev_mode)
+        with torch.no_grad():
+            for dst, src in zip((opt.flat_p, opt.exp_avg, opt.exp_avg_sq, opt.max_exp_avg_sq), keep):
+                dst.copy_(src)
+        opt.step_count = keep_count
+        del keep, ref_data
+        if reducer is not None:
+            reducer.overlap = True
+        extra_untimed += 15
+        pet('overlap probe')
     if bdist.is_active() and reducer is not None and os.environ.get('BN_OVERLAP_ALLREDUCE') is None:
         timing = {}
         for mode in (True, False):
@@ -579,10 +841,12 @@ def main():
             for _ in range(3):
                 one_step(model, opt, gen)
             barrier()
+            pet('overlap probe')
             t_a = time.perf_counter()
             for _ in range(8):
                 one_step(model, opt, gen)
             barrier()
+            extra_untimed += 11
             tt = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64,
                               device='cpu' if torch.distributed.get_backend() == 'gloo' else 'cuda')
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -605,9 +869,20 @@ def main():
             'gradient_bytes': int(opt.flat_g.numel() * 4),
             'bucket_bytes': [int((hi - lo) * 4) for lo, hi, _ in reducer.buckets]
             if reducer is not None else [int(opt.flat_g.numel() * 4)],
-            'allreduce_alone_ms': round(measure_allreduce(opt), 3)})
+            'allreduce_alone_ms': round(measure_allreduce(opt), 3),
+            'shard_optimizer': bool(shard_opt),
+            'shard_optimizer_decision': (
+                'default for --shard %s at N = %d (fitting/distributed.py default_shard_optimizer): %s'
+                % (args.shard, world, 'on' if shard_default else 'off')
+                if args.shard_optimizer is None else 'command line: %s' % ('on' if shard_opt else 'off')),
+            'devices': devices, 'single_gpu_reference': single_ref})
+    pet('warm-up')
     for _ in range(args.warmup):
         one_step(model, opt, gen)
+    # test hook (tests/test_gpu_sharding.py): BN_BENCH_FAULT='<rank>:<step>' -- that rank dies without
+    # a word in front of that timed step; the job must end with an error line, not hang
+    fault = os.environ.get('BN_BENCH_FAULT')
+    fault = tuple(int(v) for v in fault.split(':')) if fault else None
 
     if os.environ.get('BN_BENCH_NOHOOK') != '1':
         _hip.prof_set_bracket(False)                    # dispatch-attached events only
@@ -620,11 +895,16 @@ def main():
         global _PARTS
         _PARTS = []
         ms0 = torch.cuda.memory_stats()
-    for _ in range(args.steps):
+    for i_step in range(args.steps):
+        if fault is not None and fault == (rank, i_step):
+            os._exit(9)
         last = one_step(model, opt, gen)
         trace.append(time.perf_counter())
+        if dog is not None and (i_step & 7) == 7:
+            pet('timed steps')
     barrier()
     elapsed = time.perf_counter() - t0
+    pet('report')
     if os.environ.get('BN_BENCH_TRACE') == '1' and rank == 0:
         print('host ms per step: ' + ' '.join(
             '%.2f' % ((b - a) * 1e3) for a, b in zip([t0] + trace[:-1], trace)) +
@@ -691,9 +971,12 @@ def main():
             50, torch.cuda.current_stream().cuda_stream)), 2)}
 
     out = {
-        'metric': 'AE training frames/sec (128x128x1, batch 256)',
+        'metric': METRIC,
         'value': round(value, 1), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+        # untimed steps in front of the W warm-up steps (setup: runtime priming in blocks of 8 until the step
+        # time is steady, and for N > 1 the single-GPU reference and the overlapped-vs-behind probe)
+        'priming_steps': primed, 'other_untimed_steps': extra_untimed,
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
@@ -797,7 +1080,9 @@ def main():
             out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if dog is not None:
+        dog.stop()
     if bdist.is_active():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -459,3 +459,36 @@ def test_bench_two_ranks_frame_sharded(tmp_path):
     # same model seed, same trials, same order: after 24 + 1 + 4 steps the two-rank trajectory
     # reports the single-device loss (Adam on rounding-level gradient differences: 1e-4)
     assert d2['final_loss'] == pytest.approx(d1['final_loss'], rel=1e-4)
+
+
+@pytest.mark.parametrize('launcher', ['torchrun', 'self'])
+def test_bench_rank_dies_mid_run_error_line(launcher, tmp_path):
+    """the first real N > 1 run happens on the driver's box -- if a rank dies in
+    the middle of the timed steps (BN_BENCH_FAULT: rank 1 leaves without a word in front of timed
+    step 2) the job must END, non-zero, with ONE JSON line that carries an `error` field, within
+    180 s -- not hang in a collective."""
+    import time
+    env = _child_env(BN_DIST_BACKEND='gloo', BN_BENCH_FAULT='1:2', BN_BENCH_WATCHDOG_S='60',
+                     BN_DIST_TIMEOUT_S='60')
+    tail = [os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '1',
+            '--no-cpu-baseline', '--no-secondary']
+    if launcher == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
+    t0 = time.time()
+    proc = subprocess.Popen(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            text=True, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=180)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)
+        proc.communicate()
+        pytest.fail('bench.py --gpus 2 with a dead rank was still running after 180 s')
+    assert proc.returncode != 0, out[-2000:]
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith('{') and '"metric"' in l]
+    assert len(lines) == 1, (out[-3000:], err[-3000:])
+    assert lines[0].get('error') and lines[0]['value'] is None
+    assert time.time() - t0 < 180

@@ -8,7 +8,7 @@ import torch
 from behavenet_amd.models import AE, ConditionalAE, AEMSP, VAE, ConditionalVAE, BetaTCVAE, PSVAE
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
-from tests.golden_utils import base_hparams, make_frames, make_labels
+from behavenet_amd.data.synthetic import base_hparams, make_frames, make_labels
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B, DIM = 256, [1, 128, 128]

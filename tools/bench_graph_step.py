@@ -12,7 +12,7 @@ from behavenet_amd.models.ae_model_architecture_generator import load_handcrafte
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
 from behavenet_amd.fitting.graph_step import GraphedLoss
 from behavenet_amd.fitting import distributed as bdist
-from tests.golden_utils import base_hparams, make_frames
+from behavenet_amd.data.synthetic import base_hparams, make_frames
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 
@@ -51,8 +51,8 @@ def run(label, dim, batch, shard=None, extra=None):
             if ctx:
                 ctx.__exit__(None, None, None)
                 bdist.set_shard_mode(prev)
-        if graphed:
-            assert fn.n_replays >= steps, (fn.n_replays, fn.n_eager)
+        if graphed and fn.n_replays < steps:
+            label += ' [NOT recorded: %d eager]' % fn.n_eager
     print('%-44s eager %7.3f ms   graph %7.3f ms   (%.2fx)' % (label, out[0], out[1], out[0] / out[1]))
 
 

@@ -7,7 +7,7 @@ import torch
 from behavenet_amd.models import PSVAE
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
-from tests.golden_utils import base_hparams, make_frames, make_labels
+from behavenet_amd.data.synthetic import base_hparams, make_frames, make_labels
 
 B = 256
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20

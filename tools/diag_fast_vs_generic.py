@@ -7,7 +7,7 @@ from behavenet_amd import _hip
 from behavenet_amd import hip_functions
 from behavenet_amd.models import AE
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
-from tests.golden_utils import base_hparams
+from behavenet_amd.data.synthetic import base_hparams
 js = sys.argv[1]; n = int(sys.argv[2])
 arch = load_handcrafted_arch([1, 128, 128], 12, js, check_memory=False)
 torch.manual_seed(0); hip = AE(base_hparams(arch, 'ae', None)).to('cuda')

@@ -10,7 +10,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch  # noqa: E402
 from oracle import ref_cpu  # noqa: E402
-from tests.golden_utils import base_hparams, make_frames  # noqa: E402
+from behavenet_amd.data.synthetic import base_hparams, make_frames  # noqa: E402
 
 
 def run(dim, n_lat, batch, dtype):

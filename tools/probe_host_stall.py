@@ -7,7 +7,7 @@ from behavenet_amd import hip_functions as hf
 from behavenet_amd.models import AE
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
-from tests.golden_utils import base_hparams, make_frames
+from behavenet_amd.data.synthetic import base_hparams, make_frames
 
 stall = float(sys.argv[1]) / 1e3 if len(sys.argv) > 1 else 0.008
 arch = load_handcrafted_arch([1, 128, 128], 12, None, check_memory=False)

@@ -5,7 +5,7 @@ import torch
 from behavenet_amd.models import AE
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
-from tests.golden_utils import base_hparams, make_frames
+from behavenet_amd.data.synthetic import base_hparams, make_frames
 
 js = sys.argv[1]
 C, H, W, B = [int(v) for v in sys.argv[2:6]]

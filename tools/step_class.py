@@ -7,7 +7,7 @@ import torch
 from behavenet_amd.models import AE, VAE
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
-from tests.golden_utils import base_hparams, make_frames
+from behavenet_amd.data.synthetic import base_hparams, make_frames
 
 cls = {'ae': AE, 'vae': VAE}[sys.argv[1]]
 bn = len(sys.argv) > 2 and sys.argv[2] == 'bn'

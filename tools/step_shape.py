@@ -8,7 +8,7 @@ from behavenet_amd.models import AE
 from behavenet_amd.models.ae_model_architecture_generator import load_handcrafted_arch
 from behavenet_amd.fitting.optim import FlatAdamAMSGrad
 from behavenet_amd.fitting import distributed as bdist
-from tests.golden_utils import base_hparams, make_frames
+from behavenet_amd.data.synthetic import base_hparams, make_frames
 
 C, H, W, B = [int(v) for v in sys.argv[1:5]]
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
