@@ -103,6 +103,20 @@ bool bn_qg2_wgrad_supported(const BnGeom& g);
 int bn_launch_qg2_wgrad(const float* small, const float* big, float* dw, const BnGeom& g,
                         int accumulate, float* db, int bias_side, hipStream_t st);
 
+// conv_s5win.hip: stride == kernel (5x5 s5) between ANY pair of maps whose windows tile the big one: one dense
+// GEMM per window over the taps that fall on the map (down, up), one GEMM over (frame, window) for the weight
+// gradient; operands gathered from the NCHW tensors, no column matrix
+bool bn_s5win_supported(const BnGeom& g);
+size_t bn_s5win_ws_bytes(int role, const BnGeom& g);     // role: 0 down, 1 up, 2 wgrad
+int bn_launch_s5win_down(const float* big, const float* w, const float* bias, float* out,
+                         const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                         void* ws, hipStream_t st);
+int bn_launch_s5win_up(const float* small, const float* w, const float* bias, float* out,
+                       const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                       hipStream_t st);
+int bn_launch_s5win_wgrad(const float* small, const float* big, float* dw, const BnGeom& g,
+                          int accumulate, hipStream_t st);
+
 // conv_mfma.hip: out = epilogue(sum_z part[z]) of a reduction split over workgroups (NCHW, C channels
 // of npix pixels; fixed summation order)
 int bn_launch_split_epilogue(const float* part, const float* bias, float* out, const float* dact_src,

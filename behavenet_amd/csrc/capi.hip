@@ -689,6 +689,11 @@ static int run_down(int family, const float* big, const float* w, const float* b
         BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<0>", st);
         return bn_launch_qgemm_down(big, w, bias, out, dact_src, g, act, dact, slope, ws, st);
     }
+    if (!generic && bn_s5win_supported(g)) {
+        if (!ws || ws_bytes < bn_s5win_ws_bytes(0, g)) return BN_E_WORKSPACE;
+        BnProfScope prof(family, g.Cb, g.Cs, "k_s5win<down>", st);
+        return bn_launch_s5win_down(big, w, bias, out, dact_src, g, act, dact, slope, ws, st);
+    }
     BnFastPlan plan = bn_fast_down_plan(g);
     if (generic) plan.supported = false;
     if (!generic && !plan.supported && bn_s5_down_small_ok(g)) {
@@ -786,6 +791,10 @@ static int run_up(int family, const float* small, const float* w, const float* b
         if (bn_qgemm_ws_bytes(1, g) && (!ws || ws_bytes < bn_qgemm_ws_bytes(1, g))) return BN_E_WORKSPACE;
         BnProfScope prof(family, g.Cs, g.Cb, "k_qgemm<1>", st);
         return bn_launch_qgemm_up(small, w, bias, out, dact_src, g, act, dact, slope, ws, st);
+    }
+    if (!generic && bn_s5win_supported(g)) {
+        BnProfScope prof(family, g.Cs, g.Cb, "k_s5win<up>", st);
+        return bn_launch_s5win_up(small, w, bias, out, dact_src, g, act, dact, slope, st);
     }
     if (!generic) {
         const BnFastPlan s5 = bn_s5_up_plan(g);
@@ -1008,6 +1017,10 @@ static int run_wgrad(int family, const float* small, const float* big, float* dw
         BnProfScope prof(family, g.Cb, g.Cs, "k_qgemm<2>", st);
         return bn_launch_qgemm_wgrad(small, big, dw, g, accumulate, ws, st);
     }
+    if (!generic && bn_s5win_supported(g)) {
+        BnProfScope prof(family, g.Cb, g.Cs, "k_s5win<wgrad>", st);
+        return bn_launch_s5win_wgrad(small, big, dw, g, accumulate, st);
+    }
     if (!generic && s5_wgrad_by_col(g)) {
         BnProfScope prof(family, g.Cb, g.Cs, "k_im2col + k_gemm_mfma (dW, stride 5)", st);
         return bn_launch_col_wgrad(small, big, dw, g, accumulate, ws, ws_bytes, st, db, bias_side, bias_done);
@@ -1114,6 +1127,7 @@ static size_t role_ws_need(int role, const BnGeom& g) {
         return bigk1_map_bytes(g, b1) + bigk_w_bytes(g) + (role == 2 ? 4096 : 0) + bigk1_inner_ws(role, g, g5, b1);
     if (chan_plan(role, g, &g5)) return chan_bytes(g) + role_ws_need(role, g5);
     if (bn_qgemm_supported(g)) return bn_qgemm_ws_bytes(role, g);
+    if (bn_s5win_supported(g)) return bn_s5win_ws_bytes(role, g);
     if (role == 2 && s5_wgrad_by_col(g)) return bn_col_ws_bytes(g);
     BnFastPlan plan;
     if (role == 0) plan = bn_fast_down_plan(g);
@@ -1516,7 +1530,7 @@ extern "C" int bn_sqerr_bwd(const float* pred, const float* target, const float*
 // other geometry: the same result composed from the stand-alone kernels (xhat goes through `ws`
 // if the caller does not want it).
 static bool fused_sqerr_fast(const BnGeom& g) {
-    return !force_generic() && !bn_qgemm_supported(g) && !bn_s5_up_plan(g).supported &&
+    return !force_generic() && !bn_qgemm_supported(g) && !bn_s5win_supported(g) && !bn_s5_up_plan(g).supported &&
            bn_edge_up_plan(g).supported && bn_edge_up_plan(g).variant != 9;
 }
 

@@ -36,13 +36,16 @@ __all__ = ['GraphedLoss', 'LazyLoss', 'enabled_by_default']
 
 
 def enabled_by_default():
-    """``fit`` replays graphs when ``hparams['hip_graph']`` is true or ``BN_GRAPH=1``.  Off by
-    default: measured on the MI355X (tools/bench_graph_step.py) the step is bound by the GPU, not
-    by the host, at every size tried -- 4.38 / 4.40 ms eager / graph at 256 frames of 128x128,
-    3.17 / 3.18 at 64x48, 1.38 / 1.39 ms at 32 frames, 1.25 / 1.16 ms at 32 frames of 32x32 --
-    so a graph only pays where the host is slower than here (busy host cores, many ranks per
-    socket)."""
-    return os.environ.get('BN_GRAPH', '0') == '1'
+    """``fit`` replays graphs when ``hparams['hip_graph']`` is true, ``BN_GRAPH=1``, or -- round 5 -- the
+    fit is frame-sharded over four or more ranks.  Measured on the MI355X (tools/bench_graph_step.py,
+    tools/bench_frames_shard.py): with a whole trial per step the GPU is the bound -- 4.32 / 4.33 ms
+    eager / graph at 256 frames of 128x128 -- so a graph only pays where the host is slower than
+    here; the 32-frame shard of an 8-rank frame-sharded step is ~75 launches of 5-40 us, which the
+    host issues in 1.41 ms and the graph replays in 1.04 (bit-identical results either way)."""
+    env = os.environ.get('BN_GRAPH')
+    if env is not None:
+        return env == '1'
+    return bdist.frames_sharded() and bdist.shard_rank_world()[1] >= 4
 
 
 LazyLoss = hf.LazyLoss      # (the class lives next to Readback: eager steps hand it out as well, set_lazy_losses)

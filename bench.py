@@ -69,6 +69,7 @@ def build_hparams():
 
 
 _PARTS = None    # BN_BENCH_TRACE=1: host time of the components of every step
+_LOSS = None     # what a step calls for the loss: model.loss, or its HIP-graph replay (fitting/graph_step.py)
 _AVERAGE = False  # N > 1, --shard trial: mean over the ranks' trials (fit()'s 'trial' mode)
 
 
@@ -82,7 +83,7 @@ def one_step(model, opt, gen):
         gen.reset_iterators('train')
         data, dataset = gen.next_batch('train')
     if t: t.append(time.perf_counter())
-    loss = model.loss(data, dataset=dataset, accumulate_grad=True)
+    loss = (_LOSS or model.loss)(data, dataset=dataset, accumulate_grad=True)
     if t: t.append(time.perf_counter())
     if getattr(opt, 'shard_over', 1) > 1:
         bdist.sharded_step(opt, average=_AVERAGE)      # --shard-optimizer
@@ -733,6 +734,11 @@ def run(args):
     bdist.broadcast_parameters_(opt.flat_p)
     if not shard_opt:
         bdist.attach_reducer(opt)
+    # the step as fit() runs it: recorded into a HIP graph where graph_step.enabled_by_default() says so
+    # (frame sharding over >= 4 ranks, or BN_GRAPH=1)
+    global _LOSS
+    from behavenet_amd.fitting import graph_step
+    _LOSS = graph_step.GraphedLoss(model) if graph_step.enabled_by_default() else None
 
     # 20 trials x 256 frames per rank, trial_splits 8;1;1;0 -> 16 train trials
     # ('frames': every rank holds the same trials and walks them in the same order)
@@ -999,6 +1005,7 @@ def run(args):
                               'host_u8': 'pinned host uint8, prefetched over PCIe per batch',
                               'host': 'pinned host float32, copied per batch'}[args.feed]},
         'allreduce': allreduce_mode,
+        'hip_graph': bool(_LOSS is not None and _LOSS.n_replays > 0),
         'final_loss': last['loss'] if last else None,
         'whole_step_fp32_tflops_per_gpu': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12, 2),
         'whole_step_fp32_frac': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12 /

@@ -73,6 +73,14 @@ CONV_CASES = [
     ('pad_E0_64x48', 3, 1, 64, 48, 32, 5, 2, (1, 2), (1, 2)),
     ('s5_2x1', 4, 256, 6, 5, 512, 5, 5, (2, 2), (0, 0)),
     ('s5_1x1', 4, 256, 4, 3, 512, 5, 5, (0, 1), (1, 1)),
+    # round 5: the stride-5 last layer on ANY pair of maps without im2col (csrc/conv_s5win.hip: one dense GEMM
+    # per window over the taps that fall on the map): 12x12 <-> 3x3 (192x192 frames; 70 frames: a second,
+    # partly filled row tile), 12x10 <-> 3x2 (192x160), channel counts that are no multiples of the tile,
+    # the benchmark's 8x8 <-> 2x2 maps with channel counts its own kernels do not take
+    ('s5_3x3', 70, 256, 12, 12, 512, 5, 5, (1, 2), (1, 2)),
+    ('s5_3x2', 5, 256, 12, 10, 512, 5, 5, (1, 2), (0, 0)),
+    ('s5_oddch_2x2', 3, 40, 7, 9, 72, 5, 5, (1, 2), (0, 1)),
+    ('s5_2x2_c64_c96', 4, 64, 8, 8, 96, 5, 5, (1, 1), (1, 1)),
     # maps larger than the specialised kernels take: spatial tiles with halos (conv_pad.hip):
     # 2x2 tiles of 32x32 (enc.conv1 of a 192x160 frame), 4x1 tiles, an odd-sized map with the
     # first tap 2 pixels outside, single- and two-channel 192x160 frames on the edge kernels
@@ -245,6 +253,9 @@ CONVT_CASES = [
     ('k3s1', 2, 6, 9, 11, 4, 3, 1, (1, 1), None, 0),
     ('valid_outpad', 2, 9, 8, 6, 3, 7, 2, 0, None, (1, 0)),
     ('nonsquare_first', 3, 512, 1, 1, 256, 5, 5, 0, (1, 1, 0, 1), 0),
+    ('s5_3x3', 70, 512, 3, 3, 256, 5, 5, 0, (1, 2, 1, 2), 0),
+    ('s5_3x2', 5, 512, 3, 2, 256, 5, 5, 0, (0, 0, 1, 2), 0),
+    ('s5_oddch_2x2', 3, 72, 2, 2, 40, 5, 5, 0, (0, 1, 1, 2), 0),
     ('odd_channels', 2, 65, 10, 10, 33, 5, 2, 0, (1, 2, 1, 2), 0),
     ('pad_24x20', 3, 64, 24, 20, 32, 5, 2, 0, (1, 2, 1, 2), 0),
     ('pad_4x3', 3, 256, 4, 3, 128, 5, 2, 0, (1, 2, 1, 2), 0),
@@ -950,6 +961,31 @@ def test_kernels_larger_than_5x5_run_without_im2col(case_name):
         finally:
             _hip.prof_select(_hip.PROF_NONE)
         assert n >= 1 and want in name and 'im2col' not in name and 'col2im' not in name, name
+
+
+@pytest.mark.parametrize('case_name', ['s5_3x3', 's5_3x2', 's5_oddch_2x2', 's5_2x2_c64_c96', 's5_2x1', 's5_1x1',
+                                       'E4_cfg1', 'nonsquare_last'])
+def test_stride5_layers_run_without_im2col_on_any_map(case_name):
+    """Round 5: the stride-5 last layer of the default architecture, whatever the frame size
+    makes of its maps, runs all three roles on the window GEMMs of csrc/conv_s5win.hip -- no k_im2col*, k_col2im,
+    k_gemm_tiled, k_up_s5, k_wgrad_s5."""
+    case = [c for c in CONV_CASES if c[0] == case_name][0]
+    x, w, b, geom, ref = _conv_setup(case)
+    N, K, P, Q = geom[0], geom[4], geom[10], geom[11]
+    dy = torch.ones((N, K, P, Q), device=DEV)
+    for prof, fn in (
+            (_hip.PROF_CONV_FWD, lambda: _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE)),
+            (_hip.PROF_CONV_BWD_D, lambda: _hip.conv2d_bwd_data(dy, w.to(DEV), geom, None, _hip.ACT_NONE, SLOPE)),
+            (_hip.PROF_CONV_BWD_W, lambda: _hip.conv2d_bwd_weight(
+                x.to(DEV), dy, torch.empty_like(w, device=DEV), torch.empty_like(b, device=DEV), geom, False))):
+        _hip.prof_select(prof, 0, 0)
+        try:
+            fn()
+            torch.cuda.synchronize()
+            _, n, name = _hip.prof_read()
+        finally:
+            _hip.prof_select(_hip.PROF_NONE)
+        assert n >= 1 and 'k_s5win<' in name, name
 
 
 @pytest.mark.parametrize('case_name, want', [
