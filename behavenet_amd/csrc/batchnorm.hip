@@ -101,9 +101,25 @@ __device__ __forceinline__ void bnk_affine(float mean, float invstd, const float
     *sh = fmaf(-mean, *sc, beta ? beta[c] : 0.f);
 }
 
+// The shift of the one-pass statistics: the mean of eight samples of the channel spread over the chunk's
+// frames and pixels.  (Round 4 took the chunk's FIRST value -- the corner pixel of the first frame, which
+// after a zero-padded convolution is often an outlier: the variance then loses a factor
+// 1 + (mean - s)^2 / var of precision, ADVICE r4.  One outlier among eight samples moves the shift by an
+// eighth of its distance.)  The same function in the statistics kernel and in its finalize kernel.
+__device__ __forceinline__ float bnk_shift(const float* __restrict__ x, int beg, int end, int c, int C, int HW) {
+    const int N = end - beg;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int n = beg + (int)(((long)k * N) >> 3);
+        const int i = (int)(((long)(2 * k + 1) * HW) >> 4);
+        s += x[((size_t)n * C + c) * HW + i];
+    }
+    return s * 0.125f;
+}
+
 // Statistics in ONE pass over x (round 4; they were two: mean, then the centred second moment):
-// part1 = sum (x - s), part2 = sum (x - s)^2 around a per-channel shift s = the chunk's first value
-// of the channel.  With s inside the data the subtraction var = E[(x-s)^2] - (E[x-s])^2 loses a
+// part1 = sum (x - s), part2 = sum (x - s)^2 around a per-channel shift s inside the data (bnk_shift).  With s inside the data the subtraction var = E[(x-s)^2] - (E[x-s])^2 loses a
 // factor (1 + (mean - s)^2 / var) of precision -- a few units in the last place for any channel
 // that is not constant, against the catastrophic E[x^2] - mean^2 -- and 0.5 GB less traffic per
 // training step of the batch-norm model.
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_stats_part(
     const int c = blockIdx.x, sp = blockIdx.y, z = blockIdx.z;
     const int N = ch.end[z] - ch.beg[z];
     const int n_beg = ch.beg[z] + (int)((long)sp * N / S), n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
-    const float sh = x[((size_t)ch.beg[z] * C + c) * HW];
+    const float sh = bnk_shift(x, ch.beg[z], ch.end[z], c, C, HW);
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);
     if (vec) {
@@ -173,7 +189,7 @@ __global__ void k_bn_stats_finalize(const float* __restrict__ x, const float* __
             s2 += part2[((size_t)z * C + c) * S + s];
         }
         const float inv_n = 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW);
-        const float sh = x[((size_t)ch.beg[z] * C + c) * HW];
+        const float sh = bnk_shift(x, ch.beg[z], ch.end[z], c, C, HW);
         const float d = s1 * inv_n;
         const float m = sh + d;
         const float v = fmaxf(fmaf(-d, d, s2 * inv_n), 0.f);

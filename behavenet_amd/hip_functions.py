@@ -763,16 +763,27 @@ def _batches_tracked(module, added=1):
     is 1 / count -- nine host synchronisations per training step otherwise).  The counter itself is
     advanced by ``added`` on the device by the statistics kernel (round 4: it was two torch
     element-wise launches per layer); a host mirror follows it and is re-read from the device
-    whenever something else has touched the tensor (load_state_dict, a new tensor, a reset)."""
+    whenever something else has touched the tensor (load_state_dict, a new tensor, a reset).
+
+    The mirror is NOT advanced here: the caller does that with ``_batches_advance`` once the library
+    call that bumps the device counter has returned (a call that raised used to leave the
+    mirror ahead of the device, and every later cumulative-average factor silently wrong)."""
     t = module.num_batches_tracked
     mirror = getattr(module, '_bn_count_mirror', None)
     if mirror is not None and mirror[0] is t and mirror[1] == t._version:
-        value = mirror[2]
-    else:
-        value = int(t.item())
-    # (the kernel's in-place add does not move torch's version counter)
-    module._bn_count_mirror = (t, t._version, value + added)
+        return mirror[2]
+    value = int(t.item())
+    module._bn_count_mirror = (t, t._version, value)
     return value
+
+
+def _batches_advance(module, added):
+    """The device counter has been advanced by ``added`` (inside a kernel: torch's version counter of
+    the tensor did not move)."""
+    t = module.num_batches_tracked
+    mirror = getattr(module, '_bn_count_mirror', None)
+    if mirror is not None and mirror[0] is t:
+        module._bn_count_mirror = (t, t._version, mirror[2] + added)
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -812,9 +823,9 @@ class BatchNormActFn(torch.autograd.Function):
                     module.num_batches_tracked.add_(1)
                     mirror = getattr(module, '_bn_count_mirror', None)
                     if mirror is not None and module.momentum is None:
-                        # (torch's add_ moved the version counter: the mirror stays valid)
+                        # (torch's add_ moved the version counter: the mirror follows both)
                         t = module.num_batches_tracked
-                        module._bn_count_mirror = (t, t._version, mirror[2])
+                        module._bn_count_mirror = (t, t._version, mirror[2] + 1)
                     else:
                         module._bn_count_mirror = None
                 y, mean, invstd, ctx.sync_count = _hip.batchnorm_sync_train_fwd(
@@ -840,9 +851,15 @@ class BatchNormActFn(torch.autograd.Function):
                     else:
                         factors = [float(module.momentum)] * k
                         module._bn_count_mirror = None
-                y, mean, invstd = _hip.batchnorm_train_fwd_chunks(
-                    x, g, b, rm, rv, factors, float(module.eps), act, LRELU_SLOPE, bounds,
-                    num_batches_tracked=module.num_batches_tracked if tracking else None)
+                try:
+                    y, mean, invstd = _hip.batchnorm_train_fwd_chunks(
+                        x, g, b, rm, rv, factors, float(module.eps), act, LRELU_SLOPE, bounds,
+                        num_batches_tracked=module.num_batches_tracked if tracking else None)
+                except Exception:
+                    module._bn_count_mirror = None      # (whatever the device counter is now: re-read it)
+                    raise
+                if tracking and module.momentum is None:
+                    _batches_advance(module, k)
                 ctx.chunks = list(bounds)
         else:
             ctx.sync_count = None

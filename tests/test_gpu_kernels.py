@@ -550,6 +550,36 @@ def test_batchnorm_one_pass_statistics_are_well_conditioned(offset, spread):
     assert int(mh.num_batches_tracked) == 2
 
 
+def test_batchnorm_statistics_with_an_outlier_at_the_first_pixel():
+    """the one-pass statistics used to be shifted by the chunk's FIRST value of a channel -- the
+    corner pixel of the first frame, often an outlier behind a zero-padded convolution.  With the corner 500
+    standard deviations away the variance lost 2.5e5 x of its precision (1 + (mean - s)^2 / var).  The shift is
+    now the mean of eight samples spread over the chunk: same comparison as above, against float64."""
+    from behavenet_amd.hip_functions import BatchNormActFn, bn_chunks
+    N, C, H, W = 24, 16, 16, 12
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn((N, C, H, W), generator=g) * 0.2 + 1.5
+    bounds = [(0, 17), (17, 24)]
+    for b, _ in bounds:
+        x[b, :, 0, 0] = 100.0                    # the corner pixel of each chunk's first frame
+    gy = torch.randn((N, C, H, W), generator=g)
+    outs = {}
+    for key, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        m = torch.nn.BatchNorm2d(C, momentum=None).to(dt).train()
+        xi = x.detach().clone().to(dt).requires_grad_(True)
+        y = torch.cat([F.leaky_relu(m(xi[b:e]), SLOPE) for b, e in bounds])
+        y.backward(gy.to(dt))
+        outs[key] = (y, xi.grad, m)
+    mh = torch.nn.BatchNorm2d(C, momentum=None).to(DEV).train()
+    xh = x.detach().clone().to(DEV).requires_grad_(True)
+    with bn_chunks(bounds):
+        yh = BatchNormActFn.apply(xh, mh.weight, mh.bias, mh, _hip.ACT_LRELU)
+    yh.backward(gy.to(DEV))
+    close(yh, outs['f32'][0], outs['f64'][0], name='bn y (outlier)')
+    close(xh.grad, outs['f32'][1], outs['f64'][1], name='bn dx (outlier)')
+    close(mh.running_var, outs['f32'][2].running_var, outs['f64'][2].running_var, name='bn rvar (outlier)')
+
+
 @pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_SIGMOID, _hip.ACT_NONE])
 def test_act_bwd(act):
     g = torch.Generator().manual_seed(0)
