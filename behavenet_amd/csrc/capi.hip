@@ -1531,7 +1531,7 @@ extern "C" int bn_sqerr_bwd(const float* pred, const float* target, const float*
 // if the caller does not want it).
 static bool fused_sqerr_fast(const BnGeom& g) {
     return !force_generic() && !bn_qgemm_supported(g) && !bn_s5win_supported(g) && !bn_s5_up_plan(g).supported &&
-           bn_edge_up_plan(g).supported && bn_edge_up_plan(g).variant != 9;
+           bn_edge_up_plan(g).supported;
 }
 
 extern "C" int bn_convT2d_fwd_sqerr_parts(int N, int Ci, int Hi, int Wi, int Co, int R, int S,

@@ -1724,7 +1724,8 @@ __global__ __launch_bounds__(64) void k_up_c1v(
     float* __restrict__ out, const float* __restrict__ target, const float* __restrict__ mask,
     float* __restrict__ dpre, float* __restrict__ partial, BnGeom g, int act, float slope,
     int units) {
-    static_assert(!GENW || !LOSS, "the fused pixel loss keeps the 64-column geometry");
+    // (round 5: the fused pixel loss serves the column blocks too -- 2x192x160 / 1x192x192 frames ran
+    // k_sqerr_frame_sums + k_sqerr_bwd + k_act_bwd behind this layer: 80-125 us per step)
     constexpr int NR = R + 2;                        // strip rows + halo above / below
     const int lane = threadIdx.x;
     const int strips = GENW ? (g.Hs + R - 1) / R : g.Hs / R;
@@ -2128,8 +2129,8 @@ BnFastPlan bn_edge_up_plan(const BnGeom& g) {
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return p;
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return p;
     if (g.Ws != UV_W || (g.Hs % 8) != 0) {
-        // round 4: any other small map in blocks of 62 columns (k_up_c1v<8, false, GENW>; variant 9: no fused
-        // pixel loss)
+        // round 4: any other small map in blocks of 62 columns (k_up_c1v<8, .., GENW>; variant 9; the fused
+        // pixel loss since round 5)
         static int off = -1;                          // BN_UP_C1G=0: off
         if (off < 0) { const char* e = bn_tune_env("BN_UP_C1G"); off = (e && e[0] == '0') ? 1 : 0; }
         if (off) return p;
@@ -2144,13 +2145,18 @@ BnFastPlan bn_edge_up_plan(const BnGeom& g) {
 }
 
 const char* bn_edge_up_kernel_name(const BnGeom& g, bool loss) {
+    if (g.Ws != UV_W || (g.Hs % 8) != 0) return loss ? "k_up_c1v<8, true, gen>" : "k_up_c1v<8, false, gen>";
     if (UP_C1_VARIANT == 1 && up_c1m_ok(g)) return loss ? "k_up_c1m<true>" : "k_up_c1m<false>";
     return loss ? "k_up_c1v<8, true>" : "k_up_c1v<8, false>";
 }
 
 #define UV_R 8          // strip height of the production instantiation
 
-int bn_edge_up_parts_per_frame(const BnGeom& g) { return g.Cb * (g.Hs / UV_R); }
+static bool up_c1_gen(const BnGeom& g) { return g.Ws != UV_W || (g.Hs % 8) != 0; }
+int bn_edge_up_parts_per_frame(const BnGeom& g) {
+    if (up_c1_gen(g)) return g.Cb * ((g.Hs + UV_R - 1) / UV_R) * ((g.Ws + 61) / 62);     // strips x column blocks
+    return g.Cb * (g.Hs / UV_R);
+}
 
 // target == nullptr: plain forward (out required).  Otherwise the loss epilogue: `dpre` and
 // `partial` (N * bn_edge_up_parts_per_frame floats) are written, `out` only if non-null.
@@ -2174,11 +2180,18 @@ int bn_launch_edge_up(const float* small, const float* w, const float* bias, flo
         return 0;
     }
 #endif
-    if (g.Ws != UV_W || (g.Hs % 8) != 0) {
-        if (target) return BN_E_SHAPE;
+    if (up_c1_gen(g)) {
         const int unitsg = g.N * g.Cb * ((g.Hs + UV_R - 1) / UV_R) * ((g.Ws + 61) / 62);
-        BN_LAUNCH_MAIN((k_up_c1v<UV_R, false, true>), dim3(unitsg < 256 * 16 ? unitsg : 256 * 16), dim3(64), 0, st,
-                           small, w, bias, out, nullptr, nullptr, nullptr, nullptr, g, act, slope, unitsg);
+        // (the loss epilogue reads / writes pixel pairs: 8-byte accesses need an even row length, which
+        // Wb = 2 Ws is, and 8-byte aligned tensors)
+        if (target && (((((uintptr_t)target) | ((uintptr_t)dpre) | ((uintptr_t)mask) | ((uintptr_t)out)) & 7u) != 0))
+            return BN_E_SHAPE;
+        if (target)
+            BN_LAUNCH_MAIN((k_up_c1v<UV_R, true, true>), dim3(unitsg < 256 * 16 ? unitsg : 256 * 16), dim3(64), 0, st,
+                               small, w, bias, out, target, mask, dpre, partial, g, act, slope, unitsg);
+        else
+            BN_LAUNCH_MAIN((k_up_c1v<UV_R, false, true>), dim3(unitsg < 256 * 16 ? unitsg : 256 * 16), dim3(64), 0, st,
+                               small, w, bias, out, nullptr, nullptr, nullptr, nullptr, g, act, slope, unitsg);
         BN_LAUNCH_CHECK();
         return 0;
     }

@@ -381,14 +381,16 @@ def test_convT2d_bwd(case):
     close(dw, 2 * dwr, 2 * dw64, name=case[0] + ' dw acc')
 
 
-@pytest.mark.parametrize('case_name', ['D4', 'D4_2ch', 'k4s2', 'D1'])
+@pytest.mark.parametrize('case_name', ['D4', 'D4_2ch', 'k4s2', 'D1', 'pad_D4_64x48', 'tile_D4_96x80',
+                                       'tile_D4c2_80x128'])
 @pytest.mark.parametrize('masked', [False, True])
 @pytest.mark.parametrize('act', [_hip.ACT_SIGMOID, _hip.ACT_LRELU])
 def test_convT2d_fwd_sqerr(case_name, masked, act):
     """Last decoder layer fused with the pixel loss (bn_convT2d_fwd_sqerr; reference
     aes.py:315-330,466-470 + losses.py:56-59): x_hat, the per-frame squared-error sums and
     d(frame sum)/d(pre-activation) against the oracle's operators -- on the fused VALU kernel
-    (D4 geometries) and on the composed fallback (any other geometry)."""
+    (D4 geometries; round 5: also frames that are not 128 columns wide, in blocks of 62 input columns:
+    64x48, 192x160 and two-channel 160x256 frames) and on the composed fallback (any other geometry)."""
     case = [c for c in CONVT_CASES if c[0] == case_name][0]
     x, w, b, geom, ref = _convT_setup(case, seed=3)
     N, Co, Ho, Wo = geom[0], geom[4], geom[10], geom[11]

@@ -14,6 +14,6 @@ tools/prof_cmd.sh ${T}_maxpool_arch 30 python tools/step_arch.py tests/golden/ar
 tools/prof_cmd.sh ${T}_drawn_k3 30 python tools/step_arch.py tools/arch_jsons/drawn_k3.json 1 128 128 256 20 | head -3
 tools/prof_cmd.sh ${T}_drawn_k7_k5_k9_k3 30 python tools/step_arch.py tools/arch_jsons/drawn_k7_k5_k9_k3.json 1 128 128 256 20 | head -3
 tools/prof_cmd.sh ${T}_drawn_maxpool_k9_k7 30 python tools/step_arch.py tools/arch_jsons/drawn_maxpool_k9_k7.json 1 128 128 256 20 | head -3
-bash tools/prof_shape.sh ${T}_frames_rank0of8 1 128 128 256 20 0 8 | head -3
+BN_R=8 tools/prof_cmd.sh ${T}_frames_rank0of8 110 python tools/bench_frames_shard.py 40 | head -4   # 2 x (15 + 40) steps: eager, then the HIP graph; Adam on 1/8 of the arena
 bash tools/prof_psvae.sh ${T}_psvae | head -3
 for spec in "e0 E0 fwd" "e0w E0 bwd_w" "d4w D4 bwd_w" "d4l D4 fwd_sqerr"; do set -- $spec; bash tools/pmc_hbm.sh ${T}_$1 $2 $3; done
