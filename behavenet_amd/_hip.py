@@ -175,6 +175,26 @@ def _stream():
 _ws_cache = {}
 
 
+def _arena(device, nbytes, tag=None):
+    """Pointer to at least ``nbytes`` of scratch on ``device``: a grow-only arena per (device,
+    stream, tag) -- kernels on different streams may run concurrently -- or, while a HIP graph is
+    being recorded, a block of the GRAPH's memory pool for this call only (freed right away: the
+    pool re-issues it within the recording in stream order and keeps it reserved for the replays).
+    A recording's block must never enter the cache: an arena cached from one graph's pool outlives
+    the pool, and the next recording (another pool) would be handed memory that went back to the
+    driver with the first graph (round 5: "write access to a read-only page" in the third recording
+    of a process)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device).data_ptr()
+    key = (device, torch.cuda.current_stream(device).cuda_stream) + ((tag,) if tag else ())
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        with torch.cuda.stream(torch.cuda.current_stream(device)):
+            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf.data_ptr()
+
+
 def _workspace(op, geom, device):
     """(pointer, nbytes) of the grow-only scratch arena of `device` sized for this call."""
     if torch.device(device).type != 'cuda':
@@ -183,14 +203,7 @@ def _workspace(op, geom, device):
     nbytes = load().bn_conv_ws_bytes(op, *geom)
     if nbytes == 0:
         return None, 0
-    # one arena per (device, stream): kernels on different streams may run concurrently
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        with torch.cuda.stream(torch.cuda.current_stream(device)):
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf.data_ptr(), nbytes
+    return _arena(device, nbytes), nbytes
 
 
 def conv2d_fwd(x, w, b, geom, act, slope):
@@ -211,12 +224,7 @@ def conv2d_fwd_u8(x_u8, w, b, geom, act, slope):
     nbytes = lib.bn_conv2d_fwd_u8_ws_bytes(*geom, act)
     ws = None
     if nbytes:
-        key = (x_u8.device, torch.cuda.current_stream(x_u8.device).cuda_stream, 'fwd_u8')
-        buf = _ws_cache.get(key)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=x_u8.device)
-            _ws_cache[key] = buf
-        ws = buf.data_ptr()
+        ws = _arena(x_u8.device, nbytes, 'fwd_u8')
     _check(lib.bn_conv2d_fwd_u8(
         _ptr(x_u8, 'x', dtype=torch.uint8), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True),
         _ptr(y, 'y'), *geom, act, slope, ws, nbytes, _stream()), 'bn_conv2d_fwd_u8')
@@ -283,12 +291,7 @@ def lib_call(name):
 
 def _bn_ws(n, c, device):
     nbytes = load().bn_batchnorm_ws_bytes(n, c)
-    key = (device, torch.cuda.current_stream(device).cuda_stream, 'bn')
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf.data_ptr(), nbytes
+    return _arena(device, nbytes, 'bn'), nbytes
 
 
 def batchnorm_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, y=None):
@@ -485,12 +488,7 @@ def _linear_ws(M, K, N, device):
     nbytes = load().bn_linear_ws_bytes(M, K, N)
     if nbytes == 0:
         return None, 0
-    key = (device, torch.cuda.current_stream(device).cuda_stream, 'linear')
-    buf = _ws_cache.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
-    return buf.data_ptr(), nbytes
+    return _arena(device, nbytes, 'linear'), nbytes
 
 
 def linear_fwd(x, w, b):
@@ -552,12 +550,7 @@ def convT2d_fwd_sqerr(x, w, b, target, mask, geom, act, slope, want_xhat):
     nbytes = lib.bn_convT2d_fwd_sqerr_ws_bytes(*geom, int(want_xhat))
     ws = None
     if nbytes:
-        key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, 'fwd_sqerr')
-        buf = _ws_cache.get(key)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)
-            _ws_cache[key] = buf
-        ws = buf.data_ptr()
+        ws = _arena(x.device, nbytes, 'fwd_sqerr')
     _check(lib.bn_convT2d_fwd_sqerr(
         _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(target, 'target'),
         _ptr(mask, 'mask', allow_none=True), _ptr(xhat, 'xhat', allow_none=True),

@@ -221,14 +221,20 @@ __device__ __forceinline__ void sw_body(const SWArgs& a, const int z, const int 
 
     if (ubeg < uend) fetch(ubeg);
     for (int u0 = ubeg; u0 < uend; u0 += ustep) {
+#ifndef SW_ABL_NOBAR
         __syncthreads();                       // everyone is done reading the previous stage
+#endif
+#ifndef SW_ABL_NOLDSW
 #pragma unroll
         for (int e = 0; e < EA; ++e)
             if (als[e] >= 0) As[als[e]] = ra[e];
 #pragma unroll
         for (int e = 0; e < EB; ++e)
             if (bls[e] >= 0) Bs[bls[e]] = rb[e];
+#endif
+#ifndef SW_ABL_NOBAR
         __syncthreads();
+#endif
 #pragma unroll
         for (int t = 0; t < KS / 2; ++t) {
             const float av = ap[2 * t];
@@ -247,6 +253,9 @@ __device__ __forceinline__ void sw_body(const SWArgs& a, const int z, const int 
 
     // lane holds C[(t & 3) + 8 (t >> 2) + 4 lk][li] of its 32 x 32 block of granule h
     const int irow = i0 + (wv >> 1) * 32 + 4 * lk;
+#ifdef SW_ABL_NOEPI
+    if (acc[0][0] != 12345.678f) return;
+#endif
     if (MODE == SW_DOWN) {
         float* dst = a.part + ((size_t)(ks * a.Z + z) * a.N) * a.Cs;
 #pragma unroll

@@ -374,7 +374,7 @@ class _LazyTrials(object):
         if _LazyTrials._pool is None:
             from concurrent.futures import ThreadPoolExecutor
             _LazyTrials._pool = ThreadPoolExecutor(
-                max_workers=int(os.environ.get('BN_READ_THREADS', '3')),
+                max_workers=int(os.environ.get('BN_READ_THREADS', '2')),      # (1: 332 k, 2: 341 k, 3: 327 k frames/s end to end)
                 thread_name_prefix='bn-trial-reader')
         self._pending[trial] = _LazyTrials._pool.submit(self._load, trial)
 

@@ -55,6 +55,73 @@ def encode_trial_device(model, y, sess=None, labels_2d=None, chunk_size=200):
     return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
 
+class _GraphedTrialEncoder(object):
+    """``encode_trial_device`` as a HIP graph per trial shape: a trial's encode is ~25 launches of
+    20-200 us issued through autograd-free Python and ctypes in 0.6-0.9 ms of host time -- longer than
+    the device needs for them (0.69 ms for 256 frames of 128x128) once the trials come from a file-backed
+    generator that also keeps the main thread busy.  Recorded after the first trial of a shape (same
+    kernels on the same operands: bit-identical latents), replayed with the trial copied into the
+    graph's static input; trials with extra input channels, host tensors and shapes beyond
+    ``max_graphs`` run eagerly.  Opt-in: ``hparams['hip_graph_encode'] = True`` / ``BN_GRAPH_ENCODE=1``."""
+
+    def __init__(self, model, warmup=1, max_graphs=6):
+        self.model, self.warmup, self.max_graphs = model, int(warmup), int(max_graphs)
+        self._graphs, self._seen, self._refused, self._pool = {}, {}, set(), None
+        self.n_replays = self.n_eager = 0
+        # opt-in: measured (tools/probe_export.py, one MI355X, idle host) 0.72 ms per 256-frame trial replayed
+        # against 0.70 ms launched eagerly -- the encoder is bound by the device; for hosts that are not idle
+        self.enabled = bool(model.hparams.get('hip_graph_encode', os.environ.get('BN_GRAPH_ENCODE', '0') == '1'))
+        # The reference encodes a trial in chunks of 200 frames (eval.py:51-97): that bounds ITS memory
+        # use, nothing else -- in eval mode frames are independent through every encoder (batch norm
+        # normalises with the running estimates).  A 256-frame trial as 200 + 56 frames is two passes,
+        # the second on a quarter-filled chip: 0.91 ms against 0.69 ms for one pass (tools/probe_export.py).
+        # Device-resident trials are therefore encoded whole, up to ``export_chunk_frames`` frames a pass.
+        self.chunk = int(model.hparams.get('export_chunk_frames', 1024))
+
+    def __call__(self, y, sess=None, labels_2d=None):
+        if not self.enabled or labels_2d is not None or not y.is_cuda or not y.is_contiguous():
+            self.n_eager += 1
+            return encode_trial_device(self.model, y, sess, labels_2d, self.chunk)
+        key = (tuple(y.shape), y.dtype, repr(sess))
+        rec = self._graphs.get(key)
+        if rec is None:
+            n = self._seen[key] = self._seen.get(key, 0) + 1
+            if n <= self.warmup or key in self._refused or len(self._graphs) >= self.max_graphs:
+                self.n_eager += 1
+                return encode_trial_device(self.model, y, sess, labels_2d, self.chunk)
+            rec = self._record(key, y, sess)
+            if rec is None:
+                self.n_eager += 1
+                return encode_trial_device(self.model, y, sess, labels_2d, self.chunk)
+        static_in, graph, out = rec
+        static_in.copy_(y, non_blocking=True)
+        graph.replay()
+        self.n_replays += 1
+        return out.clone()
+
+    def _record(self, key, y, sess):
+        import warnings
+        static_in = torch.empty_like(y)
+        static_in.copy_(y)
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        try:
+            # thread_local: the generator's reader threads and copy stream keep working meanwhile
+            with torch.cuda.graph(graph, pool=self._pool, capture_error_mode='thread_local'):
+                out = encode_trial_device(self.model, static_in, sess, None, self.chunk)
+        except Exception as err:                        # noqa: BLE001 (reported, then eager)
+            torch.cuda.synchronize()
+            self._refused.add(key)
+            warnings.warn('HIP graph capture of the trial encoder failed (%s: %s); trials of shape %s '
+                          'stay on eager launches' % (type(err).__name__, err, key[0]))
+            return None
+        rec = (static_in, graph, out)
+        self._graphs[key] = rec
+        return rec
+
+
 def export_latents(data_generator, model, filename=None):
     """Encode train/val/test trials of every session and pickle them (ref eval.py:6-118)."""
     # multi-session generators serve lists of batches for training; latents are exported trial by
@@ -89,6 +156,7 @@ def export_latents(data_generator, model, filename=None):
     if serve_prev is not None and conv_u8:
         data_generator.serve_uint8 = True
     on_device = {}          # (session, trial) -> device tensor: ONE transfer to the host at the end
+    encode = _GraphedTrialEncoder(model)
     try:
         for dtype in ['train', 'val', 'test']:
             data_generator.reset_iterators(dtype)
@@ -110,7 +178,7 @@ def export_latents(data_generator, model, filename=None):
                 if not torch.is_tensor(images):      # generators serving numpy arrays (as_numpy)
                     images = torch.from_numpy(np.asarray(images))
                 if images.is_cuda:
-                    on_device[(sess, idx)] = encode_trial_device(model, images, sess, labels_2d)
+                    on_device[(sess, idx)] = encode(images, sess, labels_2d)
                 else:
                     latents[sess][idx] = encode_trial(model, images, sess, labels_2d)
     finally:

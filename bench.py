@@ -359,8 +359,8 @@ def export_latents_throughput(hp_ae, n_trials=2048):
         frames = n_done * BATCH
         return {'config': 'configs[4] through the product entry point export_latents(): %d trials of 256 uint8 '
                           'frames (1x128x128) from a data.npz trial store on local disk (page cache warm: second '
-                          'pass) -> ConcatSessionsGenerator (pinned uint8, 3 reader threads, device copy one trial '
-                          'ahead) -> encoder -> latents on the device -> one D2H -> *_latents.pkl' % n_trials,
+                          'pass) -> ConcatSessionsGenerator (pinned uint8, 2 reader threads, device copy one trial '
+                          'ahead) -> encoder (a trial in one pass) -> latents on the device -> one D2H -> *_latents.pkl' % n_trials,
                 'value': round(frames / dt, 1), 'unit': 'frames/s', 'seconds': round(dt, 3),
                 'trials_encoded': n_done, 'ms_per_trial': round(dt * 1e3 / max(n_done, 1), 3),
                 'seconds_per_1M_frames': round(1e6 * dt / max(frames, 1), 2),
