@@ -198,15 +198,25 @@ __device__ __forceinline__ void sw_body(const SWArgs& a, const int z, const int 
     auto fetch = [&](const int u0) __attribute__((always_inline)) {
         const bool tail = u0 + ustep > uend;                // wave-uniform: units past the end read 0.0f
         const int sa = u0 * a_ustride, sb = u0 * b_ustride;
+        if (!tail) {
+            // (the common stage: no per-element select -- 30 v_cndmask inside the MFMA stream otherwise)
 #pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            const int vo = (tail && u0 + aun[e] >= uend) ? OOB : avo[e];
-            ra[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, vo, sa, 0));
-        }
+            for (int e = 0; e < EA; ++e)
+                ra[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, avo[e], sa, 0));
 #pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            const int vo = (tail && u0 + bun[e] >= uend) ? OOB : bvo[e];
-            rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, vo, sb, 0));
+            for (int e = 0; e < EB; ++e)
+                rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, bvo[e], sb, 0));
+        } else {
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                const int vo = (u0 + aun[e] >= uend) ? OOB : avo[e];
+                ra[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, vo, sa, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                const int vo = (u0 + bun[e] >= uend) ? OOB : bvo[e];
+                rb[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, vo, sb, 0));
+            }
         }
     };
 
