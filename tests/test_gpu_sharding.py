@@ -492,3 +492,22 @@ def test_bench_rank_dies_mid_run_error_line(launcher, tmp_path):
     assert len(lines) == 1, (out[-3000:], err[-3000:])
     assert lines[0].get('error') and lines[0]['value'] is None
     assert time.time() - t0 < 180
+
+
+def test_bench_four_ranks_frame_sharded_defaults(tmp_path):
+    """Round 5 defaults of frame sharding over >= 4 ranks -- the step recorded into a HIP graph (its one
+    collective, the per-chunk loss table, issued behind the replay), reduce-scatter -> Adam on 1/4 of the arena ->
+    all-gather -- with four real processes on the one GPU over gloo: the trajectory reports the single-device
+    loss, and the line says what ran."""
+    env = _child_env(BN_DIST_BACKEND='gloo', BN_BENCH_PRIME='24')
+    tail = ['--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary', '--no-pmc']
+    d4 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--shard', 'frames'] + tail,
+                     env, tmp_path, limit_s=400)
+    d1 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1'] + tail, env, tmp_path)
+    assert d4['n_gpus'] == 4 and d4['scaling'] == 'strong' and d4['hip_graph'] is True
+    ar = d4['allreduce']
+    assert ar['shard_optimizer'] is True and ar['world_size'] == 4 and ar['op'] == 'sum'
+    assert ar['gradient_bytes'] % (4 * 16) == 0
+    assert len(ar['devices']) == 4 and len(ar['single_gpu_reference']['ms_per_step_per_rank']) == 4
+    assert d4['config']['frames_per_step_per_gpu'] == 64
+    assert d4['final_loss'] == pytest.approx(d1['final_loss'], rel=1e-4)
