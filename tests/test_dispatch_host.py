@@ -18,8 +18,10 @@ from behavenet_amd import _hip
 
 def _cases(seed, count):
     """The seeded sweep plus every named conv case of the device tests."""
-    from tests.test_gpu_kernels import _random_conv_cases, CONV_CASES
-    return list(CONV_CASES) + _random_conv_cases(seed, count) + _random_conv_cases(seed + 1, count // 4, big=True)
+    from tests.test_gpu_kernels import _random_conv_cases, _random_stride5_cases, CONV_CASES
+    # (round 5: plus a sweep of the stride-5 last layer on maps of 1..17 pixels -- csrc/conv_s5win.hip)
+    return list(CONV_CASES) + _random_conv_cases(seed, count) + _random_conv_cases(seed + 1, count // 4, big=True) + \
+        _random_stride5_cases(seed + 2, count // 4)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='launches real kernels on dummy pointers when a GPU is present')

@@ -906,6 +906,54 @@ def test_random_geometries_all_roles(case):
     test_conv2d_bwd(case)
 
 
+def _random_stride5_cases(seed, n):
+    """5x5 stride-5 layers as the reference's planner pads them (TF-"same": out = ceil(in / 5), the total padding
+    split before / after, ae_model_architecture_generator.py:379-383) on maps of 1..17 pixels per side, plus
+    offsets a planner would not produce (any split of the padding)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        H, W = int(rng.integers(1, 18)), int(rng.integers(1, 18))
+        C = int(rng.choice([3, 8, 17, 40, 64]))
+        K = int(rng.choice([5, 16, 33, 72, 130]))
+        N = int(rng.choice([1, 2, 5, 67]))
+        pads = []
+        for size in (H, W):
+            o = -(-size // 5)
+            tot = max(0, (o - 1) * 5 + 5 - size)
+            before = tot // 2 if i % 3 else int(rng.integers(0, tot + 1))
+            pads.append((before, tot - before))
+        out.append(('rs5_%d_%dx%d_c%d_k%d_n%d_p%d%d' % (i, H, W, C, K, N, pads[0][0], pads[1][0]),
+                    N, C, H, W, K, 5, 5, pads[0], pads[1]))
+    return out
+
+
+RANDOM_S5_CASES = _random_stride5_cases(5051, 40)
+
+
+@pytest.mark.parametrize('case', RANDOM_S5_CASES, ids=[c[0] for c in RANDOM_S5_CASES])
+def test_random_stride5_geometries_all_roles(case):
+    """Round 5: the window GEMMs of csrc/conv_s5win.hip on a seeded sweep of maps, paddings, channel counts and
+    batch sizes (tile tails in every dimension), through the Conv2d entry points and -- same maps -- the
+    ConvTranspose2d ones, against float64."""
+    x, w, b, geom, pad = _conv_setup(case)
+    want = act_ref(F.conv2d(F.pad(x, pad), w, b, stride=5), _hip.ACT_LRELU)
+    want64 = act_ref(F.conv2d(F.pad(x.double(), pad), w.double(), b.double(), stride=5), _hip.ACT_LRELU)
+    assert tuple(want.shape[2:]) == (geom[10], geom[11]), (want.shape, geom)
+    got = _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE)
+    close(got, want, want64, name=case[0] + ' fwd')
+    test_conv2d_bwd(case)
+    c = case
+    tcase = (c[0] + 'T', c[1], c[5], (c[3] + sum(c[8]) - 5) // 5 + 1, (c[4] + sum(c[9]) - 5) // 5 + 1, c[2], 5, 5, 0,
+             (c[9][0], c[9][1], c[8][0], c[8][1]), 0)
+    xt, wt, bt, geomt, ref = _convT_setup(tcase)
+    wantt = act_ref(ref(xt, wt, bt), _hip.ACT_LRELU)
+    wantt64 = act_ref(ref(xt.double(), wt.double(), bt.double()), _hip.ACT_LRELU)
+    gott = _hip.convT2d_fwd(xt.to(DEV), wt.to(DEV), bt.to(DEV), geomt, _hip.ACT_LRELU, SLOPE)
+    close(gott, wantt, wantt64, name=tcase[0] + ' fwd')
+    test_convT2d_bwd(tcase)
+
+
 # the transposed layers between the same maps: small (K, P, Q) -> big (C, H, W), cropped by the conv's pads
 RANDOM_T_CASES = [(c[0] + 'T', c[1], c[5], (c[3] + sum(c[8]) - c[6]) // c[7] + 1,
                    (c[4] + sum(c[9]) - c[6]) // c[7] + 1, c[2], c[6], c[7], 0,
