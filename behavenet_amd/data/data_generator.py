@@ -204,7 +204,9 @@ class SyntheticSessionsGenerator(object):
                     if self._n_left(sess, dtype):
                         trial = self._queue(sess, dtype).pop(0)
                         break
-                skip = bool(skip)       # (multi-session batches: all or nothing)
+                if callable(skip):      # (multi-session batches are skipped whole: True / False only)
+                    raise ValueError('next_batch: a skip predicate needs one trial per batch '
+                                     '(return_multiple=False)')
                 samples.append(SKIPPED if skip else self._sample(sess, trial, dtype))
                 sessions.append(sess)
             return (SKIPPED if skip else samples), sessions
