@@ -26,6 +26,10 @@
 // a scalar offset -- and staged through LDS (rows of KS + 1 words: conflict-free MFMA operand reads),
 // the next stage's loads issued from inside the MFMA stream of the current one (DESIGN.md section 4,
 // issue rules).  Tile 64 x 128 per workgroup of four waves, v_mfma_f32_32x32x2_f32, fp32 throughout.
+//
+// Lab hooks (compile-time, `tools/build_variant.sh <name> conv_s5win.hip -D...`, measured with tools/bench_s5.py):
+// SW_ABL_NOFETCH (no gathers after the first stage), SW_ABL_NOLDSW (no LDS writes), SW_ABL_NOBAR (no barriers),
+// SW_ABL_NOEPI (no epilogue), SW_SPLIT_TARGET=<workgroups> (reduction slices of the down role).  Results: DESIGN.md 4.
 #include <stdlib.h>
 #include "bn_common.h"
 #include "bn_fast.h"

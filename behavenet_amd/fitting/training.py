@@ -173,6 +173,8 @@ class _CheckpointWriter(object):
         self._thread = None
         self._error = None
         self._stream = None
+        self._plan = None           # (dtype, ((key, shape), ...)) groups the flat buffers were laid out for
+        self._flat = {}             # dtype -> (flat device buffer, flat pinned host buffer)
 
     def wait(self):
         if self._thread is not None:
@@ -207,7 +209,7 @@ class _CheckpointWriter(object):
             if v.is_cuda:
                 groups.setdefault(v.dtype, []).append(k)
         plan = tuple((dt, tuple((k, tuple(state[k].shape)) for k in ks)) for dt, ks in groups.items())
-        if getattr(self, '_plan', None) != plan:
+        if self._plan != plan:
             self._plan = plan
             self._flat = {}
             for dt, ks in groups.items():

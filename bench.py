@@ -553,6 +553,10 @@ def self_launch(n_gpus, limit_s):
         child.wait()
         rc, why = 124, 'no result within %d s: job killed' % limit_s
     t.join(timeout=5)
+    try:        # (the ranks' first-to-report marker: named after the port and the launcher's pid)
+        os.remove(os.path.join('/tmp', 'bn_bench_error_%s_%s' % (port, child.pid)))
+    except OSError:
+        pass
     if not seen['line']:
         print(error_line('%d-rank run produced no result line (%s)' % (n_gpus, why), n_gpus=n_gpus))
         rc = rc or 1
