@@ -39,6 +39,22 @@ __device__ __forceinline__ float ed_ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
 #define WC_RW (2 * WC_W + 4)            // big-tile row stride (131 used)
 #define WC_KS (32 * WC_TPX / ED_THREADS)            // 32 small elements per thread per stage
 
+// Grid of the two weight-gradient kernels below: G workgroups per big-side channel.  `pair` = 0: grid (G, Cb).
+// `pair` = 1 (round 5, two-channel frames -- PS-VAE, BASELINE configs[3]): a 1-D grid of G * Cb workgroups decoded
+// so that the Cb workgroups walking the SAME stages sit on ONE XCD, 8 blocks apart in dispatch order (block b runs on
+// XCD b % 8): they read the same 134 MB small-side tensor, which used to come from HBM once per channel -- the second
+// reader now finds the stage in that XCD's L2.
+#define WC_DECODE_GRID()                                                                    \
+    int bch, bx, G;                                                                         \
+    if (pair) {                                                                             \
+        const int id = blockIdx.x, r = id >> 3;                                             \
+        G = gridDim.x / g.Cb;                                                               \
+        bch = r % g.Cb;                                                                     \
+        bx = (r / g.Cb) * 8 + (id & 7);                                                     \
+    } else {                                                                                \
+        bch = blockIdx.y; bx = blockIdx.x; G = gridDim.x;                                   \
+    }
+
 // ST = 1 (round 4): stride-1 layers with a single-channel side (the first / last layer of a max-pooling
 // architecture: im2col + a GEMM over 4 M rows before).  A frame's stages are blocks of 4 rows x 64
 // columns of the small map (any size: the blocks at the right and lower edge are masked), so the
@@ -49,7 +65,7 @@ __device__ __forceinline__ float ed_ld(__amdgpu_buffer_rsrc_t r, int byte_off) {
 template <int ST, bool VEC = false>
 __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
-    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame, int cblocks) {
+    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame, int cblocks, int pair) {
     constexpr int IH = ST * (WC_ROWS - 1) + 5, RW = ST * WC_W + 4;
     constexpr int KB = (IH * RW + ED_THREADS - 1) / ED_THREADS;
     __shared__ float sl[32 * WC_SP];
@@ -63,7 +79,8 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)big, 0, (int)((size_t)g.N * g.Cb * HWb * 4), 0x00020000);
-    const int bch = blockIdx.y;                     // big-side channel (Cb <= 4: 2-channel frames)
+    // big-side channel (Cb <= 4: 2-channel frames) and this workgroup's slot among the G of its channel
+    WC_DECODE_GRID();
 
     floatx16 acc;
 #pragma unroll
@@ -118,9 +135,9 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
     const float* bq = bl + (ST * wv + tr) * RW + ts + ST * kk;
     const float* aq = sl + li * WC_SP + wv * WC_W + kk;
 
-    int st = blockIdx.x;
+    int st = bx;
     if (st < n_stages) issue_loads(st);
-    for (; st < n_stages; st += gridDim.x) {
+    for (; st < n_stages; st += G) {
         __syncthreads();
         if (VEC) {
 #pragma unroll
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
             if (e < IH * RW) bl[e] = br[k];
         }
         __syncthreads();
-        if (st + (int)gridDim.x < n_stages) issue_loads(st + gridDim.x);
+        if (st + G < n_stages) issue_loads(st + G);
 #pragma unroll 8
         for (int t = 0; t < WC_W / 2; ++t) {
             const float av = aq[2 * t];
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
                             (red[(32 + e) * 64 + lane] + red[(48 + e) * 64 + lane]);
             const int a = (e & 3) + 8 * (e >> 2) + 4 * kk;
             if (a < g.Cs)
-                part[((size_t)bch * gridDim.x + blockIdx.x) * (g.Cs * 25) + a * 25 + li] = v;
+                part[((size_t)bch * G + bx) * (g.Cs * 25) + a * 25 + li] = v;
         }
     }
     if (bias_part && bch == 0) {
@@ -175,7 +192,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_wgrad_c1(
         if (lane < 32) red[wv * 32 + lane] = bsum;
         __syncthreads();
         if (tid < 32 && tid < g.Cs)
-            bias_part[(size_t)blockIdx.x * g.Cs + tid] =
+            bias_part[(size_t)bx * g.Cs + tid] =
                 (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
     }
 }
@@ -207,13 +224,13 @@ __device__ __forceinline__ void wd_dma16(__amdgpu_buffer_rsrc_t rsrc, float* lds
 template <bool BIAS>
 __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
-    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame) {
+    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame, int pair) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
     const int PQ = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
-    const int bch = blockIdx.y;
+    WC_DECODE_GRID();
     const bool do_bias = BIAS && bch == 0;
     // (the small side may be a window of Cs channels in frames of css: the last frame's window ends
     // the buffer range)
@@ -280,16 +297,16 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
     if (do_bias && li >= 25) bq_cur = bq_oth = 2 * WD_BUF * 4;
     const char* sm = reinterpret_cast<const char*>(wsm);
 
-    int st = blockIdx.x;
+    int st = bx;
     if (st < n_stages) {
 #pragma unroll
         for (int d = 0; d < 10; ++d) issue_dma(d, 0, st);
     }
     int cur = 0;
-    for (; st < n_stages; st += gridDim.x) {
+    for (; st < n_stages; st += G) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int nx = st + gridDim.x;
+        const int nx = st + G;
         const bool more = nx < n_stages;
 #pragma unroll
         for (int t = 0; t < WC_W / 2; ++t) {
@@ -317,8 +334,8 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
                             (red[(32 + e) * 64 + lane] + red[(48 + e) * 64 + lane]);
             const int a = (e & 3) + 8 * (e >> 2) + 4 * kk;
             if (a < g.Cs) {
-                if (li < 25) part[((size_t)bch * gridDim.x + blockIdx.x) * (g.Cs * 25) + a * 25 + li] = v;
-                else         bias_part[(size_t)blockIdx.x * g.Cs + a] = v;
+                if (li < 25) part[((size_t)bch * G + bx) * (g.Cs * 25) + a * 25 + li] = v;
+                else         bias_part[(size_t)bx * g.Cs + a] = v;
             }
         }
     }
@@ -378,13 +395,16 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
         ? (float*)ws + (size_t)g.Cb * plan.d * g.Cs * 25 : nullptr;
     if (g.CsS > 0 && g.CsS != g.Cs && !(g.pt == 1 && g.pl == 1)) return BN_E_SHAPE;   // k_wgrad_c1d only
     const bool vec = (g.Ws & 3) == 0 && (((uintptr_t)small) & 15u) == 0 && g.CsS == 0;
+    // several big-side channels: their workgroups of a stage together on one XCD (WC_DECODE_GRID)
+    const int pair = (g.Cb > 1 && (plan.d & 7) == 0) ? 1 : 0;
+    const dim3 wgrid = pair ? dim3(plan.d * g.Cb) : dim3(plan.d, g.Cb);
     if (g.stride == 1) {
         if (vec)
-            BN_LAUNCH_MAIN((k_wgrad_c1<1, true>), dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
-                               (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g));
+            BN_LAUNCH_MAIN((k_wgrad_c1<1, true>), wgrid, dim3(ED_THREADS), 0, st, small, big,
+                               (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
         else
-            BN_LAUNCH_MAIN((k_wgrad_c1<1, false>), dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
-                               (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g));
+            BN_LAUNCH_MAIN((k_wgrad_c1<1, false>), wgrid, dim3(ED_THREADS), 0, st, small, big,
+                               (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
     } else if (g.pt == 1 && g.pl == 1 && plan.variant != 1) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -397,17 +417,17 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
             attr_set = true;
         }
         if (bias_part)
-            BN_LAUNCH_MAIN(k_wgrad_c1d<true>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
-                               big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
+            BN_LAUNCH_MAIN(k_wgrad_c1d<true>, wgrid, dim3(ED_THREADS), WD_LDS, st, small,
+                               big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS, pair);
         else
-            BN_LAUNCH_MAIN(k_wgrad_c1d<false>, dim3(plan.d, g.Cb), dim3(ED_THREADS), WD_LDS, st, small,
-                               big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS);
+            BN_LAUNCH_MAIN(k_wgrad_c1d<false>, wgrid, dim3(ED_THREADS), WD_LDS, st, small,
+                               big, (float*)ws, bias_part, g, n_stages, g.Hs / WC_ROWS, pair);
     } else if (vec) {
-        BN_LAUNCH_MAIN((k_wgrad_c1<2, true>), dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
-                           (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g));
+        BN_LAUNCH_MAIN((k_wgrad_c1<2, true>), wgrid, dim3(ED_THREADS), 0, st, small, big,
+                           (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
     } else {
-        BN_LAUNCH_MAIN((k_wgrad_c1<2, false>), dim3(plan.d, g.Cb), dim3(ED_THREADS), 0, st, small, big,
-                           (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g));
+        BN_LAUNCH_MAIN((k_wgrad_c1<2, false>), wgrid, dim3(ED_THREADS), 0, st, small, big,
+                           (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
     }
     BN_LAUNCH_CHECK();
     if (bias_part) {
