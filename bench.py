@@ -139,6 +139,23 @@ def _timed(fn, warm, steps):
     return (time.perf_counter() - t0) / steps
 
 
+def _guarded(label, fn, *args, **kwargs):
+    """A secondary measurement must never cost the headline line: what goes wrong in one of them (a full /tmp
+    under the trial store, an out-of-memory in an odd geometry) is reported in ITS entry."""
+    try:
+        return fn(*args, **kwargs)
+    except Exception as err:                                    # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        except Exception:                                       # noqa: BLE001
+            pass
+        return {'config': '%s (%s)' % (label, str(args[-1])[:120] if args and isinstance(args[-1], str) else ''),
+                'value': None, 'error': '%s: %s' % (type(err).__name__, str(err)[:500])}
+
+
 def secondary_configs(hp_ae, feed_rates=True):
     """The other BASELINE configs that fit one GPU, a few steps each, all driver-run:
     configs[3] (PS-VAE training), configs[4] (encode-only from resident uint8 trials, the
@@ -199,40 +216,40 @@ def secondary_configs(hp_ae, feed_rates=True):
                              'note': 'encoder forward, algorithmic 0.3474 GFLOP/frame'}})
     del ae
     # --- the product entry point itself: fit() on the headline workload
-    out.append(fit_throughput(hp_ae))
-    out.append(export_latents_throughput(hp_ae))
+    out.append(_guarded('configs[1] through fit()', fit_throughput, hp_ae))
+    out.append(_guarded('configs[4] through export_latents()', export_latents_throughput, hp_ae))
     # --- geometries OFF the benchmark's fast paths (their cost was never measured)
     cfg = os.path.join(REPO, 'behavenet_amd', 'configs', 'ae_jsons')
-    out.append(geometry_step(os.path.join(cfg, 'ae_arch_default.json'), [1, 128, 128],
+    out.append(_guarded('geometry step', geometry_step, os.path.join(cfg, 'ae_arch_default.json'), [1, 128, 128],
                              'shipped configs/ae_jsons/ae_arch_default.json (4 layers 32-64-256-512, '
                              'k5 s2, last map 8x8) on 1x128x128'))
-    out.append(geometry_step(None, [1, 64, 48],
+    out.append(_guarded('geometry step', geometry_step, None, [1, 64, 48],
                              'default architecture on 1x64x48 frames (the reference\'s '
                              'tests/integration.py shape)'))
-    out.append(geometry_step(os.path.join(cfg, 'ae_arch_2.json'), [1, 128, 128],
+    out.append(_guarded('geometry step', geometry_step, os.path.join(cfg, 'ae_arch_2.json'), [1, 128, 128],
                              'shipped configs/ae_jsons/ae_arch_2.json (5 layers of 64 channels, k4, '
                              'strides 2,2,2,2,1) on 1x128x128'))
-    out.append(geometry_step(None, [2, 192, 160],
+    out.append(_guarded('geometry step', geometry_step, None, [2, 192, 160],
                              'default architecture on 2x192x160 frames (48x40 / 24x20 / 12x10 maps '
                              'directly on the stride-2 families since round 4; edge layers on tiles)'))
-    out.append(geometry_step(None, [1, 192, 192],
+    out.append(_guarded('geometry step', geometry_step, None, [1, 192, 192],
                              'default architecture on 1x192x192 frames (the frame size of the reference\'s '
                              'examples/msps-vae/ibl_ephys_params.json; 48x48 maps: weight gradient in '
                              'column windows)'))
-    out.append(geometry_step(None, [1, 128, 128],
+    out.append(_guarded('geometry step', geometry_step, None, [1, 128, 128],
                              'default architecture with ae_batch_norm = 1 on 1x128x128 (per-chunk '
                              'statistics inside one pass; momentum None = cumulative average, the '
                              'reference\'s default)', names=False, extra={'ae_batch_norm': True}))
-    out.append(geometry_step(os.path.join(REPO, 'tests', 'golden', 'arch_maxpool.json'), [1, 128, 128],
+    out.append(_guarded('geometry step', geometry_step, os.path.join(REPO, 'tests', 'golden', 'arch_maxpool.json'), [1, 128, 128],
                              'max-pooling test architecture (tests/golden/arch_maxpool.json: 5x5 stride-1 '
                              'conv 1 -> 16 / pool / conv 16 -> 32 / pool, mirrored unpooling decoder) on '
                              '1x128x128', names=False))
     # two architectures as the reference's random search draws them (kernel sizes 3 / 5 / 7 / 9 with equal weight,
     # models/ae_model_architecture_generator.py:94 of the reference)
-    out.append(geometry_step(os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k3.json'), [1, 128, 128],
+    out.append(_guarded('geometry step', geometry_step, os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k3.json'), [1, 128, 128],
                              'drawn architecture, all 3x3 stride 2 (32-64-128-256-512; the tap window [1, 4) of the '
                              '5x5 stride-2 families) on 1x128x128', names=False))
-    out.append(geometry_step(os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k7_k5_k9_k3.json'), [1, 128, 128],
+    out.append(_guarded('geometry step', geometry_step, os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k7_k5_k9_k3.json'), [1, 128, 128],
                              'drawn architecture, kernels 7-5-9-3 stride 2 (32-64-128-256; 7x7 / 9x9 as stride-1 5x5 '
                              'layers on the four phases of the big map, no im2col) on 1x128x128', names=False))
     if feed_rates:
@@ -328,6 +345,9 @@ def export_latents_throughput(hp_ae, n_trials=2048):
     from behavenet_amd.fitting.eval import export_latents
     tmp = tempfile.mkdtemp(prefix='bn_export_', dir='/tmp')
     try:
+        # (the store is 4.2 MB per trial: no more than a third of what /tmp has free)
+        free = shutil.disk_usage(tmp).free
+        n_trials = int(max(64, min(n_trials, free // 3 // (BATCH * int(np.prod(DIM))))))
         ids = {'lab': 'lab', 'expt': 'expt', 'animal': 'animal', 'session': 'sess'}
         sess_dir = os.path.join(tmp, 'lab', 'expt', 'animal', 'sess')
         os.makedirs(sess_dir)
@@ -1088,10 +1108,22 @@ def run(args):
         if not args.no_secondary:
             del model, opt, gen
             torch.cuda.empty_cache()
-            out['secondary'] = secondary_configs(hp)
+            try:
+                out['secondary'] = secondary_configs(hp)
+            except Exception as err:                             # noqa: BLE001 (the headline line still goes out)
+                import traceback
+                traceback.print_exc()
+                out['secondary'] = [{'config': 'secondary configurations', 'value': None,
+                                     'error': '%s: %s' % (type(err).__name__, str(err)[:500])}]
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(hp, args.cpu_budget)
-            out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+            try:
+                out['cpu_baseline'] = cpu_baseline(hp, args.cpu_budget)
+                out['speedup_vs_cpu_baseline'] = round(value / out['cpu_baseline']['value'], 1)
+            except Exception as err:                             # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                out['cpu_baseline'] = {'value': None, 'unit': 'frames/s', 'cores': 0, 'kind': 'port',
+                                       'sample': 'failed: %s: %s' % (type(err).__name__, str(err)[:300])}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
