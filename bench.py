@@ -122,6 +122,8 @@ def cpu_baseline(hp_template, budget_s=20.0):
             break
     return {'value': BATCH * steps / el, 'unit': 'frames/s', 'cores': threads,
             'kind': 'port',
+            'sample_short': '%d full training steps (batch %d, fwd+bwd+Adam) in %.1f s, %d threads' % (
+                steps, BATCH, el, threads),
             'sample': '%d full training step(s) of the same workload (batch %d, chunks 200+56, '
                       'fwd+bwd+Adam) in %.1f s, torch %s CPU, %d threads = the container\'s CPU '
                       'quota (the machine shows %d hardware threads)' % (
@@ -143,7 +145,9 @@ def _guarded(label, fn, *args, **kwargs):
     """A secondary measurement must never cost the headline line: what goes wrong in one of them (a full /tmp
     under the trial store, an out-of-memory in an odd geometry) is reported in ITS entry."""
     try:
-        return fn(*args, **kwargs)
+        got = fn(*args, **kwargs)
+        got['id'] = label
+        return got
     except Exception as err:                                    # noqa: BLE001
         import traceback
         traceback.print_exc()
@@ -152,7 +156,7 @@ def _guarded(label, fn, *args, **kwargs):
             torch.cuda.empty_cache()
         except Exception:                                       # noqa: BLE001
             pass
-        return {'config': '%s (%s)' % (label, str(args[-1])[:120] if args and isinstance(args[-1], str) else ''),
+        return {'id': label, 'config': '%s (%s)' % (label, str(args[-1])[:120] if args and isinstance(args[-1], str) else ''),
                 'value': None, 'error': '%s: %s' % (type(err).__name__, str(err)[:500])}
 
 
@@ -187,7 +191,8 @@ def secondary_configs(hp_ae, feed_rates=True):
         opt.step()
     t4 = _timed(step4, 30, 20)
     flop4 = 3 * 0.7079e9        # fwd 0.7079 GFLOP/frame, training = 3x
-    out.append({'config': 'configs[3]: PS-VAE training, 2x128x128, 16 latents, 4 labels, batch 256 '
+    out.append({'id': 'psvae_2x128x128',
+                'config': 'configs[3]: PS-VAE training, 2x128x128, 16 latents, 4 labels, batch 256 '
                           '(all 11 loss keys, decomposed KL, Adam(amsgrad))',
                 'value': round(BATCH / t4, 1), 'unit': 'frames/s', 'ms_per_step': round(t4 * 1e3, 3),
                 'steps': 20, 'roofline': {
@@ -206,7 +211,8 @@ def secondary_configs(hp_ae, feed_rates=True):
         with torch.no_grad():
             ae.encoding(xu, dataset=0)
     t5 = _timed(enc, 20, 50)
-    out.append({'config': 'configs[4] per GPU: encode-only, 1x128x128 uint8 trials of 256 frames '
+    out.append({'id': 'encode_u8',
+                'config': 'configs[4] per GPU: encode-only, 1x128x128 uint8 trials of 256 frames '
                           '(resident in HBM) -> 12 latents; uint8 -> float fused into enc.conv0',
                 'value': round(BATCH / t5, 1), 'unit': 'frames/s', 'ms_per_trial': round(t5 * 1e3, 3),
                 'steps': 50, 'seconds_per_1M_frames': round(1e6 / (BATCH / t5), 2),
@@ -216,40 +222,40 @@ def secondary_configs(hp_ae, feed_rates=True):
                              'note': 'encoder forward, algorithmic 0.3474 GFLOP/frame'}})
     del ae
     # --- the product entry point itself: fit() on the headline workload
-    out.append(_guarded('configs[1] through fit()', fit_throughput, hp_ae))
-    out.append(_guarded('configs[4] through export_latents()', export_latents_throughput, hp_ae))
+    out.append(_guarded('fit', fit_throughput, hp_ae))
+    out.append(_guarded('export_latents', export_latents_throughput, hp_ae))
     # --- geometries OFF the benchmark's fast paths (their cost was never measured)
     cfg = os.path.join(REPO, 'behavenet_amd', 'configs', 'ae_jsons')
-    out.append(_guarded('geometry step', geometry_step, os.path.join(cfg, 'ae_arch_default.json'), [1, 128, 128],
+    out.append(_guarded('ae_arch_default', geometry_step, os.path.join(cfg, 'ae_arch_default.json'), [1, 128, 128],
                              'shipped configs/ae_jsons/ae_arch_default.json (4 layers 32-64-256-512, '
                              'k5 s2, last map 8x8) on 1x128x128'))
-    out.append(_guarded('geometry step', geometry_step, None, [1, 64, 48],
+    out.append(_guarded('1x64x48', geometry_step, None, [1, 64, 48],
                              'default architecture on 1x64x48 frames (the reference\'s '
                              'tests/integration.py shape)'))
-    out.append(_guarded('geometry step', geometry_step, os.path.join(cfg, 'ae_arch_2.json'), [1, 128, 128],
+    out.append(_guarded('ae_arch_2', geometry_step, os.path.join(cfg, 'ae_arch_2.json'), [1, 128, 128],
                              'shipped configs/ae_jsons/ae_arch_2.json (5 layers of 64 channels, k4, '
                              'strides 2,2,2,2,1) on 1x128x128'))
-    out.append(_guarded('geometry step', geometry_step, None, [2, 192, 160],
+    out.append(_guarded('2x192x160', geometry_step, None, [2, 192, 160],
                              'default architecture on 2x192x160 frames (48x40 / 24x20 / 12x10 maps '
                              'directly on the stride-2 families since round 4; edge layers on tiles)'))
-    out.append(_guarded('geometry step', geometry_step, None, [1, 192, 192],
+    out.append(_guarded('1x192x192', geometry_step, None, [1, 192, 192],
                              'default architecture on 1x192x192 frames (the frame size of the reference\'s '
                              'examples/msps-vae/ibl_ephys_params.json; 48x48 maps: weight gradient in '
                              'column windows)'))
-    out.append(_guarded('geometry step', geometry_step, None, [1, 128, 128],
+    out.append(_guarded('batch_norm', geometry_step, None, [1, 128, 128],
                              'default architecture with ae_batch_norm = 1 on 1x128x128 (per-chunk '
                              'statistics inside one pass; momentum None = cumulative average, the '
                              'reference\'s default)', names=False, extra={'ae_batch_norm': True}))
-    out.append(_guarded('geometry step', geometry_step, os.path.join(REPO, 'tests', 'golden', 'arch_maxpool.json'), [1, 128, 128],
+    out.append(_guarded('maxpool', geometry_step, os.path.join(REPO, 'tests', 'golden', 'arch_maxpool.json'), [1, 128, 128],
                              'max-pooling test architecture (tests/golden/arch_maxpool.json: 5x5 stride-1 '
                              'conv 1 -> 16 / pool / conv 16 -> 32 / pool, mirrored unpooling decoder) on '
                              '1x128x128', names=False))
     # two architectures as the reference's random search draws them (kernel sizes 3 / 5 / 7 / 9 with equal weight,
     # models/ae_model_architecture_generator.py:94 of the reference)
-    out.append(_guarded('geometry step', geometry_step, os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k3.json'), [1, 128, 128],
+    out.append(_guarded('all_3x3', geometry_step, os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k3.json'), [1, 128, 128],
                              'drawn architecture, all 3x3 stride 2 (32-64-128-256-512; the tap window [1, 4) of the '
                              '5x5 stride-2 families) on 1x128x128', names=False))
-    out.append(_guarded('geometry step', geometry_step, os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k7_k5_k9_k3.json'), [1, 128, 128],
+    out.append(_guarded('k7_5_9_3', geometry_step, os.path.join(REPO, 'tools', 'arch_jsons', 'drawn_k7_k5_k9_k3.json'), [1, 128, 128],
                              'drawn architecture, kernels 7-5-9-3 stride 2 (32-64-128-256; 7x7 / 9x9 as stride-1 5x5 '
                              'layers on the four phases of the big map, no im2col) on 1x128x128', names=False))
     if feed_rates:
@@ -263,7 +269,7 @@ def secondary_configs(hp_ae, feed_rates=True):
         np.random.seed(1)
         gen.reset_iterators('train')
         tp = _timed(lambda: one_step(model, opt, gen), 20, 20)
-        out.append({'config': 'configs[1] fed over PCIe: same training step, trials in pinned host '
+        out.append({'id': 'pcie_fed', 'config': 'configs[1] fed over PCIe: same training step, trials in pinned host '
                               'memory as uint8 (4.2 MB each), copied one trial ahead on a copy stream',
                     'value': round(BATCH / tp, 1), 'unit': 'frames/s',
                     'ms_per_step': round(tp * 1e3, 3), 'steps': 20})
@@ -496,6 +502,93 @@ def geometry_step(arch_json, dim, label, batch=256, names=True, extra=None):
             'dispatched_kernels': kernels}
 
 
+LINE_LIMIT = 4096     # the driver keeps a bounded tail of stdout: the result line stays far below it
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + '...'
+
+
+def compact_line(full):
+    """The ONE line for stdout (< LINE_LIMIT characters) out of the full result dict: the contract's keys,
+    `roofline` and `cpu_baseline` in numbers, `secondary` as {id, value, ms_per_step, frac}.  Everything
+    else (kernel tables, prose, per-layer rooflines) goes to the detail file (`write_detail`)."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+            'scaling', 'vs_baseline', 'dtype', 'data', 'hip_graph', 'final_loss', 'error', 'rank')
+    line = {k: full[k] for k in keep if k in full}
+    cfg = full.get('config') or {}
+    line['config'] = {'workload': _short(cfg.get('workload_short') or cfg.get('workload', ''), 160)}
+    for k in ('frames_per_step_per_gpu', 'global_frames_per_step'):
+        if k in cfg:
+            line['config'][k] = cfg[k]
+    if full.get('n_gpus', 1) > 1 and cfg.get('sharding'):
+        line['config']['sharding'] = _short(cfg['sharding'], 60)
+    roof = full.get('roofline')
+    if roof:
+        line['roofline'] = {k: roof.get(k) for k in (
+            'bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us',
+            'algorithmic_bytes_per_launch_avg', 'traffic')}
+        line['roofline']['kernel'] = _short(line['roofline']['kernel'], 48)
+    if 'whole_step_fp32_frac' in full:
+        line['whole_step_fp32_frac'] = full['whole_step_fp32_frac']
+    cpu = full.get('cpu_baseline')
+    if cpu:
+        line['cpu_baseline'] = {'value': None if cpu.get('value') is None else round(cpu['value'], 2),
+                                'unit': cpu.get('unit'), 'cores': cpu.get('cores'), 'kind': cpu.get('kind'),
+                                'sample': _short(cpu.get('sample_short') or cpu.get('sample', ''), 100)}
+        if 'speedup_vs_cpu_baseline' in full:
+            line['speedup_vs_cpu_baseline'] = full['speedup_vs_cpu_baseline']
+    ar = full.get('allreduce')
+    if ar:
+        line['allreduce'] = {k: ar[k] for k in (
+            'world_size', 'backend', 'op', 'gradient_bytes', 'allreduce_alone_ms', 'shard_optimizer',
+            'ms_per_step_overlapped', 'ms_per_step_behind') if k in ar}
+        line['allreduce']['chosen'] = _short(ar.get('chosen', ''), 48)
+        ref = ar.get('single_gpu_reference')
+        if ref:
+            line['allreduce']['single_gpu_ms_per_step_max'] = ref.get('ms_per_step_max')
+    sec = full.get('secondary')
+    if sec:
+        rows = []
+        for s in sec:
+            row = {'id': _short(s.get('id', '?'), 24), 'value': s.get('value')}
+            ms = s.get('ms_per_step', s.get('ms_per_trial'))
+            if ms is not None:
+                row['ms_per_step'] = ms
+            if isinstance(s.get('roofline'), dict):
+                row['frac'] = s['roofline'].get('frac')
+            if s.get('error'):
+                row['error'] = _short(s['error'], 60)
+            rows.append(row)
+        line['secondary'] = rows
+    if full.get('detail_file'):
+        line['detail_file'] = full['detail_file']
+    text = json.dumps(line, separators=(',', ':'))
+    # (belt and braces: whatever grew, the headline keys go out)
+    for drop in ('secondary', 'allreduce', 'detail_file'):
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(',', ':'))
+    return text
+
+
+def write_detail(full):
+    """The full result (kernel tables, per-layer rooflines, prose) -> gpurun_out/bench_detail.json (N = 1) or
+    bench_detail_n<N>.json; returns the path relative to the repository, or None when it cannot be written."""
+    n = full.get('n_gpus', 1)
+    rel = os.environ.get('BN_BENCH_DETAIL') or os.path.join(
+        'gpurun_out', 'bench_detail.json' if n == 1 else 'bench_detail_n%d.json' % n)
+    try:
+        os.makedirs(os.path.dirname(os.path.join(REPO, rel)), exist_ok=True)
+        with open(os.path.join(REPO, rel), 'w') as f:
+            json.dump(full, f, indent=1)
+        return rel
+    except OSError:
+        return None
+
+
 def profile_kernel(model, opt, gen, family, C, K, steps=2):
     """HIP-event time of one kernel family/geometry over a few extra steps: per call (everything it
     launches, bracketed on the stream) and of its main kernel alone (events attached to the dispatch
@@ -512,7 +605,7 @@ def profile_kernel(model, opt, gen, family, C, K, steps=2):
 
 def error_line(message, **extra):
     """The one JSON line of a run that failed: same metric name, no value, an ``error`` string."""
-    out = {'metric': METRIC, 'value': None, 'unit': 'frames/s', 'error': str(message)[:2000]}
+    out = {'metric': METRIC, 'value': None, 'unit': 'frames/s', 'error': str(message)[:1500]}
     out.update(extra)
     return json.dumps(out)
 
@@ -654,6 +747,9 @@ def main():
                     help="where the trials live (default 'device': resident float32, the headline "
                          "metric; 'host_u8' = pinned uint8 + prefetch, the PCIe-inclusive rate)")
     ap.add_argument('--cpu-budget', type=float, default=20.0)
+    ap.add_argument('--full-line', action='store_true',
+                    help='print the full result (kernel tables, per-layer rooflines: ~20 KB) on the line instead of '
+                         'the compact one -- for tools/ab_*.sh; the driver-facing default stays below 4 KB')
     ap.add_argument('--shard-optimizer', dest='shard_optimizer', action='store_true', default=None,
                     help='N > 1: reduce-scatter -> Adam on 1/N of the arena per rank -> all-gather, instead '
                          'of the overlapped bucketed all-reduce + N identical steps (default: on for '
@@ -1013,7 +1109,9 @@ def run(args):
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
-        'config': {'workload': 'configs[1]: conv AE (default arch 32-64-128-256-512, k5, strides '
+        'config': {'workload_short': 'configs[1]: conv AE default arch, 1x128x128 f32 frames resident in HBM, 12 latents, '
+                                     'batch 256 (chunks 200+56), fwd+bwd+Adam(amsgrad)',
+                   'workload': 'configs[1]: conv AE (default arch 32-64-128-256-512, k5, strides '
                                '2,2,2,2,5), 1x128x128 uint8-noise frames as float32/255, 12 '
                                'latents, one 256-frame trial per step per GPU (the reference\'s 200+56 '
                                'chunk loss normalisation; one forward/backward pass), '
@@ -1113,7 +1211,7 @@ def run(args):
             except Exception as err:                             # noqa: BLE001 (the headline line still goes out)
                 import traceback
                 traceback.print_exc()
-                out['secondary'] = [{'config': 'secondary configurations', 'value': None,
+                out['secondary'] = [{'id': 'secondary', 'config': 'secondary configurations', 'value': None,
                                      'error': '%s: %s' % (type(err).__name__, str(err)[:500])}]
         if not args.no_cpu_baseline:
             try:
@@ -1126,7 +1224,9 @@ def run(args):
                                        'sample': 'failed: %s: %s' % (type(err).__name__, str(err)[:300])}
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        out['detail_file'] = write_detail(out)
+        sys.stderr.flush()
+        print(json.dumps(out) if args.full_line else compact_line(out), flush=True)
     if dog is not None:
         dog.stop()
     if bdist.is_active():

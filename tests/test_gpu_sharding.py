@@ -384,6 +384,7 @@ def test_fit_in_frames_mode_matches_single_process(two_rank_dir, tmp_path):
 
 def _bench_line(cmd, env, tmp_path, limit_s=240):
     log = os.path.join(str(tmp_path), 'bench_%d.log' % len(os.listdir(str(tmp_path))))
+    env = dict(env, BN_BENCH_DETAIL=log + '.detail.json')
     with open(log, 'wb') as f:
         proc = subprocess.Popen(cmd, env=env, cwd=REPO, stdout=f, stderr=subprocess.STDOUT,
                                 stdin=subprocess.DEVNULL, start_new_session=True)
@@ -392,7 +393,12 @@ def _bench_line(cmd, env, tmp_path, limit_s=240):
         out = f.read()
     lines = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, out[-3000:]
-    return json.loads(lines[0])
+    # the line the driver parses stays small; the full record sits in the detail file it names
+    assert len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    with open(os.path.join(REPO, d['detail_file'])) as f:
+        d['detail'] = json.load(f)
+    return d
 
 
 @pytest.mark.parametrize('launcher', ['torchrun', 'self'])
@@ -419,7 +425,7 @@ def test_bench_two_ranks_control_flow(launcher, tmp_path):
     ar = d['allreduce']
     assert ar['world_size'] == 2 and ar['backend'].startswith('gloo') and ar['op'] == 'mean'
     # (the flat arena pads every parameter to 16 bytes)
-    assert sum(ar['bucket_bytes']) == ar['gradient_bytes']
+    assert sum(d['detail']['allreduce']['bucket_bytes']) == ar['gradient_bytes']
     assert 8758285 * 4 <= ar['gradient_bytes'] <= 8758285 * 4 + 16 * 24
     assert ar['allreduce_alone_ms'] > 0
 
@@ -508,6 +514,8 @@ def test_bench_four_ranks_frame_sharded_defaults(tmp_path):
     ar = d4['allreduce']
     assert ar['shard_optimizer'] is True and ar['world_size'] == 4 and ar['op'] == 'sum'
     assert ar['gradient_bytes'] % (4 * 16) == 0
-    assert len(ar['devices']) == 4 and len(ar['single_gpu_reference']['ms_per_step_per_rank']) == 4
+    full = d4['detail']['allreduce']
+    assert len(full['devices']) == 4 and len(full['single_gpu_reference']['ms_per_step_per_rank']) == 4
+    assert ar['single_gpu_ms_per_step_max'] == full['single_gpu_reference']['ms_per_step_max']
     assert d4['config']['frames_per_step_per_gpu'] == 64
     assert d4['final_loss'] == pytest.approx(d1['final_loss'], rel=1e-4)
