@@ -79,8 +79,9 @@ def init_from_env(backend=None, timeout_s=None, rendezvous_timeout_s=None):
             'nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        # a collective that times out (or a peer that died) raises on this rank instead of
-        # leaving it spinning inside a kernel
+        # a collective that times out (or a peer that died) takes this rank's PROCESS down (mode 1 =
+        # tear down: it does not raise) instead of leaving it spinning inside a kernel; the launcher
+        # then stops the peers (bench.py's SIGTERM handler / watchdog print the error line)
         os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
     if timeout_s is None:
         timeout_s = float(os.environ.get('BN_DIST_TIMEOUT_S', '1800'))
@@ -92,9 +93,10 @@ def init_from_env(backend=None, timeout_s=None, rendezvous_timeout_s=None):
     # serves a store on MASTER_PORT (TORCHELASTIC_USE_AGENT_STORE): every worker is a client of it,
     # with a per-attempt key prefix, as torch's own env:// handler does
     agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '') == 'True'
-    store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), ws,
-                          (r == 0) and not agent_store,
-                          timeout=datetime.timedelta(seconds=float(rendezvous_timeout_s)))
+    tcp_store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), ws,
+                              (r == 0) and not agent_store,
+                              timeout=datetime.timedelta(seconds=float(rendezvous_timeout_s)))
+    store = tcp_store
     if agent_store:
         store = dist.PrefixStore('/bn/attempt_%s' % os.environ.get('TORCHELASTIC_RESTART_COUNT', '0'),
                                  store)
@@ -110,6 +112,13 @@ def init_from_env(backend=None, timeout_s=None, rendezvous_timeout_s=None):
             raise RuntimeError('rendezvous: %d of %d ranks came up within %.0f s' % (
                 int(store.add('bn_ranks_up', 0)), ws, float(rendezvous_timeout_s)))
         time.sleep(0.01)
+    # from here on the store carries the COLLECTIVE limit: torch only calls set_timeout on a store it
+    # made itself, and the store-backed waits that come later (the lazy RCCL communicator bootstrap at
+    # the first collective, new_group, gloo pair set-up) would otherwise keep the short rendezvous
+    # limit -- ranks that reach their first collective more than two minutes apart (rank 0 in
+    # create_experiment, one rank compiling the library) aborted the job
+    for s in {id(tcp_store): tcp_store, id(store): store}.values():
+        s.set_timeout(datetime.timedelta(seconds=float(timeout_s)))
     return rank(), world_size()
 
 
