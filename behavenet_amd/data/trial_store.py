@@ -13,6 +13,7 @@ same key space:
 """
 
 import os
+import threading
 import zipfile
 
 import numpy as np
@@ -41,7 +42,12 @@ class _NpzStore(object):
         for zi in self._npz.zip.infolist():
             self._info[zi.filename] = zi
         self._layout = {}
-        self._fd = None
+        # opened here, not on first use: the reader pool calls layout() / read_into() from several threads
+        # (two of them opening at once leaked a descriptor per store)
+        self._fd = os.open(self.path, os.O_RDONLY)
+        self._lock = threading.Lock()
+        self._readers = 0                   # preadv calls in flight
+        self._idle = threading.Condition(self._lock)
 
     def signals(self):
         return sorted(self._members)
@@ -58,7 +64,7 @@ class _NpzStore(object):
         zi = self._info.get(key + '.npy')
         if zi is not None and zi.compress_type == zipfile.ZIP_STORED:
             if self._fd is None:
-                self._fd = os.open(self.path, os.O_RDONLY)
+                raise ValueError('%s: trial store is closed' % self.path)
             head = os.pread(self._fd, 30, zi.header_offset)
             if len(head) == 30 and head[:4] == b'PK\x03\x04':
                 n_name = int.from_bytes(head[26:28], 'little')
@@ -99,11 +105,21 @@ class _NpzStore(object):
                 out.dtype, out.shape, dtype, shape))
         view = memoryview(out).cast('B')
         done, total = 0, view.nbytes
-        while done < total:
-            n = os.preadv(self._fd, [view[done:]], offset + done)
-            if n <= 0:
-                raise IOError('%s: short read of %s' % (self.path, key))
-            done += n
+        with self._lock:
+            if self._fd is None:
+                raise ValueError('%s: trial store is closed' % self.path)
+            fd = self._fd
+            self._readers += 1
+        try:
+            while done < total:
+                n = os.preadv(fd, [view[done:]], offset + done)
+                if n <= 0:
+                    raise IOError('%s: short read of %s' % (self.path, key))
+                done += n
+        finally:
+            with self._idle:
+                self._readers -= 1
+                self._idle.notify_all()
         return out
 
     def read(self, signal, trial):
@@ -113,10 +129,14 @@ class _NpzStore(object):
         return self.read_into(signal, trial, np.empty(lay[1], dtype=lay[0]))
 
     def close(self):
+        """Waits for the reads in flight (a reader thread inside ``preadv``) before the descriptor goes."""
+        with self._idle:
+            fd, self._fd = self._fd, None
+            while self._readers:
+                self._idle.wait()
         self._npz.close()
-        if self._fd is not None:
-            os.close(self._fd)
-            self._fd = None
+        if fd is not None:
+            os.close(fd)
 
 
 class _Hdf5Store(object):

@@ -166,7 +166,10 @@ def export_latents(data_generator, model, filename=None):
             for _ in range(n_batches):
                 data, sess = data_generator.next_batch(dtype, **single, **skip)
                 if data is None:
-                    break
+                    # the generator ran dry before its own count: latents of the remaining trials would be
+                    # exported EMPTY without a word
+                    raise RuntimeError('export_latents: the generator ended after %d of %d %s batches'
+                                       % (_, n_batches, dtype))
                 if not isinstance(data, dict):       # SKIPPED: another rank's trial
                     continue
                 idx = data['batch_idx']

@@ -120,6 +120,7 @@ class GraphedLoss(object):
                 self.n_eager += 1
                 return self.model.loss(data, dataset=dataset, accumulate_grad=accumulate_grad)
             rec = self._record(key, data, dataset, accumulate_grad)
+            self._compare_with_peers(rec is not None)
             if rec is None:
                 self.n_eager += 1
                 return self.model.loss(data, dataset=dataset, accumulate_grad=accumulate_grad)
@@ -136,6 +137,25 @@ class GraphedLoss(object):
             # sum over ranks is the one collective of the step, issued here, behind the replay
             tensors = [None if t is None else bdist.all_reduce_(t.clone()) for t in tensors]
         return LazyLoss([None if t is None else hf.Readback(t) for t in tensors], d.fn)
+
+    # ------------------------------------------------------------------------------------------
+    def _compare_with_peers(self, recorded):
+        """Real ranks record at the same step (same warm-up count, same signatures).  A rank whose capture
+        failed keeps launching eagerly while its peers replay: the collectives still line up (the loss-table
+        all-reduce sits behind the backward pass either way), but the job then runs at the eager rank's pace
+        -- say so on every rank instead of leaving a slow job unexplained."""
+        self.peers_recorded = None
+        if not bdist.is_active() or bdist._emulated is not None or not bdist.frames_sharded():
+            return
+        import torch.distributed as dist
+        flags = [None] * dist.get_world_size()
+        dist.all_gather_object(flags, bool(recorded))
+        self.peers_recorded = flags
+        if any(flags) and not all(flags):
+            warnings.warn('HIP graph of the frame-sharded step: ranks %s replay a graph, ranks %s stayed on eager '
+                          'launches (capture failed there); results are the same, the step runs at the eager '
+                          'ranks\' pace' % ([r for r, f in enumerate(flags) if f],
+                                            [r for r, f in enumerate(flags) if not f]))
 
     # ------------------------------------------------------------------------------------------
     def _record(self, key, data, dataset, accumulate_grad):
@@ -158,7 +178,11 @@ class GraphedLoss(object):
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         hf._capturing = True
+        # test hook: BN_GRAPH_FAULT_RANK=<r> -- that rank's capture fails (mixed eager / replaying ranks)
+        fault = os.environ.get('BN_GRAPH_FAULT_RANK')
         try:
+            if fault is not None and bdist.is_active() and int(fault) == bdist.rank():
+                raise RuntimeError('injected capture failure (BN_GRAPH_FAULT_RANK)')
             # thread_local: the data generator's prefetch thread may be copying on its own stream
             with torch.cuda.graph(graph, pool=self._pool, capture_error_mode='thread_local'):
                 out = self.model.loss(static, dataset=dataset, accumulate_grad=accumulate_grad)

@@ -20,6 +20,8 @@ reference's Python surface:
 
 import copy
 import os
+import sys
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -176,13 +178,17 @@ class _CheckpointWriter(object):
         self._plan = None           # (dtype, ((key, shape), ...)) groups the flat buffers were laid out for
         self._flat = {}             # dtype -> (flat device buffer, flat pinned host buffer)
 
-    def wait(self):
+    def wait(self, reraise=True):
+        """Join the write in flight; its failure (disk full, pickling error) is raised here -- or, with
+        ``reraise=False`` (fit() is already on its way out with another exception), only dropped: the
+        thread has reported it on stderr when it happened."""
         if self._thread is not None:
             self._thread.join()
             self._thread = None
         if self._error is not None:
             err, self._error = self._error, None
-            raise err
+            if reraise:
+                raise err
 
     def save(self, model, path):
         from behavenet_amd.models.base import BaseModel
@@ -242,12 +248,17 @@ class _CheckpointWriter(object):
         # (the next save's packing copy cannot overtake this transfer: save() starts with wait(), and the
         # writer thread has waited for `done` by then)
         on_host = {k: state[k].detach().clone() for k in names if not state[k].is_cuda}
+        metadata = getattr(state, '_metadata', None)
         flats = {dt: pair[1] for dt, pair in self._flat.items()}
 
         def write():
             try:
                 done.synchronize()
-                out = {}
+                # the structure BaseModel.save writes: an OrderedDict that carries the modules' version
+                # metadata (the file must not depend on which of the two paths wrote it)
+                out = OrderedDict()
+                if metadata is not None:
+                    out._metadata = metadata
                 for k in names:
                     if k in layout:
                         dt, pos, n, shape = layout[k]
@@ -259,6 +270,9 @@ class _CheckpointWriter(object):
                 os.replace(tmp, path)
             except BaseException as err:            # noqa: BLE001 (re-raised by wait())
                 self._error = err
+                # said at once: if fit() fails before its next save() / wait(), nobody would hear of it
+                print('checkpoint writer: %s was NOT written (%s: %s)' % (path, type(err).__name__, err),
+                      file=sys.stderr, flush=True)
         self._thread = threading.Thread(target=write, name='bn-checkpoint', daemon=False)
         self._thread.start()
 
@@ -303,6 +317,20 @@ def _progress(iterable, enabled):
         return iterable
 
 
+def _log_rows(exp, logger, dtype, i_epoch, i_batch, dataset, n_datasets, best_epoch):
+    """The metric rows of one check (ref training.py:358-368 train, :400-417 val): the row pooled over
+    sessions (dataset -1), then -- when several sessions are fit and batches come from one session at a
+    time -- one row per session; ``dataset`` is what the last ``next_batch`` returned."""
+    single = dataset is not None and (isinstance(dataset, int) or len(dataset) == 1)
+    targets = [(-1, False)]
+    if n_datasets > 1 and single:
+        targets.extend((d, True) for d in range(n_datasets))
+    for d, per_session in targets:
+        exp.log(logger.create_metric_row(dtype, i_epoch, i_batch, d, trial=-1, by_dataset=per_session,
+                                         best_epoch=best_epoch))
+    exp.save()
+
+
 def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
     """Fit a model with Adam(amsgrad) SGD and early stopping (ref training.py:244-461).
 
@@ -315,13 +343,23 @@ def fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
     """
     from behavenet_amd import hip_functions as hf
     prev = hf.set_lazy_losses(bool(hparams.get('lazy_losses', True)))
+    # checkpoints leave through a background writer unless hparams['async_checkpoint'] is False
+    writer = _CheckpointWriter() if hparams.get('async_checkpoint', True) else None
     try:
-        return _fit(hparams, model, data_generator, exp, method=method, optimizer=optimizer)
+        out = _fit(hparams, model, data_generator, exp, method=method, optimizer=optimizer, writer=writer)
+    except BaseException:
+        if writer is not None:
+            writer.wait(reraise=False)          # a write in flight still finishes: the best model so far stays valid
+        raise
+    else:
+        if writer is not None:
+            writer.wait()                       # the checkpoint files are complete before fit() returns
+        return out
     finally:
         hf.set_lazy_losses(prev)
 
 
-def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
+def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None, writer=None):
     if hparams.get('dp_shard') is not None:
         bdist.set_shard_mode(hparams['dp_shard'])
     # hparams['shard_optimizer'] (BN_SHARD_OPTIMIZER=0/1): reduce-scatter -> Adam on this rank's 1/R
@@ -387,8 +425,6 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
     best_val_epoch = None
     best_val_model = None
     best_model_saved = False
-    # checkpoints leave through a background writer unless hparams['async_checkpoint'] is False
-    writer = _CheckpointWriter() if hparams.get('async_checkpoint', True) else None
 
     if hparams.get('rng_seed_train', None) is None:
         rng_train = np.random.randint(0, 10000)
@@ -462,16 +498,8 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
             if (i_train + 1) % n_train == 0:
                 if trial_mode:
                     _merge_rank_metrics(logger, 'train')
-                exp.log(logger.create_metric_row(
-                    'train', i_epoch, i_train, -1, trial=-1,
-                    by_dataset=False, best_epoch=best_val_epoch))
-                if data_generator.n_datasets > 1 and dataset is not None and \
-                        (isinstance(dataset, int) or len(dataset) == 1):
-                    for dataset in range(data_generator.n_datasets):
-                        exp.log(logger.create_metric_row(
-                            'train', i_epoch, i_train, dataset, trial=-1,
-                            by_dataset=True, best_epoch=best_val_epoch))
-                exp.save()
+                _log_rows(exp, logger, 'train', i_epoch, i_train, dataset, data_generator.n_datasets,
+                          best_val_epoch)
 
             curr_batch = (i_train + 1) + i_epoch * n_train
             if np.any(curr_batch == val_check_batch):
@@ -491,16 +519,8 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None):
                     best_val_model = _snapshot(model, hparams, into=best_val_model)
                     best_val_epoch = i_epoch
 
-                exp.log(logger.create_metric_row(
-                    'val', i_epoch, i_train, -1, trial=-1,
-                    by_dataset=False, best_epoch=best_val_epoch))
-                if data_generator.n_datasets > 1 and \
-                        (isinstance(dataset, int) or len(dataset) == 1):
-                    for dataset in range(data_generator.n_datasets):
-                        exp.log(logger.create_metric_row(
-                            'val', i_epoch, i_train, dataset, trial=-1,
-                            by_dataset=True, best_epoch=best_val_epoch))
-                exp.save()
+                _log_rows(exp, logger, 'val', i_epoch, i_train, dataset, data_generator.n_datasets,
+                          best_val_epoch)
 
         if hparams['enable_early_stop']:
             early_stop.on_val_check(i_epoch, logger.get_loss('val'))

@@ -863,24 +863,26 @@ class AEMSP(AE):
     graph_capturable = False
 
     def __init__(self, hparams):
+        n_lat, n_lab = hparams['n_ae_latents'], hparams['n_labels']
         if hparams['model_type'] == 'linear':
             raise NotImplementedError
-        if hparams['n_ae_latents'] < hparams['n_labels']:
+        if n_lab > n_lat:
             raise ValueError('AEMSP model must contain at least as many latents as labels')
-        self.n_latents = hparams['n_ae_latents']
-        self.n_labels = hparams['n_labels']
-        self.projection = None
-        self.U = None
+        # P (`projection`: latents -> labels) and U (`U`: latents <-> transformed latents) are made by
+        # build_model, which the base constructor calls; nn.Module wants the names to exist before that
+        self.n_latents, self.n_labels = n_lat, n_lab
+        self.projection = self.U = None
         super().__init__(hparams)
 
     def build_model(self):
-        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
-        self.encoding = ConvAEEncoder(self.hparams)
-        self.decoding = ConvAEDecoder(self.hparams)
-        self.projection = nn.Linear(self.n_latents, self.n_labels, bias=False)
-        # in the state dict from the start, overwritten by create_orthogonal_matrix (ref :950-954)
-        with torch.no_grad():
-            self.U = nn.Linear(self.n_latents, self.n_latents, bias=False)
+        hp = self.hparams
+        hp['hidden_layer_size'] = hp['n_ae_latents']
+        # construction order = the order the seeded generator is consumed in (ref :943-950): conv encoder,
+        # conv decoder, P, then U -- U only so that its key is in the state dict from the start
+        # (create_orthogonal_matrix replaces its weight)
+        self.encoding, self.decoding = ConvAEEncoder(hp), ConvAEDecoder(hp)
+        heads = [nn.Linear(self.n_latents, n_out, bias=False) for n_out in (self.n_labels, self.n_latents)]
+        self.projection, self.U = heads
 
     def _chunk_streams_ok(self):
         return False     # `projection` is used twice per chunk and accumulates through torch
@@ -997,25 +999,20 @@ class AEMSP(AE):
         super().save(filepath)
 
     def create_orthogonal_matrix(self):
-        """U = [P; null_space(P)^T] (ref :1067-1080)."""
+        """U = the rows of P stacked on an orthonormal basis of P's null space (ref :1067-1080; scipy's
+        ``null_space`` on the float32 matrix, as there, so that the basis -- any would do -- is the same one)."""
         from scipy.linalg import null_space
-        M = self.projection.weight.data.detach().cpu().numpy()
-        N = null_space(M)
-        U = np.concatenate([M, N.T], axis=0)
-        with torch.no_grad():
-            self.U.weight = nn.Parameter(torch.from_numpy(U).float(), requires_grad=False)
-        self.U.to(self.hparams['device'])
+        P = self.projection.weight.detach().cpu().numpy()
+        complement = null_space(P).T                           # (n_latents - n_labels, n_latents)
+        full = torch.from_numpy(np.vstack((P, complement))).to(torch.float32)
+        self.U.weight = nn.Parameter(full.to(self.hparams['device']), requires_grad=False)
 
     def get_transformed_latents(self, inputs, dataset=None, as_numpy=True):
-        """Latents in the transformed space U z (ref :1082-1122); images or latents in."""
-        if not isinstance(inputs, torch.Tensor):
-            inputs = torch.Tensor(inputs)
-        if len(inputs.shape) == 2:
-            latents_og = inputs
-        else:
-            latents_og, _, _ = self.encoding(inputs, dataset=dataset)
-        latents_tr = linear(latents_og, self.U.weight, None)
-        return latents_tr.cpu().detach().numpy() if as_numpy else latents_tr
+        """U z (ref :1082-1122) of latents (2-d input) or of the latents of images (anything else)."""
+        t = inputs if torch.is_tensor(inputs) else torch.Tensor(inputs)
+        z = t if t.dim() == 2 else self.encoding(t, dataset=dataset)[0]
+        out = linear(z, self.U.weight, None)
+        return out.detach().cpu().numpy() if as_numpy else out
 
     def get_inverse_transformed_latents(self, latents, as_numpy=True):
         """Back to the original latent space: latents U (ref :1124-1146)."""

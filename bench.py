@@ -1131,6 +1131,7 @@ def run(args):
                               'host': 'pinned host float32, copied per batch'}[args.feed]},
         'allreduce': allreduce_mode,
         'hip_graph': bool(_LOSS is not None and _LOSS.n_replays > 0),
+        'hip_graph_ranks_recorded': getattr(_LOSS, 'peers_recorded', None),
         'final_loss': last['loss'] if last else None,
         'whole_step_fp32_tflops_per_gpu': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12, 2),
         'whole_step_fp32_frac': round(TRAIN_FLOP_PER_FRAME * value / world / 1e12 /

@@ -519,3 +519,18 @@ def test_bench_four_ranks_frame_sharded_defaults(tmp_path):
     assert ar['single_gpu_ms_per_step_max'] == full['single_gpu_reference']['ms_per_step_max']
     assert d4['config']['frames_per_step_per_gpu'] == 64
     assert d4['final_loss'] == pytest.approx(d1['final_loss'], rel=1e-4)
+
+
+def test_bench_two_ranks_frame_sharded_mixed_graph_and_eager(tmp_path):
+    """a rank whose graph capture fails keeps launching eagerly while its peer replays (BN_GRAPH_FAULT_RANK:
+    rank 1's capture raises).  The collectives must still line up -- the job ends, reports the single-device loss --
+    and the record says which ranks replay."""
+    env = _child_env(BN_DIST_BACKEND='gloo', BN_BENCH_PRIME='24', BN_GRAPH='1', BN_GRAPH_FAULT_RANK='1')
+    tail = ['--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary', '--no-pmc']
+    d2 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--shard', 'frames'] + tail,
+                     env, tmp_path, limit_s=400)
+    env1 = _child_env(BN_DIST_BACKEND='gloo', BN_BENCH_PRIME='24')
+    d1 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1'] + tail, env1, tmp_path)
+    assert d2['n_gpus'] == 2 and d2['hip_graph'] is True
+    assert d2['detail']['hip_graph_ranks_recorded'] == [True, False]
+    assert d2['final_loss'] == pytest.approx(d1['final_loss'], rel=1e-4)
