@@ -19,13 +19,60 @@ struct BnChunks {
     int beg[BNK_MAX_CHUNKS], end[BNK_MAX_CHUNKS];
     float scale[BNK_MAX_CHUNKS];          // per-chunk factor (1 / count, running-estimate factor, ...)
     float aux[BNK_MAX_CHUNKS];            // second per-chunk factor (unbiasing)
+    // frame slices of the (channel, slice) grids: chunk z owns the global slices [sl_beg[z], sl_beg[z] + sl_n[z]),
+    // their number proportional to the chunk's length (round 6: with S slices PER chunk the 56-frame chunk's
+    // workgroups finished in a quarter of the time of the 200-frame chunk's and left the tail half empty)
+    int sl_beg[BNK_MAX_CHUNKS], sl_n[BNK_MAX_CHUNKS];
 };
 static BnChunks bnk_one_chunk(int N, float scale = 1.f, float aux = 1.f) {
     BnChunks ch;
     ch.n = 1;
-    for (int i = 0; i < BNK_MAX_CHUNKS; ++i) { ch.beg[i] = 0; ch.end[i] = 0; ch.scale[i] = scale; ch.aux[i] = aux; }
+    for (int i = 0; i < BNK_MAX_CHUNKS; ++i) {
+        ch.beg[i] = 0; ch.end[i] = 0; ch.scale[i] = scale; ch.aux[i] = aux; ch.sl_beg[i] = 0; ch.sl_n[i] = 0;
+    }
     ch.end[0] = N;
     return ch;
+}
+// S slices in total over the chunks, by length, at least one each, none longer than its chunk; -> the total
+static int bnk_set_slices(BnChunks* ch, int S) {
+    int N = 0;
+    for (int z = 0; z < ch->n; ++z) N += ch->end[z] - ch->beg[z];
+    if (S < ch->n) S = ch->n;
+    int used = 0;
+    for (int z = 0; z < ch->n; ++z) {
+        const int len = ch->end[z] - ch->beg[z];
+        int k = N > 0 ? (int)(((long)S * len + N / 2) / N) : 1;
+        if (k < 1) k = 1;
+        if (k > len && len > 0) k = len;
+        ch->sl_n[z] = k;
+        used += k;
+    }
+    // the rounding's surplus / deficit goes to the longest chunk
+    int big = 0;
+    for (int z = 1; z < ch->n; ++z)
+        if (ch->end[z] - ch->beg[z] > ch->end[big] - ch->beg[big]) big = z;
+    if (used > S && ch->sl_n[big] - (used - S) >= 1) { ch->sl_n[big] -= used - S; used = S; }
+    if (used < S) {
+        int add = S - used;
+        const int room = (ch->end[big] - ch->beg[big]) - ch->sl_n[big];
+        if (add > room) add = room > 0 ? room : 0;
+        ch->sl_n[big] += add;
+        used += add;
+    }
+    int pos = 0;
+    for (int z = 0; z < ch->n; ++z) { ch->sl_beg[z] = pos; pos += ch->sl_n[z]; }
+    return pos;
+}
+// global slice -> (chunk, frames [n_beg, n_end))
+__device__ __forceinline__ int bnk_slice(const BnChunks& ch, int gs, int* n_beg, int* n_end) {
+    int z = 0;
+#pragma unroll
+    for (int i = 1; i < BNK_MAX_CHUNKS; ++i)
+        if (i < ch.n && gs >= ch.sl_beg[i]) z = i;
+    const int sp = gs - ch.sl_beg[z], S = ch.sl_n[z], N = ch.end[z] - ch.beg[z];
+    *n_beg = ch.beg[z] + (int)((long)sp * N / S);
+    *n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
+    return z;
 }
 __device__ __forceinline__ int bnk_chunk_of(const BnChunks& ch, int n) {
     int z = 0;
@@ -127,9 +174,9 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_stats_part(
     const float* __restrict__ x, float* __restrict__ part1, float* __restrict__ part2, BnChunks ch,
     int C, int HW, int S) {
     __shared__ float red[4];
-    const int c = blockIdx.x, sp = blockIdx.y, z = blockIdx.z;
-    const int N = ch.end[z] - ch.beg[z];
-    const int n_beg = ch.beg[z] + (int)((long)sp * N / S), n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
+    const int c = blockIdx.x, gs = blockIdx.y;
+    int n_beg, n_end;
+    const int z = bnk_slice(ch, gs, &n_beg, &n_end);
     const float sh = bnk_shift(x, ch.beg[z], ch.end[z], c, C, HW);
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);
@@ -164,8 +211,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_stats_part(
     const float s1 = bnk_block_sum(a1 + b1, red);
     const float s2 = bnk_block_sum(a2 + b2, red);
     if (threadIdx.x == 0) {
-        part1[((size_t)z * C + c) * S + sp] = s1;
-        part2[((size_t)z * C + c) * S + sp] = s2;
+        part1[(size_t)c * S + gs] = s1;
+        part2[(size_t)c * S + gs] = s2;
     }
 }
 
@@ -272,9 +319,9 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     const float* __restrict__ beta, float* __restrict__ part0,
     float* __restrict__ part1, BnChunks ch, int C, int HW, int S, int act, float slope) {
     __shared__ float red[4];
-    const int c = blockIdx.x, sp = blockIdx.y, z = blockIdx.z;
-    const int N = ch.end[z] - ch.beg[z];
-    const int n_beg = ch.beg[z] + (int)((long)sp * N / S), n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
+    const int c = blockIdx.x, gs = blockIdx.y;
+    int n_beg, n_end;
+    const int z = bnk_slice(ch, gs, &n_beg, &n_end);
     const float m = mean[z * C + c], is = invstd[z * C + c];
     float sc = 1.f, sh = 0.f;
     if (FROMX) bnk_affine(m, is, gamma, beta, c, &sc, &sh);
@@ -322,8 +369,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     const float s0 = bnk_block_sum(a0, red);
     const float s1 = bnk_block_sum(a1, red);
     if (threadIdx.x == 0) {
-        part0[((size_t)z * C + c) * S + sp] = s0;
-        part1[((size_t)z * C + c) * S + sp] = s1;
+        part0[(size_t)c * S + gs] = s0;
+        part1[(size_t)c * S + gs] = s1;
     }
 }
 
@@ -395,6 +442,214 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply(
             const float dz = dy[e] * (FROMX ? (fmaf(x[e], sc, sh) > 0.f ? 1.f : neg)
                                             : bn_act_grad_from_output(y[e], act, slope));
             dx[e] = g * (dz - k0 - ((x[e] - m) * is) * k1);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: the per-channel finalize / combine launches folded into their neighbours.  The apply kernels
+// run on the (channel, frame-slice, chunk) grid of the partial-sum kernels; a workgroup first adds up
+// the S partials of ITS (chunk, channel) -- one wave, a fixed shuffle tree, so every workgroup of the
+// channel derives bit-identical statistics -- and then streams its slice.  Slice 0 of a channel
+// publishes what the backward pass / the running estimates need.  54 -> 36 batch-norm launches per
+// training step of the default architecture.
+// ---------------------------------------------------------------------------------------------
+// totals of two partial arrays p1[0..S), p2[0..S) (S <= 64) for every thread of the workgroup
+__device__ __forceinline__ void bnk_reduce_parts(const float* __restrict__ p1, const float* __restrict__ p2,
+                                                 int S, float* red, float* o1, float* o2) {
+    __syncthreads();                                   // (red may still be read from a previous call)
+    if (threadIdx.x < 64) {
+        float a = (int)threadIdx.x < S ? p1[threadIdx.x] : 0.f;
+        float b = (int)threadIdx.x < S ? p2[threadIdx.x] : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            a += __shfl_xor(a, off, 64);
+            b += __shfl_xor(b, off, 64);
+        }
+        if (threadIdx.x == 0) { red[0] = a; red[1] = b; }
+    }
+    __syncthreads();
+    *o1 = red[0];
+    *o2 = red[1];
+}
+
+// mean / biased variance of (chunk z, channel c) from the one-pass partial sums (k_bn_stats_part)
+__device__ __forceinline__ void bnk_stats_of(const float* __restrict__ x, const float* __restrict__ part1,
+                                             const float* __restrict__ part2, const BnChunks& ch, int z, int c,
+                                             int C, int HW, int S, float* red, float* m, float* v) {
+    float s1, s2;
+    bnk_reduce_parts(part1 + (size_t)c * S + ch.sl_beg[z], part2 + (size_t)c * S + ch.sl_beg[z], ch.sl_n[z], red,
+                     &s1, &s2);
+    const float inv_n = 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW);
+    const float sh = bnk_shift(x, ch.beg[z], ch.end[z], c, C, HW);
+    const float d = s1 * inv_n;
+    *m = sh + d;
+    *v = fmaxf(fmaf(-d, d, s2 * inv_n), 0.f);
+}
+
+// statistics finalize + y = act((x - mean) * invstd * gamma + beta) of one (channel, slice, chunk)
+__global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd_fin(
+    const float* __restrict__ x, const float* __restrict__ part1, const float* __restrict__ part2,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ num_batches, BnChunks ch, int C, int HW, int S,
+    float eps, int act, float slope) {
+    __shared__ float red[2];
+    const int c = blockIdx.x, gs = blockIdx.y;
+    int n_beg, n_end;
+    const int z = bnk_slice(ch, gs, &n_beg, &n_end);
+    float m, v;
+    if (gs == 0) {
+        // this workgroup also owns the channel's running estimates: one update per chunk, in chunk order
+        // (factor scale[z], unbiasing aux[z]), and the batch counter
+        float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+        float m0 = 0.f, v0 = 0.f;
+        for (int zz = 0; zz < ch.n; ++zz) {
+            float mz, vz;
+            bnk_stats_of(x, part1, part2, ch, zz, c, C, HW, S, red, &mz, &vz);
+            if (zz == 0) { m0 = mz; v0 = vz; }
+            const float momentum = ch.scale[zz];
+            rm = (1.f - momentum) * rm + momentum * mz;
+            rv = (1.f - momentum) * rv + momentum * vz * ch.aux[zz];
+            if (threadIdx.x == 0) {
+                mean[zz * C + c] = mz;
+                invstd[zz * C + c] = 1.0f / sqrtf(vz + eps);
+            }
+        }
+        if (threadIdx.x == 0) {
+            if (running_mean) running_mean[c] = rm;
+            if (running_var) running_var[c] = rv;
+            if (c == 0 && num_batches) *num_batches += ch.n;
+        }
+        m = m0; v = v0;
+    } else {
+        bnk_stats_of(x, part1, part2, ch, z, c, C, HW, S, red, &m, &v);
+    }
+    const float is = 1.0f / sqrtf(v + eps);
+    float sc, sh;
+    bnk_affine(m, is, gamma, beta, c, &sc, &sh);
+    const bool vec = (HW & 3) == 0 && (((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0);
+    if (vec) {
+        const unsigned hw4 = HW >> 2, cnt = (unsigned)(n_end - n_beg) * hw4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        for (unsigned e = threadIdx.x; e < cnt; e += 2 * BNK_THREADS) {
+            const unsigned e2 = e + BNK_THREADS;
+            const unsigned n = e / hw4, i = e - n * hw4;
+            const size_t o = ((size_t)(n_beg + n) * C + c) * hw4 + i;
+            size_t o2 = o;
+            if (e2 < cnt) {
+                const unsigned n2 = e2 / hw4, i2 = e2 - n2 * hw4;
+                o2 = ((size_t)(n_beg + n2) * C + c) * hw4 + i2;
+            }
+            const float4 a = x4[o], b = x4[o2];
+            float4 p, q;
+            p.x = bn_apply_act(fmaf(a.x, sc, sh), act, slope);
+            p.y = bn_apply_act(fmaf(a.y, sc, sh), act, slope);
+            p.z = bn_apply_act(fmaf(a.z, sc, sh), act, slope);
+            p.w = bn_apply_act(fmaf(a.w, sc, sh), act, slope);
+            q.x = bn_apply_act(fmaf(b.x, sc, sh), act, slope);
+            q.y = bn_apply_act(fmaf(b.y, sc, sh), act, slope);
+            q.z = bn_apply_act(fmaf(b.z, sc, sh), act, slope);
+            q.w = bn_apply_act(fmaf(b.w, sc, sh), act, slope);
+            y4[o] = p;
+            if (e2 < cnt) y4[o2] = q;
+        }
+    } else {
+        const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
+        for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
+            const unsigned n = e / HW, i = e - n * HW;
+            const size_t o = ((size_t)(n_beg + n) * C + c) * HW + i;
+            y[o] = bn_apply_act(fmaf(x[o], sc, sh), act, slope);
+        }
+    }
+}
+
+// combine of the backward sums + dx = gamma * invstd * (dz - sum_dz / n - xhat * sum_dzx / n) of one
+// (channel, slice, chunk); slice 0 of chunk 0 adds the parameter gradients (chunks in order, as separate
+// backward passes would)
+template <bool FROMX>
+__global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply_fin(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ part0, const float* __restrict__ part1,
+    float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, BnChunks ch,
+    int C, int HW, int S, int act, float slope) {
+    __shared__ float red[2];
+    const int c = blockIdx.x, gs = blockIdx.y;
+    int n_beg, n_end;
+    const int z = bnk_slice(ch, gs, &n_beg, &n_end);
+    float v0, v1;
+    if (gs == 0 && (dgamma || dbeta)) {
+        float g = (accumulate && dgamma) ? dgamma[c] : 0.f, b = (accumulate && dbeta) ? dbeta[c] : 0.f;
+        float f0 = 0.f, f1 = 0.f;
+        for (int zz = 0; zz < ch.n; ++zz) {
+            float a0, a1;
+            bnk_reduce_parts(part0 + (size_t)c * S + ch.sl_beg[zz], part1 + (size_t)c * S + ch.sl_beg[zz],
+                             ch.sl_n[zz], red, &a0, &a1);
+            if (zz == 0) { f0 = a0; f1 = a1; }
+            g += a1;
+            b += a0;
+        }
+        if (threadIdx.x == 0) {
+            if (dgamma) dgamma[c] = g;
+            if (dbeta) dbeta[c] = b;
+        }
+        v0 = f0; v1 = f1;
+    } else {
+        bnk_reduce_parts(part0 + (size_t)c * S + ch.sl_beg[z], part1 + (size_t)c * S + ch.sl_beg[z], ch.sl_n[z],
+                         red, &v0, &v1);
+    }
+    const int zc = z * C + c;
+    const float m = mean[zc], is = invstd[zc], inv_n = ch.scale[z];
+    const float g = (gamma ? gamma[c] : 1.f) * is;
+    const float k0 = v0 * inv_n, k1 = v1 * inv_n;
+    float sc = 1.f, sh = 0.f;
+    if (FROMX) bnk_affine(m, is, gamma, beta, c, &sc, &sh);
+    const float neg = act == BN_ACT_LRELU ? slope : 1.f;
+    const bool vec = (HW & 3) == 0 &&
+                     (((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15u) == 0);
+    if (vec) {
+        const unsigned hw4 = HW >> 2, cnt = (unsigned)(n_end - n_beg) * hw4;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        const float4* y4 = reinterpret_cast<const float4*>(y);
+        const float4* d4 = reinterpret_cast<const float4*>(dy);
+        float4* o4 = reinterpret_cast<float4*>(dx);
+        // two groups per thread and iteration: four 16-byte loads in flight
+        for (unsigned e0 = threadIdx.x; e0 < cnt; e0 += 2 * BNK_THREADS)
+#pragma unroll
+        for (unsigned e = e0; e < e0 + 2 * BNK_THREADS && e < cnt; e += BNK_THREADS) {
+            const unsigned n = e / hw4, i = e - n * hw4;
+            const size_t o = ((size_t)(n_beg + n) * C + c) * hw4 + i;
+            const float4 xv = x4[o], dv = d4[o];
+            float4 f;
+            if (FROMX) {
+                f.x = fmaf(xv.x, sc, sh) > 0.f ? 1.f : neg;
+                f.y = fmaf(xv.y, sc, sh) > 0.f ? 1.f : neg;
+                f.z = fmaf(xv.z, sc, sh) > 0.f ? 1.f : neg;
+                f.w = fmaf(xv.w, sc, sh) > 0.f ? 1.f : neg;
+            } else {
+                const float4 yv = y4[o];
+                f.x = bn_act_grad_from_output(yv.x, act, slope);
+                f.y = bn_act_grad_from_output(yv.y, act, slope);
+                f.z = bn_act_grad_from_output(yv.z, act, slope);
+                f.w = bn_act_grad_from_output(yv.w, act, slope);
+            }
+            float4 r;
+            r.x = g * (dv.x * f.x - k0 - ((xv.x - m) * is) * k1);
+            r.y = g * (dv.y * f.y - k0 - ((xv.y - m) * is) * k1);
+            r.z = g * (dv.z * f.z - k0 - ((xv.z - m) * is) * k1);
+            r.w = g * (dv.w * f.w - k0 - ((xv.w - m) * is) * k1);
+            o4[o] = r;
+        }
+    } else {
+        const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
+        for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
+            const unsigned n = e / HW, i = e - n * HW;
+            const size_t o = ((size_t)(n_beg + n) * C + c) * HW + i;
+            const float dz = dy[o] * (FROMX ? (fmaf(x[o], sc, sh) > 0.f ? 1.f : neg)
+                                            : bn_act_grad_from_output(y[o], act, slope));
+            dx[o] = g * (dz - k0 - ((x[o] - m) * is) * k1);
         }
     }
 }
@@ -495,25 +750,30 @@ static int bn_launch_act_bwd_chunks(const float* x, const float* y, const float*
                                     float* dgamma, float* dbeta, int accumulate, int batch_stats, int N,
                                     BnChunks ch, int C, int HW, int act, float slope, void* ws,
                                     hipStream_t st) {
-    const int S = bn_splits(bnk_max_len(ch), C);
+    const int S = bnk_set_slices(&ch, bn_splits(N, C));
     float* part0 = (float*)ws;
-    float* part1 = part0 + (size_t)ch.n * C * S;
-    float* sum0 = part1 + (size_t)ch.n * C * S;
-    float* sum1 = sum0 + (size_t)ch.n * C;
+    float* part1 = part0 + (size_t)C * S;
     if (!y && act != BN_ACT_NONE && act != BN_ACT_LRELU) return BN_E_BADARG;
     if (y)
-        hipLaunchKernelGGL(k_bn_bwd_part<false>, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
+        hipLaunchKernelGGL(k_bn_bwd_part<false>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
                            invstd, gamma, beta, part0, part1, ch, C, HW, S, act, slope);
     else
-        hipLaunchKernelGGL(k_bn_bwd_part<true>, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
+        hipLaunchKernelGGL(k_bn_bwd_part<true>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
                            invstd, gamma, beta, part0, part1, ch, C, HW, S, act, slope);
-    hipLaunchKernelGGL(k_bn_bwd_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, part1, sum0, sum1,
-                       dgamma, dbeta, C, S, accumulate, ch.n);
-    BN_LAUNCH_CHECK();
+    if ((size_t)N * C * HW >= 0xffffffffull) return BN_E_SHAPE;
     for (int z = 0; z < ch.n; ++z)
         ch.scale[z] = batch_stats ? 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW) : 0.0f;
-    return bn_launch_bwd_apply_chunks(x, y, dy, mean, invstd, gamma, beta, sum0, sum1, dx, N, C, HW, act,
-                                      slope, ch, st);
+    // combine (both sums, parameter gradients) inside the launch that writes dx
+    if (y)
+        hipLaunchKernelGGL(k_bn_bwd_apply_fin<false>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
+                           invstd, gamma, beta, (const float*)part0, (const float*)part1, dx, dgamma, dbeta,
+                           accumulate, ch, C, HW, S, act, slope);
+    else
+        hipLaunchKernelGGL(k_bn_bwd_apply_fin<true>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
+                           invstd, gamma, beta, (const float*)part0, (const float*)part1, dx, dgamma, dbeta,
+                           accumulate, ch, C, HW, S, act, slope);
+    BN_LAUNCH_CHECK();
+    return 0;
 }
 
 int bn_launch_bn_act_bwd(const float* x, const float* y, const float* dy, const float* mean,
@@ -547,22 +807,24 @@ int bn_launch_bn_train_fwd_chunks(const float* x, const float* gamma, const floa
     BnChunks ch;
     int N = 0;
     if (!bnk_make_chunks(bounds, n_chunks, &ch, &N)) return BN_E_SHAPE;
-    const int S = bn_splits(bnk_max_len(ch), C);
+    const int S = bnk_set_slices(&ch, bn_splits(N, C));
     float* part1 = (float*)ws;
-    float* part2 = part1 + (size_t)ch.n * C * S;
-    // one pass over x for both moments, one small launch for everything per channel
-    hipLaunchKernelGGL(k_bn_stats_part, dim3(C, S, ch.n), dim3(BNK_THREADS), 0, st, x, part1, part2, ch, C,
+    float* part2 = part1 + (size_t)C * S;
+    // one pass over x for both moments
+    hipLaunchKernelGGL(k_bn_stats_part, dim3(C, S), dim3(BNK_THREADS), 0, st, x, part1, part2, ch, C,
                        HW, S);
     for (int z = 0; z < ch.n; ++z) {
         const double cnt = (double)(ch.end[z] - ch.beg[z]) * HW;
         ch.scale[z] = factors ? factors[z] : 0.f;
         ch.aux[z] = cnt > 1 ? (float)(cnt / (cnt - 1.0)) : 1.f;
     }
-    hipLaunchKernelGGL(k_bn_stats_finalize, dim3((C + 63) / 64), dim3(64), 0, st, x, (const float*)part1,
-                       (const float*)part2, mean, (float*)nullptr, invstd, running_mean, running_var,
-                       num_batches, C, HW, S, eps, ch);
+    if ((size_t)N * C * HW >= 0xffffffffull) return BN_E_SHAPE;
+    // finalize (mean / invstd / running estimates / batch counter) inside the normalising launch
+    hipLaunchKernelGGL(k_bn_act_fwd_fin, dim3(C, S), dim3(BNK_THREADS), 0, st, x, (const float*)part1,
+                       (const float*)part2, gamma, beta, y, mean, invstd, running_mean, running_var, num_batches,
+                       ch, C, HW, S, eps, act, slope);
     BN_LAUNCH_CHECK();
-    return bn_launch_act_fwd_chunks(x, mean, invstd, gamma, beta, y, N, C, HW, act, slope, ch, st);
+    return 0;
 }
 
 int bn_launch_bn_act_bwd_chunks(const float* x, const float* y, const float* dy, const float* mean,
@@ -602,10 +864,10 @@ int bn_launch_bn_moment(const float* x, const float* center, float* sums, int N,
 int bn_launch_bn_bwd_reduce(const float* x, const float* y, const float* dy, const float* mean,
                             const float* invstd, float* sum_dz, float* sum_dzx, int N, int C,
                             int HW, int act, float slope, void* ws, hipStream_t st) {
-    const int S = bn_splits(N, C);
+    BnChunks ch = bnk_one_chunk(N);
+    const int S = bnk_set_slices(&ch, bn_splits(N, C));
     float* part0 = (float*)ws;
     float* part1 = part0 + (size_t)C * S;
-    const BnChunks ch = bnk_one_chunk(N);
     hipLaunchKernelGGL(k_bn_bwd_part<false>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean, invstd,
                        (const float*)nullptr, (const float*)nullptr, part0, part1, ch, C, HW, S, act, slope);
     hipLaunchKernelGGL(k_bn_combine, dim3((C + 63) / 64), dim3(64), 0, st, part0, sum_dz, C, S, ch);

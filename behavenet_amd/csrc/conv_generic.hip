@@ -1,4 +1,4 @@
-// Generic (any kernel size <= 9, any stride) direct convolution kernels.
+// Generic (any kernel size <= 16, any stride) direct convolution kernels.
 //
 // These are the shape-agnostic fallbacks of the three kernel families (bn_common.h).  They are
 // im2col-free direct loops with per-thread register blocking over output channels; the
@@ -9,7 +9,7 @@
 
 #define GEN_THREADS 256
 #define GEN_MT 8          // output channels per thread
-#define GEN_MAXS 9
+#define GEN_MAXS 16
 
 // out = small side; weights [Cs][Cb][R][S]
 __global__ __launch_bounds__(GEN_THREADS) void k_down_generic(

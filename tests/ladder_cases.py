@@ -30,6 +30,42 @@ LADDER_EXTRA = [
 
 DETOUR_TOKENS = ('im2col', 'col2im', 'generic')
 
+# The ONLY geometries (of the named cases + the ones above) that may still reach the column-matrix or the
+# shape-agnostic rungs of csrc/capi.hip's run_down / run_up / run_wgrad, role by role -- DESIGN.md section 8's list of
+# detours as a checked contract.  Everything else must land on a specialised kernel (possibly on zero-padded /
+# tiled / phase-split copies, which the kernel name says).
+DETOURS = {
+    # operands that are not 16-byte aligned: the first rung sends every role to the direct loops
+    'E1 @unaligned': ('fwd', 'bwd_data', 'bwd_weight'),
+    'E4 @unaligned': ('fwd', 'bwd_data', 'bwd_weight'),
+    'pad_24x20 @unaligned': ('fwd', 'bwd_data', 'bwd_weight'),
+    # kernels past 10 taps: direct loops (the architecture search draws <= 9)
+    'k11_s1': ('fwd', 'bwd_data', 'bwd_weight'),
+    'k11_s2': ('fwd', 'bwd_data', 'bwd_weight'),
+    'k11s2': ('fwd', 'bwd_data', 'bwd_weight'),
+    'k13s1_valid': ('fwd', 'bwd_data', 'bwd_weight'),
+    # strides other than 1, 2 and the kernel size: column matrix + GEMM
+    'stride3_k3': ('fwd', 'bwd_data', 'bwd_weight'),
+    'stride3_k5': ('fwd', 'bwd_data', 'bwd_weight'),
+    'stride4_k5': ('fwd', 'bwd_data', 'bwd_weight'),
+    # 1x1 kernels, odd channel counts under 3x3 / 4x4 kernels, odd big maps under 7x7
+    'k1_s1': ('fwd', 'bwd_data', 'bwd_weight'),
+    'k3_s1_c3': ('fwd', 'bwd_data'),
+    'k3s1': ('fwd', 'bwd_data'),
+    'k4s2': ('fwd', 'bwd_data', 'bwd_weight'),
+    'k7_odd_map_s2': ('fwd', 'bwd_data', 'bwd_weight'),
+    'k7s2_valid': ('fwd', 'bwd_data', 'bwd_weight'),
+    # a single channel against 48 (no multiple of 32) on the other side
+    'c1_to_48': ('fwd', 'bwd_weight'),
+    # stride-1 5x5 on odd maps / odd channel counts: gather-up and weight gradient
+    'k5_s1_odd_19x23': ('bwd_data', 'bwd_weight'),
+    'odd_channels': ('bwd_data',),
+    # weight gradients of wide-kernel layers whose small side has few channels / odd widths
+    'k7s2_same_24x20': ('bwd_weight',),
+    's1_16_to_1_k5': ('bwd_weight',),
+    's1_k7_2ch_50x70': ('bwd_weight',),
+}
+
 
 def _operands(case, misalign=False, dev='cuda'):
     name, N, C, H, W, K, R, st, (pt, pb), (pl, pr) = case
@@ -63,6 +99,9 @@ def kernel_names(case, misalign=False):
             fn()
             torch.cuda.synchronize()
             _, n, name = _hip.prof_read()
+        except _hip.HipLibraryError as err:
+            # the library's own refusal (a negative code: nothing was launched) is part of the contract
+            n, name = 1, 'refused: ' + str(err).split('failed: ')[-1].split(':')[0]
         finally:
             _hip.prof_select(_hip.PROF_NONE)
         out[role] = name if n >= 1 else 'no scope'

@@ -11,6 +11,8 @@ Where no float64 evaluation is supplied the scale-normalised error vs the fp32 o
 <= 1e-4.
 """
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -64,6 +66,9 @@ CONV_CASES = [
     ('k7s2_valid', 2, 3, 21, 18, 9, 7, 2, (0, 0), (0, 0)),
     ('nonsquare_last', 3, 256, 4, 3, 512, 5, 5, (0, 1), (1, 1)),
     ('odd_channels', 2, 33, 20, 20, 65, 5, 2, (1, 2), (1, 2)),
+    # kernels past 9 (a handcrafted architecture json may ask for any size; the search draws <= 9): direct loops
+    ('k11s2', 2, 3, 33, 29, 5, 11, 2, (4, 5), (4, 5)),
+    ('k13s1_valid', 2, 4, 20, 18, 6, 13, 1, (0, 0), (0, 0)),
     # geometries served by the specialised kernels on zero-padded copies / by the im2col GEMM
     # (csrc/conv_pad.hip): 24x20 and 4x3 small maps, a 64x48 single-channel frame, stride-5
     # windows onto 2x1 and 1x1 maps
@@ -1102,3 +1107,23 @@ def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, wan
             _hip.prof_select(_hip.PROF_NONE)
         assert n >= 1 and ('tiles of' in name or 'zero-padded' in name or 'mfma' in name or
                            'k_wgrad_c1<' in name or 'k_up_c1v<8, false, gen>' in name), name
+
+
+def test_dispatch_ladder_is_pinned():
+    """csrc/capi.hip's run_down / run_up / run_wgrad are ladders of ten rungs.  Every named case
+    and the odd ones of tests/ladder_cases.py (odd widths, strides 3 / 4, kernels of 1 and past 9 taps, unaligned
+    views) must land on the kernel tests/golden/dispatch_ladder.json names for it (regenerate with
+    tools/ladder_probe.py when a dispatch change is MEANT), and the column-matrix / direct-loop rungs may be reached
+    by the (case, role) pairs of ladder_cases.DETOURS only."""
+    import json
+    from tests import ladder_cases
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'dispatch_ladder.json')) as f:
+        want = json.load(f)
+    got = ladder_cases.ladder_table()
+    assert sorted(got) == sorted(want)
+    wrong = [(c, r, got[c][r], want[c][r]) for c in want for r in want[c] if got[c].get(r) != want[c][r]]
+    assert not wrong, wrong[:8]
+    on_detour = {(c, r) for c in got for r, name in got[c].items()
+                 if any(t in name for t in ladder_cases.DETOUR_TOKENS)}
+    allowed = {(c, r) for c, roles in ladder_cases.DETOURS.items() for r in roles}
+    assert on_detour == allowed, (sorted(on_detour - allowed), sorted(allowed - on_detour))
