@@ -1063,7 +1063,9 @@ def run(args):
     conv0_frames = BATCH
     if strong:      # rank 0's slice of the two chunks
         conv0_frames = sum(e - b for b, e in bdist.shard_chunks(BATCH, 200)[1])
-    conv0_bytes = CONV0_BYTES_PER_FRAME * conv0_frames * args.steps
+    # (per launch the hook SAW: under HIP-graph replay -- frame sharding over >= 4 ranks -- the dispatch events are
+    # attached to the eager launches only, fewer than K; round 5 multiplied by K there and overstated `achieved`)
+    conv0_bytes = CONV0_BYTES_PER_FRAME * conv0_frames * max(conv0_n, 0)
     achieved = conv0_bytes / (conv0_ms * 1e-3) / 1e9 if conv0_ms > 0 else 0.0
     traffic = None
     traffic_source = None

@@ -534,3 +534,26 @@ def test_bench_two_ranks_frame_sharded_mixed_graph_and_eager(tmp_path):
     assert d2['n_gpus'] == 2 and d2['hip_graph'] is True
     assert d2['detail']['hip_graph_ranks_recorded'] == [True, False]
     assert d2['final_loss'] == pytest.approx(d1['final_loss'], rel=1e-4)
+
+
+def test_bench_eight_ranks_frame_sharded_defaults(tmp_path):
+    """the driver's first N = 8 run must not be the first time eight ranks ever met.  Eight real
+    processes on the one GPU over gloo in 'frames' mode -- every 200-frame chunk in slices of 25, the 56-frame chunk
+    in slices of 7, the step replayed from a HIP graph, Adam on 1/8 of the arena -- report the single-device loss of
+    the same trajectory."""
+    env = _child_env(BN_DIST_BACKEND='gloo', BN_BENCH_PRIME='24', OMP_NUM_THREADS='1', MKL_NUM_THREADS='1',
+                     BN_DIST_TIMEOUT_S='180', BN_BENCH_WATCHDOG_S='300')
+    tail = ['--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-secondary', '--no-pmc']
+    d8 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '8', '--shard', 'frames'] + tail,
+                     env, tmp_path, limit_s=900)
+    d1 = _bench_line([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1'] + tail, env, tmp_path)
+    assert d8['n_gpus'] == 8 and d8['scaling'] == 'strong' and d8['hip_graph'] is True
+    ar = d8['allreduce']
+    assert ar['shard_optimizer'] is True and ar['world_size'] == 8 and ar['op'] == 'sum'
+    assert ar['gradient_bytes'] % (8 * 16) == 0
+    assert d8['config']['frames_per_step_per_gpu'] == 32 and d8['config']['global_frames_per_step'] == 256
+    # rank 0's slices: 25 of the first chunk's 200 frames + 7 of the second's 56 (the dispatch hook sees the eager
+    # launches only: none when every timed step was a graph replay)
+    assert d8['roofline']['algorithmic_bytes_per_launch_avg'] in (0, 32 * 589824)
+    assert d8['detail']['hip_graph_ranks_recorded'] == [True] * 8
+    assert d8['final_loss'] == pytest.approx(d1['final_loss'], rel=1e-4)
