@@ -655,6 +655,218 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply_fin(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 6, the deep layers (many channels, small maps: E2-E4 / D0-D1 of the default architecture, a third of the
+// batch-norm launches and none of the big tensors): ONE workgroup of 1024 threads owns a channel.  A chunk's
+// values of that channel (<= 56 K floats: 200 frames of a 16x16 map) are loaded ONCE into registers; mean, then the centred second moment
+// (torch's own two-pass form: no shift, no cancellation) by two workgroup reductions; the normalised values leave
+// from the registers.  Chunks one after the other inside the workgroup, so the running estimates see their updates
+// in order.  Forward = 1 launch and x read once (was stats + normalise: 2 launches, x read twice); backward = 1
+// launch (was sums + apply), x held in registers, dy re-read from the L2 when both do not fit.
+// ---------------------------------------------------------------------------------------------
+#define BNO_THREADS 1024
+#define BNO_NV 14                                        // float4 groups per thread: 1024 x 14 x 4 = 56 K floats
+
+__device__ __forceinline__ float bno_block_sum(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();                                     // (red may still be read from the previous reduction)
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < BNO_THREADS / 64; ++w) t += red[w];          // fixed order, every thread the same
+    return t;
+}
+
+static bool bno_fits(const BnChunks& ch, int C, int HW, const void* a, const void* b, const void* c2,
+                     const void* d) {
+    if ((HW & 3) != 0) return false;
+    if ((size_t)ch.end[ch.n - 1] * C * HW >= 0xffffffffull) return false;
+    if (((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c2) | ((uintptr_t)d)) & 15u) != 0) return false;
+    int total = 0;
+    for (int z = 0; z < ch.n; ++z) {
+        const long cnt = (long)(ch.end[z] - ch.beg[z]) * (HW >> 2);
+        if (cnt > (long)BNO_THREADS * BNO_NV) return false;
+        total += ch.end[z] - ch.beg[z];
+    }
+    static int off = -1;                                 // BN_BN_OWNED=0: the two-launch forms (tuning builds)
+    if (off < 0) { const char* e = bn_tune_env("BN_BN_OWNED"); off = (e && e[0] == '0') ? 1 : 0; }
+    if (off) return false;
+    // few channels: only when the tensor is small anyway (a workgroup per channel must fill the chip)
+    return C >= 64 || (size_t)total * C * HW * 4 <= ((size_t)2 << 20);
+}
+
+__global__ __launch_bounds__(BNO_THREADS) void k_bn_fwd_owned(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ running_mean,
+    float* __restrict__ running_var, long long* __restrict__ num_batches, BnChunks ch, int C, int HW, float eps,
+    int act, float slope) {
+    __shared__ float red[BNO_THREADS / 64];
+    const int c = blockIdx.x;
+    const unsigned hw4 = HW >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    float4* y4 = reinterpret_cast<float4*>(y);
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+#pragma unroll
+    for (int z = 0; z < BNK_MAX_CHUNKS; ++z) {
+        if (z >= ch.n) break;                            // (static indices into the chunk table: it stays in scalar registers)
+        const unsigned cnt = (unsigned)(ch.end[z] - ch.beg[z]) * hw4;
+        float4 v[BNO_NV];
+        // float4 index of group k (the launcher checked N C HW < 2^32); not kept: 14 offsets next to 56 data
+        // registers spilled.  Maps whose group count divides 1024 (powers of two): linear in k
+        const unsigned n0 = threadIdx.x / hw4, i0 = threadIdx.x - n0 * hw4;
+        const unsigned off0 = ((unsigned)(ch.beg[z] + n0) * C + c) * hw4 + i0;
+        const bool lin = (BNO_THREADS % hw4) == 0;
+        const unsigned kstride = (BNO_THREADS / hw4) * C * hw4;
+        auto off_of = [&](int k) __attribute__((always_inline)) {
+            if (lin) return off0 + k * kstride;
+            const unsigned e = threadIdx.x + BNO_THREADS * k;
+            const unsigned n = e / hw4, i = e - n * hw4;
+            return ((unsigned)(ch.beg[z] + n) * C + c) * hw4 + i;
+        };
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < BNO_NV; ++k)
+            v[k] = threadIdx.x + BNO_THREADS * k < cnt ? x4[off_of(k)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < BNO_NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        const float inv_n = 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW);
+        const float m = bno_block_sum(s, red) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < BNO_NV; ++k) {
+            if (threadIdx.x + BNO_THREADS * k < cnt) {
+                const float a0 = v[k].x - m, a1 = v[k].y - m, a2 = v[k].z - m, a3 = v[k].w - m;
+                q += fmaf(a0, a0, a1 * a1) + fmaf(a2, a2, a3 * a3);
+            }
+        }
+        const float var = bno_block_sum(q, red) * inv_n;
+        const float is = 1.0f / sqrtf(var + eps);
+        float sc, sh;
+        bnk_affine(m, is, gamma, beta, c, &sc, &sh);
+#pragma unroll
+        for (int k = 0; k < BNO_NV; ++k) {
+            if (threadIdx.x + BNO_THREADS * k < cnt) {
+                float4 o;
+                o.x = bn_apply_act(fmaf(v[k].x, sc, sh), act, slope);
+                o.y = bn_apply_act(fmaf(v[k].y, sc, sh), act, slope);
+                o.z = bn_apply_act(fmaf(v[k].z, sc, sh), act, slope);
+                o.w = bn_apply_act(fmaf(v[k].w, sc, sh), act, slope);
+                y4[off_of(k)] = o;
+            }
+        }
+        const float momentum = ch.scale[z];
+        rm = (1.f - momentum) * rm + momentum * m;
+        rv = (1.f - momentum) * rv + momentum * var * ch.aux[z];
+        if (threadIdx.x == 0) {
+            mean[z * C + c] = m;
+            invstd[z * C + c] = is;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
+        if (c == 0 && num_batches) *num_batches += ch.n;
+    }
+}
+
+// KEEP: dz stays in registers next to xhat (both fit); else dy is read again for the second pass
+template <bool FROMX, bool KEEP>
+__global__ __launch_bounds__(BNO_THREADS) void k_bn_bwd_owned(
+    const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    int accumulate, BnChunks ch, int C, int HW, int act, float slope) {
+    __shared__ float red[BNO_THREADS / 64];
+    constexpr int NV = KEEP ? BNO_NV / 2 : BNO_NV;
+    const int c = blockIdx.x;
+    const unsigned hw4 = HW >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    const float4* d4 = reinterpret_cast<const float4*>(dy);
+    float4* o4 = reinterpret_cast<float4*>(dx);
+    const float neg = act == BN_ACT_LRELU ? slope : 1.f;
+    float gsum = (accumulate && dgamma) ? dgamma[c] : 0.f, bsum = (accumulate && dbeta) ? dbeta[c] : 0.f;
+#pragma unroll
+    for (int z = 0; z < BNK_MAX_CHUNKS; ++z) {
+        if (z >= ch.n) break;
+        const unsigned cnt = (unsigned)(ch.end[z] - ch.beg[z]) * hw4;
+        const int zc = z * C + c;
+        const float m = mean[zc], is = invstd[zc], inv_n = ch.scale[z];
+        float sc = 1.f, sh = 0.f;
+        if (FROMX) bnk_affine(m, is, gamma, beta, c, &sc, &sh);
+        float4 xh[NV], dz[KEEP ? NV : 1];
+        const unsigned n0 = threadIdx.x / hw4, i0 = threadIdx.x - n0 * hw4;
+        const unsigned off0 = ((unsigned)(ch.beg[z] + n0) * C + c) * hw4 + i0;
+        const bool lin = (BNO_THREADS % hw4) == 0;
+        const unsigned kstride = (BNO_THREADS / hw4) * C * hw4;
+        auto off_of = [&](int k) __attribute__((always_inline)) {
+            if (lin) return off0 + k * kstride;
+            const unsigned e = threadIdx.x + BNO_THREADS * k;
+            const unsigned n = e / hw4, i = e - n * hw4;
+            return ((unsigned)(ch.beg[z] + n) * C + c) * hw4 + i;
+        };
+        float a0 = 0.f, a1 = 0.f;
+        auto dz_of = [&](const float4& xv, const float4& dv, unsigned o) __attribute__((always_inline)) {
+            float4 f;
+            if (FROMX) {
+                f.x = fmaf(xv.x, sc, sh) > 0.f ? 1.f : neg;
+                f.y = fmaf(xv.y, sc, sh) > 0.f ? 1.f : neg;
+                f.z = fmaf(xv.z, sc, sh) > 0.f ? 1.f : neg;
+                f.w = fmaf(xv.w, sc, sh) > 0.f ? 1.f : neg;
+            } else {
+                const float4 yv = y4[o];
+                f.x = bn_act_grad_from_output(yv.x, act, slope);
+                f.y = bn_act_grad_from_output(yv.y, act, slope);
+                f.z = bn_act_grad_from_output(yv.z, act, slope);
+                f.w = bn_act_grad_from_output(yv.w, act, slope);
+            }
+            return make_float4(dv.x * f.x, dv.y * f.y, dv.z * f.z, dv.w * f.w);
+        };
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (KEEP) dz[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (threadIdx.x + BNO_THREADS * k < cnt) {
+                const unsigned o = off_of(k);
+                const float4 xv = x4[o], dv = d4[o];
+                const float4 g = dz_of(xv, dv, o);
+                // (FROMX: the sign is rebuilt from x in the second pass as well: keep x, not xhat)
+                xh[k] = xv;
+                if (KEEP) dz[k] = g;
+                a0 += (g.x + g.y) + (g.z + g.w);
+                a1 += (g.x * ((xv.x - m) * is) + g.y * ((xv.y - m) * is)) +
+                      (g.z * ((xv.z - m) * is) + g.w * ((xv.w - m) * is));
+            }
+        }
+        const float s0 = bno_block_sum(a0, red);
+        const float s1 = bno_block_sum(a1, red);
+        gsum += s1;
+        bsum += s0;
+        const float gm = (gamma ? gamma[c] : 1.f) * is;
+        const float k0 = s0 * inv_n, k1 = s1 * inv_n;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (threadIdx.x + BNO_THREADS * k < cnt) {
+                const float4 xv = xh[k];
+                const unsigned o = off_of(k);
+                const float4 g = KEEP ? dz[KEEP ? k : 0] : dz_of(xv, d4[o], o);
+                float4 r;
+                r.x = gm * (g.x - k0 - ((xv.x - m) * is) * k1);
+                r.y = gm * (g.y - k0 - ((xv.y - m) * is) * k1);
+                r.z = gm * (g.z - k0 - ((xv.z - m) * is) * k1);
+                r.w = gm * (g.w - k0 - ((xv.w - m) * is) * k1);
+                o4[o] = r;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (dgamma) dgamma[c] = gsum;
+        if (dbeta) dbeta[c] = bsum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 static int bn_splits(int N, int C) {
     int s = 1024 / C;
     if (s > 64) s = 64;
@@ -750,10 +962,25 @@ static int bn_launch_act_bwd_chunks(const float* x, const float* y, const float*
                                     float* dgamma, float* dbeta, int accumulate, int batch_stats, int N,
                                     BnChunks ch, int C, int HW, int act, float slope, void* ws,
                                     hipStream_t st) {
+    if (!y && act != BN_ACT_NONE && act != BN_ACT_LRELU) return BN_E_BADARG;
+    if (bno_fits(ch, C, HW, x, y, dy, dx)) {
+        for (int z = 0; z < ch.n; ++z)
+            ch.scale[z] = batch_stats ? 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW) : 0.0f;
+        bool keep = true;                               // x and dz both in registers: half the groups each
+        for (int z = 0; z < ch.n; ++z)
+            keep = keep && (long)(ch.end[z] - ch.beg[z]) * (HW >> 2) <= (long)BNO_THREADS * (BNO_NV / 2);
+#define BNO_BWD(F, K)                                                                                          \
+        hipLaunchKernelGGL((k_bn_bwd_owned<F, K>), dim3(C), dim3(BNO_THREADS), 0, st, x, y, dy, mean, invstd,    \
+                           gamma, beta, dx, dgamma, dbeta, accumulate, ch, C, HW, act, slope)
+        if (y) { if (keep) BNO_BWD(false, true); else BNO_BWD(false, false); }
+        else { if (keep) BNO_BWD(true, true); else BNO_BWD(true, false); }
+#undef BNO_BWD
+        BN_LAUNCH_CHECK();
+        return 0;
+    }
     const int S = bnk_set_slices(&ch, bn_splits(N, C));
     float* part0 = (float*)ws;
     float* part1 = part0 + (size_t)C * S;
-    if (!y && act != BN_ACT_NONE && act != BN_ACT_LRELU) return BN_E_BADARG;
     if (y)
         hipLaunchKernelGGL(k_bn_bwd_part<false>, dim3(C, S), dim3(BNK_THREADS), 0, st, x, y, dy, mean,
                            invstd, gamma, beta, part0, part1, ch, C, HW, S, act, slope);
@@ -807,6 +1034,17 @@ int bn_launch_bn_train_fwd_chunks(const float* x, const float* gamma, const floa
     BnChunks ch;
     int N = 0;
     if (!bnk_make_chunks(bounds, n_chunks, &ch, &N)) return BN_E_SHAPE;
+    if (bno_fits(ch, C, HW, x, y, nullptr, nullptr)) {
+        for (int z = 0; z < ch.n; ++z) {
+            const double cnt = (double)(ch.end[z] - ch.beg[z]) * HW;
+            ch.scale[z] = factors ? factors[z] : 0.f;
+            ch.aux[z] = cnt > 1 ? (float)(cnt / (cnt - 1.0)) : 1.f;
+        }
+        hipLaunchKernelGGL(k_bn_fwd_owned, dim3(C), dim3(BNO_THREADS), 0, st, x, gamma, beta, y, mean, invstd,
+                           running_mean, running_var, num_batches, ch, C, HW, eps, act, slope);
+        BN_LAUNCH_CHECK();
+        return 0;
+    }
     const int S = bnk_set_slices(&ch, bn_splits(N, C));
     float* part1 = (float*)ws;
     float* part2 = part1 + (size_t)C * S;
