@@ -617,7 +617,6 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply_fin(
         float4* o4 = reinterpret_cast<float4*>(dx);
         // two groups per thread and iteration: four 16-byte loads in flight
         for (unsigned e0 = threadIdx.x; e0 < cnt; e0 += 2 * BNK_THREADS)
-#pragma unroll
         for (unsigned e = e0; e < e0 + 2 * BNK_THREADS && e < cnt; e += BNK_THREADS) {
             const unsigned n = e / hw4, i = e - n * hw4;
             const size_t o = ((size_t)(n_beg + n) * C + c) * hw4 + i;
