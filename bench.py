@@ -796,7 +796,9 @@ def run(args):
         # fail in seconds, with a line, not in half an hour: short limits for the rendezvous and for
         # every collective of this short job (a user's BN_DIST_* settings win), errors of the
         # collective library raised instead of swallowed
-        os.environ.setdefault('BN_DIST_RDZV_TIMEOUT_S', '120')
+        # (300 s for the rendezvous: on a cold node the ranks' first `import torch` takes minutes and need not end
+        # together; collectives after that fail within 120 s)
+        os.environ.setdefault('BN_DIST_RDZV_TIMEOUT_S', '300')
         os.environ.setdefault('BN_DIST_TIMEOUT_S', '120')
         os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
         local = int(os.environ.get('LOCAL_RANK', '0'))

@@ -789,11 +789,12 @@ def test_errors_are_loud():
     with pytest.raises(_hip.HipLibraryError):
         _hip.conv2d_fwd(x, x, None, (1, 1, 8, 8, 1, 3, 3, 1, 1, 1, 8, 8), 0, 0.0)   # CPU tensor
     xd = torch.zeros((1, 1, 8, 8), device=DEV)
-    wd = torch.zeros((1, 1, 11, 11), device=DEV)
-    with pytest.raises(_hip.HipLibraryError):   # kernel larger than supported -> BN_E_SHAPE
-        _hip.conv2d_fwd(xd, wd, None, (1, 1, 8, 8, 1, 11, 11, 1, 5, 5, 8, 8), 0, 0.0)
+    xd = torch.zeros((1, 1, 24, 24), device=DEV)
+    wd = torch.zeros((1, 1, 17, 17), device=DEV)
+    with pytest.raises(_hip.HipLibraryError):   # kernel larger than supported (16 taps since round 6) -> BN_E_SHAPE
+        _hip.conv2d_fwd(xd, wd, None, (1, 1, 24, 24, 1, 17, 17, 1, 8, 8, 24, 24), 0, 0.0)
     with pytest.raises(_hip.HipLibraryError):
-        _hip.conv2d_fwd(xd.double(), wd, None, (1, 1, 8, 8, 1, 11, 11, 1, 5, 5, 8, 8), 0, 0.0)
+        _hip.conv2d_fwd(xd.double(), wd, None, (1, 1, 24, 24, 1, 17, 17, 1, 8, 8, 24, 24), 0, 0.0)
 
 
 @pytest.mark.parametrize('shape,k,s,pad', [
