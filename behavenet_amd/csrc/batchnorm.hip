@@ -63,17 +63,23 @@ static int bnk_set_slices(BnChunks* ch, int S) {
     for (int z = 0; z < ch->n; ++z) { ch->sl_beg[z] = pos; pos += ch->sl_n[z]; }
     return pos;
 }
-// global slice -> (chunk, frames [n_beg, n_end))
-__device__ __forceinline__ int bnk_slice(const BnChunks& ch, int gs, int* n_beg, int* n_end) {
+// global slice -> chunk; its frames are n_beg + k * n_step for k < n_end - n_beg: the slices of a chunk INTERLEAVE
+// (slice sp takes frames sp, sp + S, sp + 2 S, ... of the chunk).  With contiguous frame ranges per slice the ~1000
+// workgroups of a launch were ~1000 separate streams through the tensor (4.3-4.6 TB/s for the two reductions against
+// 6.2 for the flat normalise pass); interleaved, the workgroups that run at the same time read the same frames'
+// planes, i.e. one region that moves through memory in address order (round 6).
+__device__ __forceinline__ int bnk_slice(const BnChunks& ch, int gs, int* n_beg, int* n_end, int* n_step) {
     int z = 0;
 #pragma unroll
     for (int i = 1; i < BNK_MAX_CHUNKS; ++i)
         if (i < ch.n && gs >= ch.sl_beg[i]) z = i;
     const int sp = gs - ch.sl_beg[z], S = ch.sl_n[z], N = ch.end[z] - ch.beg[z];
-    *n_beg = ch.beg[z] + (int)((long)sp * N / S);
-    *n_end = ch.beg[z] + (int)((long)(sp + 1) * N / S);
+    *n_beg = ch.beg[z] + sp;
+    *n_end = *n_beg + (N - sp + S - 1) / S;              // (count of frames, not the last frame)
+    *n_step = S;
     return z;
 }
+
 __device__ __forceinline__ int bnk_chunk_of(const BnChunks& ch, int n) {
     int z = 0;
 #pragma unroll
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_stats_part(
     int C, int HW, int S) {
     __shared__ float red[4];
     const int c = blockIdx.x, gs = blockIdx.y;
-    int n_beg, n_end;
-    const int z = bnk_slice(ch, gs, &n_beg, &n_end);
+    int n_beg, n_end, n_step;
+    const int z = bnk_slice(ch, gs, &n_beg, &n_end, &n_step);
     const float sh = bnk_shift(x, ch.beg[z], ch.end[z], c, C, HW);
     float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)x) & 15u) == 0);
@@ -186,11 +192,11 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_stats_part(
         for (unsigned e = threadIdx.x; e < cnt; e += 2 * BNK_THREADS) {
             const unsigned e2 = e + BNK_THREADS;
             const unsigned n = e / hw4, i = e - n * hw4;
-            float4 v = x4[((size_t)(n_beg + n) * C + c) * hw4 + i];
+            float4 v = x4[((size_t)(n_beg + n * n_step) * C + c) * hw4 + i];
             float4 w = make_float4(sh, sh, sh, sh);
             if (e2 < cnt) {
                 const unsigned n2 = e2 / hw4, i2 = e2 - n2 * hw4;
-                w = x4[((size_t)(n_beg + n2) * C + c) * hw4 + i2];
+                w = x4[((size_t)(n_beg + n2 * n_step) * C + c) * hw4 + i2];
             }
             v.x -= sh; v.y -= sh; v.z -= sh; v.w -= sh;
             w.x -= sh; w.y -= sh; w.z -= sh; w.w -= sh;
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_stats_part(
         const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
         for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
             const unsigned n = e / HW, i = e - n * HW;
-            const float v = x[((size_t)(n_beg + n) * C + c) * HW + i] - sh;
+            const float v = x[((size_t)(n_beg + n * n_step) * C + c) * HW + i] - sh;
             a1 += v;
             a2 = fmaf(v, v, a2);
         }
@@ -320,8 +326,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
     float* __restrict__ part1, BnChunks ch, int C, int HW, int S, int act, float slope) {
     __shared__ float red[4];
     const int c = blockIdx.x, gs = blockIdx.y;
-    int n_beg, n_end;
-    const int z = bnk_slice(ch, gs, &n_beg, &n_end);
+    int n_beg, n_end, n_step;
+    const int z = bnk_slice(ch, gs, &n_beg, &n_end, &n_step);
     const float m = mean[z * C + c], is = invstd[z * C + c];
     float sc = 1.f, sh = 0.f;
     if (FROMX) bnk_affine(m, is, gamma, beta, c, &sc, &sh);
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
         const float4* d4 = reinterpret_cast<const float4*>(dy);
         for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
             const unsigned n = e / hw4, i = e - n * hw4;
-            const size_t o = ((size_t)(n_beg + n) * C + c) * hw4 + i;
+            const size_t o = ((size_t)(n_beg + n * n_step) * C + c) * hw4 + i;
             const float4 xv = x4[o], dv = d4[o];
             float z0, z1, z2, z3;
             if (FROMX) {
@@ -359,7 +365,7 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_part(
         const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
         for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
             const unsigned n = e / HW, i = e - n * HW;
-            const size_t o = ((size_t)(n_beg + n) * C + c) * HW + i;
+            const size_t o = ((size_t)(n_beg + n * n_step) * C + c) * HW + i;
             const float dz = dy[o] * (FROMX ? (fmaf(x[o], sc, sh) > 0.f ? 1.f : neg)
                                             : bn_act_grad_from_output(y[o], act, slope));
             a0 += dz;
@@ -496,8 +502,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd_fin(
     float eps, int act, float slope) {
     __shared__ float red[2];
     const int c = blockIdx.x, gs = blockIdx.y;
-    int n_beg, n_end;
-    const int z = bnk_slice(ch, gs, &n_beg, &n_end);
+    int n_beg, n_end, n_step;
+    const int z = bnk_slice(ch, gs, &n_beg, &n_end, &n_step);
     float m, v;
     if (gs == 0) {
         // this workgroup also owns the channel's running estimates: one update per chunk, in chunk order
@@ -536,11 +542,11 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd_fin(
         for (unsigned e = threadIdx.x; e < cnt; e += 2 * BNK_THREADS) {
             const unsigned e2 = e + BNK_THREADS;
             const unsigned n = e / hw4, i = e - n * hw4;
-            const size_t o = ((size_t)(n_beg + n) * C + c) * hw4 + i;
+            const size_t o = ((size_t)(n_beg + n * n_step) * C + c) * hw4 + i;
             size_t o2 = o;
             if (e2 < cnt) {
                 const unsigned n2 = e2 / hw4, i2 = e2 - n2 * hw4;
-                o2 = ((size_t)(n_beg + n2) * C + c) * hw4 + i2;
+                o2 = ((size_t)(n_beg + n2 * n_step) * C + c) * hw4 + i2;
             }
             const float4 a = x4[o], b = x4[o2];
             float4 p, q;
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd_fin(
         const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
         for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
             const unsigned n = e / HW, i = e - n * HW;
-            const size_t o = ((size_t)(n_beg + n) * C + c) * HW + i;
+            const size_t o = ((size_t)(n_beg + n * n_step) * C + c) * HW + i;
             y[o] = bn_apply_act(fmaf(x[o], sc, sh), act, slope);
         }
     }
@@ -577,8 +583,8 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply_fin(
     int C, int HW, int S, int act, float slope) {
     __shared__ float red[2];
     const int c = blockIdx.x, gs = blockIdx.y;
-    int n_beg, n_end;
-    const int z = bnk_slice(ch, gs, &n_beg, &n_end);
+    int n_beg, n_end, n_step;
+    const int z = bnk_slice(ch, gs, &n_beg, &n_end, &n_step);
     float v0, v1;
     if (gs == 0 && (dgamma || dbeta)) {
         float g = (accumulate && dgamma) ? dgamma[c] : 0.f, b = (accumulate && dbeta) ? dbeta[c] : 0.f;
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply_fin(
         for (unsigned e0 = threadIdx.x; e0 < cnt; e0 += 2 * BNK_THREADS)
         for (unsigned e = e0; e < e0 + 2 * BNK_THREADS && e < cnt; e += BNK_THREADS) {
             const unsigned n = e / hw4, i = e - n * hw4;
-            const size_t o = ((size_t)(n_beg + n) * C + c) * hw4 + i;
+            const size_t o = ((size_t)(n_beg + n * n_step) * C + c) * hw4 + i;
             const float4 xv = x4[o], dv = d4[o];
             float4 f;
             if (FROMX) {
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply_fin(
         const unsigned cnt = (unsigned)(n_end - n_beg) * HW;
         for (unsigned e = threadIdx.x; e < cnt; e += BNK_THREADS) {
             const unsigned n = e / HW, i = e - n * HW;
-            const size_t o = ((size_t)(n_beg + n) * C + c) * HW + i;
+            const size_t o = ((size_t)(n_beg + n * n_step) * C + c) * HW + i;
             const float dz = dy[o] * (FROMX ? (fmaf(x[o], sc, sh) > 0.f ? 1.f : neg)
                                             : bn_act_grad_from_output(y[o], act, slope));
             dx[o] = g * (dz - k0 - ((x[o] - m) * is) * k1);
@@ -656,14 +662,15 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_bwd_apply_fin(
 // ---------------------------------------------------------------------------------------------
 // Round 6, the deep layers (many channels, small maps: E2-E4 / D0-D1 of the default architecture, a third of the
 // batch-norm launches and none of the big tensors): ONE workgroup of 1024 threads owns a channel.  A chunk's
-// values of that channel (<= 56 K floats: 200 frames of a 16x16 map) are loaded ONCE into registers; mean, then the centred second moment
+// values of that channel (<= 32 K floats: 200 frames of an 8x8 map four times over) are loaded ONCE into registers; mean, then the centred second moment
 // (torch's own two-pass form: no shift, no cancellation) by two workgroup reductions; the normalised values leave
 // from the registers.  Chunks one after the other inside the workgroup, so the running estimates see their updates
 // in order.  Forward = 1 launch and x read once (was stats + normalise: 2 launches, x read twice); backward = 1
-// launch (was sums + apply), x held in registers, dy re-read from the L2 when both do not fit.
+// launch (was sums + apply), x and dz held in registers.  Larger chunks (the 16x16 maps: 51 K floats) stay on the
+// two-launch forms: one workgroup per channel is a chain of four dependent memory phases and loses there.
 // ---------------------------------------------------------------------------------------------
 #define BNO_THREADS 1024
-#define BNO_NV 14                                        // float4 groups per thread: 1024 x 14 x 4 = 56 K floats
+#define BNO_NV 8                                         // float4 groups per thread: 1024 x 8 x 4 = 32 K floats
 
 __device__ __forceinline__ float bno_block_sum(float v, float* red) {
 #pragma unroll
@@ -672,9 +679,19 @@ __device__ __forceinline__ float bno_block_sum(float v, float* red) {
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < BNO_THREADS / 64; ++w) t += red[w];          // fixed order, every thread the same
+    const int nw = blockDim.x >> 6;                                  // (256 threads for the smallest maps)
+    for (int w = 0; w < nw; ++w) t += red[w];                        // fixed order, every thread the same
     return t;
+}
+
+// 256 threads when every chunk of a channel fits them (2x2 maps: 200 groups), else 1024
+static int bno_threads(const BnChunks& ch, int HW) {
+    long m = 0;
+    for (int z = 0; z < ch.n; ++z) {
+        const long cnt = (long)(ch.end[z] - ch.beg[z]) * (HW >> 2);
+        m = cnt > m ? cnt : m;
+    }
+    return m <= 256 * BNO_NV ? 256 : BNO_THREADS;
 }
 
 static bool bno_fits(const BnChunks& ch, int C, int HW, const void* a, const void* b, const void* c2,
@@ -702,7 +719,7 @@ __global__ __launch_bounds__(BNO_THREADS) void k_bn_fwd_owned(
     int act, float slope) {
     __shared__ float red[BNO_THREADS / 64];
     const int c = blockIdx.x;
-    const unsigned hw4 = HW >> 2;
+    const unsigned hw4 = HW >> 2, nthr = blockDim.x;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     float4* y4 = reinterpret_cast<float4*>(y);
     float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
@@ -715,18 +732,18 @@ __global__ __launch_bounds__(BNO_THREADS) void k_bn_fwd_owned(
         // registers spilled.  Maps whose group count divides 1024 (powers of two): linear in k
         const unsigned n0 = threadIdx.x / hw4, i0 = threadIdx.x - n0 * hw4;
         const unsigned off0 = ((unsigned)(ch.beg[z] + n0) * C + c) * hw4 + i0;
-        const bool lin = (BNO_THREADS % hw4) == 0;
-        const unsigned kstride = (BNO_THREADS / hw4) * C * hw4;
+        const bool lin = (nthr % hw4) == 0;
+        const unsigned kstride = (nthr / hw4) * C * hw4;
         auto off_of = [&](int k) __attribute__((always_inline)) {
             if (lin) return off0 + k * kstride;
-            const unsigned e = threadIdx.x + BNO_THREADS * k;
+            const unsigned e = threadIdx.x + nthr * k;
             const unsigned n = e / hw4, i = e - n * hw4;
             return ((unsigned)(ch.beg[z] + n) * C + c) * hw4 + i;
         };
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < BNO_NV; ++k)
-            v[k] = threadIdx.x + BNO_THREADS * k < cnt ? x4[off_of(k)] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[k] = threadIdx.x + nthr * k < cnt ? x4[off_of(k)] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < BNO_NV; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
         const float inv_n = 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW);
@@ -734,7 +751,7 @@ __global__ __launch_bounds__(BNO_THREADS) void k_bn_fwd_owned(
         float q = 0.f;
 #pragma unroll
         for (int k = 0; k < BNO_NV; ++k) {
-            if (threadIdx.x + BNO_THREADS * k < cnt) {
+            if (threadIdx.x + nthr * k < cnt) {
                 const float a0 = v[k].x - m, a1 = v[k].y - m, a2 = v[k].z - m, a3 = v[k].w - m;
                 q += fmaf(a0, a0, a1 * a1) + fmaf(a2, a2, a3 * a3);
             }
@@ -745,7 +762,7 @@ __global__ __launch_bounds__(BNO_THREADS) void k_bn_fwd_owned(
         bnk_affine(m, is, gamma, beta, c, &sc, &sh);
 #pragma unroll
         for (int k = 0; k < BNO_NV; ++k) {
-            if (threadIdx.x + BNO_THREADS * k < cnt) {
+            if (threadIdx.x + nthr * k < cnt) {
                 float4 o;
                 o.x = bn_apply_act(fmaf(v[k].x, sc, sh), act, slope);
                 o.y = bn_apply_act(fmaf(v[k].y, sc, sh), act, slope);
@@ -777,9 +794,9 @@ __global__ __launch_bounds__(BNO_THREADS) void k_bn_bwd_owned(
     const float* __restrict__ beta, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
     int accumulate, BnChunks ch, int C, int HW, int act, float slope) {
     __shared__ float red[BNO_THREADS / 64];
-    constexpr int NV = KEEP ? BNO_NV / 2 : BNO_NV;
+    constexpr int NV = BNO_NV;
     const int c = blockIdx.x;
-    const unsigned hw4 = HW >> 2;
+    const unsigned hw4 = HW >> 2, nthr = blockDim.x;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const float4* y4 = reinterpret_cast<const float4*>(y);
     const float4* d4 = reinterpret_cast<const float4*>(dy);
@@ -797,11 +814,11 @@ __global__ __launch_bounds__(BNO_THREADS) void k_bn_bwd_owned(
         float4 xh[NV], dz[KEEP ? NV : 1];
         const unsigned n0 = threadIdx.x / hw4, i0 = threadIdx.x - n0 * hw4;
         const unsigned off0 = ((unsigned)(ch.beg[z] + n0) * C + c) * hw4 + i0;
-        const bool lin = (BNO_THREADS % hw4) == 0;
-        const unsigned kstride = (BNO_THREADS / hw4) * C * hw4;
+        const bool lin = (nthr % hw4) == 0;
+        const unsigned kstride = (nthr / hw4) * C * hw4;
         auto off_of = [&](int k) __attribute__((always_inline)) {
             if (lin) return off0 + k * kstride;
-            const unsigned e = threadIdx.x + BNO_THREADS * k;
+            const unsigned e = threadIdx.x + nthr * k;
             const unsigned n = e / hw4, i = e - n * hw4;
             return ((unsigned)(ch.beg[z] + n) * C + c) * hw4 + i;
         };
@@ -826,7 +843,7 @@ __global__ __launch_bounds__(BNO_THREADS) void k_bn_bwd_owned(
         for (int k = 0; k < NV; ++k) {
             xh[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (KEEP) dz[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (threadIdx.x + BNO_THREADS * k < cnt) {
+            if (threadIdx.x + nthr * k < cnt) {
                 const unsigned o = off_of(k);
                 const float4 xv = x4[o], dv = d4[o];
                 const float4 g = dz_of(xv, dv, o);
@@ -846,7 +863,7 @@ __global__ __launch_bounds__(BNO_THREADS) void k_bn_bwd_owned(
         const float k0 = s0 * inv_n, k1 = s1 * inv_n;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            if (threadIdx.x + BNO_THREADS * k < cnt) {
+            if (threadIdx.x + nthr * k < cnt) {
                 const float4 xv = xh[k];
                 const unsigned o = off_of(k);
                 const float4 g = KEEP ? dz[KEEP ? k : 0] : dz_of(xv, d4[o], o);
@@ -965,14 +982,11 @@ static int bn_launch_act_bwd_chunks(const float* x, const float* y, const float*
     if (bno_fits(ch, C, HW, x, y, dy, dx)) {
         for (int z = 0; z < ch.n; ++z)
             ch.scale[z] = batch_stats ? 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW) : 0.0f;
-        bool keep = true;                               // x and dz both in registers: half the groups each
-        for (int z = 0; z < ch.n; ++z)
-            keep = keep && (long)(ch.end[z] - ch.beg[z]) * (HW >> 2) <= (long)BNO_THREADS * (BNO_NV / 2);
-#define BNO_BWD(F, K)                                                                                          \
-        hipLaunchKernelGGL((k_bn_bwd_owned<F, K>), dim3(C), dim3(BNO_THREADS), 0, st, x, y, dy, mean, invstd,    \
-                           gamma, beta, dx, dgamma, dbeta, accumulate, ch, C, HW, act, slope)
-        if (y) { if (keep) BNO_BWD(false, true); else BNO_BWD(false, false); }
-        else { if (keep) BNO_BWD(true, true); else BNO_BWD(true, false); }
+        const int thr = bno_threads(ch, HW);
+#define BNO_BWD(F)                                                                                             \
+        hipLaunchKernelGGL((k_bn_bwd_owned<F, true>), dim3(C), dim3(thr), 0, st, x, y, dy, mean, invstd, gamma,  \
+                           beta, dx, dgamma, dbeta, accumulate, ch, C, HW, act, slope)
+        if (y) BNO_BWD(false); else BNO_BWD(true);
 #undef BNO_BWD
         BN_LAUNCH_CHECK();
         return 0;
@@ -1039,7 +1053,7 @@ int bn_launch_bn_train_fwd_chunks(const float* x, const float* gamma, const floa
             ch.scale[z] = factors ? factors[z] : 0.f;
             ch.aux[z] = cnt > 1 ? (float)(cnt / (cnt - 1.0)) : 1.f;
         }
-        hipLaunchKernelGGL(k_bn_fwd_owned, dim3(C), dim3(BNO_THREADS), 0, st, x, gamma, beta, y, mean, invstd,
+        hipLaunchKernelGGL(k_bn_fwd_owned, dim3(C), dim3(bno_threads(ch, HW)), 0, st, x, gamma, beta, y, mean, invstd,
                            running_mean, running_var, num_batches, ch, C, HW, eps, act, slope);
         BN_LAUNCH_CHECK();
         return 0;
