@@ -587,6 +587,65 @@ def test_batchnorm_statistics_with_an_outlier_at_the_first_pixel():
     close(mh.running_var, outs['f32'][2].running_var, outs['f64'][2].running_var, name='bn rvar (outlier)')
 
 
+@pytest.mark.parametrize('shape,bounds', [
+    # the (channel, interleaved frame-slice) grid with finalize / combine folded into the apply launches (round 6):
+    # a chunk of a channel is > 32 K floats, so the owner-workgroup kernels do not take it
+    ((40, 8, 32, 32), [(0, 33), (33, 34), (34, 40)]),           # a one-frame chunk between two others
+    ((40, 8, 30, 36), [(0, 31), (31, 40)]),                     # 270 16-byte groups per plane: no power of two
+    ((70, 4, 64, 32), [(0, 17), (17, 34), (34, 51), (51, 70)]),  # four chunks (the kernels' maximum)
+    ((36, 3, 33, 31), [(0, 35), (35, 36)]),                     # odd plane size: the scalar paths
+    # one workgroup per channel, a chunk in registers (deep layers): 1024 and 256 threads, odd group counts
+    ((210, 64, 8, 8), [(0, 200), (200, 210)]),
+    ((210, 96, 2, 2), [(0, 200), (200, 210)]),
+    ((23, 70, 6, 4), [(0, 9), (9, 10), (10, 23)]),
+])
+def test_batchnorm_chunked_paths(shape, bounds):
+    """Both round-6 forms of the chunked train-mode batch norm against a float64 nn.BatchNorm2d run chunk by chunk:
+    outputs, input gradient, parameter gradients, running estimates (cumulative average: one update per chunk, in
+    order) and the batch counter."""
+    from behavenet_amd.hip_functions import BatchNormActFn, bn_chunks
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((N, C, H, W), generator=g) * 0.7 + torch.randn((1, C, 1, 1), generator=g)
+    gy = torch.randn((N, C, H, W), generator=g)
+    outs = {}
+    for key, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        m = torch.nn.BatchNorm2d(C, momentum=None).to(dt).train()
+        with torch.no_grad():
+            m.weight.copy_(torch.rand((C,), generator=torch.Generator().manual_seed(5)) + 0.5)
+            m.bias.copy_(torch.rand((C,), generator=torch.Generator().manual_seed(6)) - 0.5)
+        xi = x.detach().clone().to(dt).requires_grad_(True)
+        y = torch.cat([F.leaky_relu(m(xi[b:e]), SLOPE) for b, e in bounds])
+        y.backward(gy.to(dt))
+        outs[key] = (y, xi.grad, m)
+    mh = torch.nn.BatchNorm2d(C, momentum=None).to(DEV).train()
+    with torch.no_grad():
+        mh.weight.copy_(outs['f32'][2].weight.detach().float())
+        mh.bias.copy_(outs['f32'][2].bias.detach().float())
+    xh = x.detach().clone().to(DEV).requires_grad_(True)
+    with bn_chunks(bounds):
+        yh = BatchNormActFn.apply(xh, mh.weight, mh.bias, mh, _hip.ACT_LRELU)
+    yh.backward(gy.to(DEV))
+    r32, r64 = outs['f32'], outs['f64']
+    close(yh, r32[0], r64[0], name='bn y')
+    close(xh.grad, r32[1], r64[1], name='bn dx')
+    close(mh.weight.grad, r32[2].weight.grad, r64[2].weight.grad, name='bn dgamma')
+    close(mh.bias.grad, r32[2].bias.grad, r64[2].bias.grad, name='bn dbeta')
+    close(mh.running_mean, r32[2].running_mean, r64[2].running_mean, name='bn rmean')
+    close(mh.running_var, r32[2].running_var, r64[2].running_var, name='bn rvar')
+    assert int(mh.num_batches_tracked) == len(bounds)
+    # run-to-run bit-identical (fixed-order reductions, no atomics)
+    xh2 = x.detach().clone().to(DEV).requires_grad_(True)
+    mh2 = torch.nn.BatchNorm2d(C, momentum=None).to(DEV).train()
+    with torch.no_grad():
+        mh2.weight.copy_(outs['f32'][2].weight.detach().float())
+        mh2.bias.copy_(outs['f32'][2].bias.detach().float())
+    with bn_chunks(bounds):
+        yh2 = BatchNormActFn.apply(xh2, mh2.weight, mh2.bias, mh2, _hip.ACT_LRELU)
+    yh2.backward(gy.to(DEV))
+    assert torch.equal(yh2, yh) and torch.equal(xh2.grad, xh.grad) and torch.equal(mh2.weight.grad, mh.weight.grad)
+
+
 @pytest.mark.parametrize('act', [_hip.ACT_LRELU, _hip.ACT_SIGMOID, _hip.ACT_NONE])
 def test_act_bwd(act):
     g = torch.Generator().manual_seed(0)
