@@ -536,18 +536,16 @@ def _fit(hparams, model, data_generator, exp, method='ae', optimizer=None, write
 
     # test loss, one row per test trial.  NB the reference evaluates `model`, not
     # `best_val_model`, here (training.py:433,442) -- kept.
-    logger.reset_metrics('test')
+    # (one row per test trial: the logger is cleared in front of every trial)
     data_generator.reset_iterators('test')
     best_val_model.eval()
-    for i_test in range(data_generator.n_tot_batches['test']):
-        data, dataset = data_generator.next_batch('test')
+    n_test = data_generator.n_tot_batches['test']
+    for i_test, (data, dataset) in enumerate(data_generator.next_batch('test') for _ in range(n_test)):
         logger.reset_metrics('test')
-        loss_dict = model.loss(data, dataset=dataset, accumulate_grad=False)
-        logger.update_metrics('test', loss_dict, dataset=dataset)
-        trial = data['batch_idx']
-        trial = trial.item() if hasattr(trial, 'item') else int(trial)
-        exp.log(logger.create_metric_row(
-            'test', i_epoch, i_test, dataset, trial=trial, by_dataset=True))
+        logger.update_metrics('test', model.loss(data, dataset=dataset, accumulate_grad=False), dataset=dataset)
+        idx = data['batch_idx']
+        exp.log(logger.create_metric_row('test', i_epoch, i_test, dataset, by_dataset=True,
+                                         trial=idx.item() if hasattr(idx, 'item') else int(idx)))
     exp.save()
     if writer is not None:
         writer.wait()           # the checkpoint files are complete before fit() returns

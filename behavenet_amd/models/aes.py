@@ -583,18 +583,20 @@ class AE(BaseModel):
         return out
 
     def build_model(self):
-        self.hparams['hidden_layer_size'] = self.hparams['n_ae_latents']
-        if self.model_type == 'conv':
-            self.encoding = ConvAEEncoder(self.hparams)
-            self.decoding = ConvAEDecoder(self.hparams)
-        elif self.model_type == 'linear':
-            if self.hparams.get('fit_sess_io_layers', False):
-                raise NotImplementedError
-            n_latents = self.hparams['n_ae_latents']
-            self.encoding = LinearAEEncoder(n_latents, self.img_size)
-            self.decoding = LinearAEDecoder(n_latents, self.img_size, self.encoding)
-        else:
-            raise ValueError('"%s" is an invalid model_type' % self.model_type)
+        hp = self.hparams
+        hp['hidden_layer_size'] = hp['n_ae_latents']
+        kind = self.model_type
+        if kind == 'conv':
+            # (encoder first: the order the seeded generator is consumed in, ref aes.py:680-693)
+            self.encoding, self.decoding = ConvAEEncoder(hp), ConvAEDecoder(hp)
+            return
+        if kind != 'linear':
+            raise ValueError('"%s" is an invalid model_type' % kind)
+        if hp.get('fit_sess_io_layers', False):
+            raise NotImplementedError
+        # tied weights: the decoder shares the encoder's matrix
+        self.encoding = LinearAEEncoder(hp['n_ae_latents'], self.img_size)
+        self.decoding = LinearAEDecoder(hp['n_ae_latents'], self.img_size, self.encoding)
 
     def _reserve_pools(self, x):
         """First call (or a larger batch than seen so far): pre-grow the allocator pools."""
