@@ -23,7 +23,8 @@ import numpy as np
 __all__ = [
     'calculate_output_dim', 'get_decoding_conv_block', 'get_handcrafted_dims',
     'load_default_arch', 'load_handcrafted_arch', 'load_handcrafted_arches',
-    'estimate_model_footprint', 'load_commented_json']
+    'estimate_model_footprint', 'load_commented_json',
+    'default_search_options', 'get_encoding_conv_block', 'get_possible_arch', 'draw_archs']
 
 
 def load_commented_json(path):
@@ -260,3 +261,109 @@ def load_handcrafted_arches(
     return [
         load_handcrafted_arch(input_dim, n, ae_arch_json, batch_size, check_memory, mem_limit_gb)
         for n in n_ae_latents]
+
+
+# ---------------------------------------------------------------------------------------------
+# Random architecture search (ref :7-268).  The SEQUENCE of draws from numpy's global generator is the
+# reference's -- seed, padding type, then per layer: kernel size, stride, channel count, [pool size], stop
+# flag -- so a seed names the same architecture in both code bases (tests/golden/drawn_archs.json, recorded
+# from the imported reference).  The construction differs: layers are collected as records and the
+# ``ae_encoding_*`` lists are written once at the end.
+# ---------------------------------------------------------------------------------------------
+def default_search_options():
+    """The search space of ``get_possible_arch`` (ref :90-100): what a layer may be drawn from."""
+    return {
+        'possible_kernel_sizes': np.asarray([3, 5, 7, 9]),
+        'possible_strides': np.asarray([1, 2]),                 # always 1 under max pooling
+        'possible_strides_probs': np.asarray([0.1, 0.9]),
+        'possible_max_pool_sizes': np.asarray([2]),             # (larger windows: not implemented there either)
+        'possible_n_channels': np.asarray([16, 32, 64, 128, 256, 512]),
+        'prob_stopping': np.arange(0, 1, .05),                  # chance to stop after the k-th block
+        'max_latents': 64,
+    }
+
+
+_ENC_KEYS = ('n_channels', 'kernel_size', 'stride_size', 'x_dim', 'y_dim', 'x_padding', 'y_padding', 'layer_type')
+
+
+def get_encoding_conv_block(arch, opts):
+    """Draw the encoder of ``arch`` (needs ``ae_input_dim``, ``ae_network_type``, ``ae_padding_type``) layer by
+    layer from ``opts`` until the feature map would fall below ``opts['max_latents']`` values, a side below one
+    pixel, or the stop flag comes up; fills the ``ae_encoding_*`` lists (ref :132-268)."""
+    c_in, y_in, x_in = arch['ae_input_dim']
+    pooled = arch['ae_network_type'] == 'max_pooling'
+    pad = arch['ae_padding_type']
+    floor = opts['max_latents']
+    menu = opts['possible_n_channels']
+
+    def survives(c, y, x):
+        return c * x * y >= floor and min(x, y) >= 1
+
+    layers = []          # (channels, kernel, stride, x_dim, y_dim, x_padding, y_padding, kind)
+    cur_c, cur_y, cur_x = c_in, y_in, x_in
+    blocks = 0
+    while cur_c * cur_y * cur_x >= floor and min(cur_y, cur_x) >= 1:
+        kernel = np.random.choice(opts['possible_kernel_sizes'])
+        stride = 1 if pooled else np.random.choice(opts['possible_strides'], p=opts['possible_strides_probs'])
+        y_out, y_lo, y_hi = calculate_output_dim(cur_y, kernel, stride, padding_type=pad, layer_type='conv')
+        x_out, x_lo, x_hi = calculate_output_dim(cur_x, kernel, stride, padding_type=pad, layer_type='conv')
+        # channel counts never shrink; the smallest admissible one is favoured 3 : 1 over all the others together
+        wider = menu[menu >= cur_c]
+        weights = [1.0] if len(wider) == 1 else [.75] + [.25 / (len(wider) - 1)] * (len(wider) - 1)
+        n_ch = np.random.choice(wider, p=weights)
+        if not survives(n_ch, y_out, x_out):
+            break
+        layers.append((n_ch, kernel, stride, x_out, y_out, (x_lo, x_hi), (y_lo, y_hi), 'conv'))
+        cur_c, cur_y, cur_x = n_ch, y_out, x_out
+        if pooled:
+            window = np.random.choice(opts['possible_max_pool_sizes'])
+            y_out, y_lo, y_hi = calculate_output_dim(cur_y, window, window, padding_type=pad, layer_type='maxpool')
+            x_out, x_lo, x_hi = calculate_output_dim(cur_x, window, window, padding_type=pad, layer_type='maxpool')
+            if not survives(n_ch, y_out, x_out):
+                layers.pop()                      # a convolution is never left without its pooling layer
+                break
+            layers.append((n_ch, window, window, x_out, y_out, (x_lo, x_hi), (y_lo, y_hi), 'maxpool'))
+            cur_y, cur_x = y_out, x_out
+        p_stop = opts['prob_stopping'][blocks]
+        if np.random.choice([0, 1], p=[1 - p_stop, p_stop]):
+            break
+        blocks += 1
+    for pos, key in enumerate(_ENC_KEYS):
+        arch['ae_encoding_' + key] = [rec[pos] for rec in layers]
+    return arch
+
+
+def get_possible_arch(input_dim, n_ae_latents, arch_seed=0):
+    """One random strides-only conv architecture, reproducible from ``arch_seed`` (ref :70-129)."""
+    np.random.seed(arch_seed)
+    opts = default_search_options()
+    if n_ae_latents > opts['max_latents']:
+        raise ValueError('Number of latents higher than max latents')
+    arch = {'ae_input_dim': input_dim, 'model_type': 'conv', 'n_ae_latents': n_ae_latents,
+            'ae_decoding_last_FF_layer': 0, 'ae_batch_norm': 0, 'ae_batch_norm_momentum': None,
+            'ae_network_type': 'strides_only'}
+    arch['ae_padding_type'] = ('valid', 'same')[np.random.randint(2)]
+    return get_decoding_conv_block(get_encoding_conv_block(arch, opts))
+
+
+def draw_archs(batch_size, input_dim, n_ae_latents, n_archs=100, check_memory=True, mem_limit_gb=5.0):
+    """``n_archs`` distinct random architectures with ``n_ae_latents`` latents (seeds 0, 1, 2, ... in order);
+    with ``check_memory`` those whose estimated footprint at ``batch_size`` exceeds ``mem_limit_gb`` are skipped
+    and the others carry ``mem_size_gb`` (ref :7-67)."""
+    kept, seed = [], 0
+    while len(kept) < n_archs:
+        cand = get_possible_arch(input_dim, n_ae_latents, arch_seed=seed)
+        seed += 1
+        if check_memory:
+            from behavenet_amd.models import AE
+            probe = copy.deepcopy(cand)
+            probe.update(model_class='ae', n_input_channels=input_dim[0], y_pixels=input_dim[1],
+                         x_pixels=input_dim[2])
+            gb = estimate_model_footprint(AE(probe), tuple([batch_size] + list(input_dim))) / 1e9
+            if gb > mem_limit_gb:
+                print('Model size of %02.3f GB is larger than limit of %1.3f GB; skipping model' % (gb, mem_limit_gb))
+                continue
+            cand['mem_size_gb'] = gb
+        if not any(cand == other for other in kept):
+            kept.append(cand)
+    return kept

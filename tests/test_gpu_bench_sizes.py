@@ -366,6 +366,39 @@ def test_whole_model_other_architectures_at_bench_batch_vs_oracle(which):
         assert err <= tol, 'AE %s batch %d grad %s: normalised max err %.3e' % (which, n_frames, k, err)
 
 
+@pytest.mark.parametrize('seed', [0, 2, 6, 9, 11, 13])
+def test_whole_model_architectures_the_search_draws_vs_oracle(seed):
+    """Architectures exactly as ``get_possible_arch`` draws them (the reference's random search, same seeds -> same
+    architectures: tests/test_planner.py) on 1x64x64 frames: 'valid' padding with odd maps (28 -> 12 -> 5, 31 -> 15 ->
+    5 -> 2, down to 1x1), stride-1 9x9 / 5x5 layers, kernels 3-9, 16 to 256 channels -- whatever rung of the dispatch
+    each layer lands on, loss and every parameter gradient against the float64 oracle on the device's LeakyReLU
+    branch pattern."""
+    from behavenet_amd.models import AE
+    from behavenet_amd.models.ae_model_architecture_generator import get_possible_arch
+    from oracle import ref_cpu
+    from tests.branches import record_branches, BranchReplay
+    from tests.golden_utils import base_hparams, make_frames
+    from tests.test_gpu_model import grads_close_on_same_branches
+
+    dim, n_frames = [1, 64, 64], 12
+    arch = get_possible_arch(list(dim), 12, arch_seed=seed)
+    arch.update(n_input_channels=dim[0], y_pixels=dim[1], x_pixels=dim[2])
+    torch.manual_seed(0)
+    hip = AE(base_hparams(dict(arch), 'ae')).to(DEV)
+    torch.manual_seed(0)
+    ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae')).double()
+    x = torch.from_numpy(make_frames(n_frames, dim, seed=37 + seed))
+    hip.train()
+    hip.zero_grad(set_to_none=True)
+    with record_branches(hip) as rec:
+        lh = hip.loss({'images': x.to(DEV)[None]}, dataset=0, accumulate_grad=True)['loss']
+    with BranchReplay(rec) as br:
+        l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True)['loss']
+    br.assert_only_ties()
+    assert lh == pytest.approx(l64, rel=1e-5)
+    grads_close_on_same_branches(hip, ora64, 'AE drawn with seed %d' % seed)
+
+
 def test_whole_model_batch256_loss_and_gradients_vs_oracle():
     """BASELINE configs[1] at full size through ``AE.loss`` (one forward / one backward pass over
     256 frames, the reference's 200 + 56 chunk normalisation; reference aes.py:722-773): loss

@@ -121,3 +121,82 @@ def test_load_handcrafted_arches_latent_formats():
     assert [a['n_ae_latents'] for a in archs] == [4, 8]
     archs = gen.load_handcrafted_arches([1, 32, 32], '12', None, check_memory=False)
     assert archs[0]['n_ae_latents'] == 12
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# random architecture search (ref ae_model_architecture_generator.py:7-268): a seed must name the same architecture
+# as in the reference -- tests/golden/drawn_archs.json was recorded from the imported reference
+# (tests/golden/make_drawn_archs.py)
+# ---------------------------------------------------------------------------------------------------------------
+def _drawn():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'drawn_archs.json')) as f:
+        return json.load(f)
+
+
+def _plain(v):
+    import numpy as np
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    if isinstance(v, np.generic):
+        return v.item()
+    return v
+
+
+def test_get_possible_arch_draws_the_references_architectures():
+    from behavenet_amd.models import ae_model_architecture_generator as gen
+    drawn = _drawn()
+    keys = [k for k in drawn if not k.startswith('maxpool/')]
+    assert len(keys) == 120
+    kinds = set()
+    for key in keys:
+        dims, n_lat, seed = key.split('/')
+        arch = gen.get_possible_arch([int(v) for v in dims.split('x')], int(n_lat), arch_seed=int(seed))
+        assert _plain(arch) == drawn[key], key
+        kinds.add((arch['ae_padding_type'], len(arch['ae_encoding_n_channels'])))
+    assert len(kinds) >= 8                      # both padding types, depths from one layer to many
+    with pytest.raises(ValueError):
+        gen.get_possible_arch([2, 32, 32], 65, 0)
+
+
+def test_get_encoding_conv_block_under_max_pooling_matches_the_reference():
+    import numpy as np
+    from behavenet_amd.models import ae_model_architecture_generator as gen
+    drawn = _drawn()
+    opts = {'possible_kernel_sizes': np.asarray([3, 5]), 'possible_strides': np.asarray([1, 2]),
+            'possible_strides_probs': np.asarray([0.1, 0.9]), 'possible_max_pool_sizes': np.asarray([2]),
+            'possible_n_channels': np.asarray([16, 32, 64, 128]), 'prob_stopping': np.arange(0, 1, .05),
+            'max_latents': 64}
+    n = 0
+    for key in drawn:
+        if not key.startswith('maxpool/'):
+            continue
+        _, pad, seed = key.split('/')
+        arch = {'ae_input_dim': [2, 32, 32], 'model_type': 'conv', 'n_ae_latents': 6,
+                'ae_decoding_last_FF_layer': 0, 'ae_network_type': 'max_pooling', 'ae_padding_type': pad}
+        np.random.seed(int(seed))
+        got = gen.get_encoding_conv_block(arch, opts)
+        assert _plain(got) == drawn[key], key
+        kinds = got['ae_encoding_layer_type']
+        assert all(a == 'conv' and b == 'maxpool' for a, b in zip(kinds[0::2], kinds[1::2])) and len(kinds) % 2 == 0
+        n += 1
+    assert n == 24
+
+
+def test_draw_archs_distinct_and_memory_checked():
+    """The reference's own test (tests/test_models/test_ae_model_architecture_generator.py:7-38)."""
+    from behavenet_amd.models import ae_model_architecture_generator as gen
+    archs = gen.draw_archs(batch_size=100, input_dim=[2, 32, 32], n_ae_latents=6, n_archs=3, check_memory=False,
+                           mem_limit_gb=None)
+    assert len(archs) == 3 and all(a['n_ae_latents'] == 6 for a in archs)
+    assert all(sum(a == b for b in archs) == 1 for a in archs)
+    # seeds in order: the first three distinct draws
+    assert archs[0] == gen.get_possible_arch([2, 32, 32], 6, arch_seed=0)
+    archs = gen.draw_archs(batch_size=100, input_dim=[2, 32, 32], n_ae_latents=6, n_archs=3, check_memory=True,
+                           mem_limit_gb=1)
+    assert len(archs) == 3
+    assert all(a['mem_size_gb'] < 1 and a['n_ae_latents'] == 6 for a in archs)
+    assert all(sum(a == b for b in archs) == 1 for a in archs)
