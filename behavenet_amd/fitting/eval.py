@@ -17,7 +17,7 @@ import torch
 from behavenet_amd import _hip
 from behavenet_amd.fitting import distributed as bdist
 
-__all__ = ['export_latents', 'encode_trial', 'encode_trial_device']
+__all__ = ['export_latents', 'encode_trial', 'encode_trial_device', 'get_reconstruction']
 
 
 def encode_trial(model, y, sess=None, labels_2d=None, chunk_size=200):
@@ -226,3 +226,46 @@ def export_latents(data_generator, model, filename=None):
             pickle.dump({'latents': latents[sess], 'trials': dataset.batch_idxs}, f)
         filenames.append(out)
     return filenames
+
+
+# which element of ``model(x)`` holds the latents (the reconstruction is always element 0): AE / cond-AE -> (x_hat, z);
+# AEMSP -> (x_hat, z, y); VAE / beta-TC-VAE / cond-VAE -> (x_hat, z, mu, logvar); PS-VAE / MSPS-VAE -> (x_hat, sample,
+# mu, logvar, y_hat), where the reference takes mu
+_LATENTS_AT = {'ae': 1, 'cond-ae': 1, 'cond-ae-msp': 1, 'vae': 1, 'beta-tcvae': 1, 'cond-vae': 1, 'ps-vae': 2,
+               'msps-vae': 2}
+
+
+def get_reconstruction(model, inputs, dataset=None, return_latents=False, labels=None, labels_2d=None,
+                       apply_inverse_transform=True, use_mean=True):
+    """Images from images (through the whole model) or from latents (through the decoder) as numpy arrays
+    (ref fitting/eval.py:286-374; the caller of ``forward`` / ``decoding`` behind the reference's plotting code).
+
+    ``inputs`` with two dimensions are latents, anything else images.  Latents of the label-aware classes are
+    completed first: cond-AE / cond-VAE get ``labels`` appended, AEMSP / PS-VAE / MSPS-VAE latents given in the
+    transformed space are mapped back (``apply_inverse_transform``).  ``use_mean`` picks the posterior mean for the
+    variational classes -- except cond-VAE, which the reference calls without it (kept: it samples there).
+    Runs under ``no_grad`` in eval mode."""
+    cls = model.hparams['model_class']
+    model.eval()
+    # (arrays go where the model's parameters are -- the reference sends them to hparams['device'], which a model
+    # moved with .to() no longer matches)
+    t = inputs if torch.is_tensor(inputs) else torch.Tensor(inputs).to(next(model.parameters()).device)
+    with torch.no_grad():
+        if t.dim() != 2:
+            if cls not in _LATENTS_AT:
+                raise ValueError('Invalid model class %s' % cls)
+            kwargs = {'dataset': dataset}
+            if cls in ('vae', 'beta-tcvae', 'ps-vae', 'msps-vae'):
+                kwargs['use_mean'] = use_mean
+            elif cls in ('cond-ae', 'cond-vae'):
+                kwargs.update(labels=labels, labels_2d=labels_2d)
+            out = model(t, **kwargs)
+            recon, latents = out[0], out[_LATENTS_AT[cls]]
+        else:
+            if cls in ('cond-ae', 'cond-vae'):
+                t = torch.cat((t, labels), dim=1)
+            elif cls in ('cond-ae-msp', 'ps-vae', 'msps-vae') and apply_inverse_transform:
+                t = model.get_inverse_transformed_latents(t, as_numpy=False)
+            recon, latents = model.decoding(t, None, None, dataset=None), t
+    recon, latents = recon.detach().cpu().numpy(), latents.detach().cpu().numpy()
+    return (recon, latents) if return_latents else recon

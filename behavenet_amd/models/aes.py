@@ -1007,7 +1007,8 @@ class AEMSP(AE):
         P = self.projection.weight.detach().cpu().numpy()
         complement = null_space(P).T                           # (n_latents - n_labels, n_latents)
         full = torch.from_numpy(np.vstack((P, complement))).to(torch.float32)
-        self.U.weight = nn.Parameter(full.to(self.hparams['device']), requires_grad=False)
+        # (next to P, wherever the model was moved; the reference sends it to hparams['device'])
+        self.U.weight = nn.Parameter(full.to(self.projection.weight.device), requires_grad=False)
 
     def get_transformed_latents(self, inputs, dataset=None, as_numpy=True):
         """U z (ref :1082-1122) of latents (2-d input) or of the latents of images (anything else)."""

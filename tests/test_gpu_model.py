@@ -969,3 +969,65 @@ def test_export_latents_from_a_trial_store_graph_replay_equals_eager(tmp_path):
     with torch.no_grad():
         want = ora.encoding(torch.from_numpy(trials[i].astype(np.float32) / 255), dataset=0)[0].numpy()
     assert np.abs(a['latents'][i] - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize('model_class', ['ae', 'vae', 'beta-tcvae', 'cond-ae', 'cond-vae', 'cond-ae-msp', 'ps-vae'])
+def test_get_reconstruction_from_images_and_from_latents(model_class):
+    """``fitting.eval.get_reconstruction`` (ref eval.py:286-374) for every class of the path: from images -- the
+    reconstruction and the right element of ``forward`` as latents, equal to the CPU oracle's forward on the same
+    parameters -- and from latents through the decoder (labels appended for the conditional classes, latents mapped
+    back from the transformed space for AEMSP / PS-VAE); numpy out, no gradient state left behind."""
+    from behavenet_amd.fitting.eval import get_reconstruction
+    extra = {'msp.alpha': 0.05, 'conditional_encoder': False, 'vae.beta': 1.0, 'vae.beta_anneal_epochs': 0,
+             'beta_tcvae.beta': 1.0, 'beta_tcvae.beta_anneal_epochs': 0, 'ps_vae.alpha': 1, 'ps_vae.beta': 1,
+             'ps_vae.anneal_epochs': 0, 'max_n_epochs': 4}
+    n_labels = 4 if model_class in ('cond-ae', 'cond-vae', 'cond-ae-msp', 'ps-vae') else 0
+    meta = {'dim': [1, 32, 32], 'n_lat': 8, 'model_class': model_class, 'extra_hp': extra, 'n_labels': n_labels,
+            'n_frames': 6}
+    hip, ora, hp = _pair(meta)
+    if model_class == 'cond-ae-msp':
+        hip.create_orthogonal_matrix()          # U = [P; null space of P]: what save() does before it writes
+    data_c = case_data(meta)
+    x = data_c['images'][0]
+    labels = data_c['labels'][0] if n_labels else None
+    kw = {'labels': labels.to(DEV)} if model_class in ('cond-ae', 'cond-vae') else {}
+    recon, latents = get_reconstruction(hip, x.to(DEV), dataset=0, return_latents=True, **kw)
+    assert isinstance(recon, np.ndarray) and recon.shape == tuple(x.shape) and latents.shape == (6, 8)
+    assert not hip.training
+    ora.eval()
+    with torch.no_grad():
+        okw = {'labels': labels} if model_class in ('cond-ae', 'cond-vae') else {}
+        if model_class in ('vae', 'beta-tcvae', 'ps-vae'):
+            okw['use_mean'] = True
+        out = ora(x, dataset=0, **okw)
+    slot = 2 if model_class == 'ps-vae' else 1
+    if model_class != 'cond-vae':               # (the reference calls cond-VAE without use_mean: it samples)
+        assert np.abs(recon - out[0].numpy()).max() <= 2e-6
+        assert np.abs(latents - out[slot].numpy()).max() <= 2e-5 * max(1.0, np.abs(out[slot].numpy()).max())
+    # plain numpy in, reconstruction only
+    again = get_reconstruction(hip, x.numpy(), dataset=0, **kw)
+    assert isinstance(again, np.ndarray) and again.shape == recon.shape
+    if model_class != 'cond-vae':
+        assert np.array_equal(again, recon)
+    # from latents
+    z = torch.from_numpy(latents).to(DEV)
+    lkw = {'labels': labels.to(DEV)} if model_class in ('cond-ae', 'cond-vae') else {}
+    rec_z, z_used = get_reconstruction(hip, z, return_latents=True, **lkw)
+    with torch.no_grad():
+        if model_class in ('cond-ae', 'cond-vae'):
+            z_in = torch.cat((z, labels.to(DEV)), dim=1)
+        elif model_class in ('cond-ae-msp', 'ps-vae'):
+            z_in = hip.get_inverse_transformed_latents(z, as_numpy=False)
+        else:
+            z_in = z
+        want = hip.decoding(z_in, None, None, dataset=None)
+    assert np.array_equal(rec_z, want.cpu().numpy()) and np.array_equal(z_used, z_in.cpu().numpy())
+    if model_class == 'ae':
+        # the decoder applied to the encoder's latents is the forward pass
+        assert np.abs(rec_z - recon).max() <= 1e-6
+    for p_ in hip.parameters():
+        assert p_.grad is None or float(p_.grad.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        hip.hparams['model_class'] = 'nope'
+        get_reconstruction(hip, x.to(DEV))
+    hip.hparams['model_class'] = model_class
