@@ -14,3 +14,23 @@ import os as _os
 _os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 __version__ = '0.1.0'
+
+
+# the reference's package-level helpers (behavenet/__init__.py:5-53): where the user's data / results / figures
+# and the per-dataset parameter files live
+def get_params_dir():
+    """``~/.behavenet``: directories.json and the ``<lab>_<expt>_params.json`` files."""
+    return _os.path.join(_os.path.expanduser('~'), '.behavenet')
+
+
+def get_user_dir(type):                         # noqa: A002 (the reference's argument name)
+    """'data' | 'save' | 'figs' directory (``fitting.hyperparam_utils.get_user_dir``)."""
+    from behavenet_amd.fitting.hyperparam_utils import get_user_dir as _impl
+    return _impl(type)
+
+
+def make_dir_if_not_exists(save_file):
+    """Create the directory a file is about to be written into."""
+    folder = _os.path.dirname(save_file)
+    if folder:
+        _os.makedirs(folder, exist_ok=True)

@@ -29,7 +29,7 @@ __all__ = [
     'get_subdirs', 'get_session_dir', 'get_expt_dir', 'read_session_info_from_csv',
     'export_session_info_to_csv', 'contains_session', 'find_session_dirs', 'experiment_exists',
     'get_model_params', 'export_hparams', 'create_tt_experiment', 'create_experiment',
-    'get_best_model_version', 'get_best_model_and_data']
+    'get_best_model_version', 'get_best_model_and_data', 'get_lab_example']
 
 AE_CLASSES = ('ae', 'vae', 'beta-tcvae', 'cond-vae', 'cond-ae', 'cond-ae-msp', 'ps-vae',
               'msps-vae')
@@ -495,3 +495,12 @@ def _print_hparams(hparams):
         for key in load_config_json(path).keys():
             print('    {}: {}'.format(key, hparams.get(key)))
     print('')
+
+
+def get_lab_example(hparams, lab, expt):
+    """Update ``hparams`` in place with the dataset's parameters, ``~/.behavenet/<lab>_<expt>_params.json``
+    (ref fitting/utils.py:780-803: frame size, channels, neural bin size ... of a dataset the user has registered)."""
+    import json
+    from behavenet_amd import get_params_dir
+    with open(os.path.join(get_params_dir(), '%s_%s_params.json' % (lab, expt)), 'r') as f:
+        hparams.update(json.load(f))

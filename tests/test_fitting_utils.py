@@ -385,3 +385,30 @@ def test_paths_and_bookkeeping_match_the_reference_module(tree):
         exists, version = utils.experiment_exists(dict(probe), which_version=True)
         assert bool(exists) == case['exists'], case
         assert (None if version is None else int(version)) == case['version'], case
+
+
+def test_package_level_directories_and_lab_example(tmp_path, monkeypatch):
+    """behavenet/__init__.py:5-53 and fitting/utils.py:780-803: the user directory helpers a script written against the
+    reference imports from the package, and the per-dataset parameter file."""
+    import json
+    import os
+    import behavenet_amd
+    from behavenet_amd.fitting.utils import get_lab_example
+    monkeypatch.setenv('HOME', str(tmp_path))
+    for k in ('BEHAVENET_DATA_DIR', 'BEHAVENET_SAVE_DIR', 'BEHAVENET_FIGS_DIR'):
+        monkeypatch.delenv(k, raising=False)
+    assert behavenet_amd.get_params_dir() == os.path.join(str(tmp_path), '.behavenet')
+    assert behavenet_amd.get_user_dir('data') == os.path.join(str(tmp_path), '.behavenet', 'data')
+    os.makedirs(behavenet_amd.get_params_dir())
+    with open(os.path.join(behavenet_amd.get_params_dir(), 'directories.json'), 'w') as f:
+        json.dump({'data_dir': '/d', 'save_dir': '/s', 'figs_dir': '/f'}, f)
+    assert [behavenet_amd.get_user_dir(k) for k in ('data', 'save', 'figs')] == ['/d', '/s', '/f']
+    with open(os.path.join(behavenet_amd.get_params_dir(), 'musall_vistrained_params.json'), 'w') as f:
+        json.dump({'y_pixels': 128, 'x_pixels': 128, 'n_input_channels': 2}, f)
+    hp = {'lab': 'musall', 'y_pixels': 1}
+    get_lab_example(hp, 'musall', 'vistrained')
+    assert hp == {'lab': 'musall', 'y_pixels': 128, 'x_pixels': 128, 'n_input_channels': 2}
+    target = os.path.join(str(tmp_path), 'a', 'b', 'file.pkl')
+    behavenet_amd.make_dir_if_not_exists(target)
+    assert os.path.isdir(os.path.dirname(target)) and not os.path.exists(target)
+    behavenet_amd.make_dir_if_not_exists(target)                    # twice: no error
