@@ -29,7 +29,8 @@ import torch
 from behavenet_amd import _hip
 
 __all__ = ['split_trials', 'SyntheticSession', 'SyntheticSessionsGenerator',
-           'SingleSessionDatasetBatchedLoad', 'ConcatSessionsGenerator']
+           'SingleSessionDatasetBatchedLoad', 'SingleSessionDataset', 'ConcatSessionsGenerator',
+           'ConcatSessionsGeneratorMulti']
 
 
 def split_trials(n_trials, rng_seed=0, train_tr=8, val_tr=1, test_tr=1, gap_tr=0):
@@ -617,3 +618,27 @@ class ConcatSessionsGenerator(SyntheticSessionsGenerator):
         for ds in self.datasets:
             out += ds.__str__()
         return out
+
+
+class SingleSessionDataset(SingleSessionDatasetBatchedLoad):
+    """The reference's in-memory variant (ref data_generator.py:345-429: every trial read at construction).  Here
+    the trials of a session are read on first use and then kept (``keep_in_memory``), which serves the same
+    purpose without the start-up pass; the name exists so that code written against the reference finds it."""
+
+    def __init__(self, data_dir, lab='', expt='', animal='', session='', signals=None, transforms=None,
+                 paths=None, device='cuda', as_numpy=False):
+        super().__init__(data_dir, lab=lab, expt=expt, animal=animal, session=session, signals=signals,
+                         transforms=transforms, paths=paths, device=device, as_numpy=as_numpy, keep_in_memory=True)
+
+
+class ConcatSessionsGeneratorMulti(ConcatSessionsGenerator):
+    """Several sessions per training batch (ref data_generator.py:636-790, the MSPS-VAE's generator): the
+    ``n_sessions_per_batch`` form of :class:`ConcatSessionsGenerator` under the reference's name and default."""
+
+    def __init__(self, data_dir, ids_list, signals_list=None, transforms_list=None, paths_list=None,
+                 device='cuda', as_numpy=False, batch_load=True, rng_seed=0, trial_splits=None, train_frac=1.0,
+                 n_sessions_per_batch=2, **kwargs):
+        super().__init__(data_dir, ids_list, signals_list=signals_list, transforms_list=transforms_list,
+                         paths_list=paths_list, device=device, as_numpy=as_numpy, batch_load=batch_load,
+                         rng_seed=rng_seed, trial_splits=trial_splits, train_frac=train_frac,
+                         n_sessions_per_batch=n_sessions_per_batch, **kwargs)
