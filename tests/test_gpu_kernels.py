@@ -598,6 +598,9 @@ def test_batchnorm_statistics_with_an_outlier_at_the_first_pixel():
     ((210, 64, 8, 8), [(0, 200), (200, 210)]),
     ((210, 96, 2, 2), [(0, 200), (200, 210)]),
     ((23, 70, 6, 4), [(0, 9), (9, 10), (10, 23)]),
+    # more chunks than one launch takes (four): the entry point falls back to one call per chunk
+    ((15, 8, 8, 8), [(0, 3), (3, 6), (6, 9), (9, 12), (12, 15)]),
+    ((45, 4, 64, 32), [(0, 17), (17, 18), (18, 30), (30, 31), (31, 45)]),
 ])
 def test_batchnorm_chunked_paths(shape, bounds):
     """Both round-6 forms of the chunked train-mode batch norm against a float64 nn.BatchNorm2d run chunk by chunk:
