@@ -479,18 +479,31 @@ __device__ __forceinline__ void bnk_reduce_parts(const float* __restrict__ p1, c
     *o2 = red[1];
 }
 
-// mean / biased variance of (chunk z, channel c) from the one-pass partial sums (k_bn_stats_part)
+// The arithmetic between the reduced sums and (mean, variance, invstd) -- ONE piece of machine code (noinline) for
+// every caller.  The forward pass normalises with values a workgroup derives itself, the backward pass rebuilds the
+// activation's sign from the STORED mean / invstd: the two must agree to the last bit, and an inlined copy per call
+// site leaves that to the compiler's contraction choices (`shift + s1 * inv_n` fused at one site and not at the
+// other moved one pre-activation in 10^8 across zero: tools/fuzz_archs.py, seed 410 with batch norm -- a branch the
+// backward pass then took differently from the forward pass).
+__device__ __noinline__ void bnk_finish_stats(float s1, float s2, float inv_n, float shift, float eps, float* m,
+                                              float* v, float* is) {
+    const float d = s1 * inv_n;
+    *m = shift + d;
+    *v = fmaxf(fmaf(-d, d, s2 * inv_n), 0.f);
+    *is = 1.0f / sqrtf(*v + eps);
+}
+
+// mean / biased variance / invstd of (chunk z, channel c) from the one-pass partial sums (k_bn_stats_part)
 __device__ __forceinline__ void bnk_stats_of(const float* __restrict__ x, const float* __restrict__ part1,
                                              const float* __restrict__ part2, const BnChunks& ch, int z, int c,
-                                             int C, int HW, int S, float* red, float* m, float* v) {
+                                             int C, int HW, int S, float eps, float* red, float* m, float* v,
+                                             float* is) {
     float s1, s2;
     bnk_reduce_parts(part1 + (size_t)c * S + ch.sl_beg[z], part2 + (size_t)c * S + ch.sl_beg[z], ch.sl_n[z], red,
                      &s1, &s2);
     const float inv_n = 1.0f / ((float)(ch.end[z] - ch.beg[z]) * (float)HW);
     const float sh = bnk_shift(x, ch.beg[z], ch.end[z], c, C, HW);
-    const float d = s1 * inv_n;
-    *m = sh + d;
-    *v = fmaxf(fmaf(-d, d, s2 * inv_n), 0.f);
+    bnk_finish_stats(s1, s2, inv_n, sh, eps, m, v, is);
 }
 
 // statistics finalize + y = act((x - mean) * invstd * gamma + beta) of one (channel, slice, chunk)
@@ -504,22 +517,22 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd_fin(
     const int c = blockIdx.x, gs = blockIdx.y;
     int n_beg, n_end, n_step;
     const int z = bnk_slice(ch, gs, &n_beg, &n_end, &n_step);
-    float m, v;
+    float m, v, is;
     if (gs == 0) {
         // this workgroup also owns the channel's running estimates: one update per chunk, in chunk order
         // (factor scale[z], unbiasing aux[z]), and the batch counter
         float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
-        float m0 = 0.f, v0 = 0.f;
+        float m0 = 0.f, v0 = 0.f, is0 = 0.f;
         for (int zz = 0; zz < ch.n; ++zz) {
-            float mz, vz;
-            bnk_stats_of(x, part1, part2, ch, zz, c, C, HW, S, red, &mz, &vz);
-            if (zz == 0) { m0 = mz; v0 = vz; }
+            float mz, vz, iz;
+            bnk_stats_of(x, part1, part2, ch, zz, c, C, HW, S, eps, red, &mz, &vz, &iz);
+            if (zz == 0) { m0 = mz; v0 = vz; is0 = iz; }
             const float momentum = ch.scale[zz];
             rm = (1.f - momentum) * rm + momentum * mz;
             rv = (1.f - momentum) * rv + momentum * vz * ch.aux[zz];
             if (threadIdx.x == 0) {
                 mean[zz * C + c] = mz;
-                invstd[zz * C + c] = 1.0f / sqrtf(vz + eps);
+                invstd[zz * C + c] = iz;
             }
         }
         if (threadIdx.x == 0) {
@@ -527,11 +540,11 @@ __global__ __launch_bounds__(BNK_THREADS) void k_bn_act_fwd_fin(
             if (running_var) running_var[c] = rv;
             if (c == 0 && num_batches) *num_batches += ch.n;
         }
-        m = m0; v = v0;
+        m = m0; v = v0; is = is0;
     } else {
-        bnk_stats_of(x, part1, part2, ch, z, c, C, HW, S, red, &m, &v);
+        bnk_stats_of(x, part1, part2, ch, z, c, C, HW, S, eps, red, &m, &v, &is);
     }
-    const float is = 1.0f / sqrtf(v + eps);
+    (void)v;
     float sc, sh;
     bnk_affine(m, is, gamma, beta, c, &sc, &sh);
     const bool vec = (HW & 3) == 0 && (((((uintptr_t)x) | ((uintptr_t)y)) & 15u) == 0);

@@ -399,6 +399,47 @@ def test_whole_model_architectures_the_search_draws_vs_oracle(seed):
     grads_close_on_same_branches(hip, ora64, 'AE drawn with seed %d' % seed)
 
 
+def test_drawn_architecture_with_batch_norm_two_chunks_vs_oracle():
+    """Found by tools/fuzz_archs.py (round 6): the architecture the search draws for seed 410 -- 'valid' padding, four
+    512-channel layers (7x7 s2, 3x3 s1, 3x3 s2, 3x3 s2) -- with batch norm on 210 frames of 1x64x48 (chunks 200 + 10).
+    The forward kernels normalised with statistics each workgroup finalised itself, the backward kernels rebuilt the
+    LeakyReLU branch from the stored mean / invstd; the two copies of the finalize arithmetic were contracted
+    differently by the compiler, one pre-activation in 10^8 changed sides between the passes, and the gradients of the
+    two lowest layers were off by 2e-3 .. 7e-2.  One piece of code now (``bnk_finish_stats``)."""
+    from behavenet_amd.models import AE
+    from behavenet_amd.models.ae_model_architecture_generator import get_possible_arch
+    from oracle import ref_cpu
+    from tests.branches import record_branches, BranchReplay
+    from tests.golden_utils import base_hparams, make_frames
+    from tests.test_gpu_model import _bias_before_batchnorm
+
+    dim, n_frames, seed = [1, 64, 48], 210, 410
+    arch = get_possible_arch(list(dim), 12, arch_seed=seed)
+    arch.update(n_input_channels=dim[0], y_pixels=dim[1], x_pixels=dim[2])
+    extra = {'ae_batch_norm': True}
+    torch.manual_seed(0)
+    hip = AE(base_hparams(dict(arch), 'ae', extra)).to(DEV)
+    torch.manual_seed(0)
+    ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae', extra)).double()
+    ora64.train()
+    x = torch.from_numpy(make_frames(n_frames, dim, seed=500 + seed))
+    hip.train()
+    hip.zero_grad(set_to_none=True)
+    with record_branches(hip) as rec:
+        lh = hip.loss({'images': x.to(DEV)[None]}, dataset=0, accumulate_grad=True)['loss']
+    with BranchReplay(rec) as br:
+        l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True)['loss']
+    br.assert_only_ties(max_rel=1e-5)           # (batch norm amplifies fp32 rounding of the pre-activations)
+    assert lh == pytest.approx(l64, rel=1e-5)
+    names = {k for k, _ in hip.named_parameters()}
+    for (k, ph), (_, po) in zip(hip.named_parameters(), ora64.named_parameters()):
+        if po.grad is None or _bias_before_batchnorm(k, names):
+            continue
+        w = po.grad.numpy()
+        err = np.abs(ph.grad.cpu().double().numpy() - w).max() / max(np.abs(w).max(), 1e-30)
+        assert err <= 2e-4, 'grad %s: normalised max err %.3e' % (k, err)
+
+
 def test_whole_model_batch256_loss_and_gradients_vs_oracle():
     """BASELINE configs[1] at full size through ``AE.loss`` (one forward / one backward pass over
     256 frames, the reference's 200 + 56 chunk normalisation; reference aes.py:722-773): loss

@@ -1,6 +1,6 @@
 """Whole-model fuzz over the architectures the reference's random search draws:
 
-    python tools/fuzz_archs.py [first_seed] [n_seeds] [C H W] [frames]
+    python tools/fuzz_archs.py [first_seed] [n_seeds] [C H W] [frames]          (BN_FUZZ_BN=1: with ae_batch_norm)
 
 for every seed: ``get_possible_arch`` -> AE on the device and the float64 CPU oracle with the same parameters -> one
 ``loss(accumulate_grad=True)`` -> the loss to 1e-5 and every parameter gradient to 2e-5 of its maximum on the device's
@@ -28,6 +28,8 @@ def main():
     from tests.golden_utils import base_hparams, make_frames
     from tests.test_gpu_model import grads_close_on_same_branches
     limit_host_threads(cap=32)
+    with_bn = os.environ.get('BN_FUZZ_BN') == '1'
+    extra = {'ae_batch_norm': True} if with_bn else None
     bad = 0
     for seed in range(first, first + count):
         arch = get_possible_arch(list(dim), 12, arch_seed=seed)
@@ -39,9 +41,10 @@ def main():
         t0 = time.time()
         try:
             torch.manual_seed(0)
-            hip = AE(base_hparams(dict(arch), 'ae')).to('cuda')
+            hip = AE(base_hparams(dict(arch), 'ae', extra)).to('cuda')
             torch.manual_seed(0)
-            ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae')).double()
+            ora64 = ref_cpu.AE(base_hparams(dict(arch), 'ae', extra)).double()
+            ora64.train()
             x = torch.from_numpy(make_frames(n_frames, dim, seed=500 + seed))
             hip.train()
             hip.zero_grad(set_to_none=True)
@@ -49,9 +52,29 @@ def main():
                 lh = hip.loss({'images': x.to('cuda')[None]}, dataset=0, accumulate_grad=True)['loss']
             with BranchReplay(rec) as br:
                 l64 = ora64.loss({'images': x.double()[None]}, dataset=0, accumulate_grad=True)['loss']
-            br.assert_only_ties()
+            # (batch norm over few values amplifies fp32 rounding: pre-activations up to 1e-5 of the layer's maximum
+            # may land on the other side of zero)
+            br.assert_only_ties(max_rel=1e-5 if with_bn else 2e-6)
             assert abs(lh - l64) <= 1e-5 * abs(l64), (lh, l64)
-            grads_close_on_same_branches(hip, ora64, 'seed %d' % seed)
+            if not with_bn:
+                grads_close_on_same_branches(hip, ora64, 'seed %d' % seed)
+            else:
+                # batch norm: statistics over few values amplify fp32 rounding (the golden batch-norm cases' 2e-4), and
+                # a conv bias in front of a batch norm has an analytically zero gradient: rounding noise on both sides
+                import numpy as np
+                from tests.test_gpu_model import _bias_before_batchnorm
+                names = {k for k, _ in hip.named_parameters()}
+                top = max(float(po.grad.abs().max()) for po in ora64.parameters() if po.grad is not None)
+                for (k, ph), (_, po) in zip(hip.named_parameters(), ora64.named_parameters()):
+                    if po.grad is None or _bias_before_batchnorm(k, names):
+                        continue
+                    w = po.grad.numpy()
+                    # another analytically-zero class: when the decoder starts from 1x1 maps, a constant added to the
+                    # latents of every frame (enc.FF.bias, dec.FF.bias) is removed by the first batch norm's batch mean
+                    if np.abs(w).max() < 1e-9 * top and float(ph.grad.abs().max()) < 1e-6 * top:
+                        continue
+                    err = np.abs(ph.grad.cpu().double().numpy() - w).max() / max(np.abs(w).max(), 1e-30)
+                    assert err <= 2e-4, 'seed %d grad %s: normalised max err %.3e' % (seed, k, err)
             print('ok   seed %d  %s  (%.1f s)' % (seed, desc, time.time() - t0), flush=True)
         except BaseException as err:                                  # noqa: BLE001
             bad += 1
