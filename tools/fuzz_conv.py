@@ -42,6 +42,30 @@ def wild_cases(seed, count):
     return cases
 
 
+def many_frames_cases(seed, count):
+    """Small maps, MANY frames: the detours that walk the batch in passes (column matrices below 512 MB, tiled / shifted
+    copies below 2 GB, frame groups of the stride-1 big-kernel blocks) must get their last, partly filled pass right."""
+    rng = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < count:
+        R = int(rng.choice([3, 4, 5, 5, 7, 9]))
+        st = int(rng.choice([1, 2, 2, 3]))
+        H, W = int(rng.randint(max(R, 4), 28)), int(rng.randint(max(R, 4), 28))
+        C = int(rng.choice([1, 2, 3, 16, 32, 33, 64]))
+        K = int(rng.choice([1, 2, 16, 32, 48, 64]))
+        N = int(rng.choice([64, 97, 200, 256, 300]))
+        pt, pb = int(rng.randint(0, R)), int(rng.randint(0, R))
+        pl, pr = int(rng.randint(0, R)), int(rng.randint(0, R))
+        P, Q = (H + pt + pb - R) // st + 1, (W + pl + pr - R) // st + 1
+        if P < 1 or Q < 1 or N * C * H * W > 2e7 or N * K * P * Q > 2e7:
+            continue
+        if (P - 1) * st + R - pt - pb != H or (Q - 1) * st + R - pl - pr != W:
+            continue
+        cases.append(('many%d_s%d_k%d_%dx%d_c%d_k%d_n%d_p%d%d%d%d' % (len(cases), st, R, H, W, C, K, N, pt, pb, pl, pr),
+                      N, C, H, W, K, R, st, (pt, pb), (pl, pr)))
+    return cases
+
+
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 9000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -50,6 +74,7 @@ def main():
         ('big kernels', T._random_conv_cases(seed + 1, count // 3, big=True), T.test_random_geometries_all_roles),
         ('stride 5', T._random_stride5_cases(seed + 2, count // 2), T.test_random_stride5_geometries_all_roles),
         ('wild', wild_cases(seed + 3, count), T.test_random_geometries_all_roles),
+        ('many frames', many_frames_cases(seed + 6, count // 3), T.test_random_geometries_all_roles),
     ]
     bad = 0
     total = 0
