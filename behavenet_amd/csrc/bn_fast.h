@@ -31,6 +31,7 @@ int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float
 // conv_mfma_down2.hip: 16-byte-DMA generation of the stride-2 gather-down kernel (chosen by
 // bn_fast_down_plan when the geometry fits and no split-K is needed; plan.variant == 2)
 bool bn_down2_supported(const BnGeom& g, int MR, int NR);
+bool bn_down2_m16_supported(const BnGeom& g, int NR);   // the 16-row tile (MR = 0 in the plans)
 int bn_down2_splits(const BnGeom& g, int MR, int NR);
 float bn_down2_fill(const BnGeom& g, int MR, int NR);
 int bn_launch_down2(int MR, int NR, const float* big, const float* w, const float* bias,

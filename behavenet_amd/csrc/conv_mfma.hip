@@ -365,6 +365,32 @@ BnFastPlan bn_fast_down_plan(const BnGeom& g) {
     if (g.Cb < 2 && !s1) return p;
     if (g.Cs < 16) return p;
     const int CC = (g.stride == 5) ? 2 : 4;
+    if (g.Cs == 16 && g.R == 5 && g.S == 5 && (g.stride == 1 || g.stride == 2) && g.K0 == 0) {
+        // round 6: a 16-channel small side on the 16-row MFMA tile (k_down2_m16) -- the 32-row tiles below would
+        // multiply 16 rows of zeros; the 256-pixel tile unless the 128-pixel one wastes fewer pixels
+        static int off = -1;
+        if (off < 0) { const char* e = bn_tune_env("BN_DOWN_M16"); off = (e && e[0] == '0') ? 1 : 0; }
+        float fill = 0.f;
+        int bn = 0;
+        for (int nr = 2; nr >= 1 && !off; --nr) {
+            if (!bn_down2_m16_supported(g, nr)) continue;
+            const float f = bn_down2_fill(g, 1, nr);
+            if (f > fill + 0.02f) { fill = f; bn = nr; }
+        }
+        if (bn) {
+            static const char* const names16[2][2] = {{"k_down2_m16<2, 1>", "k_down2_m16<4, 1>"},
+                                                      {"k_down2_m16<2, 2>", "k_down2_m16<4, 2>"}};
+            p.supported = true;
+            p.a = 0; p.b = bn; p.c = CC; p.d = 1; p.variant = 2;
+            p.kernel_name = names16[g.stride - 1][bn - 1];
+            const int s2 = bn_down2_splits(g, 1, bn);
+            if (s2 > 1) {
+                p.d = s2;
+                p.ws_bytes = (size_t)s2 * g.N * g.Cs * g.Hs * g.Ws * sizeof(float);
+            }
+            return p;
+        }
+    }
     if (g.stride == 1 && g.R == 5 && g.S == 5) {
         // round 4: the streamlined kernel's stride-1 instantiation (16-byte LDS-DMA, double-buffered images, pinned
         // issue order) where its tile serves the map; the tile shape that wastes the fewest pixels

@@ -440,6 +440,251 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
 #endif
 }
 
+// ---- 16-row tile (round 6): layers whose small side has 16 channels (the max-pooling test architecture's 32 -> 16
+// layers, a drawn architecture's first block).  k_down2_mfma's 32-row MFMA multiplied 16 rows of zeros for them; here
+// the products run on v_mfma_f32_16x16x4_f32: A = 16 channels x the chunk's 4 input channels of one tap, B = those 4
+// channels x 16 pixels, so a chunk is 5 kernel rows x 5 taps x NR pixel blocks of ONE instruction each (32 cycles, the
+// same rate as the 32x32x2 one).  Tile = 16 channels x 64 NR pixels on Down2Tile's geometry (NR = 4: the 256-pixel
+// tile), images / weights / boundary / issue order exactly as above.  Lane = (li = pixel or channel 0..15, kk = input
+// channel 0..3 of the chunk); the weight rows' li * 100 + kk * 25 words fall on 64 different banks.
+typedef float floatx4d __attribute__((ext_vector_type(4)));
+
+template <int NR, int ST>
+__global__ __launch_bounds__(D2_THREADS, 2) void k_down2_m16(
+    const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, Down2Tile t, int act,
+    int dact, float slope, int cper, size_t zstride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int c_beg = blockIdx.z * cper;
+    const int c_end = min(g.Cb, c_beg + cper);
+    out += blockIdx.z * zstride;
+    constexpr int CC = D2_CC, R = 5, S = 5, RS = 25;
+    constexpr int TM = 16;
+    constexpr int WS = CC * RS;
+    constexpr int WG = TM * WS / 4;                   // 400 16-byte groups
+    constexpr int WK = (WG + D2_THREADS - 1) / D2_THREADS;
+    float* wl = smem + 2 * D2_XBUF_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kk = lane >> 4;
+
+    const int u0 = blockIdx.x * t.F;
+    const int n0 = u0 / t.UPF;
+    const int m0 = blockIdx.y * TM;
+    const int Q = g.Ws, PQ = g.Hs * g.Ws;
+    const int HW = g.Hb * g.Wb;
+
+    int base[NR];
+    size_t opix[NR];
+    bool pvalid[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        int pix = 16 * (wv * NR + nr) + li;
+        const bool inside = pix < t.F * t.PTQ;
+        if (!inside) pix = 0;
+        const int f = pix / t.PTQ;
+        const int rem = pix - f * t.PTQ;
+        const int pj = rem / Q, qj = rem - pj * Q;
+        const int un = (u0 + f) / t.UPF, up0 = (u0 + f - un * t.UPF) * t.PT_H;
+        base[nr] = ST == 2 ? f * t.FS + (2 * pj) * t.RW + 2 * qj + (D2_X0 - 2) + kk * t.CHS
+                           : f * t.FS + pj * t.RW + qj + (D2_X0 - 1 - g.pl) + kk * t.CHS;
+        pvalid[nr] = inside && un < g.N && (up0 + pj) < g.Hs;
+        opix[nr] = (size_t)un * g.Cs * PQ + (size_t)(up0 + pj) * Q + qj;
+    }
+
+    const __amdgpu_buffer_rsrc_t rbig = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)big, 0, (int)((size_t)g.N * g.Cb * HW * 4), 0x00020000);
+    const int C4 = t.RW / 4;
+    int xoff[D2_XK];
+#pragma unroll
+    for (int k = 0; k < D2_XK; ++k) {
+        const int e = tid + D2_THREADS * k;
+        const int cc = (int)(((float)e + 0.5f) * t.inv_chs4);
+        const int within = e - cc * (t.CHS / 4);
+        const int f = (int)(((float)within + 0.5f) * t.inv_fs4);
+        const int r2 = within - f * (t.FS / 4);
+        const int y = (int)(((float)r2 + 0.5f) * t.inv_c4);
+        const int c4 = r2 - y * C4;
+        const int un = (u0 + f) / t.UPF, up0 = (u0 + f - un * t.UPF) * t.PT_H;
+        const int hb = ST * up0 - g.pt + y, wb = 4 * c4 - D2_X0;
+        const bool ok = e < t.groups && un < g.N && hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+        xoff[k] = ok ? (((un - n0) * g.Cb + cc) * HW + hb * g.Wb + wb) * 4 : 0x7fffffff;
+    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)w, 0, (int)((size_t)g.Cs * g.Cb * RS * 4), 0x00020000);
+    int woff[WK];
+#pragma unroll
+    for (int k = 0; k < WK; ++k) {
+        const int e = tid + D2_THREADS * k;
+        const int m = e / (WS / 4), j = e - m * (WS / 4);
+        woff[k] = (e < WG && m0 + m < g.Cs) ? ((m0 + m) * g.Cb * RS + 4 * j) * 4 : 0x7fffffff;
+    }
+
+    floatx4d acc[NR];
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[nr][e] = 0.f;
+
+    auto issue_image = [&](const int k, int c0, int buf) __attribute__((always_inline)) {
+        if (D2_THREADS * k + 64 * wv < t.groups)                      // wave-uniform
+            d2_dma16(rbig, smem + buf * D2_XBUF_FLOATS + 4 * (D2_THREADS * k + 64 * wv), xoff[k],
+                     (n0 * g.Cb + c0) * HW * 4);
+    };
+    typedef unsigned int d2_u4 __attribute__((ext_vector_type(4)));
+    d2_u4 wreg[WK];
+    auto load_weights = [&](const int k, int c0) __attribute__((always_inline)) {
+        if (D2_THREADS * k + 64 * wv < WG)                            // wave-uniform
+            wreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff[k], c0 * RS * 4, 0);
+    };
+    auto store_weights = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < WK; ++k) {
+            if (D2_THREADS * k + 64 * wv < WG)
+                *reinterpret_cast<d2_u4*>(wl + 4 * (D2_THREADS * k + tid)) = wreg[k];
+        }
+    };
+
+    int xro[2][NR][R];
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                xro[bf][nr][r] = bf * D2_XBUF_FLOATS + base[nr] + r * t.RW;
+                asm volatile("" : "+v"(xro[bf][nr][r]));
+            }
+    int wao = 2 * D2_XBUF_FLOATS + li * WS + kk * RS;
+    asm volatile("" : "+v"(wao));
+
+    constexpr int NIT = R;                            // one MFMA takes the chunk's four channels
+    constexpr int NM = S * NR;                        // MFMAs per kernel row
+    constexpr int WU = 3;
+    constexpr int NU = WU + 2 * NR;
+    static_assert(NU <= NM, "one read unit per MFMA at most");
+    auto load_unit = [&](const int BUF, const int r, const int u, float (&a)[S],
+                         float (&bq)[S][NR]) __attribute__((always_inline)) {
+        if (u < WU) {
+            const float* wp = smem + wao + r * S;
+            if (u == 0) { a[0] = wp[0]; a[1] = wp[1]; }
+            else if (u == 1) { a[2] = wp[2]; a[3] = wp[3]; }
+            else a[4] = wp[4];
+        } else {
+            const int v = u - WU, nr = v / 2;
+            const float* xb = smem + xro[BUF][nr][r];
+            if (ST == 1) {
+                if ((v & 1) == 0) bq[0][nr] = xb[1];
+                else { bq[1][nr] = xb[2]; bq[2][nr] = xb[3]; bq[3][nr] = xb[4]; bq[4][nr] = xb[5]; }
+            } else if ((v & 1) == 0) bq[0][nr] = xb[1];
+            else {
+                const floatx2d c1p = *reinterpret_cast<const floatx2d*>(xb + 2);
+                const floatx2d c2p = *reinterpret_cast<const floatx2d*>(xb + 4);
+                bq[1][nr] = c1p.x; bq[2][nr] = c1p.y;
+                bq[3][nr] = c2p.x; bq[4][nr] = c2p.y;
+            }
+        }
+    };
+    auto chunk_rows = [&](const int BUF, const int c0) __attribute__((always_inline)) {
+        float av[2][S], bv[2][S][NR];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) load_unit(BUF, 0, u, av[0], bv[0]);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                const int s = j / NR, nr = j % NR;
+                acc[nr] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[it & 1][s], bv[it & 1][s][nr], acc[nr], 0, 0, 0);
+                if (it + 1 < NIT) {
+#pragma unroll
+                    for (int u = (j * NU) / NM; u < ((j + 1) * NU) / NM; ++u)
+                        load_unit(BUF, it + 1, u, av[(it + 1) & 1], bv[(it + 1) & 1]);
+                }
+                const int sl = it * NM + j;
+                if (sl >= 1 && sl < 1 + D2_XK) { if (c0 + CC < c_end) issue_image(sl - 1, c0 + CC, BUF ^ 1); }
+                if (sl >= 1 + D2_XK && sl < 1 + D2_XK + WK) { if (c0 + CC < c_end) load_weights(sl - 1 - D2_XK, c0 + CC); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    static_assert(1 + D2_XK + WK <= NIT * NM, "load slots");
+    auto boundary = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        store_weights();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+#pragma unroll
+    for (int k = 0; k < D2_XK; ++k) issue_image(k, c_beg, 0);
+#pragma unroll
+    for (int k = 0; k < WK; ++k) load_weights(k, c_beg);
+    for (int c0 = c_beg; c0 < c_end; c0 += 2 * CC) {
+        boundary();
+        chunk_rows(0, c0);
+        if (c0 + CC < c_end) {
+            boundary();
+            chunk_rows(1, c0 + CC);
+        }
+    }
+
+    // ---- epilogue: register e of block nr = channel m0 + 4 kk + e of pixel li
+    const int mlane = m0 + 4 * kk;
+    if (act != BN_ACT_SIGMOID && dact != BN_ACT_SIGMOID) {             // wave-uniform
+        const float es = (act == BN_ACT_LRELU) ? slope : 1.f;
+        const float ds = (dact == BN_ACT_LRELU) ? slope : 1.f;
+        const int obytes = (int)((size_t)g.N * g.Cs * PQ * 4);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, obytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)dact_src, 0, dact_src ? obytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rbs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)bias, 0, bias ? g.Cs * 4 : 0, 0x00020000);
+        float bz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            bz[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbs, (mlane + e) * 4, 0, 0));
+        int vo[NR];
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+            vo[nr] = pvalid[nr] ? (int)((opix[nr] + (size_t)mlane * PQ) * 4) : 0x7fffffff;
+        float d[NR][4];
+        if (dact_src) {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    d[nr][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rd, (mlane + e < g.Cs) ? vo[nr] : 0x7fffffff, e * PQ * 4, 0));
+        }
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[nr][e] + bz[e];
+                v = v > 0.f ? v : v * es;
+                if (dact_src) v *= d[nr][e] > 0.f ? 1.f : ds;
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __builtin_bit_cast(int, v), ro, (mlane + e < g.Cs) ? vo[nr] : 0x7fffffff, e * PQ * 4, DOWN2_ST_AUX);
+            }
+    } else {
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            if (!pvalid[nr]) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = mlane + e;
+                if (m >= g.Cs) continue;
+                const size_t idx = opix[nr] + (size_t)m * PQ;
+                float v = acc[nr][e];
+                if (bias) v += bias[m];
+                v = bn_apply_act(v, act, slope);
+                if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
+                out[idx] = v;
+            }
+        }
+    }
+}
+
 static bool down2_tile(const BnGeom& g, int MR, int NR, Down2Tile* t, size_t* lds_bytes) {
     const int ST = g.stride;
     if (g.R != 5 || g.S != 5 || (ST != 2 && ST != 1) || g.pt < 0) return false;
@@ -526,6 +771,29 @@ static int launch_down2(const Down2Tile& t, dim3 grid, size_t lds, const float* 
     return 0;
 }
 
+template <int NR, int ST>
+static int launch_down2_m16(const Down2Tile& t, dim3 grid, size_t lds, const float* big, const float* w,
+                            const float* bias, float* out, const float* dact_src, const BnGeom& g,
+                            int act, int dact, float slope, hipStream_t st, int cper, size_t zstride) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_down2_m16<NR, ST>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, D2_MAX_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    BN_LAUNCH_MAIN((k_down2_m16<NR, ST>), grid, dim3(D2_THREADS), lds, st, big, w, bias, out,
+                       dact_src, g, t, act, dact, slope, cper, zstride);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
+// the 16-row tile serves 5x5 layers (all 25 taps) of either stride; MR = 0 names it in the plans
+bool bn_down2_m16_supported(const BnGeom& g, int NR) {
+    if (g.K0 != 0) return false;        // (zero-extended 4x4 taps are multiplied as they are)
+    return bn_down2_supported(g, 1, NR);
+}
+
 // share of a tile's pixels that are pixels of the map (1 for powers of two), 0 if not served
 float bn_down2_fill(const BnGeom& g, int MR, int NR) {
     Down2Tile t;
@@ -553,10 +821,11 @@ int bn_launch_down2(int MR, int NR, const float* big, const float* w, const floa
                     float slope, hipStream_t st, int splits, void* ws) {
     Down2Tile t;
     size_t lds = 0;
-    if (!down2_tile(g, MR, NR, &t, &lds)) return BN_E_SHAPE;
+    const bool m16 = MR == 0;
+    if (!down2_tile(g, m16 ? 1 : MR, NR, &t, &lds)) return BN_E_SHAPE;
     const int tiles = (g.N * t.UPF + t.F - 1) / t.F;
     if (splits < 1) splits = 1;
-    dim3 grid(tiles, (g.Cs + 32 * MR - 1) / (32 * MR), splits);
+    dim3 grid(tiles, m16 ? (g.Cs + 15) / 16 : (g.Cs + 32 * MR - 1) / (32 * MR), splits);
     const size_t total = (size_t)g.N * g.Cs * g.Hs * g.Ws;
     if (splits > 1 && !ws) return BN_E_WORKSPACE;
     // (split: raw sums into the slabs, no bias / activation / mask in the kernel)
@@ -576,6 +845,15 @@ int bn_launch_down2(int MR, int NR, const float* big, const float* w, const floa
                 : launch_down2<mr, nr, 5>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
     D2_CASE(2, 2) D2_CASE(2, 1) D2_CASE(1, 1) D2_CASE(1, 2)
 #undef D2_CASE
+    if (m16) {
+        if (!bn_down2_m16_supported(g, NR)) return BN_E_SHAPE;
+        if (NR == 2)
+            rc = g.stride == 1 ? launch_down2_m16<4, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs)
+                               : launch_down2_m16<4, 2>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
+        else if (NR == 1)
+            rc = g.stride == 1 ? launch_down2_m16<2, 1>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs)
+                               : launch_down2_m16<2, 2>(t, grid, lds, big, w, kb, ko, kd, g, ka, kda, slope, st, cper, zs);
+    }
     if (rc || splits == 1) return rc;
     return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cs,
                                     g.Hs * g.Ws, act, dact, slope, st);

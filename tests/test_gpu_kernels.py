@@ -142,6 +142,15 @@ CONV_CASES = [
     ('s1_k5_valid_4ch_128x128', 2, 4, 132, 132, 16, 5, 1, (0, 0), (0, 0)),
     ('s1_k7_64x64', 2, 16, 64, 64, 32, 7, 1, (3, 3), (3, 3)),
     ('s1_k5_valid_64ch_64x64', 2, 64, 68, 68, 32, 5, 1, (0, 0), (0, 0)),
+    # round 6: a 16-channel small side on the 16-row MFMA tile (k_down2_m16): stride 2 and stride 1, a map that is no
+    # power of two, 4x4 taps (zero-extended, multiplied as they are), a batch small enough for the reduction split
+    ('m16_s2_c32_to_16_32x32', 3, 32, 64, 64, 16, 5, 2, (1, 2), (1, 2)),
+    ('m16_s2_c64_to_16_12x10', 5, 64, 24, 20, 16, 5, 2, (1, 2), (1, 2)),
+    ('m16_s1_c32_to_16_64x64', 2, 32, 64, 64, 16, 5, 1, (2, 2), (2, 2)),
+    ('m16_s1_c48_to_16_24x20_n7', 7, 48, 24, 20, 16, 5, 1, (2, 2), (2, 2)),
+    ('m16_k4s2_c32_to_16', 3, 32, 32, 32, 16, 4, 2, (1, 1), (1, 1)),
+    ('m16_s2_c64_to_16_8x8_n40', 40, 64, 16, 16, 16, 5, 2, (1, 2), (1, 2)),
+    ('m16_s1_c16_to_16_64x64', 2, 16, 64, 64, 16, 5, 1, (2, 2), (2, 2)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
