@@ -237,7 +237,12 @@ static int gemm_slices(int M, int N, int K) {
     const int tiles = ((N + 31) / 32) * ((M + 31) / 32);
     if (K < 1024 || tiles > 32) return 1;
     int s = K / 128;
-    if (s > 16) s = 16;
+    // (round 6) a very deep reduction -- the 32768-wide FF layer of the max-pooling test architecture: 8 tiles x 16
+    // slices were 128 workgroups walking 2048 elements each, 33 us for 33.5 MB -- takes slices of >= 256 elements
+    // until the units fill the chip twice; K = 2048 (the default architecture) keeps its 16
+    int cap = 16;
+    while (cap < 128 && tiles * cap < 512 && K / (2 * cap) >= 256) cap *= 2;
+    if (s > cap) s = cap;
     return s < 1 ? 1 : s;
 }
 
@@ -418,7 +423,18 @@ __global__ __launch_bounds__(256) void k_gemm_combine(GemmArgs a, int slices) {
     if (idx >= a.M * a.N) return;
     const int i = idx / a.N, j = idx - i * a.N;
     float v = 0.f;
-    for (int z = 0; z < slices; ++z) v += a.part[((size_t)z * a.M + i) * a.N + j];
+    // sixteen loads in flight, added in slice order (one load per trip is a chain of `slices` memory latencies:
+    // 17 us for the 64 slices of a 32768-deep product)
+    const size_t zs = (size_t)a.M * a.N;
+    const float* p0 = a.part + (size_t)i * a.N + j;
+    for (int z0 = 0; z0 < slices; z0 += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = p0[(size_t)(z0 + u < slices ? z0 + u : z0) * zs];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (z0 + u < slices) v += t[u];
+    }
     if (a.bias_j) v += a.bias_j[j];
     const long off = (long)i * a.sci + (long)j * a.scj;
     if (a.dact_src) v *= bn_act_grad_from_output(a.dact_src[off], a.dact, a.slope);
