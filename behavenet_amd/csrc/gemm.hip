@@ -47,7 +47,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
     // instruction for 2 useful floats each; this touches them once per 8 k.
     // These skinny products are bound by memory LATENCY: a trip requests 32 k of both operands
     // (8 independent 16-byte loads) before its first MFMA, and the trips of a wave are few.
-    const bool vec = (a.sak == 1) && (a.sbk == 1) && ((kbeg & 7) == 0) && ((kend & 7) == 0) &&
+    // (a reduction that ends on a multiple of 4, K = 12: the second lane half of the last group of 8 is masked)
+    const bool vec = (a.sak == 1) && (a.sbk == 1) && ((kbeg & 7) == 0) && ((kend & 3) == 0) && kend - kbeg >= 4 &&
                      ((a.sai & 3) == 0) && ((a.sbj & 3) == 0) &&
                      ((((uintptr_t)a.A) | ((uintptr_t)a.B)) & 15u) == 0;
     if (vec) {
@@ -61,7 +62,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
             }
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const bool ok = (k0 + 8 * h) < kend;
+                const bool ok = (k0 + 8 * h + 4 * lk) < kend;
+                if (k0 + 8 * h >= kend) break;                    // wave-uniform
                 const float ax[4] = {av4[h].x, av4[h].y, av4[h].z, av4[h].w};
                 const float bx4[4] = {bv4[h].x, bv4[h].y, bv4[h].z, bv4[h].w};
 #pragma unroll
@@ -76,7 +78,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
     // B = the 12-column weight): A by 16-byte loads as above -- a 4-byte gather along a row-strided
     // operand touches 64 cache lines per instruction, and the CU's line rate, not bytes, sets the
     // pace -- B by four 4-byte loads from its small, cache-resident matrix
-    const bool veca = !vec && (a.sak == 1) && ((kbeg & 7) == 0) && ((kend & 7) == 0) &&
+    const bool veca = !vec && (a.sak == 1) && ((kbeg & 7) == 0) && ((kend & 3) == 0) && kend - kbeg >= 4 &&
                       ((a.sai & 3) == 0) && (((uintptr_t)a.A) & 15u) == 0;
     if (veca) {
         for (int k0 = kbeg; k0 < kend; k0 += 32) {
@@ -91,7 +93,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& a, const int bx, const
             }
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const bool ok = (k0 + 8 * h) < kend;
+                const bool ok = (k0 + 8 * h + 4 * lk) < kend;
+                if (k0 + 8 * h >= kend) break;                    // wave-uniform
                 const float ax[4] = {av4[h].x, av4[h].y, av4[h].z, av4[h].w};
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
