@@ -39,6 +39,9 @@ SIGNATURES = {
     'bn_set_force_generic': (_c_int, [_c_int]),
     'bn_set_bigk1_block_bytes': (_c_size_t, [_c_size_t]),
     'bn_conv_ws_bytes': (_c_size_t, [_c_int] + _CONV_GEOM),
+    'bn_conv_taps_bytes': (_c_size_t, [_c_int] + _CONV_GEOM),
+    'bn_conv_taps_pad': (_c_int, [_c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
+    'bn_conv_taps_hint': (_c_int, [_c_void_p, _c_void_p]),
     'bn_conv2d_fwd': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
     'bn_conv2d_fwd_u8_ws_bytes': (_c_size_t, _CONV_GEOM + [_c_int]),
     'bn_conv2d_fwd_u8': (_c_int, [_c_void_p] * 4 + _CONV_GEOM + _ACT_WS),
@@ -206,10 +209,54 @@ def _workspace(op, geom, device):
     return _arena(device, nbytes), nbytes
 
 
-def conv2d_fwd(x, w, b, geom, act, slope):
+_taps_bytes = {}
+_generic_epoch = 0      # set_force_generic() changes what the dispatch pads
+
+
+def conv_taps_bytes(op, geom):
+    """Bytes of the 5x5 copy of a small-kernel layer's taps if `op` pads them, else 0 (bn_conv_taps_bytes)."""
+    key = (_generic_epoch, op) + tuple(geom)
+    v = _taps_bytes.get(key)
+    if v is None:
+        v = _taps_bytes[key] = int(load().bn_conv_taps_bytes(op, *geom))
+    return v
+
+
+def conv_taps_pad(jobs, device):
+    """jobs = [(op, geom, w)] -> [w5]: the 5x5 copies of the layers' taps, all in ONE launch (bn_conv_taps_pad).
+    The copies are slices of one fresh buffer; pass them to the forward / data-gradient wrappers as ``w5=``."""
+    n = len(jobs)
+    if n == 0:
+        return []
+    sizes = [(conv_taps_bytes(op, geom) // 4 + 63) // 64 * 64 for op, geom, _ in jobs]
+    if min(sizes) == 0:
+        raise HipLibraryError('conv_taps_pad: a layer whose op does not pad its taps')
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    out, o = [], 0
+    for sz in sizes:
+        out.append(buf[o:o + sz])
+        o += sz
+    wp = (ctypes.c_void_p * n)(*[_ptr(w, 'w') for _, _, w in jobs])
+    w5p = (ctypes.c_void_p * n)(*[t.data_ptr() for t in out])
+    flat = []
+    for op, geom, _ in jobs:
+        flat.append(op)
+        flat.extend(int(v) for v in geom)
+    geoms = (ctypes.c_int * (13 * n))(*flat)
+    _check(load().bn_conv_taps_pad(n, wp, w5p, geoms, _stream()), 'bn_conv_taps_pad')
+    return out
+
+
+def _taps_hint(w, w5):
+    if w5 is not None:
+        load().bn_conv_taps_hint(w.data_ptr(), w5.data_ptr())
+
+
+def conv2d_fwd(x, w, b, geom, act, slope, w5=None):
     N, C, H, W, K, R, S, st, pt, pl, P, Q = geom
     y = torch.empty((N, K, P, Q), dtype=torch.float32, device=x.device)
     ws, nb = _workspace(OP_CONV_FWD, geom, x.device)
+    _taps_hint(w, w5)
     _check(load().bn_conv2d_fwd(
         _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), *geom,
         act, slope, ws, nb, _stream()), 'bn_conv2d_fwd')
@@ -231,10 +278,11 @@ def conv2d_fwd_u8(x_u8, w, b, geom, act, slope):
     return y
 
 
-def conv2d_bwd_data(dy, w, geom, dact_src, dact, slope):
+def conv2d_bwd_data(dy, w, geom, dact_src, dact, slope, w5=None):
     N, C, H, W = geom[:4]
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
     ws, nb = _workspace(OP_CONV_BWD_D, geom, dy.device)
+    _taps_hint(w, w5)
     _check(load().bn_conv2d_bwd_data(
         _ptr(dy, 'dy'), _ptr(w, 'w'), _ptr(dx, 'dx'), _ptr(dact_src, 'dact_src', allow_none=True),
         *geom, dact, slope, ws, nb, _stream()), 'bn_conv2d_bwd_data')
@@ -248,20 +296,22 @@ def conv2d_bwd_weight(x, dy, dw, db, geom, accumulate):
         int(accumulate), ws, nb, _stream()), 'bn_conv2d_bwd_weight')
 
 
-def convT2d_fwd(x, w, b, geom, act, slope):
+def convT2d_fwd(x, w, b, geom, act, slope, w5=None):
     N, Ci, Hi, Wi, Co, R, S, st, ct, cl, Ho, Wo = geom
     y = torch.empty((N, Co, Ho, Wo), dtype=torch.float32, device=x.device)
     ws, nb = _workspace(OP_CONVT_FWD, geom, x.device)
+    _taps_hint(w, w5)
     _check(load().bn_convT2d_fwd(
         _ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'), *geom,
         act, slope, ws, nb, _stream()), 'bn_convT2d_fwd')
     return y
 
 
-def convT2d_bwd_data(dy, w, geom, dact_src, dact, slope):
+def convT2d_bwd_data(dy, w, geom, dact_src, dact, slope, w5=None):
     N, Ci, Hi, Wi = geom[:4]
     dx = torch.empty((N, Ci, Hi, Wi), dtype=torch.float32, device=dy.device)
     ws, nb = _workspace(OP_CONVT_BWD_D, geom, dy.device)
+    _taps_hint(w, w5)
     _check(load().bn_convT2d_bwd_data(
         _ptr(dy, 'dy'), _ptr(w, 'w'), _ptr(dx, 'dx'), _ptr(dact_src, 'dact_src', allow_none=True),
         *geom, dact, slope, ws, nb, _stream()), 'bn_convT2d_bwd_data')
@@ -277,6 +327,8 @@ def convT2d_bwd_weight(x, dy, dw, db, geom, accumulate):
 
 def set_force_generic(on):
     """Route convolutions through the shape-agnostic kernels (test hook); returns previous."""
+    global _generic_epoch
+    _generic_epoch += 1
     return bool(load().bn_set_force_generic(1 if on else 0))
 
 

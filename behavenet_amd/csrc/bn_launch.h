@@ -136,6 +136,10 @@ int bn_launch_col_wgrad(const float* small, const float* big, float* dw, const B
                         void* ws, size_t ws_bytes, hipStream_t st, float* db, int bias_side,
                         bool* bias_done);
 // kernels smaller than 5x5 embedded in 5x5 taps (weights [pairs][R][S] <-> [pairs][5][5])
+#define BN_PAD_TAPS_MAX_JOBS 16
+struct BnPadTapsJob { const float* w; float* w5; unsigned pairs; int R, S, dr, ds, blocks; };
+struct BnPadTapsJobs { int n; BnPadTapsJob job[BN_PAD_TAPS_MAX_JOBS]; };
+int bn_launch_pad_taps_jobs(BnPadTapsJobs* p, hipStream_t st);
 int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hipStream_t st, int dr = 0,
                        int ds = 0);
 int bn_launch_flip_taps(const float* w, float* wf, int Cs, int Cb, int RS, hipStream_t st);

@@ -450,6 +450,17 @@ static bool taps_plan(int role, const BnGeom& g, BnGeom* g5) {
     return served_fast(role, *g5);
 }
 static inline size_t taps_bytes(const BnGeom& g) { return align256((size_t)g.Cs * g.Cb * 25 * sizeof(float)); }
+// One-shot hint (round 6, bn_conv_taps_hint): the caller already holds the 5x5 copy of `w` (bn_conv_taps_pad, one
+// launch for all the layers of a stack).  The next forward / data-gradient entry of THIS thread takes it if the
+// weight pointer matches and drops it otherwise -- a hint never outlives one call.
+static thread_local const float* g_taps_hint_w = nullptr;
+static thread_local const float* g_taps_hint_w5 = nullptr;
+struct TapsHintDrop { ~TapsHintDrop() { g_taps_hint_w = g_taps_hint_w5 = nullptr; } };   // every conv entry ends with no hint
+static const float* taps_hint_take(const float* w) {
+    const float* w5 = (w && g_taps_hint_w == w) ? g_taps_hint_w5 : nullptr;
+    g_taps_hint_w = g_taps_hint_w5 = nullptr;
+    return w5;
+}
 
 // ---- kernels larger than 5x5 with stride 2 (7x7, 9x9): conv_pad.hip, "Kernels LARGER than 5x5"
 struct BigK {
@@ -589,7 +600,10 @@ static int run_down(int family, const float* big, const float* w, const float* b
                     const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                     void* ws, size_t ws_bytes, hipStream_t st) {
     const bool generic = force_generic() || !aligned16_all(big, w, out, dact_src);
+    const float* w5 = taps_hint_take(w);
     BnGeom g5;
+    if (!generic && w5 && aligned16_all(w5, w5, w5) && taps_plan(0, g, &g5))        // the caller's padded copy
+        return run_down(family, big, w5, bias, out, dact_src, g5, act, dact, slope, ws, ws_bytes, st);
     if (!generic && taps_plan(0, g, &g5)) {
         const size_t wb = taps_bytes(g);
         if (!ws || ws_bytes < wb + role_ws_need(0, g5)) return BN_E_WORKSPACE;
@@ -761,7 +775,10 @@ static int run_up(int family, const float* small, const float* w, const float* b
                   const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                   void* ws, size_t ws_bytes, hipStream_t st) {
     const bool generic = force_generic() || !aligned16_all(small, w, out, dact_src);
+    const float* w5 = taps_hint_take(w);
     BnGeom g5;
+    if (!generic && w5 && aligned16_all(w5, w5, w5) && taps_plan(1, g, &g5))        // the caller's padded copy
+        return run_up(family, small, w5, bias, out, dact_src, g5, act, dact, slope, ws, ws_bytes, st);
     if (!generic && taps_plan(1, g, &g5)) {
         const size_t wb = taps_bytes(g);
         if (!ws || ws_bytes < wb + role_ws_need(1, g5)) return BN_E_WORKSPACE;
@@ -1174,10 +1191,67 @@ extern "C" size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, in
     return need > bias_ws ? need : bias_ws;
 }
 
+static bool taps_op_geom(int op, int N, int C, int H, int W, int K, int R, int S, int stride, int off_t,
+                         int off_l, int P, int Q, BnGeom* g, int* role) {
+    switch (op) {
+        case BN_OP_CONV_FWD: *g = conv_geom(N, C, H, W, K, R, S, stride, off_t, off_l, P, Q); *role = 0; break;
+        case BN_OP_CONV_BWD_D: *g = conv_geom(N, C, H, W, K, R, S, stride, off_t, off_l, P, Q); *role = 1; break;
+        case BN_OP_CONVT_FWD: *g = convT_geom(N, C, H, W, K, R, S, stride, off_t, off_l, P, Q); *role = 1; break;
+        case BN_OP_CONVT_BWD_D: *g = convT_geom(N, C, H, W, K, R, S, stride, off_t, off_l, P, Q); *role = 0; break;
+        default: return false;
+    }
+    return bn_geom_ok(*g);
+}
+
+// Bytes of the 5x5 copy of a small-kernel layer's weights if the forward / data-gradient op pads them (0: it does not)
+extern "C" size_t bn_conv_taps_bytes(int op, int N, int C, int H, int W, int K, int R, int S, int stride,
+                                     int off_t, int off_l, int P, int Q) {
+    BnGeom g, g5;
+    int role = 0;
+    if (!taps_op_geom(op, N, C, H, W, K, R, S, stride, off_t, off_l, P, Q, &g, &role)) return 0;
+    return taps_plan(role, g, &g5) ? taps_bytes(g) : 0;
+}
+
+// w5[j] <- the 5x5 copy of w[j] for n layers in one launch; geoms = n x (op, N, C, H, W, K, R, S, stride, off_t,
+// off_l, P, Q) as bn_conv_taps_bytes takes them.  A layer whose op does not pad is an error (BN_E_SHAPE).
+extern "C" int bn_conv_taps_pad(int n, const float* const* w, float* const* w5, const int* geoms,
+                                bn_stream_t stream) {
+    if (n < 0 || (n && (!w || !w5 || !geoms))) return BN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int j0 = 0; j0 < n; j0 += BN_PAD_TAPS_MAX_JOBS) {
+        BnPadTapsJobs p;
+        p.n = 0;
+        for (int j = j0; j < n && j < j0 + BN_PAD_TAPS_MAX_JOBS; ++j) {
+            const int* q = geoms + 13 * j;
+            BnGeom g, g5;
+            int role = 0;
+            if (!w[j] || !w5[j]) return BN_E_BADARG;
+            if (!taps_op_geom(q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7], q[8], q[9], q[10], q[11], q[12], &g, &role))
+                return BN_E_BADARG;
+            if (!taps_plan(role, g, &g5)) return BN_E_SHAPE;
+            BnPadTapsJob& jb = p.job[p.n++];
+            jb.w = w[j]; jb.w5 = w5[j]; jb.pairs = (unsigned)((size_t)g.Cs * g.Cb);
+            jb.R = g.R; jb.S = g.S; jb.dr = taps_dr(g); jb.ds = taps_ds(g); jb.blocks = 0;
+        }
+        const int rc = bn_launch_pad_taps_jobs(&p, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// One-shot: the next forward / data-gradient call of this thread on weights `w` reads their 5x5 copy from `w5`
+// (written by bn_conv_taps_pad for the same layer) instead of padding them again; any other call drops the hint.
+extern "C" int bn_conv_taps_hint(const float* w, const float* w5) {
+    g_taps_hint_w = w5 ? w : nullptr;
+    g_taps_hint_w5 = w ? w5 : nullptr;
+    return 0;
+}
+
 extern "C" int bn_conv2d_fwd(const float* x, const float* w, const float* b, float* y, int N,
                              int C, int H, int W, int K, int R, int S, int stride, int pad_t,
                              int pad_l, int P, int Q, int act, float slope, void* ws,
                              size_t ws_bytes, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
     if (!x || !w || !y) return BN_E_BADARG;
     const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
@@ -1205,6 +1279,7 @@ extern "C" int bn_conv2d_fwd_u8(const unsigned char* x, const float* w, const fl
                                 int N, int C, int H, int W, int K, int R, int S, int stride,
                                 int pad_t, int pad_l, int P, int Q, int act, float slope, void* ws,
                                 size_t ws_bytes, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
     if (!x || !w || !y) return BN_E_BADARG;
     const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
@@ -1229,6 +1304,7 @@ extern "C" int bn_conv2d_bwd_data(const float* dy, const float* w, float* dx,
                                   const float* dact_src, int N, int C, int H, int W, int K, int R,
                                   int S, int stride, int pad_t, int pad_l, int P, int Q, int dact,
                                   float slope, void* ws, size_t ws_bytes, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
     if (!dy || !w || !dx) return BN_E_BADARG;
     const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
@@ -1240,6 +1316,7 @@ extern "C" int bn_conv2d_bwd_weight(const float* x, const float* dy, float* dw, 
                                     int C, int H, int W, int K, int R, int S, int stride,
                                     int pad_t, int pad_l, int P, int Q, int accumulate, void* ws,
                                     size_t ws_bytes, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
     if (!x || !dy || !dw) return BN_E_BADARG;
     const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
@@ -1257,6 +1334,7 @@ extern "C" int bn_convT2d_fwd(const float* x, const float* w, const float* b, fl
                               int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                               int crop_t, int crop_l, int Ho, int Wo, int act, float slope,
                               void* ws, size_t ws_bytes, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
     if (!x || !w || !y) return BN_E_BADARG;
     const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
@@ -1269,6 +1347,7 @@ extern "C" int bn_convT2d_bwd_data(const float* dy, const float* w, float* dx,
                                    int R, int S, int stride, int crop_t, int crop_l, int Ho,
                                    int Wo, int dact, float slope, void* ws, size_t ws_bytes,
                                    bn_stream_t stream) {
+    TapsHintDrop hint_drop;
     if (!dy || !w || !dx) return BN_E_BADARG;
     const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
@@ -1280,6 +1359,7 @@ extern "C" int bn_convT2d_bwd_weight(const float* x, const float* dy, float* dw,
                                      int Ci, int Hi, int Wi, int Co, int R, int S, int stride,
                                      int crop_t, int crop_l, int Ho, int Wo, int accumulate,
                                      void* ws, size_t ws_bytes, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
     if (!x || !dy || !dw) return BN_E_BADARG;
     const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
     if (!bn_geom_ok(g)) return BN_E_BADARG;
@@ -1558,6 +1638,7 @@ extern "C" int bn_convT2d_fwd_sqerr(const float* x, const float* w, const float*
                                     int Co, int R, int S, int stride, int crop_t, int crop_l,
                                     int Ho, int Wo, int act, float slope, void* ws,
                                     size_t ws_bytes, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
     if (!x || !w || !target || !dpre || !part) return BN_E_BADARG;
     const BnGeom g = convT_geom(N, Ci, Hi, Wi, Co, R, S, stride, crop_t, crop_l, Ho, Wo);
     if (!bn_geom_ok(g)) return BN_E_BADARG;

@@ -137,6 +137,37 @@ int bn_launch_pad_taps(const float* w, float* w5, size_t pairs, int R, int S, hi
     BN_LAUNCH_CHECK();
     return 0;
 }
+// the same for several layers in ONE launch (round 6): a fused conv stack pads the taps of all its small-kernel layers
+// when its forward pass starts and hands the copies to the forward and data-gradient entry points (bn_conv_taps_hint);
+// k_pad_taps ran once per layer and role, 19 launches of 5-6 us in a step of ae_arch_2.json
+__global__ __launch_bounds__(PD_THREADS) void k_pad_taps_jobs(BnPadTapsJobs p) {
+    int b = blockIdx.x;
+    for (int j = 0; j < p.n; ++j) {
+        const BnPadTapsJob& jb = p.job[j];
+        if (b < jb.blocks) {
+            const unsigned total = jb.pairs * 25;
+            for (unsigned q = b * PD_THREADS + threadIdx.x; q < total; q += jb.blocks * PD_THREADS) {
+                const unsigned pr = q / 25, t = q - pr * 25;
+                const int r = (int)(t / 5) - jb.dr, c = (int)(t - 5 * (t / 5)) - jb.ds;
+                jb.w5[q] = (r >= 0 && r < jb.R && c >= 0 && c < jb.S) ? jb.w[pr * (jb.R * jb.S) + r * jb.S + c] : 0.f;
+            }
+            return;
+        }
+        b -= jb.blocks;
+    }
+}
+int bn_launch_pad_taps_jobs(BnPadTapsJobs* p, hipStream_t st) {
+    int blocks = 0;
+    for (int j = 0; j < p->n; ++j) {
+        const int b = pd_blocks((size_t)p->job[j].pairs * 25);
+        p->job[j].blocks = b;
+        blocks += b;
+    }
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL(k_pad_taps_jobs, dim3(blocks), dim3(PD_THREADS), 0, st, *p);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
 // ---------------------------------------------------------------------------------------------
 // Stride-1 gather-up as a gather-down (round 4, no im2col / col2im): with stride 1
 //   out[n,m,h,w] = sum_{c,r,s} small[n,c,h+pt-r,w+pl-s] W[c][m][r][s]

@@ -443,14 +443,41 @@ class ConvLayerPlan(object):
             self.S, self.stride, self.off_t, self.off_l, self.act)
 
 
-def _fwd(layer, x, w, b):
+def _fwd(layer, x, w, b, w5=None):
     g = layer.geom(x.shape[0])
     if layer.kind == 'conv':
         if x.dtype == torch.uint8:
             # frames as stored on disk: value / 255 is fused into the first layer's patch load
             return _hip.conv2d_fwd_u8(x, w, b, g, layer.act, LRELU_SLOPE)
-        return _hip.conv2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE)
-    return _hip.convT2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE)
+        return _hip.conv2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE, w5=w5)
+    return _hip.convT2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE, w5=w5)
+
+
+_FWD_OP = {'conv': _hip.OP_CONV_FWD, 'convT': _hip.OP_CONVT_FWD}
+_BWD_OP = {'conv': _hip.OP_CONV_BWD_D, 'convT': _hip.OP_CONVT_BWD_D}
+
+
+def _stack_taps(plan, n, params, first=0):
+    """Layers with kernels smaller than 5x5 run on the 5x5 kernel families with their taps embedded in 5x5 ones
+    (csrc/capi.hip, taps_plan).  The entry points make that copy per call -- once for the forward pass and once for
+    the data gradient of every such layer, 19 launches in a step of ae_arch_2.json; a stack makes the copies of ALL
+    its layers in one launch when its forward pass starts and keeps them for its backward pass (same weights: the
+    node's saved tensors).  -> [w5 | None] per layer, None for a stack without such layers."""
+    jobs, idx = [], []
+    for i in range(first, len(plan)):
+        layer = plan[i]
+        g = layer.geom(n)
+        for op in (_FWD_OP[layer.kind], _BWD_OP[layer.kind]):
+            if _hip.conv_taps_bytes(op, g):
+                jobs.append((op, g, params[2 * i].detach()))
+                idx.append(i)
+                break
+    if not jobs:
+        return None
+    taps = [None] * len(plan)
+    for i, w5 in zip(idx, _hip.conv_taps_pad(jobs, params[0].device)):
+        taps[i] = w5
+    return taps
 
 
 def first_layer_forward(plan, x, params):
@@ -479,11 +506,14 @@ class ConvStackFn(torch.autograd.Function):
         x = x.contiguous()
         acts = [x]
         h = x
+        skip_first = h1 is not None and not x.requires_grad
+        taps = _stack_taps(plan, x.shape[0], params, first=1 if skip_first else 0) if x.is_cuda else None
         for i, layer in enumerate(plan):
             if i == 0 and h1 is not None:
                 h = h1
             else:
-                h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach())
+                h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach(),
+                         w5=taps[i] if taps else None)
             acts.append(h)
         if _sign_tap is not None:
             rec = _sign_tap.setdefault(id(plan), [[] for _ in plan])
@@ -491,6 +521,7 @@ class ConvStackFn(torch.autograd.Function):
                 if layer.act == _hip.ACT_LRELU:
                     rec[i].append((acts[i + 1] > 0).cpu())
         ctx.plan = plan
+        ctx.taps = taps
         ctx.need_dx = x.requires_grad
         ctx.param_refs = params
         _note_use(params, any(ctx.needs_input_grad[3:]))
@@ -524,6 +555,7 @@ def _stack_backward(ctx, dpre, first_param):
     acts, weights = saved[:n_layers + 1], saved[n_layers + 1:2 * n_layers + 1]
     n = dpre.shape[0]
     grads = [None] * (2 * n_layers)
+    taps = getattr(ctx, 'taps', None)       # the forward pass's 5x5 copies of small-kernel taps (_stack_taps)
     tail = []     # weight gradients deferred to the main stream (see _tail_on_main)
     for i in range(n_layers - 1, -1, -1):
         layer = plan[i]
@@ -547,7 +579,7 @@ def _stack_backward(ctx, dpre, first_param):
         if i > 0 and min(plan[i - 1].cin, plan[i - 1].cout) <= 4 and _DGRAD_FIRST:
             dact_src, dact = acts[i], plan[i - 1].act
             bwd_data = _hip.conv2d_bwd_data if layer.kind == 'conv' else _hip.convT2d_bwd_data
-            dpre_below = bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
+            dpre_below = bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE, w5=taps[i] if taps else None)
         if need_w:
             gw = _grad_buffer(ctx.param_refs[2 * i])
             gb = _grad_buffer(ctx.param_refs[2 * i + 1]) if need_b else None
@@ -588,10 +620,11 @@ def _stack_backward(ctx, dpre, first_param):
             # fuse the derivative of the layer below into this kernel's epilogue
             dact_src = acts[i] if i > 0 else None
             dact = plan[i - 1].act if i > 0 else _hip.ACT_NONE
+            w5 = taps[i] if taps else None
             if layer.kind == 'conv':
-                dpre = _hip.conv2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
+                dpre = _hip.conv2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE, w5=w5)
             else:
-                dpre = _hip.convT2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE)
+                dpre = _hip.convT2d_bwd_data(dpre, w, g, dact_src, dact, LRELU_SLOPE, w5=w5)
     for (wgrad, x_in, dy, dw, db, g), refs in tail:
         wgrad(x_in, dy, dw, db, g, True)
         _report_ready(refs)
@@ -643,8 +676,9 @@ class ConvStackSqErrFn(torch.autograd.Function):
         mask = mask.contiguous() if mask is not None else None
         acts = [x]
         h = x
+        taps = _stack_taps(plan, x.shape[0], params) if x.is_cuda else None
         for i, layer in enumerate(plan[:-1]):
-            h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach())
+            h = _fwd(layer, h, params[2 * i].detach(), params[2 * i + 1].detach(), w5=taps[i] if taps else None)
             acts.append(h)
         top = plan[-1]
         n = h.shape[0]
@@ -660,6 +694,7 @@ class ConvStackSqErrFn(torch.autograd.Function):
         for c, ((beg, end), sc) in enumerate(zip(bounds, scales)):
             _hip.reduce_sum(part[beg:end], float(sc), out=out[c:c + 1])
         ctx.plan = plan
+        ctx.taps = taps
         ctx.need_dx = x.requires_grad
         ctx.param_refs = params
         ctx.bounds, ctx.scales = list(bounds), [float(sc) for sc in scales]

@@ -76,6 +76,21 @@ int bn_set_force_generic(int on);
 size_t bn_set_bigk1_block_bytes(size_t bytes);
 size_t bn_conv_ws_bytes(int op, int N, int C, int H, int W, int K, int R, int S, int stride,
                         int off_t, int off_l, int P, int Q);
+/* Kernels smaller than 5x5 (the reference's architecture search draws 3x3; configs/ae_jsons/ae_arch_2.json has 4x4:
+ * /root/reference/behavenet/models/ae_model_architecture_generator.py:90-100) run on the 5x5 kernel families with
+ * their taps embedded in 5x5 ones.  Every forward / data-gradient entry point makes that copy itself; a caller that
+ * runs a whole stack of layers (and both roles of each) can make the copies of all layers in ONE launch instead:
+ *   bn_conv_taps_bytes  bytes of the 5x5 copy if `op` (BN_OP_CONV_FWD / _BWD_D, BN_OP_CONVT_FWD / _BWD_D) pads this
+ *                       geometry's taps, 0 if it does not (the copy is the same for the two ops of a layer)
+ *   bn_conv_taps_pad    w5[j] <- 5x5 copy of w[j], j < n, one launch; geoms = n x 13 ints (op + the twelve geometry
+ *                       arguments); BN_E_SHAPE if an op does not pad
+ *   bn_conv_taps_hint   one-shot: the NEXT conv entry point called by this thread reads the 5x5 copy of `w` from `w5`
+ *                       if it is called on weights `w` (and pads for itself otherwise); every conv entry point
+ *                       clears the hint on return.  w5 = NULL clears it. */
+size_t bn_conv_taps_bytes(int op, int N, int C, int H, int W, int K, int R, int S, int stride,
+                          int off_t, int off_l, int P, int Q);
+int bn_conv_taps_pad(int n, const float* const* w, float* const* w5, const int* geoms, bn_stream_t stream);
+int bn_conv_taps_hint(const float* w, const float* w5);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution (replaces ZeroPad2d + nn.Conv2d + LeakyReLU, aes.py:81-86,113-114,145-155).

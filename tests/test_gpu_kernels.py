@@ -1095,6 +1095,61 @@ def test_random_geometries_all_roles_transposed(case):
     test_convT2d_bwd(case)
 
 
+@pytest.mark.parametrize('case_name', ['k4_64ch_32x32', 'k3s2_same_32x32', 'k3_16x16', 'k3s2_pt0_pl1', 'k4x3_24x20',
+                                       'k3s2_same_8x8_4x4', 'k2s2_same_16x16'])
+def test_padded_taps_made_once_serve_both_roles(case_name):
+    """Round 6: a conv stack makes the 5x5 copies of its small-kernel layers' taps in one launch (bn_conv_taps_pad) and
+    hands them to the forward and data-gradient entry points (bn_conv_taps_hint, one-shot) -- same bits as the
+    copies the entry points make themselves; a hint for other weights is dropped, never used later."""
+    case = [c for c in CONV_CASES if c[0] == case_name][0]
+    x, w, b, geom, _ = _conv_setup(case)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    N, C, H, W, K, R, S, st, pt, pl, P, Q = geom
+    dy = (torch.rand((N, K, P, Q), generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    assert _hip.conv_taps_bytes(_hip.OP_CONV_FWD, geom) >= K * C * 25 * 4
+    assert _hip.conv_taps_bytes(_hip.OP_CONV_BWD_D, geom) == _hip.conv_taps_bytes(_hip.OP_CONV_FWD, geom)
+    w5, w5b = _hip.conv_taps_pad([(_hip.OP_CONV_FWD, geom, wd), (_hip.OP_CONV_BWD_D, geom, wd)], DEV)
+    t5 = w5[:K * C * 25]
+    assert torch.equal(t5, w5b[:K * C * 25])
+    assert torch.equal(t5[t5 != 0].sort().values, wd.flatten().sort().values)       # every tap once, zeros elsewhere
+    y0 = _hip.conv2d_fwd(xd, wd, bd, geom, _hip.ACT_LRELU, SLOPE)
+    y1 = _hip.conv2d_fwd(xd, wd, bd, geom, _hip.ACT_LRELU, SLOPE, w5=w5)
+    assert torch.equal(y0, y1)
+    dx0 = _hip.conv2d_bwd_data(dy, wd, geom, None, _hip.ACT_NONE, SLOPE)
+    dx1 = _hip.conv2d_bwd_data(dy, wd, geom, None, _hip.ACT_NONE, SLOPE, w5=w5)
+    assert torch.equal(dx0, dx1)
+    # the copy IS what the kernels read ...
+    poison = torch.full_like(w5, float('nan'))
+    assert bool(torch.isnan(_hip.conv2d_fwd(xd, wd, bd, geom, _hip.ACT_LRELU, SLOPE, w5=poison)).all())
+    # ... only for the weights it was made for, and only in the very next call
+    other = wd.clone()
+    _hip.load().bn_conv_taps_hint(other.data_ptr(), poison.data_ptr())
+    assert torch.equal(_hip.conv2d_fwd(xd, wd, bd, geom, _hip.ACT_LRELU, SLOPE), y0)
+    assert torch.equal(_hip.conv2d_fwd(xd, other, bd, geom, _hip.ACT_LRELU, SLOPE), y0)
+    _hip.load().bn_conv_taps_hint(wd.data_ptr(), poison.data_ptr())
+    dwt = torch.zeros_like(wd)
+    _hip.conv2d_bwd_weight(xd, dy, dwt, None, geom, False)          # (an entry point that takes no hint drops it)
+    assert torch.equal(_hip.conv2d_fwd(xd, wd, bd, geom, _hip.ACT_LRELU, SLOPE), y0)
+
+
+@pytest.mark.parametrize('case_name', ['k4_64ch_16x16', 'k3_8x8', 'k3s2_same_16x16', 'k3s2_same_10x12'])
+def test_padded_taps_made_once_serve_both_roles_transposed(case_name):
+    case = [c for c in CONVT_CASES if c[0] == case_name][0]
+    x, w, b, geom, _ = _convT_setup(case)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    N, Ci, Hi, Wi, Co, R, S, st, ct, cl, Ho, Wo = geom
+    dy = (torch.rand((N, Co, Ho, Wo), generator=torch.Generator().manual_seed(3)) - 0.5).to(DEV)
+    assert _hip.conv_taps_bytes(_hip.OP_CONVT_FWD, geom) >= Ci * Co * 25 * 4
+    (w5,) = _hip.conv_taps_pad([(_hip.OP_CONVT_FWD, geom, wd)], DEV)
+    y0 = _hip.convT2d_fwd(xd, wd, bd, geom, _hip.ACT_LRELU, SLOPE)
+    assert torch.equal(y0, _hip.convT2d_fwd(xd, wd, bd, geom, _hip.ACT_LRELU, SLOPE, w5=w5))
+    dx0 = _hip.convT2d_bwd_data(dy, wd, geom, None, _hip.ACT_NONE, SLOPE)
+    assert torch.equal(dx0, _hip.convT2d_bwd_data(dy, wd, geom, None, _hip.ACT_NONE, SLOPE, w5=w5))
+    poison = torch.full_like(w5, float('nan'))
+    assert bool(torch.isnan(_hip.convT2d_bwd_data(dy, wd, geom, None, _hip.ACT_NONE, SLOPE, w5=poison)).all())
+    assert torch.equal(_hip.convT2d_bwd_data(dy, wd, geom, None, _hip.ACT_NONE, SLOPE), dx0)
+
+
 @pytest.mark.parametrize('case_name', ['s1_k5_64x64', 's1_k3_32x32', 's1_k4_8x8', 's1_k5_24x16', 's1_k5_pad13',
                                        's1_k5_48x40', 's1_k3_18x12', 's1_k5_7x20'])
 def test_stride1_roles_run_without_im2col(case_name):
@@ -1148,9 +1203,9 @@ def test_kernels_larger_than_5x5_run_without_im2col(case_name):
     dy = torch.ones((N, K, P, Q), device=DEV)
     for prof, fn, want in (
             (_hip.PROF_CONV_FWD, lambda: _hip.conv2d_fwd(x.to(DEV), w.to(DEV), b.to(DEV), geom, _hip.ACT_LRELU, SLOPE),
-             'k_down2_mfma<'),
+             'k_down2_m'),              # (k_down2_mfma<..> or the 16-row k_down2_m16<..>)
             (_hip.PROF_CONV_BWD_D, lambda: _hip.conv2d_bwd_data(dy, w.to(DEV), geom, None, _hip.ACT_NONE, SLOPE),
-             'k_down2_mfma<'),
+             'k_down2_m'),
             (_hip.PROF_CONV_BWD_W, lambda: _hip.conv2d_bwd_weight(
                 x.to(DEV), dy, torch.empty_like(w, device=DEV), torch.empty_like(b, device=DEV), geom, False),
              'k_wgrad4s_mfma<')):
@@ -1221,7 +1276,7 @@ def test_large_and_odd_maps_are_served_by_the_specialised_kernels(case_name, wan
             _, n, name = _hip.prof_read()
         finally:
             _hip.prof_select(_hip.PROF_NONE)
-        assert n >= 1 and ('tiles of' in name or 'zero-padded' in name or 'mfma' in name or
+        assert n >= 1 and ('tiles of' in name or 'zero-padded' in name or 'mfma' in name or 'k_down2_m16<' in name or
                            'k_wgrad_c1<' in name or 'k_up_c1v<8, false, gen>' in name), name
 
 
