@@ -268,6 +268,14 @@ template <>
 struct UP2<0> {
     static constexpr int CHSP = 256;
 };
+// LGW == 1 (round 6): the same with room for 320 elements -- eight 4x4 maps with their halos are 288, ten 4x3 maps 300;
+// the elements past 256 are copied by wave 0's second DMA of a channel.  Its own instantiation, chosen only where it
+// fills the tile better: with the four extra slots in the DMA schedule the 256-element tiles of 192x160 frames ran
+// 2.7 % slower (A/B on one box).
+template <>
+struct UP2<1> {
+    static constexpr int CHSP = 320;
+};
 struct Up2Geo {
     int F, AT_H, ATW;             // UNITS per tile, rows per unit, AT_H * Ws
     int SWp, FS, CHS;             // LDS row / unit strides of the small tile, elements of a channel
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     float slope, int cper, size_t zstride, Up2Geo tg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using T = UP2<LGW>;
-    constexpr bool RT = LGW == 0;                         // runtime tile geometry (tg)
+    constexpr bool RT = LGW <= 1;                         // runtime tile geometry (tg)
     // reduction split over workgroups (small batches: gridDim.z slices of cper input channels, raw
     // sums into slab blockIdx.z of the scratch, finished by k_split_epilogue); gridDim.z == 1: all
     const int c_beg = blockIdx.z * cper;
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
     constexpr int WGRP = CC * WCH / 4;                    // 16-byte groups per chunk
     constexpr int WDMA = (WGRP + MF_THREADS - 1) / MF_THREADS;
     constexpr int WBUF = WDMA * MF_THREADS * 4;           // floats per weight image (whole waves)
-    constexpr int XW = T::CHSP / 64;                      // waves that copy input elements
+    constexpr int XW = T::CHSP > MF_THREADS ? MF_THREADS / 64 : T::CHSP / 64;   // waves that copy input elements
     constexpr int OOB = 0x7fffffff;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -358,9 +366,9 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
         (void*)small, 0, (int)((size_t)g.N * g.Cs * HWs * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
         (void*)w, 0, (int)((size_t)g.Cs * g.Cb * RS * 4), 0x00020000);
-    int xvo = OOB;                                        // element tid of a channel's tile
-    if (tid < tCHS) {
-        const int f = tid / tFS, r2 = tid - f * tFS;
+    auto tile_elem = [&](const int el) {                  // element el of a channel's tile -> byte offset or OOB
+        if (el >= tCHS) return OOB;
+        const int f = el / tFS, r2 = el - f * tFS;
         const int y = r2 / SWp, x = r2 - y * SWp;
         int fn = f, fa0 = a0;                             // frame behind n0 and first row of element's unit
         if constexpr (RT) {
@@ -370,8 +378,12 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
         }
         const int p = fa0 - 1 + y, q = x - 1;
         const bool ok = (n0 + fn < g.N) && p >= 0 && p < Hs_rt && q >= 0 && q < Ws;
-        if (ok) xvo = (fn * (g.Cs * HWs) + p * Ws + q) * 4;
-    }
+        return ok ? (fn * (g.Cs * HWs) + p * Ws + q) * 4 : OOB;
+    };
+    const int xvo = tile_elem(tid);                       // element tid of a channel's tile
+    constexpr int NX2 = T::CHSP > MF_THREADS ? CC : 0;    // second DMA of a channel: elements 256 .. CHSP - 1 (wave 0)
+    int xvo2 = OOB;
+    if constexpr (NX2 > 0) xvo2 = tile_elem(tid + MF_THREADS);
     int wvo[WDMA];                                        // group tid + 256 k of [cc][m][tap]
 #pragma unroll
     for (int k = 0; k < WDMA; ++k) {
@@ -385,13 +397,17 @@ __global__ __launch_bounds__(MF_THREADS, UP2_WGS) void k_up2_mfma(
             if (wv < XW)
                 up_dma4(rs_x, smem + buf * XBUF + d * T::CHSP + 64 * wv, xvo,
                         (n0 * g.Cs + c0 + d) * HWs * 4);
+        } else if (d < CC + NX2) {
+            if (wv == 0 && tCHS > MF_THREADS)             // (uniform: most tiles end below element 256)
+                up_dma4(rs_x, smem + buf * XBUF + (d - CC) * T::CHSP + MF_THREADS, xvo2,
+                        (n0 * g.Cs + c0 + d - CC) * HWs * 4);
         } else {
-            const int k = d - CC;
+            const int k = d - CC - NX2;
             up_dma16(rs_w, smem + 2 * XBUF + buf * WBUF + 4 * (MF_THREADS * k + 64 * wv), wvo[k],
                      c0 * g.Cb * RS * 4);
         }
     };
-    constexpr int NDMA = CC + WDMA;
+    constexpr int NDMA = CC + NX2 + WDMA;
 
     floatx16 acc[4];
 #pragma unroll
@@ -685,7 +701,18 @@ static int launch_up2(const float* small, const float* w, const float* bias, flo
 // ---- runtime tile geometry (k_up2_mfma<0, CC, KV>): maps that are no power-of-two squares ----------
 // tile = F whole frames, or AT_H rows of one frame (rows spread evenly over a frame's tiles), at most 128
 // positions and 256 elements of the haloed LDS image
+static bool up2g_geo_lim(const BnGeom& g, Up2Geo* t, int chsp, float* fill_out);
+// the 256-element image unless the 320-element one fills the tile's 128 positions at least a tenth better
 static bool up2g_geo(const BnGeom& g, Up2Geo* t) {
+    float f0 = 0.f, f1 = 0.f;
+    Up2Geo t1;
+    const bool ok0 = up2g_geo_lim(g, t, UP2<0>::CHSP, &f0);
+    // (only maps the small image serves too: the dispatch keeps wider maps on tiles of the square instantiations)
+    const bool ok1 = ok0 && up2g_geo_lim(g, &t1, UP2<1>::CHSP, &f1);
+    if (ok1 && f1 > 1.1f * f0) { *t = t1; return true; }
+    return ok0;
+}
+static bool up2g_geo_lim(const BnGeom& g, Up2Geo* t, int chsp, float* fill_out) {
     if (g.R != 5 || g.S != 5 || g.stride != 2 || g.pt != 1 || g.pl != 1) return false;
     if (g.Hb != 2 * g.Hs || g.Wb != 2 * g.Ws) return false;
     if ((g.Cs % 4) != 0 || (g.Cb & 3) != 0 || g.Cb < 16) return false;
@@ -706,13 +733,14 @@ static bool up2g_geo(const BnGeom& g, Up2Geo* t) {
         if ((g.Hs + ath - 1) / ath != upf || ath * g.Ws > TP) continue;
         int F = TP / (ath * g.Ws);
         const int fs = (ath + 2) * t->SWp;
-        while (F >= 1 && F * fs > UP2<0>::CHSP) --F;
+        while (F >= 1 && F * fs > chsp) --F;
         if (F < 1) continue;
         const float fill = (float)(F * ath * g.Ws) / (float)TP * (float)g.Hs / (float)(upf * ath);
         if (fill > best + 1e-6f) { best = fill; b_upf = upf; b_ath = ath; b_F = F; }
         if (best >= 0.999f) break;
     }
     if (b_upf == 0) return false;
+    *fill_out = best;
     t->UPF = b_upf; t->AT_H = b_ath; t->F = b_F;
     t->FS = (b_ath + 2) * t->SWp;
     t->CHS = b_F * t->FS;
@@ -728,18 +756,18 @@ static int up2g_splits(const BnGeom& g, const Up2Geo& t, int cc) {
     return s > 8 ? 8 : (s < 1 ? 1 : s);
 }
 
-template <int KV>
-static int launch_up2g(const float* small, const float* w, const float* bias, float* out,
+template <int KV, int LG>
+static int launch_up2g_img(const float* small, const float* w, const float* bias, float* out,
                        const float* dact_src, const BnGeom& g, int act, int dact, float slope,
                        hipStream_t st, int splits, void* ws) {
     constexpr int CC = 4;
     Up2Geo t;
     if (!up2g_geo(g, &t)) return BN_E_SHAPE;
     constexpr int WDMA = (CC * 32 * 25 / 4 + MF_THREADS - 1) / MF_THREADS;
-    constexpr size_t lds = ((size_t)2 * CC * UP2<0>::CHSP + (size_t)2 * WDMA * MF_THREADS * 4) * 4;
+    constexpr size_t lds = ((size_t)2 * CC * UP2<LG>::CHSP + (size_t)2 * WDMA * MF_THREADS * 4) * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_up2_mfma<0, CC, KV>,
+        hipError_t e = hipFuncSetAttribute((const void*)k_up2_mfma<LG, CC, KV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -748,17 +776,28 @@ static int launch_up2g(const float* small, const float* w, const float* bias, fl
     if (splits > 1) {
         if (!ws) return BN_E_WORKSPACE;
         const size_t total = (size_t)g.N * g.Cb * g.Hb * g.Wb;
-        BN_LAUNCH_MAIN((k_up2_mfma<0, CC, KV>), grid, dim3(MF_THREADS), lds, st, small, w,
+        BN_LAUNCH_MAIN((k_up2_mfma<LG, CC, KV>), grid, dim3(MF_THREADS), lds, st, small, w,
                        (const float*)nullptr, (float*)ws, (const float*)nullptr, g, BN_ACT_NONE,
                        BN_ACT_NONE, slope, g.Cs / splits, total, t);
         BN_LAUNCH_CHECK();
         return bn_launch_split_epilogue((const float*)ws, bias, out, dact_src, total, splits, g.Cb,
                                         g.Hb * g.Wb, act, dact, slope, st);
     }
-    BN_LAUNCH_MAIN((k_up2_mfma<0, CC, KV>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
+    BN_LAUNCH_MAIN((k_up2_mfma<LG, CC, KV>), grid, dim3(MF_THREADS), lds, st, small, w, bias, out,
                        dact_src, g, act, dact, slope, g.Cs, (size_t)0, t);
     BN_LAUNCH_CHECK();
     return 0;
+}
+
+template <int KV>
+static int launch_up2g(const float* small, const float* w, const float* bias, float* out,
+                       const float* dact_src, const BnGeom& g, int act, int dact, float slope,
+                       hipStream_t st, int splits, void* ws) {
+    Up2Geo t;
+    if (!up2g_geo(g, &t)) return BN_E_SHAPE;
+    return t.CHS > UP2<0>::CHSP
+        ? launch_up2g_img<KV, 1>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws)
+        : launch_up2g_img<KV, 0>(small, w, bias, out, dact_src, g, act, dact, slope, st, splits, ws);
 }
 
 BnFastPlan bn_fast_up_plan(const BnGeom& g) {
@@ -781,7 +820,7 @@ BnFastPlan bn_fast_up_plan(const BnGeom& g) {
         if (off || !up2g_geo(g, &tg)) return p;
         p.supported = true;
         p.a = 1; p.c = 4; p.variant = 3;
-        p.kernel_name = "k_up2_mfma<0, 4>";
+        p.kernel_name = tg.CHS > UP2<0>::CHSP ? "k_up2_mfma<1, 4>" : "k_up2_mfma<0, 4>";
         p.d = up2g_splits(g, tg, 4);
         p.ws_bytes = p.d > 1 ? (size_t)p.d * g.N * g.Cb * g.Hb * g.Wb * sizeof(float) : 0;
         return p;
