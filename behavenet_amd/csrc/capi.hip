@@ -614,7 +614,7 @@ static int run_down(int family, const float* big, const float* w, const float* b
     }
     if (!generic && bn_s1in1_ok(g)) {
         static const char* names1[4] = {"k_down_s1_in1<3>", "k_down_s1_in1<5>", "k_down_s1_in1<7>", "k_down_s1_in1<9>"};
-        BnProfScope prof(family, g.Cb, g.Cs, names1[(g.R - 3) / 2], st);
+        BnProfScope prof(family, g.Cb, g.Cs, (g.R == 5 && (g.Cs & 15) == 0) ? "k_down_s1_in1m" : names1[(g.R - 3) / 2], st);
         return bn_launch_s1in1(big, w, bias, out, dact_src, g, act, dact, slope, st);
     }
     if (!generic && bn_s1c1_ok(g)) {

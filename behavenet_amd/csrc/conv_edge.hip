@@ -341,12 +341,142 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The DMA generation for STRIDE 1 (round 6): the first / last layer of a max-pooling architecture (1 <-> 16 channels on
+// the full frame).  k_wgrad_c1<1, true> moved its stage through registers (8 16-byte loads, 19 ds_writes, two barriers
+// per stage: 90 us for 285 MB).  Same stages (4 rows x 64 columns of the small map = the big map), MFMA roles and
+// partial layout as k_wgrad_c1d; what differs is the geometry of the tiles:
+//   small tile: a stage's four rows lie Ws apart in memory (Ws = 64 k): lane = 16-byte group (row lane / 16, column
+//               4 (lane % 16)), offset computed once, a stage adds a scalar;
+//   big tile:   8 patch rows (4 + 4) of 72 words: image column wb at LDS column wb - q00 + 4, any offsets pt, pl <= 4;
+//               the rows above / below the frame and the groups left / right of it are out-of-range reads (per-lane
+//               row number and column class against the stage's scalars), interior column blocks read their neighbours'.
+// ---------------------------------------------------------------------------------------------
+#define WE_IH (WC_ROWS + 4)
+#define WE_RW (WC_W + 8)
+#define WE_BG (WE_IH * WE_RW / 4)                     // 144 groups of the big tile
+#define WE_BGP ((WE_BG + 63) / 64 * 64)               // whole wave rows: 192
+#define WE_BUF (32 * WD_SP + 4 * WE_BGP)
+#define WE_LDS ((2 * WE_BUF + WD_ONES) * 4)
+
+template <bool BIAS>
+__global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1e(
+    const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
+    float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame, int cblocks, int pair) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int PQ = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
+    WC_DECODE_GRID();
+    const bool do_bias = BIAS && bch == 0;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)small, 0, (int)((size_t)g.N * g.Cs * PQ * 4), 0x00020000);
+    // the big image is addressed from pt rows and 4 columns in front of its start (patch row y = image row
+    // p0 - pt + y, LDS column c = image column q00 - 4 + c): what lies in front of a frame is masked, not read
+    const int shift = g.pt * g.Wb + 4;
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(big - shift), 0, (int)(((size_t)g.N * g.Cb * HWb + shift) * 4), 0x00020000);
+
+    for (int e = tid; e < 2 * WE_BUF; e += ED_THREADS) {
+        const int w = e % WE_BUF;
+        if (w < 32 * WD_SP && w / WD_SP >= g.Cs) wsm[e] = 0.f;
+    }
+    if (BIAS) for (int e = tid; e < WD_ONES; e += ED_THREADS) wsm[2 * WE_BUF + e] = 1.f;
+    // DMA descriptors: small rows a = wv + 4 d, group = lane; big groups e = lane + 64 wv (waves 0 .. 2)
+    const int svo = (wv * PQ + (lane >> 4) * g.Ws + 4 * (lane & 15)) * 4;
+    const int be = lane + 64 * wv;
+    const int by = be / (WE_RW / 4), bc = be - by * (WE_RW / 4);
+    const int bvo = (by * g.Wb + 4 * bc) * 4;
+    const bool b_in = be < WE_BG;
+    auto issue_dma = [&](const int d, const int buf, const int st) __attribute__((always_inline)) {
+        const int n = st / stages_per_frame;
+        const int rem = st - n * stages_per_frame;
+        const int rblk = rem / cblocks;
+        const int p0 = rblk * WC_ROWS, q00 = (rem - rblk * cblocks) * WC_W;
+        float* img = wsm + buf * WE_BUF;
+        if (d < 8) {
+            if (wv + 4 * d < g.Cs)                                   // wave-uniform
+                wd_dma16(rs, img + (wv + 4 * d) * WD_SP, svo, (((n * g.Cs + 4 * d) * g.Hs + p0) * g.Ws + q00) * 4);
+        } else if (64 * wv < WE_BGP) {                               // wave-uniform
+            const int hb = p0 - g.pt + by;                           // image row of this lane's group
+            const bool ok = b_in && hb >= 0 && hb < g.Hb && (bc > 0 || q00 > 0) &&
+                            (bc < WE_RW / 4 - 1 || q00 + WC_W < g.Wb);
+            wd_dma16(rb, img + 32 * WD_SP + 4 * 64 * wv, ok ? bvo : ED_OOB,
+                     (((n * g.Cb + bch) * g.Hb + p0) * g.Wb + q00) * 4);
+        }
+    };
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;
+
+    // operand addresses: tap j = li -> (r, s); pixel (row wv, column 2t + kk)
+    const int tap = li < 25 ? li : 0;
+    const int tr = tap / 5, ts = tap - tr * 5;
+    int aq_cur = (li * WD_SP + wv * WC_W + kk) * 4;                              // bytes
+    int bq_cur = (32 * WD_SP + (wv + tr) * WE_RW + ts + kk + 4 - g.pl) * 4;      // column wb - q00 + 4
+    int aq_oth = aq_cur + WE_BUF * 4, bq_oth = bq_cur + WE_BUF * 4;
+    if (do_bias && li >= 25) bq_cur = bq_oth = 2 * WE_BUF * 4;
+    const char* sm = reinterpret_cast<const char*>(wsm);
+
+    int st = bx;
+    if (st < n_stages) {
+#pragma unroll
+        for (int d = 0; d < 9; ++d) issue_dma(d, 0, st);
+    }
+    int cur = 0;
+    for (; st < n_stages; st += G) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nx = st + G;
+        const bool more = nx < n_stages;
+#pragma unroll
+        for (int t = 0; t < WC_W / 2; ++t) {
+            const float av = *reinterpret_cast<const float*>(sm + aq_cur + 8 * t);
+            const float bv = *reinterpret_cast<const float*>(sm + bq_cur + 8 * t);     // (bias lanes: inside the 1.0f region)
+            acc[t & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t & 1], 0, 0, 0);
+            if (t >= 2 && t < 11) { if (more) issue_dma(t - 2, cur ^ 1, nx); }
+        }
+        cur ^= 1;
+        int tmp = aq_cur; aq_cur = aq_oth; aq_oth = tmp;
+        tmp = bq_cur; bq_cur = bq_oth; bq_oth = tmp;
+    }
+
+    __syncthreads();
+    float* red = wsm;    // 4 x 16 x 64 floats
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wv * 16 + e) * 64 + lane] = acc[0][e] + acc[1][e];
+    __syncthreads();
+    if (wv == 0 && (li < 25 || (do_bias && li == 25))) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = (red[e * 64 + lane] + red[(16 + e) * 64 + lane]) +
+                            (red[(32 + e) * 64 + lane] + red[(48 + e) * 64 + lane]);
+            const int a = (e & 3) + 8 * (e >> 2) + 4 * kk;
+            if (a < g.Cs) {
+                if (li < 25) part[((size_t)bch * G + bx) * (g.Cs * 25) + a * 25 + li] = v;
+                else         bias_part[(size_t)bx * g.Cs + a] = v;
+            }
+        }
+    }
+}
+
+// stride-1 layers the DMA generation takes: whole stages (maps of 64 k columns, 4 k rows), "same"-sized maps
+static bool wgrad_c1e_ok(const BnGeom& g) {
+    return g.stride == 1 && g.R == 5 && g.S == 5 && g.Cs <= 32 && g.CsS == 0 && (g.Ws % WC_W) == 0 &&
+           (g.Hs % WC_ROWS) == 0 && g.Hb == g.Hs && g.Wb == g.Ws && g.pt <= 4 && g.pl <= 4;
+}
+
 static inline int wgrad_c1_rblocks(const BnGeom& g) { return (g.Hs + WC_ROWS - 1) / WC_ROWS; }
 static inline int wgrad_c1_cblocks(const BnGeom& g) { return (g.Ws + WC_W - 1) / WC_W; }
 static int wgrad_c1_grid(const BnGeom& g) {
     const int n_stages = g.N * wgrad_c1_rblocks(g) * wgrad_c1_cblocks(g);
     // resident workgroups per CU in total: 3 (first generation), 2 (DMA generation: 79 KB of LDS)
-    const int cap = ((g.pt == 1 && g.pl == 1) ? 512 : 768) / (g.Cb > 0 ? g.Cb : 1);
+    const int cap = (((g.pt == 1 && g.pl == 1) || wgrad_c1e_ok(g)) ? 512 : 768) / (g.Cb > 0 ? g.Cb : 1);
     return n_stages < cap ? n_stages : cap;
 }
 
@@ -362,7 +492,7 @@ BnFastPlan bn_edge_wgrad_plan(const BnGeom& g) {
         p.variant = 1;
         p.d = wgrad_c1_grid(g);
         p.ws_bytes = ((size_t)g.Cb * p.d * g.Cs * 25 + (size_t)p.d * 32) * sizeof(float);
-        p.kernel_name = "k_wgrad_c1<1>";
+        p.kernel_name = wgrad_c1e_ok(g) ? "k_wgrad_c1e" : "k_wgrad_c1<1>";
         return p;
     }
     if (g.Cs > 32) return p;
@@ -398,7 +528,24 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
     // several big-side channels: their workgroups of a stage together on one XCD (WC_DECODE_GRID)
     const int pair = (g.Cb > 1 && (plan.d & 7) == 0) ? 1 : 0;
     const dim3 wgrid = pair ? dim3(plan.d * g.Cb) : dim3(plan.d, g.Cb);
-    if (g.stride == 1) {
+    if (g.stride == 1 && wgrad_c1e_ok(g) && vec) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e1 = hipFuncSetAttribute((const void*)k_wgrad_c1e<true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, WE_LDS);
+            hipError_t e2 = hipFuncSetAttribute((const void*)k_wgrad_c1e<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, WE_LDS);
+            if (e1 != hipSuccess) return (int)e1;
+            if (e2 != hipSuccess) return (int)e2;
+            attr_set = true;
+        }
+        if (bias_part)
+            BN_LAUNCH_MAIN(k_wgrad_c1e<true>, wgrid, dim3(ED_THREADS), WE_LDS, st, small, big, (float*)ws,
+                               bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
+        else
+            BN_LAUNCH_MAIN(k_wgrad_c1e<false>, wgrid, dim3(ED_THREADS), WE_LDS, st, small, big, (float*)ws,
+                               bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
+    } else if (g.stride == 1) {
         if (vec)
             BN_LAUNCH_MAIN((k_wgrad_c1<1, true>), wgrid, dim3(ED_THREADS), 0, st, small, big,
                                (float*)ws, bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
@@ -2488,6 +2635,90 @@ __global__ __launch_bounds__(256) void k_down_s1_in1(const float* __restrict__ b
     }
 }
 
+// Round 6: the same layer with 5x5 taps and 16 k output channels on the matrix cores.  The vector kernel above spends
+// 3.4 GFLOP of v_fma on the first layer of the max-pooling test architecture (83 us, vector-ALU bound, for 285 MB).
+// v_mfma_f32_16x16x4_f32 with the TAPS as the reduction: A = 16 channels x 4 taps (28 = 7 steps for one input channel,
+// 52 = 13 for two; held in registers), B = 4 taps x 16 adjacent pixels of a row, read from the same LDS tile through
+// per-lane tap offsets computed once (one ds_read_b32 per instruction: 19 consecutive words, no conflicts); a wave owns
+// 4 rows x 64 columns, four pixel blocks in flight (independent accumulators).  Output: lane = (pixel, 4 channels).
+typedef float floatx4e __attribute__((ext_vector_type(4)));
+template <int CIN>
+__global__ __launch_bounds__(256) void k_down_s1_in1m(const float* __restrict__ big, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       const float* __restrict__ dact_src, BnGeom g, int act, int dact,
+                                                       float slope, int tiles_h, int tiles_w) {
+    constexpr int KS = 5, IH = S1C_TH + KS - 1, IWP = (S1C_TW + KS - 1 + 3) & ~3;
+    constexpr int KT = CIN * KS * KS, NK = (KT + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float tile[CIN * IH * IWP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, kg = lane >> 4;
+    int b = blockIdx.x;
+    const int tw = b % tiles_w; b /= tiles_w;
+    const int th = b % tiles_h;
+    const int n = b / tiles_h;
+    const int h0 = th * S1C_TH, w0 = tw * S1C_TW;
+    const size_t HWb = (size_t)g.Hb * g.Wb;
+    for (int e = tid; e < CIN * IH * IWP; e += 256) {
+        const int cc = e / (IH * IWP), rem = e - cc * (IH * IWP);
+        const int y = rem / IWP, xx = rem - y * IWP;
+        const int hb = h0 - g.pt + y, wb = w0 - g.pl + xx;
+        const bool ok = hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+        tile[e] = ok ? big[((size_t)n * g.Cb + cc) * HWb + (size_t)hb * g.Wb + wb] : 0.f;
+    }
+    int toff[NK];                                    // tap 4 t + kg -> its word offset in the tile (0 for no tap)
+#pragma unroll
+    for (int t = 0; t < NK; ++t) {
+        const int tap = 4 * t + kg;
+        const int cc = tap / (KS * KS), rem = tap - cc * (KS * KS);
+        const int r = rem / KS, sx = rem - r * KS;
+        toff[t] = tap < KT ? (cc * IH + r) * IWP + sx : 0;
+    }
+    __syncthreads();
+    const size_t PQ = (size_t)g.Hs * g.Ws;
+    for (int m0 = 0; m0 < g.Cs; m0 += 16) {
+        float a[NK];
+#pragma unroll
+        for (int t = 0; t < NK; ++t) {
+            const int tap = 4 * t + kg;
+            a[t] = (tap < KT && m0 + j < g.Cs) ? w[(size_t)(m0 + j) * KT + tap] : 0.f;
+        }
+        float bz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bz[e] = (bias && m0 + 4 * kg + e < g.Cs) ? bias[m0 + 4 * kg + e] : 0.f;
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * wv + rr;
+            floatx4e acc[4];
+#pragma unroll
+            for (int xb = 0; xb < 4; ++xb) acc[xb] = (floatx4e){0.f, 0.f, 0.f, 0.f};
+            const float* tp = tile + row * IWP + j;
+#pragma unroll
+            for (int t = 0; t < NK; ++t) {
+#pragma unroll
+                for (int xb = 0; xb < 4; ++xb)
+                    acc[xb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], tp[toff[t] + 16 * xb], acc[xb], 0, 0, 0);
+            }
+            const int h = h0 + row;
+            if (h >= g.Hs) continue;
+#pragma unroll
+            for (int xb = 0; xb < 4; ++xb) {
+                const int wq = w0 + 16 * xb + j;
+                if (wq >= g.Ws) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + 4 * kg + e;
+                    if (m >= g.Cs) continue;
+                    const size_t idx = ((size_t)n * g.Cs + m) * PQ + (size_t)h * g.Ws + wq;
+                    float v = bn_apply_act(acc[xb][e] + bz[e], act, slope);
+                    if (dact_src) v *= bn_act_grad_from_output(dact_src[idx], dact, slope);
+                    out[idx] = v;
+                }
+            }
+        }
+    }
+}
+
 bool bn_s1in1_ok(const BnGeom& g) {
     if (g.stride != 1 || g.R != g.S || (g.R != 3 && g.R != 5 && g.R != 7 && g.R != 9)) return false;
     if (g.Cb > 2 || g.Cs < 3 || g.CsS) return false;      // (one / two OUTPUT channels: k_down_s1_c1)
@@ -2500,6 +2731,16 @@ int bn_launch_s1in1(const float* big, const float* w, const float* bias, float* 
     if (!bn_s1in1_ok(g)) return BN_E_SHAPE;
     const int tiles_h = (g.Hs + S1C_TH - 1) / S1C_TH, tiles_w = (g.Ws + S1C_TW - 1) / S1C_TW;
     const dim3 grid((unsigned)((size_t)g.N * tiles_h * tiles_w));
+    if (g.R == 5 && (g.Cs & 15) == 0) {             // 16 k output channels: the taps on the matrix cores
+        if (g.Cb == 1)
+            BN_LAUNCH_MAIN((k_down_s1_in1m<1>), grid, dim3(256), 0, st, big, w, bias, out, dact_src, g, act, dact, slope,
+                           tiles_h, tiles_w);
+        else
+            BN_LAUNCH_MAIN((k_down_s1_in1m<2>), grid, dim3(256), 0, st, big, w, bias, out, dact_src, g, act, dact, slope,
+                           tiles_h, tiles_w);
+        BN_LAUNCH_CHECK();
+        return 0;
+    }
 #define S1I_CASE(K)                                                                                         \
     if (g.R == K) {                                                                                         \
         BN_LAUNCH_MAIN((k_down_s1_in1<K>), grid, dim3(256), 0, st, big, w, bias, out, dact_src, g, act,     \

@@ -151,6 +151,12 @@ CONV_CASES = [
     ('m16_k4s2_c32_to_16', 3, 32, 32, 32, 16, 4, 2, (1, 1), (1, 1)),
     ('m16_s2_c64_to_16_8x8_n40', 40, 64, 16, 16, 16, 5, 2, (1, 2), (1, 2)),
     ('m16_s1_c16_to_16_64x64', 2, 16, 64, 64, 16, 5, 1, (2, 2), (2, 2)),
+    # round 6: the stride-1 single-channel weight gradient's DMA generation (k_wgrad_c1e): three column blocks and an
+    # odd number of frames, offsets that are not the kernel's half, two-channel frames, 32 channels
+    ('s1_k5_1ch_64x192_n5', 5, 1, 64, 192, 16, 5, 1, (2, 2), (2, 2)),
+    ('s1_k5_1ch_pad13_128x64', 3, 1, 128, 64, 32, 5, 1, (1, 3), (3, 1)),
+    ('s1_k5_1ch_pad40_64x64', 3, 1, 64, 64, 16, 5, 1, (4, 0), (0, 4)),
+    ('s1_k5_2ch_64x128', 2, 2, 64, 128, 16, 5, 1, (2, 2), (2, 2)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
@@ -306,6 +312,8 @@ CONVT_CASES = [
     ('s1_k3_to_1ch_50x30', 2, 7, 50, 30, 1, 3, 1, (1, 1), None, 0),
     ('s1_k5_to_1ch_pad04', 2, 16, 20, 24, 1, 5, 1, 0, (0, 4, 4, 0), 0),
     ('s1_k5_to_2ch_128x128', 2, 16, 128, 128, 2, 5, 1, (2, 2), None, 0),
+    ('s1_k5_to_1ch_128x128', 2, 16, 128, 128, 1, 5, 1, (2, 2), None, 0),
+    ('s1_k5_32_to_1ch_64x64_n3', 3, 32, 64, 64, 1, 5, 1, (2, 2), None, 0),
     # round 4: no powers of two, directly on the stride-2 families (see CONV_CASES)
     ('np2_16x12', 5, 64, 16, 12, 32, 5, 2, 0, (1, 2, 1, 2), 0),
     ('np2_12x10', 7, 128, 12, 10, 64, 5, 2, 0, (1, 2, 1, 2), 0),
