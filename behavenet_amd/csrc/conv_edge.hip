@@ -359,7 +359,10 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1d(
 #define WE_BUF (32 * WD_SP + 4 * WE_BGP)
 #define WE_LDS ((2 * WE_BUF + WD_ONES) * 4)
 
-template <bool BIAS>
+// M16: at most 16 small-side channels (the max-pooling test architecture's 1 <-> 16 layers) on v_mfma_f32_16x16x4_f32 --
+// rows = 16 channels, reduction = 4 pixels, columns = 16 taps, two instructions (taps 0-15, 16-31) per 4 pixels: half the
+// matrix time of the 32-row form, whose 32 x 64-cycle instructions per stage row were the pace (4.9 TB/s at best).
+template <bool BIAS, bool M16>
 __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1e(
     const float* __restrict__ small, const float* __restrict__ big, float* __restrict__ part,
     float* __restrict__ bias_part, BnGeom g, int n_stages, int stages_per_frame, int cblocks, int pair) {
@@ -408,19 +411,30 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1e(
         }
     };
 
+    typedef float floatx4w __attribute__((ext_vector_type(4)));
     floatx16 acc[2];
+    floatx4w acc4[2][2];                              // M16: [tap block][even / odd step]
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[h][e] = 0.f;
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) acc4[h][b2] = (floatx4w){0.f, 0.f, 0.f, 0.f};
+    }
 
-    // operand addresses: tap j = li -> (r, s); pixel (row wv, column 2t + kk)
-    const int tap = li < 25 ? li : 0;
+    // operand addresses: tap j -> (r, s); 32-row form: tap li, pixel (row wv, column 2t + kk);
+    // M16: channel / tap lane & 15, pixel (row wv, column 4t + lane / 16), tap blocks lane & 15 and 16 + lane & 15
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int tap = M16 ? l16 : (li < 25 ? li : 0);
     const int tr = tap / 5, ts = tap - tr * 5;
-    int aq_cur = (li * WD_SP + wv * WC_W + kk) * 4;                              // bytes
-    int bq_cur = (32 * WD_SP + (wv + tr) * WE_RW + ts + kk + 4 - g.pl) * 4;      // column wb - q00 + 4
-    int aq_oth = aq_cur + WE_BUF * 4, bq_oth = bq_cur + WE_BUF * 4;
-    if (do_bias && li >= 25) bq_cur = bq_oth = 2 * WE_BUF * 4;
+    const int tap2 = 16 + l16 < 25 ? 16 + l16 : 0;
+    const int tr2 = tap2 / 5, ts2 = tap2 - tr2 * 5;
+    int aq_cur = M16 ? (l16 * WD_SP + wv * WC_W + kq) * 4 : (li * WD_SP + wv * WC_W + kk) * 4;   // bytes
+    int bq_cur = (32 * WD_SP + (wv + tr) * WE_RW + ts + (M16 ? kq : kk) + 4 - g.pl) * 4;         // column wb - q00 + 4
+    int b2_cur = (32 * WD_SP + (wv + tr2) * WE_RW + ts2 + kq + 4 - g.pl) * 4;
+    int aq_oth = aq_cur + WE_BUF * 4, bq_oth = bq_cur + WE_BUF * 4, b2_oth = b2_cur + WE_BUF * 4;
+    if (!M16 && do_bias && li >= 25) bq_cur = bq_oth = 2 * WE_BUF * 4;
+    if (M16 && do_bias && l16 == 9) b2_cur = b2_oth = 2 * WE_BUF * 4;             // tap column 25 = the bias sums
     const char* sm = reinterpret_cast<const char*>(wsm);
 
     int st = bx;
@@ -434,16 +448,57 @@ __global__ __launch_bounds__(ED_THREADS, 2) void k_wgrad_c1e(
         __syncthreads();
         const int nx = st + G;
         const bool more = nx < n_stages;
+        if constexpr (M16) {
 #pragma unroll
-        for (int t = 0; t < WC_W / 2; ++t) {
-            const float av = *reinterpret_cast<const float*>(sm + aq_cur + 8 * t);
-            const float bv = *reinterpret_cast<const float*>(sm + bq_cur + 8 * t);     // (bias lanes: inside the 1.0f region)
-            acc[t & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t & 1], 0, 0, 0);
-            if (t >= 2 && t < 11) { if (more) issue_dma(t - 2, cur ^ 1, nx); }
+            for (int t = 0; t < WC_W / 4; ++t) {
+                const float av = *reinterpret_cast<const float*>(sm + aq_cur + 16 * t);
+                const float bv = *reinterpret_cast<const float*>(sm + bq_cur + 16 * t);
+                const float b2 = *reinterpret_cast<const float*>(sm + b2_cur + 16 * t);
+                acc4[t & 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc4[t & 1][0], 0, 0, 0);
+                acc4[t & 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2, acc4[t & 1][1], 0, 0, 0);
+                if (t >= 2 && t < 11) { if (more) issue_dma(t - 2, cur ^ 1, nx); }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < WC_W / 2; ++t) {
+                const float av = *reinterpret_cast<const float*>(sm + aq_cur + 8 * t);
+                const float bv = *reinterpret_cast<const float*>(sm + bq_cur + 8 * t);     // (bias lanes: inside the 1.0f region)
+                acc[t & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t & 1], 0, 0, 0);
+                if (t >= 2 && t < 11) { if (more) issue_dma(t - 2, cur ^ 1, nx); }
+            }
         }
         cur ^= 1;
         int tmp = aq_cur; aq_cur = aq_oth; aq_oth = tmp;
         tmp = bq_cur; bq_cur = bq_oth; bq_oth = tmp;
+        tmp = b2_cur; b2_cur = b2_oth; b2_oth = tmp;
+    }
+
+    if constexpr (M16) {
+        // register e of block b2 = channel 4 (lane / 16) + e, tap 16 b2 + lane % 16; the four waves in fixed order
+        __syncthreads();
+        float* red = wsm;    // 4 waves x 2 blocks x 4 x 64 floats
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[((wv * 2 + b2) * 4 + e) * 64 + lane] = acc4[0][b2][e] + acc4[1][b2][e];
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int tp = 16 * b2 + l16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = (b2 * 4 + e) * 64 + lane;
+                    const float v = (red[o] + red[512 + o]) + (red[1024 + o] + red[1536 + o]);
+                    const int a = 4 * kq + e;
+                    if (a < g.Cs) {
+                        if (tp < 25) part[((size_t)bch * G + bx) * (g.Cs * 25) + a * 25 + tp] = v;
+                        else if (do_bias && tp == 25) bias_part[(size_t)bx * g.Cs + a] = v;
+                    }
+                }
+            }
+        }
+        return;
     }
 
     __syncthreads();
@@ -531,20 +586,20 @@ int bn_launch_edge_wgrad(const BnFastPlan& plan, const float* small, const float
     if (g.stride == 1 && wgrad_c1e_ok(g) && vec) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e1 = hipFuncSetAttribute((const void*)k_wgrad_c1e<true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, WE_LDS);
-            hipError_t e2 = hipFuncSetAttribute((const void*)k_wgrad_c1e<false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, WE_LDS);
-            if (e1 != hipSuccess) return (int)e1;
-            if (e2 != hipSuccess) return (int)e2;
+            const void* fns[4] = {(const void*)k_wgrad_c1e<true, false>, (const void*)k_wgrad_c1e<false, false>,
+                                  (const void*)k_wgrad_c1e<true, true>, (const void*)k_wgrad_c1e<false, true>};
+            for (const void* fn : fns) {
+                hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WE_LDS);
+                if (e1 != hipSuccess) return (int)e1;
+            }
             attr_set = true;
         }
-        if (bias_part)
-            BN_LAUNCH_MAIN(k_wgrad_c1e<true>, wgrid, dim3(ED_THREADS), WE_LDS, st, small, big, (float*)ws,
-                               bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
-        else
-            BN_LAUNCH_MAIN(k_wgrad_c1e<false>, wgrid, dim3(ED_THREADS), WE_LDS, st, small, big, (float*)ws,
-                               bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair);
+#define WE_LAUNCH(B, M)                                                                                     \
+        BN_LAUNCH_MAIN((k_wgrad_c1e<B, M>), wgrid, dim3(ED_THREADS), WE_LDS, st, small, big, (float*)ws,   \
+                           bias_part, g, n_stages, spf, wgrad_c1_cblocks(g), pair)
+        if (g.Cs <= 16) { if (bias_part) WE_LAUNCH(true, true); else WE_LAUNCH(false, true); }
+        else { if (bias_part) WE_LAUNCH(true, false); else WE_LAUNCH(false, false); }
+#undef WE_LAUNCH
     } else if (g.stride == 1) {
         if (vec)
             BN_LAUNCH_MAIN((k_wgrad_c1<1, true>), wgrid, dim3(ED_THREADS), 0, st, small, big,

@@ -252,14 +252,17 @@ __global__ __launch_bounds__(GEN_THREADS) void k_channel_sum_part(
     if (threadIdx.x == 0) part[(size_t)c * S + sp] = s;
 }
 
-__global__ void k_channel_sum_final(const float* __restrict__ part, float* __restrict__ db, int C,
-                                    int S, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one wave per channel: a lane adds its <= S / 64 slices, the lanes are added as a tree (fixed order).  (Round 6: it was
+// one thread walking all S slices -- 256 sequential additions; the single-channel sum of a zero-mean gradient, whose
+// cancellation multiplies every rounding error by ~200, came out at 6e-6 where the CPU's pairwise sum gives 2e-7.)
+__global__ __launch_bounds__(64) void k_channel_sum_final(const float* __restrict__ part, float* __restrict__ db,
+                                                          int C, int S, int accumulate) {
+    const int c = blockIdx.x;
     float v = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < S; ++s) v += part[(size_t)c * S + s];
-    db[c] = accumulate ? db[c] + v : v;
+    for (int s = threadIdx.x; s < S; s += 64) v += part[(size_t)c * S + s];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + v : v;
 }
 
 static int channel_sum_splits(int N, int C, int npix) {
@@ -282,7 +285,7 @@ int bn_launch_channel_sum(const float* t, float* db, int N, int C, int npix, int
         hipLaunchKernelGGL(k_channel_sum_part, dim3(C, S), dim3(GEN_THREADS), 0, st, t, (float*)ws,
                            N, C, npix, S);
         BN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_channel_sum_final, dim3((C + 63) / 64), dim3(64), 0, st,
+        hipLaunchKernelGGL(k_channel_sum_final, dim3(C), dim3(64), 0, st,
                            (const float*)ws, db, C, S, accumulate);
         BN_LAUNCH_CHECK();
         return 0;

@@ -25,7 +25,7 @@ DEV = 'cuda'
 SLOPE = 0.05
 
 
-def close(got, want, want64=None, rtol=1e-4, norm_tol=1e-4, name=''):
+def close(got, want, want64=None, rtol=1e-4, norm_tol=1e-4, name='', sum_of=None):
     got = got.detach().cpu().double().numpy()
     want = want.detach().cpu().double().numpy()
     assert got.shape == want.shape, (name, got.shape, want.shape)
@@ -40,7 +40,14 @@ def close(got, want, want64=None, rtol=1e-4, norm_tol=1e-4, name=''):
     e_hip = np.abs(got - w64).max() / scale
     e_cpu = np.abs(want - w64).max() / scale
     assert e_hip <= norm_tol, '%s: err vs f64 %.3e' % (name, e_hip)
-    assert e_hip <= max(8 * e_cpu, 3e-6), \
+    # `sum_of` (a reduction's terms: the bias gradient of one or two channels is a sum of 10^4..10^5 zero-mean values
+    # that cancel to a thousandth of their magnitudes): an error of four roundings of sum |terms| is what ANY fp32
+    # summation order may leave -- the gate relative to the result would measure the cancellation, not the kernel
+    floor = 3e-6
+    if sum_of is not None:
+        mags = sum_of.detach().cpu().double().abs()
+        floor = max(floor, 4 * 2.0 ** -24 * float(mags.sum(dim=[d for d in range(mags.dim()) if d != 1]).max()) / scale)
+    assert e_hip <= max(8 * e_cpu, floor), \
         '%s: hip err %.3e vs f64, cpu fp32 oracle err %.3e' % (name, e_hip, e_cpu)
 
 
@@ -253,7 +260,7 @@ def test_conv2d_bwd(case):
     db = torch.full((K,), 7.0, device=DEV)
     _hip.conv2d_bwd_weight(xind, dyd, dw, db, geom, False)
     close(dw, dwr, dw64, name=case[0] + ' dw')
-    close(db, dbr, db64, name=case[0] + ' db')
+    close(db, dbr, db64, name=case[0] + ' db', sum_of=dy)
     # accumulate: a second call adds on top (cross-chunk accumulation)
     _hip.conv2d_bwd_weight(xind, dyd, dw, db, geom, True)
     close(dw, 2 * dwr, 2 * dw64, name=case[0] + ' dw acc')
@@ -398,7 +405,7 @@ def test_convT2d_bwd(case):
     db = torch.full((Co,), -3.0, device=DEV)
     _hip.convT2d_bwd_weight(xind, dyd, dw, db, geom, False)
     close(dw, dwr, dw64, name=case[0] + ' dw')
-    close(db, dbr, db64, name=case[0] + ' db')
+    close(db, dbr, db64, name=case[0] + ' db', sum_of=dy)
     _hip.convT2d_bwd_weight(xind, dyd, dw, db, geom, True)
     close(dw, 2 * dwr, 2 * dw64, name=case[0] + ' dw acc')
 
