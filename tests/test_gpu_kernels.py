@@ -164,6 +164,8 @@ CONV_CASES = [
     ('s1_k5_1ch_pad13_128x64', 3, 1, 128, 64, 32, 5, 1, (1, 3), (3, 1)),
     ('s1_k5_1ch_pad40_64x64', 3, 1, 64, 64, 16, 5, 1, (4, 0), (0, 4)),
     ('s1_k5_2ch_64x128', 2, 2, 64, 128, 16, 5, 1, (2, 2), (2, 2)),
+    # (fuzz, round 6: one output channel, 256 frames -- its bias gradient is a sum of 59,136 terms that cancel)
+    ('fuzz_db_cancel_18x14_n256', 256, 2, 18, 14, 1, 5, 1, (3, 4), (0, 1)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
