@@ -453,6 +453,7 @@ def _fwd(layer, x, w, b, w5=None):
     return _hip.convT2d_fwd(x, w, b, g, layer.act, LRELU_SLOPE, w5=w5)
 
 
+_STACK_TAPS = os.environ.get('BN_STACK_TAPS', '1') != '0'      # 0: every entry point pads for itself (A/B switch)
 _FWD_OP = {'conv': _hip.OP_CONV_FWD, 'convT': _hip.OP_CONVT_FWD}
 _BWD_OP = {'conv': _hip.OP_CONV_BWD_D, 'convT': _hip.OP_CONVT_BWD_D}
 
@@ -463,6 +464,8 @@ def _stack_taps(plan, n, params, first=0):
     the data gradient of every such layer, 19 launches in a step of ae_arch_2.json; a stack makes the copies of ALL
     its layers in one launch when its forward pass starts and keeps them for its backward pass (same weights: the
     node's saved tensors).  -> [w5 | None] per layer, None for a stack without such layers."""
+    if not _STACK_TAPS:
+        return None
     jobs, idx = [], []
     for i in range(first, len(plan)):
         layer = plan[i]
