@@ -64,3 +64,29 @@ def test_scratch_sizes_of_the_sweep_are_finite():
         for op in (4, 5, 6):          # BN_OP_CONVT_*: small (K, P, Q) -> big (C, H, W)
             ws = lib.bn_conv_ws_bytes(op, N, K, P, Q, C, R, R, st, pt, pl, H, W)
             assert 0 <= ws < (1 << 32), (name, op, ws)
+
+
+def test_padded_taps_queries_and_argument_checks():
+    """bn_conv_taps_bytes / _pad / _hint (round 6) on the host: a 5x5 layer pads nothing, the 3x3 / 4x4 stride-2 layers of
+    the architecture search / ae_arch_2.json ask for a [pairs][5][5] copy in both of their roles, the weight-gradient ops
+    and unknown ops for none; the batched copy checks its arguments before it launches anything."""
+    lib = _hip.load()
+    five = (8, 32, 32, 32, 64, 5, 5, 2, 1, 1, 16, 16)
+    three = (8, 32, 32, 32, 64, 3, 3, 2, 0, 0, 16, 16)          # TF-"same": first tap on the frame
+    four = (8, 64, 32, 32, 64, 4, 4, 2, 1, 1, 16, 16)           # ae_arch_2.json
+    for op in (_hip.OP_CONV_FWD, _hip.OP_CONV_BWD_D):
+        assert lib.bn_conv_taps_bytes(op, *five) == 0
+        assert lib.bn_conv_taps_bytes(op, *three) >= 64 * 32 * 25 * 4
+        assert lib.bn_conv_taps_bytes(op, *four) >= 64 * 64 * 25 * 4
+    # the transposed layer with the same maps: small (64, 16, 16) -> big (32, 32, 32)
+    threeT = (8, 64, 16, 16, 32, 3, 3, 2, 0, 0, 32, 32)
+    assert lib.bn_conv_taps_bytes(_hip.OP_CONVT_FWD, *threeT) == lib.bn_conv_taps_bytes(_hip.OP_CONV_FWD, *three)
+    assert lib.bn_conv_taps_bytes(_hip.OP_CONVT_BWD_D, *threeT) == lib.bn_conv_taps_bytes(_hip.OP_CONV_FWD, *three)
+    assert lib.bn_conv_taps_bytes(_hip.OP_CONV_BWD_W, *three) == 0 and lib.bn_conv_taps_bytes(99, *three) == 0
+    assert lib.bn_conv_taps_pad(0, None, None, None, None) == 0
+    buf = (ctypes.c_char * 256)()
+    ptrs = (ctypes.c_void_p * 1)(ctypes.addressof(buf))
+    geoms = (ctypes.c_int * 13)(_hip.OP_CONV_FWD, *five)
+    assert lib.bn_conv_taps_pad(1, ptrs, ptrs, geoms, None) < 0             # a layer that does not pad: refused
+    assert lib.bn_conv_taps_pad(1, None, ptrs, geoms, None) < 0
+    assert lib.bn_conv_taps_hint(None, None) == 0
