@@ -145,6 +145,13 @@ def _guarded(label, fn, *args, **kwargs):
     """A secondary measurement must never cost the headline line: what goes wrong in one of them (a full /tmp
     under the trial store, an out-of-memory in an odd geometry) is reported in ITS entry."""
     try:
+        # every secondary starts from an empty allocator cache, like a fresh process: the blocks the previous
+        # ones left behind (thousands of small tensors of the export / fit runs) otherwise end up under this one's
+        # activations (round 6: ae_arch_2 / batch-norm steps read 1.7-2.5 % slower inside the bench process than
+        # alone, the secondaries AFTER them did not)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
         got = fn(*args, **kwargs)
         got['id'] = label
         return got
