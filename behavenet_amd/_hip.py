@@ -72,6 +72,8 @@ SIGNATURES = {
     'bn_maxpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
     'bn_maxpool2d_bwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 9 + [_c_void_p]),
     'bn_maxpool2d_act_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [ctypes.c_float, _c_void_p]),
+    'bn_conv2d_pool2_act_fwd': (_c_int, [_c_void_p] * 5 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
+    'bn_conv2d_pool2_act_ok': (_c_int, _CONV_GEOM),
     'bn_maxpool2d_act_bwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_void_p]),
     'bn_maxunpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
     'bn_maxunpool2d_fwd_k2': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
@@ -803,6 +805,26 @@ def maxpool2d_act_fwd(x, act, slope):
     rc = load().bn_maxpool2d_act_fwd(_ptr(x, 'x'), _ptr(y, 'y'), _ptr(idx, 'idx', torch.int32), N * C, H, W,
                                      int(act), float(slope), _stream())
     return (y, idx) if rc == 0 else None
+
+
+def conv2d_pool_act_ok(geom):
+    """Whether bn_conv2d_pool2_act_fwd serves this layer (host-side query)."""
+    return bool(load().bn_conv2d_pool2_act_ok(*geom))
+
+
+def conv2d_pool_act_fwd(x, w, b, geom, act, slope):
+    """Conv2d + 2x2 / stride-2 max pooling + activation in one kernel -> (y, idx) or None where it is not served."""
+    N, C, H, W, K, R, S, st, pt, pl, P, Q = geom
+    if P % 2 or Q % 4 or x.dtype != torch.float32:
+        return None
+    y = torch.empty((N, K, P // 2, Q // 2), dtype=torch.float32, device=x.device)
+    idx = torch.empty((N, K, P // 2, Q // 2), dtype=torch.int32, device=x.device)
+    rc = load().bn_conv2d_pool2_act_fwd(_ptr(x, 'x'), _ptr(w, 'w'), _ptr(b, 'b', allow_none=True), _ptr(y, 'y'),
+                                        _ptr(idx, 'idx', torch.int32), *geom, int(act), float(slope), _stream())
+    if rc == -2:                      # BN_E_SHAPE: not served
+        return None
+    _check(rc, 'bn_conv2d_pool2_act_fwd')
+    return y, idx
 
 
 def maxpool2d_act_bwd(dy, y, idx, in_hw, act, slope):

@@ -30,6 +30,12 @@ int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float
 
 // conv_mfma_down2.hip: 16-byte-DMA generation of the stride-2 gather-down kernel (chosen by
 // bn_fast_down_plan when the geometry fits and no split-K is needed; plan.variant == 2)
+bool bn_s1in1_pool_ok(const BnGeom& g);
+int bn_launch_s1in1_pool(const float* big, const float* w, const float* bias, float* y, int* idx, const BnGeom& g,
+                         int act, float slope, hipStream_t st);
+bool bn_down2_pool_ok(const BnGeom& g);
+int bn_launch_down2_pool(const float* big, const float* w, const float* bias, float* y, int* idx, const BnGeom& g,
+                         int act, float slope, hipStream_t st);
 bool bn_down2_supported(const BnGeom& g, int MR, int NR);
 bool bn_down2_m16_supported(const BnGeom& g, int NR);   // the 16-row tile (MR = 0 in the plans)
 int bn_down2_splits(const BnGeom& g, int MR, int NR);

@@ -1259,6 +1259,38 @@ extern "C" int bn_conv2d_fwd(const float* x, const float* w, const float* b, flo
                     ws_bytes, (hipStream_t)stream);
 }
 
+// Conv2d + 2x2 / stride-2 max pooling + activation in one kernel (round 6): y:(N,K,P/2,Q/2), idx int32 = h Q + w of
+// the window's winner in the (P, Q) plane of the convolution's output, which is never written.  Served for the first
+// layer of a max-pooling architecture (stride 1, 5x5 taps, one or two input channels, 16 k output channels, even
+// maps); BN_E_SHAPE otherwise: convolve, then bn_maxpool2d_act_fwd.
+extern "C" int bn_conv2d_pool2_act_fwd(const float* x, const float* w, const float* b, float* y, int* idx, int N,
+                                       int C, int H, int W, int K, int R, int S, int stride, int pad_t, int pad_l,
+                                       int P, int Q, int act, float slope, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
+    if (!x || !w || !y || !idx) return BN_E_BADARG;
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    if (force_generic() || !aligned16_all(x, w, y, idx)) return BN_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (bn_s1in1_pool_ok(g)) {
+        BnProfScope prof(BN_PROF_CONV_FWD, g.Cb, g.Cs, "k_down_s1_in1m<pool>", st);
+        return bn_launch_s1in1_pool(x, w, b, y, idx, g, act, slope, st);
+    }
+    if (bn_down2_pool_ok(g)) {
+        BnProfScope prof(BN_PROF_CONV_FWD, g.Cb, g.Cs, "k_down2_mfma<1, 2, 5, 0, 1, pool>", st);
+        return bn_launch_down2_pool(x, w, b, y, idx, g, act, slope, st);
+    }
+    return BN_E_SHAPE;
+}
+
+// 1 if bn_conv2d_pool2_act_fwd serves this layer (aligned operands assumed), else 0
+extern "C" int bn_conv2d_pool2_act_ok(int N, int C, int H, int W, int K, int R, int S, int stride, int pad_t,
+                                      int pad_l, int P, int Q) {
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g) || force_generic()) return 0;
+    return (bn_s1in1_pool_ok(g) || bn_down2_pool_ok(g)) ? 1 : 0;
+}
+
 static bool u8_fast(const BnGeom& g, int act) {
     return !force_generic() && g.Cb == 1 && bn_edge_down_plan(g).supported && bn_edge_down_plan(g).variant != 9 &&
            (act == BN_ACT_NONE || act == BN_ACT_LRELU);

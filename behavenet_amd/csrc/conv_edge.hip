@@ -2697,11 +2697,16 @@ __global__ __launch_bounds__(256) void k_down_s1_in1(const float* __restrict__ b
 // per-lane tap offsets computed once (one ds_read_b32 per instruction: 19 consecutive words, no conflicts); a wave owns
 // 4 rows x 64 columns, four pixel blocks in flight (independent accumulators).  Output: lane = (pixel, 4 channels).
 typedef float floatx4e __attribute__((ext_vector_type(4)));
-template <int CIN>
+// POOL: the 2x2 / stride-2 max pooling and the activation that follow the first layer of a max-pooling architecture in
+// the epilogue (ref aes.py:200-211: conv -> pool -> LeakyReLU).  A lane pair (j, j ^ 1) holds a window's two columns,
+// two rows are multiplied before the epilogue; the even lane picks the winner in row-major window order (a later
+// element wins only if it is strictly larger or NaN: k_maxpool_fwd_k2's rule, torch's indices h W + w) and stores the
+// activated maximum and its index: the 268 MB of the layer's output are neither written nor read back (`pidx` != null).
+template <int CIN, bool POOL = false>
 __global__ __launch_bounds__(256) void k_down_s1_in1m(const float* __restrict__ big, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        const float* __restrict__ dact_src, BnGeom g, int act, int dact,
-                                                       float slope, int tiles_h, int tiles_w) {
+                                                       float slope, int tiles_h, int tiles_w, int* __restrict__ pidx = nullptr) {
     constexpr int KS = 5, IH = S1C_TH + KS - 1, IWP = (S1C_TW + KS - 1 + 3) & ~3;
     constexpr int KT = CIN * KS * KS, NK = (KT + 3) / 4;
     __shared__ __attribute__((aligned(16))) float tile[CIN * IH * IWP];
@@ -2741,6 +2746,48 @@ __global__ __launch_bounds__(256) void k_down_s1_in1m(const float* __restrict__ 
         float bz[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) bz[e] = (bias && m0 + 4 * kg + e < g.Cs) ? bias[m0 + 4 * kg + e] : 0.f;
+        if constexpr (POOL) {
+            const int Ho = g.Hs >> 1, Wo = g.Ws >> 1;
+#pragma unroll 1
+            for (int rp = 0; rp < 2; ++rp) {
+                const int row = 4 * wv + 2 * rp;
+                floatx4e a0[4], a1[4];
+#pragma unroll
+                for (int xb = 0; xb < 4; ++xb) a0[xb] = a1[xb] = (floatx4e){0.f, 0.f, 0.f, 0.f};
+                const float* tp = tile + row * IWP + j;
+#pragma unroll
+                for (int t = 0; t < NK; ++t) {
+#pragma unroll
+                    for (int xb = 0; xb < 4; ++xb) {
+                        a0[xb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], tp[toff[t] + 16 * xb], a0[xb], 0, 0, 0);
+                        a1[xb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], tp[toff[t] + IWP + 16 * xb], a1[xb], 0, 0, 0);
+                    }
+                }
+                const int h = h0 + row;
+#pragma unroll
+                for (int xb = 0; xb < 4; ++xb) {
+                    const int wq = w0 + 16 * xb + j;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v0 = a0[xb][e] + bz[e], v1 = a1[xb][e] + bz[e];
+                        const float n0 = __shfl_xor(v0, 1, 64), n1 = __shfl_xor(v1, 1, 64);
+                        const int m = m0 + 4 * kg + e;
+                        if ((j & 1) || h >= g.Hs || wq >= g.Ws || m >= g.Cs) continue;
+                        const int me = h * g.Ws + wq;
+                        float best = -INFINITY;
+                        int bi = me;
+                        if (v0 > best || isnan(v0)) { best = v0; bi = me; }
+                        if (n0 > best || isnan(n0)) { best = n0; bi = me + 1; }
+                        if (v1 > best || isnan(v1)) { best = v1; bi = me + g.Ws; }
+                        if (n1 > best || isnan(n1)) { best = n1; bi = me + g.Ws + 1; }
+                        const size_t o = (((size_t)n * g.Cs + m) * Ho + (h >> 1)) * Wo + (wq >> 1);
+                        out[o] = bn_apply_act(best, act, slope);
+                        pidx[o] = bi;
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll 1
         for (int rr = 0; rr < 4; ++rr) {
             const int row = 4 * wv + rr;
@@ -2781,6 +2828,26 @@ bool bn_s1in1_ok(const BnGeom& g) {
     return tiles < 0x7fffffffull;
 }
 
+// the pooled form: 5x5 taps, 16 k channels, even maps (every window inside one workgroup tile of 16 x 64 pixels)
+bool bn_s1in1_pool_ok(const BnGeom& g) {
+    return bn_s1in1_ok(g) && g.R == 5 && (g.Cs & 15) == 0 && !(g.Hs & 1) && !(g.Ws & 1) &&
+           (size_t)g.Hs * g.Ws < 0x7fffffffull;
+}
+int bn_launch_s1in1_pool(const float* big, const float* w, const float* bias, float* y, int* idx, const BnGeom& g,
+                         int act, float slope, hipStream_t st) {
+    if (!bn_s1in1_pool_ok(g)) return BN_E_SHAPE;
+    const int tiles_h = (g.Hs + S1C_TH - 1) / S1C_TH, tiles_w = (g.Ws + S1C_TW - 1) / S1C_TW;
+    const dim3 grid((unsigned)((size_t)g.N * tiles_h * tiles_w));
+    if (g.Cb == 1)
+        BN_LAUNCH_MAIN((k_down_s1_in1m<1, true>), grid, dim3(256), 0, st, big, w, bias, y, (const float*)nullptr, g, act,
+                       BN_ACT_NONE, slope, tiles_h, tiles_w, idx);
+    else
+        BN_LAUNCH_MAIN((k_down_s1_in1m<2, true>), grid, dim3(256), 0, st, big, w, bias, y, (const float*)nullptr, g, act,
+                       BN_ACT_NONE, slope, tiles_h, tiles_w, idx);
+    BN_LAUNCH_CHECK();
+    return 0;
+}
+
 int bn_launch_s1in1(const float* big, const float* w, const float* bias, float* out, const float* dact_src,
                     const BnGeom& g, int act, int dact, float slope, hipStream_t st) {
     if (!bn_s1in1_ok(g)) return BN_E_SHAPE;
@@ -2789,10 +2856,10 @@ int bn_launch_s1in1(const float* big, const float* w, const float* bias, float* 
     if (g.R == 5 && (g.Cs & 15) == 0) {             // 16 k output channels: the taps on the matrix cores
         if (g.Cb == 1)
             BN_LAUNCH_MAIN((k_down_s1_in1m<1>), grid, dim3(256), 0, st, big, w, bias, out, dact_src, g, act, dact, slope,
-                           tiles_h, tiles_w);
+                           tiles_h, tiles_w, (int*)nullptr);
         else
             BN_LAUNCH_MAIN((k_down_s1_in1m<2>), grid, dim3(256), 0, st, big, w, bias, out, dact_src, g, act, dact, slope,
-                           tiles_h, tiles_w);
+                           tiles_h, tiles_w, (int*)nullptr);
         BN_LAUNCH_CHECK();
         return 0;
     }

@@ -82,7 +82,11 @@ struct Down2Tile {
 // 5x5 layer on phases / shifted copies (capi.hip) -- on the same schedule: image rows `Ws + 8` words, a unit's image
 // PT_H + 4 rows, a lane's five columns are consecutive words of either parity (4-byte reads paired by ds_read2_b32
 // instead of 8-byte ones), any column offset 0..4.  KV = 5 only.
-template <int MR, int NR, int KV, int K0 = 0, int ST = 2>
+// POOL (round 6, stride 1 only): the 2x2 / stride-2 max pooling and the activation behind a max-pooling architecture's
+// layer in the epilogue -- the tile's sums + bias go through LDS (rows of a window belong to different waves), a thread
+// picks the winner of a window in row-major order (a later element wins only if strictly larger or NaN: torch's
+// indices) and stores the activated maximum and its index h Ws + w; `dact_src` carries the index tensor.
+template <int MR, int NR, int KV, int K0 = 0, int ST = 2, bool POOL = false>
 __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     const float* __restrict__ big, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ out, const float* __restrict__ dact_src, BnGeom g, Down2Tile t, int act,
@@ -358,6 +362,55 @@ __global__ __launch_bounds__(D2_THREADS, 2) void k_down2_mfma(
     // accumulator block): with a load -> wait -> store chain per element the 64 elements of a lane
     // cost 64 memory round trips (59 k of the kernel's 490 k cycles, s_memtime trace).
     D2_MARK(16);
+    if constexpr (POOL) {
+        constexpr int TP = 128 * NR;
+        __syncthreads();                                   // every wave is done reading the images
+        float* ps = smem;                                  // [TM][TP] sums + bias
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int chn = mr * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                const float bzv = (bias && m0 + chn < g.Cs) ? bias[m0 + chn] : 0.f;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) ps[chn * TP + 32 * (wv * NR + nr) + li] = acc[mr][nr][e] + bzv;
+            }
+        __syncthreads();
+        int* pidx = reinterpret_cast<int*>(const_cast<float*>(dact_src));
+        const int Wo = Q >> 1, Ho = g.Hs >> 1, hp = t.PT_H >> 1;
+        const int per_unit = hp * Wo, per_tile = t.F * per_unit;      // <= TP / 4 windows of a channel
+        // thread -> one window position (decoded once), TM * 4 / TP ... channels c0, c0 + 256 / (TP / 4), ...
+        constexpr int WPT = TP / 4, CSTEP = D2_THREADS / WPT;
+        const int pp = tid % WPT, c0 = tid / WPT;
+        if (pp < per_tile) {
+            const int f = pp / per_unit, r2 = pp - f * per_unit;
+            const int pr = r2 / Wo, pc = r2 - pr * Wo;
+            const int un = (u0 + f) / t.UPF, up0 = (u0 + f - un * t.UPF) * t.PT_H;
+            const int h = up0 + 2 * pr;
+            if (un < g.N && h < g.Hs) {
+                const int me = h * Q + 2 * pc;
+                const float* pv0 = ps + f * t.PTQ + 2 * pr * Q + 2 * pc;
+                const size_t o0 = (((size_t)un * g.Cs + m0) * Ho + (h >> 1)) * Wo + pc;
+                const size_t ostep = (size_t)Ho * Wo;
+#pragma unroll 4
+                for (int chn = c0; chn < TM; chn += CSTEP) {
+                    if (m0 + chn >= g.Cs) break;
+                    const float* pv = pv0 + chn * TP;
+                    float best = -INFINITY;
+                    int bi = me;
+                    const float v00 = pv[0], v01 = pv[1], v10 = pv[Q], v11 = pv[Q + 1];
+                    if (v00 > best || isnan(v00)) { best = v00; bi = me; }
+                    if (v01 > best || isnan(v01)) { best = v01; bi = me + 1; }
+                    if (v10 > best || isnan(v10)) { best = v10; bi = me + Q; }
+                    if (v11 > best || isnan(v11)) { best = v11; bi = me + Q + 1; }
+                    const size_t oi = o0 + chn * ostep;
+                    out[oi] = bn_apply_act(best, act, slope);
+                    pidx[oi] = bi;
+                }
+            }
+        }
+        return;
+    }
     if (act != BN_ACT_SIGMOID && dact != BN_ACT_SIGMOID) {             // wave-uniform
         // branch-free: buffer loads / stores whose lane offset is out of range for lanes (or
         // channels) that do not exist -- per-element branches made the compiler drain the memory
@@ -792,6 +845,35 @@ static int launch_down2_m16(const Down2Tile& t, dim3 grid, size_t lds, const flo
 bool bn_down2_m16_supported(const BnGeom& g, int NR) {
     if (g.K0 != 0) return false;        // (zero-extended 4x4 taps are multiplied as they are)
     return bn_down2_supported(g, 1, NR);
+}
+
+// Conv2d + 2x2 pooling + activation (POOL instantiation): stride-1 5x5 layers with 32 k output channels on even maps
+// whose tiles are whole even row blocks (32 channels x 256 pixels)
+bool bn_down2_pool_ok(const BnGeom& g) {
+    Down2Tile t;
+    size_t lds = 0;
+    if (g.stride != 1 || g.R != 5 || g.S != 5 || g.KV != 0 || g.K0 != 0 || (g.Cs & 31) || (g.Hs & 1) || (g.Ws & 1)) return false;
+    if (!bn_down2_supported(g, 1, 2) || !down2_tile(g, 1, 2, &t, &lds)) return false;
+    if ((t.PT_H & 1) || bn_down2_splits(g, 1, 2) != 1) return false;
+    return (size_t)32 * 256 * 4 <= lds && (size_t)g.Hs * g.Ws < 0x7fffffffull;
+}
+int bn_launch_down2_pool(const float* big, const float* w, const float* bias, float* y, int* idx, const BnGeom& g,
+                         int act, float slope, hipStream_t st) {
+    Down2Tile t;
+    size_t lds = 0;
+    if (!bn_down2_pool_ok(g) || !down2_tile(g, 1, 2, &t, &lds)) return BN_E_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_down2_mfma<1, 2, 5, 0, 1, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, D2_MAX_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((g.N * t.UPF + t.F - 1) / t.F, (g.Cs + 31) / 32, 1);
+    BN_LAUNCH_MAIN((k_down2_mfma<1, 2, 5, 0, 1, true>), grid, dim3(D2_THREADS), lds, st, big, w, bias, y,
+                       reinterpret_cast<const float*>(idx), g, t, act, BN_ACT_NONE, slope, g.Cb, (size_t)0);
+    BN_LAUNCH_CHECK();
+    return 0;
 }
 
 // share of a tile's pixels that are pixels of the map (1 for powers of two), 0 if not served

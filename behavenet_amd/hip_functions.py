@@ -1232,6 +1232,58 @@ def max_pool_act(x, k, stride, pad, out_hw, act):
     return y, idx
 
 
+class ConvPoolActFn(torch.autograd.Function):
+    """One conv layer, the 2x2 / stride-2 max pooling behind it and the activation behind that in ONE kernel
+    (bn_conv2d_pool2_act_fwd: the first layer of a max-pooling architecture, whose 268 MB of output per 256 frames of
+    128x128 were written, read back by the pooling and never looked at again) -> (y, idx int32).  Backward: the pooling's
+    own (dy * act'(y) spread to the winners), then the layer's weight gradient through _stack_backward."""
+
+    @staticmethod
+    def forward(ctx, plan, x, act, *params):
+        layer = plan[0]
+        x = x.contiguous()
+        out = _hip.conv2d_pool_act_fwd(x, params[0].detach(), params[1].detach(), layer.geom(x.shape[0]), act, LRELU_SLOPE)
+        if out is None:
+            raise RuntimeError('conv_pool_act: geometry not served')
+        y, idx = out
+        ctx.plan = plan
+        ctx.taps = None
+        ctx.need_dx = x.requires_grad
+        ctx.param_refs = params
+        ctx.pool_args = ((layer.hout, layer.wout), act)
+        _note_use(params, any(ctx.needs_input_grad[3:]))
+        # (slot 1 = the layer's output in ConvStackFn's layout: the pooled output stands in, _stack_backward does
+        # not read it for a one-layer plan whose activation is applied here)
+        ctx.save_for_backward(x, y, params[0], idx)
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, dy, _didx):
+        y, idx = ctx.saved_tensors[1], ctx.saved_tensors[3]
+        in_hw, act = ctx.pool_args
+        dpre = _hip.maxpool2d_act_bwd(dy.contiguous(), y, idx, in_hw, act, LRELU_SLOPE)
+        dx, grads = _stack_backward(ctx, dpre, first_param=3)
+        return (None, dx, None) + tuple(grads)
+
+
+_CONV_POOL = os.environ.get('BN_CONV_POOL', '1') != '0'      # 0: convolve, then pool (A/B switch)
+
+
+def conv_pool_act(layer, x, params, k, stride, pad, out_hw, act):
+    """``max_pool_act(conv_stack([layer], x, params), ...)`` in one kernel where bn_conv2d_pool2_act_fwd serves the layer
+    (bn_conv2d_pool2_act_ok; pooling 2x2 / stride 2 / unpadded on an even map) -> (y, idx), else None."""
+    if not (_CONV_POOL and x.is_cuda and layer.kind == 'conv' and layer.act == _hip.ACT_NONE and int(k) == 2 and
+            int(stride) == 2 and int(pad[0]) == 0 and int(pad[1]) == 0 and layer.hout == 2 * int(out_hw[0]) and
+            layer.wout == 2 * int(out_hw[1]) and layer.wout % 4 == 0 and x.dtype == torch.float32 and
+            x.data_ptr() % 16 == 0 and params[0].data_ptr() % 16 == 0 and
+            _hip.conv2d_pool_act_ok(layer.geom(x.shape[0]))):
+        return None
+    y, idx = ConvPoolActFn.apply([layer], x, int(act), *params)
+    idx.bn_own_window = True
+    return y, idx
+
+
 def max_pool(x, k, stride, pad, out_hw):
     y, idx = MaxPoolFn.apply(x, int(k), int(stride), (int(pad[0]), int(pad[1])),
                              (int(out_hw[0]), int(out_hw[1])))

@@ -22,7 +22,7 @@ from behavenet_amd.hip_functions import (
     ChunkScalars, ConvLayerPlan, FusedPixelLoss, Readback, activation, backward_chunks, bn_chunks,
     capturing, finish_loss,
     chunked_sq_err, conv_stack, conv_stack_bn, conv_stack_sq_err, first_layer_forward,
-    join_side_streams, linear, begin_chunks, chunk_stream, max_pool, max_pool_act, max_unpool,
+    join_side_streams, linear, begin_chunks, chunk_stream, max_pool, max_pool_act, max_unpool, conv_pool_act,
     pixel_loss_scales, reserve_device_pools)
 
 __all__ = [
@@ -224,6 +224,16 @@ class ConvAEEncoder(BaseModule):
         for j, layer in enumerate(self._plan):
             pool = self._pool_after[j]
             one = [layer.with_act(_hip.ACT_NONE) if pool is not None else layer]
+            fused = None
+            if pool is not None and bns[j] is None:
+                # conv -> pool -> LeakyReLU of the first layer in one kernel where the library serves it
+                fused = conv_pool_act(one[0], h, params[2 * j:2 * j + 2], *pool, _hip.ACT_LRELU)
+            if fused is not None:
+                sizes.append(torch.Size((h.size(0), layer.cout, layer.hout, layer.wout)))
+                h, idx = fused
+                pool_idx.append(idx)
+                _tap_signs(self._plan, j, layer, h)
+                continue
             if bns[j] is not None:
                 h = conv_stack_bn(one, h, params[2 * j:2 * j + 2], [bns[j]])
             else:

@@ -164,6 +164,20 @@ int bn_maxpool2d_fwd(const float* x, float* y, int* idx, int planes, int H, int 
                      int k, int stride, int pad_t, int pad_l, bn_stream_t stream);
 int bn_maxpool2d_bwd(const float* dy, const int* idx, float* dx, int planes, int H, int W,
                      int Ho, int Wo, int k, int stride, int pad_t, int pad_l, bn_stream_t stream);
+/* Conv2d + the 2x2 / stride-2 max pooling + the activation behind it in ONE kernel (the reference's conv -> pool ->
+ * LeakyReLU order, aes.py:200-211): y:(N,K,P/2,Q/2), idx:(N,K,P/2,Q/2) int32 = h * Q + w of each window's winner in
+ * the (P, Q) plane of the convolution's output (torch's MaxPool2d(return_indices) convention, first maximum in row-major
+ * window order) -- that output itself is never written.  Served for the stride-1 5x5 layers of a max-pooling architecture
+ * on even maps: from 1 or 2 input channels onto a multiple of 16, and from a multiple of 4 onto a multiple of 32 where the
+ * matrix-core kernel's tile is whole even row blocks (bn_conv2d_pool2_act_ok); BN_E_SHAPE otherwise
+ * (the caller then runs bn_conv2d_fwd and bn_maxpool2d_act_fwd).  Backward: bn_maxpool2d_act_bwd on (y, idx), then the
+ * layer's own weight gradient. */
+int bn_conv2d_pool2_act_fwd(const float* x, const float* w, const float* b, float* y, int* idx,
+                            int N, int C, int H, int W, int K, int R, int S, int stride,
+                            int pad_t, int pad_l, int P, int Q, int act, float slope, bn_stream_t stream);
+/* 1 if bn_conv2d_pool2_act_fwd serves this geometry (16-byte aligned operands assumed), else 0 */
+int bn_conv2d_pool2_act_ok(int N, int C, int H, int W, int K, int R, int S, int stride,
+                           int pad_t, int pad_l, int P, int Q);
 /* 2x2 / stride-2 / unpadded max pooling of an even map WITH the activation that follows it (aes.py:204-211: conv ->
  * pool -> LeakyReLU), one pass each way: y = act(max), idx as bn_maxpool2d_fwd; dx = spread(dy * act'(y)).
  * BN_E_SHAPE if W / 2 is odd or a pointer is not 16-byte aligned (use bn_maxpool2d_fwd + the activation then). */

@@ -972,6 +972,61 @@ def test_maxpool_unpool_vs_torch(shape, k, s, pad):
         assert torch.equal(dv.cpu(), vr.grad)
 
 
+@pytest.mark.parametrize('N,C,H,W,K,pad', [(3, 1, 128, 128, 16, (2, 2)), (2, 2, 64, 192, 32, (2, 2)), (5, 1, 36, 60, 16, (2, 2)),
+                                           (2, 1, 20, 24, 16, (0, 4)), (3, 1, 66, 68, 48, (1, 3)),
+                                           # the second layer: the matrix-core kernel's tile through LDS
+                                           (3, 16, 64, 64, 32, (2, 2)), (5, 16, 32, 32, 64, (2, 2)), (2, 32, 24, 20, 32, (2, 2)),
+                                           (7, 16, 16, 16, 96, (1, 3)), (2, 64, 12, 36, 32, (2, 2))])
+def test_conv_pool_activation_in_one_kernel(N, C, H, W, K, pad):
+    """Round 6: the first layer of a max-pooling architecture -- Conv2d, 2x2 / stride-2 pooling, LeakyReLU -- in ONE kernel
+    (bn_conv2d_pool2_act_fwd): the same bits and the same winners as the convolution followed by bn_maxpool2d_act_fwd
+    (the matrix-core kernel of the layer with the pooling in its epilogue), torch's values and indices, and through
+    ConvPoolActFn the same gradients as the two nodes it replaces."""
+    from behavenet_amd import hip_functions as hf
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    x = (torch.rand((N, C, H, W), generator=g) - 0.4)
+    w = (torch.rand((K, C, 5, 5), generator=g) - 0.5) * 0.4
+    b = torch.rand((K,), generator=g) - 0.5
+    pt, pl = pad
+    geom = (N, C, H, W, K, 5, 5, 1, pt, pl, H, W)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    got = _hip.conv2d_pool_act_fwd(xd, wd, bd, geom, _hip.ACT_LRELU, SLOPE)
+    layer = hf.ConvLayerPlan('conv', C, H, W, K, H, W, 5, 5, 1, pt, pl, _hip.ACT_NONE)
+    if not _hip.conv2d_pool_act_ok(geom):
+        # (a map whose tiles are no whole even row blocks: refused, the model convolves and pools in two launches)
+        assert got is None and hf.conv_pool_act(layer, xd, (wd, bd), 2, 2, (0, 0), (H // 2, W // 2), _hip.ACT_LRELU) is None
+        return
+    assert got is not None
+    y, idx = got
+    conv = _hip.conv2d_fwd(xd, wd, bd, geom, _hip.ACT_NONE, SLOPE)
+    y2, idx2 = _hip.maxpool2d_act_fwd(conv, _hip.ACT_LRELU, SLOPE)
+    assert torch.equal(y, y2) and torch.equal(idx, idx2)
+    ref = F.conv2d(F.pad(x.double(), (pl, 4 - pl, pt, 4 - pt)), w.double(), b.double())
+    yr, ir = F.max_pool2d(ref, 2, 2, return_indices=True)
+    close(y, F.leaky_relu(yr, SLOPE).float(), F.leaky_relu(yr, SLOPE), name='conv+pool+act')
+    # (indices: fp32 and float64 may pick different winners among values within rounding -- compare the VALUES they name)
+    flat = conv.flatten(2)
+    assert torch.equal(flat.gather(2, idx.flatten(2).long()), F.max_pool2d(conv, 2, 2).flatten(2))
+    # gradients: the fused node against conv_stack + max_pool_act
+    dy = (torch.rand(y.shape, generator=g) - 0.5).to(DEV)
+    grads = []
+    for fused in (True, False):
+        wp, bp = wd.clone().requires_grad_(True), bd.clone().requires_grad_(True)
+        xp = xd.clone().requires_grad_(True)
+        if fused:
+            out = hf.conv_pool_act(layer, xp, (wp, bp), 2, 2, (0, 0), (H // 2, W // 2), _hip.ACT_LRELU)
+            assert out is not None
+            yy = out[0]
+        else:
+            yy, _ = hf.max_pool_act(hf.conv_stack([layer], xp, (wp, bp)), 2, 2, (0, 0), (H // 2, W // 2), _hip.ACT_LRELU)
+        yy.backward(dy)
+        hf.join_side_streams()
+        torch.cuda.synchronize()
+        grads.append((xp.grad.clone(), wp.grad.clone(), bp.grad.clone()))
+    for a, bb in zip(*grads):
+        assert torch.equal(a, bb)
+
+
 @pytest.mark.parametrize('shape', [(3, 16, 64, 48), (2, 5, 8, 12), (2, 3, 6, 10)])
 def test_maxpool_with_activation_vs_torch(shape):
     """max_pool_act (2x2 / stride-2 pooling + LeakyReLU in one pass each way where the pooled width is even, the two
