@@ -74,6 +74,9 @@ SIGNATURES = {
     'bn_maxpool2d_act_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 4 + [ctypes.c_float, _c_void_p]),
     'bn_conv2d_pool2_act_fwd': (_c_int, [_c_void_p] * 5 + _CONV_GEOM + [_c_int, _c_float, _c_void_p]),
     'bn_conv2d_pool2_act_ok': (_c_int, _CONV_GEOM),
+    'bn_conv2d_pool2_bwd_weight_ws_bytes': (_c_size_t, _CONV_GEOM),
+    'bn_conv2d_pool2_bwd_weight': (
+        _c_int, [_c_void_p] * 6 + _CONV_GEOM + [_c_int, _c_float, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     'bn_maxpool2d_act_bwd': (_c_int, [_c_void_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_void_p]),
     'bn_maxunpool2d_fwd': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
     'bn_maxunpool2d_fwd_k2': (_c_int, [_c_void_p] * 3 + [_c_int] * 3 + [_c_void_p]),
@@ -810,6 +813,24 @@ def maxpool2d_act_fwd(x, act, slope):
 def conv2d_pool_act_ok(geom):
     """Whether bn_conv2d_pool2_act_fwd serves this layer (host-side query)."""
     return bool(load().bn_conv2d_pool2_act_ok(*geom))
+
+
+def conv2d_pool_bwd_weight_ws_bytes(geom):
+    """Scratch of bn_conv2d_pool2_bwd_weight; 0 where the pooled-side weight gradient is not served."""
+    return int(load().bn_conv2d_pool2_bwd_weight_ws_bytes(*geom))
+
+
+def conv2d_pool_bwd_weight(x, dy, y, idx, dw, db, geom, act, slope, accumulate):
+    """dw (+)=, db (+)= of a layer run by conv2d_pool_act_fwd from the pooled gradient `dy`, its saved output `y` and the
+    winners `idx` (bn_conv2d_pool2_bwd_weight)."""
+    nbytes = conv2d_pool_bwd_weight_ws_bytes(geom)
+    if nbytes == 0:
+        raise HipLibraryError('conv2d_pool_bwd_weight: geometry not served')
+    ws = _arena(x.device, nbytes)
+    _check(load().bn_conv2d_pool2_bwd_weight(
+        _ptr(x, 'x'), _ptr(dy, 'dy'), _ptr(y, 'y'), _ptr(idx, 'idx', torch.int32), _ptr(dw, 'dw'),
+        _ptr(db, 'db', allow_none=True), *geom, int(act), float(slope), int(accumulate), ws, nbytes, _stream()),
+        'bn_conv2d_pool2_bwd_weight')
 
 
 def conv2d_pool_act_fwd(x, w, b, geom, act, slope):

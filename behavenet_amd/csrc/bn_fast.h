@@ -30,6 +30,10 @@ int bn_launch_wgrad_fast(const BnFastPlan& plan, const float* small, const float
 
 // conv_mfma_down2.hip: 16-byte-DMA generation of the stride-2 gather-down kernel (chosen by
 // bn_fast_down_plan when the geometry fits and no split-K is needed; plan.variant == 2)
+bool bn_wgrad_pool_c1_ok(const BnGeom& g);
+size_t bn_wgrad_pool_c1_ws_bytes(const BnGeom& g);
+int bn_launch_wgrad_pool_c1(const float* x, const float* dy, const float* y, const int* idx, float* dw, float* db,
+                            const BnGeom& g, int act, float slope, int accumulate, void* ws, hipStream_t st);
 bool bn_s1in1_pool_ok(const BnGeom& g);
 int bn_launch_s1in1_pool(const float* big, const float* w, const float* bias, float* y, int* idx, const BnGeom& g,
                          int act, float slope, hipStream_t st);

@@ -1291,6 +1291,31 @@ extern "C" int bn_conv2d_pool2_act_ok(int N, int C, int H, int W, int K, int R, 
     return (bn_s1in1_pool_ok(g) || bn_down2_pool_ok(g)) ? 1 : 0;
 }
 
+// Weight (+ bias) gradient of a layer run by bn_conv2d_pool2_act_fwd straight from the POOLED gradient: dy, y, idx are
+// the (N,K,P/2,Q/2) tensors of the pooling's output side; the dense gradient of the convolution's output (3/4 zeros)
+// is never built.  Served for the first layer (1 or 2 input channels; 16 / 32 / 64 output channels); the scratch
+// query returns 0 where it is not (the caller then runs bn_maxpool2d_act_bwd and bn_conv2d_bwd_weight).
+extern "C" size_t bn_conv2d_pool2_bwd_weight_ws_bytes(int N, int C, int H, int W, int K, int R, int S, int stride,
+                                                      int pad_t, int pad_l, int P, int Q) {
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g) || force_generic() || !bn_wgrad_pool_c1_ok(g)) return 0;
+    return bn_wgrad_pool_c1_ws_bytes(g);
+}
+extern "C" int bn_conv2d_pool2_bwd_weight(const float* x, const float* dy, const float* y, const int* idx, float* dw,
+                                          float* db, int N, int C, int H, int W, int K, int R, int S, int stride,
+                                          int pad_t, int pad_l, int P, int Q, int act, float slope, int accumulate,
+                                          void* ws, size_t ws_bytes, bn_stream_t stream) {
+    TapsHintDrop hint_drop;
+    if (!x || !dy || !y || !idx || !dw) return BN_E_BADARG;
+    const BnGeom g = conv_geom(N, C, H, W, K, R, S, stride, pad_t, pad_l, P, Q);
+    if (!bn_geom_ok(g)) return BN_E_BADARG;
+    if (force_generic() || !bn_wgrad_pool_c1_ok(g) || (act != BN_ACT_NONE && act != BN_ACT_LRELU)) return BN_E_SHAPE;
+    if (!ws || ws_bytes < bn_wgrad_pool_c1_ws_bytes(g)) return BN_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    BnProfScope prof(BN_PROF_CONV_BWD_W, g.Cb, g.Cs, "k_wgrad_pool_c1", st);
+    return bn_launch_wgrad_pool_c1(x, dy, y, idx, dw, db, g, act, slope, accumulate, ws, st);
+}
+
 static bool u8_fast(const BnGeom& g, int act) {
     return !force_generic() && g.Cb == 1 && bn_edge_down_plan(g).supported && bn_edge_down_plan(g).variant != 9 &&
            (act == BN_ACT_NONE || act == BN_ACT_LRELU);

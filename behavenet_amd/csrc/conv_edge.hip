@@ -2821,6 +2821,149 @@ __global__ __launch_bounds__(256) void k_down_s1_in1m(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the FIRST layer of a max-pooling architecture straight from the POOLED gradient (round 6).  The
+// layer's output gradient is 3/4 zeros -- one winner per 2x2 window -- and was materialised (bn_maxpool2d_act_bwd:
+// 268 MB written for 256 frames of 16 x 128 x 128) only to be read back by the weight gradient (the first layer has no
+// data gradient).  Here
+//   dW[a][c][r][s] = sum_{n,ph,pw} g[n,a,ph,pw] x[n, c, h* + r - pt, w* + s - pl],   g = dy * act'(y),
+// with (h*, w*) the window's winner (idx = h* Ws + w*): a workgroup loads the (16 + 4) x (64 + 4) input tile of a frame
+// per input channel, every thread owns ONE output channel and 8 x 32 / (256 / Cs) window positions of the tile, reads
+// dy / y / idx there (67 MB each instead of 268 + 268) and gathers its 25 taps from LDS at the winner's position;
+// 25 CIN accumulators per thread over all the tiles of the workgroup, combined across the channel's threads at the end
+// (shuffles), one partial row per workgroup as k_wgrad_c1 leaves them (+ the bias sums).
+// ---------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void k_wgrad_pool_c1(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ y, const int* __restrict__ idx,
+                                                        float* __restrict__ part, float* __restrict__ bias_part,
+                                                        BnGeom g, int n_tiles, int tiles_h, int tiles_w, int act,
+                                                        float slope) {
+    constexpr int KS = 5, IH = S1C_TH + KS - 1, IWP = (S1C_TW + KS - 1 + 3) & ~3;
+    __shared__ __attribute__((aligned(16))) float tile[CIN * IH * IWP];
+    const int tid = threadIdx.x;
+    const int tpc = 256 / g.Cs;                           // threads of a channel (Cs in {16, 32, 64})
+    const int a = tid / tpc, lt = tid - a * tpc;
+    const int Ho = g.Hs >> 1, Wo = g.Ws >> 1;
+    const size_t HWb = (size_t)g.Hb * g.Wb;
+    float acc[CIN][25];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int t = 0; t < 25; ++t) acc[c][t] = 0.f;
+    float bsum = 0.f;
+    const float dslope = (act == BN_ACT_LRELU) ? slope : 1.f;     // (identity or LeakyReLU behind the pooling)
+    for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        int b = tl;
+        const int tw = b % tiles_w; b /= tiles_w;
+        const int th = b % tiles_h;
+        const int n = b / tiles_h;
+        const int h0 = th * S1C_TH, w0 = tw * S1C_TW;
+        __syncthreads();                                  // the previous tile's gathers are done
+        for (int e = tid; e < CIN * IH * IWP; e += 256) {
+            const int cc = e / (IH * IWP), rem = e - cc * (IH * IWP);
+            const int yy = rem / IWP, xx = rem - yy * IWP;
+            const int hb = h0 - g.pt + yy, wb = w0 - g.pl + xx;
+            const bool ok = hb >= 0 && hb < g.Hb && wb >= 0 && wb < g.Wb;
+            tile[e] = ok ? x[((size_t)n * g.Cb + cc) * HWb + (size_t)hb * g.Wb + wb] : 0.f;
+        }
+        __syncthreads();
+        // window positions of the tile: 8 rows x 32 columns, dealt to the channel's threads
+        const size_t pbase = ((size_t)n * g.Cs + a) * Ho * Wo;
+        // sixteen positions' loads in flight before the first gather (one position per trip was a chain of 16 x 3
+        // dependent global loads per tile: 111 us for 201 MB)
+        constexpr int UN = 16;
+        for (int p0 = lt; p0 < (S1C_TH / 2) * (S1C_TW / 2); p0 += UN * tpc) {
+            float gq[UN], yq[UN];
+            int iq[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int p = p0 + u * tpc;
+                const int ph = (h0 >> 1) + (p >> 5), pw = (w0 >> 1) + (p & 31);
+                const bool ok = ph < Ho && pw < Wo;
+                const size_t o = pbase + (size_t)(ok ? ph : 0) * Wo + (ok ? pw : 0);
+                gq[u] = ok ? dy[o] : 0.f;
+                yq[u] = y[o];
+                iq[u] = ok ? idx[o] : (2 * ph) * g.Ws + 2 * pw;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int p = p0 + u * tpc;
+                const int pr = p >> 5, pc = p & 31;
+                const int me = (2 * ((h0 >> 1) + pr)) * g.Ws + 2 * ((w0 >> 1) + pc);
+                const float gv = gq[u] * (yq[u] > 0.f ? 1.f : dslope);
+                const int d = iq[u] - me;
+                const int dh = d >= g.Ws ? 1 : 0, dw = d - dh * g.Ws;
+                bsum += gv;
+                const float* xp = tile + (2 * pr + dh) * IWP + 2 * pc + dw;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                    for (int r = 0; r < KS; ++r)
+#pragma unroll
+                        for (int sx = 0; sx < KS; ++sx)
+                            acc[c][r * KS + sx] = fmaf(gv, xp[(c * IH + r) * IWP + sx], acc[c][r * KS + sx]);
+            }
+        }
+    }
+    // the channel's threads are tpc adjacent lanes of one wave (tpc <= 16): butterfly, fixed order
+    for (int off = tpc >> 1; off > 0; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int t = 0; t < 25; ++t) acc[c][t] += __shfl_xor(acc[c][t], off, 64);
+        bsum += __shfl_xor(bsum, off, 64);
+    }
+    if (lt == 0) {
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int t = 0; t < 25; ++t)
+                part[((size_t)c * gridDim.x + blockIdx.x) * (g.Cs * 25) + a * 25 + t] = acc[c][t];
+        if (bias_part) bias_part[(size_t)blockIdx.x * g.Cs + a] = bsum;
+    }
+}
+
+bool bn_wgrad_pool_c1_ok(const BnGeom& g) {
+    return g.stride == 1 && g.R == 5 && g.S == 5 && g.Cb >= 1 && g.Cb <= 2 && (g.Cs == 16 || g.Cs == 32 || g.Cs == 64) &&
+           !(g.Hs & 1) && !(g.Ws & 1) && g.pt <= 4 && g.pl <= 4 && g.CsS == 0 && (size_t)g.Hs * g.Ws < 0x7fffffffull;
+}
+static int wgrad_pool_c1_grid(const BnGeom& g) {
+    const size_t tiles = (size_t)g.N * ((g.Hs + S1C_TH - 1) / S1C_TH) * ((g.Ws + S1C_TW - 1) / S1C_TW);
+    return (int)(tiles < 1024 ? tiles : 1024);
+}
+size_t bn_wgrad_pool_c1_ws_bytes(const BnGeom& g) {
+    const int G = wgrad_pool_c1_grid(g);
+    return ((size_t)g.Cb * G * g.Cs * 25 + (size_t)G * g.Cs) * sizeof(float);
+}
+// dw[a][c][25] (+)= ..., db[a] (+)= sum g  (db nullable); ws >= bn_wgrad_pool_c1_ws_bytes
+int bn_launch_wgrad_pool_c1(const float* x, const float* dy, const float* y, const int* idx, float* dw, float* db,
+                            const BnGeom& g, int act, float slope, int accumulate, void* ws, hipStream_t st) {
+    if (!bn_wgrad_pool_c1_ok(g)) return BN_E_SHAPE;
+    if (!ws) return BN_E_WORKSPACE;
+    const int tiles_h = (g.Hs + S1C_TH - 1) / S1C_TH, tiles_w = (g.Ws + S1C_TW - 1) / S1C_TW;
+    const int n_tiles = g.N * tiles_h * tiles_w, G = wgrad_pool_c1_grid(g);
+    float* part = (float*)ws;
+    float* bias_part = db ? part + (size_t)g.Cb * G * g.Cs * 25 : nullptr;
+    if (g.Cb == 1)
+        BN_LAUNCH_MAIN((k_wgrad_pool_c1<1>), dim3(G), dim3(256), 0, st, x, dy, y, idx, part, bias_part, g, n_tiles,
+                       tiles_h, tiles_w, act, slope);
+    else
+        BN_LAUNCH_MAIN((k_wgrad_pool_c1<2>), dim3(G), dim3(256), 0, st, x, dy, y, idx, part, bias_part, g, n_tiles,
+                       tiles_h, tiles_w, act, slope);
+    BN_LAUNCH_CHECK();
+    if (bias_part) {
+        const int rc = bn_launch_sum_partials(bias_part, db, g.Cs, G, accumulate, 0, 0, st);
+        if (rc) return rc;
+    }
+    for (int b = 0; b < g.Cb; ++b) {
+        const int rc = bn_launch_sum_partials(part + (size_t)b * G * g.Cs * 25, dw + b * 25, g.Cs * 25, G, accumulate,
+                                              0, 0, st, 25, g.Cb * 25);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 bool bn_s1in1_ok(const BnGeom& g) {
     if (g.stride != 1 || g.R != g.S || (g.R != 3 && g.R != 5 && g.R != 7 && g.R != 9)) return false;
     if (g.Cb > 2 || g.Cs < 3 || g.CsS) return false;      // (one / two OUTPUT channels: k_down_s1_c1)

@@ -1260,14 +1260,36 @@ class ConvPoolActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _didx):
-        y, idx = ctx.saved_tensors[1], ctx.saved_tensors[3]
+        x, y, w, idx = ctx.saved_tensors
         in_hw, act = ctx.pool_args
-        dpre = _hip.maxpool2d_act_bwd(dy.contiguous(), y, idx, in_hw, act, LRELU_SLOPE)
+        dy = dy.contiguous()
+        layer = ctx.plan[0]
+        g = layer.geom(dy.shape[0])
+        need_w, need_b = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        if (_CONV_POOL_WGRAD and not ctx.need_dx and need_w and x.dtype == torch.float32 and
+                _hip.conv2d_pool_bwd_weight_ws_bytes(g)):
+            # the first layer: no data gradient, and its weight gradient needs the winners only -- straight from the
+            # pooled gradient (the dense one, 3/4 zeros, is never built: bn_conv2d_pool2_bwd_weight)
+            gw = _grad_buffer(ctx.param_refs[0])
+            gb = _grad_buffer(ctx.param_refs[1]) if need_b else None
+            direct = gw is not None and (gb is not None or not need_b)
+            if direct:
+                dw, db = gw, gb
+            else:
+                dw = torch.empty_like(w)
+                db = torch.empty((layer.cout,), dtype=w.dtype, device=w.device) if need_b else None
+            _hip.conv2d_pool_bwd_weight(x, dy, y, idx, dw, db, g, act, LRELU_SLOPE, direct)
+            if direct:
+                _report_ready(ctx.param_refs[0:2])
+                return (None, None, None, None, None)
+            return (None, None, None, dw, db)
+        dpre = _hip.maxpool2d_act_bwd(dy, y, idx, in_hw, act, LRELU_SLOPE)
         dx, grads = _stack_backward(ctx, dpre, first_param=3)
         return (None, dx, None) + tuple(grads)
 
 
 _CONV_POOL = os.environ.get('BN_CONV_POOL', '1') != '0'      # 0: convolve, then pool (A/B switch)
+_CONV_POOL_WGRAD = os.environ.get('BN_CONV_POOL_WGRAD', '1') != '0'      # 0: dense gradient, then the layer's weight gradient
 
 
 def conv_pool_act(layer, x, params, k, stride, pad, out_hw, act):

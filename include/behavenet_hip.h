@@ -178,6 +178,16 @@ int bn_conv2d_pool2_act_fwd(const float* x, const float* w, const float* b, floa
 /* 1 if bn_conv2d_pool2_act_fwd serves this geometry (16-byte aligned operands assumed), else 0 */
 int bn_conv2d_pool2_act_ok(int N, int C, int H, int W, int K, int R, int S, int stride,
                            int pad_t, int pad_l, int P, int Q);
+/* Weight (+ bias, db nullable) gradient of such a layer straight from the POOLED side: dy, y (the saved output of
+ * bn_conv2d_pool2_act_fwd) and idx are (N,K,P/2,Q/2); dw (+)= sum_n,windows dy act'(y) x[winner + tap], db (+)= sum dy act'(y).
+ * The dense gradient of the convolution's output is never built.  Served for 1 or 2 input channels and 16 / 32 / 64 output
+ * channels (the first layer); the scratch query returns 0 where it is not, the call BN_E_SHAPE. */
+size_t bn_conv2d_pool2_bwd_weight_ws_bytes(int N, int C, int H, int W, int K, int R, int S, int stride,
+                                           int pad_t, int pad_l, int P, int Q);
+int bn_conv2d_pool2_bwd_weight(const float* x, const float* dy, const float* y, const int* idx, float* dw, float* db,
+                               int N, int C, int H, int W, int K, int R, int S, int stride,
+                               int pad_t, int pad_l, int P, int Q, int act, float slope, int accumulate,
+                               void* ws, size_t ws_bytes, bn_stream_t stream);
 /* 2x2 / stride-2 / unpadded max pooling of an even map WITH the activation that follows it (aes.py:204-211: conv ->
  * pool -> LeakyReLU), one pass each way: y = act(max), idx as bn_maxpool2d_fwd; dx = spread(dy * act'(y)).
  * BN_E_SHAPE if W / 2 is odd or a pointer is not 16-byte aligned (use bn_maxpool2d_fwd + the activation then). */

@@ -1025,6 +1025,26 @@ def test_conv_pool_activation_in_one_kernel(N, C, H, W, K, pad):
         grads.append((xp.grad.clone(), wp.grad.clone(), bp.grad.clone()))
     for a, bb in zip(*grads):
         assert torch.equal(a, bb)
+    # the first layer (no data gradient wanted): weight / bias gradient straight from the pooled gradient and the
+    # winners (bn_conv2d_pool2_bwd_weight) -- against float64 on the DEVICE's winners (dense gradient = dy act'(y) at idx)
+    if not _hip.conv2d_pool_bwd_weight_ws_bytes(geom):
+        return
+    wp, bp = wd.clone().requires_grad_(True), bd.clone().requires_grad_(True)
+    yy, ii = hf.conv_pool_act(layer, xd, (wp, bp), 2, 2, (0, 0), (H // 2, W // 2), _hip.ACT_LRELU)
+    yy.backward(dy)
+    hf.join_side_streams()
+    torch.cuda.synchronize()
+    gsm = (dy * torch.where(yy.detach() > 0, 1.0, SLOPE)).cpu()
+    dense = torch.zeros((N, K, H * W)).scatter_(2, ii.cpu().flatten(2).long(), gsm.flatten(2)).view(N, K, H, W)
+    refs = []
+    for dt in (torch.float32, torch.float64):
+        w_ = w.detach().clone().to(dt).requires_grad_(True)
+        b_ = b.detach().clone().to(dt).requires_grad_(True)
+        F.conv2d(F.pad(x.detach().to(dt), (pl, 4 - pl, pt, 4 - pt)), w_, b_).backward(dense.to(dt))
+        refs.append((w_.grad, b_.grad))
+    close(wp.grad, refs[0][0], refs[1][0], name='pooled-side dw')
+    close(bp.grad, refs[0][1], refs[1][1], name='pooled-side db', sum_of=dense)
+    assert torch.equal(grads[0][1], grads[1][1])
 
 
 @pytest.mark.parametrize('shape', [(3, 16, 64, 48), (2, 5, 8, 12), (2, 3, 6, 10)])
