@@ -1185,10 +1185,15 @@ class MaxPoolFn(torch.autograd.Function):
         ctx.save_for_backward(idx)
         ctx.args = (tuple(x.shape[2:]), k, stride, pad)
         ctx.mark_non_differentiable(idx)
+        # (autograd would otherwise materialise a zero "gradient" of the int32 index output for every backward pass:
+        # a 33-67 MB fill per pooling layer of the max-pooling test architecture)
+        ctx.set_materialize_grads(False)
         return y, idx
 
     @staticmethod
     def backward(ctx, dy, _didx):
+        if dy is None:
+            return None, None, None, None, None
         idx, = ctx.saved_tensors
         in_hw, k, stride, pad = ctx.args
         return _hip.maxpool2d_bwd(dy.contiguous(), idx, in_hw, k, stride, pad), None, None, None, \
@@ -1209,10 +1214,13 @@ class MaxPoolActFn(torch.autograd.Function):
         ctx.save_for_backward(idx, y)
         ctx.args = (tuple(x.shape[2:]), act)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
         return y, idx
 
     @staticmethod
     def backward(ctx, dy, _didx):
+        if dy is None:
+            return None, None
         idx, y = ctx.saved_tensors
         in_hw, act = ctx.args
         return _hip.maxpool2d_act_bwd(dy.contiguous(), y, idx, in_hw, act, LRELU_SLOPE), None
@@ -1256,10 +1264,13 @@ class ConvPoolActFn(torch.autograd.Function):
         # not read it for a one-layer plan whose activation is applied here)
         ctx.save_for_backward(x, y, params[0], idx)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
         return y, idx
 
     @staticmethod
     def backward(ctx, dy, _didx):
+        if dy is None:
+            return (None,) * (3 + len(ctx.param_refs))
         x, y, w, idx = ctx.saved_tensors
         in_hw, act = ctx.pool_args
         dy = dy.contiguous()
