@@ -1482,10 +1482,13 @@ class CombineChunkTermsFn(torch.autograd.Function):
         ctx.flat = [t.dim() == 1 for t in terms]
         ctx.save_for_backward(cvec)
         ctx.mark_non_differentiable(mat)
+        ctx.set_materialize_grads(False)
         return torch.mv(mat, cvec), mat
 
     @staticmethod
     def backward(ctx, g, _gmat):
+        if g is None:
+            return (None,) * (1 + len(ctx.widths))
         (cvec,) = ctx.saved_tensors
         G = g[:, None] * cvec[None, :]                     # (n_chunks, sum k_i)
         out, pos = [], 0
@@ -1556,6 +1559,7 @@ class PSVAEHeadFn(torch.autograd.Function):
         ctx.has_bias = Db is not None
         _note_use((Dw, Db), ctx.needs_input_grad[3])
         ctx.mark_non_differentiable(yhat, cols5)
+        ctx.set_materialize_grads(False)      # (no zero "gradients" of y_hat / cols5: two fill launches per backward pass)
         return z, T, yhat, cols5
 
     @staticmethod
