@@ -452,7 +452,9 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
 #pragma unroll
         for (int r = 0; r < 5; ++r) { load_row(bb, bs, 0, r, 0, bv); load_row(bb, bs, 0, r, 1, bv); }
         constexpr int KS = KSG;
-        static_assert(NDMA <= T::KS, "one DMA slot per k-step of the stage");
+        // (a 16-pixel stage -- 4-column maps -- has four k-steps for five DMA instructions: two slots per k-step)
+        constexpr bool DMA2 = NG == 1 && NDMA > T::KS;
+        static_assert(NDMA <= (DMA2 ? 2 : 1) * T::KS, "DMA slots of the stage");
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (BIAS == 1) bsum += av[ks & 1];
@@ -469,7 +471,11 @@ __global__ __launch_bounds__(W4_THREADS, 1) void k_wgrad4s_mfma(
                 if (r >= 1 && ks + 1 < KS && (sx == 0 || sx == 2)) load_row(bb, bs, ks + 1, r - 1, sx >> 1, bv);
                 if (r == 0 && ks >= 1 && (sx == 0 || sx == 2)) load_row(bb, bs, ks, 4, sx >> 1, bv);
                 if (r == 2 && sx == 4 && ks + 1 < KS) load_a(ab, ks + 1, av[(ks + 1) & 1]);
-                if (NG == 1) {
+                if (NG == 1 && DMA2) {
+                    if ((r == 3 || r == 1) && sx == 4 && 2 * ks + (r == 3 ? 1 : 0) < NDMA) {
+                        if (more) issue_dma(2 * ks + (r == 3 ? 1 : 0), nbuf, n0n, p0n);
+                    }
+                } else if (NG == 1) {
                     if (r == 3 && sx == 4 && ks < NDMA) {
                         if (more) issue_dma(ks, nbuf, n0n, p0n);
                     }
@@ -621,11 +627,11 @@ static inline int w4g_window(const BnGeom& g) {
 static inline int w4g_pth(const BnGeom& g) {
     if (w4g_window(g)) return W4_TPX / w4g_window(g);
     if ((g.Ws & 3) == 2) return (W4_TPX / g.Ws) & ~1;          // an even number of rows (W4S<Q, 2, PTH>)
-    return (g.stride == 2 && g.Ws == 8 && g.Hs <= 4) ? 4 : W4_TPX / g.Ws;
+    return (g.stride == 2 && (g.Ws == 8 || g.Ws == 4) && g.Hs <= 4) ? 4 : W4_TPX / g.Ws;
 }
 // maps that are no powers of two on the streamlined kernel (GEN instantiations): widths the kernel is
 // instantiated for, any height, big map exactly twice the small one
-static const int W4G_WIDTHS[] = {6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40, 44};
+static const int W4G_WIDTHS[] = {4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40, 44};   // (4: maps of at most four rows)
 static bool wgrad4g_ok(const BnGeom& g) {
     static int disabled = -1;                          // BN_WGRAD4G=0: off
     if (disabled < 0) { const char* e = bn_tune_env("BN_WGRAD4G"); disabled = (e && e[0] == '0') ? 1 : 0; }
@@ -635,6 +641,7 @@ static bool wgrad4g_ok(const BnGeom& g) {
     for (int q : W4G_WIDTHS) width = width || q == g.Ws;
     if (!width) return false;
     if ((g.Ws & 3) == 2 && (g.Hs & 1)) return false;   // half-row k-steps: rows come in pairs
+    if (g.Ws == 4 && g.Hs > 4) return false;           // (round 6: the 4-column instantiation has 4-row stages)
     if ((size_t)g.N * g.Cb * g.Hb * g.Wb * 4 >= 0x7fffffffull) return false;   // 32-bit offsets
     if ((size_t)g.N * g.Cs * g.Hs * g.Ws * 4 >= 0x7fffffffull) return false;
     const int tpf = (g.Hs + w4g_pth(g) - 1) / w4g_pth(g);
@@ -859,6 +866,13 @@ int bn_launch_wgrad4(const BnFastPlan& plan, const float* small, const float* bi
                                                  bias_part, g, t.n_stages, t.splits, magic, t.nbias);
             W4H_CASE(6, 0) W4H_CASE(6, 1) W4H_CASE(10, 0) W4H_CASE(10, 1) W4H_CASE(14, 0) W4H_CASE(14, 1)
 #undef W4H_CASE
+        } else if (g.Ws == 4 && pth == 4) {
+#define W4Q_CASE(B, K)                                                                           \
+    if (t.bias_side == B && (k3 ? 14 : 5) == K)                                                  \
+        rc = launch_wgrad4s<4, B, true, K, 2, 4>(grid, st, small, big, (float*)ws, bias_part, g, \
+                                                 t.n_stages, t.splits, magic, t.nbias);
+            W4Q_CASE(0, 5) W4Q_CASE(1, 5) W4Q_CASE(0, 14) W4Q_CASE(1, 14)
+#undef W4Q_CASE
         } else if (g.Ws == 8 && pth == 4) {
 #define W4P_CASE(B, K)                                                                           \
     if (t.bias_side == B && (k3 ? 14 : 5) == K)                                                  \

@@ -166,6 +166,12 @@ CONV_CASES = [
     ('s1_k5_2ch_64x128', 2, 2, 64, 128, 16, 5, 1, (2, 2), (2, 2)),
     # (fuzz, round 6: one output channel, 256 frames -- its bias gradient is a sum of 59,136 terms that cancel)
     ('fuzz_db_cancel_18x14_n256', 256, 2, 18, 14, 1, 5, 1, (3, 4), (0, 1)),
+    # round 6: the weight gradient of maps with four columns on its own instantiation (16-pixel stages; they ran on
+    # zero-padded 4x8 copies): 4x4, 2x4, 3x4 and -- zero-padded to 4x4 -- 4x3 maps, an odd number of frames
+    ('w4_4x4_n7', 7, 64, 8, 8, 128, 5, 2, (1, 2), (1, 2)),
+    ('w4_2x4_n5', 5, 64, 4, 8, 96, 5, 2, (1, 2), (1, 2)),
+    ('w4_3x4_n3', 3, 32, 6, 8, 64, 5, 2, (1, 2), (1, 2)),
+    ('w4_4x3_n9', 9, 128, 8, 6, 256, 5, 2, (1, 2), (1, 2)),
     # single-channel frames onto 64 channels: two groups of 32 on the edge kernels
     ('E0_64ch', 2, 1, 128, 128, 64, 5, 2, (1, 2), (1, 2)),
     ('E0_k4_64ch', 2, 1, 128, 128, 64, 4, 2, (1, 1), (1, 1)),
